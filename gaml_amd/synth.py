@@ -1,0 +1,293 @@
+"""Seeded synthetic inputs for the GAML likelihood path.
+
+Everything here is ours (the reference ships no data): a uniform random genome, cut into
+alternating long / short nodes written as a Velvet ``LastGraph`` (the format
+``LoadGraph`` parses, reference graph.cc:52-106), paired / single FASTQ with substitution
+errors, PacBio-like alignment records, and a GAML config file (reference gaml.cc:748-872,
+README.md:40-95).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[_a] = _b
+
+
+def revcomp(a: np.ndarray) -> np.ndarray:
+    """Reverse complement along the last axis (reference graph.h:58-72)."""
+    return _COMP[a[..., ::-1]]
+
+
+def make_genome(length: int, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return _ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)]
+
+
+def plant_repeats(genome: np.ndarray, n_copies: int, rep_len: int, seed: int) -> np.ndarray:
+    """Copy one segment to n_copies other places (raises alignments per read)."""
+    rng = np.random.default_rng(seed + 7)
+    g = genome.copy()
+    src = int(rng.integers(0, len(g) - rep_len))
+    for _ in range(n_copies):
+        dst = int(rng.integers(0, len(g) - rep_len))
+        g[dst:dst + rep_len] = g[src:src + rep_len]
+    return g
+
+
+def cut_lengths(total: int, seed: int, long_rng=(2000, 8000), short_rng=(40, 120)) -> list[int]:
+    """Alternating long / short piece lengths summing to ``total``."""
+    rng = np.random.default_rng(seed + 1)
+    out, left, want_long = [], total, True
+    while left > 0:
+        lo, hi = long_rng if want_long else short_rng
+        n = int(rng.integers(lo, hi + 1))
+        if left - n < short_rng[0]:
+            n = left
+        out.append(n)
+        left -= n
+        want_long = not want_long
+    return out
+
+
+@dataclass
+class Graph:
+    """2n node sequences; node 2i is piece i forward, node 2i+1 its twin (reverse complement)."""
+    seqs: list  # list[np.ndarray uint8]
+    arcs: list = field(default_factory=list)  # (src velvet id, dst velvet id), 1-based signed
+
+    @property
+    def n_nodes(self) -> int:
+        return len(self.seqs)
+
+    def node_len(self, i: int) -> int:
+        return len(self.seqs[i])
+
+    def packed(self):
+        offs = np.zeros(len(self.seqs) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([len(s) for s in self.seqs])
+        bases = np.concatenate(self.seqs) if self.seqs else np.zeros(0, np.uint8)
+        return np.ascontiguousarray(bases), offs
+
+
+def make_graph(genome: np.ndarray, cuts: list[int]) -> Graph:
+    seqs, arcs, pos = [], [], 0
+    for i, n in enumerate(cuts):
+        piece = genome[pos:pos + n]
+        seqs.append(np.ascontiguousarray(piece))
+        seqs.append(np.ascontiguousarray(revcomp(piece)))
+        if i > 0:
+            arcs.append((i, i + 1))
+        pos += n
+    return Graph(seqs, arcs)
+
+
+def write_lastgraph(path: str, g: Graph) -> None:
+    n = g.n_nodes // 2
+    with open(path, "wb") as f:
+        f.write(b"%d\t0\t31\t1\n" % n)
+        for i in range(n):
+            f.write(b"NODE\t%d\t%d\t0\t0\t0\t0\n" % (i + 1, g.node_len(2 * i)))
+            f.write(g.seqs[2 * i].tobytes() + b"\n")
+            f.write(g.seqs[2 * i + 1].tobytes() + b"\n")
+        for s, d in g.arcs:
+            f.write(b"ARC\t%d\t%d\t1\n" % (s, d))
+
+
+def genome_walk(g: Graph) -> list[int]:
+    """The true genome as one walk: all forward pieces in order."""
+    return list(range(0, g.n_nodes, 2))
+
+
+def _mutate(reads: np.ndarray, err: float, rng) -> np.ndarray:
+    if err <= 0:
+        return reads
+    hit = rng.random(reads.shape) < err
+    # substitute with one of the three other bases
+    code = np.zeros(256, dtype=np.uint8)
+    code[list(b"ACGT")] = [0, 1, 2, 3]
+    c = code[reads]
+    c = np.where(hit, (c + rng.integers(1, 4, size=reads.shape, dtype=np.uint8)) & 3, c)
+    return _ACGT[c]
+
+
+@dataclass
+class PairedReads:
+    mate1: np.ndarray  # [n, L] uint8
+    mate2: np.ndarray
+    frag_start: np.ndarray
+    frag_len: np.ndarray
+    swapped: np.ndarray
+
+    @property
+    def n(self) -> int:
+        return self.mate1.shape[0]
+
+
+def make_paired_reads(genome: np.ndarray, n_pairs: int, read_len: int, mean: float, sd: float,
+                      err: float, seed: int, chunk: int = 1 << 18) -> PairedReads:
+    """Innie pairs: mate1 = forward prefix of the fragment, mate2 = reverse complement of its
+    suffix; mates are swapped on odd ids."""
+    rng = np.random.default_rng(seed + 2)
+    G = len(genome)
+    flen = np.maximum(read_len + 10, np.rint(rng.normal(mean, sd, n_pairs))).astype(np.int64)
+    flen = np.minimum(flen, G)
+    start = (rng.random(n_pairs) * (G - flen + 1)).astype(np.int64)
+    m1 = np.empty((n_pairs, read_len), np.uint8)
+    m2 = np.empty((n_pairs, read_len), np.uint8)
+    ar = np.arange(read_len, dtype=np.int64)
+    for lo in range(0, n_pairs, chunk):
+        hi = min(n_pairs, lo + chunk)
+        s, fl = start[lo:hi, None], flen[lo:hi, None]
+        a = genome[s + ar]
+        b = revcomp(genome[s + fl - read_len + ar])
+        m1[lo:hi] = _mutate(a, err, rng)
+        m2[lo:hi] = _mutate(b, err, rng)
+    swapped = (np.arange(n_pairs) & 1).astype(bool)
+    t = m1[swapped].copy()
+    m1[swapped] = m2[swapped]
+    m2[swapped] = t
+    return PairedReads(m1, m2, start, flen, swapped)
+
+
+def make_single_reads(genome: np.ndarray, n: int, read_len: int, err: float, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed + 3)
+    G = len(genome)
+    start = (rng.random(n) * (G - read_len + 1)).astype(np.int64)
+    reads = genome[start[:, None] + np.arange(read_len, dtype=np.int64)]
+    flip = rng.random(n) < 0.5
+    reads[flip] = revcomp(reads[flip])
+    return _mutate(reads, err, rng)
+
+
+def pack_reads(reads: np.ndarray):
+    """[n, L] matrix -> (bases, int64 offsets[n+1]) as the C ABI takes them."""
+    n, L = reads.shape
+    return np.ascontiguousarray(reads).reshape(-1), (np.arange(n + 1, dtype=np.int64) * L)
+
+
+def write_fastq(path: str, reads: np.ndarray, prefix: str, mate: int | None) -> None:
+    n, L = reads.shape
+    qual = b"I" * L
+    with open(path, "wb") as f:
+        for i in range(n):
+            name = b"@%s%d" % (prefix.encode(), i)
+            if mate is not None:
+                name += b"/%d" % mate
+            f.write(name + b"\n" + reads[i].tobytes() + b"\n+\n" + qual + b"\n")
+
+
+def write_config(path: str, graph_file: str, readsets: list[dict], extra: dict | None = None) -> None:
+    """GAML config (reference gaml.cc:748-780): global key=value lines, then [name] sections."""
+    with open(path, "w") as f:
+        f.write(f"graph={graph_file}\n")
+        for k, v in (extra or {}).items():
+            f.write(f"{k}={v}\n")
+        for rs in readsets:
+            f.write(f"\n[{rs['name']}]\n")
+            for k, v in rs.items():
+                if k != "name":
+                    f.write(f"{k}={v}\n")
+
+
+@dataclass
+class PacbioRecords:
+    """Synthetic stand-in for what BLASR + the banded DP leave in the PacBio cache
+    (reference graph.cc:2776-2782): per sub-walk, (position, position_end, read_id, logprob)."""
+    lens: np.ndarray
+    walks: list  # list[list[int]]
+    recs: list   # list[np.ndarray [k,3] int32]
+    logps: list  # list[np.ndarray [k] float64]
+
+
+def make_pacbio_records(g: Graph, walk: list[int], n_reads: int, read_len: int, mismatch: float,
+                        seed: int, extra_per_read: float = 0.3) -> PacbioRecords:
+    """Place reads uniformly on ``walk``; each read gets a record under the sub-walk that the
+    reference would file it under -- the run of nodes overlapping [tstart-5, tstart+len+5]
+    (reference graph.cc:2761-2776) -- with a log-probability near L*(0.85*log M + 0.15*log m),
+    plus a few weaker secondary records."""
+    rng = np.random.default_rng(seed + 4)
+    node_len = np.array([g.node_len(x) for x in walk], dtype=np.int64)
+    ends = np.cumsum(node_len)
+    begins = ends - node_len
+    total = int(ends[-1])
+    lens = np.full(n_reads, read_len, dtype=np.int32)
+    lens = np.minimum(lens, total - 20).astype(np.int32)
+    M, m = 1.0 - 4 * mismatch, mismatch
+    by_walk: dict[tuple, list] = {}
+
+    def file_record(rid, tstart, tlen, logp):
+        ib = int(np.searchsorted(ends, max(0, tstart - 5), side="left"))
+        ie = int(np.searchsorted(ends, min(tstart + tlen + 5, total), side="left"))
+        ie = min(ie, len(walk) - 1)
+        key = tuple(walk[ib:ie + 1])
+        pb = int(begins[ib])
+        by_walk.setdefault(key, []).append((tstart - pb, tstart + tlen - pb, rid, logp))
+
+    for rid in range(n_reads):
+        L = int(lens[rid])
+        tstart = int(rng.integers(0, total - L))
+        good = int(round(L * 0.85))
+        logp = good * np.log(M) + (L - good) * np.log(m) + float(rng.normal(0, 3.0))
+        file_record(rid, tstart, L, logp)
+        if rng.random() < extra_per_read:
+            t2 = int(rng.integers(0, total - L))
+            file_record(rid, t2, L, logp - float(rng.uniform(5, 400)))
+    walks, recs, logps = [], [], []
+    for key, lst in by_walk.items():
+        lst.sort(key=lambda t: t[0])
+        walks.append(list(key))
+        recs.append(np.array([[a, b, c] for a, b, c, _ in lst], dtype=np.int32))
+        logps.append(np.array([d for *_, d in lst], dtype=np.float64))
+    return PacbioRecords(lens, walks, recs, logps)
+
+
+def all_subwalks_for_pacbio(g: Graph, walk: list[int], max_read_len: int) -> list[list[int]]:
+    """Every sub-walk the PacBio scorer looks up for ``walk`` (reference graph.cc:2438-2454)."""
+    node_len = [g.node_len(x) if x >= 0 else -x for x in walk]
+    ends = np.cumsum(node_len)
+    begins = ends - np.array(node_len)
+    out = []
+    for i in range(len(walk)):
+        for j in range(i, len(walk)):
+            out.append(walk[i:j + 1])
+            if (ends[j] - begins[i]) - (ends[i] - begins[i]) > max_read_len:
+                break
+    return out
+
+
+@dataclass
+class Workload:
+    name: str
+    genome_len: int
+    n_pairs: int
+    read_len: int = 150
+    insert_mean: float = 300.0
+    insert_std: float = 30.0
+    err: float = 0.01
+    seed: int = 20260301
+
+
+# BASELINE.json configs (SURVEY.md 8d sizes)
+WORKLOADS = {
+    "cfg2": Workload("cfg2: 1 Mbp, 30x 2x150 paired, insert 300+-30", 1_000_000, 100_000),
+    "cfg3": Workload("cfg3: 5 Mbp, 50x 2x150 paired, insert 300+-30", 5_000_000, 833_333),
+    "tiny": Workload("tiny: 60 kbp, 2x150 paired", 60_000, 3_000),
+}
+
+
+def flatten_paths(paths: list[list[int]]):
+    flat = np.array([x for p in paths for x in p], dtype=np.int32)
+    offs = np.zeros(len(paths) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(p) for p in paths])
+    return flat, offs
+
+
+def ensure_dir(d: str) -> str:
+    os.makedirs(d, exist_ok=True)
+    return d
