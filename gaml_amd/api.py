@@ -1,0 +1,280 @@
+"""ctypes binding of libgaml_hip.so (C ABI in include/gaml_hip.h).
+
+The library is the product: there is no Python or CPU scoring path behind this module. If
+the shared object is missing, import fails; if no HIP device is present, every scoring call
+raises GamlHipError(ENODEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgaml_hip.so")
+
+OK, EINVAL, ENODEVICE, EHIP, ESTATE = 0, -1, -2, -3, -4
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+ALIGMENT = np.dtype([("position", np.int32), ("edit_dist", np.int32), ("read_id", np.int32), ("orientation", np.int32)])
+PACBIO_ALIGMENT = np.dtype([("position", np.int32), ("position_end", np.int32), ("read_id", np.int32), ("pad_", np.int32),
+                            ("logprob", np.float64)])
+
+
+class SingleCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("penalty_constant", "step", "min_prob_per_base", "min_prob_start", "weight", "mismatch_prob")]
+
+
+class PairedCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("penalty_constant", "step", "insert_mean", "insert_std", "min_prob_per_base", "min_prob_start", "weight",
+                 "mismatch_prob")]
+
+
+def single_cfg(penalty_constant=0.0, penalty_step=50.0, min_prob_per_base=-0.7, min_prob_start=-10.0, weight=1.0,
+               mismatch_prob=0.01) -> SingleCfg:
+    """Defaults of the reference's config reader (gaml.cc:812-819)."""
+    return SingleCfg(penalty_constant, penalty_step, min_prob_per_base, min_prob_start, weight, mismatch_prob)
+
+
+def paired_cfg(insert_mean, insert_std, penalty_constant=0.0, penalty_step=50.0, min_prob_per_base=-0.7,
+               min_prob_start=-10.0, weight=1.0, mismatch_prob=0.01) -> PairedCfg:
+    """Defaults of the reference's config reader (gaml.cc:851-862); step = insert_mean - penalty_step."""
+    return PairedCfg(penalty_constant, insert_mean - penalty_step, insert_mean, insert_std, min_prob_per_base,
+                     min_prob_start, weight, mismatch_prob)
+
+
+class GamlHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gaml_hip error {code}: {msg}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no fallback implementation)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.gaml_hip_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.gaml_hip_destroy.argtypes = [vp]
+    L.gaml_hip_destroy.restype = None
+    L.gaml_hip_last_error.argtypes = [vp]
+    L.gaml_hip_last_error.restype = C.c_char_p
+    L.gaml_hip_version.restype = C.c_char_p
+    L.gaml_hip_set_graph.argtypes = [vp, C.c_int32, _u8p, _i64p]
+    L.gaml_hip_load_graph.argtypes = [vp, C.c_char_p]
+    L.gaml_hip_add_single.argtypes = [vp, C.POINTER(SingleCfg), C.c_int32, _u8p, _i64p]
+    L.gaml_hip_add_paired.argtypes = [vp, C.POINTER(PairedCfg), C.c_int32, _u8p, _i64p, _u8p, _i64p]
+    L.gaml_hip_add_pacbio.argtypes = [vp, C.POINTER(SingleCfg), C.c_int32, _i32p]
+    L.gaml_hip_add_single_fastq.argtypes = [vp, C.POINTER(SingleCfg), C.c_char_p]
+    L.gaml_hip_add_paired_fastq.argtypes = [vp, C.POINTER(PairedCfg), C.c_char_p, C.c_char_p]
+    L.gaml_hip_add_pacbio_fastq.argtypes = [vp, C.POINTER(SingleCfg), C.c_char_p]
+    L.gaml_hip_set_shard.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gaml_hip_put_window_records.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
+    L.gaml_hip_put_pacbio_records.argtypes = [vp, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
+    L.gaml_hip_calc_prob.argtypes = [vp, _i32p, _i64p, C.c_int32, C.POINTER(C.c_double), _i32p, C.POINTER(C.c_int32)]
+    L.gaml_hip_calc_partials.argtypes = [vp, _i32p, _i64p, C.c_int32, _f64p, C.POINTER(C.c_int32)]
+    L.gaml_hip_combine_partials.argtypes = [vp, _f64p, C.c_int32, C.POINTER(C.c_double), _i32p]
+    L.gaml_hip_calc_partials_async.argtypes = [vp, _i32p, _i64p, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
+    L.gaml_hip_num_readsets.argtypes = [vp]
+    L.gaml_hip_readset_kind.argtypes = [vp, C.c_int]
+    L.gaml_hip_readset_reads.argtypes = [vp, C.c_int]
+    L.gaml_hip_readset_reads.restype = C.c_int64
+    L.gaml_hip_num_nodes.argtypes = [vp]
+    L.gaml_hip_node_len.argtypes = [vp, C.c_int32]
+    L.gaml_hip_read_probs.argtypes = [vp, C.c_int, _f64p, C.c_int64]
+    L.gaml_hip_bad_bases.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+    L.gaml_hip_window_count.argtypes = [vp, C.c_int, C.c_int]
+    L.gaml_hip_window_count.restype = C.c_int64
+    L.gaml_hip_window_records.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
+    L.gaml_hip_window_records.restype = C.c_int64
+    L.gaml_hip_align_window.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int32]
+    L.gaml_hip_align_window.restype = C.c_int64
+    L.gaml_hip_last_timing.argtypes = [vp, _f64p]
+    L.gaml_hip_set_event_timing.argtypes = [vp, C.c_int]
+    L.gaml_hip_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    return L
+
+
+_lib = _load()
+
+# every symbol include/gaml_hip.h declares (checked by tests/test_abi.py against the header text)
+def lib():
+    return _lib
+
+
+def version() -> str:
+    return _lib.gaml_hip_version().decode()
+
+
+def _flat(paths):
+    flat = np.array([x for p in paths for x in p], dtype=np.int32)
+    if flat.size == 0:
+        flat = np.zeros(1, np.int32)
+    offs = np.zeros(len(paths) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(p) for p in paths])
+    return flat, offs
+
+
+class Context:
+    """One graph + its read sets + their device state (one per process / GPU)."""
+
+    def __init__(self, device: int = 0, rank: int = 0, world: int = 1):
+        self._h = C.c_void_p()
+        rc = _lib.gaml_hip_create(C.byref(self._h), device)
+        if rc != OK:
+            raise GamlHipError(rc, f"gaml_hip_create(device={device}) failed")
+        self.device = device
+        if world != 1:
+            self._check(_lib.gaml_hip_set_shard(self._h, rank, world))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self._h:
+            _lib.gaml_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise GamlHipError(rc, _lib.gaml_hip_last_error(self._h).decode())
+        return rc
+
+    # ---- inputs
+    def set_graph(self, bases: np.ndarray, offs: np.ndarray):
+        self._check(_lib.gaml_hip_set_graph(self._h, len(offs) - 1, np.ascontiguousarray(bases, np.uint8),
+                                            np.ascontiguousarray(offs, np.int64)))
+
+    def load_graph(self, path: str):
+        self._check(_lib.gaml_hip_load_graph(self._h, path.encode()))
+
+    def add_single(self, cfg: SingleCfg, bases, offs) -> int:
+        return self._check(_lib.gaml_hip_add_single(self._h, C.byref(cfg), len(offs) - 1, bases, offs))
+
+    def add_paired(self, cfg: PairedCfg, b1, o1, b2, o2) -> int:
+        return self._check(_lib.gaml_hip_add_paired(self._h, C.byref(cfg), len(o1) - 1, b1, o1, b2, o2))
+
+    def add_pacbio(self, cfg: SingleCfg, lens) -> int:
+        lens = np.ascontiguousarray(lens, np.int32)
+        return self._check(_lib.gaml_hip_add_pacbio(self._h, C.byref(cfg), len(lens), lens))
+
+    def add_single_fastq(self, cfg, f) -> int:
+        return self._check(_lib.gaml_hip_add_single_fastq(self._h, C.byref(cfg), f.encode()))
+
+    def add_paired_fastq(self, cfg, f1, f2) -> int:
+        return self._check(_lib.gaml_hip_add_paired_fastq(self._h, C.byref(cfg), f1.encode(), f2.encode()))
+
+    def add_pacbio_fastq(self, cfg, f) -> int:
+        return self._check(_lib.gaml_hip_add_pacbio_fastq(self._h, C.byref(cfg), f.encode()))
+
+    def put_window_records(self, rs, mate, walk, recs: np.ndarray):
+        walk = np.ascontiguousarray(walk, np.int32)
+        recs = np.ascontiguousarray(recs, ALIGMENT)
+        self._check(_lib.gaml_hip_put_window_records(self._h, rs, mate, walk, len(walk), recs.ctypes.data, len(recs)))
+
+    def put_pacbio_records(self, rs, walk, rec3, logp):
+        walk = np.ascontiguousarray(walk, np.int32)
+        rec3 = np.asarray(rec3, np.int32).reshape(-1, 3)
+        recs = np.zeros(len(rec3), PACBIO_ALIGMENT)
+        recs["position"], recs["position_end"], recs["read_id"] = rec3[:, 0], rec3[:, 1], rec3[:, 2]
+        recs["logprob"] = logp
+        self._check(_lib.gaml_hip_put_pacbio_records(self._h, rs, walk, len(walk), recs.ctypes.data, len(recs)))
+
+    # ---- hot path
+    def calc_prob(self, paths):
+        flat, offs = _flat(paths)
+        prob = C.c_double()
+        tl = C.c_int32()
+        zeros = np.zeros(2 * max(1, self.num_readsets()), np.int32)
+        self._check(_lib.gaml_hip_calc_prob(self._h, flat, offs, len(paths), C.byref(prob), zeros, C.byref(tl)))
+        return prob.value, zeros.reshape(-1, 2)[: self.num_readsets()].copy(), tl.value
+
+    def calc_partials(self, paths):
+        flat, offs = _flat(paths)
+        tl = C.c_int32()
+        part = np.zeros(4 * max(1, self.num_readsets()), np.float64)
+        self._check(_lib.gaml_hip_calc_partials(self._h, flat, offs, len(paths), part, C.byref(tl)))
+        return part.reshape(-1, 4)[: self.num_readsets()].copy(), tl.value
+
+    def calc_partials_async(self, paths, d_partials_ptr: int, stream_ptr: int = 0):
+        flat, offs = _flat(paths)
+        tl = C.c_int32()
+        self._check(_lib.gaml_hip_calc_partials_async(self._h, flat, offs, len(paths), C.c_void_p(d_partials_ptr),
+                                                      C.c_void_p(stream_ptr), C.byref(tl)))
+        return tl.value
+
+    def combine_partials(self, partials, total_len):
+        part = np.ascontiguousarray(partials, np.float64).reshape(-1)
+        prob = C.c_double()
+        zeros = np.zeros(2 * max(1, self.num_readsets()), np.int32)
+        self._check(_lib.gaml_hip_combine_partials(self._h, part, total_len, C.byref(prob), zeros))
+        return prob.value, zeros.reshape(-1, 2)[: self.num_readsets()].copy()
+
+    # ---- introspection
+    def num_readsets(self) -> int:
+        return _lib.gaml_hip_num_readsets(self._h)
+
+    def readset_reads(self, rs) -> int:
+        return _lib.gaml_hip_readset_reads(self._h, rs)
+
+    def readset_kind(self, rs) -> int:
+        return _lib.gaml_hip_readset_kind(self._h, rs)
+
+    def num_nodes(self) -> int:
+        return _lib.gaml_hip_num_nodes(self._h)
+
+    def node_len(self, i) -> int:
+        return _lib.gaml_hip_node_len(self._h, i)
+
+    def read_probs(self, rs) -> np.ndarray:
+        n = self.readset_reads(rs)
+        out = np.zeros(max(1, n), np.float64)
+        got = self._check(_lib.gaml_hip_read_probs(self._h, rs, out, len(out)))
+        return out[:got]
+
+    def bad_bases(self, rs) -> int:
+        v = C.c_int64()
+        self._check(_lib.gaml_hip_bad_bases(self._h, rs, C.byref(v)))
+        return v.value
+
+    def window_count(self, rs, mate=0) -> int:
+        return _lib.gaml_hip_window_count(self._h, rs, mate)
+
+    def window_records(self, rs, mate, walk):
+        walk = np.ascontiguousarray(walk, np.int32)
+        n = _lib.gaml_hip_window_records(self._h, rs, mate, walk, len(walk), None, 0)
+        if n < 0:
+            return None
+        out = np.zeros(max(1, n), ALIGMENT)
+        _lib.gaml_hip_window_records(self._h, rs, mate, walk, len(walk), out.ctypes.data, n)
+        o = out[:n]
+        return np.stack([o["position"], o["edit_dist"], o["read_id"], o["orientation"]], axis=1)
+
+    def align_window(self, rs, mate, walk) -> int:
+        walk = np.ascontiguousarray(walk, np.int32)
+        return _lib.gaml_hip_align_window(self._h, rs, mate, walk, len(walk))
+
+    def last_timing(self):
+        out = np.zeros(3, np.float64)
+        _lib.gaml_hip_last_timing(self._h, out)
+        return {"host_us": out[0], "device_wall_us": out[1], "kernel_us": out[2]}
+
+    def set_event_timing(self, on: bool):
+        _lib.gaml_hip_set_event_timing(self._h, 1 if on else 0)
+
+    def kernel_stats(self, reset=False):
+        n, us, b = C.c_int64(), C.c_double(), C.c_double()
+        _lib.gaml_hip_kernel_stats(self._h, 1 if reset else 0, C.byref(n), C.byref(us), C.byref(b))
+        return {"launches": n.value, "device_us": us.value, "algo_bytes": b.value}

@@ -1,0 +1,1080 @@
+// gaml_hip.hip -- context, device memory, launches and the C ABI of libgaml_hip.so.
+// The kernels are in kernels.hip.h, the host data model in host_model.{h,cc}.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "host_model.h"
+#include "kernels.hip.h"
+
+using namespace gaml;
+
+namespace {
+
+double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// grow-only device / pinned buffers
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    size_t want = std::max(bytes + bytes / 4, (size_t)256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return (T*)p; }
+};
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = std::max(bytes + bytes / 4, (size_t)4096);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr int kRing = 4;  // staging slots, so that async callers may run ahead of the device
+
+struct Staging {
+  PinBuf host[kRing];
+  hipEvent_t done[kRing] = {};
+  bool armed[kRing] = {};
+  int next = 0;
+};
+
+struct Reducer {  // per read set: partials + ticket + 2-double result
+  DevBuf part_sum, part_zero, ticket, out;
+  hipError_t init() {
+    hipError_t e;
+    if ((e = part_sum.reserve(kMaxBlocks * sizeof(double))) != hipSuccess) return e;
+    if ((e = part_zero.reserve(kMaxBlocks * sizeof(int))) != hipSuccess) return e;
+    if ((e = ticket.reserve(sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = out.reserve(4 * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMemset(ticket.p, 0, sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMemset(out.p, 0, 4 * sizeof(double))) != hipSuccess) return e;
+    return hipDeviceSynchronize();  // the scoring stream is non-blocking: make the zeroes land first
+  }
+  void release() { part_sum.release(); part_zero.release(); ticket.release(); out.release(); }
+};
+
+struct MateDev {
+  DevBuf first, extra, pows;  // pows = mismatch_pow | match_pow
+  uint64_t uploaded_generation = ~0ull;
+  size_t pow_n = 0;
+};
+
+struct PairedSet {
+  gaml_paired_cfg cfg;
+  ShortMate mate[2];
+  ReadMajor rm[2];
+  MateDev dev[2];
+  DevBuf len12, probs, tabs, occ_arena, cov_bits, cov_meta, bad;
+  Reducer red;
+  std::vector<double> ins_tab, floor_tab, logfloor_tab, covthr_tab;
+  bool tabs_uploaded = false;
+  int64_t last_bad_bases = 0;
+  Staging stage;
+  PinBuf bad_host;
+};
+
+struct SingleSet {
+  gaml_single_cfg cfg;
+  ShortMate mate;
+  ReadMajor rm;
+  MateDev dev;
+  DevBuf lens, probs, tabs, occ_arena;
+  Reducer red;
+  std::vector<double> floor_tab, logfloor_tab;
+  bool tabs_uploaded = false;
+  Staging stage;
+};
+
+struct PacbioSet {
+  gaml_single_cfg cfg;
+  int64_t n_global = 0, lo = 0, hi = 0;
+  std::vector<int32_t> lens;  // shard
+  double log_match = 0, log_mismatch = 0;
+  std::unordered_map<Walk, int32_t, WalkHasher> walk_id;
+  std::vector<std::vector<gaml_pacbio_aligment>> recs;  // per sub-walk, local read ids
+  uint64_t generation = 0, uploaded_generation = ~0ull;
+  int32_t max_len = 0;
+  int64_t misses = 0;
+  DevBuf d_lens, rec_off, rec_walk, rec_logp, walk_count, logprobs;
+  Reducer red;
+  int64_t last_bad_bases = 0;
+  Staging stage;
+};
+
+struct SetRef { int kind, idx; };
+
+}  // namespace
+
+struct gaml_hip_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  GraphStore g;
+  bool have_graph = false;
+  std::vector<std::unique_ptr<SingleSet>> singles;
+  std::vector<std::unique_ptr<PairedSet>> paireds;
+  std::vector<std::unique_ptr<PacbioSet>> pacbios;
+  std::vector<SetRef> handles;  // creation order -> (kind, index)
+  int32_t rank = 0, world = 1;
+  std::string err;
+  // timing
+  bool event_timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // one pair per scoring launch of a call
+  size_t ev_used = 0;
+  double t_host_us = 0, t_dev_wall_us = 0, t_kernel_us = 0;
+  int64_t stat_launches = 0;
+  double stat_device_us = 0, stat_algo_bytes = 0;
+  DevBuf packed;  // 4 doubles per read set
+  PinBuf packed_host;
+};
+
+namespace {
+
+int fail(gaml_hip_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define HIP_TRY(c, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      return fail(c, GAML_HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
+  } while (0)
+
+// reference order of zeros / summation: single sets, paired sets, pacbio sets (prob_calculator.h:70-107)
+std::vector<SetRef> scoring_order(const gaml_hip_ctx* c) {
+  std::vector<SetRef> o;
+  for (int k = 0; k < 3; k++)
+    for (auto& h : c->handles) if (h.kind == k) o.push_back(h);
+  return o;
+}
+
+void shard_range(const gaml_hip_ctx* c, int64_t n, int64_t* lo, int64_t* hi) {
+  *lo = n * c->rank / c->world;
+  *hi = n * (c->rank + 1) / c->world;
+}
+
+int grid_for(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(b, kMaxBlocks));
+}
+
+// take the next staging slot; waits only if the device is kRing evaluations behind
+int stage_acquire(gaml_hip_ctx* c, Staging& s, size_t bytes, void** host) {
+  int k = s.next;
+  s.next = (s.next + 1) % kRing;
+  if (s.armed[k]) { HIP_TRY(c, hipEventSynchronize(s.done[k])); s.armed[k] = false; }
+  if (!s.done[k]) HIP_TRY(c, hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming));
+  HIP_TRY(c, s.host[k].reserve(bytes));
+  *host = s.host[k].p;
+  return k;
+}
+int stage_release(gaml_hip_ctx* c, Staging& s, int k, hipStream_t st) {
+  HIP_TRY(c, hipEventRecord(s.done[k], st));
+  s.armed[k] = true;
+  return 0;
+}
+
+size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(c, hipEventCreate(&a));
+    HIP_TRY(c, hipEventCreate(&b));
+    c->ev_pool.emplace_back(a, b);
+  }
+  *out = &c->ev_pool[c->ev_used++];
+  return 0;
+}
+
+// layout of one OccTable inside an arena
+struct OccLayout { size_t direct, multi_off, multi, end; };
+OccLayout layout_occ(const OccTable& t, size_t at) {
+  OccLayout l;
+  l.direct = at;
+  l.multi_off = align16(l.direct + std::max<size_t>(1, t.direct.size()) * sizeof(OccQuad));
+  l.multi = align16(l.multi_off + t.multi_off.size() * sizeof(int32_t));
+  l.end = align16(l.multi + std::max<size_t>(1, t.multi.size()) * sizeof(OccQuad));
+  return l;
+}
+void pack_occ(const OccTable& t, const OccLayout& l, char* base) {
+  if (!t.direct.empty()) memcpy(base + l.direct, t.direct.data(), t.direct.size() * sizeof(OccQuad));
+  memcpy(base + l.multi_off, t.multi_off.data(), t.multi_off.size() * sizeof(int32_t));
+  if (!t.multi.empty()) memcpy(base + l.multi, t.multi.data(), t.multi.size() * sizeof(OccQuad));
+}
+
+int upload_mate(gaml_hip_ctx* c, const ShortMate& m, ReadMajor& rm, MateDev& d, hipStream_t st) {
+  if (d.pow_n == 0) {
+    d.pow_n = m.match_pow.size();
+    HIP_TRY(c, d.pows.reserve(2 * d.pow_n * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(d.pows.p, m.mismatch_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d.pows.as<double>() + d.pow_n, m.match_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (d.uploaded_generation == m.generation) return 0;
+  // the window cache changed: rebuild the read-major table (cold path) and upload it
+  build_read_major(m, rm);
+  HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old table
+  HIP_TRY(c, d.first.reserve(std::max<size_t>(1, rm.first.size()) * sizeof(RecQuad)));
+  HIP_TRY(c, d.extra.reserve(std::max<size_t>(1, rm.extra.size()) * sizeof(RecQuad)));
+  if (!rm.first.empty()) HIP_TRY(c, hipMemcpy(d.first.p, rm.first.data(), rm.first.size() * sizeof(RecQuad), hipMemcpyHostToDevice));
+  if (!rm.extra.empty()) HIP_TRY(c, hipMemcpy(d.extra.p, rm.extra.data(), rm.extra.size() * sizeof(RecQuad), hipMemcpyHostToDevice));
+  d.uploaded_generation = m.generation;
+  return 0;
+}
+
+MateView view_of(const MateDev& d, const char* arena, const OccLayout& l) {
+  MateView v;
+  v.first = d.first.as<int4>();
+  v.extra = d.extra.as<int4>();
+  v.occ = (const int4*)(arena + l.direct);
+  v.multi_off = (const int*)(arena + l.multi_off);
+  v.multi = (const int4*)(arena + l.multi);
+  v.mism_pow = d.pows.as<double>();
+  v.match_pow = d.pows.as<double>() + d.pow_n;
+  return v;
+}
+
+std::vector<Walk> unflatten(const int32_t* flat, const int64_t* offs, int32_t n) {
+  std::vector<Walk> r(n);
+  for (int32_t i = 0; i < n; i++) r[i].assign(flat + offs[i], flat + offs[i + 1]);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// paired read set: host preparation + launch (CalcScoreForPathsNew graph.cc:1952-1989,
+// evaluated from scratch)
+// ---------------------------------------------------------------------------------------
+int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
+  if (s.tabs_uploaded) return 0;
+  const double c0 = s.cfg.min_prob_start, k0 = s.cfg.min_prob_per_base;
+  int n_ins = (int)(s.cfg.insert_mean + 5 * s.cfg.insert_std);  // graph.cc:1801
+  if (n_ins < 0) n_ins = 0;
+  s.ins_tab.resize(n_ins);
+  for (int i = 0; i < n_ins; i++) {
+    double z = ((double)i - s.cfg.insert_mean) / s.cfg.insert_std;  // graph.cc:1593-1598
+    s.ins_tab[i] = std::exp(-z * z / 2.0) / (std::sqrt(2 * M_PI) * s.cfg.insert_std);
+  }
+  int smax = s.mate[0].max_len + s.mate[1].max_len;
+  s.floor_tab.resize(smax + 1);
+  s.logfloor_tab.resize(smax + 1);
+  for (int v = 0; v <= smax; v++) {
+    s.floor_tab[v] = std::exp(c0 + k0 * v);          // graph.cc:1506-1507
+    s.logfloor_tab[v] = std::log(s.floor_tab[v]);    // graph.cc:1510-1512 on a floored read
+  }
+  s.covthr_tab.resize(s.mate[1].max_len + 1);
+  for (int v = 0; v <= s.mate[1].max_len; v++) s.covthr_tab[v] = std::exp(c0 + k0 * (v + v));  // graph.cc:1855-1857
+  size_t total = s.ins_tab.size() + s.floor_tab.size() + s.logfloor_tab.size() + s.covthr_tab.size();
+  HIP_TRY(c, s.tabs.reserve(std::max<size_t>(1, total) * sizeof(double)));
+  double* d = s.tabs.as<double>();
+  size_t at = 0;
+  auto up = [&](const std::vector<double>& v) -> hipError_t {
+    hipError_t e = v.empty() ? hipSuccess : hipMemcpy(d + at, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+    at += v.size();
+    return e;
+  };
+  HIP_TRY(c, up(s.ins_tab));
+  HIP_TRY(c, up(s.floor_tab));
+  HIP_TRY(c, up(s.logfloor_tab));
+  HIP_TRY(c, up(s.covthr_tab));
+  // len12
+  const int64_t n = s.mate[0].n_local();
+  std::vector<uint32_t> l12(n);
+  for (int64_t i = 0; i < n; i++) l12[i] = (uint32_t)s.mate[0].lens[i] | ((uint32_t)s.mate[1].lens[i] << 16);
+  HIP_TRY(c, s.len12.reserve(std::max<size_t>(1, n) * sizeof(uint32_t)));
+  if (n) HIP_TRY(c, hipMemcpy(s.len12.p, l12.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, s.probs.reserve(std::max<size_t>(1, n) * sizeof(double)));
+  HIP_TRY(c, s.red.init());
+  HIP_TRY(c, s.bad.reserve(sizeof(unsigned long long)));
+  HIP_TRY(c, s.bad_host.reserve(sizeof(unsigned long long)));
+  s.tabs_uploaded = true;
+  return 0;
+}
+
+struct PairedPrep {
+  OccTable occ[2];
+  std::vector<int32_t> path_base, start_off, starts;
+  int32_t total_bits = 0;
+};
+
+void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p) {
+  // 1. windows registered over the whole path set, per mate (graph.cc:1967-1968)
+  register_for_paths(c->g, s.mate[0], paths);
+  register_for_paths(c->g, s.mate[1], paths);
+  // 2. per path, per contig: register the contig's windows, then read off which cached windows
+  //    sit where (graph.cc:1830-1844, in the reference's interleaving of the two mates)
+  std::vector<Occ> occs[2];
+  int32_t rank[2] = {0, 0};
+  std::vector<std::pair<int32_t, int32_t>> ranges;
+  std::vector<int32_t> gaps;
+  const bool cov = s.cfg.penalty_constant > 0;
+  p.path_base.assign(1, 0);
+  p.start_off.assign(1, 0);
+  p.starts.clear();
+  for (int32_t pi = 0; pi < (int32_t)paths.size(); pi++) {
+    const Walk& path = paths[pi];
+    split_contigs(path, ranges, gaps);
+    int32_t cur_len = 0;
+    p.starts.push_back(0);  // events (0,1) graph.cc:1826
+    for (size_t ci = 0; ci < ranges.size(); ci++) {
+      if (ci > 0) { cur_len += gaps[ci - 1]; p.starts.push_back(cur_len); }  // graph.cc:1833-1835
+      const int32_t* ctg = path.data() + ranges[ci].first;
+      const int32_t n = ranges[ci].second - ranges[ci].first;
+      for (int mt = 0; mt < 2; mt++) {
+        register_for_contig(c->g, s.mate[mt], ctg, n);
+        occurrences_paired_contig(c->g, s.mate[mt], ctg, n, cur_len, pi, &rank[mt], occs[mt]);
+      }
+      for (int32_t k = 0; k < n; k++) cur_len += c->g.len(ctg[k]);
+    }
+    p.start_off.push_back((int32_t)p.starts.size());
+    // coverage bitmap: one bit per path position, paths padded to 32-bit words (+ slack)
+    int32_t bits = ((cur_len + 64 + 31) / 32) * 32;
+    p.path_base.push_back(p.path_base.back() + (cov ? bits : 0));
+  }
+  p.total_bits = p.path_base.back();
+  // windows may have been added after an occurrence list entry was made; tables are sized to
+  // the final window count
+  build_occ_table(s.mate[0].wins.size(), occs[0], p.occ[0]);
+  build_occ_table(s.mate[1].wins.size(), occs[1], p.occ[1]);
+}
+
+int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, int32_t total_len, hipStream_t st) {
+  if (int e = prepare_paired_tables(c, s)) return e;
+  PairedPrep p;
+  prepare_paired_host(c, s, paths, p);
+  const double t_after_host = now_us();
+  for (int mt = 0; mt < 2; mt++)
+    if (int e = upload_mate(c, s.mate[mt], s.rm[mt], s.dev[mt], st)) return e;
+
+  const bool cov = s.cfg.penalty_constant > 0;
+  OccLayout l0 = layout_occ(p.occ[0], 0);
+  OccLayout l1 = layout_occ(p.occ[1], l0.end);
+  size_t meta = l1.end;
+  size_t pb_off = meta, so_off = 0, st_off = 0, total = meta;
+  if (cov) {
+    so_off = align16(pb_off + p.path_base.size() * sizeof(int32_t));
+    st_off = align16(so_off + p.start_off.size() * sizeof(int32_t));
+    total = align16(st_off + p.starts.size() * sizeof(int32_t));
+  }
+  void* host = nullptr;
+  int slot = stage_acquire(c, s.stage, total, &host);
+  if (slot < 0) return slot;
+  pack_occ(p.occ[0], l0, (char*)host);
+  pack_occ(p.occ[1], l1, (char*)host);
+  if (cov) {
+    memcpy((char*)host + pb_off, p.path_base.data(), p.path_base.size() * sizeof(int32_t));
+    memcpy((char*)host + so_off, p.start_off.data(), p.start_off.size() * sizeof(int32_t));
+    memcpy((char*)host + st_off, p.starts.data(), p.starts.size() * sizeof(int32_t));
+  }
+  // the arena is overwritten in stream order: earlier launches that read it have been enqueued
+  // before this copy on the same stream
+  if (total > s.occ_arena.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.occ_arena.reserve(total)); }
+  HIP_TRY(c, hipMemcpyAsync(s.occ_arena.p, host, total, hipMemcpyHostToDevice, st));
+  if (int e = stage_release(c, s.stage, slot, st)) return e;
+
+  const int64_t n = s.mate[0].n_local();
+  const char* arena = (const char*)s.occ_arena.p;
+  PairedArgs a;
+  a.m[0] = view_of(s.dev[0], arena, l0);
+  a.m[1] = view_of(s.dev[1], arena, l1);
+  a.len12 = s.len12.as<uint32_t>();
+  const double* tabs = s.tabs.as<double>();
+  a.ins_tab = tabs; a.ins_n = (int)s.ins_tab.size();
+  a.ins_mean = s.cfg.insert_mean; a.ins_sd = s.cfg.insert_std;
+  a.floor_tab = tabs + s.ins_tab.size();
+  a.logfloor_tab = a.floor_tab + s.floor_tab.size();
+  a.covthr_tab = a.logfloor_tab + s.logfloor_tab.size();
+  int tl = total_len == 0 ? 1 : total_len;  // graph.cc:1500-1502
+  a.two_T = (double)(2 * tl);
+  a.n = (int)n;
+  a.probs = s.probs.as<double>();
+  a.cov_bits = nullptr; a.path_base = nullptr;
+  if (cov) {
+    size_t words = (size_t)p.total_bits / 32;
+    if (words * 4 > s.cov_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.cov_bits.reserve(std::max<size_t>(4, words * 4))); }
+    HIP_TRY(c, hipMemsetAsync(s.cov_bits.p, 0, std::max<size_t>(4, words * 4), st));
+    HIP_TRY(c, hipMemsetAsync(s.bad.p, 0, sizeof(unsigned long long), st));
+    a.cov_bits = s.cov_bits.as<uint32_t>();
+    a.path_base = (const int*)(arena + pb_off);
+  }
+  a.part_sum = s.red.part_sum.as<double>();
+  a.part_zero = s.red.part_zero.as<int>();
+  a.ticket = s.red.ticket.as<unsigned>();
+  a.out = s.red.out.as<double>();
+
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (c->event_timing) { if (int e = take_events(c, &ev)) return e; HIP_TRY(c, hipEventRecord(ev->first, st)); }
+  if (n > 0) {
+    hipLaunchKernelGGL(paired_score_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, a);
+    HIP_TRY(c, hipGetLastError());
+  } else {
+    HIP_TRY(c, hipMemsetAsync(s.red.out.p, 0, 2 * sizeof(double), st));
+  }
+  if (cov && n > 0 && p.total_bits > 0) {
+    CovArgs ca;
+    ca.bits = s.cov_bits.as<uint32_t>();
+    ca.path_base = (const int*)(arena + pb_off);
+    ca.start_off = (const int*)(arena + so_off);
+    ca.starts = (const int*)(arena + st_off);
+    ca.n_paths = (int)paths.size();
+    ca.total_words = p.total_bits / 32;
+    ca.cov_move = s.cfg.step;
+    ca.far = s.cfg.insert_mean + 5 * s.cfg.insert_std;
+    ca.bad = s.bad.as<unsigned long long>();
+    hipLaunchKernelGGL(coverage_sweep_kernel, dim3(grid_for(ca.total_words)), dim3(kBlock), 0, st, ca);
+    HIP_TRY(c, hipGetLastError());
+  }
+  if (ev) HIP_TRY(c, hipEventRecord(ev->second, st));
+  // SURVEY.md 8d accounting: 16 B per record, 8 B read lengths, 8 B probability written, per pair
+  c->stat_algo_bytes += 16.0 * (double)(s.rm[0].total_records + s.rm[1].total_records) + 16.0 * (double)n;
+  c->stat_launches++;
+  c->t_host_us += t_after_host;  // caller subtracts the start stamp
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// single-end read set (CalcScoreForPaths graph.cc:1650-1743)
+// ---------------------------------------------------------------------------------------
+int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths, int32_t total_len, hipStream_t st) {
+  if (!s.tabs_uploaded) {
+    const int lmax = s.mate.max_len;
+    s.floor_tab.resize(lmax + 1); s.logfloor_tab.resize(lmax + 1);
+    for (int v = 0; v <= lmax; v++) {
+      s.floor_tab[v] = std::exp(s.cfg.min_prob_start + s.cfg.min_prob_per_base * v);  // graph.cc:1528
+      s.logfloor_tab[v] = std::log(s.floor_tab[v]);
+    }
+    HIP_TRY(c, s.tabs.reserve(2 * (size_t)(lmax + 1) * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(s.tabs.p, s.floor_tab.data(), (lmax + 1) * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(s.tabs.as<double>() + lmax + 1, s.logfloor_tab.data(), (lmax + 1) * sizeof(double), hipMemcpyHostToDevice));
+    const int64_t n = s.mate.n_local();
+    HIP_TRY(c, s.lens.reserve(std::max<size_t>(1, n) * sizeof(int32_t)));
+    if (n) HIP_TRY(c, hipMemcpy(s.lens.p, s.mate.lens.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, s.probs.reserve(std::max<size_t>(1, n) * sizeof(double)));
+    HIP_TRY(c, s.red.init());
+    s.tabs_uploaded = true;
+  }
+  // host: per path (offset by 1,000,000 each, graph.cc:1685), per contig: register + occurrences
+  std::vector<Occ> occs;
+  int32_t rank = 0, tl = 0, stv = 0;
+  std::vector<std::pair<int32_t, int32_t>> ranges;
+  std::vector<int32_t> gaps;
+  for (const Walk& path : paths) {
+    split_contigs(path, ranges, gaps);
+    for (size_t ci = 0; ci < ranges.size(); ci++) {
+      if (ci > 0) tl += gaps[ci - 1];
+      const int32_t* ctg = path.data() + ranges[ci].first;
+      const int32_t n = ranges[ci].second - ranges[ci].first;
+      register_for_contig(c->g, s.mate, ctg, n);
+      occurrences_single_contig(c->g, s.mate, ctg, n, stv + tl, &rank, occs);
+      for (int32_t k = 0; k < n; k++) tl += c->g.len(ctg[k]);
+    }
+    stv += 1000000;
+  }
+  (void)total_len;
+  OccTable occ;
+  build_occ_table(s.mate.wins.size(), occs, occ);
+  const double t_after_host = now_us();
+  if (int e = upload_mate(c, s.mate, s.rm, s.dev, st)) return e;
+  OccLayout l0 = layout_occ(occ, 0);
+  void* host = nullptr;
+  int slot = stage_acquire(c, s.stage, l0.end, &host);
+  if (slot < 0) return slot;
+  pack_occ(occ, l0, (char*)host);
+  if (l0.end > s.occ_arena.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.occ_arena.reserve(l0.end)); }
+  HIP_TRY(c, hipMemcpyAsync(s.occ_arena.p, host, l0.end, hipMemcpyHostToDevice, st));
+  if (int e = stage_release(c, s.stage, slot, st)) return e;
+  const int64_t n = s.mate.n_local();
+  SingleArgs a;
+  a.m = view_of(s.dev, (const char*)s.occ_arena.p, l0);
+  a.lens = s.lens.as<int>();
+  a.floor_tab = s.tabs.as<double>();
+  a.logfloor_tab = s.tabs.as<double>() + s.mate.max_len + 1;
+  int t2 = tl == 0 ? 1 : tl;
+  a.two_T = (double)(2 * t2);
+  a.n = (int)n;
+  a.probs = s.probs.as<double>();
+  a.part_sum = s.red.part_sum.as<double>(); a.part_zero = s.red.part_zero.as<int>();
+  a.ticket = s.red.ticket.as<unsigned>(); a.out = s.red.out.as<double>();
+  if (n > 0) {
+    hipLaunchKernelGGL(single_score_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, a);
+    HIP_TRY(c, hipGetLastError());
+  } else {
+    HIP_TRY(c, hipMemsetAsync(s.red.out.p, 0, 2 * sizeof(double), st));
+  }
+  c->stat_algo_bytes += 16.0 * (double)s.rm.total_records + 12.0 * (double)n;  // 16k + 4 + 8 per read
+  c->stat_launches++;
+  c->t_host_us += t_after_host;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// PacBio read set (CalcScoreForPacbio graph.cc:3171-3261)
+// ---------------------------------------------------------------------------------------
+int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_in, hipStream_t st) {
+  const int64_t n = s.hi - s.lo;
+  if (!s.red.part_sum.p) {
+    HIP_TRY(c, s.red.init());
+    HIP_TRY(c, s.d_lens.reserve(std::max<size_t>(1, n) * sizeof(int32_t)));
+    if (n) HIP_TRY(c, hipMemcpy(s.d_lens.p, s.lens.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, s.logprobs.reserve(std::max<size_t>(1, n) * sizeof(double)));
+  }
+  // sub-walk occurrence counts + coverage events, per path (graph.cc:3183-3251)
+  std::vector<int32_t> count(s.recs.size(), 0);
+  int64_t bad_bases = 0;
+  const bool cov = s.cfg.penalty_constant > 0;
+  for (Walk path : paths_in) {
+    for (auto& x : path) if (x >= 0) x = c->g.norm[x];  // NormalizePath graph.h:268-273
+    const int32_t m = (int32_t)path.size();
+    std::vector<int32_t> begins(m), ends(m);
+    int32_t len = 0;
+    for (int32_t i = 0; i < m; i++) {  // graph.cc:2412-2431 (a leading gap contributes its length)
+      begins[i] = len;
+      len += path[i] < 0 ? -path[i] : c->g.len(path[i]);
+      ends[i] = len;
+    }
+    const int32_t tl = len;
+    std::vector<std::pair<int32_t, int32_t>> events;
+    if (cov) {
+      events.emplace_back(-1000, 1); events.emplace_back(2000, -3000);  // graph.cc:3198-3199
+      int32_t pp = 0;
+      for (int32_t e : path) {
+        if (e >= 0) { int32_t cl = c->g.len(e); events.emplace_back(pp, 1); events.emplace_back(pp + cl, -cl); pp += cl; }
+        else pp += -e;
+      }
+    }
+    Walk sub;
+    for (int32_t i = 0; i < m; i++) {  // graph.cc:2438-2454
+      sub.clear();
+      for (int32_t j = i; j < m; j++) {
+        sub.push_back(path[j]);
+        auto it = s.walk_id.find(sub);
+        if (it == s.walk_id.end()) s.misses++;  // the reference would run BLASR here (out of scope)
+        else {
+          count[it->second]++;
+          if (cov) {
+            // host-side interval events of this occurrence (graph.cc:3214-3222); only records that
+            // clear GetMinReadProb (graph.h:478-481) count
+            for (const auto& r : s.recs[it->second]) {
+              double min_lp = s.log_mismatch * (s.lens[r.read_id] * 0.25) + s.log_match * (s.lens[r.read_id] * 0.75);
+              if (r.logprob < min_lp) continue;
+              events.emplace_back(begins[i] + r.position, 1);
+              events.emplace_back(begins[i] + r.position_end, r.position - r.position_end);
+            }
+          }
+        }
+        if ((ends[j] - begins[i]) - (ends[i] - begins[i]) > s.max_len) break;
+      }
+    }
+    if (cov) {
+      // NOTE: with sharding each rank only sees its own reads' intervals; the coverage penalty of a
+      // PacBio set is therefore only evaluated unsharded (world == 1). Integer event sweep,
+      // graph.cc:3226-3250.
+      std::sort(events.begin(), events.end());
+      std::multiset<int32_t> open;
+      for (size_t j = 0; j < events.size(); j++) {
+        if (events[j].second == 1) open.insert(events[j].first);
+        else { auto it = open.find(events[j].first + events[j].second); if (it != open.end()) open.erase(it); }
+        int32_t good = tl - 250;
+        if (!open.empty()) good = (int32_t)(*open.begin() + s.cfg.step);
+        if (j + 1 < events.size()) good = std::min(events[j + 1].first, good);
+        good = std::min(good, tl - 250);
+        int32_t from = std::max(2500, events[j].first);
+        if (good > from) bad_bases += good - from;
+      }
+    }
+  }
+  s.last_bad_bases = bad_bases;
+  const double t_after_host = now_us();
+  // read-major CSR of the cached records (rebuilt when the cache changed)
+  if (s.uploaded_generation != s.generation) {
+    std::vector<int32_t> off(n + 1, 0);
+    for (auto& v : s.recs) for (auto& r : v) off[r.read_id + 1]++;
+    for (int64_t i = 0; i < n; i++) off[i + 1] += off[i];
+    std::vector<int32_t> walk(off[n]), fill(off.begin(), off.end() - 1);
+    std::vector<double> lp(off[n]);
+    for (size_t w = 0; w < s.recs.size(); w++)
+      for (auto& r : s.recs[w]) { int32_t at = fill[r.read_id]++; walk[at] = (int32_t)w; lp[at] = r.logprob; }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, s.rec_off.reserve((n + 1) * sizeof(int32_t)));
+    HIP_TRY(c, s.rec_walk.reserve(std::max<size_t>(1, walk.size()) * sizeof(int32_t)));
+    HIP_TRY(c, s.rec_logp.reserve(std::max<size_t>(1, lp.size()) * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(s.rec_off.p, off.data(), (n + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!walk.empty()) {
+      HIP_TRY(c, hipMemcpy(s.rec_walk.p, walk.data(), walk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(s.rec_logp.p, lp.data(), lp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    s.uploaded_generation = s.generation;
+  }
+  size_t bytes = std::max<size_t>(1, count.size()) * sizeof(int32_t);
+  void* host = nullptr;
+  int slot = stage_acquire(c, s.stage, bytes, &host);
+  if (slot < 0) return slot;
+  if (!count.empty()) memcpy(host, count.data(), count.size() * sizeof(int32_t));
+  if (bytes > s.walk_count.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.walk_count.reserve(bytes)); }
+  HIP_TRY(c, hipMemcpyAsync(s.walk_count.p, host, bytes, hipMemcpyHostToDevice, st));
+  if (int e = stage_release(c, s.stage, slot, st)) return e;
+  PacbioArgs a;
+  a.rec_off = s.rec_off.as<int>(); a.rec_walk = s.rec_walk.as<int>(); a.rec_logp = s.rec_logp.as<double>();
+  a.walk_count = s.walk_count.as<int>(); a.lens = s.d_lens.as<int>();
+  a.floor_a = std::log(std::exp(s.cfg.min_prob_start));     // logdouble(exp(c)) graph.cc:3075
+  a.floor_b = std::log(std::exp(s.cfg.min_prob_per_base));  // logdouble(exp(k))
+  a.n = (int)n;
+  a.logprobs = s.logprobs.as<double>();
+  a.part_sum = s.red.part_sum.as<double>(); a.part_zero = s.red.part_zero.as<int>();
+  a.ticket = s.red.ticket.as<unsigned>(); a.out = s.red.out.as<double>();
+  if (n > 0) {
+    int64_t threads = n * 64;  // one wave per read
+    hipLaunchKernelGGL(pacbio_score_kernel, dim3(grid_for(threads)), dim3(kBlock), 0, st, a);
+    HIP_TRY(c, hipGetLastError());
+  } else {
+    HIP_TRY(c, hipMemsetAsync(s.red.out.p, 0, 2 * sizeof(double), st));
+  }
+  int64_t nrec = 0;
+  for (auto& v : s.recs) nrec += (int64_t)v.size();
+  c->stat_algo_bytes += 24.0 * (double)nrec + 12.0 * (double)n;
+  c->stat_launches++;
+  c->t_host_us += t_after_host;
+  return 0;
+}
+
+// gather {sum_log, zeros, bad_bases, n} of every read set into one packed device array
+struct PackArgs { const double* out[64]; const unsigned long long* bad[64]; double host_bad[64]; double n[64]; int count; double* dst; };
+__global__ void pack_partials_kernel(PackArgs a) {
+  int i = threadIdx.x;
+  if (i >= a.count) return;
+  a.dst[4 * i + 0] = a.out[i][0];
+  a.dst[4 * i + 1] = a.out[i][1];
+  a.dst[4 * i + 2] = a.bad[i] ? (double)*a.bad[i] : a.host_bad[i];
+  a.dst[4 * i + 3] = a.n[i];
+}
+
+int evaluate(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t n_paths, void* d_partials,
+             hipStream_t st, int32_t* total_len_out) {
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
+  if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
+  if (n_paths < 0 || (n_paths > 0 && (!flat || !offs))) return fail(c, GAML_HIP_EINVAL, "bad path arguments");
+  std::vector<Walk> paths = unflatten(flat, offs, n_paths);
+  for (auto& p : paths)
+    for (int32_t x : p)
+      if (x >= c->g.n()) return fail(c, GAML_HIP_EINVAL, "path refers to a node outside the graph");
+  int32_t total_len = 0;
+  for (auto& p : paths) total_len += walk_length(c->g, p);  // GetTotalLen graph.cc:1775-1781
+  if (total_len_out) *total_len_out = total_len;
+  auto order = scoring_order(c);
+  if (order.size() > 64) return fail(c, GAML_HIP_EINVAL, "more than 64 read sets");
+  PackArgs pa;
+  pa.count = (int)order.size();
+  pa.dst = (double*)d_partials;
+  const double t0 = now_us();
+  c->t_host_us = 0;
+  c->ev_used = 0;
+  int k = 0;
+  for (auto& h : order) {
+    const double tk = now_us();
+    int e = 0;
+    pa.bad[k] = nullptr; pa.host_bad[k] = 0;
+    if (h.kind == 0) {
+      SingleSet& s = *c->singles[h.idx];
+      e = launch_single(c, s, paths, total_len, st);
+      pa.out[k] = s.red.out.as<double>(); pa.n[k] = (double)s.mate.n_local();
+    } else if (h.kind == 1) {
+      PairedSet& s = *c->paireds[h.idx];
+      e = launch_paired(c, s, paths, total_len, st);
+      pa.out[k] = s.red.out.as<double>(); pa.n[k] = (double)s.mate[0].n_local();
+      if (s.cfg.penalty_constant > 0) pa.bad[k] = s.bad.as<unsigned long long>();
+    } else {
+      PacbioSet& s = *c->pacbios[h.idx];
+      e = launch_pacbio(c, s, paths, st);
+      pa.out[k] = s.red.out.as<double>(); pa.n[k] = (double)(s.hi - s.lo);
+      pa.host_bad[k] = (double)s.last_bad_bases;
+    }
+    if (e) return e;
+    c->t_host_us -= tk;  // launch_* added its "host part finished" stamp
+    k++;
+  }
+  if (pa.count > 0) {
+    hipLaunchKernelGGL(pack_partials_kernel, dim3(1), dim3(64), 0, st, pa);
+    HIP_TRY(c, hipGetLastError());
+  }
+  c->t_dev_wall_us = now_us() - t0 - c->t_host_us;
+  return 0;
+}
+
+int combine(gaml_hip_ctx* c, const double* partials, double* prob_out, int32_t* zeros_out, int32_t total_len) {
+  // prob = sum over read sets of weight * (mean log-probability - bad_bases * penalty)
+  // (prob_calculator.h:70-107; graph.cc:1515,1988 / 1536,1742 / 3087,3260)
+  auto order = scoring_order(c);
+  double prob = 0;
+  int k = 0;
+  for (auto& h : order) {
+    const double sum = partials[4 * k], zeros = partials[4 * k + 1], bad = partials[4 * k + 2], n = partials[4 * k + 3];
+    double v;
+    if (h.kind == 0) {
+      const gaml_single_cfg& cfg = c->singles[h.idx]->cfg;
+      v = (sum / (double)(int64_t)n - bad * cfg.penalty_constant) * cfg.weight;
+    } else if (h.kind == 1) {
+      const gaml_paired_cfg& cfg = c->paireds[h.idx]->cfg;
+      v = (sum / (double)(int64_t)n - bad * cfg.penalty_constant) * cfg.weight;
+    } else {
+      const gaml_single_cfg& cfg = c->pacbios[h.idx]->cfg;
+      int tl = total_len == 0 ? 1 : total_len;
+      v = (sum / (double)(int64_t)n - std::log((double)(2 * tl)) - bad * cfg.penalty_constant) * cfg.weight;
+    }
+    prob += v;
+    if (zeros_out) { zeros_out[2 * k] = (int32_t)zeros; zeros_out[2 * k + 1] = (int32_t)n; }
+    k++;
+  }
+  *prob_out = prob;
+  return 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char* gaml_hip_version(void) { return "gaml_hip 0.1 (gfx950)"; }
+
+int gaml_hip_create(gaml_hip_ctx** out, int device) {
+  if (!out) return GAML_HIP_EINVAL;
+  *out = nullptr;
+  std::unique_ptr<gaml_hip_ctx> c(new gaml_hip_ctx());
+  c->device = device;
+  if (device >= 0) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device >= count) {
+      fprintf(stderr, "gaml_hip_create: HIP device %d not available (%s)\n", device, e == hipSuccess ? "ordinal out of range" : hipGetErrorString(e));
+      return GAML_HIP_ENODEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) return GAML_HIP_EHIP;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return GAML_HIP_EHIP;
+  }
+  *out = c.release();
+  return GAML_HIP_OK;
+}
+
+void gaml_hip_destroy(gaml_hip_ctx* c) {
+  if (!c) return;
+  if (c->device >= 0) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    auto drop_stage = [](Staging& s) { for (int k = 0; k < kRing; k++) { s.host[k].release(); if (s.done[k]) (void)hipEventDestroy(s.done[k]); } };
+    for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
+    for (auto& s : c->paireds) {
+      for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); }
+      s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->cov_meta.release(); s->bad.release();
+      s->red.release(); s->bad_host.release(); drop_stage(s->stage);
+    }
+    for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage); }
+    c->packed.release(); c->packed_host.release();
+    for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+const char* gaml_hip_last_error(const gaml_hip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gaml_hip_set_graph(gaml_hip_ctx* c, int32_t n_nodes, const char* bases, const int64_t* offs) {
+  if (!c || n_nodes < 0 || !offs || (n_nodes > 0 && !bases)) return fail(c, GAML_HIP_EINVAL, "bad graph arguments");
+  if (n_nodes & 1) return fail(c, GAML_HIP_EINVAL, "node count must be even (twin of i is i^1)");
+  c->g.bases.assign(bases + offs[0], bases + offs[n_nodes]);
+  c->g.off.resize(n_nodes + 1);
+  for (int32_t i = 0; i <= n_nodes; i++) c->g.off[i] = offs[i] - offs[0];
+  c->g.finish();
+  c->have_graph = true;
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_load_graph(gaml_hip_ctx* c, const char* file) {
+  if (!c || !file) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  std::string err;
+  if (!c->g.load_lastgraph(file, &err)) return fail(c, GAML_HIP_EINVAL, err);
+  c->have_graph = true;
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_set_shard(gaml_hip_ctx* c, int32_t rank, int32_t world) {
+  if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, GAML_HIP_EINVAL, "bad shard");
+  if (!c->handles.empty()) return fail(c, GAML_HIP_ESTATE, "set the shard before adding read sets");
+  c->rank = rank; c->world = world;
+  return GAML_HIP_OK;
+}
+
+static void init_mate(gaml_hip_ctx* c, ShortMate& m, double mismatch, int64_t n, const char* b, const int64_t* offs) {
+  m.mismatch = mismatch;
+  m.match = 1.0 - 4 * mismatch;  // gaml.cc:813,854
+  int64_t lo, hi;
+  shard_range(c, n, &lo, &hi);
+  m.set_reads(n, lo, hi, b, offs);
+}
+
+int gaml_hip_add_single(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, const char* bases, const int64_t* offs) {
+  if (!c || !cfg || n < 0 || !offs) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  std::unique_ptr<SingleSet> s(new SingleSet());
+  s->cfg = *cfg;
+  init_mate(c, s->mate, cfg->mismatch_prob, n, bases, offs);
+  c->singles.push_back(std::move(s));
+  c->handles.push_back(SetRef{0, (int)c->singles.size() - 1});
+  return (int)c->handles.size() - 1;
+}
+
+int gaml_hip_add_paired(gaml_hip_ctx* c, const gaml_paired_cfg* cfg, int32_t n, const char* b1, const int64_t* o1,
+                        const char* b2, const int64_t* o2) {
+  if (!c || !cfg || n < 0 || !o1 || !o2) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  std::unique_ptr<PairedSet> s(new PairedSet());
+  s->cfg = *cfg;
+  init_mate(c, s->mate[0], cfg->mismatch_prob, n, b1, o1);
+  init_mate(c, s->mate[1], cfg->mismatch_prob, n, b2, o2);
+  if (s->mate[0].max_len > 65535 || s->mate[1].max_len > 65535) return fail(c, GAML_HIP_EINVAL, "paired reads longer than 65535 bases");
+  c->paireds.push_back(std::move(s));
+  c->handles.push_back(SetRef{1, (int)c->paireds.size() - 1});
+  return (int)c->handles.size() - 1;
+}
+
+int gaml_hip_add_pacbio(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, const int32_t* lens) {
+  if (!c || !cfg || n < 0 || (n > 0 && !lens)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  std::unique_ptr<PacbioSet> s(new PacbioSet());
+  s->cfg = *cfg;
+  s->n_global = n;
+  shard_range(c, n, &s->lo, &s->hi);
+  s->lens.assign(lens + s->lo, lens + s->hi);
+  s->max_len = 0;
+  for (int32_t i = 0; i < n; i++) s->max_len = std::max(s->max_len, lens[i]);  // CalcMaxReadLen graph.cc:1456-1461 (all reads)
+  s->log_mismatch = std::log(cfg->mismatch_prob);          // logdouble(mismatch_prob) graph.h:446-449
+  s->log_match = std::log(1.0 - 4 * cfg->mismatch_prob);
+  c->pacbios.push_back(std::move(s));
+  c->handles.push_back(SetRef{2, (int)c->pacbios.size() - 1});
+  return (int)c->handles.size() - 1;
+}
+
+int gaml_hip_add_single_fastq(gaml_hip_ctx* c, const gaml_single_cfg* cfg, const char* fastq) {
+  if (!c || !cfg || !fastq) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  std::string bases, err; std::vector<int64_t> offs;
+  if (!read_fastq(fastq, bases, offs, &err)) return fail(c, GAML_HIP_EINVAL, err);
+  return gaml_hip_add_single(c, cfg, (int32_t)offs.size() - 1, bases.data(), offs.data());
+}
+int gaml_hip_add_paired_fastq(gaml_hip_ctx* c, const gaml_paired_cfg* cfg, const char* f1, const char* f2) {
+  if (!c || !cfg || !f1 || !f2) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  std::string b1, b2, err; std::vector<int64_t> o1, o2;
+  if (!read_fastq(f1, b1, o1, &err) || !read_fastq(f2, b2, o2, &err)) return fail(c, GAML_HIP_EINVAL, err);
+  if (o1.size() != o2.size()) return fail(c, GAML_HIP_EINVAL, "mate files hold different numbers of reads");  // graph.cc:1962
+  return gaml_hip_add_paired(c, cfg, (int32_t)o1.size() - 1, b1.data(), o1.data(), b2.data(), o2.data());
+}
+int gaml_hip_add_pacbio_fastq(gaml_hip_ctx* c, const gaml_single_cfg* cfg, const char* fastq) {
+  if (!c || !cfg || !fastq) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  std::string bases, err; std::vector<int64_t> offs;
+  if (!read_fastq(fastq, bases, offs, &err)) return fail(c, GAML_HIP_EINVAL, err);
+  std::vector<int32_t> lens(offs.size() - 1);
+  for (size_t i = 0; i + 1 < offs.size(); i++) lens[i] = (int32_t)(offs[i + 1] - offs[i]);
+  return gaml_hip_add_pacbio(c, cfg, (int32_t)lens.size(), lens.data());
+}
+
+static ShortMate* mate_of(gaml_hip_ctx* c, int readset, int mate) {
+  if (!c || readset < 0 || readset >= (int)c->handles.size()) return nullptr;
+  SetRef h = c->handles[readset];
+  if (h.kind == 0) return mate == 0 ? &c->singles[h.idx]->mate : nullptr;
+  if (h.kind == 1) return (mate == 0 || mate == 1) ? &c->paireds[h.idx]->mate[mate] : nullptr;
+  return nullptr;
+}
+
+int gaml_hip_put_window_records(gaml_hip_ctx* c, int readset, int mate, const int32_t* subpath, int32_t len,
+                                const gaml_aligment* recs, int64_t n) {
+  ShortMate* m = mate_of(c, readset, mate);
+  if (!m || !subpath || len <= 0 || n < 0) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  Walk w(subpath, subpath + len);
+  if (m->find(w) >= 0) return fail(c, GAML_HIP_ESTATE, "window already cached");
+  std::vector<gaml_aligment> v;
+  for (int64_t i = 0; i < n; i++) {
+    if (recs[i].read_id < m->lo || recs[i].read_id >= m->hi) continue;  // other shard
+    gaml_aligment r = recs[i];
+    r.read_id -= (int32_t)m->lo;
+    v.push_back(r);
+  }
+  std::stable_sort(v.begin(), v.end(), [](const gaml_aligment& a, const gaml_aligment& b) {  // graph.cc:1024-1026
+    return a.position == b.position ? a.read_id < b.read_id : a.position < b.position;
+  });
+  m->add_window(w, v);
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_put_pacbio_records(gaml_hip_ctx* c, int readset, const int32_t* subpath, int32_t len,
+                                const gaml_pacbio_aligment* recs, int64_t n) {
+  if (!c || readset < 0 || readset >= (int)c->handles.size() || c->handles[readset].kind != 2 || !subpath || len <= 0 || n < 0)
+    return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  PacbioSet& s = *c->pacbios[c->handles[readset].idx];
+  Walk w(subpath, subpath + len);
+  auto it = s.walk_id.find(w);
+  int32_t id;
+  if (it == s.walk_id.end()) { id = (int32_t)s.recs.size(); s.walk_id.emplace(w, id); s.recs.emplace_back(); }
+  else id = it->second;
+  for (int64_t i = 0; i < n; i++) {
+    if (recs[i].read_id < s.lo || recs[i].read_id >= s.hi) continue;
+    gaml_pacbio_aligment r = recs[i];
+    r.read_id -= (int32_t)s.lo;
+    s.recs[id].push_back(r);
+  }
+  s.generation++;
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_calc_partials_async(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths,
+                                 void* d_partials, void* stream, int32_t* total_len_out) {
+  if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
+  return evaluate(c, paths, offs, n_paths, d_partials, stream ? (hipStream_t)stream : c->stream, total_len_out);
+}
+
+int gaml_hip_calc_partials(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths,
+                           double* partials_out, int32_t* total_len_out) {
+  if (!c || !partials_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t bytes = std::max<size_t>(1, c->handles.size()) * 4 * sizeof(double);
+  HIP_TRY(c, c->packed.reserve(bytes));
+  HIP_TRY(c, c->packed_host.reserve(bytes));
+  int e = evaluate(c, paths, offs, n_paths, c->packed.p, c->stream, total_len_out);
+  if (e) return e;
+  const double t0 = now_us();
+  HIP_TRY(c, hipMemcpyAsync(c->packed_host.p, c->packed.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->t_dev_wall_us += now_us() - t0;
+  memcpy(partials_out, c->packed_host.p, c->handles.size() * 4 * sizeof(double));
+  c->t_kernel_us = 0;
+  for (size_t i = 0; i < c->ev_used; i++) {
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+    c->t_kernel_us += ms * 1000.0;
+  }
+  c->stat_device_us += c->t_kernel_us;
+  // bookkeeping for gaml_hip_bad_bases
+  auto order = scoring_order(c);
+  for (size_t k = 0; k < order.size(); k++)
+    if (order[k].kind == 1) c->paireds[order[k].idx]->last_bad_bases = (int64_t)partials_out[4 * k + 2];
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_combine_partials(gaml_hip_ctx* c, const double* partials, int32_t total_len, double* prob_out, int32_t* zeros_out) {
+  if (!c || !partials || !prob_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  return combine(c, partials, prob_out, zeros_out, total_len);
+}
+
+int gaml_hip_calc_prob(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths,
+                       double* prob_out, int32_t* zeros_out, int32_t* total_len_out) {
+  if (!c || !prob_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->world != 1) return fail(c, GAML_HIP_ESTATE, "sharded context: use gaml_hip_calc_partials + all-reduce + gaml_hip_combine_partials");
+  std::vector<double> partials(std::max<size_t>(1, c->handles.size()) * 4);
+  int32_t tl = 0;
+  int e = gaml_hip_calc_partials(c, paths, offs, n_paths, partials.data(), &tl);
+  if (e) return e;
+  if (total_len_out) *total_len_out = tl;
+  return combine(c, partials.data(), prob_out, zeros_out, tl);
+}
+
+int gaml_hip_num_readsets(const gaml_hip_ctx* c) { return c ? (int)c->handles.size() : 0; }
+int gaml_hip_readset_kind(const gaml_hip_ctx* c, int rs) { return (c && rs >= 0 && rs < (int)c->handles.size()) ? c->handles[rs].kind : -1; }
+int64_t gaml_hip_readset_reads(const gaml_hip_ctx* c, int rs) {
+  if (!c || rs < 0 || rs >= (int)c->handles.size()) return -1;
+  SetRef h = c->handles[rs];
+  if (h.kind == 0) return c->singles[h.idx]->mate.n_global;
+  if (h.kind == 1) return c->paireds[h.idx]->mate[0].n_global;
+  return c->pacbios[h.idx]->n_global;
+}
+int32_t gaml_hip_num_nodes(const gaml_hip_ctx* c) { return c && c->have_graph ? c->g.n() : 0; }
+int32_t gaml_hip_node_len(const gaml_hip_ctx* c, int32_t node) { return (c && c->have_graph && node >= 0 && node < c->g.n()) ? c->g.len(node) : -1; }
+
+int gaml_hip_read_probs(gaml_hip_ctx* c, int rs, double* out, int64_t n) {
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || !out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "host-only context");
+  SetRef h = c->handles[rs];
+  const void* src; int64_t have;
+  if (h.kind == 0) { src = c->singles[h.idx]->probs.p; have = c->singles[h.idx]->mate.n_local(); }
+  else if (h.kind == 1) { src = c->paireds[h.idx]->probs.p; have = c->paireds[h.idx]->mate[0].n_local(); }
+  else { src = c->pacbios[h.idx]->logprobs.p; have = c->pacbios[h.idx]->hi - c->pacbios[h.idx]->lo; }
+  if (!src) return fail(c, GAML_HIP_ESTATE, "read set not scored yet");
+  if (n < have) return fail(c, GAML_HIP_EINVAL, "output too small");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (have) HIP_TRY(c, hipMemcpy(out, src, have * sizeof(double), hipMemcpyDeviceToHost));
+  return (int)std::min<int64_t>(have, 0x7fffffff);
+}
+
+int gaml_hip_bad_bases(gaml_hip_ctx* c, int rs, int64_t* out) {
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || !out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  SetRef h = c->handles[rs];
+  if (h.kind == 0) *out = 0;  // graph.cc:1701-1733 can never count a base (last_event_type is only -1 or 1)
+  else if (h.kind == 1) *out = c->paireds[h.idx]->last_bad_bases;
+  else *out = c->pacbios[h.idx]->last_bad_bases;
+  return GAML_HIP_OK;
+}
+
+int64_t gaml_hip_window_count(const gaml_hip_ctx* c, int rs, int mate) {
+  ShortMate* m = mate_of(const_cast<gaml_hip_ctx*>(c), rs, mate);
+  return m ? (int64_t)m->wins.size() : -1;
+}
+
+int64_t gaml_hip_window_records(gaml_hip_ctx* c, int rs, int mate, const int32_t* subpath, int32_t len, gaml_aligment* out, int64_t cap) {
+  ShortMate* m = mate_of(c, rs, mate);
+  if (!m || !subpath || len <= 0) return -2;
+  int32_t id = m->find(Walk(subpath, subpath + len));
+  if (id < 0) return -1;
+  const Window& w = m->wins[id];
+  for (int64_t i = 0; i < w.count && i < cap; i++) {
+    out[i] = m->pool[w.first + i];
+    out[i].read_id += (int32_t)m->lo;
+  }
+  return w.count;
+}
+
+int64_t gaml_hip_align_window(gaml_hip_ctx* c, int rs, int mate, const int32_t* subpath, int32_t len) {
+  ShortMate* m = mate_of(c, rs, mate);
+  if (!m || !subpath || len <= 0 || !c->have_graph) return -2;
+  int32_t id = m->align(c->g, Walk(subpath, subpath + len));
+  return m->wins[id].count;
+}
+
+int gaml_hip_last_timing(const gaml_hip_ctx* c, double* out3) {
+  if (!c || !out3) return GAML_HIP_EINVAL;
+  out3[0] = c->t_host_us; out3[1] = c->t_dev_wall_us; out3[2] = c->t_kernel_us;
+  return GAML_HIP_OK;
+}
+int gaml_hip_set_event_timing(gaml_hip_ctx* c, int on) {
+  if (!c) return GAML_HIP_EINVAL;
+  c->event_timing = on != 0;
+  return GAML_HIP_OK;
+}
+int gaml_hip_kernel_stats(gaml_hip_ctx* c, int reset, int64_t* launches, double* device_us, double* algo_bytes) {
+  if (!c) return GAML_HIP_EINVAL;
+  if (launches) *launches = c->stat_launches;
+  if (device_us) *device_us = c->stat_device_us;
+  if (algo_bytes) *algo_bytes = c->stat_algo_bytes;
+  if (reset) { c->stat_launches = 0; c->stat_device_us = 0; c->stat_algo_bytes = 0; }
+  return GAML_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,554 @@
+// host_model.cc -- see host_model.h. Reference citations are file:line under the reference tree.
+#include "host_model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+namespace gaml {
+
+// ---------------------------------------------------------------------------------------
+// graph
+// ---------------------------------------------------------------------------------------
+void GraphStore::finish() {
+  // nodes of length <= 3 with equal strings collapse onto the first one (graph.h:249-266);
+  // only the PacBio scorer normalises walks with it (graph.cc:3184).
+  norm.resize(n());
+  std::unordered_map<std::string, int32_t> tiny;
+  for (int32_t i = 0; i < n(); i++) {
+    norm[i] = i;
+    if (len(i) > 3) continue;
+    std::string s(seq(i), len(i));
+    auto it = tiny.find(s);
+    if (it == tiny.end()) tiny.emplace(s, i);
+    else norm[i] = it->second;
+  }
+}
+
+bool GraphStore::load_lastgraph(const std::string& file, std::string* err) {
+  // Velvet LastGraph as LoadGraph reads it (graph.cc:52-106): first field of the header = node
+  // count; per node one ignored line, the forward string, the twin string; ARC lines follow.
+  std::ifstream f(file.c_str());
+  if (!f.is_open()) { if (err) *err = "cannot open graph file " + file; return false; }
+  std::string line;
+  if (!std::getline(f, line)) { if (err) *err = "empty graph file"; return false; }
+  long nn = strtol(line.c_str(), nullptr, 10);
+  if (nn < 0) { if (err) *err = "bad node count"; return false; }
+  bases.clear();
+  off.assign(1, 0);
+  std::string fwd, twin;
+  for (long i = 0; i < nn; i++) {
+    std::getline(f, line);
+    std::getline(f, fwd);
+    std::getline(f, twin);
+    bases += fwd; off.push_back((int64_t)bases.size());
+    bases += twin; off.push_back((int64_t)bases.size());
+  }
+  finish();
+  return true;
+}
+
+int32_t walk_length(const GraphStore& g, const Walk& w) {  // GetPathLen graph.cc:1766-1773
+  int32_t t = 0;
+  for (int32_t e : w) t += e < 0 ? -e : g.len(e);
+  return t;
+}
+
+void split_contigs(const Walk& path, std::vector<std::pair<int32_t, int32_t>>& ranges, std::vector<int32_t>& gaps) {
+  // graph.cc:1808-1824: a negative entry -k is a gap of k bases and ends a contig
+  ranges.clear(); gaps.clear();
+  int32_t last = 0;
+  for (int32_t i = 0; i < (int32_t)path.size(); i++)
+    if (path[i] < 0) { gaps.push_back(-path[i]); ranges.emplace_back(last, i); last = i + 1; }
+  ranges.emplace_back(last, (int32_t)path.size());
+}
+
+// ---------------------------------------------------------------------------------------
+// seed code / max-hash
+// ---------------------------------------------------------------------------------------
+static inline uint32_t base_code(char c) {  // graph.h:326-331 (G0 A1 T2 C3; anything else 0)
+  switch (c) { case 'A': return 1; case 'T': return 2; case 'C': return 3; default: return 0; }
+}
+static inline uint64_t scramble(uint64_t code) { return code ^ 0x2204abcdull; }  // graph.cc:1245
+static const uint64_t kSeedMask = (1ull << (2 * kSeed)) - 1;
+
+uint64_t read_max_hash(const char* s, int32_t n) {
+  uint64_t code = 0, best = 0;
+  for (int32_t i = 0; i < n; i++) {
+    code = ((code << 2) & kSeedMask) + base_code(s[i]);
+    if (i >= kSeed - 1) best = std::max(best, scramble(code));
+  }
+  return best;
+}
+
+void span_maxima(const char* s, int32_t n, int32_t read_len, std::vector<std::pair<uint64_t, int32_t>>& out) {
+  // For every i >= read_len-1: M(i) = max scrambled seed code over seeds whose last base lies in
+  // [i-read_len+kSeed, i], P(i) = the earliest such seed attaining it. Emit (M(i), P(i)) at the
+  // first full span and whenever M(i) != M(i-1)  (graph.cc:1303-1321: `last_mh` always equals the
+  // previous span's maximum). Monotone queue on two flat arrays.
+  if (n < kSeed) return;
+  std::vector<uint64_t> qh(n);
+  std::vector<int32_t> qp(n);
+  int32_t head = 0, tail = 0;
+  uint64_t code = 0, prev = 0;
+  for (int32_t i = 0; i < n; i++) {
+    code = ((code << 2) & kSeedMask) + base_code(s[i]);
+    if (i < kSeed - 1) continue;
+    uint64_t h = scramble(code);
+    if (i > kSeed - 1) {
+      while (head < tail && qp[head] < i - read_len + kSeed) head++;
+      while (head < tail && qh[tail - 1] < h) tail--;
+    }
+    qh[tail] = h; qp[tail] = i; tail++;
+    if (i >= kSeed && i >= read_len - 1) {
+      uint64_t top = qh[head];
+      if (i == read_len - 1 || top != prev) { out.emplace_back(top, qp[head]); prev = top; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// seed extension: same accept set, error counts and end points as the reference's 0-1 BFS
+// (graph.cc:730-837), computed as a FIFO of "chain heads":
+//   a zero-cost diagonal step is pushed to the FRONT of the reference's deque and therefore
+//   popped next, so a popped state simply slides down its diagonal while bases match and the
+//   next cell is unvisited; at the first mismatch it appends its (<=3) successors at cost+1 to
+//   the back. Heads leave the queue in non-decreasing cost; the first head that slides off the
+//   read end wins; a head with cost > 3 means failure.
+// Visited cells are kept as one bitset per diagonal (|shift| <= 4 because cost <= 4).
+// ---------------------------------------------------------------------------------------
+namespace {
+struct Visited {
+  int32_t words;
+  std::vector<uint64_t> bits;
+  void reset(int32_t rlen) {
+    words = (rlen + 2 + 63) / 64;
+    bits.assign((size_t)9 * words, 0);
+  }
+  // returns true if (diag k, read index r) was unvisited, and marks it
+  bool mark(int32_t k, int32_t r) {
+    int32_t b = r + 1;
+    uint64_t& w = bits[(size_t)(k + 4) * words + (b >> 6)];
+    uint64_t m = 1ull << (b & 63);
+    if (w & m) return false;
+    w |= m;
+    return true;
+  }
+};
+struct Head { int32_t d, g, r; };
+}  // namespace
+
+bool extend_seed(int32_t win_pos, int32_t read_pos, const char* read, int32_t R, const char* win, int32_t W,
+                 Extension* out) {
+  static thread_local Visited vis;
+  static thread_local std::vector<Head> q;
+  auto diag = [&](int32_t g, int32_t r) { return (g - win_pos) - (r - read_pos); };
+
+  // ---- forward (graph.cc:761-793)
+  int32_t fwd = -1, end_pos = -1;
+  vis.reset(R);
+  q.clear();
+  q.push_back(Head{0, win_pos + kSeed, read_pos + kSeed});
+  for (size_t qi = 0; qi < q.size() && fwd < 0; qi++) {
+    Head h = q[qi];
+    if (h.d > 3) return false;
+    int32_t g = h.g, r = h.r;
+    while (true) {
+      if (r == R) { fwd = h.d; end_pos = g - 1; break; }
+      char wc = g < W ? win[g] : '\0';  // the reference reads the string terminator at g == W
+      if (wc == read[r]) {
+        if (g + 1 < W || r + 1 == R) {
+          if (!vis.mark(diag(g + 1, r + 1), r + 1)) break;
+          g++; r++;
+          continue;
+        }
+        break;
+      }
+      if (g + 1 < W) {
+        if (vis.mark(diag(g + 1, r + 1), r + 1)) q.push_back(Head{h.d + 1, g + 1, r + 1});
+        if (vis.mark(diag(g + 1, r), r)) q.push_back(Head{h.d + 1, g + 1, r});
+      }
+      if (vis.mark(diag(g, r + 1), r + 1)) q.push_back(Head{h.d + 1, g, r + 1});
+      break;
+    }
+  }
+  if (fwd < 0) return false;
+
+  // ---- backward (graph.cc:794-835)
+  int32_t bwd = -1, begin_pos = -1;
+  if (win_pos == 0) {
+    if (read_pos < 6) bwd = read_pos;
+  } else {
+    vis.reset(R);
+    q.clear();
+    q.push_back(Head{0, win_pos - 1, read_pos - 1});
+    for (size_t qi = 0; qi < q.size() && bwd < 0; qi++) {
+      Head h = q[qi];
+      if (h.d > 3) return false;
+      int32_t g = h.g, r = h.r;
+      while (true) {
+        if (r == -1) { bwd = h.d; begin_pos = g + 1; break; }
+        if (win[g] == read[r]) {
+          if (g - 1 >= 0 || r - 1 == -1) {
+            if (!vis.mark(diag(g - 1, r - 1), r - 1)) break;
+            g--; r--;
+            continue;
+          }
+          break;
+        }
+        if (g - 1 >= 0) {
+          if (vis.mark(diag(g - 1, r - 1), r - 1)) q.push_back(Head{h.d + 1, g - 1, r - 1});
+          if (vis.mark(diag(g - 1, r), r)) q.push_back(Head{h.d + 1, g - 1, r});
+        }
+        if (vis.mark(diag(g, r - 1), r - 1)) q.push_back(Head{h.d + 1, g, r - 1});
+        break;
+      }
+    }
+  }
+  if (bwd < 0) return false;
+  out->errs = fwd + bwd; out->begin = begin_pos; out->end = end_pos;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// ShortMate
+// ---------------------------------------------------------------------------------------
+void ShortMate::set_reads(int64_t n_global_, int64_t lo_, int64_t hi_, const char* b, const int64_t* offs) {
+  n_global = n_global_; lo = lo_; hi = hi_;
+  int64_t n = hi - lo;
+  roff.assign(n + 1, 0);
+  lens.assign(n, 0);
+  max_len = 0;
+  bases.assign(b + offs[lo], b + offs[hi]);
+  for (int64_t i = 0; i < n; i++) {
+    roff[i] = offs[lo + i] - offs[lo];
+    lens[i] = (int32_t)(offs[lo + i + 1] - offs[lo + i]);
+    max_len = std::max(max_len, lens[i]);
+  }
+  roff[n] = offs[hi] - offs[lo];
+  // pow tables sized max_read_len + 7 (graph.cc:1448-1453). NOTE: with sharding max_len is the
+  // shard's maximum; tables are indexed by edit count and by L - edit only, both <= L.
+  match_pow.resize(max_len + 7);
+  mismatch_pow.resize(max_len + 7);
+  for (size_t i = 0; i < match_pow.size(); i++) {
+    match_pow[i] = std::pow(match, (double)i);
+    mismatch_pow[i] = std::pow(mismatch, (double)i);
+  }
+  build_index();
+}
+
+static bool only_acgt(const char* s, int32_t n) {  // CheckRead graph.cc:1271-1278
+  for (int32_t i = 0; i < n; i++) if (s[i] != 'A' && s[i] != 'C' && s[i] != 'G' && s[i] != 'T') return false;
+  return true;
+}
+
+void ShortMate::build_index() {
+  // bucket = reads whose maximum scrambled 15-mer code equals the key (graph.cc:1280-1287);
+  // flat sorted arrays instead of a hash map of vectors.
+  int64_t n = n_local();
+  std::vector<std::pair<uint64_t, int32_t>> keyed;
+  keyed.reserve(n);
+  index_read_len = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (lens[i] < kSeed || !only_acgt(read(i), lens[i])) continue;
+    keyed.emplace_back(read_max_hash(read(i), lens[i]), (int32_t)i);
+    index_read_len = lens[i];
+  }
+  std::sort(keyed.begin(), keyed.end());
+  bucket_hash.clear(); bucket_off.clear(); bucket_reads.clear();
+  bucket_reads.reserve(keyed.size());
+  for (size_t i = 0; i < keyed.size(); i++) {
+    if (i == 0 || keyed[i].first != keyed[i - 1].first) { bucket_hash.push_back(keyed[i].first); bucket_off.push_back((int32_t)i); }
+    bucket_reads.push_back(keyed[i].second);
+  }
+  bucket_off.push_back((int32_t)keyed.size());
+}
+
+std::string ShortMate::window_string(const GraphStore& g, const Walk& w, int32_t* offset) const {
+  // first node of a multi-node window keeps only its last kTail bases, the last node only its
+  // first kTail (graph.cc:846-857)
+  std::string s;
+  *offset = 0;
+  for (size_t i = 0; i < w.size(); i++) {
+    const char* ns = g.seq(w[i]);
+    int32_t nl = g.len(w[i]);
+    if (i == 0 && w.size() > 1 && nl > kTail) { *offset = nl - kTail; s.append(ns + *offset, kTail); }
+    else if (i > 0 && nl > kTail && i + 1 == w.size()) s.append(ns, kTail);
+    else s.append(ns, nl);
+  }
+  return s;
+}
+
+static inline char comp(char c) {
+  switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return c; }
+}
+static void revcomp_into(const char* s, int32_t n, std::string& out) {
+  out.resize(n);
+  for (int32_t i = 0; i < n; i++) out[i] = comp(s[n - 1 - i]);
+}
+
+int32_t ShortMate::add_window(const Walk& w, std::vector<gaml_aligment>& recs) {
+  auto it = win_id.find(w);
+  if (it != win_id.end()) return it->second;  // re-alignment would give the same records
+  Window win;
+  win.first = (int64_t)pool.size();
+  win.count = (int32_t)recs.size();
+  for (auto& r : recs) win.max_pos = std::max(win.max_pos, r.position);
+  pool.insert(pool.end(), recs.begin(), recs.end());
+  int32_t id = (int32_t)wins.size();
+  wins.push_back(win);
+  win_id.emplace(w, id);
+  generation++;
+  return id;
+}
+
+int32_t ShortMate::align(const GraphStore& g, const Walk& w) {
+  int32_t existing = find(w);
+  if (existing >= 0) return existing;
+  int32_t offset = 0;
+  std::string ws = window_string(g, w, &offset), rc;
+  revcomp_into(ws.data(), (int32_t)ws.size(), rc);
+  const int32_t W = (int32_t)ws.size();
+
+  struct Hit { int32_t pos, edit, read, orient, order; };
+  std::vector<Hit> hits;
+  std::vector<std::pair<uint64_t, int32_t>> spans;
+  std::string rbuf;
+  int32_t order = 0;
+  for (int strand = 0; strand < 2; strand++) {
+    spans.clear();
+    span_maxima(strand == 0 ? ws.data() : rc.data(), W, index_read_len, spans);
+    for (auto& sp : spans) {
+      auto b = std::lower_bound(bucket_hash.begin(), bucket_hash.end(), sp.first);
+      if (b == bucket_hash.end() || *b != sp.first) continue;
+      size_t bi = b - bucket_hash.begin();
+      // seed start in the forward window string (graph.cc:866-872)
+      int32_t win_pos = strand == 0 ? sp.second - kSeed + 1 : W - (sp.second + 1);
+      for (int32_t k = bucket_off[bi]; k < bucket_off[bi + 1]; k++) {
+        int32_t rid = bucket_reads[k];
+        const char* rs = read(rid);
+        int32_t R = lens[rid];
+        if (strand == 1) { revcomp_into(rs, R, rbuf); rs = rbuf.data(); }
+        // first position of the read carrying the window's seed (graph.cc:873-879)
+        int32_t read_pos = -1;
+        for (int32_t i = 0; i + kSeed <= R; i++)
+          if (memcmp(rs + i, ws.data() + win_pos, kSeed) == 0) { read_pos = i; break; }
+        if (read_pos < 0) continue;  // cannot happen: the bucket key is a seed of this read
+        Extension e;
+        if (extend_seed(win_pos, read_pos, rs, R, ws.data(), W, &e))
+          hits.push_back(Hit{e.begin + 1 + offset, e.errs, rid, strand, order++});
+      }
+    }
+  }
+  // the reference collects into a set ordered by (position, read): the first alignment found for a
+  // key survives (graph.cc:841, 891, 895-897). Per read, its candidates are visited forward-strand
+  // spans first, then reverse -- the order used above.
+  std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) {
+    if (a.pos != b.pos) return a.pos < b.pos;
+    if (a.read != b.read) return a.read < b.read;
+    return a.order < b.order;
+  });
+  std::vector<gaml_aligment> recs;
+  recs.reserve(hits.size());
+  for (size_t i = 0; i < hits.size(); i++) {
+    if (i > 0 && hits[i].pos == hits[i - 1].pos && hits[i].read == hits[i - 1].read) continue;
+    recs.push_back(gaml_aligment{hits[i].pos, hits[i].edit, hits[i].read, hits[i].orient});
+  }
+  windows_aligned++;
+  return add_window(w, recs);
+}
+
+// ---------------------------------------------------------------------------------------
+// window registration
+// ---------------------------------------------------------------------------------------
+// junction window starting at index i of `p` (stops at a gap when stop_at_gap): node i plus
+// following nodes until more than kTail bases were added (graph.cc:453-469, 552-561)
+static int32_t junction(const GraphStore& g, const int32_t* p, int32_t n, int32_t i, bool stop_at_gap, Walk& w) {
+  w.clear();
+  w.push_back(p[i]);
+  int32_t tail = 0, end = i;
+  for (int32_t j = i + 1; j < n; j++) {
+    if (stop_at_gap && p[j] < 0) break;
+    tail += g.len(p[j]);
+    w.push_back(p[j]);
+    end = j;
+    if (tail > kTail) break;
+  }
+  return end;
+}
+
+static Walk inverted(const Walk& w) {  // InvertPath utility.h:28-38
+  Walk r(w.rbegin(), w.rend());
+  for (auto& x : r) if (x >= 0) x ^= 1;
+  return r;
+}
+
+void register_for_paths(const GraphStore& g, ShortMate& m, const std::vector<Walk>& paths) {
+  // PrecomputeAlignmentForPaths (graph.cc:447-493). `last_end` deliberately survives from one
+  // path to the next, as in the reference (:449).
+  int32_t last_end = -1;
+  Walk w;
+  for (const Walk& p : paths) {
+    const int32_t n = (int32_t)p.size();
+    for (int32_t i = 0; i < n; i++) {
+      if (p[i] < 0) continue;
+      int32_t end = junction(g, p.data(), n, i, true, w);
+      if (m.find(w) < 0 && (last_end != end || (w.size() == 1 && g.len(w[0]) > 150))) {
+        m.align(g, w);
+        m.align(g, inverted(w));
+      }
+      if (g.len(p[i]) > kTail) {
+        Walk one(1, p[i]);
+        if (m.find(one) < 0) { m.align(g, one); m.align(g, Walk(1, p[i] ^ 1)); }
+      }
+      last_end = end;
+    }
+  }
+}
+
+void register_for_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n) {
+  // GetSubpathsFromPath + the precompute that follows it (graph.cc:495-533, 538-542)
+  int32_t last_end = -1;
+  Walk w;
+  for (int32_t i = 0; i < n; i++) {
+    if (ctg[i] < 0) continue;
+    int32_t end = junction(g, ctg, n, i, true, w);
+    if (end != last_end && m.find(w) < 0) m.align(g, w);
+    last_end = end;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// occurrences
+// ---------------------------------------------------------------------------------------
+void occurrences_paired_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n, int32_t st,
+                               int32_t path, int32_t* rank, std::vector<Occ>& out) {
+  // GetPositionsOnlyPath (graph.cc:544-597). The reference drops a record when its path position
+  // is < max_pos - 5, where max_pos is the largest position kept at EARLIER nodes of this contig
+  // (never below 0). Because the largest record of a node is kept whenever any is, max_pos before
+  // node i equals max(0, max over earlier nodes of (node offset + largest record position of the
+  // node's cached windows)) -- a prefix maximum that needs no per-record state.
+  int32_t cur_pos = st, max_pos = 0;
+  Walk w;
+  for (int32_t i = 0; i < n; i++) {
+    junction(g, ctg, n, i, false, w);
+    int32_t node_max = INT_MIN;
+    int32_t ids[2] = {m.find(w), -1};
+    if (g.len(ctg[i]) > kTail && w.size() > 1) ids[1] = m.find(Walk(1, ctg[i]));
+    // (when the junction window IS the single node, the reference scans the same records twice;
+    //  the second pass rewrites identical values, so one occurrence is emitted.)
+    for (int32_t id : ids) {
+      if (id < 0) continue;  // not cached at this point: contributes nothing (graph.cc:571-573)
+      const Window& win = m.wins[id];
+      if (win.count == 0) continue;
+      out.push_back(Occ{id, cur_pos, (max_pos - 5) - cur_pos, path, (*rank)++});
+      node_max = std::max(node_max, win.max_pos);
+    }
+    if (node_max != INT_MIN) max_pos = std::max(max_pos, cur_pos + node_max);
+    cur_pos += g.len(ctg[i]);
+  }
+}
+
+void occurrences_single_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n, int32_t st,
+                               int32_t* rank, std::vector<Occ>& out) {
+  // AddPositions (graph.cc:611-647): junction windows only, no position filter; a window missing
+  // from the cache contributes nothing.
+  int32_t cur_pos = st;
+  Walk w;
+  for (int32_t i = 0; i < n; i++) {
+    junction(g, ctg, n, i, false, w);
+    int32_t id = m.find(w);
+    if (id >= 0 && m.wins[id].count > 0) out.push_back(Occ{id, cur_pos, INT_MIN / 2, 0, (*rank)++});
+    cur_pos += g.len(ctg[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// device tables
+// ---------------------------------------------------------------------------------------
+void build_read_major(const ShortMate& m, ReadMajor& out) {
+  const int64_t n = m.n_local();
+  std::vector<int32_t> cnt(n + 1, 0);
+  for (const auto& r : m.pool) cnt[r.read_id + 1]++;
+  std::vector<int64_t> start(n + 1, 0);
+  int64_t extras = 0;
+  for (int64_t i = 0; i < n; i++) { start[i] = extras; extras += cnt[i + 1] > 1 ? cnt[i + 1] - 1 : 0; }
+  out.first.assign(n, RecQuad{-1, 0, 0, 0});
+  out.extra.assign(extras, RecQuad{-1, 0, 0, 0});
+  std::vector<int32_t> seen(n, 0);
+  for (size_t wid = 0; wid < m.wins.size(); wid++) {
+    const Window& win = m.wins[wid];
+    for (int64_t k = win.first; k < win.first + win.count; k++) {
+      const gaml_aligment& r = m.pool[k];
+      RecQuad q{(int32_t)wid, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
+      int32_t s = seen[r.read_id]++;
+      if (s == 0) {
+        int32_t more = cnt[r.read_id + 1] - 1;
+        q.flags |= more << 9;  // extra_count in bits 9..31
+        q.link = (int32_t)start[r.read_id];
+        out.first[r.read_id] = q;
+      } else {
+        out.extra[start[r.read_id] + s - 1] = q;
+      }
+    }
+  }
+  out.total_records = (int64_t)m.pool.size();
+  out.built_generation = m.generation;
+}
+
+void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& out) {
+  out.direct.assign(n_windows, OccQuad{0, 0, -1, 0});
+  out.multi_off.assign(1, 0);
+  out.multi.clear();
+  std::vector<int32_t> cnt(n_windows, 0);
+  for (const Occ& o : occs) cnt[o.wid]++;
+  // windows with several occurrences get a list (in rank order, which is the order of `occs`)
+  std::vector<int32_t> slot(n_windows, -1);
+  for (const Occ& o : occs) {
+    if (cnt[o.wid] == 1) { out.direct[o.wid] = OccQuad{o.shift, o.min_pos, o.path, o.rank}; continue; }
+    if (slot[o.wid] < 0) {
+      slot[o.wid] = (int32_t)out.multi_off.size() - 1;
+      out.multi_off.push_back(out.multi_off.back() + cnt[o.wid]);
+      out.direct[o.wid] = OccQuad{0, 0, o.path, -(slot[o.wid] + 1)};
+      cnt[o.wid] = -cnt[o.wid];  // negative: running fill position follows
+    }
+  }
+  out.multi.resize(out.multi_off.back());
+  std::vector<int32_t> fill(out.multi_off.size(), 0);
+  for (const Occ& o : occs) {
+    if (slot[o.wid] < 0) continue;
+    int32_t s = slot[o.wid];
+    out.multi[out.multi_off[s] + fill[s]++] = OccQuad{o.shift, o.min_pos, o.path, o.rank};
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// FASTQ (graph.cc:1366-1415): 4 lines per record, name = first blank-separated token after
+// the first character; a repeated name overwrites the earlier read of that id.
+// ---------------------------------------------------------------------------------------
+bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t>& offs, std::string* err) {
+  std::ifstream f(file.c_str());
+  if (!f.is_open()) { if (err) *err = "cannot open reads file " + file; return false; }
+  std::unordered_map<std::string, int64_t> ids;
+  std::vector<std::string> reads;
+  std::string l, s;
+  while (std::getline(f, l)) {
+    std::string name = l.size() > 0 ? l.substr(1) : std::string();
+    size_t cut = name.find_first_of(" \t");
+    if (cut != std::string::npos) name.resize(cut);
+    std::getline(f, s);
+    auto it = ids.find(name);
+    if (it == ids.end()) { ids.emplace(name, (int64_t)reads.size()); reads.push_back(s); }
+    else reads[it->second] = s;
+    std::getline(f, l);
+    std::getline(f, l);
+  }
+  bases.clear();
+  offs.assign(1, 0);
+  for (auto& r : reads) { bases += r; offs.push_back((int64_t)bases.size()); }
+  return true;
+}
+
+}  // namespace gaml

@@ -1,0 +1,147 @@
+// host_model.h -- host side of libgaml_hip: flat data model for the assembly graph, the read
+// sets, the alignment-window cache and the per-evaluation window-occurrence tables that the
+// HIP kernels consume. Plain C++17, no HIP types: everything the GPU needs leaves this file as
+// POD arrays.
+//
+// Reference behaviour mirrored here (file:line under the reference tree):
+//   * which windows get aligned, and when           graph.cc:447-533
+//   * what a window's string is                     graph.cc:846-857
+//   * max-hash candidate lookup                     graph.cc:1243-1348
+//   * seed extension accept set / edit counts       graph.cc:730-837
+//   * how window records become path positions      graph.cc:535-649
+// The data structures are NOT the reference's (hash maps of vectors per call); see DESIGN.md.
+#pragma once
+#include <climits>
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/gaml_hip.h"
+
+namespace gaml {
+
+constexpr int kTail = 300;  // window tail length, kMinSubpathLength graph.cc:27
+constexpr int kSeed = 15;   // kIndexKmer graph.cc:33
+
+struct GraphStore {
+  std::string bases;
+  std::vector<int64_t> off;   // n+1
+  std::vector<int32_t> norm;  // normalize_map graph.h:247-266
+  int32_t n() const { return (int32_t)off.size() - 1; }
+  int32_t len(int32_t node) const { return (int32_t)(off[node + 1] - off[node]); }
+  const char* seq(int32_t node) const { return bases.data() + off[node]; }
+  void finish();
+  bool load_lastgraph(const std::string& file, std::string* err);
+};
+
+struct WalkHasher {
+  size_t operator()(const std::vector<int32_t>& w) const {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ w.size();
+    for (int32_t x : w) { h ^= (uint32_t)x; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+    return (size_t)h;
+  }
+};
+using Walk = std::vector<int32_t>;
+
+// One cached window: records live in ShortMate::pool[first, first+count), sorted by
+// (position, read_id) like the reference's per-window vector.
+struct Window {
+  int64_t first = 0;
+  int32_t count = 0;
+  int32_t max_pos = INT_MIN;  // largest record position (INT_MIN when empty)
+};
+
+// One occurrence of a window in the path set being scored.
+struct Occ {
+  int32_t wid;
+  int32_t shift;    // add to a record's window position to get the path position
+  int32_t min_pos;  // keep a record only if its window position >= min_pos (graph.cc:577)
+  int32_t path;     // index of the path (single-end: 0)
+  int32_t rank;     // order in which the reference would visit this occurrence
+};
+
+// reads of one FASTQ file = the reference's ReadSet (graph.h:344-442)
+struct ShortMate {
+  double match = 0, mismatch = 0;
+  std::vector<double> match_pow, mismatch_pow;  // pow tables graph.cc:1448-1453
+  int64_t n_global = 0;
+  int64_t lo = 0, hi = 0;                // shard: global read ids [lo, hi)
+  std::string bases;                     // shard reads, concatenated
+  std::vector<int64_t> roff;             // hi-lo+1
+  std::vector<int32_t> lens;             // per shard read
+  int32_t max_len = 0;
+  // flat max-hash index over the shard's reads
+  std::vector<uint64_t> bucket_hash;     // sorted unique
+  std::vector<int32_t> bucket_off;       // size+1
+  std::vector<int32_t> bucket_reads;     // local read ids, ascending inside a bucket
+  int32_t index_read_len = 0;            // length of the LAST indexed read (graph.cc:1286)
+  // window cache
+  std::unordered_map<Walk, int32_t, WalkHasher> win_id;
+  std::vector<Window> wins;
+  std::vector<gaml_aligment> pool;       // read_id = LOCAL id inside the shard
+  uint64_t generation = 0;               // bumped whenever a window is added
+  int64_t windows_aligned = 0;
+
+  int64_t n_local() const { return hi - lo; }
+  const char* read(int64_t local) const { return bases.data() + roff[local]; }
+  void set_reads(int64_t n_global_, int64_t lo_, int64_t hi_, const char* b, const int64_t* offs_global);
+  void build_index();
+  int32_t find(const Walk& w) const { auto it = win_id.find(w); return it == win_id.end() ? -1 : it->second; }
+  int32_t add_window(const Walk& w, std::vector<gaml_aligment>& recs_sorted_local);
+  // the library's own aligner (AlignSubpathInternal graph.cc:839-899)
+  int32_t align(const GraphStore& g, const Walk& w);
+  std::string window_string(const GraphStore& g, const Walk& w, int32_t* offset) const;
+};
+
+// seed extension; returns false when no alignment within 3+3 errors exists (ProcessHit semantics)
+struct Extension { int32_t errs, begin, end; };
+bool extend_seed(int32_t win_pos, int32_t read_pos, const char* read, int32_t rlen, const char* win, int32_t wlen,
+                 Extension* out);
+
+// sliding maximum of the seed code over read-length spans (graph.cc:1289-1323)
+void span_maxima(const char* s, int32_t n, int32_t read_len, std::vector<std::pair<uint64_t, int32_t>>& out);
+uint64_t read_max_hash(const char* s, int32_t n);  // graph.cc:1254-1269
+
+// window registration rules
+void register_for_paths(const GraphStore& g, ShortMate& m, const std::vector<Walk>& paths);  // graph.cc:447-493
+void register_for_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n);  // graph.cc:495-533, 538-542
+
+// occurrence lists
+// paired: contig at path coordinate `st` (GetPositionsOnlyPath graph.cc:544-597)
+void occurrences_paired_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n, int32_t st,
+                               int32_t path, int32_t* rank, std::vector<Occ>& out);
+// single: contig at absolute coordinate `st` (AddPositions graph.cc:611-647)
+void occurrences_single_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n, int32_t st,
+                               int32_t* rank, std::vector<Occ>& out);
+
+// read-major record table for the device: every shard read's records in (window id, index in
+// window) order. first[i] holds the read's first record (wid = -1 when it has none) plus the
+// count / start of its remaining records in extra[].
+struct RecQuad { int32_t wid, pos, flags, link; };  // flags = edit | orient<<8 | extra_count<<9 ; link = extra start
+struct ReadMajor {
+  std::vector<RecQuad> first;  // n_local
+  std::vector<RecQuad> extra;
+  uint64_t built_generation = ~0ull;
+  int64_t total_records = 0;
+};
+void build_read_major(const ShortMate& m, ReadMajor& out);
+
+// direct-mapped occurrence table for the device: one 16-B entry per window.
+//   path < 0            : the window does not occur in the current path set
+//   path >= 0, rank >= 0: exactly one occurrence, described by the entry
+//   rank < 0            : several; they are multi[multi_off[-rank-1] .. multi_off[-rank])
+struct OccQuad { int32_t shift, min_pos, path, rank; };
+struct OccTable {
+  std::vector<OccQuad> direct;      // per window
+  std::vector<int32_t> multi_off;
+  std::vector<OccQuad> multi;
+};
+void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& out);
+
+void split_contigs(const Walk& path, std::vector<std::pair<int32_t, int32_t>>& ctg_ranges, std::vector<int32_t>& gaps);
+int32_t walk_length(const GraphStore& g, const Walk& w);
+
+bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t>& offs, std::string* err);
+
+}  // namespace gaml

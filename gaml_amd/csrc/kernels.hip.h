@@ -1,0 +1,372 @@
+// kernels.hip.h -- hand-written gfx950 kernels of the GAML likelihood path.
+//
+// All three scorers are HBM/L2-streaming reductions (no MFMA: SURVEY.md 8d): one lane owns one
+// read (pair), loads its 16-B alignment records with coalesced dwordx4 loads from the READ-MAJOR
+// record table, resolves each record's window against the per-evaluation window-occurrence table
+// (a few KB..MB, L2 resident), accumulates the read's probability in f64, applies the reference's
+// per-read floor + log and reduces (sum of logs, floored reads) wave -> block -> grid inside the
+// same launch. f64 throughout, compiled with -ffp-contract=off so that products and sums round
+// exactly like the reference's scalar C++ (the per-read probabilities are bit-identical to the
+// oracle's; only log() and the order of the final sum differ).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gaml {
+
+constexpr int kBlock = 256;      // 4 waves of 64
+constexpr int kMaxBlocks = 2048; // 256 CUs x 8 blocks, grid-stride beyond (guide G11)
+
+struct MateView {
+  const int4* first;      // per read: {wid | -1, pos, edit | orient<<8 | extra_count<<9, extra_start}
+  const int4* extra;      // further records of reads that have more than one
+  const int4* occ;        // per window: {shift, min_pos, path | -1, rank | -(list+1)}
+  const int* multi_off;   // windows occurring several times: list bounds
+  const int4* multi;      //   ... and entries
+  const double* mism_pow; // mismatch_prob^e
+  const double* match_pow;// match_prob^k
+};
+
+struct PairedArgs {
+  MateView m[2];
+  const uint32_t* len12;     // L1 | L2<<16 per pair
+  const double* ins_tab;     // insert-size Gaussian for d in [0, ins_n) (graph.cc:1801-1804)
+  int ins_n;
+  double ins_mean, ins_sd;
+  const double* floor_tab;   // exp(c + k*s), s = L1+L2 (graph.cc:1506-1507), host libm
+  const double* logfloor_tab;// log(floor_tab[s]), host libm
+  const double* covthr_tab;  // exp(c + k*2*L2) indexed by L2 (graph.cc:1855-1857 quirk), or null
+  double two_T;              // 2 * total_len as double (graph.cc:1505)
+  int n;                     // pairs in this shard
+  double* probs;             // out: per-pair summed probability (ScoringState::probs)
+  uint32_t* cov_bits;        // coverage marks (only when penalty_constant > 0), else null
+  const int* path_base;      // bit offset of each path in cov_bits
+  double* part_sum;          // [gridDim.x]
+  int* part_zero;            // [gridDim.x]
+  unsigned* ticket;          // zero before first launch; the last block resets it
+  double* out;               // out[0] = sum of logs, out[1] = floored reads
+};
+
+__device__ __forceinline__ double insert_prob_dev(double len, double mean, double sd) {
+  // GetInsertProbability graph.cc:1593-1598 (device exp: <= 1 ulp from glibc)
+  double z = (len - mean) / sd;
+  double e = exp(-z * z / 2.0);
+  double c = sqrt(2 * 3.14159265358979323846) * sd;
+  return e / c;
+}
+
+struct Cand { int path, pos, edit, orient, rank, k; bool valid; };
+
+__device__ __forceinline__ Cand make_cand(const int4& r, const int4& o, int k) {
+  Cand c;
+  c.path = o.z; c.pos = r.y + o.x; c.edit = r.z & 0xff; c.orient = (r.z >> 8) & 1;
+  c.rank = o.w; c.k = k; c.valid = r.y >= o.y;
+  return c;
+}
+
+// visit every (record, occurrence) combination of one read of one mate, in (record, occurrence) order
+template <class F>
+__device__ __forceinline__ void for_each_cand(const MateView& v, const int4& r0, F f) {
+  const int cnt = 1 + (int)((unsigned)r0.z >> 9);
+  for (int k = 0; k < cnt; k++) {
+    int4 r = k == 0 ? r0 : v.extra[r0.w + k - 1];
+    if (r.x < 0) continue;
+    int4 o = v.occ[r.x];
+    if (o.z < 0) continue;  // window not part of the scored paths
+    if (o.w >= 0) {
+      f(make_cand(r, o, k));
+    } else {
+      const int s = -o.w - 1;
+      for (int q = v.multi_off[s]; q < v.multi_off[s + 1]; q++) f(make_cand(r, v.multi[q], k));
+    }
+  }
+}
+
+// The reference keeps, per path and read, one alignment per path position: a later record at the
+// same position overwrites the earlier one (graph.cc:583-592). "Later" = visited later = larger
+// (occurrence rank, record index). A candidate is live iff it is valid and no later valid
+// candidate of the same read/mate shares its (path, position).
+__device__ __forceinline__ bool is_live(const MateView& v, const int4& r0, const Cand& c) {
+  if (!c.valid) return false;
+  bool live = true;
+  for_each_cand(v, r0, [&](const Cand& d) {
+    if (d.valid && d.path == c.path && d.pos == c.pos && (d.rank > c.rank || (d.rank == c.rank && d.k > c.k))) live = false;
+  });
+  return live;
+}
+
+__device__ __forceinline__ void mark_bit(uint32_t* bits, int bit) {
+  atomicOr(&bits[bit >> 5], 1u << (bit & 31));
+}
+
+// one pair term (graph.cc:1858-1889); returns 0 when the orientation rule rejects the pair
+__device__ __forceinline__ double pair_term(const PairedArgs& a, const Cand& x, const Cand& y, int L1, int L2) {
+  if (x.orient == y.orient) return 0.0;
+  int dist;
+  if (x.pos < y.pos) {
+    if (x.orient != 0 || y.orient != 1) return 0.0;
+    dist = y.pos - x.pos + L2;
+  } else {
+    if (x.orient != 1 || y.orient != 0) return 0.0;
+    dist = x.pos - y.pos + L1;
+  }
+  double p1 = a.m[0].mism_pow[x.edit] * a.m[0].match_pow[L1 - x.edit];
+  double p2 = a.m[1].mism_pow[y.edit] * a.m[1].match_pow[L2 - y.edit];
+  double ip = (unsigned)dist < (unsigned)a.ins_n ? a.ins_tab[dist] : insert_prob_dev((double)dist, a.ins_mean, a.ins_sd);
+  double t = p1 * p2 * ip;
+  if (a.cov_bits && t > a.covthr_tab[L2]) {  // coverage events at both ends (use_all_to_cov, graph.cc:1883-1888)
+    int base = a.path_base[x.path];
+    mark_bit(a.cov_bits, base + max(x.pos, y.pos));
+    mark_bit(a.cov_bits, base + min(x.pos, y.pos));
+  }
+  return t;
+}
+
+// reads with several records and/or windows that occur several times
+__device__ __noinline__ double paired_general(const PairedArgs& a, const int4& r1, const int4& r2, int L1, int L2) {
+  double acc = 0.0;
+  for_each_cand(a.m[0], r1, [&](const Cand& x) {
+    if (!is_live(a.m[0], r1, x)) return;
+    for_each_cand(a.m[1], r2, [&](const Cand& y) {
+      if (y.path != x.path) return;
+      if (!is_live(a.m[1], r2, y)) return;
+      acc += pair_term(a, x, y, L1, L2);
+    });
+  });
+  return acc;
+}
+
+// wave (64 lanes) + block reduction of (double, int); result valid in thread 0
+__device__ __forceinline__ void block_reduce(double& s, int& z, double* sh_s, int* sh_z) {
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    z += __shfl_down(z, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sh_s[wave] = s; sh_z[wave] = z; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0; int tz = 0;
+    for (int w = 0; w < kBlock / 64; w++) { ts += sh_s[w]; tz += sh_z[w]; }
+    s = ts; z = tz;
+  }
+}
+
+// grid-level finish: every block publishes its partial; the last block to arrive sums all
+// partials in index order (deterministic), writes out[0..1] and resets the ticket.
+__device__ __forceinline__ void grid_finish(double s, int z, double* part_sum, int* part_zero, unsigned* ticket,
+                                            double* out, double* sh_s, int* sh_z) {
+  __shared__ bool is_last;
+  if (threadIdx.x == 0) {
+    part_sum[blockIdx.x] = s;
+    part_zero[blockIdx.x] = z;
+    __threadfence();  // release the partial at agent scope before taking a ticket
+    unsigned t = atomicAdd(ticket, 1u);
+    is_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();  // acquire side
+  double ts = 0; int tz = 0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += kBlock) {
+    ts += __builtin_nontemporal_load(&part_sum[b]);
+    tz += __builtin_nontemporal_load(&part_zero[b]);
+  }
+  __syncthreads();
+  block_reduce(ts, tz, sh_s, sh_z);
+  if (threadIdx.x == 0) {
+    out[0] = ts;
+    out[1] = (double)tz;
+    *ticket = 0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void paired_score_kernel(PairedArgs a) {
+  __shared__ double sh_s[kBlock / 64];
+  __shared__ int sh_z[kBlock / 64];
+  double lsum = 0.0;
+  int zeros = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) {
+    const int4 r1 = a.m[0].first[i];
+    const int4 r2 = a.m[1].first[i];
+    const uint32_t l12 = a.len12[i];
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    double acc = 0.0;
+    if (r1.x >= 0 && r2.x >= 0) {
+      const int4 o1 = a.m[0].occ[r1.x];
+      const int4 o2 = a.m[1].occ[r2.x];
+      const bool simple = (((unsigned)r1.z | (unsigned)r2.z) >> 9) == 0 && o1.w >= 0 && o2.w >= 0;
+      if (simple) {
+        // one record per mate, each window occurring at most once: no overwrite rule to apply
+        if (o1.z >= 0 && o1.z == o2.z && r1.y >= o1.y && r2.y >= o2.y)
+          acc = pair_term(a, make_cand(r1, o1, 0), make_cand(r2, o2, 0), L1, L2);
+      } else {
+        acc = paired_general(a, r1, r2, L1, L2);
+      }
+    }
+    a.probs[i] = acc;
+    // GetTotalProb (graph.cc:1504-1513)
+    const double p = acc / a.two_T;
+    const int s = L1 + L2;
+    if (p < a.floor_tab[s]) { zeros++; lsum += a.logfloor_tab[s]; }
+    else lsum += log(p);
+  }
+  block_reduce(lsum, zeros, sh_s, sh_z);
+  grid_finish(lsum, zeros, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
+}
+
+// ---------------------------------------------------------------------------------------
+// coverage penalty sweep (graph.cc:1893-1919) over the bitmap of marked path positions.
+// A marked position p (not itself a contig start) adds p - q to bad_bases, q = previous marked
+// position of the same path, when no contig start lies in (q, p], p - q > cov_move and
+// p - (contig start before p) > mean + 5 sd.
+// ---------------------------------------------------------------------------------------
+struct CovArgs {
+  const uint32_t* bits;
+  const int* path_base;     // [n_paths+1] bit offsets (multiples of 32)
+  const int* start_off;     // [n_paths+1] into starts
+  const int* starts;        // contig start positions (path coordinates), ascending per path
+  int n_paths;
+  int total_words;
+  double cov_move;
+  double far;               // insert_mean + 5*insert_std
+  unsigned long long* bad;  // out
+};
+
+__global__ __launch_bounds__(kBlock) void coverage_sweep_kernel(CovArgs a) {
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < a.total_words; w += gridDim.x * kBlock) {
+    uint32_t word = a.bits[w];
+    if (!word) continue;
+    // locate the path of this word (few paths: binary search)
+    int lo = 0, hi = a.n_paths - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (a.path_base[mid] <= w * 32) lo = mid; else hi = mid - 1; }
+    const int base = a.path_base[lo], base_word = base >> 5;
+    const int* st = a.starts + a.start_off[lo];
+    const int nst = a.start_off[lo + 1] - a.start_off[lo];
+    unsigned long long local = 0;
+    uint32_t rest = word;
+    while (rest) {
+      const int b = __ffs(rest) - 1;
+      rest &= rest - 1;
+      const int p = w * 32 + b - base;
+      // previous marked position q
+      int q = -1;
+      uint32_t below = word & ((1u << b) - 1);
+      if (below) q = w * 32 + (31 - __clz(below)) - base;
+      else {
+        for (int v = w - 1; v >= base_word; v--) {
+          uint32_t x = a.bits[v];
+          if (x) { q = v * 32 + (31 - __clz(x)) - base; break; }
+        }
+      }
+      if (q < 0) continue;  // previous event is the path start (type 1)
+      // largest contig start <= p
+      int l2 = 0, h2 = nst - 1;
+      while (l2 < h2) { int mid = (l2 + h2 + 1) >> 1; if (st[mid] <= p) l2 = mid; else h2 = mid - 1; }
+      const int lb = st[l2];
+      if (lb > q) continue;  // a contig start in (q, p]: previous event has type 1 (or p is a start)
+      if ((double)(p - q) > a.cov_move && (double)(p - lb) > a.far) local += (unsigned long long)(p - q);
+    }
+    if (local) atomicAdd(a.bad, local);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// single-end scorer (graph.cc:1650-1743): probs_i = sum over distinct absolute positions of
+// m^e * M^(L-e); later record at the same position overwrites (graph.cc:633-644).
+// ---------------------------------------------------------------------------------------
+struct SingleArgs {
+  MateView m;
+  const int* lens;
+  const double* floor_tab;     // exp(c + k*L)
+  const double* logfloor_tab;
+  double two_T;
+  int n;
+  double* probs;
+  double* part_sum; int* part_zero; unsigned* ticket; double* out;
+};
+
+__global__ __launch_bounds__(kBlock) void single_score_kernel(SingleArgs a) {
+  __shared__ double sh_s[kBlock / 64];
+  __shared__ int sh_z[kBlock / 64];
+  double lsum = 0.0;
+  int zeros = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) {
+    const int4 r0 = a.m.first[i];
+    const int L = a.lens[i];
+    double acc = 0.0;
+    if (r0.x >= 0) {
+      for_each_cand(a.m, r0, [&](const Cand& x) {
+        // positions are absolute here (path index * 1e6 folded into shift); all paths share one map
+        bool live = true;
+        for_each_cand(a.m, r0, [&](const Cand& d) {
+          if (d.pos == x.pos && (d.rank > x.rank || (d.rank == x.rank && d.k > x.k))) live = false;
+        });
+        if (live) acc += a.m.mism_pow[x.edit] * a.m.match_pow[L - x.edit];
+      });
+    }
+    a.probs[i] = acc;
+    const double p = acc / a.two_T;  // GetTotalProb single (graph.cc:1526-1534)
+    if (p < a.floor_tab[L]) { zeros++; lsum += a.logfloor_tab[L]; }
+    else lsum += log(p);
+  }
+  block_reduce(lsum, zeros, sh_s, sh_z);
+  grid_finish(lsum, zeros, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
+}
+
+// ---------------------------------------------------------------------------------------
+// PacBio scorer (graph.cc:3052-3088, 3223): per read log-sum-exp over its cached alignments,
+// each counted once per occurrence of its sub-walk in the scored paths; floor; sum.
+// One WAVE per read: lanes stride over the read's records (coalesced 8-B logprob loads),
+// each lane folds its share with the reference's pairwise rule max + log1p(exp(min-max)),
+// then the 64 partial values are combined by a butterfly of the same rule.
+// ---------------------------------------------------------------------------------------
+struct PacbioArgs {
+  const int* rec_off;        // [n+1] read-major CSR
+  const int* rec_walk;       // sub-walk id per record
+  const double* rec_logp;    // log probability per record
+  const int* walk_count;     // occurrences of each sub-walk in the scored paths
+  const int* lens;
+  double floor_a, floor_b;   // log(exp(min_prob_start)), log(exp(min_prob_per_base)) (graph.cc:3075-3076)
+  int n;
+  double* logprobs;          // out: per-read log probability (-inf when no alignment)
+  double* part_sum; int* part_zero; unsigned* ticket; double* out;
+};
+
+__device__ __forceinline__ double lse2(double a, double b) {  // logdouble operator+ (logdouble.hpp:37-47)
+  const double ninf = -__builtin_huge_val();
+  if (a == ninf) return b;
+  if (b == ninf) return a;
+  const double hi = fmax(a, b), lo = fmin(a, b);
+  return hi + log1p(exp(lo - hi));
+}
+
+__global__ __launch_bounds__(kBlock) void pacbio_score_kernel(PacbioArgs a) {
+  __shared__ double sh_s[kBlock / 64];
+  __shared__ int sh_z[kBlock / 64];
+  const int lane = threadIdx.x & 63;
+  const int wave_global = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kBlock) >> 6;
+  double lsum = 0.0;
+  int zeros = 0;
+  for (int i = wave_global; i < a.n; i += n_waves) {
+    const int b = a.rec_off[i], e = a.rec_off[i + 1];
+    double v = -__builtin_huge_val();
+    for (int k = b + lane; k < e; k += 64) {
+      const int c = a.walk_count[a.rec_walk[k]];
+      const double lp = a.rec_logp[k];
+      for (int t = 0; t < c; t++) v = lse2(v, lp);
+    }
+    for (int off = 32; off > 0; off >>= 1) v = lse2(v, __shfl_xor(v, off, 64));
+    if (lane == 0) {
+      a.logprobs[i] = v;
+      const double floor_lp = a.floor_a + a.floor_b * (double)a.lens[i];
+      if (v < floor_lp) { zeros++; v = floor_lp; }
+      lsum += v;
+    }
+  }
+  block_reduce(lsum, zeros, sh_s, sh_z);
+  grid_finish(lsum, zeros, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
+}
+
+}  // namespace gaml

@@ -1,0 +1,170 @@
+/* gaml_hip.h -- C ABI of libgaml_hip.so: the MI355X (gfx950) implementation of GAML's
+ * assembly-likelihood hot path.
+ *
+ * This is the drop-in boundary.  GAML has no plugin/FFI layer; the path sits behind the
+ * header-only class ProbCalculator (reference prob_calculator.h:37-124) whose CalcProb()
+ * calls the three per-read-set scorers of graph.cc.  A maintainer replaces
+ * prob_calculator.h by include/gaml_hip_prob_calculator.h; that
+ * header forwards to the functions below.  Plain C types only, caller-owned input
+ * buffers (copied during the call), library-owned host and device state, integer status
+ * returns (0 = ok, <0 = error, text via gaml_hip_last_error).  No exceptions cross.
+ *
+ * Every entry point cites the reference interface it replaces (file:line under the
+ * reference tree).  All citations: graph.cc / graph.h / gaml.cc / prob_calculator.h.
+ */
+#ifndef GAML_HIP_H_
+#define GAML_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gaml_hip_ctx gaml_hip_ctx; /* opaque: graph + read sets + device state */
+
+/* Aligment record, 4 x int32 = 16 B (reference graph.h:211-231). */
+typedef struct gaml_aligment {
+  int32_t position;    /* 1-based start inside the window's node string (graph.cc:890) */
+  int32_t edit_dist;
+  int32_t read_id;
+  int32_t orientation; /* 0 forward, 1 reverse complement */
+} gaml_aligment;
+
+/* PacbioAligment record (reference graph.h:516-535): 3 x int32 + logdouble (f64 log). */
+typedef struct gaml_pacbio_aligment {
+  int32_t position;
+  int32_t position_end;
+  int32_t read_id;
+  int32_t pad_;
+  double logprob;
+} gaml_pacbio_aligment;
+
+/* SingleReadConfig (prob_calculator.h:7-18) + the read set's error model (gaml.cc:812-813). */
+typedef struct gaml_single_cfg {
+  double penalty_constant;
+  double step;              /* penalty_step for single / pacbio (gaml.cc:818) */
+  double min_prob_per_base;
+  double min_prob_start;
+  double weight;
+  double mismatch_prob;     /* match_prob = 1 - 4*mismatch_prob */
+} gaml_single_cfg;
+
+/* PairedReadConfig (prob_calculator.h:20-35). step = insert_mean - penalty_step (gaml.cc:860). */
+typedef struct gaml_paired_cfg {
+  double penalty_constant;
+  double step;
+  double insert_mean;
+  double insert_std;
+  double min_prob_per_base;
+  double min_prob_start;
+  double weight;
+  double mismatch_prob;
+} gaml_paired_cfg;
+
+/* ---- life cycle ------------------------------------------------------------------- */
+/* device >= 0: HIP device ordinal (required for scoring). device = -1: host-only context:
+ * graph / read sets / window alignment / occurrence tables work, every scoring call fails
+ * with GAML_HIP_ENODEVICE (there is no CPU scoring path in this library). */
+int gaml_hip_create(gaml_hip_ctx** out, int device);
+void gaml_hip_destroy(gaml_hip_ctx* ctx);
+const char* gaml_hip_last_error(const gaml_hip_ctx* ctx);
+const char* gaml_hip_version(void);
+
+#define GAML_HIP_OK 0
+#define GAML_HIP_EINVAL (-1)
+#define GAML_HIP_ENODEVICE (-2)
+#define GAML_HIP_EHIP (-3)
+#define GAML_HIP_ESTATE (-4)
+
+/* ---- inputs ----------------------------------------------------------------------- */
+/* Graph node sequences, what Graph::nodes[i]->s holds after LoadGraph (graph.cc:52-106):
+ * n_nodes = 2 * velvet nodes, twin of i is i^1. bases = concatenation, offs[n_nodes+1]. */
+int gaml_hip_set_graph(gaml_hip_ctx* ctx, int32_t n_nodes, const char* bases, const int64_t* offs);
+/* Same, parsed from a Velvet LastGraph file by the library (graph.cc:52-106). */
+int gaml_hip_load_graph(gaml_hip_ctx* ctx, const char* lastgraph_file);
+
+/* Read sets. Returns the read-set handle (>= 0). Reads = concatenated bases + offs[n+1];
+ * what ReadSet::PreprocessReads + PrepareReadIndex leave in a ReadSet (graph.cc:1366-1415).
+ * Order of creation within a kind = order of ProbCalculator's constructor vectors. */
+int gaml_hip_add_single(gaml_hip_ctx* ctx, const gaml_single_cfg* cfg, int32_t n_reads,
+                        const char* bases, const int64_t* offs);
+int gaml_hip_add_paired(gaml_hip_ctx* ctx, const gaml_paired_cfg* cfg, int32_t n_pairs,
+                        const char* bases1, const int64_t* offs1, const char* bases2, const int64_t* offs2);
+/* PacBio: only read lengths are needed by the scoring side (graph.cc:3062-3088, graph.h:478-481). */
+int gaml_hip_add_pacbio(gaml_hip_ctx* ctx, const gaml_single_cfg* cfg, int32_t n_reads, const int32_t* read_lens);
+/* FASTQ-file variants (read ids by first appearance of the name, graph.h:410-420). */
+int gaml_hip_add_single_fastq(gaml_hip_ctx* ctx, const gaml_single_cfg* cfg, const char* fastq);
+int gaml_hip_add_paired_fastq(gaml_hip_ctx* ctx, const gaml_paired_cfg* cfg, const char* fastq1, const char* fastq2);
+int gaml_hip_add_pacbio_fastq(gaml_hip_ctx* ctx, const gaml_single_cfg* cfg, const char* fastq);
+
+/* Read sharding for multi-GPU runs (new design): this context keeps and
+ * scores only reads [n*rank/world, n*(rank+1)/world) of every read set. Call before adding
+ * read sets. Partial results are combined with gaml_hip_combine_partials. */
+int gaml_hip_set_shard(gaml_hip_ctx* ctx, int32_t rank, int32_t world);
+
+/* Alignment records computed outside the library (the reference's external-aligner branch
+ * graph.cc:924-1033 produces exactly these per sub-walk; BLASR output for PacBio,
+ * graph.cc:2776-2782). mate = 0/1 for paired sets, 0 otherwise. read_id is global. */
+int gaml_hip_put_window_records(gaml_hip_ctx* ctx, int readset, int mate, const int32_t* subpath, int32_t subpath_len,
+                                const gaml_aligment* recs, int64_t n);
+int gaml_hip_put_pacbio_records(gaml_hip_ctx* ctx, int readset, const int32_t* subpath, int32_t subpath_len,
+                                const gaml_pacbio_aligment* recs, int64_t n);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* ProbCalculator::CalcProb(paths, zeros, total_len) (prob_calculator.h:63-109):
+ * paths = flattened node ids (>= 0) / gaps (< 0), path_offs[n_paths+1].
+ * zeros_out: 2 ints per read set (low-probability reads, reads) in the reference's order:
+ * single sets, then paired, then pacbio, each in creation order. May be NULL.
+ * The value is a pure function of (paths, alignment-window cache): every call rescoring all
+ * reads from scratch on the GPU (= the reference evaluated with a fresh ScoringState). */
+int gaml_hip_calc_prob(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths,
+                       double* prob_out, int32_t* zeros_out, int32_t* total_len_out);
+
+/* Sharded form: per read set 4 doubles {sum of log-probabilities over this shard's reads,
+ * floored reads, bad_bases (valid on every rank), reads in shard}. After an all-reduce(sum)
+ * of elements 0, 1 and 3 (element 2 is replicated: take any rank's), gaml_hip_combine_partials
+ * gives CalcProb's value. n_sets = gaml_hip_num_readsets. */
+int gaml_hip_calc_partials(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths,
+                           double* partials_out /* 4 * n_sets */, int32_t* total_len_out);
+int gaml_hip_combine_partials(gaml_hip_ctx* ctx, const double* partials /* 4 * n_sets, reduced */,
+                              int32_t total_len, double* prob_out, int32_t* zeros_out);
+
+/* Device-resident form for callers that already own a HIP stream (e.g. torch): enqueue the
+ * whole evaluation on `stream` and leave the 4*n_sets partials in device memory at
+ * d_partials (f64). No host synchronisation. */
+int gaml_hip_calc_partials_async(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths,
+                                 void* d_partials, void* hip_stream, int32_t* total_len_out);
+
+/* ---- introspection (tests, bench, logging) ----------------------------------------- */
+int gaml_hip_num_readsets(const gaml_hip_ctx* ctx);
+int gaml_hip_readset_kind(const gaml_hip_ctx* ctx, int readset);   /* 0 single, 1 paired, 2 pacbio */
+int64_t gaml_hip_readset_reads(const gaml_hip_ctx* ctx, int readset); /* global read (pair) count */
+int32_t gaml_hip_num_nodes(const gaml_hip_ctx* ctx);
+int32_t gaml_hip_node_len(const gaml_hip_ctx* ctx, int32_t node);
+/* per-read values of the last evaluation of a read set: probs (linear; log for pacbio),
+ * n = reads in this shard. ScoringState::probs (graph.h:612-619) for paired sets. */
+int gaml_hip_read_probs(gaml_hip_ctx* ctx, int readset, double* out, int64_t n);
+/* bad_bases of the last evaluation (graph.cc:1893-1919 / 1701-1733 / 3226-3250). */
+int gaml_hip_bad_bases(gaml_hip_ctx* ctx, int readset, int64_t* out);
+/* alignment-window cache (aligment_cache_, graph.h:427): number of windows, and the sorted
+ * records of one window (returns count, -1 if the window is not cached). */
+int64_t gaml_hip_window_count(const gaml_hip_ctx* ctx, int readset, int mate);
+int64_t gaml_hip_window_records(gaml_hip_ctx* ctx, int readset, int mate, const int32_t* subpath, int32_t subpath_len,
+                                gaml_aligment* out, int64_t cap);
+/* force alignment of one window with the library's own aligner (AlignSubpathInternal graph.cc:839-899) */
+int64_t gaml_hip_align_window(gaml_hip_ctx* ctx, int readset, int mate, const int32_t* subpath, int32_t subpath_len);
+/* timing of the last scoring call, microseconds: [0] host preparation (window registration,
+ * alignment of new windows, occurrence tables), [1] H2D + kernels + D2H wall, [2] device time
+ * of the scoring kernels measured with HIP events on the library's stream (0 if events off). */
+int gaml_hip_last_timing(const gaml_hip_ctx* ctx, double* out3);
+/* enable/disable per-call HIP event timing of the kernels (default off). */
+int gaml_hip_set_event_timing(gaml_hip_ctx* ctx, int on);
+/* cumulative kernel statistics since the last reset: launches, total device microseconds
+ * (HIP events), algorithmic bytes streamed (SURVEY.md 8d accounting). */
+int gaml_hip_kernel_stats(gaml_hip_ctx* ctx, int reset, int64_t* launches, double* device_us, double* algo_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAML_HIP_H_ */

@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))  # oracle_py: the checker (tests only)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure both shared objects exist (product + oracle)."""
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "gaml_amd", "libgaml_hip.so")) or not os.path.exists(
+            os.path.join(ROOT, "oracle", "_build", "libgaml_oracle.so")):
+        ge.build()
+    return True
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)

@@ -1,0 +1,95 @@
+"""GPU parity of the paired-end scorer (through the C ABI) against the oracle."""
+import numpy as np
+import pytest
+
+from gaml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(G, n, seed, repeats=0, penalty=0.0, err=0.01, min_prob_per_base=-0.7, min_prob_start=-10.0):
+    from gaml_amd import api
+    import oracle_py as op
+    genome = synth.make_genome(G, seed)
+    if repeats:
+        genome = synth.plant_repeats(genome, repeats, 700, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed))
+    pr = synth.make_paired_reads(genome, n, 150, 300.0, 30.0, err, seed)
+    gb, go = g.packed()
+    b1, o1 = synth.pack_reads(pr.mate1)
+    b2, o2 = synth.pack_reads(pr.mate2)
+    ctx = api.Context(device=0)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_paired(api.paired_cfg(300.0, 30.0, penalty_constant=penalty, min_prob_per_base=min_prob_per_base,
+                                       min_prob_start=min_prob_start), b1, o1, b2, o2)
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    ors = orc.add_paired(b1, o1, b2, o2, 0.01, op.paired_cfg(300.0, 30.0, penalty_constant=penalty,
+                                                             min_prob_per_base=min_prob_per_base,
+                                                             min_prob_start=min_prob_start))
+    return g, ctx, rs, orc, ors
+
+
+def _check(ctx, rs, orc, ors, paths, rel_tol=1e-9):
+    got, zeros, tl = ctx.calc_prob(paths)
+    want, wzeros, wtl = orc.calc_prob(paths, fresh=True)
+    assert tl == wtl
+    assert zeros.tolist() == wzeros.tolist()
+    probs = ctx.read_probs(rs)
+    wprobs, wbad = orc.paired_probs(ors)
+    # per-read probabilities: same products, same tables; reads with one term are bit-identical,
+    # reads with several terms may differ in summation order (<= a few ulp)
+    np.testing.assert_allclose(probs, wprobs, rtol=4e-16, atol=0)
+    assert ctx.bad_bases(rs) == wbad or orc is None
+    assert abs(got - want) <= rel_tol * abs(want), (got, want)
+    return got, want
+
+
+def test_true_genome_one_walk():
+    g, ctx, rs, orc, ors = _setup(120_000, 6_000, 3)
+    _check(ctx, rs, orc, ors, [synth.genome_walk(g)])
+
+
+def test_singleton_start_state_and_back():
+    g, ctx, rs, orc, ors = _setup(120_000, 6_000, 4)
+    walk = synth.genome_walk(g)
+    singles = [[i] for i in walk if g.node_len(i) > 500]
+    a, _ = _check(ctx, rs, orc, ors, singles)
+    b, _ = _check(ctx, rs, orc, ors, [walk])
+    c, _ = _check(ctx, rs, orc, ors, singles)
+    assert a == c  # pure function of (paths, cache)
+
+
+def test_gaps_reversed_and_repeats():
+    g, ctx, rs, orc, ors = _setup(150_000, 8_000, 5, repeats=4)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 3
+    inv = [x ^ 1 for x in reversed(walk[k:2 * k])]
+    paths = [walk[:k] + [-137] + walk[k + 2:2 * k], inv, walk[2 * k:], walk[3:9]]  # gap, twin walk, duplicate nodes
+    _check(ctx, rs, orc, ors, paths)
+    _check(ctx, rs, orc, ors, [[]] + paths[:2])  # an empty path
+    _check(ctx, rs, orc, ors, [[-50] + walk[:k]])  # leading gap
+
+
+def test_coverage_penalty_bad_bases():
+    g, ctx, rs, orc, ors = _setup(150_000, 2_500, 6, penalty=0.0001)  # thin coverage -> uncovered stretches
+    walk = synth.genome_walk(g)
+    k = len(walk) // 2
+    for paths in ([walk], [walk[:k], walk[k:]], [walk[:k] + [-300] + walk[k + 4:]]):
+        got, zeros, tl = ctx.calc_prob(paths)
+        want, wzeros, wtl = orc.calc_prob(paths, fresh=True)
+        _, wbad = orc.paired_probs(ors)
+        assert ctx.bad_bases(rs) == wbad
+        assert wbad > 0
+        assert abs(got - want) <= 1e-9 * abs(want)
+
+
+def test_no_reads_align():
+    g, ctx, rs, orc, ors = _setup(60_000, 500, 7)
+    # a path of only short nodes: nothing aligns well -> every read floored
+    walk = synth.genome_walk(g)
+    paths = [[walk[1]]]
+    got, zeros, tl = ctx.calc_prob(paths)
+    want, wzeros, wtl = orc.calc_prob(paths, fresh=True)
+    assert zeros.tolist() == wzeros.tolist()
+    assert abs(got - want) <= 1e-12 * abs(want)
