@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s scored by the MI355X likelihood path (BASELINE.json metric).
+
+A STEP is one ProbCalculator::CalcProb over the whole resident read shard: host builds the
+window-occurrence tables for the path set, the GPU rescoring every read pair from scratch
+(paired_score_kernel), the value comes back to the host (CalcProb is a blocking call in the
+reference, gaml.cc:284). Consecutive steps score DIFFERENT path sets (the genome walk broken at
+rotating points, as simulated-annealing moves do) so nothing can be reused from the previous
+step; the alignment-window cache is warm (all windows aligned before the timed region), which
+is the "warm from-scratch" evaluation SURVEY.md 8d defines as what the kernels replace.
+
+N > 1: one process per GPU (torch.distributed / RCCL). Every rank holds its own shard of
+reads (weak scaling: 833,333 pairs per GPU), no data-path collective, one all-reduce(sum) of
+the 4 partial doubles per step.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def path_variants(walk, k=8):
+    """k path sets: the whole walk, and the walk broken in two at k-1 rotating points."""
+    out = [[list(walk)]]
+    n = len(walk)
+    for i in range(1, k):
+        cut = (n * i) // k
+        cut -= cut % 2  # keep the long/short alternation aligned
+        cut = max(1, min(n - 1, cut))
+        out.append([list(walk[:cut]), list(walk[cut:])])
+    return out
+
+
+def cpu_baseline(gb, go, b1, o1, b2, o2, sample_pairs, read_len, variants, budget_s=20.0):
+    """Oracle (CPU restatement of the reference, 1 thread) timed on a bounded sample of the same
+    workload: the first `sample_pairs` pairs against the full graph, warm from-scratch CalcProb
+    (fresh ScoringState, window cache hot)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    nb = sample_pairs * read_len
+    rs = orc.add_paired(b1[:nb], o1[:sample_pairs + 1], b2[:nb], o2[:sample_pairs + 1], 0.01, op.paired_cfg(300.0, 30.0))
+    t0 = time.time()
+    vals = [orc.calc_prob(v, fresh=True)[0] for v in variants]  # cold: aligns every window
+    cold_s = time.time() - t0
+    n_eval, t_warm = 0, 0.0
+    while t_warm < budget_s and n_eval < 4 * len(variants):
+        v = variants[n_eval % len(variants)]
+        t0 = time.time()
+        orc.calc_prob(v, fresh=True)
+        t_warm += time.time() - t0
+        n_eval += 1
+    reads_per_s = 2.0 * sample_pairs * n_eval / t_warm
+    return {"value": reads_per_s, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample_pairs} pairs of rank 0's reads vs the full graph, {n_eval} warm from-scratch "
+                      f"CalcProb calls ({t_warm:.1f} s); cold pass incl. window alignment {cold_s:.1f} s "
+                      f"({2.0 * sample_pairs * len(variants) / cold_s:.0f} reads/s)"}, vals, rs, orc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "tiny"])
+    ap.add_argument("--cpu-sample-pairs", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gaml_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    wl = synth.WORKLOADS[args.workload]
+    # same genome + graph on every rank; each rank draws its own reads (its shard of the N x larger read set)
+    genome = synth.make_genome(wl.genome_len, wl.seed)
+    g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
+    pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed + 1000 * rank)
+    gb, go = g.packed()
+    b1, o1 = synth.pack_reads(pr.mate1)
+    b2, o2 = synth.pack_reads(pr.mate2)
+    walk = synth.genome_walk(g)
+    variants = path_variants(walk)
+
+    ctx = api.Context(device=local_rank)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), b1, o1, b2, o2)
+    n_pairs_rank = wl.n_pairs
+
+    stream = torch.cuda.current_stream()
+    d_part = torch.zeros(4, dtype=torch.float64, device="cuda")
+
+    def step(paths):
+        tl = ctx.calc_partials_async(paths, d_part.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_reduce(d_part, op=dist.ReduceOp.SUM)
+        part = d_part.cpu().numpy()  # blocking: CalcProb returns a value
+        prob, zeros = ctx.combine_partials(part, tl)
+        return prob, zeros
+
+    # prime: align every window any variant needs (cold path, untimed), then warm-up steps
+    t0 = time.time()
+    vals = [step(v)[0] for v in variants]
+    prime_s = time.time() - t0
+    for i in range(args.warmup):
+        step(variants[i % len(variants)])
+
+    ctx.set_event_timing(True)
+    ctx.kernel_stats(reset=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(variants[i % len(variants)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ks = ctx.kernel_stats(reset=True)
+    ctx.set_event_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_reads = 2.0 * n_pairs_rank * world
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_reads * args.steps / elapsed
+        launches = max(1, ks["launches"])
+        kern_us = ks["device_us"] / launches
+        bytes_per_launch = ks["algo_bytes"] / launches
+        achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        out = {
+            "metric": "reads_per_sec_scored", "value": value, "unit": "reads/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl.name + f"; {n_pairs_rank} pairs per GPU, whole true genome as 1-2 walks, "
+                                             "8 rotating path sets, window cache warm", "pairs_per_gpu": n_pairs_rank,
+                       "genome_bp": wl.genome_len, "parallelism": f"reads sharded over {world} GPU(s), 1 all-reduce of 32 B/step"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "paired_score_kernel", "kernel_us": kern_us, "algo_bytes_per_launch": bytes_per_launch},
+            "log_likelihood": last[0], "prime_s": prime_s,
+        }
+        if not args.no_cpu_baseline:
+            sample = min(args.cpu_sample_pairs, n_pairs_rank)
+            cb, cpu_vals, _, _ = cpu_baseline(gb, go, b1, o1, b2, o2, sample, wl.read_len, variants)
+            out["cpu_baseline"] = cb
+            # log-likelihood delta vs the CPU reference restatement on the same sample of reads
+            c2 = api.Context(device=local_rank)
+            c2.set_graph(gb, go)
+            nb = sample * wl.read_len
+            c2.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), b1[:nb], o1[:sample + 1], b2[:nb], o2[:sample + 1])
+            gpu_vals = [c2.calc_prob(v)[0] for v in variants]
+            out["ll_max_rel_delta_vs_cpu"] = max(abs(a - b) / abs(b) for a, b in zip(gpu_vals, cpu_vals))
+            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,8 +65,8 @@ struct Reducer {  // per read set: partials + ticket + 2-double result
   DevBuf part_sum, part_zero, ticket, out;
   hipError_t init() {
     hipError_t e;
-    if ((e = part_sum.reserve(kMaxBlocks * sizeof(double))) != hipSuccess) return e;
-    if ((e = part_zero.reserve(kMaxBlocks * sizeof(int))) != hipSuccess) return e;
+    if ((e = part_sum.reserve((kMaxBlocks + kOvfBlocks) * sizeof(double))) != hipSuccess) return e;
+    if ((e = part_zero.reserve((kMaxBlocks + kOvfBlocks) * sizeof(int))) != hipSuccess) return e;
     if ((e = ticket.reserve(sizeof(unsigned))) != hipSuccess) return e;
     if ((e = out.reserve(4 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMemset(ticket.p, 0, sizeof(unsigned))) != hipSuccess) return e;
@@ -87,7 +87,9 @@ struct PairedSet {
   ShortMate mate[2];
   ReadMajor rm[2];
   MateDev dev[2];
-  DevBuf len12, probs, tabs, occ_arena, cov_bits, cov_meta, bad;
+  DevBuf len12, probs, tabs, occ_arena, cov_bits, cov_meta, bad, ovf_cnt, ovf_list;
+  std::vector<int32_t> slot_of_read, read_of_slot;  // device order of pairs (by record-count class)
+  int64_t class_count[4] = {0, 0, 0, 0};
   Reducer red;
   std::vector<double> ins_tab, floor_tab, logfloor_tab, covthr_tab;
   bool tabs_uploaded = false;
@@ -199,6 +201,21 @@ int stage_release(gaml_hip_ctx* c, Staging& s, int k, hipStream_t st) {
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// sum the elapsed time of every event pair recorded since the last collection (the stream
+// they were recorded on must have been synchronised by the caller)
+int collect_events(gaml_hip_ctx* c) {
+  c->t_kernel_us = 0;
+  for (size_t i = 0; i < c->ev_used; i++) {
+    float ms = 0;
+    HIP_TRY(c, hipEventSynchronize(c->ev_pool[i].second));
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+    c->t_kernel_us += ms * 1000.0;
+  }
+  c->stat_device_us += c->t_kernel_us;
+  c->ev_used = 0;
+  return 0;
+}
+
 int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
   if (c->ev_used == c->ev_pool.size()) {
     hipEvent_t a, b;
@@ -226,22 +243,23 @@ void pack_occ(const OccTable& t, const OccLayout& l, char* base) {
   if (!t.multi.empty()) memcpy(base + l.multi, t.multi.data(), t.multi.size() * sizeof(OccQuad));
 }
 
-int upload_mate(gaml_hip_ctx* c, const ShortMate& m, ReadMajor& rm, MateDev& d, hipStream_t st) {
+int upload_mate(gaml_hip_ctx* c, const ShortMate& m, ReadMajor& rm, MateDev& d, hipStream_t st,
+                const std::vector<int32_t>* slot_of_read = nullptr, bool force = false) {
   if (d.pow_n == 0) {
     d.pow_n = m.match_pow.size();
     HIP_TRY(c, d.pows.reserve(2 * d.pow_n * sizeof(double)));
     HIP_TRY(c, hipMemcpy(d.pows.p, m.mismatch_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d.pows.as<double>() + d.pow_n, m.match_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
   }
-  if (d.uploaded_generation == m.generation) return 0;
+  if (d.uploaded_generation == m.active_generation && !force) return 0;
   // the window cache changed: rebuild the read-major table (cold path) and upload it
-  build_read_major(m, rm);
+  build_read_major(m, slot_of_read, rm);
   HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old table
   HIP_TRY(c, d.first.reserve(std::max<size_t>(1, rm.first.size()) * sizeof(RecQuad)));
   HIP_TRY(c, d.extra.reserve(std::max<size_t>(1, rm.extra.size()) * sizeof(RecQuad)));
   if (!rm.first.empty()) HIP_TRY(c, hipMemcpy(d.first.p, rm.first.data(), rm.first.size() * sizeof(RecQuad), hipMemcpyHostToDevice));
   if (!rm.extra.empty()) HIP_TRY(c, hipMemcpy(d.extra.p, rm.extra.data(), rm.extra.size() * sizeof(RecQuad), hipMemcpyHostToDevice));
-  d.uploaded_generation = m.generation;
+  d.uploaded_generation = m.active_generation;
   return 0;
 }
 
@@ -299,12 +317,8 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
   HIP_TRY(c, up(s.floor_tab));
   HIP_TRY(c, up(s.logfloor_tab));
   HIP_TRY(c, up(s.covthr_tab));
-  // len12
   const int64_t n = s.mate[0].n_local();
-  std::vector<uint32_t> l12(n);
-  for (int64_t i = 0; i < n; i++) l12[i] = (uint32_t)s.mate[0].lens[i] | ((uint32_t)s.mate[1].lens[i] << 16);
   HIP_TRY(c, s.len12.reserve(std::max<size_t>(1, n) * sizeof(uint32_t)));
-  if (n) HIP_TRY(c, hipMemcpy(s.len12.p, l12.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
   HIP_TRY(c, s.probs.reserve(std::max<size_t>(1, n) * sizeof(double)));
   HIP_TRY(c, s.red.init());
   HIP_TRY(c, s.bad.reserve(sizeof(unsigned long long)));
@@ -315,6 +329,7 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
 
 struct PairedPrep {
   OccTable occ[2];
+  int64_t assembled_records = 0;  // records the reference would touch in GetPositionsOnlyPath
   std::vector<int32_t> path_base, start_off, starts;
   int32_t total_bits = 0;
 };
@@ -358,6 +373,8 @@ void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>&
   // the final window count
   build_occ_table(s.mate[0].wins.size(), occs[0], p.occ[0]);
   build_occ_table(s.mate[1].wins.size(), occs[1], p.occ[1]);
+  p.assembled_records = 0;
+  for (int mt = 0; mt < 2; mt++) for (const Occ& o : occs[mt]) p.assembled_records += s.mate[mt].wins[o.wid].count;
 }
 
 int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, int32_t total_len, hipStream_t st) {
@@ -365,8 +382,19 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   PairedPrep p;
   prepare_paired_host(c, s, paths, p);
   const double t_after_host = now_us();
-  for (int mt = 0; mt < 2; mt++)
-    if (int e = upload_mate(c, s.mate[mt], s.rm[mt], s.dev[mt], st)) return e;
+  if (s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation) {
+    // cold path: the cache of either mate changed -> new device order of the pairs, both tables rebuilt
+    pair_device_order(s.mate[0], s.mate[1], s.slot_of_read, s.read_of_slot, s.class_count);
+    for (int mt = 0; mt < 2; mt++)
+      if (int e = upload_mate(c, s.mate[mt], s.rm[mt], s.dev[mt], st, &s.slot_of_read, true)) return e;
+    const int64_t np = s.mate[0].n_local();
+    std::vector<uint32_t> l12(np);
+    for (int64_t j = 0; j < np; j++) {
+      const int32_t i = s.read_of_slot[j];
+      l12[j] = (uint32_t)s.mate[0].lens[i] | ((uint32_t)s.mate[1].lens[i] << 16);
+    }
+    if (np) HIP_TRY(c, hipMemcpy(s.len12.p, l12.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
 
   const bool cov = s.cfg.penalty_constant > 0;
   OccLayout l0 = layout_occ(p.occ[0], 0);
@@ -423,11 +451,27 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   a.part_zero = s.red.part_zero.as<int>();
   a.ticket = s.red.ticket.as<unsigned>();
   a.out = s.red.out.as<double>();
+  const int main_blocks = grid_for(n);
+  a.main_waves = main_blocks * (kBlock / 64);
+  a.ovf_cap = 64 * (int)((n + (int64_t)main_blocks * kBlock - 1) / ((int64_t)main_blocks * kBlock));
+  if (a.ovf_cap < 64) a.ovf_cap = 64;
+  {
+    const size_t need_cnt = (size_t)a.main_waves * sizeof(int), need_list = (size_t)a.main_waves * a.ovf_cap * sizeof(int);
+    if (need_cnt > s.ovf_cnt.cap || need_list > s.ovf_list.cap) {
+      HIP_TRY(c, hipStreamSynchronize(st));
+      HIP_TRY(c, s.ovf_cnt.reserve(need_cnt));
+      HIP_TRY(c, s.ovf_list.reserve(need_list));
+    }
+  }
+  a.ovf_cnt = s.ovf_cnt.as<int>();
+  a.ovf_list = s.ovf_list.as<int>();
 
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (c->event_timing) { if (int e = take_events(c, &ev)) return e; HIP_TRY(c, hipEventRecord(ev->first, st)); }
   if (n > 0) {
-    hipLaunchKernelGGL(paired_score_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(paired_score_kernel, dim3(main_blocks), dim3(kBlock), 0, st, a);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(paired_overflow_kernel, dim3(kOvfBlocks), dim3(kBlock), 0, st, a, main_blocks);
     HIP_TRY(c, hipGetLastError());
   } else {
     HIP_TRY(c, hipMemsetAsync(s.red.out.p, 0, 2 * sizeof(double), st));
@@ -448,7 +492,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   }
   if (ev) HIP_TRY(c, hipEventRecord(ev->second, st));
   // SURVEY.md 8d accounting: 16 B per record, 8 B read lengths, 8 B probability written, per pair
-  c->stat_algo_bytes += 16.0 * (double)(s.rm[0].total_records + s.rm[1].total_records) + 16.0 * (double)n;
+  c->stat_algo_bytes += 16.0 * (double)p.assembled_records + 16.0 * (double)n;
   c->stat_launches++;
   c->t_host_us += t_after_host;  // caller subtracts the start stamp
   return 0;
@@ -689,7 +733,6 @@ int evaluate(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t 
   pa.dst = (double*)d_partials;
   const double t0 = now_us();
   c->t_host_us = 0;
-  c->ev_used = 0;
   int k = 0;
   for (auto& h : order) {
     const double tk = now_us();
@@ -787,7 +830,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); }
-      s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->cov_meta.release(); s->bad.release();
+      s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->cov_meta.release(); s->bad.release(); s->ovf_cnt.release(); s->ovf_list.release();
       s->red.release(); s->bad_host.release(); drop_stage(s->stage);
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage); }
@@ -966,12 +1009,7 @@ int gaml_hip_calc_partials(gaml_hip_ctx* c, const int32_t* paths, const int64_t*
   c->t_dev_wall_us += now_us() - t0;
   memcpy(partials_out, c->packed_host.p, c->handles.size() * 4 * sizeof(double));
   c->t_kernel_us = 0;
-  for (size_t i = 0; i < c->ev_used; i++) {
-    float ms = 0;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
-    c->t_kernel_us += ms * 1000.0;
-  }
-  c->stat_device_us += c->t_kernel_us;
+  if (int e2 = collect_events(c)) return e2;
   // bookkeeping for gaml_hip_bad_bases
   auto order = scoring_order(c);
   for (size_t k = 0; k < order.size(); k++)
@@ -1019,8 +1057,13 @@ int gaml_hip_read_probs(gaml_hip_ctx* c, int rs, double* out, int64_t n) {
   if (!src) return fail(c, GAML_HIP_ESTATE, "read set not scored yet");
   if (n < have) return fail(c, GAML_HIP_EINVAL, "output too small");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipDeviceSynchronize());
   if (have) HIP_TRY(c, hipMemcpy(out, src, have * sizeof(double), hipMemcpyDeviceToHost));
+  if (h.kind == 1 && have) {  // device order -> read order
+    const auto& ros = c->paireds[h.idx]->read_of_slot;
+    std::vector<double> tmp(out, out + have);
+    for (int64_t j = 0; j < have; j++) out[ros[j]] = tmp[j];
+  }
   return (int)std::min<int64_t>(have, 0x7fffffff);
 }
 
@@ -1070,6 +1113,7 @@ int gaml_hip_set_event_timing(gaml_hip_ctx* c, int on) {
 }
 int gaml_hip_kernel_stats(gaml_hip_ctx* c, int reset, int64_t* launches, double* device_us, double* algo_bytes) {
   if (!c) return GAML_HIP_EINVAL;
+  if (c->device >= 0 && c->ev_used) { if (int e = collect_events(c)) return e; }  // async calls leave pairs pending
   if (launches) *launches = c->stat_launches;
   if (device_us) *device_us = c->stat_device_us;
   if (algo_bytes) *algo_bytes = c->stat_algo_bytes;

@@ -443,6 +443,7 @@ void occurrences_paired_contig(const GraphStore& g, ShortMate& m, const int32_t*
       if (id < 0) continue;  // not cached at this point: contributes nothing (graph.cc:571-573)
       const Window& win = m.wins[id];
       if (win.count == 0) continue;
+      m.activate(id);
       out.push_back(Occ{id, cur_pos, (max_pos - 5) - cur_pos, path, (*rank)++});
       node_max = std::max(node_max, win.max_pos);
     }
@@ -460,7 +461,7 @@ void occurrences_single_contig(const GraphStore& g, ShortMate& m, const int32_t*
   for (int32_t i = 0; i < n; i++) {
     junction(g, ctg, n, i, false, w);
     int32_t id = m.find(w);
-    if (id >= 0 && m.wins[id].count > 0) out.push_back(Occ{id, cur_pos, INT_MIN / 2, 0, (*rank)++});
+    if (id >= 0 && m.wins[id].count > 0) { m.activate(id); out.push_back(Occ{id, cur_pos, INT_MIN / 2, 0, (*rank)++}); }
     cur_pos += g.len(ctg[i]);
   }
 }
@@ -468,10 +469,30 @@ void occurrences_single_contig(const GraphStore& g, ShortMate& m, const int32_t*
 // ---------------------------------------------------------------------------------------
 // device tables
 // ---------------------------------------------------------------------------------------
-void build_read_major(const ShortMate& m, ReadMajor& out) {
+void pair_device_order(const ShortMate& a, const ShortMate& b, std::vector<int32_t>& slot_of_read,
+                       std::vector<int32_t>& read_of_slot, int64_t class_count[4]) {
+  const int64_t n = a.n_local();
+  std::vector<int32_t> k1(n, 0), k2(n, 0);
+  for (const Window& w : a.wins) if (w.active) for (int64_t k = w.first; k < w.first + w.count; k++) k1[a.pool[k].read_id]++;
+  for (const Window& w : b.wins) if (w.active) for (int64_t k = w.first; k < w.first + w.count; k++) k2[b.pool[k].read_id]++;
+  auto cls = [&](int64_t i) { int m = std::max(k1[i], k2[i]); return m <= 1 ? 0 : m <= 2 ? 1 : m <= 4 ? 2 : 3; };
+  int64_t start[5] = {0, 0, 0, 0, 0};
+  for (int64_t i = 0; i < n; i++) start[cls(i) + 1]++;
+  for (int c = 0; c < 4; c++) { class_count[c] = start[c + 1]; start[c + 1] += start[c]; }
+  slot_of_read.assign(n, 0);
+  read_of_slot.assign(n, 0);
+  for (int64_t i = 0; i < n; i++) {
+    int32_t s = (int32_t)start[cls(i)]++;
+    slot_of_read[i] = s;
+    read_of_slot[s] = (int32_t)i;
+  }
+}
+
+void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_read, ReadMajor& out) {
   const int64_t n = m.n_local();
+  auto slot = [&](int32_t read) { return slot_of_read ? (*slot_of_read)[read] : read; };
   std::vector<int32_t> cnt(n + 1, 0);
-  for (const auto& r : m.pool) cnt[r.read_id + 1]++;
+  for (const Window& w : m.wins) if (w.active) for (int64_t k = w.first; k < w.first + w.count; k++) cnt[slot(m.pool[k].read_id) + 1]++;
   std::vector<int64_t> start(n + 1, 0);
   int64_t extras = 0;
   for (int64_t i = 0; i < n; i++) { start[i] = extras; extras += cnt[i + 1] > 1 ? cnt[i + 1] - 1 : 0; }
@@ -480,22 +501,24 @@ void build_read_major(const ShortMate& m, ReadMajor& out) {
   std::vector<int32_t> seen(n, 0);
   for (size_t wid = 0; wid < m.wins.size(); wid++) {
     const Window& win = m.wins[wid];
+    if (!win.active) continue;
     for (int64_t k = win.first; k < win.first + win.count; k++) {
       const gaml_aligment& r = m.pool[k];
+      const int32_t at = slot(r.read_id);
       RecQuad q{(int32_t)wid, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
-      int32_t s = seen[r.read_id]++;
+      int32_t s = seen[at]++;
       if (s == 0) {
-        int32_t more = cnt[r.read_id + 1] - 1;
+        int32_t more = cnt[at + 1] - 1;
         q.flags |= more << 9;  // extra_count in bits 9..31
-        q.link = (int32_t)start[r.read_id];
-        out.first[r.read_id] = q;
+        q.link = (int32_t)start[at];
+        out.first[at] = q;
       } else {
-        out.extra[start[r.read_id] + s - 1] = q;
+        out.extra[start[at] + s - 1] = q;
       }
     }
   }
-  out.total_records = (int64_t)m.pool.size();
-  out.built_generation = m.generation;
+  out.total_records = m.active_records;
+  out.built_generation = m.active_generation;
 }
 
 void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& out) {

@@ -50,6 +50,7 @@ struct Window {
   int64_t first = 0;
   int32_t count = 0;
   int32_t max_pos = INT_MIN;  // largest record position (INT_MIN when empty)
+  bool active = false;        // has occurred in a scored path set: its records are on the device
 };
 
 // One occurrence of a window in the path set being scored.
@@ -81,7 +82,16 @@ struct ShortMate {
   std::vector<Window> wins;
   std::vector<gaml_aligment> pool;       // read_id = LOCAL id inside the shard
   uint64_t generation = 0;               // bumped whenever a window is added
+  uint64_t active_generation = 0;        // bumped whenever a window is activated (device table stale)
+  int64_t active_records = 0;            // records of activated windows
   int64_t windows_aligned = 0;
+  // The alignment cache also holds windows no scored path has used yet (the reference aligns the
+  // inverse of every junction window and the twin of every long node up front, graph.cc:474-481).
+  // Only windows that occurred in some scored path set are kept in the device record table.
+  void activate(int32_t wid) {
+    Window& w = wins[wid];
+    if (!w.active) { w.active = true; active_records += w.count; if (w.count) active_generation++; }
+  }
 
   int64_t n_local() const { return hi - lo; }
   const char* read(int64_t local) const { return bases.data() + roff[local]; }
@@ -125,7 +135,13 @@ struct ReadMajor {
   uint64_t built_generation = ~0ull;
   int64_t total_records = 0;
 };
-void build_read_major(const ShortMate& m, ReadMajor& out);
+// slot_of_read maps a local read id to its device slot (identity when null)
+void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_read, ReadMajor& out);
+// Device order of the pairs of a paired set: stable by record-count class so that the lanes of a
+// wave take the same code path: 0 = at most one record per mate, 1 = at most 2, 2 = at most 4,
+// 3 = more (goes to the overflow kernel).
+void pair_device_order(const ShortMate& a, const ShortMate& b, std::vector<int32_t>& slot_of_read,
+                       std::vector<int32_t>& read_of_slot, int64_t class_count[4]);
 
 // direct-mapped occurrence table for the device: one 16-B entry per window.
 //   path < 0            : the window does not occur in the current path set

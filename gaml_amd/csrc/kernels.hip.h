@@ -41,8 +41,12 @@ struct PairedArgs {
   double* probs;             // out: per-pair summed probability (ScoringState::probs)
   uint32_t* cov_bits;        // coverage marks (only when penalty_constant > 0), else null
   const int* path_base;      // bit offset of each path in cov_bits
-  double* part_sum;          // [gridDim.x]
-  int* part_zero;            // [gridDim.x]
+  int* ovf_cnt;              // per main-kernel wave: number of pairs it deferred to the overflow kernel
+  int* ovf_list;             // per main-kernel wave: ovf_cap slots (filled in lane order: deterministic)
+  int ovf_cap;
+  int main_waves;
+  double* part_sum;          // per-block partials: main kernel blocks, then overflow kernel blocks
+  int* part_zero;
   unsigned* ticket;          // zero before first launch; the last block resets it
   double* out;               // out[0] = sum of logs, out[1] = floored reads
 };
@@ -122,8 +126,9 @@ __device__ __forceinline__ double pair_term(const PairedArgs& a, const Cand& x, 
   return t;
 }
 
-// reads with several records and/or windows that occur several times
-__device__ __noinline__ double paired_general(const PairedArgs& a, const int4& r1, const int4& r2, int L1, int L2) {
+// reads with several records and/or windows that occur several times: fully general, one
+// thread, quadratic; only the last resort of the overflow kernel (more than kOvfCap candidates)
+__device__ __forceinline__ double paired_general(const PairedArgs& a, const int4& r1, const int4& r2, int L1, int L2) {
   double acc = 0.0;
   for_each_cand(a.m[0], r1, [&](const Cand& x) {
     if (!is_live(a.m[0], r1, x)) return;
@@ -152,14 +157,14 @@ __device__ __forceinline__ void block_reduce(double& s, int& z, double* sh_s, in
   }
 }
 
-// grid-level finish: every block publishes its partial; the last block to arrive sums all
-// partials in index order (deterministic), writes out[0..1] and resets the ticket.
-__device__ __forceinline__ void grid_finish(double s, int z, double* part_sum, int* part_zero, unsigned* ticket,
-                                            double* out, double* sh_s, int* sh_z) {
+// grid-level finish: every block publishes its partial; the last block to arrive sums
+// n_partials partials in index order (deterministic), writes out[0..1] and resets the ticket.
+__device__ __forceinline__ void grid_finish(double s, int z, int my_slot, int n_partials, double* part_sum, int* part_zero,
+                                            unsigned* ticket, double* out, double* sh_s, int* sh_z) {
   __shared__ bool is_last;
   if (threadIdx.x == 0) {
-    part_sum[blockIdx.x] = s;
-    part_zero[blockIdx.x] = z;
+    part_sum[my_slot] = s;
+    part_zero[my_slot] = z;
     __threadfence();  // release the partial at agent scope before taking a ticket
     unsigned t = atomicAdd(ticket, 1u);
     is_last = (t == gridDim.x - 1);
@@ -168,10 +173,7 @@ __device__ __forceinline__ void grid_finish(double s, int z, double* part_sum, i
   if (!is_last) return;
   __threadfence();  // acquire side
   double ts = 0; int tz = 0;
-  for (unsigned b = threadIdx.x; b < gridDim.x; b += kBlock) {
-    ts += __builtin_nontemporal_load(&part_sum[b]);
-    tz += __builtin_nontemporal_load(&part_zero[b]);
-  }
+  for (int b = threadIdx.x; b < n_partials; b += kBlock) { ts += part_sum[b]; tz += part_zero[b]; }
   __syncthreads();
   block_reduce(ts, tz, sh_s, sh_z);
   if (threadIdx.x == 0) {
@@ -181,38 +183,238 @@ __device__ __forceinline__ void grid_finish(double s, int z, double* part_sum, i
   }
 }
 
+// per-read floor + log (GetTotalProb graph.cc:1504-1513)
+__device__ __forceinline__ void finish_read(const PairedArgs& a, int i, double acc, int L1, int L2, double& lsum, int& zeros) {
+  a.probs[i] = acc;
+  const double p = acc / a.two_T;
+  const int s = L1 + L2;
+  if (p < a.floor_tab[s]) { zeros++; lsum += a.logfloor_tab[s]; }
+  else lsum += log(p);
+}
+
+// up to K records per mate held in registers (static indexing only)
+template <int K>
+struct RegCands {
+  int path[K], pos[K], ef[K], rank[K];
+  bool valid[K], live[K];
+};
+
+template <int K>
+__device__ __forceinline__ bool load_cands(const MateView& v, const int4& r0, RegCands<K>& c) {
+  const int cnt = r0.x < 0 ? 0 : 1 + (int)((unsigned)r0.z >> 9);
+  int4 r[K], o[K];
+  bool multi = false;
+#pragma unroll
+  for (int k = 0; k < K; k++) r[k] = (k == 0) ? r0 : (k < cnt ? v.extra[r0.w + k - 1] : make_int4(-1, 0, 0, 0));
+#pragma unroll
+  for (int k = 0; k < K; k++) o[k] = (k < cnt && r[k].x >= 0) ? v.occ[r[k].x] : make_int4(0, 0, -1, 0);
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    multi |= (o[k].z >= 0 && o[k].w < 0);
+    c.path[k] = o[k].z; c.pos[k] = r[k].y + o[k].x; c.ef[k] = r[k].z & 0x1ff; c.rank[k] = o[k].w;
+    c.valid[k] = (k < cnt) && o[k].z >= 0 && r[k].y >= o[k].y;
+  }
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    bool lv = c.valid[i];
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if (j != i) lv = lv && !(c.valid[j] && c.path[j] == c.path[i] && c.pos[j] == c.pos[i] &&
+                               (c.rank[j] > c.rank[i] || (c.rank[j] == c.rank[i] && j > i)));
+    c.live[i] = lv;
+  }
+  return multi;
+}
+
+template <int K>
+__device__ __forceinline__ double score_regs(const PairedArgs& a, const RegCands<K>& c1, const RegCands<K>& c2, int L1, int L2) {
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      if (c1.live[i] && c2.live[j] && c1.path[i] == c2.path[j]) {
+        Cand x, y;
+        x.path = c1.path[i]; x.pos = c1.pos[i]; x.edit = c1.ef[i] & 0xff; x.orient = c1.ef[i] >> 8;
+        y.path = c2.path[j]; y.pos = c2.pos[j]; y.edit = c2.ef[j] & 0xff; y.orient = c2.ef[j] >> 8;
+        acc += pair_term(a, x, y, L1, L2);
+      }
+    }
+  }
+  return acc;
+}
+
+// Main kernel: one lane per read pair, pairs pre-sorted by record-count class so that a wave is
+// homogeneous. Pairs that need more than 4 records per mate, or a window that occurs several
+// times in the path set, are appended to the overflow list for paired_overflow_kernel.
 __global__ __launch_bounds__(kBlock) void paired_score_kernel(PairedArgs a) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
   double lsum = 0.0;
   int zeros = 0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) {
+  const int lane = threadIdx.x & 63;
+  const int wave_id = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  int* my_list = a.ovf_list + (size_t)wave_id * a.ovf_cap;
+  int my_ovf = 0;  // wave-uniform
+  for (int base = blockIdx.x * kBlock; base < a.n; base += gridDim.x * kBlock) {  // block-uniform trip count
+    const int i = base + threadIdx.x;
+    const bool active = i < a.n;
+    int4 r1 = make_int4(-1, 0, 0, 0), r2 = make_int4(-1, 0, 0, 0);
+    uint32_t l12 = 0;
+    if (active) { r1 = a.m[0].first[i]; r2 = a.m[1].first[i]; l12 = a.len12[i]; }
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    double acc = 0.0;
+    bool defer = false;
+    if (r1.x >= 0 && r2.x >= 0) {
+      const int extra = (int)(((unsigned)r1.z | (unsigned)r2.z) >> 9);  // >0 iff some mate has >1 record
+      if (extra == 0) {
+        const int4 o1 = a.m[0].occ[r1.x];
+        const int4 o2 = a.m[1].occ[r2.x];
+        if (o1.z >= 0 && o2.z >= 0) {
+          if (o1.w < 0 || o2.w < 0) defer = true;
+          else if (o1.z == o2.z && r1.y >= o1.y && r2.y >= o2.y)
+            acc = pair_term(a, make_cand(r1, o1, 0), make_cand(r2, o2, 0), L1, L2);
+        }
+      } else {
+        const int c1 = 1 + (int)((unsigned)r1.z >> 9), c2 = 1 + (int)((unsigned)r2.z >> 9);
+        if (c1 > 4 || c2 > 4) defer = true;
+        else if (c1 <= 2 && c2 <= 2) {
+          RegCands<2> x, y;
+          bool m1 = load_cands<2>(a.m[0], r1, x), m2 = load_cands<2>(a.m[1], r2, y);
+          if (m1 || m2) defer = true; else acc = score_regs<2>(a, x, y, L1, L2);
+        } else {
+          RegCands<4> x, y;
+          bool m1 = load_cands<4>(a.m[0], r1, x), m2 = load_cands<4>(a.m[1], r2, y);
+          if (m1 || m2) defer = true; else acc = score_regs<4>(a, x, y, L1, L2);
+        }
+      }
+    }
+    // deferred pairs go to this wave's own list in lane order (no atomics: the list, and with it
+    // the overflow kernel's summation order, is the same in every run)
+    const unsigned long long dm = __ballot(defer);
+    if (defer) my_list[my_ovf + __popcll(dm & ((1ull << lane) - 1))] = i;
+    my_ovf += __popcll(dm);
+    if (active && !defer) finish_read(a, i, acc, L1, L2, lsum, zeros);
+  }
+  if (lane == 0) a.ovf_cnt[wave_id] = my_ovf;
+  block_reduce(lsum, zeros, sh_s, sh_z);
+  if (threadIdx.x == 0) { a.part_sum[blockIdx.x] = lsum; a.part_zero[blockIdx.x] = zeros; }
+}
+
+// Overflow kernel: one WAVE per deferred pair. The wave gathers every (record, occurrence)
+// candidate of both mates into LDS, settles the overwrite rule in parallel and spreads the
+// x * y pair terms over its lanes; deterministic lane-strided + butterfly summation.
+// Launched after paired_score_kernel on the same stream; its last block also folds the
+// per-block partials of both kernels into out[0..1] and resets the overflow counter.
+constexpr int kOvfCap = 128;     // candidates per mate held in LDS per wave
+constexpr int kOvfBlocks = 64;   // fixed grid: the overflow counts are only known on the device
+
+__device__ __forceinline__ int wave_gather(const MateView& v, const int4& r0, int4* lds, int lane) {
+  // returns the number of candidates, or -1 if they do not fit
+  const int cnt = r0.x < 0 ? 0 : 1 + (int)((unsigned)r0.z >> 9);
+  int total = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int k = base + lane;
+    int mine = 0;
+    int4 r = make_int4(-1, 0, 0, 0), o = make_int4(0, 0, -1, 0);
+    if (k < cnt) {
+      r = k == 0 ? r0 : v.extra[r0.w + k - 1];
+      if (r.x >= 0) o = v.occ[r.x];
+      if (o.z >= 0) mine = o.w >= 0 ? 1 : v.multi_off[-o.w] - v.multi_off[-o.w - 1];
+    }
+    // exclusive prefix sum of `mine` over the wave
+    int incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const int wave_total = __shfl(incl, 63, 64);
+    const int at = total + incl - mine;
+    if (total + wave_total > kOvfCap) return -1;
+    if (mine == 1 && o.w >= 0) {
+      lds[at] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | ((r.y >= o.y) ? 0x200 : 0), o.w);
+    } else if (mine > 0) {
+      const int s = -o.w - 1;
+      for (int q = 0; q < mine; q++) {
+        const int4 oo = v.multi[v.multi_off[s] + q];
+        lds[at + q] = make_int4(oo.z, r.y + oo.x, (r.z & 0x1ff) | ((r.y >= oo.y) ? 0x200 : 0), oo.w);
+      }
+    }
+    total += wave_total;
+  }
+  return total;
+}
+
+__global__ __launch_bounds__(kBlock) void paired_overflow_kernel(PairedArgs a, int main_blocks) {
+  __shared__ double sh_s[kBlock / 64];
+  __shared__ int sh_z[kBlock / 64];
+  __shared__ int4 cand[kBlock / 64][2][kOvfCap];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = blockIdx.x * (kBlock / 64) + wave;
+  const int n_waves = gridDim.x * (kBlock / 64);
+  double lsum = 0.0;
+  int zeros = 0;
+  // static assignment of main-kernel waves to overflow waves: deterministic order of work
+  for (int mw0 = wave_global; mw0 < a.main_waves; mw0 += 64 * n_waves) {
+   // 64 main-kernel waves per step: lane l looks at wave mw0 + l * n_waves
+   const int my_mw = mw0 + lane * n_waves;
+   const int my_cnt = my_mw < a.main_waves ? a.ovf_cnt[my_mw] : 0;
+   unsigned long long todo = __ballot(my_cnt > 0);
+   while (todo) {
+   const int src = __ffsll((long long)todo) - 1;
+   todo &= todo - 1;
+   const int count = __shfl(my_cnt, src, 64);
+   const int mw = mw0 + src * n_waves;
+   for (int item = 0; item < count; item++) {
+    const int i = a.ovf_list[(size_t)mw * a.ovf_cap + item];
     const int4 r1 = a.m[0].first[i];
     const int4 r2 = a.m[1].first[i];
     const uint32_t l12 = a.len12[i];
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    int4* c1 = cand[wave][0];
+    int4* c2 = cand[wave][1];
+    const int n1 = wave_gather(a.m[0], r1, c1, lane);
+    const int n2 = wave_gather(a.m[1], r2, c2, lane);
     double acc = 0.0;
-    if (r1.x >= 0 && r2.x >= 0) {
-      const int4 o1 = a.m[0].occ[r1.x];
-      const int4 o2 = a.m[1].occ[r2.x];
-      const bool simple = (((unsigned)r1.z | (unsigned)r2.z) >> 9) == 0 && o1.w >= 0 && o2.w >= 0;
-      if (simple) {
-        // one record per mate, each window occurring at most once: no overwrite rule to apply
-        if (o1.z >= 0 && o1.z == o2.z && r1.y >= o1.y && r2.y >= o2.y)
-          acc = pair_term(a, make_cand(r1, o1, 0), make_cand(r2, o2, 0), L1, L2);
-      } else {
-        acc = paired_general(a, r1, r2, L1, L2);
+    if (n1 < 0 || n2 < 0) {
+      if (lane == 0) acc = paired_general(a, r1, r2, L1, L2);
+    } else {
+      __builtin_amdgcn_wave_barrier();
+      // overwrite rule: candidate is live iff valid and no later-ranked valid twin (same path, pos)
+      for (int m = 0; m < 2; m++) {
+        int4* c = m == 0 ? c1 : c2;
+        const int n = m == 0 ? n1 : n2;
+        for (int x = lane; x < n; x += 64) {
+          int4 me = c[x];
+          bool live = (me.z & 0x200) != 0;
+          for (int y = 0; y < n && live; y++) {
+            const int4 ot = c[y];
+            if (y != x && (ot.z & 0x200) && ot.x == me.x && ot.y == me.y && (ot.w > me.w || (ot.w == me.w && y > x))) live = false;
+          }
+          if (live) me.z |= 0x400;
+          // every lane reads the 0x200 (valid) bit only; the live bit 0x400 is written once per slot
+          c[x].z = me.z;
+        }
       }
+      __builtin_amdgcn_wave_barrier();
+      const int pairs = n1 * n2;
+      for (int idx = lane; idx < pairs; idx += 64) {
+        const int4 xr = c1[idx / n2];
+        const int4 yr = c2[idx % n2];
+        if ((xr.z & 0x400) && (yr.z & 0x400) && xr.x == yr.x) {
+          Cand x, y;
+          x.path = xr.x; x.pos = xr.y; x.edit = xr.z & 0xff; x.orient = (xr.z >> 8) & 1;
+          y.path = yr.x; y.pos = yr.y; y.edit = yr.z & 0xff; y.orient = (yr.z >> 8) & 1;
+          acc += pair_term(a, x, y, L1, L2);
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      __builtin_amdgcn_wave_barrier();
     }
-    a.probs[i] = acc;
-    // GetTotalProb (graph.cc:1504-1513)
-    const double p = acc / a.two_T;
-    const int s = L1 + L2;
-    if (p < a.floor_tab[s]) { zeros++; lsum += a.logfloor_tab[s]; }
-    else lsum += log(p);
+    if (lane == 0) finish_read(a, i, acc, L1, L2, lsum, zeros);
+   }
+   }
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
-  grid_finish(lsum, zeros, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
+  // partial slots: [0, main_blocks) main kernel, then this kernel's blocks
+  grid_finish(lsum, zeros, main_blocks + blockIdx.x, main_blocks + gridDim.x, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -311,7 +513,7 @@ __global__ __launch_bounds__(kBlock) void single_score_kernel(SingleArgs a) {
     else lsum += log(p);
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
-  grid_finish(lsum, zeros, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
+  grid_finish(lsum, zeros, blockIdx.x, gridDim.x, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -366,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void pacbio_score_kernel(PacbioArgs a) {
     }
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
-  grid_finish(lsum, zeros, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
+  grid_finish(lsum, zeros, blockIdx.x, gridDim.x, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
 }
 
 }  // namespace gaml
