@@ -107,7 +107,7 @@ def main():
     walk = synth.genome_walk(g)
     variants = path_variants(walk)
 
-    ctx = api.Context(device=local_rank)
+    ctx = api.Context(device=local_rank, presharded=world)  # every rank hands over only its own reads
     ctx.set_graph(gb, go)
     rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), b1, o1, b2, o2)
     n_pairs_rank = wl.n_pairs
@@ -116,7 +116,13 @@ def main():
     d_part = torch.zeros(4, dtype=torch.float64, device="cuda")
 
     def step(paths):
-        tl = ctx.calc_partials_async(paths, d_part.data_ptr(), stream.cuda_stream)
+        pending, tl = ctx.eval_begin(paths)
+        if world > 1 and pending:
+            # cold path only: newly aligned windows -> all ranks exchange their largest record positions
+            mx = torch.from_numpy(ctx.eval_pending_maxpos().copy()).cuda()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            ctx.eval_apply_maxpos(mx.cpu().numpy())
+        ctx.eval_finish_async(d_part.data_ptr(), stream.cuda_stream)
         if world > 1:
             dist.all_reduce(d_part, op=dist.ReduceOp.SUM)
         part = d_part.cpu().numpy()  # blocking: CalcProb returns a value

@@ -77,12 +77,19 @@ def _load():
     L.gaml_hip_add_paired_fastq.argtypes = [vp, C.POINTER(PairedCfg), C.c_char_p, C.c_char_p]
     L.gaml_hip_add_pacbio_fastq.argtypes = [vp, C.POINTER(SingleCfg), C.c_char_p]
     L.gaml_hip_set_shard.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gaml_hip_set_presharded.argtypes = [vp, C.c_int32]
     L.gaml_hip_put_window_records.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
     L.gaml_hip_put_pacbio_records.argtypes = [vp, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
     L.gaml_hip_calc_prob.argtypes = [vp, _i32p, _i64p, C.c_int32, C.POINTER(C.c_double), _i32p, C.POINTER(C.c_int32)]
     L.gaml_hip_calc_partials.argtypes = [vp, _i32p, _i64p, C.c_int32, _f64p, C.POINTER(C.c_int32)]
     L.gaml_hip_combine_partials.argtypes = [vp, _f64p, C.c_int32, C.POINTER(C.c_double), _i32p]
     L.gaml_hip_calc_partials_async.argtypes = [vp, _i32p, _i64p, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
+    L.gaml_hip_eval_begin.argtypes = [vp, _i32p, _i64p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    L.gaml_hip_eval_pending_maxpos.argtypes = [vp, vp, C.c_int64]
+    L.gaml_hip_eval_pending_maxpos.restype = C.c_int64
+    L.gaml_hip_eval_apply_maxpos.argtypes = [vp, _i32p, C.c_int64]
+    L.gaml_hip_eval_finish.argtypes = [vp, _f64p]
+    L.gaml_hip_eval_finish_async.argtypes = [vp, vp, vp]
     L.gaml_hip_num_readsets.argtypes = [vp]
     L.gaml_hip_readset_kind.argtypes = [vp, C.c_int]
     L.gaml_hip_readset_reads.argtypes = [vp, C.c_int]
@@ -97,6 +104,11 @@ def _load():
     L.gaml_hip_window_records.restype = C.c_int64
     L.gaml_hip_align_window.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int32]
     L.gaml_hip_align_window.restype = C.c_int64
+    L.gaml_hip_debug_prepare.argtypes = [vp, _i32p, _i64p, C.c_int32]
+    L.gaml_hip_debug_occurrences.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int64]
+    L.gaml_hip_debug_occurrences.restype = C.c_int64
+    L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
+    L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_last_timing.argtypes = [vp, _f64p]
     L.gaml_hip_set_event_timing.argtypes = [vp, C.c_int]
     L.gaml_hip_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -126,7 +138,7 @@ def _flat(paths):
 class Context:
     """One graph + its read sets + their device state (one per process / GPU)."""
 
-    def __init__(self, device: int = 0, rank: int = 0, world: int = 1):
+    def __init__(self, device: int = 0, rank: int = 0, world: int = 1, presharded: int = 1):
         self._h = C.c_void_p()
         rc = _lib.gaml_hip_create(C.byref(self._h), device)
         if rc != OK:
@@ -134,6 +146,8 @@ class Context:
         self.device = device
         if world != 1:
             self._check(_lib.gaml_hip_set_shard(self._h, rank, world))
+        elif presharded != 1:
+            self._check(_lib.gaml_hip_set_presharded(self._h, presharded))
         self.rank, self.world = rank, world
 
     def close(self):
@@ -215,6 +229,31 @@ class Context:
                                                       C.c_void_p(stream_ptr), C.byref(tl)))
         return tl.value
 
+    # two-phase form (sharded contexts: exchange window maxima between begin and finish)
+    def eval_begin(self, paths):
+        flat, offs = _flat(paths)
+        pending, tl = C.c_int64(), C.c_int32()
+        self._check(_lib.gaml_hip_eval_begin(self._h, flat, offs, len(paths), C.byref(pending), C.byref(tl)))
+        return pending.value, tl.value
+
+    def eval_pending_maxpos(self) -> np.ndarray:
+        n = _lib.gaml_hip_eval_pending_maxpos(self._h, None, 0)
+        out = np.zeros(max(1, n), np.int32)
+        _lib.gaml_hip_eval_pending_maxpos(self._h, out.ctypes.data, n)
+        return out[:n]
+
+    def eval_apply_maxpos(self, reduced):
+        reduced = np.ascontiguousarray(reduced, np.int32)
+        self._check(_lib.gaml_hip_eval_apply_maxpos(self._h, reduced if reduced.size else np.zeros(1, np.int32), reduced.size))
+
+    def eval_finish(self):
+        part = np.zeros(4 * max(1, self.num_readsets()), np.float64)
+        self._check(_lib.gaml_hip_eval_finish(self._h, part))
+        return part.reshape(-1, 4)[: self.num_readsets()].copy()
+
+    def eval_finish_async(self, d_partials_ptr: int, stream_ptr: int = 0):
+        self._check(_lib.gaml_hip_eval_finish_async(self._h, C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))
+
     def combine_partials(self, partials, total_len):
         part = np.ascontiguousarray(partials, np.float64).reshape(-1)
         prob = C.c_double()
@@ -265,6 +304,29 @@ class Context:
     def align_window(self, rs, mate, walk) -> int:
         walk = np.ascontiguousarray(walk, np.int32)
         return _lib.gaml_hip_align_window(self._h, rs, mate, walk, len(walk))
+
+    def debug_prepare(self, paths):
+        flat, offs = _flat(paths)
+        self._check(_lib.gaml_hip_debug_prepare(self._h, flat, offs, len(paths)))
+
+    def debug_occurrences(self, rs, mate=0) -> np.ndarray:
+        n = _lib.gaml_hip_debug_occurrences(self._h, rs, mate, np.zeros(5, np.int32), 0)
+        out = np.zeros(5 * max(1, n), np.int32)
+        _lib.gaml_hip_debug_occurrences(self._h, rs, mate, out, n)
+        return out.reshape(-1, 5)[:n]
+
+    def debug_window_walk(self, rs, mate, wid) -> list:
+        buf = np.zeros(64, np.int32)
+        n = _lib.gaml_hip_debug_window_walk(self._h, rs, mate, wid, buf, 64)
+        if n > 64:
+            buf = np.zeros(n, np.int32)
+            _lib.gaml_hip_debug_window_walk(self._h, rs, mate, wid, buf, n)
+        return [int(x) for x in buf[:n]]
+
+    def debug_class_counts(self, rs):
+        out = np.zeros(4, np.int64)
+        self._check(_lib.gaml_hip_debug_class_counts(self._h, rs, out))
+        return out
 
     def last_timing(self):
         out = np.zeros(3, np.float64)

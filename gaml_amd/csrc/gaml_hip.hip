@@ -88,6 +88,7 @@ struct PairedSet {
   ReadMajor rm[2];
   MateDev dev[2];
   DevBuf len12, probs, tabs, occ_arena, cov_bits, cov_meta, bad, ovf_cnt, ovf_list;
+  std::vector<Occ> last_occ[2];
   std::vector<int32_t> slot_of_read, read_of_slot;  // device order of pairs (by record-count class)
   int64_t class_count[4] = {0, 0, 0, 0};
   Reducer red;
@@ -104,6 +105,7 @@ struct SingleSet {
   ReadMajor rm;
   MateDev dev;
   DevBuf lens, probs, tabs, occ_arena;
+  std::vector<Occ> last_occ;
   Reducer red;
   std::vector<double> floor_tab, logfloor_tab;
   bool tabs_uploaded = false;
@@ -126,6 +128,14 @@ struct PacbioSet {
   Staging stage;
 };
 
+struct PairedPrep {
+  std::vector<Placement> placements[2];  // pass 1
+  OccTable occ[2];
+  int64_t assembled_records = 0;  // records the reference would touch in GetPositionsOnlyPath
+  std::vector<int32_t> path_base, start_off, starts;
+  int32_t total_bits = 0;
+};
+
 struct SetRef { int kind, idx; };
 
 }  // namespace
@@ -140,6 +150,7 @@ struct gaml_hip_ctx {
   std::vector<std::unique_ptr<PacbioSet>> pacbios;
   std::vector<SetRef> handles;  // creation order -> (kind, index)
   int32_t rank = 0, world = 1;
+  int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;
   // timing
   bool event_timing = false;
@@ -150,6 +161,12 @@ struct gaml_hip_ctx {
   double stat_device_us = 0, stat_algo_bytes = 0;
   DevBuf packed;  // 4 doubles per read set
   PinBuf packed_host;
+  // evaluation in progress (between eval_begin and eval_finish)
+  bool pending_open = false;
+  std::vector<Walk> pending_paths;
+  int32_t pending_total_len = 0;
+  std::vector<std::unique_ptr<PairedPrep>> pending_prep;  // per paired set
+  double pending_host_us = 0;
 };
 
 namespace {
@@ -327,27 +344,22 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
   return 0;
 }
 
-struct PairedPrep {
-  OccTable occ[2];
-  int64_t assembled_records = 0;  // records the reference would touch in GetPositionsOnlyPath
-  std::vector<int32_t> path_base, start_off, starts;
-  int32_t total_bits = 0;
-};
 
-void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p) {
-  // 1. windows registered over the whole path set, per mate (graph.cc:1967-1968)
+// pass 1: window registration / alignment of missing windows and the placement of cached windows
+void prepare_paired_structure(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p) {
+  // windows registered over the whole path set, per mate (graph.cc:1967-1968)
   register_for_paths(c->g, s.mate[0], paths);
   register_for_paths(c->g, s.mate[1], paths);
-  // 2. per path, per contig: register the contig's windows, then read off which cached windows
-  //    sit where (graph.cc:1830-1844, in the reference's interleaving of the two mates)
-  std::vector<Occ> occs[2];
-  int32_t rank[2] = {0, 0};
+  // per path, per contig: register the contig's windows, then note which cached windows sit where
+  // (graph.cc:1830-1844, in the reference's interleaving of the two mates)
   std::vector<std::pair<int32_t, int32_t>> ranges;
   std::vector<int32_t> gaps;
   const bool cov = s.cfg.penalty_constant > 0;
+  p.placements[0].clear(); p.placements[1].clear();
   p.path_base.assign(1, 0);
   p.start_off.assign(1, 0);
   p.starts.clear();
+  int32_t contig_serial = 0;
   for (int32_t pi = 0; pi < (int32_t)paths.size(); pi++) {
     const Walk& path = paths[pi];
     split_contigs(path, ranges, gaps);
@@ -359,8 +371,9 @@ void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>&
       const int32_t n = ranges[ci].second - ranges[ci].first;
       for (int mt = 0; mt < 2; mt++) {
         register_for_contig(c->g, s.mate[mt], ctg, n);
-        occurrences_paired_contig(c->g, s.mate[mt], ctg, n, cur_len, pi, &rank[mt], occs[mt]);
+        placements_paired_contig(c->g, s.mate[mt], ctg, n, cur_len, pi, contig_serial, p.placements[mt]);
       }
+      contig_serial++;
       for (int32_t k = 0; k < n; k++) cur_len += c->g.len(ctg[k]);
     }
     p.start_off.push_back((int32_t)p.starts.size());
@@ -369,18 +382,30 @@ void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>&
     p.path_base.push_back(p.path_base.back() + (cov ? bits : 0));
   }
   p.total_bits = p.path_base.back();
-  // windows may have been added after an occurrence list entry was made; tables are sized to
-  // the final window count
+}
+
+// pass 2: position-filter thresholds (need the windows' global largest positions) + device tables
+void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
+  (void)c;
+  std::vector<Occ> occs[2];
+  for (int mt = 0; mt < 2; mt++) occurrences_from_placements(s.mate[mt], p.placements[mt], occs[mt]);
+  // tables are sized to the final window count
   build_occ_table(s.mate[0].wins.size(), occs[0], p.occ[0]);
   build_occ_table(s.mate[1].wins.size(), occs[1], p.occ[1]);
   p.assembled_records = 0;
   for (int mt = 0; mt < 2; mt++) for (const Occ& o : occs[mt]) p.assembled_records += s.mate[mt].wins[o.wid].count;
+  s.last_occ[0] = occs[0];
+  s.last_occ[1] = occs[1];
 }
 
-int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, int32_t total_len, hipStream_t st) {
+void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p) {
+  prepare_paired_structure(c, s, paths, p);
+  prepare_paired_tables_host(c, s, p);
+}
+
+int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p, int32_t total_len, hipStream_t st) {
   if (int e = prepare_paired_tables(c, s)) return e;
-  PairedPrep p;
-  prepare_paired_host(c, s, paths, p);
+  prepare_paired_tables_host(c, s, p);  // pass 2 (pass 1 ran in eval_begin)
   const double t_after_host = now_us();
   if (s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation) {
     // cold path: the cache of either mate changed -> new device order of the pairs, both tables rebuilt
@@ -501,6 +526,27 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
 // ---------------------------------------------------------------------------------------
 // single-end read set (CalcScoreForPaths graph.cc:1650-1743)
 // ---------------------------------------------------------------------------------------
+// host: per path (offset by 1,000,000 each, graph.cc:1685), per contig: register + occurrences
+int32_t prepare_single_host(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths, std::vector<Occ>& occs) {
+  int32_t rank = 0, tl = 0, stv = 0;
+  std::vector<std::pair<int32_t, int32_t>> ranges;
+  std::vector<int32_t> gaps;
+  for (const Walk& path : paths) {
+    split_contigs(path, ranges, gaps);
+    for (size_t ci = 0; ci < ranges.size(); ci++) {
+      if (ci > 0) tl += gaps[ci - 1];
+      const int32_t* ctg = path.data() + ranges[ci].first;
+      const int32_t n = ranges[ci].second - ranges[ci].first;
+      register_for_contig(c->g, s.mate, ctg, n);
+      occurrences_single_contig(c->g, s.mate, ctg, n, stv + tl, &rank, occs);
+      for (int32_t k = 0; k < n; k++) tl += c->g.len(ctg[k]);
+    }
+    stv += 1000000;
+  }
+  s.last_occ = occs;
+  return tl;
+}
+
 int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths, int32_t total_len, hipStream_t st) {
   if (!s.tabs_uploaded) {
     const int lmax = s.mate.max_len;
@@ -519,23 +565,8 @@ int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths,
     HIP_TRY(c, s.red.init());
     s.tabs_uploaded = true;
   }
-  // host: per path (offset by 1,000,000 each, graph.cc:1685), per contig: register + occurrences
   std::vector<Occ> occs;
-  int32_t rank = 0, tl = 0, stv = 0;
-  std::vector<std::pair<int32_t, int32_t>> ranges;
-  std::vector<int32_t> gaps;
-  for (const Walk& path : paths) {
-    split_contigs(path, ranges, gaps);
-    for (size_t ci = 0; ci < ranges.size(); ci++) {
-      if (ci > 0) tl += gaps[ci - 1];
-      const int32_t* ctg = path.data() + ranges[ci].first;
-      const int32_t n = ranges[ci].second - ranges[ci].first;
-      register_for_contig(c->g, s.mate, ctg, n);
-      occurrences_single_contig(c->g, s.mate, ctg, n, stv + tl, &rank, occs);
-      for (int32_t k = 0; k < n; k++) tl += c->g.len(ctg[k]);
-    }
-    stv += 1000000;
-  }
+  int32_t tl = prepare_single_host(c, s, paths, occs);
   (void)total_len;
   OccTable occ;
   build_occ_table(s.mate.wins.size(), occs, occ);
@@ -714,18 +745,53 @@ __global__ void pack_partials_kernel(PackArgs a) {
   a.dst[4 * i + 3] = a.n[i];
 }
 
-int evaluate(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t n_paths, void* d_partials,
-             hipStream_t st, int32_t* total_len_out) {
-  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
+std::vector<ShortMate*> filter_mates(gaml_hip_ctx* c) {  // mates whose windows feed a position filter, in handle order
+  std::vector<ShortMate*> v;
+  for (auto& h : c->handles)
+    if (h.kind == 1) { v.push_back(&c->paireds[h.idx]->mate[0]); v.push_back(&c->paireds[h.idx]->mate[1]); }
+  return v;
+}
+
+// phase 1: path checks, window registration/alignment, window placements. Returns (via *pending)
+// how many windows were added whose largest positions other shards have not seen yet.
+int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t n_paths, int64_t* pending) {
   if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
   if (n_paths < 0 || (n_paths > 0 && (!flat || !offs))) return fail(c, GAML_HIP_EINVAL, "bad path arguments");
-  std::vector<Walk> paths = unflatten(flat, offs, n_paths);
-  for (auto& p : paths)
+  const double t0 = now_us();
+  c->pending_paths = unflatten(flat, offs, n_paths);
+  for (auto& p : c->pending_paths)
     for (int32_t x : p)
       if (x >= c->g.n()) return fail(c, GAML_HIP_EINVAL, "path refers to a node outside the graph");
-  int32_t total_len = 0;
-  for (auto& p : paths) total_len += walk_length(c->g, p);  // GetTotalLen graph.cc:1775-1781
-  if (total_len_out) *total_len_out = total_len;
+  c->pending_total_len = 0;
+  for (auto& p : c->pending_paths) c->pending_total_len += walk_length(c->g, p);  // GetTotalLen graph.cc:1775-1781
+  c->pending_prep.clear();
+  c->pending_prep.resize(c->paireds.size());
+  for (size_t i = 0; i < c->paireds.size(); i++) {
+    c->pending_prep[i].reset(new PairedPrep());
+    prepare_paired_structure(c, *c->paireds[i], c->pending_paths, *c->pending_prep[i]);
+  }
+  int64_t n = 0;
+  for (ShortMate* m : filter_mates(c)) {
+    if (c->peers == 1) m->unsynced.clear();  // nothing to exchange: global == local
+    n += (int64_t)m->unsynced.size();
+  }
+  for (auto& s : c->singles) s->mate.unsynced.clear();  // single-end scoring has no position filter
+  if (pending) *pending = n;
+  c->pending_open = true;
+  c->pending_host_us = now_us() - t0;
+  return 0;
+}
+
+// phase 2: thresholds + device tables + launches; leaves 4 doubles per read set at d_partials
+int eval_finish(gaml_hip_ctx* c, void* d_partials, hipStream_t st) {
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
+  if (!c->pending_open) return fail(c, GAML_HIP_ESTATE, "no evaluation in progress");
+  for (ShortMate* m : filter_mates(c))
+    if (!m->unsynced.empty())
+      return fail(c, GAML_HIP_ESTATE, "sharded context: new windows were aligned; exchange their largest positions "
+                                      "(gaml_hip_eval_pending_maxpos -> all-reduce(max) -> gaml_hip_eval_apply_maxpos) before finishing");
+  const std::vector<Walk>& paths = c->pending_paths;
+  const int32_t total_len = c->pending_total_len;
   auto order = scoring_order(c);
   if (order.size() > 64) return fail(c, GAML_HIP_EINVAL, "more than 64 read sets");
   PackArgs pa;
@@ -744,7 +810,7 @@ int evaluate(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t 
       pa.out[k] = s.red.out.as<double>(); pa.n[k] = (double)s.mate.n_local();
     } else if (h.kind == 1) {
       PairedSet& s = *c->paireds[h.idx];
-      e = launch_paired(c, s, paths, total_len, st);
+      e = launch_paired(c, s, paths, *c->pending_prep[h.idx], total_len, st);
       pa.out[k] = s.red.out.as<double>(); pa.n[k] = (double)s.mate[0].n_local();
       if (s.cfg.penalty_constant > 0) pa.bad[k] = s.bad.as<unsigned long long>();
     } else {
@@ -762,7 +828,18 @@ int evaluate(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t 
     HIP_TRY(c, hipGetLastError());
   }
   c->t_dev_wall_us = now_us() - t0 - c->t_host_us;
+  c->t_host_us += c->pending_host_us;
+  c->pending_open = false;
   return 0;
+}
+
+int evaluate(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t n_paths, void* d_partials,
+             hipStream_t st, int32_t* total_len_out) {
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
+  int64_t pending = 0;
+  if (int e = eval_begin(c, flat, offs, n_paths, &pending)) return e;
+  if (total_len_out) *total_len_out = c->pending_total_len;
+  return eval_finish(c, d_partials, st);
 }
 
 int combine(gaml_hip_ctx* c, const double* partials, double* prob_out, int32_t* zeros_out, int32_t total_len) {
@@ -865,7 +942,14 @@ int gaml_hip_load_graph(gaml_hip_ctx* c, const char* file) {
 int gaml_hip_set_shard(gaml_hip_ctx* c, int32_t rank, int32_t world) {
   if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, GAML_HIP_EINVAL, "bad shard");
   if (!c->handles.empty()) return fail(c, GAML_HIP_ESTATE, "set the shard before adding read sets");
-  c->rank = rank; c->world = world;
+  c->rank = rank; c->world = world; c->peers = world;
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_set_presharded(gaml_hip_ctx* c, int32_t world) {
+  if (!c || world < 1) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->world != 1) return fail(c, GAML_HIP_ESTATE, "gaml_hip_set_shard already partitions this context's reads");
+  c->peers = world;
   return GAML_HIP_OK;
 }
 
@@ -986,6 +1070,57 @@ int gaml_hip_put_pacbio_records(gaml_hip_ctx* c, int readset, const int32_t* sub
   return GAML_HIP_OK;
 }
 
+int gaml_hip_eval_begin(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths, int64_t* pending_out,
+                        int32_t* total_len_out) {
+  if (!c) return GAML_HIP_EINVAL;
+  int e = eval_begin(c, paths, offs, n_paths, pending_out);
+  if (!e && total_len_out) *total_len_out = c->pending_total_len;
+  return e;
+}
+
+int64_t gaml_hip_eval_pending_maxpos(gaml_hip_ctx* c, int32_t* out, int64_t cap) {
+  if (!c) return -1;
+  int64_t n = 0;
+  for (ShortMate* m : filter_mates(c))
+    for (int32_t wid : m->unsynced) { if (out && n < cap) out[n] = m->wins[wid].max_pos; n++; }
+  return n;
+}
+
+int gaml_hip_eval_apply_maxpos(gaml_hip_ctx* c, const int32_t* reduced, int64_t n) {
+  if (!c || (n > 0 && !reduced)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  int64_t have = 0;
+  for (ShortMate* m : filter_mates(c)) have += (int64_t)m->unsynced.size();
+  if (have != n) return fail(c, GAML_HIP_EINVAL, "count does not match gaml_hip_eval_pending_maxpos");
+  int64_t k = 0;
+  for (ShortMate* m : filter_mates(c)) {
+    for (int32_t wid : m->unsynced) {
+      if (reduced[k] < m->wins[wid].max_pos) return fail(c, GAML_HIP_EINVAL, "reduced maximum below the local one: not an all-reduce(max)?");
+      m->wins[wid].global_max_pos = reduced[k++];
+    }
+    m->unsynced.clear();
+  }
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_eval_finish_async(gaml_hip_ctx* c, void* d_partials, void* stream) {
+  if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
+  return eval_finish(c, d_partials, stream ? (hipStream_t)stream : c->stream);
+}
+
+static int fetch_partials(gaml_hip_ctx* c, double* partials_out);
+
+int gaml_hip_eval_finish(gaml_hip_ctx* c, double* partials_out) {
+  if (!c || !partials_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t bytes = std::max<size_t>(1, c->handles.size()) * 4 * sizeof(double);
+  HIP_TRY(c, c->packed.reserve(bytes));
+  HIP_TRY(c, c->packed_host.reserve(bytes));
+  if (int e = eval_finish(c, c->packed.p, c->stream)) return e;
+  return fetch_partials(c, partials_out);
+}
+
 int gaml_hip_calc_partials_async(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths,
                                  void* d_partials, void* stream, int32_t* total_len_out) {
   if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
@@ -1003,6 +1138,11 @@ int gaml_hip_calc_partials(gaml_hip_ctx* c, const int32_t* paths, const int64_t*
   HIP_TRY(c, c->packed_host.reserve(bytes));
   int e = evaluate(c, paths, offs, n_paths, c->packed.p, c->stream, total_len_out);
   if (e) return e;
+  return fetch_partials(c, partials_out);
+}
+
+static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
+  const size_t bytes = std::max<size_t>(1, c->handles.size()) * 4 * sizeof(double);
   const double t0 = now_us();
   HIP_TRY(c, hipMemcpyAsync(c->packed_host.p, c->packed.p, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1099,6 +1239,48 @@ int64_t gaml_hip_align_window(gaml_hip_ctx* c, int rs, int mate, const int32_t* 
   if (!m || !subpath || len <= 0 || !c->have_graph) return -2;
   int32_t id = m->align(c->g, Walk(subpath, subpath + len));
   return m->wins[id].count;
+}
+
+int gaml_hip_debug_prepare(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t n_paths) {
+  if (!c || n_paths < 0 || (n_paths > 0 && (!flat || !offs))) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
+  std::vector<Walk> paths = unflatten(flat, offs, n_paths);
+  for (auto& h : scoring_order(c)) {
+    if (h.kind == 0) { std::vector<Occ> occs; prepare_single_host(c, *c->singles[h.idx], paths, occs); }
+    else if (h.kind == 1) { PairedPrep p; prepare_paired_host(c, *c->paireds[h.idx], paths, p); }
+  }
+  if (c->peers == 1) {
+    for (ShortMate* m : filter_mates(c)) m->unsynced.clear();
+  }
+  return GAML_HIP_OK;
+}
+
+int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* c, int rs, int mate, int32_t* out5, int64_t cap) {
+  if (!c || rs < 0 || rs >= (int)c->handles.size()) return -1;
+  SetRef h = c->handles[rs];
+  const std::vector<Occ>* v = nullptr;
+  if (h.kind == 0) v = &c->singles[h.idx]->last_occ;
+  else if (h.kind == 1 && (mate == 0 || mate == 1)) v = &c->paireds[h.idx]->last_occ[mate];
+  if (!v) return -1;
+  for (int64_t i = 0; i < (int64_t)v->size() && i < cap; i++) {
+    const Occ& o = (*v)[i];
+    out5[5 * i] = o.wid; out5[5 * i + 1] = o.shift; out5[5 * i + 2] = o.min_pos; out5[5 * i + 3] = o.path; out5[5 * i + 4] = o.rank;
+  }
+  return (int64_t)v->size();
+}
+
+int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wid, int32_t* out, int32_t cap) {
+  ShortMate* m = mate_of(c, rs, mate);
+  if (!m || wid < 0 || wid >= (int32_t)m->win_walk.size()) return -1;
+  const Walk& w = *m->win_walk[wid];
+  for (int32_t i = 0; i < (int32_t)w.size() && i < cap; i++) out[i] = w[i];
+  return (int32_t)w.size();
+}
+
+int gaml_hip_debug_class_counts(gaml_hip_ctx* c, int rs, int64_t* out4) {
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out4) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  for (int k = 0; k < 4; k++) out4[k] = c->paireds[c->handles[rs].idx]->class_count[k];
+  return GAML_HIP_OK;
 }
 
 int gaml_hip_last_timing(const gaml_hip_ctx* c, double* out3) {

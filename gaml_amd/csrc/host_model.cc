@@ -296,10 +296,13 @@ int32_t ShortMate::add_window(const Walk& w, std::vector<gaml_aligment>& recs) {
   win.first = (int64_t)pool.size();
   win.count = (int32_t)recs.size();
   for (auto& r : recs) win.max_pos = std::max(win.max_pos, r.position);
+  win.global_max_pos = win.max_pos;
   pool.insert(pool.end(), recs.begin(), recs.end());
   int32_t id = (int32_t)wins.size();
+  unsynced.push_back(id);
   wins.push_back(win);
-  win_id.emplace(w, id);
+  auto ins = win_id.emplace(w, id);
+  win_walk.push_back(&ins.first->first);
   generation++;
   return id;
 }
@@ -423,32 +426,46 @@ void register_for_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, 
 // ---------------------------------------------------------------------------------------
 // occurrences
 // ---------------------------------------------------------------------------------------
-void occurrences_paired_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n, int32_t st,
-                               int32_t path, int32_t* rank, std::vector<Occ>& out) {
-  // GetPositionsOnlyPath (graph.cc:544-597). The reference drops a record when its path position
-  // is < max_pos - 5, where max_pos is the largest position kept at EARLIER nodes of this contig
-  // (never below 0). Because the largest record of a node is kept whenever any is, max_pos before
-  // node i equals max(0, max over earlier nodes of (node offset + largest record position of the
-  // node's cached windows)) -- a prefix maximum that needs no per-record state.
-  int32_t cur_pos = st, max_pos = 0;
+void placements_paired_contig(const GraphStore& g, const ShortMate& m, const int32_t* ctg, int32_t n, int32_t st,
+                              int32_t path, int32_t contig_serial, std::vector<Placement>& out) {
+  // GetPositionsOnlyPath (graph.cc:544-573): node i looks up its junction window and, when the node
+  // is longer than kTail, its single-node window. A window that is not cached at this moment
+  // contributes nothing (graph.cc:571-573). When the junction window IS the single node, the
+  // reference scans the same records twice; the second pass rewrites identical values, so one
+  // placement is recorded.
+  int32_t cur_pos = st;
   Walk w;
   for (int32_t i = 0; i < n; i++) {
     junction(g, ctg, n, i, false, w);
-    int32_t node_max = INT_MIN;
     int32_t ids[2] = {m.find(w), -1};
     if (g.len(ctg[i]) > kTail && w.size() > 1) ids[1] = m.find(Walk(1, ctg[i]));
-    // (when the junction window IS the single node, the reference scans the same records twice;
-    //  the second pass rewrites identical values, so one occurrence is emitted.)
-    for (int32_t id : ids) {
-      if (id < 0) continue;  // not cached at this point: contributes nothing (graph.cc:571-573)
-      const Window& win = m.wins[id];
-      if (win.count == 0) continue;
-      m.activate(id);
-      out.push_back(Occ{id, cur_pos, (max_pos - 5) - cur_pos, path, (*rank)++});
-      node_max = std::max(node_max, win.max_pos);
-    }
-    if (node_max != INT_MIN) max_pos = std::max(max_pos, cur_pos + node_max);
+    for (int32_t id : ids)
+      if (id >= 0) out.push_back(Placement{id, cur_pos, path, contig_serial, i});
     cur_pos += g.len(ctg[i]);
+  }
+}
+
+void occurrences_from_placements(ShortMate& m, const std::vector<Placement>& pl, std::vector<Occ>& out) {
+  // The reference drops a record when its path position is < max_pos - 5 (graph.cc:577), max_pos
+  // being the largest position kept at EARLIER nodes of the contig (never below 0, reset per
+  // contig). Because the largest record of a node is kept whenever any record of the node is,
+  // max_pos before node i equals max(0, max over earlier nodes of (node offset + largest record
+  // position over the node's cached windows)): a prefix maximum that needs no per-record state --
+  // and, in a sharded run, the largest position over ALL shards (Window::global_max_pos).
+  int32_t rank = 0, max_pos = 0, node_max = INT_MIN, node_shift = 0;
+  int32_t cur_contig = -1, cur_node = -1;
+  for (const Placement& p : pl) {
+    if (p.contig != cur_contig || p.node != cur_node) {
+      if (node_max != INT_MIN) max_pos = std::max(max_pos, node_shift + node_max);  // commit the finished node
+      if (p.contig != cur_contig) max_pos = 0;
+      cur_contig = p.contig; cur_node = p.node; node_max = INT_MIN; node_shift = p.shift;
+    }
+    const Window& win = m.wins[p.wid];
+    if (win.count > 0) {
+      m.activate(p.wid);
+      out.push_back(Occ{p.wid, p.shift, (max_pos - 5) - p.shift, p.path, rank++});
+    }
+    if (win.global_max_pos != INT_MIN) node_max = std::max(node_max, win.global_max_pos);
   }
 }
 

@@ -49,7 +49,8 @@ using Walk = std::vector<int32_t>;
 struct Window {
   int64_t first = 0;
   int32_t count = 0;
-  int32_t max_pos = INT_MIN;  // largest record position (INT_MIN when empty)
+  int32_t max_pos = INT_MIN;  // largest record position among THIS shard's reads (INT_MIN when empty)
+  int32_t global_max_pos = INT_MIN;  // ... among all shards' reads (== max_pos until exchanged)
   bool active = false;        // has occurred in a scored path set: its records are on the device
 };
 
@@ -80,7 +81,9 @@ struct ShortMate {
   // window cache
   std::unordered_map<Walk, int32_t, WalkHasher> win_id;
   std::vector<Window> wins;
+  std::vector<const Walk*> win_walk;     // window id -> its node ids (keys of win_id are stable)
   std::vector<gaml_aligment> pool;       // read_id = LOCAL id inside the shard
+  std::vector<int32_t> unsynced;         // windows added since the last max-position exchange (sharded runs)
   uint64_t generation = 0;               // bumped whenever a window is added
   uint64_t active_generation = 0;        // bumped whenever a window is activated (device table stale)
   int64_t active_records = 0;            // records of activated windows
@@ -118,9 +121,15 @@ void register_for_paths(const GraphStore& g, ShortMate& m, const std::vector<Wal
 void register_for_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n);  // graph.cc:495-533, 538-542
 
 // occurrence lists
-// paired: contig at path coordinate `st` (GetPositionsOnlyPath graph.cc:544-597)
-void occurrences_paired_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n, int32_t st,
-                               int32_t path, int32_t* rank, std::vector<Occ>& out);
+// paired, pass 1 (structure): which cached windows sit where on a contig placed at path coordinate
+// `st` (GetPositionsOnlyPath graph.cc:544-573). Every cached window is listed, also one without
+// records in this shard: its global_max_pos still feeds the position filter.
+struct Placement { int32_t wid, shift, path, contig, node; };
+void placements_paired_contig(const GraphStore& g, const ShortMate& m, const int32_t* ctg, int32_t n, int32_t st,
+                              int32_t path, int32_t contig_serial, std::vector<Placement>& out);
+// paired, pass 2 (thresholds): the max_pos - 5 filter of graph.cc:577 as a prefix maximum over the
+// nodes of each contig, from the windows' GLOBAL largest positions; activates the windows used.
+void occurrences_from_placements(ShortMate& m, const std::vector<Placement>& pl, std::vector<Occ>& out);
 // single: contig at absolute coordinate `st` (AddPositions graph.cc:611-647)
 void occurrences_single_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n, int32_t st,
                                int32_t* rank, std::vector<Occ>& out);

@@ -102,6 +102,10 @@ int gaml_hip_add_pacbio_fastq(gaml_hip_ctx* ctx, const gaml_single_cfg* cfg, con
  * scores only reads [n*rank/world, n*(rank+1)/world) of every read set. Call before adding
  * read sets. Partial results are combined with gaml_hip_combine_partials. */
 int gaml_hip_set_shard(gaml_hip_ctx* ctx, int32_t rank, int32_t world);
+/* Alternative: the caller already hands each process only its own reads (world processes in
+ * all). Nothing is partitioned; the context only knows that window maxima must be exchanged
+ * with the other processes (gaml_hip_eval_* below). */
+int gaml_hip_set_presharded(gaml_hip_ctx* ctx, int32_t world);
 
 /* Alignment records computed outside the library (the reference's external-aligner branch
  * graph.cc:924-1033 produces exactly these per sub-walk; BLASR output for PacBio,
@@ -130,6 +134,24 @@ int gaml_hip_calc_partials(gaml_hip_ctx* ctx, const int32_t* paths, const int64_
 int gaml_hip_combine_partials(gaml_hip_ctx* ctx, const double* partials /* 4 * n_sets, reduced */,
                               int32_t total_len, double* prob_out, int32_t* zeros_out);
 
+/* Two-phase form, REQUIRED for sharded contexts whenever new windows get aligned (cold path):
+ * the reference drops an alignment whose path position is more than 5 below the largest position
+ * seen at earlier nodes of the contig (graph.cc:577) -- a maximum over ALL reads, so shards must
+ * exchange the largest record position of every newly aligned window once.
+ *   gaml_hip_eval_begin          registration + alignment + window placement; *pending_out = number
+ *                                of windows whose maxima need exchanging (always 0 when world == 1,
+ *                                and 0 in a sharded run once the window cache is warm)
+ *   gaml_hip_eval_pending_maxpos the local maxima, in an order that is identical on every rank
+ *   (caller: all-reduce(max) over ranks)
+ *   gaml_hip_eval_apply_maxpos   install the reduced maxima
+ *   gaml_hip_eval_finish[_async] thresholds, device tables, kernels; partials as gaml_hip_calc_partials */
+int gaml_hip_eval_begin(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths,
+                        int64_t* pending_out, int32_t* total_len_out);
+int64_t gaml_hip_eval_pending_maxpos(gaml_hip_ctx* ctx, int32_t* out, int64_t cap);
+int gaml_hip_eval_apply_maxpos(gaml_hip_ctx* ctx, const int32_t* reduced, int64_t n);
+int gaml_hip_eval_finish(gaml_hip_ctx* ctx, double* partials_out /* 4 * n_sets */);
+int gaml_hip_eval_finish_async(gaml_hip_ctx* ctx, void* d_partials, void* hip_stream);
+
 /* Device-resident form for callers that already own a HIP stream (e.g. torch): enqueue the
  * whole evaluation on `stream` and leave the 4*n_sets partials in device memory at
  * d_partials (f64). No host synchronisation. */
@@ -154,6 +176,18 @@ int64_t gaml_hip_window_records(gaml_hip_ctx* ctx, int readset, int mate, const 
                                 gaml_aligment* out, int64_t cap);
 /* force alignment of one window with the library's own aligner (AlignSubpathInternal graph.cc:839-899) */
 int64_t gaml_hip_align_window(gaml_hip_ctx* ctx, int readset, int mate, const int32_t* subpath, int32_t subpath_len);
+/* Host-side half of an evaluation WITHOUT touching the device (works on a host-only context):
+ * window registration + alignment of missing windows + window-occurrence lists for `paths`,
+ * exactly what gaml_hip_calc_* does before it launches. For tests of the host logic. */
+int gaml_hip_debug_prepare(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths);
+/* occurrence list of the last prepare/evaluation: 5 ints per entry {window id, shift, min_pos,
+ * path, rank}; returns the number of entries. */
+int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int32_t* out5, int64_t cap);
+/* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
+int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
+/* pairs per record-count class of the device table {<=1, <=2, <=4, more} (paired sets) */
+int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);
+
 /* timing of the last scoring call, microseconds: [0] host preparation (window registration,
  * alignment of new windows, occurrence tables), [1] H2D + kernels + D2H wall, [2] device time
  * of the scoring kernels measured with HIP events on the library's stream (0 if events off). */

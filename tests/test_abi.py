@@ -1,0 +1,64 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/gaml_hip.h declares, and
+refuses to score without a device (there is no CPU scoring path in the product)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gaml_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gaml_hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(built):
+    lib = ctypes.CDLL(os.path.join(ROOT, "gaml_amd", "libgaml_hip.so"))
+    names = declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_record_layouts_match_the_reference_structs(built):
+    from gaml_amd import api
+    assert api.ALIGMENT.itemsize == 16        # Aligment = 4 x int32 (graph.h:211-231)
+    assert api.PACBIO_ALIGMENT.itemsize == 24  # PacbioAligment = 3 x int32 + logdouble (graph.h:516-535)
+    assert ctypes.sizeof(api.PairedCfg) == 64 and ctypes.sizeof(api.SingleCfg) == 48
+
+
+def test_host_only_context_refuses_to_score(built):
+    from gaml_amd import api, synth
+    genome = synth.make_genome(5000, 1)
+    g = synth.make_graph(genome, synth.cut_lengths(5000, 1, long_rng=(900, 1500)))
+    pr = synth.make_paired_reads(genome, 50, 100, 250.0, 25.0, 0.01, 1)
+    ctx = api.Context(device=-1)
+    ctx.set_graph(*g.packed())
+    rs = ctx.add_paired(api.paired_cfg(250.0, 25.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    assert ctx.num_readsets() == 1 and ctx.readset_reads(rs) == 50 and ctx.readset_kind(rs) == 1
+    assert ctx.num_nodes() == g.n_nodes and ctx.node_len(0) == g.node_len(0)
+    with pytest.raises(api.GamlHipError) as e:
+        ctx.calc_prob([synth.genome_walk(g)])
+    assert e.value.code == api.ENODEVICE
+    with pytest.raises(api.GamlHipError):
+        ctx.calc_partials([synth.genome_walk(g)])
+    with pytest.raises(api.GamlHipError):
+        ctx.read_probs(rs)
+
+
+def test_argument_errors(built):
+    from gaml_amd import api
+    ctx = api.Context(device=-1)
+    with pytest.raises(api.GamlHipError):  # odd node count: twin of i is i^1
+        ctx.set_graph(np.frombuffer(b"ACGT", np.uint8), np.array([0, 2, 3, 4], np.int64))
+    with pytest.raises(api.GamlHipError):
+        ctx.load_graph("/nonexistent/LastGraph")
+    with pytest.raises(api.GamlHipError):
+        ctx.add_paired_fastq(api.paired_cfg(300, 30), "/nonexistent/a.fq", "/nonexistent/b.fq")
+    with pytest.raises(api.GamlHipError):  # device ordinal that does not exist
+        api.Context(device=4096)
+    assert "gaml_hip" in api.version()

@@ -1,0 +1,238 @@
+"""GPU parity of the single-end and PacBio scorers, mixed read sets (ProbCalculator's sum),
+golden fixtures through the C ABI, and read sharding on one GPU."""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from gaml_amd import synth
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+PINS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_pins.json")))
+
+
+def h(x):
+    return float.fromhex(x)
+
+
+def _graph(G, seed, **kw):
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, **kw))
+    return genome, g
+
+
+def test_single_end_parity():
+    from gaml_amd import api
+    import oracle_py as op
+    genome, g = _graph(60_000, 51, long_rng=(700, 3000))
+    reads = synth.make_single_reads(genome, 4000, 100, 0.01, 51)
+    gb, go = g.packed()
+    b, o = synth.pack_reads(reads)
+    ctx = api.Context(device=0)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_single(api.single_cfg(), b, o)
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    ors = orc.add_single(b, o, 0.01, op.single_cfg())
+    walk = synth.genome_walk(g)
+    for paths in ([walk], [walk[:9], walk[9:]], [[x] for x in walk], [walk[:5] + [-60] + walk[7:]], [walk[2:5], walk[2:5]]):
+        got, zeros, tl = ctx.calc_prob(paths)
+        want, wprobs, o3 = orc.single_detail(ors, paths)
+        assert zeros.tolist() == [[int(o3[0]), 4000]] and tl == int(o3[1])
+        np.testing.assert_allclose(ctx.read_probs(rs), wprobs, rtol=4e-16, atol=0)
+        assert ctx.bad_bases(rs) == int(o3[2]) == 0
+        assert abs(got - want) <= 1e-12 * abs(want)
+
+
+def _pacbio_pair(g, walk, n_reads, cfg_kw, seed=4, read_len=2000):
+    from gaml_amd import api
+    import oracle_py as op
+    gb, go = g.packed()
+    pb = synth.make_pacbio_records(g, walk, n_reads, read_len, 0.15, seed)
+    ctx = api.Context(device=0)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_pacbio(api.single_cfg(mismatch_prob=0.15, **cfg_kw), pb.lens)
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    okw = dict(cfg_kw)
+    if "penalty_step" in okw:
+        okw["step"] = okw.pop("penalty_step")
+    ors = orc.add_pacbio(pb.lens, 0.15, op.single_cfg(**okw))
+    for wk, rec, lp in zip(pb.walks, pb.recs, pb.logps):
+        ctx.put_pacbio_records(rs, wk, rec, lp)
+        orc.pacbio_put(ors, wk, rec, lp)
+    return ctx, rs, orc, ors, pb
+
+
+def test_pacbio_parity_and_golden():
+    import make_golden as mg
+    genome, g, pr = mg.tiny_case()
+    walk = synth.genome_walk(g)
+    for tag in ("pacbio", "pacbio_sparse"):
+        c = PINS[tag]
+        ctx, rs, orc, ors, pb = _pacbio_pair(g, walk, c["n_reads"], dict(penalty_constant=0.0001, min_prob_per_base=-1.06))
+        got, zeros, tl = ctx.calc_prob([walk])
+        want, wlp, o3 = orc.pacbio_detail(ors, [walk])
+        assert zeros.tolist() == [[c["zeros"], c["n_reads"]]] and tl == c["total_len"]
+        assert ctx.bad_bases(rs) == c["bad_bases"] == int(o3[2])
+        lp = ctx.read_probs(rs)
+        fin = np.isfinite(wlp)
+        assert (np.isfinite(lp) == fin).all()
+        np.testing.assert_allclose(lp[fin], wlp[fin], rtol=1e-13)
+        assert abs(got - h(c["prob"])) <= 1e-12 * abs(h(c["prob"]))
+        assert abs(got - want) <= 1e-12 * abs(want)
+
+
+def test_pacbio_many_alignments_per_read_wave_lse():
+    """A read with hundreds of candidate positions exercises the strided wave-level log-sum-exp."""
+    from gaml_amd import api
+    import oracle_py as op
+    genome, g = _graph(40_000, 53, long_rng=(900, 2500))
+    gb, go = g.packed()
+    walk = synth.genome_walk(g)[:6]
+    rng = np.random.default_rng(5)
+    lens = np.array([1500, 1500, 1800], np.int32)
+    ctx = api.Context(device=0)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_pacbio(api.single_cfg(mismatch_prob=0.15, min_prob_per_base=-2.0), lens)
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    ors = orc.add_pacbio(lens, 0.15, op.single_cfg(min_prob_per_base=-2.0))
+    for sub in synth.all_subwalks_for_pacbio(g, walk, int(lens.max())):
+        k = int(rng.integers(0, 200))
+        rec = np.stack([rng.integers(0, 500, k), rng.integers(1500, 2000, k), rng.integers(0, 2, k)], axis=1).astype(np.int32)
+        lp = rng.uniform(-2400, -1700, k)
+        ctx.put_pacbio_records(rs, sub, rec, lp)
+        orc.pacbio_put(ors, sub, rec, lp)
+    got, zeros, tl = ctx.calc_prob([walk, walk[1:4]])
+    want, wlp, o3 = orc.pacbio_detail(ors, [walk, walk[1:4]])
+    lp = ctx.read_probs(rs)
+    assert math.isinf(lp[2]) and math.isinf(wlp[2])  # read 2 has no alignment: floored
+    np.testing.assert_allclose(lp[:2], wlp[:2], rtol=1e-12)
+    assert zeros.tolist() == [[int(o3[0]), 3]]
+    assert abs(got - want) <= 1e-12 * abs(want)
+
+
+def test_mixed_read_sets_sum_like_prob_calculator():
+    """Two readsets as BASELINE config 4: paired (weight 1) + PacBio (weight 0.5, mismatch 0.15)."""
+    from gaml_amd import api
+    import oracle_py as op
+    genome, g = _graph(90_000, 55, long_rng=(900, 4000))
+    gb, go = g.packed()
+    walk = synth.genome_walk(g)
+    pr = synth.make_paired_reads(genome, 5000, 150, 300.0, 30.0, 0.01, 55)
+    pb = synth.make_pacbio_records(g, walk, 120, 5000, 0.15, 55)
+    sr = synth.make_single_reads(genome, 1500, 100, 0.01, 56)
+    ctx = api.Context(device=0)
+    ctx.set_graph(gb, go)
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    # creation order pacbio, paired, single: the value and `zeros` must come out single, paired, pacbio
+    crs = ctx.add_pacbio(api.single_cfg(mismatch_prob=0.15, weight=0.5, min_prob_per_base=-1.1), pb.lens)
+    ors = orc.add_pacbio(pb.lens, 0.15, op.single_cfg(weight=0.5, min_prob_per_base=-1.1))
+    for wk, rec, lp in zip(pb.walks, pb.recs, pb.logps):
+        ctx.put_pacbio_records(crs, wk, rec, lp)
+        orc.pacbio_put(ors, wk, rec, lp)
+    ctx.add_paired(api.paired_cfg(300.0, 30.0, weight=1.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    orc.add_paired(*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2), 0.01, op.paired_cfg(300.0, 30.0, weight=1.0))
+    ctx.add_single(api.single_cfg(weight=0.25), *synth.pack_reads(sr))
+    orc.add_single(*synth.pack_reads(sr), 0.01, op.single_cfg(weight=0.25))
+    k = len(walk) // 2
+    for paths in ([walk], [walk[:k], walk[k:]]):
+        got, zeros, tl = ctx.calc_prob(paths)
+        want, wz, wtl = orc.calc_prob(paths, fresh=True)
+        assert zeros[:, 1].tolist() == [1500, 5000, 120]
+        # sub-walks no synthetic record was filed under are cache misses on both sides (BLASR territory)
+        assert zeros.tolist() == wz.tolist() and tl == wtl
+        assert abs(got - want) <= 1e-9 * abs(want)
+
+
+def test_paired_golden_through_c_abi():
+    import make_golden as mg
+    from gaml_amd import api
+    genome, g, pr = mg.tiny_case()
+    gb, go = g.packed()
+    for pen_name, pen in (("nopenalty", 0.0), ("penalty", 0.0002)):
+        ctx = api.Context(device=0)
+        ctx.set_graph(gb, go)
+        rs = ctx.add_paired(api.paired_cfg(250.0, 25.0, penalty_constant=pen), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+        for name, c in PINS[f"paired_{pen_name}"]["cases"].items():
+            got, zeros, tl = ctx.calc_prob(c["paths"])
+            assert zeros.tolist() == c["zeros"] and tl == c["total_len"], name
+            assert ctx.bad_bases(rs) == (c["bad_bases"] if pen > 0 else 0)
+            assert abs(got - h(c["prob"])) <= 1e-12 * abs(h(c["prob"])), name
+            probs = ctx.read_probs(rs)
+            assert int((probs > 0).sum()) == c["probs_nonzero"]
+            assert abs(float(probs.sum()) - h(c["probs_sum"])) <= 1e-13 * h(c["probs_sum"])
+
+
+def test_fastq_and_lastgraph_files_end_to_end(tmp_path):
+    """Same inputs as files in the reference's formats (LastGraph, FASTQ) vs arrays."""
+    from gaml_amd import api
+    genome, g = _graph(40_000, 57, long_rng=(900, 3000))
+    pr = synth.make_paired_reads(genome, 1500, 100, 250.0, 25.0, 0.01, 57)
+    synth.write_lastgraph(str(tmp_path / "LastGraph"), g)
+    synth.write_fastq(str(tmp_path / "r_1.fastq"), pr.mate1, "p", 1)
+    synth.write_fastq(str(tmp_path / "r_2.fastq"), pr.mate2, "p", 2)
+    a = api.Context(device=0)
+    a.load_graph(str(tmp_path / "LastGraph"))
+    a.add_paired_fastq(api.paired_cfg(250.0, 25.0), str(tmp_path / "r_1.fastq"), str(tmp_path / "r_2.fastq"))
+    b = api.Context(device=0)
+    b.set_graph(*g.packed())
+    b.add_paired(api.paired_cfg(250.0, 25.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    walk = synth.genome_walk(g)
+    assert a.num_nodes() == b.num_nodes() == g.n_nodes
+    assert a.calc_prob([walk]) [0] == b.calc_prob([walk])[0]
+
+
+def test_read_sharding_on_one_gpu_sums_to_the_whole():
+    """world=3 shards scored one after the other on the same GPU: partial sums add up to the
+    unsharded partials (the only cross-rank step is a sum)."""
+    from gaml_amd import api
+    genome, g = _graph(80_000, 59, long_rng=(900, 4000))
+    pr = synth.make_paired_reads(genome, 5001, 150, 300.0, 30.0, 0.01, 59)
+    gb, go = g.packed()
+    args = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    walk = synth.genome_walk(g)
+    paths = [walk[:7], walk[7:]]
+    whole = api.Context(device=0)
+    whole.set_graph(gb, go)
+    whole.add_paired(api.paired_cfg(300.0, 30.0), *args)
+    wp, tl = whole.calc_partials(paths)
+    want, wz, _ = whole.calc_prob(paths)
+    acc = np.zeros(4)
+    probs = []
+    shards = []
+    for r in range(3):
+        c = api.Context(device=0, rank=r, world=3)
+        c.set_graph(gb, go)
+        c.add_paired(api.paired_cfg(300.0, 30.0), *args)
+        shards.append(c)
+    # cold evaluation: windows get aligned, so the shards must exchange each new window's largest
+    # record position (the all-reduce(max) a multi-process run does over RCCL)
+    pend = [c.eval_begin(paths) for c in shards]
+    assert len({p for p, _ in pend}) == 1 and pend[0][0] > 0 and all(t == tl for _, t in pend)
+    with pytest.raises(api.GamlHipError):
+        shards[0].eval_finish()  # refuses to score with unexchanged maxima
+    reduced = np.maximum.reduce([c.eval_pending_maxpos() for c in shards])
+    for r, c in enumerate(shards):
+        c.eval_apply_maxpos(reduced)
+        p = c.eval_finish()
+        acc += p[0]
+        probs.append(c.read_probs(0)[: 5001 * (r + 1) // 3 - 5001 * r // 3])
+        last = c
+    # warm cache: nothing to exchange, the one-shot call works on a sharded context
+    for c in shards:
+        assert c.eval_begin(paths)[0] == 0
+        c.eval_finish()
+    p2, _ = shards[1].calc_partials(paths)
+    assert acc[1] == wp[0][1] and acc[3] == wp[0][3] == 5001
+    assert abs(acc[0] - wp[0][0]) <= 1e-12 * abs(wp[0][0])
+    assert np.array_equal(np.concatenate(probs), whole.read_probs(0))
+    acc[2] = 0.0
+    got, z = last.combine_partials(acc, tl)
+    assert z.tolist() == wz.tolist() and abs(got - want) <= 1e-12 * abs(want)

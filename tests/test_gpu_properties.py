@@ -1,0 +1,84 @@
+"""Size-independent properties at BASELINE.json's sizes (cfg2: 1 Mbp / 100,000 pairs and
+cfg3: 5 Mbp / 833,333 pairs), where running the oracle on everything would take too long."""
+import numpy as np
+import pytest
+
+from gaml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(wl, device=0, rank=0, world=1, penalty=0.0):
+    from gaml_amd import api
+    genome = synth.make_genome(wl.genome_len, wl.seed)
+    g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
+    pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
+    ctx = api.Context(device=device, rank=rank, world=world)
+    ctx.set_graph(*g.packed())
+    rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std, penalty_constant=penalty),
+                        *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    return g, pr, ctx, rs
+
+
+def test_cfg2_determinism_purity_and_oracle_sample():
+    import oracle_py as op
+    wl = synth.WORKLOADS["cfg2"]
+    g, pr, ctx, rs = _ctx(wl)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 2
+    a1 = ctx.calc_prob([walk])
+    b1 = ctx.calc_prob([walk[:k], walk[k:]])
+    a2 = ctx.calc_prob([walk])
+    b2 = ctx.calc_prob([walk[:k], walk[k:]])
+    # pure function of (paths, cache): bit-identical on repetition, whatever was scored in between
+    assert a1[0] == a2[0] and b1[0] == b2[0] and a1[1].tolist() == a2[1].tolist()
+    # breaking the walk can only lose pairs that spanned the break
+    assert b1[0] < a1[0] and b1[1][0][0] >= a1[1][0][0]
+    # the twin walk is the same sequence read from the other strand; the reference's seed lookup and
+    # 0-1 BFS are not strand-symmetric (graph.cc:1303-1321, 753-837), so only approximately equal
+    t = ctx.calc_prob([[x ^ 1 for x in reversed(walk)]])
+    assert abs(t[0] - a1[0]) <= 1e-3 * abs(a1[0])
+    # per-read probabilities of the first 20,000 pairs vs the oracle run on those pairs alone
+    n = 20_000
+    orc = op.Oracle()
+    orc.set_graph(*g.packed())
+    ors = orc.add_paired(*synth.pack_reads(pr.mate1[:n]), *synth.pack_reads(pr.mate2[:n]), 0.01, op.paired_cfg(300.0, 30.0))
+    orc.calc_prob([walk], fresh=True)
+    wprobs, _ = orc.paired_probs(ors)
+    ctx.calc_prob([walk])
+    np.testing.assert_allclose(ctx.read_probs(rs)[:n], wprobs, rtol=4e-16, atol=0)
+
+
+def test_cfg3_full_size_shards_and_roundtrip():
+    """5 Mbp / 833,333 pairs: two half-shards add up to the whole (linearity in the reads), the
+    per-read probabilities are the same whichever shard scored them, and the floored-read count
+    equals the number of reads whose probability is below the floor."""
+    from gaml_amd import api
+    wl = synth.WORKLOADS["cfg3"]
+    g, pr, ctx, rs = _ctx(wl)
+    walk = synth.genome_walk(g)
+    part, tl = ctx.calc_partials([walk])
+    probs = ctx.read_probs(rs)
+    assert tl == wl.genome_len and part[0][3] == wl.n_pairs
+    floor = np.exp(-10 - 0.7 * 300)
+    assert int((probs / (2 * tl) < floor).sum()) == int(part[0][1])
+    want = np.where(probs / (2 * tl) < floor, np.log(floor), np.log(np.maximum(probs, 1e-300) / (2 * tl))).sum()
+    assert abs(part[0][0] - want) <= 1e-9 * abs(want)
+    acc = np.zeros(4)
+    shards = []
+    for r in range(2):
+        c = api.Context(device=0, rank=r, world=2)
+        c.set_graph(*g.packed())
+        c.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+        assert c.eval_begin([walk])[0] > 0
+        shards.append(c)
+    reduced = np.maximum.reduce([c.eval_pending_maxpos() for c in shards])  # stands in for all-reduce(max)
+    for r, c in enumerate(shards):
+        c.eval_apply_maxpos(reduced)
+        p = c.eval_finish()
+        acc += p[0]
+        lo, hi = wl.n_pairs * r // 2, wl.n_pairs * (r + 1) // 2
+        assert np.array_equal(c.read_probs(0)[: hi - lo], probs[lo:hi])
+        c.close()
+    assert acc[1] == part[0][1] and acc[3] == wl.n_pairs
+    assert abs(acc[0] - part[0][0]) <= 1e-12 * abs(part[0][0])
