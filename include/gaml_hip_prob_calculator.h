@@ -1,0 +1,146 @@
+// gaml_hip_prob_calculator.h -- drop-in replacement for the reference's prob_calculator.h.
+//
+// Same struct names and fields, same constructor, same three CalcProb overloads, same public
+// data members (reference prob_calculator.h:7-124); gaml.cc and moves.cc compile against it
+// unchanged. CalcProb forwards to libgaml_hip.so (include/gaml_hip.h) instead of calling
+// CalcScoreForPaths / CalcScoreForPathsNew / CalcScoreForPacbio (graph.cc:1650, 1952, 3171).
+//
+// The one change outside this file: ReadSet and PacbioReadSet (graph.h:344, 444) keep their FASTQ
+// path in a private member, so add
+//       friend class ProbCalculator;
+// to both classes (INTEGRATION.md shows the two-line patch). Nothing else in GAML is touched.
+//
+// NOT compile-tested in the build container: graph.h needs Boost, which the image lacks (see
+// DESIGN.md "Oracle"); gaml_amd/host/gaml_host.h is the same logic over stand-alone mirrors of
+// these classes and IS built and tested.
+#ifndef PROB_CALCULATOR_H__
+#define PROB_CALCULATOR_H__
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "gaml_hip.h"
+#include "graph.h"    // the reference's
+#include "utility.h"  // the reference's
+
+struct SingleReadConfig {
+  SingleReadConfig() {}
+  SingleReadConfig(double pc, double s, double mp, double mps, double w, bool a)
+      : penalty_constant(pc), step(s), min_prob_per_base(mp), min_prob_start(mps), weight(w), advice(a) {}
+  double penalty_constant;
+  double step;
+  double min_prob_per_base;
+  double min_prob_start;
+  double weight;
+  bool advice;
+};
+
+struct PairedReadConfig {
+  PairedReadConfig() {}
+  PairedReadConfig(double pc, double s, double im, double is, double mp, double mps, double w, bool a)
+      : penalty_constant(pc), step(s), insert_mean(im), insert_std(is), min_prob_per_base(mp), min_prob_start(mps),
+        weight(w), advice(a) {}
+  double penalty_constant;
+  double step;
+  double insert_mean;
+  double insert_std;
+  double min_prob_per_base;
+  double min_prob_start;
+  double weight;
+  bool advice;
+};
+
+class ProbCalculator {
+ public:
+  ProbCalculator(const vector<pair<SingleReadConfig, ReadSet*>>& single_reads,
+                 const vector<pair<PairedReadConfig, pair<ReadSet*, ReadSet*>>>& paired_reads,
+                 const vector<pair<SingleReadConfig, PacbioReadSet*>>& pacbio_reads, Graph& gr)
+      : single_reads(single_reads), paired_reads(paired_reads), pacbio_reads(pacbio_reads), gr(gr), ctx_(NULL) {
+    paired_scoring_states.resize(paired_reads.size());  // kept for source compatibility; unused
+  }
+  ~ProbCalculator() { if (ctx_) gaml_hip_destroy(ctx_); }
+
+  double CalcProb(vector<vector<int>>& pathso, vector<pair<int, int>>& zeros, int& total_len) {
+    // the reference constructs ProbCalculator before PrepareReads (gaml.cc:1010 vs 1017): the
+    // device context is built on first use, when the FASTQ files are known to be final
+    if (!ctx_) Build();
+    vector<int32_t> flat;
+    vector<int64_t> offs(1, 0);
+    for (size_t i = 0; i < pathso.size(); i++) {
+      flat.insert(flat.end(), pathso[i].begin(), pathso[i].end());
+      offs.push_back((int64_t)flat.size());
+    }
+    int32_t none = 0, tl = 0;
+    double prob = 0;
+    vector<int32_t> z(2 * (single_reads.size() + paired_reads.size() + pacbio_reads.size()) + 2);
+    if (gaml_hip_calc_prob(ctx_, flat.empty() ? &none : &flat[0], &offs[0], (int32_t)pathso.size(), &prob, &z[0], &tl) != GAML_HIP_OK)
+      Die("gaml_hip_calc_prob");
+    zeros.clear();
+    for (size_t i = 0; i < single_reads.size() + paired_reads.size() + pacbio_reads.size(); i++)
+      zeros.push_back(make_pair(z[2 * i], z[2 * i + 1]));
+    total_len = tl;
+    return prob;
+  }
+  double CalcProb(vector<vector<int> >& paths, int& total_len) {
+    vector<pair<int, int>> zeros;
+    return CalcProb(paths, zeros, total_len);
+  }
+  double CalcProb(vector<vector<int> >& paths) {
+    int tl;
+    return CalcProb(paths, tl);
+  }
+
+  vector<pair<SingleReadConfig, ReadSet*>> single_reads;
+  vector<pair<PairedReadConfig, pair<ReadSet*, ReadSet*>>> paired_reads;
+  vector<pair<SingleReadConfig, PacbioReadSet*>> pacbio_reads;
+  vector<ScoringState> paired_scoring_states;
+  Graph& gr;
+
+ private:
+  void Die(const char* what) {
+    fprintf(stderr, "%s failed: %s\n", what, ctx_ ? gaml_hip_last_error(ctx_) : "no context");
+    exit(1);  // the reference's convention for unrecoverable errors (assert / exit code)
+  }
+  void Build() {
+    if (gaml_hip_create(&ctx_, 0) != GAML_HIP_OK) { ctx_ = NULL; Die("gaml_hip_create (no HIP device?)"); }
+    string bases;
+    vector<int64_t> offs(1, 0);
+    for (size_t i = 0; i < gr.nodes.size(); i++) { bases += gr.nodes[i]->s; offs.push_back((int64_t)bases.size()); }
+    if (gaml_hip_set_graph(ctx_, (int32_t)gr.nodes.size(), bases.data(), &offs[0])) Die("gaml_hip_set_graph");
+    for (size_t i = 0; i < single_reads.size(); i++) {
+      const SingleReadConfig& c = single_reads[i].first;
+      ReadSet* rs = single_reads[i].second;
+      gaml_single_cfg g = {c.penalty_constant, c.step, c.min_prob_per_base, c.min_prob_start, c.weight, rs->mismatch_prob_};
+      if (gaml_hip_add_single_fastq(ctx_, &g, rs->filename_.c_str()) < 0) Die("gaml_hip_add_single_fastq");  // friend access
+    }
+    for (size_t i = 0; i < paired_reads.size(); i++) {
+      const PairedReadConfig& c = paired_reads[i].first;
+      ReadSet* r1 = paired_reads[i].second.first;
+      ReadSet* r2 = paired_reads[i].second.second;
+      gaml_paired_cfg g = {c.penalty_constant, c.step, c.insert_mean, c.insert_std, c.min_prob_per_base, c.min_prob_start, c.weight,
+                           r1->mismatch_prob_};
+      if (gaml_hip_add_paired_fastq(ctx_, &g, r1->filename_.c_str(), r2->filename_.c_str()) < 0) Die("gaml_hip_add_paired_fastq");
+    }
+    for (size_t i = 0; i < pacbio_reads.size(); i++) {
+      const SingleReadConfig& c = pacbio_reads[i].first;
+      PacbioReadSet* rs = pacbio_reads[i].second;
+      gaml_single_cfg g = {c.penalty_constant, c.step, c.min_prob_per_base, c.min_prob_start, c.weight, exp(rs->mismatch_prob_.logval)};
+      int h = gaml_hip_add_pacbio_fastq(ctx_, &g, rs->filename_.c_str());
+      if (h < 0) Die("gaml_hip_add_pacbio_fastq");
+      // hand over what BLASR + AligmentProbability already left in the PacBio cache (graph.h:587)
+      for (auto it = rs->aligment_cache_.begin(); it != rs->aligment_cache_.end(); ++it) {
+        vector<gaml_pacbio_aligment> recs;
+        for (size_t k = 0; k < it->second.size(); k++) {
+          gaml_pacbio_aligment r = {it->second[k].position, it->second[k].position_end, it->second[k].read_id, 0, it->second[k].prob.logval};
+          recs.push_back(r);
+        }
+        vector<int32_t> walk(it->first.begin(), it->first.end());
+        if (gaml_hip_put_pacbio_records(ctx_, h, &walk[0], (int32_t)walk.size(), recs.empty() ? NULL : &recs[0], (int64_t)recs.size()))
+          Die("gaml_hip_put_pacbio_records");
+      }
+    }
+  }
+  gaml_hip_ctx* ctx_;
+};
+
+#endif

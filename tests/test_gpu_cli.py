@@ -1,0 +1,73 @@
+"""The C++ host mirror (gaml_amd/host: LoadConfig / PrepareReadSetFromConfig / ProbCalculator over
+the C ABI) driven by a GAML config file, against the oracle driven by the same file."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from gaml_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "gaml_amd", "host", "gaml_score")
+
+
+def _write_case(d, two_sets=True):
+    G, seed = 60_000, 71
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(800, 3500)))
+    synth.write_lastgraph(os.path.join(d, "LastGraph"), g)
+    pr = synth.make_paired_reads(genome, 2500, 100, 250.0, 25.0, 0.01, seed)
+    synth.write_fastq(os.path.join(d, "a_1.fastq"), pr.mate1, "p", 1)
+    synth.write_fastq(os.path.join(d, "a_2.fastq"), pr.mate2, "p", 2)
+    sets = [dict(name="rs1", type="paired", filename1=os.path.join(d, "a_1.fastq"), filename2=os.path.join(d, "a_2.fastq"),
+                 insert_mean=250, insert_std=25, penalty_step=30, penalty_constant=0.00007, min_prob_per_base=0, min_prob_start=-20)]
+    if two_sets:
+        sr = synth.make_single_reads(genome, 900, 100, 0.01, seed)
+        synth.write_fastq(os.path.join(d, "s.fastq"), sr, "s", None)
+        sets.append(dict(name="zz", type="single", filename=os.path.join(d, "s.fastq"), weight=0.5, min_prob_per_base=-0.6))
+    synth.write_config(os.path.join(d, "run.cfg"), os.path.join(d, "LastGraph"), sets, extra={"t0": 0.02, "long_contig_threshold": 700})
+    return g
+
+
+@pytest.mark.gpu
+def test_gaml_score_matches_oracle_from_the_same_config(tmp_path):
+    import oracle_py as op
+    d = str(tmp_path)
+    g = _write_case(d)
+    walk = synth.genome_walk(g)
+    with open(os.path.join(d, "x.walks"), "w") as f:  # Graph::OutputPathC format (graph.cc:277-291)
+        for cid, w in enumerate([walk[:11] + [-140] + walk[13:], [x ^ 1 for x in reversed(walk[:4])]]):
+            pos, parts = 0, []
+            for x in w:
+                parts.append(f"{x}({pos})")
+                pos += g.node_len(x) if x >= 0 else -x
+            f.write(f">tmp{cid}-" + "-".join(parts) + "\n")
+    paths = [walk[:11] + [-140] + walk[13:], [x ^ 1 for x in reversed(walk[:4])]]
+    orc = op.Oracle()
+    assert orc.load_config(os.path.join(d, "run.cfg")) == 2
+    for args, ps in (([os.path.join(d, "x.walks")], paths), ([], [[i] for i in range(0, g.n_nodes, 2) if g.node_len(i) > 700])):
+        out = subprocess.run([CLI, os.path.join(d, "run.cfg")] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        m = re.search(r"start prob (\S+) len (\d+) low prob reads(.*)", out.stdout)
+        got, tl = float(m.group(1)), int(m.group(2))
+        zeros = [[int(a), int(b)] for a, b in re.findall(r"(\d+)/(\d+)", m.group(3))]
+        want, wz, wtl = orc.calc_prob(ps, fresh=True)
+        assert tl == wtl and zeros == wz.tolist()
+        assert abs(got - want) <= 1e-9 * abs(want)
+
+
+def test_gaml_score_fails_loudly_without_a_gpu(tmp_path, built):
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    d = str(tmp_path)
+    _write_case(d, two_sets=False)
+    out = subprocess.run([CLI, os.path.join(d, "run.cfg")], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert "no HIP device" in out.stderr or "HIP" in out.stderr
+    assert "start prob" not in out.stdout
