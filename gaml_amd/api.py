@@ -126,7 +126,20 @@ def version() -> str:
     return _lib.gaml_hip_version().decode()
 
 
+class FlatPaths:
+    """Paths already in the ABI's form (flattened int32 ids + int64 offsets): build once, score often."""
+
+    def __init__(self, paths):
+        self.flat, self.offs = _flat(paths)
+        self.n = len(paths)
+
+    def __len__(self):
+        return self.n
+
+
 def _flat(paths):
+    if isinstance(paths, FlatPaths):
+        return paths.flat, paths.offs
     flat = np.array([x for p in paths for x in p], dtype=np.int32)
     if flat.size == 0:
         flat = np.zeros(1, np.int32)

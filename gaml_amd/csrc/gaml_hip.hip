@@ -88,7 +88,8 @@ struct PairedSet {
   ReadMajor rm[2];
   MateDev dev[2];
   DevBuf len12, probs, tabs, occ_arena, cov_bits, cov_meta, bad, ovf_cnt, ovf_list;
-  std::vector<Occ> last_occ[2];
+  PairedPlanner planner;
+  std::vector<Occ> scratch_occ[2];
   std::vector<int32_t> slot_of_read, read_of_slot;  // device order of pairs (by record-count class)
   int64_t class_count[4] = {0, 0, 0, 0};
   Reducer red;
@@ -129,7 +130,6 @@ struct PacbioSet {
 };
 
 struct PairedPrep {
-  std::vector<Placement> placements[2];  // pass 1
   OccTable occ[2];
   int64_t assembled_records = 0;  // records the reference would touch in GetPositionsOnlyPath
   std::vector<int32_t> path_base, start_off, starts;
@@ -346,56 +346,35 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
 
 
 // pass 1: window registration / alignment of missing windows and the placement of cached windows
+// (memoised per distinct path: PairedPlanner)
 void prepare_paired_structure(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p) {
-  // windows registered over the whole path set, per mate (graph.cc:1967-1968)
-  register_for_paths(c->g, s.mate[0], paths);
-  register_for_paths(c->g, s.mate[1], paths);
-  // per path, per contig: register the contig's windows, then note which cached windows sit where
-  // (graph.cc:1830-1844, in the reference's interleaving of the two mates)
-  std::vector<std::pair<int32_t, int32_t>> ranges;
-  std::vector<int32_t> gaps;
-  const bool cov = s.cfg.penalty_constant > 0;
-  p.placements[0].clear(); p.placements[1].clear();
-  p.path_base.assign(1, 0);
-  p.start_off.assign(1, 0);
-  p.starts.clear();
-  int32_t contig_serial = 0;
-  for (int32_t pi = 0; pi < (int32_t)paths.size(); pi++) {
-    const Walk& path = paths[pi];
-    split_contigs(path, ranges, gaps);
-    int32_t cur_len = 0;
-    p.starts.push_back(0);  // events (0,1) graph.cc:1826
-    for (size_t ci = 0; ci < ranges.size(); ci++) {
-      if (ci > 0) { cur_len += gaps[ci - 1]; p.starts.push_back(cur_len); }  // graph.cc:1833-1835
-      const int32_t* ctg = path.data() + ranges[ci].first;
-      const int32_t n = ranges[ci].second - ranges[ci].first;
-      for (int mt = 0; mt < 2; mt++) {
-        register_for_contig(c->g, s.mate[mt], ctg, n);
-        placements_paired_contig(c->g, s.mate[mt], ctg, n, cur_len, pi, contig_serial, p.placements[mt]);
-      }
-      contig_serial++;
-      for (int32_t k = 0; k < n; k++) cur_len += c->g.len(ctg[k]);
-    }
-    p.start_off.push_back((int32_t)p.starts.size());
-    // coverage bitmap: one bit per path position, paths padded to 32-bit words (+ slack)
-    int32_t bits = ((cur_len + 64 + 31) / 32) * 32;
-    p.path_base.push_back(p.path_base.back() + (cov ? bits : 0));
-  }
-  p.total_bits = p.path_base.back();
+  (void)p;
+  s.planner.begin(c->g, s.mate, paths);
 }
 
 // pass 2: position-filter thresholds (need the windows' global largest positions) + device tables
 void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
   (void)c;
-  std::vector<Occ> occs[2];
-  for (int mt = 0; mt < 2; mt++) occurrences_from_placements(s.mate[mt], p.placements[mt], occs[mt]);
-  // tables are sized to the final window count
-  build_occ_table(s.mate[0].wins.size(), occs[0], p.occ[0]);
-  build_occ_table(s.mate[1].wins.size(), occs[1], p.occ[1]);
+  s.planner.finish(s.mate);
+  const PlanView& v = s.planner.view();
+  const bool cov = s.cfg.penalty_constant > 0;
+  // coverage bitmap layout + contig starts (events of type 1, graph.cc:1826,1833-1835)
+  p.path_base.assign(1, 0);
+  p.start_off.assign(1, 0);
+  p.starts.clear();
+  for (const PathMemo* pm : v.paths) {
+    p.starts.insert(p.starts.end(), pm->starts.begin(), pm->starts.end());
+    p.start_off.push_back((int32_t)p.starts.size());
+    int32_t bits = ((pm->length + 64 + 31) / 32) * 32;  // one bit per path position, padded to words (+ slack)
+    p.path_base.push_back(p.path_base.back() + (cov ? bits : 0));
+  }
+  p.total_bits = p.path_base.back();
   p.assembled_records = 0;
-  for (int mt = 0; mt < 2; mt++) for (const Occ& o : occs[mt]) p.assembled_records += s.mate[mt].wins[o.wid].count;
-  s.last_occ[0] = occs[0];
-  s.last_occ[1] = occs[1];
+  for (int mt = 0; mt < 2; mt++) {
+    s.planner.flat_occurrences(mt, s.scratch_occ[mt]);
+    build_occ_table(s.mate[mt].wins.size(), s.scratch_occ[mt], p.occ[mt]);  // sized to the final window count
+    for (const PathMemo* pm : v.paths) p.assembled_records += pm->assembled[mt];
+  }
 }
 
 void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p) {
@@ -1099,6 +1078,7 @@ int gaml_hip_eval_apply_maxpos(gaml_hip_ctx* c, const int32_t* reduced, int64_t 
     }
     m->unsynced.clear();
   }
+  for (auto& ps : c->paireds) ps->planner.invalidate_thresholds();
   return GAML_HIP_OK;
 }
 
@@ -1260,7 +1240,7 @@ int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* c, int rs, int mate, int32_t* o
   SetRef h = c->handles[rs];
   const std::vector<Occ>* v = nullptr;
   if (h.kind == 0) v = &c->singles[h.idx]->last_occ;
-  else if (h.kind == 1 && (mate == 0 || mate == 1)) v = &c->paireds[h.idx]->last_occ[mate];
+  else if (h.kind == 1 && (mate == 0 || mate == 1)) v = &c->paireds[h.idx]->scratch_occ[mate];
   if (!v) return -1;
   for (int64_t i = 0; i < (int64_t)v->size() && i < cap; i++) {
     const Occ& o = (*v)[i];

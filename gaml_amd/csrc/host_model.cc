@@ -300,6 +300,7 @@ int32_t ShortMate::add_window(const Walk& w, std::vector<gaml_aligment>& recs) {
   pool.insert(pool.end(), recs.begin(), recs.end());
   int32_t id = (int32_t)wins.size();
   unsynced.push_back(id);
+  added_log.push_back(id);
   wins.push_back(win);
   auto ins = win_id.emplace(w, id);
   win_walk.push_back(&ins.first->first);
@@ -388,27 +389,52 @@ static Walk inverted(const Walk& w) {  // InvertPath utility.h:28-38
   return r;
 }
 
+// one position of PrecomputeAlignmentForPaths' rule (graph.cc:471-482)
+static void register_position(const GraphStore& g, ShortMate& m, const Walk& p, int32_t i, int32_t last_end,
+                              int32_t* end_out, bool* skipped_for_last_end) {
+  Walk w;
+  const int32_t n = (int32_t)p.size();
+  int32_t end = junction(g, p.data(), n, i, true, w);
+  const bool by_size = (w.size() == 1 && g.len(w[0]) > 150);
+  if (skipped_for_last_end) *skipped_for_last_end = false;
+  if (m.find(w) < 0) {
+    if (last_end != end || by_size) {
+      m.align(g, w);
+      m.align(g, inverted(w));
+    } else if (skipped_for_last_end) {
+      *skipped_for_last_end = true;  // a different predecessor path would have registered it
+    }
+  }
+  if (g.len(p[i]) > kTail) {
+    Walk one(1, p[i]);
+    if (m.find(one) < 0) { m.align(g, one); m.align(g, Walk(1, p[i] ^ 1)); }
+  }
+  *end_out = end;
+}
+
+// PrecomputeAlignmentForPaths for ONE path given the last_end left by its predecessor; returns the
+// last_end it leaves. *first_skipped reports whether the first node position was not registered
+// only because of the incoming last_end.
+static int32_t register_one_path(const GraphStore& g, ShortMate& m, const Walk& p, int32_t last_end, bool* first_skipped) {
+  bool first = true;
+  if (first_skipped) *first_skipped = false;
+  for (int32_t i = 0; i < (int32_t)p.size(); i++) {
+    if (p[i] < 0) continue;
+    int32_t end;
+    bool skipped = false;
+    register_position(g, m, p, i, last_end, &end, first ? &skipped : nullptr);
+    if (first && first_skipped) *first_skipped = skipped;
+    first = false;
+    last_end = end;
+  }
+  return last_end;
+}
+
 void register_for_paths(const GraphStore& g, ShortMate& m, const std::vector<Walk>& paths) {
   // PrecomputeAlignmentForPaths (graph.cc:447-493). `last_end` deliberately survives from one
   // path to the next, as in the reference (:449).
   int32_t last_end = -1;
-  Walk w;
-  for (const Walk& p : paths) {
-    const int32_t n = (int32_t)p.size();
-    for (int32_t i = 0; i < n; i++) {
-      if (p[i] < 0) continue;
-      int32_t end = junction(g, p.data(), n, i, true, w);
-      if (m.find(w) < 0 && (last_end != end || (w.size() == 1 && g.len(w[0]) > 150))) {
-        m.align(g, w);
-        m.align(g, inverted(w));
-      }
-      if (g.len(p[i]) > kTail) {
-        Walk one(1, p[i]);
-        if (m.find(one) < 0) { m.align(g, one); m.align(g, Walk(1, p[i] ^ 1)); }
-      }
-      last_end = end;
-    }
-  }
+  for (const Walk& p : paths) last_end = register_one_path(g, m, p, last_end, nullptr);
 }
 
 void register_for_contig(const GraphStore& g, ShortMate& m, const int32_t* ctg, int32_t n) {
@@ -480,6 +506,168 @@ void occurrences_single_contig(const GraphStore& g, ShortMate& m, const int32_t*
     int32_t id = m.find(w);
     if (id >= 0 && m.wins[id].count > 0) { m.activate(id); out.push_back(Occ{id, cur_pos, INT_MIN / 2, 0, (*rank)++}); }
     cur_pos += g.len(ctg[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// PairedPlanner
+// ---------------------------------------------------------------------------------------
+int32_t PairedPlanner::lookup_or_create(const GraphStore& g, const Walk& p) {
+  auto it = by_path_.find(p);
+  if (it != by_path_.end()) { hits++; return it->second; }
+  misses++;
+  int32_t id;
+  if (memos_.size() < kMaxMemos) {
+    id = (int32_t)memos_.size();
+    memos_.emplace_back(new PathMemo());
+  } else {
+    // evict the least recently used memo that is not part of the current evaluation
+    id = -1;
+    uint64_t best = ~0ull;
+    for (int32_t k = 0; k < (int32_t)memos_.size(); k++)
+      if (memos_[k]->last_used < clock_ && memos_[k]->last_used < best) { best = memos_[k]->last_used; id = k; }
+    if (id < 0) { id = (int32_t)memos_.size(); memos_.emplace_back(new PathMemo()); }
+    else { by_path_.erase(memos_[id]->path); uint32_t ser = memos_[id]->serial + 1; memos_[id].reset(new PathMemo()); memos_[id]->serial = ser; }
+  }
+  PathMemo& pm = *memos_[id];
+  pm.path = p;
+  by_path_.emplace(p, id);
+  // path-only facts: contig starts, length, first node position and its window end, final last_end
+  std::vector<std::pair<int32_t, int32_t>> ranges;
+  std::vector<int32_t> gaps;
+  split_contigs(p, ranges, gaps);
+  int32_t cur = 0;
+  pm.starts.push_back(0);
+  for (size_t ci = 0; ci < ranges.size(); ci++) {
+    if (ci > 0) { cur += gaps[ci - 1]; pm.starts.push_back(cur); }
+    for (int32_t k = ranges[ci].first; k < ranges[ci].second; k++) cur += g.len(p[k]);
+  }
+  pm.length = cur;
+  Walk w;
+  for (int32_t i = 0; i < (int32_t)p.size(); i++) {
+    if (p[i] < 0) continue;
+    int32_t end = junction(g, p.data(), (int32_t)p.size(), i, true, w);
+    if (pm.first_idx < 0) { pm.first_idx = i; pm.first_end = end; }
+    pm.final_last_end = end;
+  }
+  return id;
+}
+
+void PairedPlanner::drain(ShortMate mate[2]) {
+  for (int mt = 0; mt < 2; mt++) {
+    ShortMate& m = mate[mt];
+    if (m.added_log.empty()) continue;
+    if (!missed_[mt].empty()) {
+      for (int32_t wid : m.added_log) {
+        auto it = missed_[mt].find(*m.win_walk[wid]);
+        if (it == missed_[mt].end()) continue;
+        for (auto& ref : it->second)
+          if (ref.first < (int32_t)memos_.size() && memos_[ref.first]->serial == ref.second) memos_[ref.first]->valid[mt] = false;
+        missed_[mt].erase(it);
+      }
+    }
+    m.added_log.clear();
+  }
+}
+
+void PairedPlanner::build_placements(const GraphStore& g, ShortMate& m, int mt, PathMemo& pm, int32_t id) {
+  // per contig: register its windows, then note which cached windows sit where (graph.cc:1830-1844)
+  std::vector<std::pair<int32_t, int32_t>> ranges;
+  std::vector<int32_t> gaps;
+  split_contigs(pm.path, ranges, gaps);
+  pm.pl[mt].clear();
+  int32_t cur_len = 0;
+  Walk w;
+  for (size_t ci = 0; ci < ranges.size(); ci++) {
+    if (ci > 0) cur_len += gaps[ci - 1];
+    const int32_t* ctg = pm.path.data() + ranges[ci].first;
+    const int32_t n = ranges[ci].second - ranges[ci].first;
+    register_for_contig(g, m, ctg, n);
+    const size_t before = pm.pl[mt].size();
+    placements_paired_contig(g, m, ctg, n, cur_len, 0, (int32_t)ci, pm.pl[mt]);
+    (void)before;
+    // remember the keys this contig looked up and missed
+    for (int32_t i = 0; i < n; i++) {
+      junction(g, ctg, n, i, false, w);
+      if (m.find(w) < 0) missed_[mt][w].emplace_back(id, pm.serial);
+      if (g.len(ctg[i]) > kTail && w.size() > 1) {
+        Walk one(1, ctg[i]);
+        if (m.find(one) < 0) missed_[mt][one].emplace_back(id, pm.serial);
+      }
+    }
+    for (int32_t k = 0; k < n; k++) cur_len += g.len(ctg[k]);
+  }
+  pm.valid[mt] = true;
+  pm.occ_valid[mt] = false;
+}
+
+void PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const std::vector<Walk>& paths) {
+  clock_++;
+  cur_ids_.clear();
+  for (const Walk& p : paths) {
+    int32_t id = lookup_or_create(g, p);
+    memos_[id]->last_used = clock_;
+    cur_ids_.push_back(id);
+  }
+  // phase 1: PrecomputeAlignmentForPaths over the whole set, per mate (graph.cc:1967-1968)
+  for (int mt = 0; mt < 2; mt++) {
+    int32_t last_end = -1;
+    for (int32_t id : cur_ids_) {
+      PathMemo& pm = *memos_[id];
+      if (!pm.registered[mt]) {
+        bool skipped = false;
+        register_one_path(g, mate[mt], pm.path, last_end, &skipped);
+        pm.registered[mt] = true;
+        pm.first_pending[mt] = skipped;
+      } else if (pm.first_pending[mt] && pm.first_idx >= 0 && last_end != pm.first_end) {
+        int32_t end;
+        bool skipped = false;
+        register_position(g, mate[mt], pm.path, pm.first_idx, last_end, &end, &skipped);
+        pm.first_pending[mt] = skipped;
+      }
+      if (pm.final_last_end != -2) last_end = pm.final_last_end;
+    }
+  }
+  // phase 2: per path in order: (re)build placements where the memo is stale
+  for (int32_t id : cur_ids_) {
+    drain(mate);
+    PathMemo& pm = *memos_[id];
+    for (int mt = 0; mt < 2; mt++)
+      if (!pm.valid[mt]) build_placements(g, mate[mt], mt, pm, id);
+  }
+  drain(mate);
+  view_.paths.clear();
+  for (int32_t id : cur_ids_) view_.paths.push_back(memos_[id].get());
+}
+
+void PairedPlanner::invalidate_thresholds() {
+  for (auto& pm : memos_) pm->occ_valid[0] = pm->occ_valid[1] = false;
+}
+
+void PairedPlanner::finish(ShortMate mate[2]) {
+  for (int32_t id : cur_ids_) {
+    PathMemo& pm = *memos_[id];
+    for (int mt = 0; mt < 2; mt++) {
+      if (pm.occ_valid[mt]) {
+        // windows stay activated once used; nothing to redo
+        continue;
+      }
+      pm.occ[mt].clear();
+      occurrences_from_placements(mate[mt], pm.pl[mt], pm.occ[mt]);
+      pm.assembled[mt] = 0;
+      for (const Occ& o : pm.occ[mt]) pm.assembled[mt] += mate[mt].wins[o.wid].count;
+      pm.occ_valid[mt] = true;
+    }
+  }
+}
+
+void PairedPlanner::flat_occurrences(int mate, std::vector<Occ>& out) const {
+  out.clear();
+  int32_t rank0 = 0;
+  for (size_t slot = 0; slot < view_.paths.size(); slot++) {
+    const PathMemo& pm = *view_.paths[slot];
+    for (const Occ& o : pm.occ[mate]) out.push_back(Occ{o.wid, o.shift, o.min_pos, (int32_t)slot, rank0 + o.rank});
+    rank0 += (int32_t)pm.occ[mate].size();
   }
 }
 

@@ -13,6 +13,7 @@
 #pragma once
 #include <climits>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -84,6 +85,7 @@ struct ShortMate {
   std::vector<const Walk*> win_walk;     // window id -> its node ids (keys of win_id are stable)
   std::vector<gaml_aligment> pool;       // read_id = LOCAL id inside the shard
   std::vector<int32_t> unsynced;         // windows added since the last max-position exchange (sharded runs)
+  std::vector<int32_t> added_log;        // windows added since the planner last looked (memo invalidation)
   uint64_t generation = 0;               // bumped whenever a window is added
   uint64_t active_generation = 0;        // bumped whenever a window is activated (device table stale)
   int64_t active_records = 0;            // records of activated windows
@@ -165,6 +167,61 @@ struct OccTable {
 void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& out);
 
 void split_contigs(const Walk& path, std::vector<std::pair<int32_t, int32_t>>& ctg_ranges, std::vector<int32_t>& gaps);
+
+// ---------------------------------------------------------------------------------------------
+// PairedPlanner: everything the host does for one paired read set per CalcProb, memoised per
+// distinct path. Replaces the reference's per-call GetChanges + hash-map position assembly
+// (graph.cc:1745-1764, 535-598) with an exact scheme:
+//   * a path's window placements depend only on the path, the graph and on WHICH of the window keys
+//     it looks up are cached. Keys it looked up and missed are remembered; when such a key is later
+//     aligned, the memos that missed it are invalidated (and only those).
+//   * registration is idempotent, so a memoised path only has to redo the one rule position whose
+//     outcome depends on the previous path in the list (`last_end`, graph.cc:449,471-472).
+// ---------------------------------------------------------------------------------------------
+struct PathMemo {
+  Walk path;
+  bool registered[2] = {false, false};   // PrecomputeAlignmentForPaths rule has run for this path
+  bool first_pending[2] = {false, false};// ... but its first position was skipped because last_end == cur_end
+  bool valid[2] = {false, false};        // placements reflect the cache
+  bool occ_valid[2] = {false, false};    // occurrence list reflects placements + window maxima
+  std::vector<Placement> pl[2];          // shifts relative to the path start, path = 0
+  std::vector<Occ> occ[2];               // rank path-local, path = 0
+  int64_t assembled[2] = {0, 0};         // records of the occurring windows
+  std::vector<int32_t> starts;           // contig start coordinates (events of type 1, graph.cc:1826,1835)
+  int32_t length = 0;                    // incl. gaps
+  int32_t first_idx = -1, first_end = -1;// first non-gap position and the end index of its junction window
+  int32_t final_last_end = -2;           // last_end after the path (-2: path has no node, passes through)
+  uint64_t last_used = 0;
+  uint32_t serial = 0;                   // bumps when the slot is reused (stale ids in the miss index)
+};
+
+struct PlanView {  // what one evaluation needs from the planner
+  std::vector<const PathMemo*> paths;    // in path-set order
+};
+
+class PairedPlanner {
+ public:
+  void begin(const GraphStore& g, ShortMate mate[2], const std::vector<Walk>& paths);  // pass 1
+  void finish(ShortMate mate[2]);                                                       // pass 2 (needs global maxima)
+  void invalidate_thresholds();          // window maxima changed (sharded cold path)
+  const PlanView& view() const { return view_; }
+  // flat occurrence list of the current path set (path = slot in the set, rank global, visiting order)
+  void flat_occurrences(int mate, std::vector<Occ>& out) const;
+  size_t memo_count() const { return memos_.size(); }
+  uint64_t hits = 0, misses = 0;
+ private:
+  int32_t lookup_or_create(const GraphStore& g, const Walk& p);
+  void drain(ShortMate mate[2]);
+  void build_placements(const GraphStore& g, ShortMate& m, int mt, PathMemo& pm, int32_t id);
+  std::vector<std::unique_ptr<PathMemo>> memos_;
+  std::unordered_map<Walk, int32_t, WalkHasher> by_path_;
+  // window key looked up and missed -> memos to invalidate when it gets aligned
+  std::unordered_map<Walk, std::vector<std::pair<int32_t, uint32_t>>, WalkHasher> missed_[2];
+  PlanView view_;
+  std::vector<int32_t> cur_ids_;
+  uint64_t clock_ = 0;
+  static constexpr size_t kMaxMemos = 2048;
+};
 int32_t walk_length(const GraphStore& g, const Walk& w);
 
 bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t>& offs, std::string* err);
