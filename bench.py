@@ -112,20 +112,26 @@ def main():
     rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), b1, o1, b2, o2)
     n_pairs_rank = wl.n_pairs
 
-    stream = torch.cuda.current_stream()
+    # N > 1: the kernels run on a torch side stream (a real, non-null HIP stream) so that the
+    # all-reduce and the D2H copy are ordered after them
+    side = torch.cuda.Stream()
     d_part = torch.zeros(4, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
 
     def step(paths):
         pending, tl = ctx.eval_begin(paths)
-        if world > 1 and pending:
-            # cold path only: newly aligned windows -> all ranks exchange their largest record positions
-            mx = torch.from_numpy(ctx.eval_pending_maxpos().copy()).cuda()
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            ctx.eval_apply_maxpos(mx.cpu().numpy())
-        ctx.eval_finish_async(d_part.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.all_reduce(d_part, op=dist.ReduceOp.SUM)
-        part = d_part.cpu().numpy()  # blocking: CalcProb returns a value
+        if world == 1:
+            part = ctx.eval_finish()  # kernels + 32-B D2H + stream sync inside the library: CalcProb is blocking
+        else:
+            if pending:
+                # cold path only: newly aligned windows -> all ranks exchange their largest record positions
+                mx = torch.from_numpy(ctx.eval_pending_maxpos().copy()).cuda()
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                ctx.eval_apply_maxpos(mx.cpu().numpy())
+            with torch.cuda.stream(side):
+                ctx.eval_finish_async(d_part.data_ptr(), side.cuda_stream)
+                dist.all_reduce(d_part, op=dist.ReduceOp.SUM)  # the one collective of the hot path
+                part = d_part.cpu().numpy()  # blocking
         prob, zeros = ctx.combine_partials(part, tl)
         return prob, zeros
 
@@ -180,6 +186,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "paired_score_kernel", "kernel_us": kern_us, "algo_bytes_per_launch": bytes_per_launch},
             "log_likelihood": last[0], "prime_s": prime_s,
+            "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
+            "timing_last_step_us": ctx.last_timing(),
         }
         if not args.no_cpu_baseline:
             sample = min(args.cpu_sample_pairs, n_pairs_rank)

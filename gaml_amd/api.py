@@ -90,6 +90,7 @@ def _load():
     L.gaml_hip_eval_apply_maxpos.argtypes = [vp, _i32p, C.c_int64]
     L.gaml_hip_eval_finish.argtypes = [vp, _f64p]
     L.gaml_hip_eval_finish_async.argtypes = [vp, vp, vp]
+    L.gaml_hip_sync.argtypes = [vp]
     L.gaml_hip_num_readsets.argtypes = [vp]
     L.gaml_hip_readset_kind.argtypes = [vp, C.c_int]
     L.gaml_hip_readset_reads.argtypes = [vp, C.c_int]
@@ -109,6 +110,7 @@ def _load():
     L.gaml_hip_debug_occurrences.restype = C.c_int64
     L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
+    L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
     L.gaml_hip_last_timing.argtypes = [vp, _f64p]
     L.gaml_hip_set_event_timing.argtypes = [vp, C.c_int]
     L.gaml_hip_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -267,6 +269,9 @@ class Context:
     def eval_finish_async(self, d_partials_ptr: int, stream_ptr: int = 0):
         self._check(_lib.gaml_hip_eval_finish_async(self._h, C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))
 
+    def sync(self):
+        self._check(_lib.gaml_hip_sync(self._h))
+
     def combine_partials(self, partials, total_len):
         part = np.ascontiguousarray(partials, np.float64).reshape(-1)
         prob = C.c_double()
@@ -335,6 +340,9 @@ class Context:
             buf = np.zeros(n, np.int32)
             _lib.gaml_hip_debug_window_walk(self._h, rs, mate, wid, buf, n)
         return [int(x) for x in buf[:n]]
+
+    def debug_set_knob(self, knob, value):
+        self._check(_lib.gaml_hip_debug_set_knob(self._h, knob, value))
 
     def debug_class_counts(self, rs):
         out = np.zeros(4, np.int64)

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <set>
@@ -65,8 +66,8 @@ struct Reducer {  // per read set: partials + ticket + 2-double result
   DevBuf part_sum, part_zero, ticket, out;
   hipError_t init() {
     hipError_t e;
-    if ((e = part_sum.reserve((kMaxBlocks + kOvfBlocks) * sizeof(double))) != hipSuccess) return e;
-    if ((e = part_zero.reserve((kMaxBlocks + kOvfBlocks) * sizeof(int))) != hipSuccess) return e;
+    if ((e = part_sum.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(double))) != hipSuccess) return e;
+    if ((e = part_zero.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(int))) != hipSuccess) return e;
     if ((e = ticket.reserve(sizeof(unsigned))) != hipSuccess) return e;
     if ((e = out.reserve(4 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipMemset(ticket.p, 0, sizeof(unsigned))) != hipSuccess) return e;
@@ -87,7 +88,11 @@ struct PairedSet {
   ShortMate mate[2];
   ReadMajor rm[2];
   MateDev dev[2];
-  DevBuf len12, probs, tabs, occ_arena, cov_bits, cov_meta, bad, ovf_cnt, ovf_list;
+  DevBuf len12, probs, tabs, occ_arena, cov_bits, cov_meta, bad;
+  std::vector<uint32_t> ovf_stamp;  // per slot: evaluation serial that last put it on the overflow list
+  uint32_t ovf_serial = 0;
+  std::vector<int32_t> ovf_items;
+  hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;
   PairedPlanner planner;
   std::vector<Occ> scratch_occ[2];
   std::vector<int32_t> slot_of_read, read_of_slot;  // device order of pairs (by record-count class)
@@ -143,6 +148,7 @@ struct SetRef { int kind, idx; };
 struct gaml_hip_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t aux_stream = nullptr;  // the overflow kernel runs beside the main kernel
   GraphStore g;
   bool have_graph = false;
   std::vector<std::unique_ptr<SingleSet>> singles;
@@ -150,6 +156,7 @@ struct gaml_hip_ctx {
   std::vector<std::unique_ptr<PacbioSet>> pacbios;
   std::vector<SetRef> handles;  // creation order -> (kind, index)
   int32_t rank = 0, world = 1;
+  int knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
   int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;
   // timing
@@ -305,13 +312,23 @@ std::vector<Walk> unflatten(const int32_t* flat, const int64_t* offs, int32_t n)
 int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
   if (s.tabs_uploaded) return 0;
   const double c0 = s.cfg.min_prob_start, k0 = s.cfg.min_prob_per_base;
-  int n_ins = (int)(s.cfg.insert_mean + 5 * s.cfg.insert_std);  // graph.cc:1801
-  if (n_ins < 0) n_ins = 0;
-  s.ins_tab.resize(n_ins);
-  for (int i = 0; i < n_ins; i++) {
-    double z = ((double)i - s.cfg.insert_mean) / s.cfg.insert_std;  // graph.cc:1593-1598
-    s.ins_tab[i] = std::exp(-z * z / 2.0) / (std::sqrt(2 * M_PI) * s.cfg.insert_std);
+  // The reference tabulates GetInsertProbability for d < mean + 5 sd (graph.cc:1801-1804) and calls
+  // the same function directly beyond (:1877-1882). Same formula, so one host table serves both;
+  // it is extended until the f64 value is exactly 0.0 (exp underflows at z ~ 38.6; it is
+  // monotone beyond the mean, so everything further is 0.0 too). No exp() on the device.
+  auto ins = [&](int d) {
+    double z = ((double)d - s.cfg.insert_mean) / s.cfg.insert_std;  // graph.cc:1593-1598
+    return std::exp(-z * z / 2.0) / (std::sqrt(2 * M_PI) * s.cfg.insert_std);
+  };
+  const int kInsCap = 1 << 22;
+  s.ins_tab.clear();
+  for (int d = 0; d < kInsCap; d++) {
+    double v = ins(d);
+    if (v == 0.0 && (double)d > s.cfg.insert_mean) break;
+    s.ins_tab.push_back(v);
   }
+  if ((int)s.ins_tab.size() >= kInsCap)
+    return fail(c, GAML_HIP_EINVAL, "insert_std too large: the insert-size table would exceed 4M entries");
   int smax = s.mate[0].max_len + s.mate[1].max_len;
   s.floor_tab.resize(smax + 1);
   s.logfloor_tab.resize(smax + 1);
@@ -382,7 +399,7 @@ void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>&
   prepare_paired_tables_host(c, s, p);
 }
 
-int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p, int32_t total_len, hipStream_t st) {
+int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p, int32_t total_len, hipStream_t st, double* out4) {
   if (int e = prepare_paired_tables(c, s)) return e;
   prepare_paired_tables_host(c, s, p);  // pass 2 (pass 1 ran in eval_begin)
   const double t_after_host = now_us();
@@ -410,11 +427,36 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     st_off = align16(so_off + p.start_off.size() * sizeof(int32_t));
     total = align16(st_off + p.starts.size() * sizeof(int32_t));
   }
+  // pairs (main-kernel slots) with a record in a window that occurs several times: the main kernel
+  // skips them, the overflow kernel scores them. O(records of such windows); empty for most path sets.
+  {
+    const int64_t n_main_slots = s.class_count[0] + s.class_count[1];
+    s.ovf_items.clear();
+    if (s.ovf_stamp.size() != (size_t)s.mate[0].n_local()) s.ovf_stamp.assign(s.mate[0].n_local(), 0);
+    if (++s.ovf_serial == 0) { std::fill(s.ovf_stamp.begin(), s.ovf_stamp.end(), 0); s.ovf_serial = 1; }
+    for (int mt = 0; mt < 2; mt++) {
+      if (p.occ[mt].multi.empty()) continue;
+      const ShortMate& m = s.mate[mt];
+      for (size_t w = 0; w < p.occ[mt].direct.size(); w++) {
+        const OccQuad& q = p.occ[mt].direct[w];
+        if (q.path < 0 || q.rank >= 0) continue;
+        const Window& win = m.wins[w];
+        for (int64_t k = win.first; k < win.first + win.count; k++) {
+          const int32_t slot_i = s.slot_of_read[m.pool[k].read_id];
+          if (slot_i < n_main_slots && s.ovf_stamp[slot_i] != s.ovf_serial) { s.ovf_stamp[slot_i] = s.ovf_serial; s.ovf_items.push_back(slot_i); }
+        }
+      }
+    }
+    std::sort(s.ovf_items.begin(), s.ovf_items.end());  // fixed item order = fixed summation order
+  }
+  const size_t ov_off = total;
+  total = align16(ov_off + std::max<size_t>(1, s.ovf_items.size()) * sizeof(int32_t));
   void* host = nullptr;
   int slot = stage_acquire(c, s.stage, total, &host);
   if (slot < 0) return slot;
   pack_occ(p.occ[0], l0, (char*)host);
   pack_occ(p.occ[1], l1, (char*)host);
+  if (!s.ovf_items.empty()) memcpy((char*)host + ov_off, s.ovf_items.data(), s.ovf_items.size() * sizeof(int32_t));
   if (cov) {
     memcpy((char*)host + pb_off, p.path_base.data(), p.path_base.size() * sizeof(int32_t));
     memcpy((char*)host + so_off, p.start_off.data(), p.start_off.size() * sizeof(int32_t));
@@ -434,7 +476,6 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   a.len12 = s.len12.as<uint32_t>();
   const double* tabs = s.tabs.as<double>();
   a.ins_tab = tabs; a.ins_n = (int)s.ins_tab.size();
-  a.ins_mean = s.cfg.insert_mean; a.ins_sd = s.cfg.insert_std;
   a.floor_tab = tabs + s.ins_tab.size();
   a.logfloor_tab = a.floor_tab + s.floor_tab.size();
   a.covthr_tab = a.logfloor_tab + s.logfloor_tab.size();
@@ -454,31 +495,41 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   a.part_sum = s.red.part_sum.as<double>();
   a.part_zero = s.red.part_zero.as<int>();
   a.ticket = s.red.ticket.as<unsigned>();
-  a.out = s.red.out.as<double>();
-  const int main_blocks = grid_for(n);
-  a.main_waves = main_blocks * (kBlock / 64);
-  a.ovf_cap = 64 * (int)((n + (int64_t)main_blocks * kBlock - 1) / ((int64_t)main_blocks * kBlock));
-  if (a.ovf_cap < 64) a.ovf_cap = 64;
-  {
-    const size_t need_cnt = (size_t)a.main_waves * sizeof(int), need_list = (size_t)a.main_waves * a.ovf_cap * sizeof(int);
-    if (need_cnt > s.ovf_cnt.cap || need_list > s.ovf_list.cap) {
-      HIP_TRY(c, hipStreamSynchronize(st));
-      HIP_TRY(c, s.ovf_cnt.reserve(need_cnt));
-      HIP_TRY(c, s.ovf_list.reserve(need_list));
-    }
-  }
-  a.ovf_cnt = s.ovf_cnt.as<int>();
-  a.ovf_list = s.ovf_list.as<int>();
+  a.out = out4;
+  a.n_reads = (double)n;
+  // main kernel: pairs with <= 2 records per mate; overflow kernel: the rest + pairs touching a
+  // window that occurs several times (list built below, same rule as the main kernel's skip)
+  const int64_t n_main = s.class_count[0] + s.class_count[1];
+  a.n_main = (int)n_main;
+  a.ovf_items = (const int*)(arena + ov_off);
+  a.n_ovf_items = (int)s.ovf_items.size();
+  const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size();
+  int main_blocks = grid_for(n_main);
+  if (c->knobs[0] > 0) main_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_main + kBlock - 1) / kBlock, c->knobs[0]));
+  const int ovf_blocks = ovf_total > 0 ? (int)std::min<int64_t>((ovf_total + 3) / 4, kOvfMaxBlocks) : 0;
+  a.main_blocks = main_blocks;
+  a.total_blocks = main_blocks + ovf_blocks;
 
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  if (c->event_timing) { if (int e = take_events(c, &ev)) return e; HIP_TRY(c, hipEventRecord(ev->first, st)); }
   if (n > 0) {
-    hipLaunchKernelGGL(paired_score_kernel, dim3(main_blocks), dim3(kBlock), 0, st, a);
+    // HIP events bracket the dominant kernel only (bench.py's roofline; rocprofv3 must agree)
+    if (c->event_timing) { if (int e = take_events(c, &ev)) return e; HIP_TRY(c, hipEventRecord(ev->first, st)); }
+    const int fin_mode = c->knobs[2] ? c->knobs[2] - 1 : 1;  // default: separate finisher kernel (2048 same-address tickets cost ~20 us)
+    const int dyn_lds = c->knobs[1];  // experiment: occupancy limiter
+    const dim3 grid(a.total_blocks), block(kBlock);
+    if (c->knobs[3] == 1) hipLaunchKernelGGL((paired_score_kernel<false, 1>), grid, block, dyn_lds, st, a);
+    else if (c->knobs[3] == 2) hipLaunchKernelGGL((paired_score_kernel<false, 2>), grid, block, dyn_lds, st, a);
+    else if (c->knobs[3] == 3) hipLaunchKernelGGL((paired_score_kernel<false, 3>), grid, block, dyn_lds, st, a);
+    else if (fin_mode) hipLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, a);
+    else hipLaunchKernelGGL((paired_score_kernel<true, 0>), grid, block, dyn_lds, st, a);
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(paired_overflow_kernel, dim3(kOvfBlocks), dim3(kBlock), 0, st, a, main_blocks);
-    HIP_TRY(c, hipGetLastError());
+    if (ev) HIP_TRY(c, hipEventRecord(ev->second, st));
+    if (fin_mode) {
+      hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, a.total_blocks, out4, cov ? -1.0 : 0.0, (double)n);
+      HIP_TRY(c, hipGetLastError());
+    }
   } else {
-    HIP_TRY(c, hipMemsetAsync(s.red.out.p, 0, 2 * sizeof(double), st));
+    HIP_TRY(c, hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
   }
   if (cov && n > 0 && p.total_bits > 0) {
     CovArgs ca;
@@ -494,7 +545,10 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     hipLaunchKernelGGL(coverage_sweep_kernel, dim3(grid_for(ca.total_words)), dim3(kBlock), 0, st, ca);
     HIP_TRY(c, hipGetLastError());
   }
-  if (ev) HIP_TRY(c, hipEventRecord(ev->second, st));
+  if (cov && n > 0) {
+    hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), out4);
+    HIP_TRY(c, hipGetLastError());
+  }
   // SURVEY.md 8d accounting: 16 B per record, 8 B read lengths, 8 B probability written, per pair
   c->stat_algo_bytes += 16.0 * (double)p.assembled_records + 16.0 * (double)n;
   c->stat_launches++;
@@ -526,7 +580,7 @@ int32_t prepare_single_host(gaml_hip_ctx* c, SingleSet& s, const std::vector<Wal
   return tl;
 }
 
-int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths, int32_t total_len, hipStream_t st) {
+int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths, int32_t total_len, hipStream_t st, double* out4) {
   if (!s.tabs_uploaded) {
     const int lmax = s.mate.max_len;
     s.floor_tab.resize(lmax + 1); s.logfloor_tab.resize(lmax + 1);
@@ -570,12 +624,13 @@ int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths,
   a.n = (int)n;
   a.probs = s.probs.as<double>();
   a.part_sum = s.red.part_sum.as<double>(); a.part_zero = s.red.part_zero.as<int>();
-  a.ticket = s.red.ticket.as<unsigned>(); a.out = s.red.out.as<double>();
+  a.ticket = s.red.ticket.as<unsigned>(); a.out = out4;
+  a.n_reads = (double)n;
   if (n > 0) {
     hipLaunchKernelGGL(single_score_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, a);
     HIP_TRY(c, hipGetLastError());
   } else {
-    HIP_TRY(c, hipMemsetAsync(s.red.out.p, 0, 2 * sizeof(double), st));
+    HIP_TRY(c, hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
   }
   c->stat_algo_bytes += 16.0 * (double)s.rm.total_records + 12.0 * (double)n;  // 16k + 4 + 8 per read
   c->stat_launches++;
@@ -586,7 +641,7 @@ int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths,
 // ---------------------------------------------------------------------------------------
 // PacBio read set (CalcScoreForPacbio graph.cc:3171-3261)
 // ---------------------------------------------------------------------------------------
-int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_in, hipStream_t st) {
+int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_in, hipStream_t st, double* out4) {
   const int64_t n = s.hi - s.lo;
   if (!s.red.part_sum.p) {
     HIP_TRY(c, s.red.init());
@@ -697,13 +752,14 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
   a.n = (int)n;
   a.logprobs = s.logprobs.as<double>();
   a.part_sum = s.red.part_sum.as<double>(); a.part_zero = s.red.part_zero.as<int>();
-  a.ticket = s.red.ticket.as<unsigned>(); a.out = s.red.out.as<double>();
+  a.ticket = s.red.ticket.as<unsigned>(); a.out = out4;
+  a.n_reads = (double)n; a.bad_bases = (double)bad_bases;
   if (n > 0) {
     int64_t threads = n * 64;  // one wave per read
     hipLaunchKernelGGL(pacbio_score_kernel, dim3(grid_for(threads)), dim3(kBlock), 0, st, a);
     HIP_TRY(c, hipGetLastError());
   } else {
-    HIP_TRY(c, hipMemsetAsync(s.red.out.p, 0, 2 * sizeof(double), st));
+    HIP_TRY(c, hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
   }
   int64_t nrec = 0;
   for (auto& v : s.recs) nrec += (int64_t)v.size();
@@ -711,17 +767,6 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
   c->stat_launches++;
   c->t_host_us += t_after_host;
   return 0;
-}
-
-// gather {sum_log, zeros, bad_bases, n} of every read set into one packed device array
-struct PackArgs { const double* out[64]; const unsigned long long* bad[64]; double host_bad[64]; double n[64]; int count; double* dst; };
-__global__ void pack_partials_kernel(PackArgs a) {
-  int i = threadIdx.x;
-  if (i >= a.count) return;
-  a.dst[4 * i + 0] = a.out[i][0];
-  a.dst[4 * i + 1] = a.out[i][1];
-  a.dst[4 * i + 2] = a.bad[i] ? (double)*a.bad[i] : a.host_bad[i];
-  a.dst[4 * i + 3] = a.n[i];
 }
 
 std::vector<ShortMate*> filter_mates(gaml_hip_ctx* c) {  // mates whose windows feed a position filter, in handle order
@@ -772,39 +817,19 @@ int eval_finish(gaml_hip_ctx* c, void* d_partials, hipStream_t st) {
   const std::vector<Walk>& paths = c->pending_paths;
   const int32_t total_len = c->pending_total_len;
   auto order = scoring_order(c);
-  if (order.size() > 64) return fail(c, GAML_HIP_EINVAL, "more than 64 read sets");
-  PackArgs pa;
-  pa.count = (int)order.size();
-  pa.dst = (double*)d_partials;
   const double t0 = now_us();
   c->t_host_us = 0;
   int k = 0;
   for (auto& h : order) {
     const double tk = now_us();
+    double* out4 = (double*)d_partials + 4 * k;  // every scorer's last block writes its 4 partials here
     int e = 0;
-    pa.bad[k] = nullptr; pa.host_bad[k] = 0;
-    if (h.kind == 0) {
-      SingleSet& s = *c->singles[h.idx];
-      e = launch_single(c, s, paths, total_len, st);
-      pa.out[k] = s.red.out.as<double>(); pa.n[k] = (double)s.mate.n_local();
-    } else if (h.kind == 1) {
-      PairedSet& s = *c->paireds[h.idx];
-      e = launch_paired(c, s, paths, *c->pending_prep[h.idx], total_len, st);
-      pa.out[k] = s.red.out.as<double>(); pa.n[k] = (double)s.mate[0].n_local();
-      if (s.cfg.penalty_constant > 0) pa.bad[k] = s.bad.as<unsigned long long>();
-    } else {
-      PacbioSet& s = *c->pacbios[h.idx];
-      e = launch_pacbio(c, s, paths, st);
-      pa.out[k] = s.red.out.as<double>(); pa.n[k] = (double)(s.hi - s.lo);
-      pa.host_bad[k] = (double)s.last_bad_bases;
-    }
+    if (h.kind == 0) e = launch_single(c, *c->singles[h.idx], paths, total_len, st, out4);
+    else if (h.kind == 1) e = launch_paired(c, *c->paireds[h.idx], paths, *c->pending_prep[h.idx], total_len, st, out4);
+    else e = launch_pacbio(c, *c->pacbios[h.idx], paths, st, out4);
     if (e) return e;
     c->t_host_us -= tk;  // launch_* added its "host part finished" stamp
     k++;
-  }
-  if (pa.count > 0) {
-    hipLaunchKernelGGL(pack_partials_kernel, dim3(1), dim3(64), 0, st, pa);
-    HIP_TRY(c, hipGetLastError());
   }
   c->t_dev_wall_us = now_us() - t0 - c->t_host_us;
   c->t_host_us += c->pending_host_us;
@@ -872,6 +897,7 @@ int gaml_hip_create(gaml_hip_ctx** out, int device) {
     }
     if (hipSetDevice(device) != hipSuccess) return GAML_HIP_EHIP;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return GAML_HIP_EHIP;
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) return GAML_HIP_EHIP;
   }
   *out = c.release();
   return GAML_HIP_OK;
@@ -886,13 +912,14 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); }
-      s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->cov_meta.release(); s->bad.release(); s->ovf_cnt.release(); s->ovf_list.release();
+      s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->cov_meta.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); s->bad_host.release(); drop_stage(s->stage);
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage); }
     c->packed.release(); c->packed_host.release();
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   }
   delete c;
 }
@@ -1088,6 +1115,13 @@ int gaml_hip_eval_finish_async(gaml_hip_ctx* c, void* d_partials, void* stream) 
   return eval_finish(c, d_partials, stream ? (hipStream_t)stream : c->stream);
 }
 
+int gaml_hip_sync(gaml_hip_ctx* c) {
+  if (!c || c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "no device");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return GAML_HIP_OK;
+}
+
 static int fetch_partials(gaml_hip_ctx* c, double* partials_out);
 
 int gaml_hip_eval_finish(gaml_hip_ctx* c, double* partials_out) {
@@ -1255,6 +1289,12 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wi
   const Walk& w = *m->win_walk[wid];
   for (int32_t i = 0; i < (int32_t)w.size() && i < cap; i++) out[i] = w[i];
   return (int32_t)w.size();
+}
+
+int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
+  if (!c || knob < 0 || knob >= 8) return GAML_HIP_EINVAL;
+  c->knobs[knob] = value;
+  return GAML_HIP_OK;
 }
 
 int gaml_hip_debug_class_counts(gaml_hip_ctx* c, int rs, int64_t* out4) {

@@ -30,9 +30,8 @@ struct MateView {
 struct PairedArgs {
   MateView m[2];
   const uint32_t* len12;     // L1 | L2<<16 per pair
-  const double* ins_tab;     // insert-size Gaussian for d in [0, ins_n) (graph.cc:1801-1804)
-  int ins_n;
-  double ins_mean, ins_sd;
+  const double* ins_tab;     // insert-size Gaussian (graph.cc:1593-1598, 1801-1804) for d in [0, ins_n); the
+  int ins_n;                 // host extends the table until the f64 value is exactly 0.0, so beyond it: 0.0
   const double* floor_tab;   // exp(c + k*s), s = L1+L2 (graph.cc:1506-1507), host libm
   const double* logfloor_tab;// log(floor_tab[s]), host libm
   const double* covthr_tab;  // exp(c + k*2*L2) indexed by L2 (graph.cc:1855-1857 quirk), or null
@@ -41,23 +40,16 @@ struct PairedArgs {
   double* probs;             // out: per-pair summed probability (ScoringState::probs)
   uint32_t* cov_bits;        // coverage marks (only when penalty_constant > 0), else null
   const int* path_base;      // bit offset of each path in cov_bits
-  int* ovf_cnt;              // per main-kernel wave: number of pairs it deferred to the overflow kernel
-  int* ovf_list;             // per main-kernel wave: ovf_cap slots (filled in lane order: deterministic)
-  int ovf_cap;
-  int main_waves;
+  int n_main;                // the main kernel scores slots [0, n_main): pairs with <= 2 records per mate
+  const int* ovf_items;      // host-built list: slots < n_main that touch a window occurring several times
+  int n_ovf_items;           // the overflow kernel scores slots [n_main, n) and this list
+  int main_blocks, total_blocks;  // grid sizes: partial slots [0, main_blocks) main, then overflow
   double* part_sum;          // per-block partials: main kernel blocks, then overflow kernel blocks
   int* part_zero;
   unsigned* ticket;          // zero before first launch; the last block resets it
-  double* out;               // out[0] = sum of logs, out[1] = floored reads
+  double* out;               // the read set's 4 partials {sum of logs, floored reads, bad_bases, reads}
+  double n_reads;
 };
-
-__device__ __forceinline__ double insert_prob_dev(double len, double mean, double sd) {
-  // GetInsertProbability graph.cc:1593-1598 (device exp: <= 1 ulp from glibc)
-  double z = (len - mean) / sd;
-  double e = exp(-z * z / 2.0);
-  double c = sqrt(2 * 3.14159265358979323846) * sd;
-  return e / c;
-}
 
 struct Cand { int path, pos, edit, orient, rank, k; bool valid; };
 
@@ -116,7 +108,7 @@ __device__ __forceinline__ double pair_term(const PairedArgs& a, const Cand& x, 
   }
   double p1 = a.m[0].mism_pow[x.edit] * a.m[0].match_pow[L1 - x.edit];
   double p2 = a.m[1].mism_pow[y.edit] * a.m[1].match_pow[L2 - y.edit];
-  double ip = (unsigned)dist < (unsigned)a.ins_n ? a.ins_tab[dist] : insert_prob_dev((double)dist, a.ins_mean, a.ins_sd);
+  double ip = (unsigned)dist < (unsigned)a.ins_n ? a.ins_tab[dist] : 0.0;
   double t = p1 * p2 * ip;
   if (a.cov_bits && t > a.covthr_tab[L2]) {  // coverage events at both ends (use_all_to_cov, graph.cc:1883-1888)
     int base = a.path_base[x.path];
@@ -160,26 +152,37 @@ __device__ __forceinline__ void block_reduce(double& s, int& z, double* sh_s, in
 // grid-level finish: every block publishes its partial; the last block to arrive sums
 // n_partials partials in index order (deterministic), writes out[0..1] and resets the ticket.
 __device__ __forceinline__ void grid_finish(double s, int z, int my_slot, int n_partials, double* part_sum, int* part_zero,
-                                            unsigned* ticket, double* out, double* sh_s, int* sh_z) {
+                                            unsigned* ticket, double* out, double bad_bases, double n_reads, double* sh_s, int* sh_z) {
+  // n_partials = number of blocks (of ALL kernels sharing this ticket) = number of partial slots
+  // Hand-off without a release fence: a full __threadfence() here writes back AND invalidates the
+  // XCD's L2 once per block, which evicts the shared tables for every block still streaming. The
+  // partials are stored write-through at agent scope (sc1), drained with vmcnt(0), then the
+  // ticket is taken with a relaxed agent-scope add; the last block reads them back with
+  // agent-scope loads (guide section 6, Guideline 16, "sc1 slab stores").
   __shared__ bool is_last;
   if (threadIdx.x == 0) {
-    part_sum[my_slot] = s;
-    part_zero[my_slot] = z;
-    __threadfence();  // release the partial at agent scope before taking a ticket
-    unsigned t = atomicAdd(ticket, 1u);
-    is_last = (t == gridDim.x - 1);
+    __hip_atomic_store(&part_sum[my_slot], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part_zero[my_slot], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == (unsigned)n_partials - 1);
   }
   __syncthreads();
   if (!is_last) return;
-  __threadfence();  // acquire side
   double ts = 0; int tz = 0;
-  for (int b = threadIdx.x; b < n_partials; b += kBlock) { ts += part_sum[b]; tz += part_zero[b]; }
+  for (int b = threadIdx.x; b < n_partials; b += kBlock) {
+    ts += __hip_atomic_load(&part_sum[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tz += __hip_atomic_load(&part_zero[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
   block_reduce(ts, tz, sh_s, sh_z);
   if (threadIdx.x == 0) {
+    // the read set's 4 partials {sum of logs, floored reads, bad_bases, reads}: ready for one D2H / all-reduce
     out[0] = ts;
     out[1] = (double)tz;
-    *ticket = 0;
+    if (bad_bases >= 0) out[2] = bad_bases;  // < 0: a later kernel (coverage sweep) fills it
+    out[3] = n_reads;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -245,69 +248,76 @@ __device__ __forceinline__ double score_regs(const PairedArgs& a, const RegCands
 }
 
 // Main kernel: one lane per read pair, pairs pre-sorted by record-count class so that a wave is
-// homogeneous. Pairs that need more than 4 records per mate, or a window that occurs several
-// times in the path set, are appended to the overflow list for paired_overflow_kernel.
-__global__ __launch_bounds__(kBlock) void paired_score_kernel(PairedArgs a) {
-  __shared__ double sh_s[kBlock / 64];
-  __shared__ int sh_z[kBlock / 64];
+// homogeneous; covers the pairs with at most 2 records per mate (slots [0, n_main)). A pair that
+// touches a window occurring several times in the path set is skipped here: the host put it on
+// the overflow list (same rule on both sides: any record, either mate, whose window entry has
+// path >= 0 and rank < 0).
+// ABL > 0: timing-only ablations for tools/kbench.py (results are wrong on purpose):
+//   1 = stream the records and lengths, write probs, nothing else; 2 = + occurrence lookups;
+//   3 = + pair terms (tables), but no floor / log
+template <bool TICKET, int ABL = 0>
+__device__ __forceinline__ void paired_main_body(const PairedArgs& a, double* sh_s, int* sh_z) {
   double lsum = 0.0;
   int zeros = 0;
-  const int lane = threadIdx.x & 63;
-  const int wave_id = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-  int* my_list = a.ovf_list + (size_t)wave_id * a.ovf_cap;
-  int my_ovf = 0;  // wave-uniform
-  for (int base = blockIdx.x * kBlock; base < a.n; base += gridDim.x * kBlock) {  // block-uniform trip count
-    const int i = base + threadIdx.x;
-    const bool active = i < a.n;
-    int4 r1 = make_int4(-1, 0, 0, 0), r2 = make_int4(-1, 0, 0, 0);
-    uint32_t l12 = 0;
-    if (active) { r1 = a.m[0].first[i]; r2 = a.m[1].first[i]; l12 = a.len12[i]; }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_main; i += a.main_blocks * kBlock) {
+    const int4 r1 = a.m[0].first[i];
+    const int4 r2 = a.m[1].first[i];
+    const uint32_t l12 = a.len12[i];
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     double acc = 0.0;
-    bool defer = false;
-    if (r1.x >= 0 && r2.x >= 0) {
-      const int extra = (int)(((unsigned)r1.z | (unsigned)r2.z) >> 9);  // >0 iff some mate has >1 record
-      if (extra == 0) {
-        const int4 o1 = a.m[0].occ[r1.x];
-        const int4 o2 = a.m[1].occ[r2.x];
-        if (o1.z >= 0 && o2.z >= 0) {
-          if (o1.w < 0 || o2.w < 0) defer = true;
-          else if (o1.z == o2.z && r1.y >= o1.y && r2.y >= o2.y)
-            acc = pair_term(a, make_cand(r1, o1, 0), make_cand(r2, o2, 0), L1, L2);
-        }
-      } else {
-        const int c1 = 1 + (int)((unsigned)r1.z >> 9), c2 = 1 + (int)((unsigned)r2.z >> 9);
-        if (c1 > 4 || c2 > 4) defer = true;
-        else if (c1 <= 2 && c2 <= 2) {
-          RegCands<2> x, y;
-          bool m1 = load_cands<2>(a.m[0], r1, x), m2 = load_cands<2>(a.m[1], r2, y);
-          if (m1 || m2) defer = true; else acc = score_regs<2>(a, x, y, L1, L2);
-        } else {
-          RegCands<4> x, y;
-          bool m1 = load_cands<4>(a.m[0], r1, x), m2 = load_cands<4>(a.m[1], r2, y);
-          if (m1 || m2) defer = true; else acc = score_regs<4>(a, x, y, L1, L2);
-        }
-      }
+    bool skip = false;
+    if (ABL == 1) { a.probs[i] = (double)(r1.y + r2.y + L1 + L2); lsum += (double)r1.x; continue; }
+    if (ABL == 2) {
+      const int4 o1 = r1.x >= 0 ? a.m[0].occ[r1.x] : make_int4(0, 0, -1, 0);
+      const int4 o2 = r2.x >= 0 ? a.m[1].occ[r2.x] : make_int4(0, 0, -1, 0);
+      a.probs[i] = (double)(r1.y + o1.x + r2.y + o2.x + L1 + L2); lsum += (double)(o1.z + o2.w); continue;
     }
-    // deferred pairs go to this wave's own list in lane order (no atomics: the list, and with it
-    // the overflow kernel's summation order, is the same in every run)
-    const unsigned long long dm = __ballot(defer);
-    if (defer) my_list[my_ovf + __popcll(dm & ((1ull << lane) - 1))] = i;
-    my_ovf += __popcll(dm);
-    if (active && !defer) finish_read(a, i, acc, L1, L2, lsum, zeros);
+    const int extra = (int)(((unsigned)r1.z | (unsigned)r2.z) >> 9);  // >0 iff some mate has 2 records
+    if (extra == 0) {
+      const int4 o1 = r1.x >= 0 ? a.m[0].occ[r1.x] : make_int4(0, 0, -1, 0);
+      const int4 o2 = r2.x >= 0 ? a.m[1].occ[r2.x] : make_int4(0, 0, -1, 0);
+      skip = (o1.z >= 0 && o1.w < 0) || (o2.z >= 0 && o2.w < 0);
+      if (!skip && o1.z >= 0 && o1.z == o2.z && r1.y >= o1.y && r2.y >= o2.y)
+        acc = pair_term(a, make_cand(r1, o1, 0), make_cand(r2, o2, 0), L1, L2);
+    } else {
+      RegCands<2> x, y;
+      const bool m1 = load_cands<2>(a.m[0], r1, x), m2 = load_cands<2>(a.m[1], r2, y);
+      skip = m1 || m2;
+      if (!skip) acc = score_regs<2>(a, x, y, L1, L2);
+    }
+    if (ABL == 3) { a.probs[i] = acc; lsum += acc; continue; }
+    if (!skip) finish_read(a, i, acc, L1, L2, lsum, zeros);
   }
-  if (lane == 0) a.ovf_cnt[wave_id] = my_ovf;
   block_reduce(lsum, zeros, sh_s, sh_z);
-  if (threadIdx.x == 0) { a.part_sum[blockIdx.x] = lsum; a.part_zero[blockIdx.x] = zeros; }
+  if (TICKET) {
+    grid_finish(lsum, zeros, blockIdx.x, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out,
+                a.cov_bits ? -1.0 : 0.0, a.n_reads, sh_s, sh_z);
+  } else if (threadIdx.x == 0) {
+    a.part_sum[blockIdx.x] = lsum;
+    a.part_zero[blockIdx.x] = zeros;
+  }
 }
 
-// Overflow kernel: one WAVE per deferred pair. The wave gathers every (record, occurrence)
-// candidate of both mates into LDS, settles the overwrite rule in parallel and spreads the
-// x * y pair terms over its lanes; deterministic lane-strided + butterfly summation.
-// Launched after paired_score_kernel on the same stream; its last block also folds the
-// per-block partials of both kernels into out[0..1] and resets the overflow counter.
+// experiment: separate one-block finisher (sums n_partials partials in index order)
+__global__ __launch_bounds__(kBlock) void finish_partials_kernel(const double* part_sum, const int* part_zero, int n_partials,
+                                                                 double* out, double bad_bases, double n_reads) {
+  __shared__ double sh_s[kBlock / 64];
+  __shared__ int sh_z[kBlock / 64];
+  double ts = 0; int tz = 0;
+  for (int b = threadIdx.x; b < n_partials; b += kBlock) { ts += part_sum[b]; tz += part_zero[b]; }
+  block_reduce(ts, tz, sh_s, sh_z);
+  if (threadIdx.x == 0) { out[0] = ts; out[1] = (double)tz; if (bad_bases >= 0) out[2] = bad_bases; out[3] = n_reads; }
+}
+
+// Overflow kernel: one WAVE per pair, for the pairs the main kernel leaves out: slots [n_main, n)
+// (more than 2 records on a mate) and the host's list of pairs touching a window that occurs
+// several times. The wave gathers every (record, occurrence) candidate of both mates into LDS,
+// settles the overwrite rule in parallel and spreads the x * y pair terms over its lanes;
+// deterministic lane-strided + butterfly summation. It reads nothing the main kernel writes, so
+// both run concurrently (two streams); they share one ticket, and whichever block finishes last
+// folds all per-block partials in index order.
 constexpr int kOvfCap = 128;     // candidates per mate held in LDS per wave
-constexpr int kOvfBlocks = 64;   // fixed grid: the overflow counts are only known on the device
+constexpr int kOvfMaxBlocks = 1024;
 
 __device__ __forceinline__ int wave_gather(const MateView& v, const int4& r0, int4* lds, int lane) {
   // returns the number of candidates, or -1 if they do not fit
@@ -342,28 +352,18 @@ __device__ __forceinline__ int wave_gather(const MateView& v, const int4& r0, in
   return total;
 }
 
-__global__ __launch_bounds__(kBlock) void paired_overflow_kernel(PairedArgs a, int main_blocks) {
-  __shared__ double sh_s[kBlock / 64];
-  __shared__ int sh_z[kBlock / 64];
-  __shared__ int4 cand[kBlock / 64][2][kOvfCap];
+template <bool TICKET>
+__device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ovf_block, int ovf_blocks, double* sh_s, int* sh_z,
+                                                     int4 (*cand)[2][kOvfCap]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wave_global = blockIdx.x * (kBlock / 64) + wave;
-  const int n_waves = gridDim.x * (kBlock / 64);
+  const int wave_global = ovf_block * (kBlock / 64) + wave;
+  const int n_waves = ovf_blocks * (kBlock / 64);
+  const int n_static = a.n - a.n_main;
+  const int n_items = n_static + a.n_ovf_items;
   double lsum = 0.0;
   int zeros = 0;
-  // static assignment of main-kernel waves to overflow waves: deterministic order of work
-  for (int mw0 = wave_global; mw0 < a.main_waves; mw0 += 64 * n_waves) {
-   // 64 main-kernel waves per step: lane l looks at wave mw0 + l * n_waves
-   const int my_mw = mw0 + lane * n_waves;
-   const int my_cnt = my_mw < a.main_waves ? a.ovf_cnt[my_mw] : 0;
-   unsigned long long todo = __ballot(my_cnt > 0);
-   while (todo) {
-   const int src = __ffsll((long long)todo) - 1;
-   todo &= todo - 1;
-   const int count = __shfl(my_cnt, src, 64);
-   const int mw = mw0 + src * n_waves;
-   for (int item = 0; item < count; item++) {
-    const int i = a.ovf_list[(size_t)mw * a.ovf_cap + item];
+  for (int item = wave_global; item < n_items; item += n_waves) {  // fixed item -> wave assignment
+    const int i = item < n_static ? a.n_main + item : a.ovf_items[item - n_static];
     const int4 r1 = a.m[0].first[i];
     const int4 r2 = a.m[1].first[i];
     const uint32_t l12 = a.len12[i];
@@ -389,8 +389,7 @@ __global__ __launch_bounds__(kBlock) void paired_overflow_kernel(PairedArgs a, i
             if (y != x && (ot.z & 0x200) && ot.x == me.x && ot.y == me.y && (ot.w > me.w || (ot.w == me.w && y > x))) live = false;
           }
           if (live) me.z |= 0x400;
-          // every lane reads the 0x200 (valid) bit only; the live bit 0x400 is written once per slot
-          c[x].z = me.z;
+          c[x].z = me.z;  // readers only test the valid bit 0x200; the live bit 0x400 is written once per slot
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -409,12 +408,27 @@ __global__ __launch_bounds__(kBlock) void paired_overflow_kernel(PairedArgs a, i
       __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) finish_read(a, i, acc, L1, L2, lsum, zeros);
-   }
-   }
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
-  // partial slots: [0, main_blocks) main kernel, then this kernel's blocks
-  grid_finish(lsum, zeros, main_blocks + blockIdx.x, main_blocks + gridDim.x, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
+  if (TICKET) {
+    grid_finish(lsum, zeros, a.main_blocks + ovf_block, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out,
+                a.cov_bits ? -1.0 : 0.0, a.n_reads, sh_s, sh_z);
+  } else if (threadIdx.x == 0) {
+    a.part_sum[a.main_blocks + ovf_block] = lsum;
+    a.part_zero[a.main_blocks + ovf_block] = zeros;
+  }
+}
+
+// ONE launch for a paired read set: blocks [0, main_blocks) run the lane-per-pair path, blocks
+// [main_blocks, total_blocks) the wave-per-pair path (block-uniform branch). They share nothing
+// but read-only tables, so no ordering between them is needed.
+template <bool TICKET, int ABL = 0>
+__global__ __launch_bounds__(kBlock) void paired_score_kernel(PairedArgs a) {
+  __shared__ double sh_s[kBlock / 64];
+  __shared__ int sh_z[kBlock / 64];
+  __shared__ int4 cand[kBlock / 64][2][kOvfCap];
+  if ((int)blockIdx.x < a.main_blocks) paired_main_body<TICKET, ABL>(a, sh_s, sh_z);
+  else paired_overflow_body<TICKET>(a, (int)blockIdx.x - a.main_blocks, a.total_blocks - a.main_blocks, sh_s, sh_z, cand);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -486,6 +500,7 @@ struct SingleArgs {
   int n;
   double* probs;
   double* part_sum; int* part_zero; unsigned* ticket; double* out;
+  double n_reads;
 };
 
 __global__ __launch_bounds__(kBlock) void single_score_kernel(SingleArgs a) {
@@ -513,7 +528,8 @@ __global__ __launch_bounds__(kBlock) void single_score_kernel(SingleArgs a) {
     else lsum += log(p);
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
-  grid_finish(lsum, zeros, blockIdx.x, gridDim.x, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
+  // bad_bases of the single-end scorer is identically 0 (graph.cc:1701-1733)
+  grid_finish(lsum, zeros, blockIdx.x, gridDim.x, a.part_sum, a.part_zero, a.ticket, a.out, 0.0, a.n_reads, sh_s, sh_z);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -533,6 +549,7 @@ struct PacbioArgs {
   int n;
   double* logprobs;          // out: per-read log probability (-inf when no alignment)
   double* part_sum; int* part_zero; unsigned* ticket; double* out;
+  double n_reads, bad_bases;
 };
 
 __device__ __forceinline__ double lse2(double a, double b) {  // logdouble operator+ (logdouble.hpp:37-47)
@@ -568,7 +585,12 @@ __global__ __launch_bounds__(kBlock) void pacbio_score_kernel(PacbioArgs a) {
     }
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
-  grid_finish(lsum, zeros, blockIdx.x, gridDim.x, a.part_sum, a.part_zero, a.ticket, a.out, sh_s, sh_z);
+  grid_finish(lsum, zeros, blockIdx.x, gridDim.x, a.part_sum, a.part_zero, a.ticket, a.out, a.bad_bases, a.n_reads, sh_s, sh_z);
+}
+
+// bad_bases of a paired set with coverage penalty: u64 counter of the sweep -> its partial slot
+__global__ void store_bad_bases_kernel(const unsigned long long* bad, double* out4) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out4[2] = (double)*bad;
 }
 
 }  // namespace gaml

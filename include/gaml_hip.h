@@ -151,10 +151,14 @@ int64_t gaml_hip_eval_pending_maxpos(gaml_hip_ctx* ctx, int32_t* out, int64_t ca
 int gaml_hip_eval_apply_maxpos(gaml_hip_ctx* ctx, const int32_t* reduced, int64_t n);
 int gaml_hip_eval_finish(gaml_hip_ctx* ctx, double* partials_out /* 4 * n_sets */);
 int gaml_hip_eval_finish_async(gaml_hip_ctx* ctx, void* d_partials, void* hip_stream);
+/* wait for everything enqueued on the library's private stream */
+int gaml_hip_sync(gaml_hip_ctx* ctx);
 
 /* Device-resident form for callers that already own a HIP stream (e.g. torch): enqueue the
  * whole evaluation on `stream` and leave the 4*n_sets partials in device memory at
- * d_partials (f64). No host synchronisation. */
+ * d_partials (f64). No host synchronisation. `hip_stream` must be a real stream handle the caller
+ * orders its own work on; NULL selects the library's private stream (then synchronise with
+ * gaml_hip_sync before touching d_partials) -- NOT the legacy default stream. */
 int gaml_hip_calc_partials_async(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths,
                                  void* d_partials, void* hip_stream, int32_t* total_len_out);
 
@@ -185,6 +189,8 @@ int gaml_hip_debug_prepare(gaml_hip_ctx* ctx, const int32_t* paths, const int64_
 int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int32_t* out5, int64_t cap);
 /* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
+/* tuning experiments (tools/kbench.py): 0 = main-kernel grid cap, 1 = dynamic LDS bytes, 2 = finish mode */
+int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
 /* pairs per record-count class of the device table {<=1, <=2, <=4, more} (paired sets) */
 int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);
 
