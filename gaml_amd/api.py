@@ -111,6 +111,7 @@ def _load():
     L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
+    L.gaml_hip_debug_profile.argtypes = [vp, _f64p]
     L.gaml_hip_last_timing.argtypes = [vp, _f64p]
     L.gaml_hip_set_event_timing.argtypes = [vp, C.c_int]
     L.gaml_hip_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -340,6 +341,11 @@ class Context:
             buf = np.zeros(n, np.int32)
             _lib.gaml_hip_debug_window_walk(self._h, rs, mate, wid, buf, n)
         return [int(x) for x in buf[:n]]
+
+    def debug_profile(self):
+        out = np.zeros(8, np.float64)
+        _lib.gaml_hip_debug_profile(self._h, out)
+        return out
 
     def debug_set_knob(self, knob, value):
         self._check(_lib.gaml_hip_debug_set_knob(self._h, knob, value))

@@ -46,7 +46,7 @@ struct PinBuf {
     if (bytes <= cap) return hipSuccess;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     size_t want = std::max(bytes + bytes / 4, (size_t)4096);
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);  // device-visible: kernels may write results here
     if (e == hipSuccess) cap = want;
     return e;
   }
@@ -86,8 +86,12 @@ struct MateDev {
 struct PairedSet {
   gaml_paired_cfg cfg;
   ShortMate mate[2];
-  ReadMajor rm[2];
+  PairTables pt;                      // device order + compact / 16-byte record tables (cold path)
   MateDev dev[2];
+  DevBuf rec8[2], len_code, len_combo, inl[2];
+  PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
+  int last_total_blocks = 0;
+  bool last_host_partials = false;
   DevBuf len12, probs, tabs, occ_arena, cov_bits, cov_meta, bad;
   std::vector<uint32_t> ovf_stamp;  // per slot: evaluation serial that last put it on the overflow list
   uint32_t ovf_serial = 0;
@@ -95,8 +99,7 @@ struct PairedSet {
   hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;
   PairedPlanner planner;
   std::vector<Occ> scratch_occ[2];
-  std::vector<int32_t> slot_of_read, read_of_slot;  // device order of pairs (by record-count class)
-  int64_t class_count[4] = {0, 0, 0, 0};
+  std::vector<uint64_t> occ8[2];
   Reducer red;
   std::vector<double> ins_tab, floor_tab, logfloor_tab, covthr_tab;
   bool tabs_uploaded = false;
@@ -174,6 +177,8 @@ struct gaml_hip_ctx {
   int32_t pending_total_len = 0;
   std::vector<std::unique_ptr<PairedPrep>> pending_prep;  // per paired set
   double pending_host_us = 0;
+  double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // phase stamps of the last blocking call (us): see gaml_hip_debug_profile
+  bool host_results = false;  // blocking call: kernels write their results into pinned host memory, no D2H copy
 };
 
 namespace {
@@ -401,20 +406,39 @@ void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>&
 
 int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p, int32_t total_len, hipStream_t st, double* out4) {
   if (int e = prepare_paired_tables(c, s)) return e;
+  const double tp0 = now_us();
   prepare_paired_tables_host(c, s, p);  // pass 2 (pass 1 ran in eval_begin)
   const double t_after_host = now_us();
-  if (s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation) {
-    // cold path: the cache of either mate changed -> new device order of the pairs, both tables rebuilt
-    pair_device_order(s.mate[0], s.mate[1], s.slot_of_read, s.read_of_slot, s.class_count);
-    for (int mt = 0; mt < 2; mt++)
-      if (int e = upload_mate(c, s.mate[mt], s.rm[mt], s.dev[mt], st, &s.slot_of_read, true)) return e;
-    const int64_t np = s.mate[0].n_local();
-    std::vector<uint32_t> l12(np);
-    for (int64_t j = 0; j < np; j++) {
-      const int32_t i = s.read_of_slot[j];
-      l12[j] = (uint32_t)s.mate[0].lens[i] | ((uint32_t)s.mate[1].lens[i] << 16);
+  c->prof[1] = t_after_host - tp0;  // thresholds + occurrence tables
+  if (s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation ||
+      s.dev[0].pow_n == 0) {
+    // cold path: the set of activated windows of either mate changed -> new device order of the
+    // pairs, record tables rebuilt on the host and uploaded
+    build_pair_tables(s.mate[0], s.mate[1], s.pt);
+    HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old tables
+    auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
+      hipError_t e = d.reserve(std::max<size_t>(16, bytes));
+      if (e != hipSuccess || bytes == 0) return e;
+      return hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    for (int mt = 0; mt < 2; mt++) {
+      MateDev& d = s.dev[mt];
+      const ShortMate& m = s.mate[mt];
+      if (d.pow_n == 0) {
+        d.pow_n = m.match_pow.size();
+        HIP_TRY(c, d.pows.reserve(2 * d.pow_n * sizeof(double)));
+        HIP_TRY(c, hipMemcpy(d.pows.p, m.mismatch_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d.pows.as<double>() + d.pow_n, m.match_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
+      }
+      HIP_TRY(c, up(s.rec8[mt], s.pt.rec8[mt].data(), s.pt.rec8[mt].size() * sizeof(uint64_t)));
+      HIP_TRY(c, up(d.first, s.pt.rm[mt].first.data(), s.pt.rm[mt].first.size() * sizeof(RecQuad)));
+      HIP_TRY(c, up(d.extra, s.pt.rm[mt].extra.data(), s.pt.rm[mt].extra.size() * sizeof(RecQuad)));
+      HIP_TRY(c, up(s.inl[mt], s.pt.inl[mt].data(), s.pt.inl[mt].size() * sizeof(RecQuad)));
+      d.uploaded_generation = m.active_generation;
     }
-    if (np) HIP_TRY(c, hipMemcpy(s.len12.p, l12.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, up(s.len_code, s.pt.len_code.data(), s.pt.len_code.size()));
+    HIP_TRY(c, up(s.len_combo, s.pt.len_combo.data(), s.pt.len_combo.size() * sizeof(uint32_t)));
+    HIP_TRY(c, up(s.len12, s.pt.len12.data(), s.pt.len12.size() * sizeof(uint32_t)));
   }
 
   const bool cov = s.cfg.penalty_constant > 0;
@@ -430,7 +454,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   // pairs (main-kernel slots) with a record in a window that occurs several times: the main kernel
   // skips them, the overflow kernel scores them. O(records of such windows); empty for most path sets.
   {
-    const int64_t n_main_slots = s.class_count[0] + s.class_count[1];
+    const int64_t n_main_slots = s.pt.class_count[0] + s.pt.class_count[1] + s.pt.class_count[2];
     s.ovf_items.clear();
     if (s.ovf_stamp.size() != (size_t)s.mate[0].n_local()) s.ovf_stamp.assign(s.mate[0].n_local(), 0);
     if (++s.ovf_serial == 0) { std::fill(s.ovf_stamp.begin(), s.ovf_stamp.end(), 0); s.ovf_serial = 1; }
@@ -442,7 +466,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
         if (q.path < 0 || q.rank >= 0) continue;
         const Window& win = m.wins[w];
         for (int64_t k = win.first; k < win.first + win.count; k++) {
-          const int32_t slot_i = s.slot_of_read[m.pool[k].read_id];
+          const int32_t slot_i = s.pt.slot_of_read[m.pool[k].read_id];
           if (slot_i < n_main_slots && s.ovf_stamp[slot_i] != s.ovf_serial) { s.ovf_stamp[slot_i] = s.ovf_serial; s.ovf_items.push_back(slot_i); }
         }
       }
@@ -451,12 +475,22 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   }
   const size_t ov_off = total;
   total = align16(ov_off + std::max<size_t>(1, s.ovf_items.size()) * sizeof(int32_t));
+  size_t o8_off[2];
+  for (int mt = 0; mt < 2; mt++) {
+    build_occ8(p.occ[mt], s.occ8[mt]);
+    o8_off[mt] = total;
+    total = align16(total + std::max<size_t>(1, s.occ8[mt].size()) * sizeof(uint64_t));
+  }
+  const double tp1 = now_us();
+  c->prof[2] = tp1 - t_after_host;  // overflow list + occ8
   void* host = nullptr;
   int slot = stage_acquire(c, s.stage, total, &host);
   if (slot < 0) return slot;
   pack_occ(p.occ[0], l0, (char*)host);
   pack_occ(p.occ[1], l1, (char*)host);
   if (!s.ovf_items.empty()) memcpy((char*)host + ov_off, s.ovf_items.data(), s.ovf_items.size() * sizeof(int32_t));
+  for (int mt = 0; mt < 2; mt++)
+    if (!s.occ8[mt].empty()) memcpy((char*)host + o8_off[mt], s.occ8[mt].data(), s.occ8[mt].size() * sizeof(uint64_t));
   if (cov) {
     memcpy((char*)host + pb_off, p.path_base.data(), p.path_base.size() * sizeof(int32_t));
     memcpy((char*)host + so_off, p.start_off.data(), p.start_off.size() * sizeof(int32_t));
@@ -465,8 +499,12 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   // the arena is overwritten in stream order: earlier launches that read it have been enqueued
   // before this copy on the same stream
   if (total > s.occ_arena.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.occ_arena.reserve(total)); }
+  const double tp2 = now_us();
+  c->prof[3] = tp2 - tp1;  // staging memcpy
+  c->prof[6] = (double)total;
   HIP_TRY(c, hipMemcpyAsync(s.occ_arena.p, host, total, hipMemcpyHostToDevice, st));
   if (int e = stage_release(c, s.stage, slot, st)) return e;
+  c->prof[4] = now_us() - tp2;  // H2D enqueue
 
   const int64_t n = s.mate[0].n_local();
   const char* arena = (const char*)s.occ_arena.p;
@@ -494,18 +532,45 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   }
   a.part_sum = s.red.part_sum.as<double>();
   a.part_zero = s.red.part_zero.as<int>();
+  if (c->host_results) {
+    // blocking call: every block stores its partial straight into pinned host memory; the host adds
+    // them up in the finisher kernel's order after the stream sync (no finisher launch, no D2H copy)
+    HIP_TRY(c, s.h_part_sum.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(double)));
+    HIP_TRY(c, s.h_part_zero.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(int)));
+    void *dp = nullptr, *dz = nullptr;
+    HIP_TRY(c, hipHostGetDevicePointer(&dp, s.h_part_sum.p, 0));
+    HIP_TRY(c, hipHostGetDevicePointer(&dz, s.h_part_zero.p, 0));
+    a.part_sum = (double*)dp;
+    a.part_zero = (int*)dz;
+  }
+  s.last_host_partials = c->host_results;
   a.ticket = s.red.ticket.as<unsigned>();
   a.out = out4;
   a.n_reads = (double)n;
   // main kernel: pairs with <= 2 records per mate; overflow kernel: the rest + pairs touching a
   // window that occurs several times (list built below, same rule as the main kernel's skip)
-  const int64_t n_main = s.class_count[0] + s.class_count[1];
+  const int64_t n0 = s.pt.class_count[0], n01 = n0 + s.pt.class_count[1], n_main = n01 + s.pt.class_count[2];
+  a.n0 = (int)n0;
+  a.n01 = (int)n01;
   a.n_main = (int)n_main;
+  for (int mt = 0; mt < 2; mt++) {
+    a.rec8[mt] = s.rec8[mt].as<unsigned long long>();
+    a.inl[mt] = s.inl[mt].as<int4>();
+    a.occ8[mt] = (const unsigned long long*)(arena + o8_off[mt]);
+  }
+  a.len_code = s.len_code.as<unsigned char>();
+  a.len_combo = s.len_combo.as<uint32_t>();
   a.ovf_items = (const int*)(arena + ov_off);
   a.n_ovf_items = (int)s.ovf_items.size();
   const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size();
-  int main_blocks = grid_for(n_main);
-  if (c->knobs[0] > 0) main_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_main + kBlock - 1) / kBlock, c->knobs[0]));
+  const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : kMaxBlocks;
+  // the compact path handles 2 pairs per lane and iteration
+  const int blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
+  const int blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, kMaxBlocks));
+  const int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>((n_main - n01 + kBlock - 1) / kBlock, kMaxBlocks / 4));
+  const int main_blocks = blocks0 + blocks1 + blocks2;
+  a.blocks0 = blocks0;
+  a.blocks01 = blocks0 + blocks1;
   const int ovf_blocks = ovf_total > 0 ? (int)std::min<int64_t>((ovf_total + 3) / 4, kOvfMaxBlocks) : 0;
   a.main_blocks = main_blocks;
   a.total_blocks = main_blocks + ovf_blocks;
@@ -514,22 +579,26 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   if (n > 0) {
     // HIP events bracket the dominant kernel only (bench.py's roofline; rocprofv3 must agree)
     if (c->event_timing) { if (int e = take_events(c, &ev)) return e; HIP_TRY(c, hipEventRecord(ev->first, st)); }
-    const int fin_mode = c->knobs[2] ? c->knobs[2] - 1 : 1;  // default: separate finisher kernel (2048 same-address tickets cost ~20 us)
+    const int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
+    s.last_total_blocks = a.total_blocks;
     const int dyn_lds = c->knobs[1];  // experiment: occupancy limiter
     const dim3 grid(a.total_blocks), block(kBlock);
     if (c->knobs[3] == 1) hipLaunchKernelGGL((paired_score_kernel<false, 1>), grid, block, dyn_lds, st, a);
     else if (c->knobs[3] == 2) hipLaunchKernelGGL((paired_score_kernel<false, 2>), grid, block, dyn_lds, st, a);
     else if (c->knobs[3] == 3) hipLaunchKernelGGL((paired_score_kernel<false, 3>), grid, block, dyn_lds, st, a);
+    else if (c->knobs[3] == 4) hipLaunchKernelGGL((paired_score_kernel<false, 4>), grid, block, dyn_lds, st, a);
+    else if (c->knobs[3] == 5) hipLaunchKernelGGL((paired_score_kernel<false, 5>), grid, block, dyn_lds, st, a);
     else if (fin_mode) hipLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, a);
     else hipLaunchKernelGGL((paired_score_kernel<true, 0>), grid, block, dyn_lds, st, a);
     HIP_TRY(c, hipGetLastError());
     if (ev) HIP_TRY(c, hipEventRecord(ev->second, st));
-    if (fin_mode) {
+    if (fin_mode == 1) {
       hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, a.total_blocks, out4, cov ? -1.0 : 0.0, (double)n);
       HIP_TRY(c, hipGetLastError());
     }
   } else {
-    HIP_TRY(c, hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
+    s.last_total_blocks = 0;
+    if (!c->host_results) HIP_TRY(c, hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
   }
   if (cov && n > 0 && p.total_bits > 0) {
     CovArgs ca;
@@ -549,6 +618,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), out4);
     HIP_TRY(c, hipGetLastError());
   }
+  c->prof[5] = now_us() - tp2 - c->prof[4];  // kernel launches
   // SURVEY.md 8d accounting: 16 B per record, 8 B read lengths, 8 B probability written, per pair
   c->stat_algo_bytes += 16.0 * (double)p.assembled_records + 16.0 * (double)n;
   c->stat_launches++;
@@ -803,6 +873,7 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
   if (pending) *pending = n;
   c->pending_open = true;
   c->pending_host_us = now_us() - t0;
+  c->prof[0] = c->pending_host_us;  // pass 1
   return 0;
 }
 
@@ -912,6 +983,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); }
+      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
       s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->cov_meta.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); s->bad_host.release(); drop_stage(s->stage);
     }
@@ -1129,9 +1201,13 @@ int gaml_hip_eval_finish(gaml_hip_ctx* c, double* partials_out) {
   if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t bytes = std::max<size_t>(1, c->handles.size()) * 4 * sizeof(double);
-  HIP_TRY(c, c->packed.reserve(bytes));
   HIP_TRY(c, c->packed_host.reserve(bytes));
-  if (int e = eval_finish(c, c->packed.p, c->stream)) return e;
+  void* dres = nullptr;
+  HIP_TRY(c, hipHostGetDevicePointer(&dres, c->packed_host.p, 0));
+  c->host_results = true;
+  int e = eval_finish(c, dres, c->stream);
+  c->host_results = false;
+  if (e) return e;
   return fetch_partials(c, partials_out);
 }
 
@@ -1148,19 +1224,53 @@ int gaml_hip_calc_partials(gaml_hip_ctx* c, const int32_t* paths, const int64_t*
   if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t bytes = std::max<size_t>(1, c->handles.size()) * 4 * sizeof(double);
-  HIP_TRY(c, c->packed.reserve(bytes));
   HIP_TRY(c, c->packed_host.reserve(bytes));
-  int e = evaluate(c, paths, offs, n_paths, c->packed.p, c->stream, total_len_out);
+  void* dres = nullptr;
+  HIP_TRY(c, hipHostGetDevicePointer(&dres, c->packed_host.p, 0));
+  c->host_results = true;
+  int e = evaluate(c, paths, offs, n_paths, dres, c->stream, total_len_out);
+  c->host_results = false;
   if (e) return e;
   return fetch_partials(c, partials_out);
 }
 
+// the one-block finisher kernel's summation order, on the host: lane t adds partials t, t+256, ...;
+// each 64-lane wave folds by halving strides (what __shfl_down does); wave results are added in order
+static void finisher_order_sum(const double* ps, const int* pz, int n, double* sum_out, double* zeros_out) {
+  double v[kBlock];
+  long long z = 0;
+  for (int t = 0; t < kBlock; t++) { double a = 0; for (int b = t; b < n; b += kBlock) a += ps[b]; v[t] = a; }
+  for (int b = 0; b < n; b++) z += pz[b];
+  double total = 0;
+  for (int w = 0; w < kBlock / 64; w++) {
+    double* l = v + 64 * w;
+    for (int off = 32; off > 0; off >>= 1) for (int i = 0; i < off; i++) l[i] += l[i + off];
+    total += l[0];
+  }
+  *sum_out = total;
+  *zeros_out = (double)z;
+}
+
 static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
-  const size_t bytes = std::max<size_t>(1, c->handles.size()) * 4 * sizeof(double);
+  // the kernels wrote into pinned host memory: nothing to copy, only to wait for
   const double t0 = now_us();
-  HIP_TRY(c, hipMemcpyAsync(c->packed_host.p, c->packed.p, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->t_dev_wall_us += now_us() - t0;
+  c->prof[7] = now_us() - t0;  // wait for the device
+  {
+    double* res = (double*)c->packed_host.p;
+    auto ord = scoring_order(c);
+    for (size_t k = 0; k < ord.size(); k++) {
+      if (ord[k].kind != 1) continue;
+      PairedSet& s = *c->paireds[ord[k].idx];
+      if (!s.last_host_partials) continue;
+      if (s.last_total_blocks > 0)
+        finisher_order_sum((const double*)s.h_part_sum.p, (const int*)s.h_part_zero.p, s.last_total_blocks, &res[4 * k], &res[4 * k + 1]);
+      else res[4 * k] = res[4 * k + 1] = 0;
+      if (!(s.cfg.penalty_constant > 0) || s.last_total_blocks == 0) res[4 * k + 2] = 0;  // else store_bad_bases_kernel wrote it
+      res[4 * k + 3] = (double)s.mate[0].n_local();
+    }
+  }
   memcpy(partials_out, c->packed_host.p, c->handles.size() * 4 * sizeof(double));
   c->t_kernel_us = 0;
   if (int e2 = collect_events(c)) return e2;
@@ -1214,7 +1324,7 @@ int gaml_hip_read_probs(gaml_hip_ctx* c, int rs, double* out, int64_t n) {
   HIP_TRY(c, hipDeviceSynchronize());
   if (have) HIP_TRY(c, hipMemcpy(out, src, have * sizeof(double), hipMemcpyDeviceToHost));
   if (h.kind == 1 && have) {  // device order -> read order
-    const auto& ros = c->paireds[h.idx]->read_of_slot;
+    const auto& ros = c->paireds[h.idx]->pt.read_of_slot;
     std::vector<double> tmp(out, out + have);
     for (int64_t j = 0; j < have; j++) out[ros[j]] = tmp[j];
   }
@@ -1291,6 +1401,12 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wi
   return (int32_t)w.size();
 }
 
+int gaml_hip_debug_profile(gaml_hip_ctx* c, double* out8) {
+  if (!c || !out8) return GAML_HIP_EINVAL;
+  for (int i = 0; i < 8; i++) out8[i] = c->prof[i];
+  return GAML_HIP_OK;
+}
+
 int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
   if (!c || knob < 0 || knob >= 8) return GAML_HIP_EINVAL;
   c->knobs[knob] = value;
@@ -1299,7 +1415,7 @@ int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
 
 int gaml_hip_debug_class_counts(gaml_hip_ctx* c, int rs, int64_t* out4) {
   if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out4) return fail(c, GAML_HIP_EINVAL, "bad arguments");
-  for (int k = 0; k < 4; k++) out4[k] = c->paireds[c->handles[rs].idx]->class_count[k];
+  for (int k = 0; k < 4; k++) out4[k] = c->paireds[c->handles[rs].idx]->pt.class_count[k];
   return GAML_HIP_OK;
 }
 

@@ -726,6 +726,136 @@ void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_re
   out.built_generation = m.active_generation;
 }
 
+void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) {
+  const int64_t n = a.n_local();
+  const ShortMate* mates[2] = {&a, &b};
+  // per read: record count over ACTIVE windows, and the single record when there is exactly one
+  std::vector<int32_t> k[2];
+  std::vector<uint64_t> one[2];
+  for (int mt = 0; mt < 2; mt++) {
+    k[mt].assign(n, 0);
+    one[mt].assign(n, kNoRec8);
+    const ShortMate& m = *mates[mt];
+    for (size_t wid = 0; wid < m.wins.size(); wid++) {
+      const Window& w = m.wins[wid];
+      if (!w.active) continue;
+      for (int64_t q = w.first; q < w.first + w.count; q++) {
+        const gaml_aligment& r = m.pool[q];
+        if (k[mt][r.read_id]++ == 0)
+          one[mt][r.read_id] = rec8_fits((int32_t)wid, r.position, r.edit_dist) ? rec8_pack((int32_t)wid, r.position, r.edit_dist, r.orientation)
+                                                                                 : kNoRec8 - 1;  // does not fit: not class 0
+      }
+    }
+  }
+  // length combos
+  std::unordered_map<uint32_t, int32_t> combo_id;
+  out.len_combo.clear();
+  auto combo_of = [&](int64_t i) { return (uint32_t)a.lens[i] | ((uint32_t)b.lens[i] << 16); };
+  std::vector<int32_t> lc(n, -1);
+  for (int64_t i = 0; i < n; i++) {
+    uint32_t c = combo_of(i);
+    auto it = combo_id.find(c);
+    if (it == combo_id.end()) {
+      if (out.len_combo.size() >= 256) continue;  // lc stays -1: not class 0
+      it = combo_id.emplace(c, (int32_t)out.len_combo.size()).first;
+      out.len_combo.push_back(c);
+    }
+    lc[i] = it->second;
+  }
+  auto cls = [&](int64_t i) {
+    int m = std::max(k[0][i], k[1][i]);
+    if (m <= 1 && lc[i] >= 0 && one[0][i] != kNoRec8 - 1 && one[1][i] != kNoRec8 - 1) return 0;
+    return m <= 2 ? 1 : m <= 4 ? 2 : 3;
+  };
+  std::vector<int32_t> order(n);
+  for (int64_t i = 0; i < n; i++) order[i] = (int32_t)i;
+  std::vector<uint8_t> cl(n);
+  for (int64_t i = 0; i < n; i++) cl[i] = (uint8_t)cls(i);
+  // class 0 by (window of mate 1, window of mate 2, read id); other classes by (class, read id)
+  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+    if (cl[x] != cl[y]) return cl[x] < cl[y];
+    if (cl[x] != 0) return false;
+    uint32_t wx1 = (uint32_t)(one[0][x] & 0xffffff), wy1 = (uint32_t)(one[0][y] & 0xffffff);
+    if (wx1 != wy1) return wx1 < wy1;
+    uint32_t wx2 = (uint32_t)(one[1][x] & 0xffffff), wy2 = (uint32_t)(one[1][y] & 0xffffff);
+    return wx2 < wy2;
+  });
+  for (int c = 0; c < 4; c++) out.class_count[c] = 0;
+  out.slot_of_read.assign(n, 0);
+  out.read_of_slot.assign(n, 0);
+  for (int64_t s = 0; s < n; s++) {
+    out.read_of_slot[s] = order[s];
+    out.slot_of_read[order[s]] = (int32_t)s;
+    out.class_count[cl[order[s]]]++;
+  }
+  const int64_t n0 = out.class_count[0];
+  for (int mt = 0; mt < 2; mt++) {
+    out.rec8[mt].resize(n0);
+    for (int64_t s = 0; s < n0; s++) out.rec8[mt][s] = one[mt][order[s]];
+  }
+  out.len_code.resize(n0);
+  for (int64_t s = 0; s < n0; s++) out.len_code[s] = (uint8_t)lc[order[s]];
+  out.len12.resize(n - n0);
+  for (int64_t s = n0; s < n; s++) out.len12[s - n0] = combo_of(order[s]);
+  // 16-byte tables of the remaining slots, indexed slot - n0
+  std::vector<int32_t> slot16(n, -1);
+  for (int64_t s = n0; s < n; s++) slot16[order[s]] = (int32_t)(s - n0);
+  for (int mt = 0; mt < 2; mt++) {
+    const ShortMate& m = *mates[mt];
+    ReadMajor& rm = out.rm[mt];
+    const int64_t n16 = n - n0;
+    std::vector<int32_t> cnt(n16 + 1, 0);
+    for (const Window& w : m.wins) if (w.active) for (int64_t q = w.first; q < w.first + w.count; q++) { int32_t t = slot16[m.pool[q].read_id]; if (t >= 0) cnt[t + 1]++; }
+    std::vector<int64_t> start(n16 + 1, 0);
+    int64_t extras = 0;
+    for (int64_t i = 0; i < n16; i++) { start[i] = extras; extras += cnt[i + 1] > 1 ? cnt[i + 1] - 1 : 0; }
+    rm.first.assign(n16, RecQuad{-1, 0, 0, 0});
+    rm.extra.assign(extras, RecQuad{-1, 0, 0, 0});
+    std::vector<int32_t> seen(n16, 0);
+    for (size_t wid = 0; wid < m.wins.size(); wid++) {
+      const Window& win = m.wins[wid];
+      if (!win.active) continue;
+      for (int64_t q = win.first; q < win.first + win.count; q++) {
+        const gaml_aligment& r = m.pool[q];
+        const int32_t at = slot16[r.read_id];
+        if (at < 0) continue;
+        RecQuad rq{(int32_t)wid, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
+        int32_t sn = seen[at]++;
+        if (sn == 0) { rq.flags |= (cnt[at + 1] - 1) << 9; rq.link = (int32_t)start[at]; rm.first[at] = rq; }
+        else rm.extra[start[at] + sn - 1] = rq;
+      }
+    }
+    rm.total_records = m.active_records;
+    rm.built_generation = m.active_generation;
+    // inline copies for the register paths
+    const int64_t n1 = out.class_count[1], n2 = out.class_count[2];
+    out.inl[mt].assign((size_t)(2 * n1 + 4 * n2), RecQuad{-1, 0, 0, 0});
+    for (int64_t t = 0; t < n1 + n2; t++) {
+      const RecQuad& f = rm.first[t];
+      if (f.wid < 0) continue;
+      const int cnt1 = 1 + (int)((uint32_t)f.flags >> 9);
+      RecQuad* dst = t < n1 ? &out.inl[mt][2 * t] : &out.inl[mt][2 * n1 + 4 * (t - n1)];
+      for (int q = 0; q < cnt1; q++) {
+        RecQuad r = q == 0 ? f : rm.extra[f.link + q - 1];
+        r.flags &= 0x1ff;
+        dst[q] = r;
+      }
+    }
+  }
+}
+
+void build_occ8(const OccTable& t, std::vector<uint64_t>& out) {
+  out.resize(t.direct.size());
+  for (size_t w = 0; w < t.direct.size(); w++) {
+    const OccQuad& q = t.direct[w];
+    if (q.path < 0) { out[w] = kNoRec8; continue; }  // window not in the path set
+    const bool general = q.rank < 0 || q.path >= 32767 || q.min_pos > 32767;
+    int32_t mp = q.min_pos < -32768 ? -32768 : q.min_pos;
+    out[w] = (uint64_t)(uint32_t)q.shift | ((uint64_t)(uint16_t)(int16_t)mp << 32) | ((uint64_t)(q.path & 0x7fff) << 48) |
+             ((uint64_t)(general ? 1 : 0) << 63);
+  }
+}
+
 void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& out) {
   out.direct.assign(n_windows, OccQuad{0, 0, -1, 0});
   out.multi_off.assign(1, 0);
@@ -734,13 +864,17 @@ void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& o
   for (const Occ& o : occs) cnt[o.wid]++;
   // windows with several occurrences get a list (in rank order, which is the order of `occs`)
   std::vector<int32_t> slot(n_windows, -1);
+  // an entry the compact 8-byte form cannot hold (path id or filter threshold out of range) is
+  // stored as a one-element list, so that "rank < 0" means "general path" for every consumer
+  for (const Occ& o : occs) if (cnt[o.wid] == 1 && (o.path >= 32767 || o.min_pos > 32767)) cnt[o.wid] = 1 << 30;
   for (const Occ& o : occs) {
     if (cnt[o.wid] == 1) { out.direct[o.wid] = OccQuad{o.shift, o.min_pos, o.path, o.rank}; continue; }
+    if (cnt[o.wid] == (1 << 30)) cnt[o.wid] = 1;  // single occurrence kept as a list
     if (slot[o.wid] < 0) {
       slot[o.wid] = (int32_t)out.multi_off.size() - 1;
       out.multi_off.push_back(out.multi_off.back() + cnt[o.wid]);
       out.direct[o.wid] = OccQuad{0, 0, o.path, -(slot[o.wid] + 1)};
-      cnt[o.wid] = -cnt[o.wid];  // negative: running fill position follows
+      cnt[o.wid] = -cnt[o.wid] - 2;  // < -1: list already opened
     }
   }
   out.multi.resize(out.multi_off.back());

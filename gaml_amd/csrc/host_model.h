@@ -154,6 +154,32 @@ void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_re
 void pair_device_order(const ShortMate& a, const ShortMate& b, std::vector<int32_t>& slot_of_read,
                        std::vector<int32_t>& read_of_slot, int64_t class_count[4]);
 
+// Compact tables of class 0 (at most one record per mate, everything within the packed ranges):
+//   rec8  = window id (24 bits) | position in window (28) | edit distance (6) | orientation (1);
+//           all ones = the mate has no record
+//   occ8  = shift (int32) | min_pos clamped to int16 | path (15 bits) | "use the general path" (1)
+// Class-0 pairs are additionally ordered by (window of mate 1, window of mate 2): the lanes of a wave
+// then mostly share their window, so the occurrence lookups are wave-broadcasts.
+constexpr uint64_t kNoRec8 = ~0ull;
+inline bool rec8_fits(int32_t wid, int32_t pos, int32_t edit) { return wid >= 0 && wid < (1 << 24) - 1 && pos >= 0 && pos < (1 << 28) && edit >= 0 && edit < 64; }
+inline uint64_t rec8_pack(int32_t wid, int32_t pos, int32_t edit, int32_t orient) {
+  return (uint64_t)(uint32_t)wid | ((uint64_t)(uint32_t)pos << 24) | ((uint64_t)(uint32_t)edit << 52) | ((uint64_t)(orient & 1) << 58);
+}
+struct PairTables {
+  std::vector<int32_t> slot_of_read, read_of_slot;
+  int64_t class_count[4] = {0, 0, 0, 0};  // 0: compact; 1: <= 2 records; 2: <= 4; 3: more
+  std::vector<uint64_t> rec8[2];          // [n0]
+  std::vector<uint8_t> len_code;          // [n0] index into len_combo
+  std::vector<uint32_t> len_combo;        // distinct L1 | L2<<16 values (<= 256)
+  std::vector<uint32_t> len12;            // [n - n0] for the 16-byte classes
+  ReadMajor rm[2];                        // 16-byte tables of slots >= n0 (indexed slot - n0)
+  // the same records once more, inline per pair, for the register paths: class 1 holds 2 slots per
+  // pair and mate at [2t + k], class 2 holds 4 at [2 n1 + 4 t2 + k] (wid = -1: no record)
+  std::vector<RecQuad> inl[2];
+};
+void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out);
+
+
 // direct-mapped occurrence table for the device: one 16-B entry per window.
 //   path < 0            : the window does not occur in the current path set
 //   path >= 0, rank >= 0: exactly one occurrence, described by the entry
@@ -165,6 +191,8 @@ struct OccTable {
   std::vector<OccQuad> multi;
 };
 void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& out);
+// 8-byte occurrence entries for the compact path (from the 16-byte table)
+void build_occ8(const OccTable& t, std::vector<uint64_t>& out);
 
 void split_contigs(const Walk& path, std::vector<std::pair<int32_t, int32_t>>& ctg_ranges, std::vector<int32_t>& gaps);
 

@@ -40,7 +40,17 @@ struct PairedArgs {
   double* probs;             // out: per-pair summed probability (ScoringState::probs)
   uint32_t* cov_bits;        // coverage marks (only when penalty_constant > 0), else null
   const int* path_base;      // bit offset of each path in cov_bits
-  int n_main;                // the main kernel scores slots [0, n_main): pairs with <= 2 records per mate
+  // class 0 (compact): slots [0, n0): 8-byte records, 1-byte length code, 8-byte occurrence entries
+  const unsigned long long* rec8[2];
+  const unsigned char* len_code;
+  const uint32_t* len_combo;
+  const unsigned long long* occ8[2];
+  const int4* inl[2];        // inline records of the register classes: [2t + k] (class 1), [2 n1 + 4 t2 + k] (class 2)
+  int n0;                    // first[] / extra[] / len12[] hold slots >= n0, indexed slot - n0
+  int blocks0;               // blocks [0, blocks0): compact path; [blocks0, blocks01): <= 2 records; [blocks01, main_blocks): <= 4
+  int blocks01;
+  int n01;                   // slots [n0, n01): class 1 (<= 2 records per mate); [n01, n_main): class 2 (<= 4)
+  int n_main;                // the lane-per-pair paths score slots [0, n_main)
   const int* ovf_items;      // host-built list: slots < n_main that touch a window occurring several times
   int n_ovf_items;           // the overflow kernel scores slots [n_main, n) and this list
   int main_blocks, total_blocks;  // grid sizes: partial slots [0, main_blocks) main, then overflow
@@ -229,8 +239,47 @@ __device__ __forceinline__ bool load_cands(const MateView& v, const int4& r0, Re
   return multi;
 }
 
+// same, from K inline records (all K loads independent: no link hop)
+template <int K>
+__device__ __forceinline__ bool load_cands_inline(const MateView& v, const int4* rec, RegCands<K>& c) {
+  int4 r[K], o[K];
+  bool multi = false;
+#pragma unroll
+  for (int k = 0; k < K; k++) r[k] = rec[k];
+#pragma unroll
+  for (int k = 0; k < K; k++) o[k] = r[k].x >= 0 ? v.occ[r[k].x] : make_int4(0, 0, -1, 0);
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    multi |= (o[k].z >= 0 && o[k].w < 0);
+    c.path[k] = o[k].z; c.pos[k] = r[k].y + o[k].x; c.ef[k] = r[k].z & 0x1ff; c.rank[k] = o[k].w;
+    c.valid[k] = r[k].x >= 0 && o[k].z >= 0 && r[k].y >= o[k].y;
+  }
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    bool lv = c.valid[i];
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if (j != i) lv = lv && !(c.valid[j] && c.path[j] == c.path[i] && c.pos[j] == c.pos[i] &&
+                               (c.rank[j] > c.rank[i] || (c.rank[j] == c.rank[i] && j > i)));
+    c.live[i] = lv;
+  }
+  return multi;
+}
+
 template <int K>
 __device__ __forceinline__ double score_regs(const PairedArgs& a, const RegCands<K>& c1, const RegCands<K>& c2, int L1, int L2) {
+  // common case: the overwrite rule leaves one alignment per mate (junction duplicates) -> one
+  // pair term, selected without branches; the general double loop only otherwise
+  int n1 = 0, n2 = 0;
+  Cand x, y;
+  x.path = -1; x.pos = 0; x.edit = 0; x.orient = 0; y = x;
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    if (c1.live[i]) { n1++; x.path = c1.path[i]; x.pos = c1.pos[i]; x.edit = c1.ef[i] & 0xff; x.orient = c1.ef[i] >> 8; }
+    if (c2.live[i]) { n2++; y.path = c2.path[i]; y.pos = c2.pos[i]; y.edit = c2.ef[i] & 0xff; y.orient = c2.ef[i] >> 8; }
+  }
+  if (n1 == 0 || n2 == 0) return 0.0;
+  if (n1 == 1 && n2 == 1) return x.path == y.path ? pair_term(a, x, y, L1, L2) : 0.0;
   double acc = 0.0;
 #pragma unroll
   for (int i = 0; i < K; i++) {
@@ -252,49 +301,107 @@ __device__ __forceinline__ double score_regs(const PairedArgs& a, const RegCands
 // touches a window occurring several times in the path set is skipped here: the host put it on
 // the overflow list (same rule on both sides: any record, either mate, whose window entry has
 // path >= 0 and rank < 0).
+constexpr unsigned long long kNone8 = ~0ull;
+
+__device__ __forceinline__ int4 rec8_to_quad(unsigned long long r) {  // 8-byte record -> the 16-byte form
+  if (r == kNone8) return make_int4(-1, 0, 0, 0);
+  return make_int4((int)(r & 0xffffff), (int)((r >> 24) & 0xfffffff), (int)((r >> 52) & 63) | ((int)((r >> 58) & 1) << 8), 0);
+}
+
 // ABL > 0: timing-only ablations for tools/kbench.py (results are wrong on purpose):
 //   1 = stream the records and lengths, write probs, nothing else; 2 = + occurrence lookups;
 //   3 = + pair terms (tables), but no floor / log
+// Class 0: at most one record per mate, packed to 8 bytes; pairs are ordered by window id, so the
+// occurrence entries of a wave's lanes are mostly the same address (broadcast).
+struct Compact1 {  // one class-0 pair in flight
+  unsigned long long r1, r2, o1, o2;
+  int L1, L2;
+};
+
+__device__ __forceinline__ double compact_score(const PairedArgs& a, const Compact1& c, bool& skip) {
+  // a record in a window that needs the general path (occurs several times, ...): the host put
+  // this pair on the overflow list
+  skip = (c.o1 != kNone8 && (c.o1 >> 63)) || (c.o2 != kNone8 && (c.o2 >> 63));
+  if (skip || c.o1 == kNone8 || c.o2 == kNone8 || ((c.o1 ^ c.o2) >> 48) != 0) return 0.0;  // both occur, same path
+  const int p1 = (int)((c.r1 >> 24) & 0xfffffff), p2 = (int)((c.r2 >> 24) & 0xfffffff);
+  if (p1 < (int)(short)(c.o1 >> 32) || p2 < (int)(short)(c.o2 >> 32)) return 0.0;  // position filter (graph.cc:577)
+  Cand x, y;
+  x.path = (int)(c.o1 >> 48); x.pos = p1 + (int)(unsigned)c.o1; x.edit = (int)((c.r1 >> 52) & 63); x.orient = (int)((c.r1 >> 58) & 1);
+  y.path = x.path; y.pos = p2 + (int)(unsigned)c.o2; y.edit = (int)((c.r2 >> 52) & 63); y.orient = (int)((c.r2 >> 58) & 1);
+  return pair_term(a, x, y, c.L1, c.L2);
+}
+
+template <int ABL>
+__device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb, double& lsum, int& zeros) {
+  // Two pairs per lane and iteration: the 6 record/length loads of both pairs are issued together,
+  // then the 4 occurrence lookups, so one round of memory latency serves two pairs.
+  const int stride = a.blocks0 * kBlock;
+  for (int i0 = lb * kBlock + threadIdx.x; i0 < a.n0; i0 += 2 * stride) {
+    const int i1 = i0 + stride;
+    const bool two = i1 < a.n0;
+    Compact1 c0, c1;
+    c0.r1 = a.rec8[0][i0]; c0.r2 = a.rec8[1][i0];
+    const unsigned char lc0 = a.len_code[i0];
+    c1.r1 = two ? a.rec8[0][i1] : kNone8; c1.r2 = two ? a.rec8[1][i1] : kNone8;
+    const unsigned char lc1 = two ? a.len_code[i1] : 0;
+    const uint32_t l0 = a.len_combo[lc0], l1 = a.len_combo[lc1];
+    c0.L1 = l0 & 0xffff; c0.L2 = l0 >> 16; c1.L1 = l1 & 0xffff; c1.L2 = l1 >> 16;
+    if (ABL == 1 || ABL == 4) {
+      a.probs[i0] = (double)(int)(c0.r1 + c0.r2 + c0.L1); lsum += (double)(int)c0.r1;
+      if (two) { a.probs[i1] = (double)(int)(c1.r1 + c1.r2 + c1.L1); lsum += (double)(int)c1.r1; }
+      continue;
+    }
+    c0.o1 = c0.r1 != kNone8 ? a.occ8[0][c0.r1 & 0xffffff] : kNone8;
+    c0.o2 = c0.r2 != kNone8 ? a.occ8[1][c0.r2 & 0xffffff] : kNone8;
+    c1.o1 = c1.r1 != kNone8 ? a.occ8[0][c1.r1 & 0xffffff] : kNone8;
+    c1.o2 = c1.r2 != kNone8 ? a.occ8[1][c1.r2 & 0xffffff] : kNone8;
+    if (ABL == 2) {
+      a.probs[i0] = (double)(int)(c0.o1 + c0.o2); lsum += (double)(int)(c0.o1 + c0.o2);
+      if (two) { a.probs[i1] = (double)(int)(c1.o1 + c1.o2); lsum += (double)(int)(c1.o1 + c1.o2); }
+      continue;
+    }
+    bool s0, s1;
+    const double acc0 = compact_score(a, c0, s0);
+    const double acc1 = compact_score(a, c1, s1);
+    if (ABL == 3) { a.probs[i0] = acc0; lsum += acc0; if (two) { a.probs[i1] = acc1; lsum += acc1; } continue; }
+    if (!s0) finish_read(a, i0, acc0, c0.L1, c0.L2, lsum, zeros);
+    if (two && !s1) finish_read(a, i1, acc1, c1.L1, c1.L2, lsum, zeros);
+  }
+}
+
+// Classes 1 and 2: at most K = 2 / 4 records per mate, 16-byte records, overwrite rule in registers.
+// Slots [slot_lo, slot_hi), blocks [block_lo, block_hi).
+template <int K, int ABL>
+__device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
+                                                 double& lsum, int& zeros) {
+  if (ABL >= 1 && ABL != 4) return;  // ablations 1,2,3,5: compact classes alone; 4: compact stream-only + these classes in full
+  for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
+    const int t = i - a.n0;
+    const uint32_t l12 = a.len12[t];
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    const size_t at = K == 2 ? (size_t)2 * (i - a.n0) : (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01);
+    RegCands<K> x, y;
+    const bool m1 = load_cands_inline<K>(a.m[0], a.inl[0] + at, x), m2 = load_cands_inline<K>(a.m[1], a.inl[1] + at, y);
+    if (m1 || m2) continue;  // on the host's overflow list
+    const double acc = score_regs<K>(a, x, y, L1, L2);
+    finish_read(a, i, acc, L1, L2, lsum, zeros);
+  }
+}
+
 template <bool TICKET, int ABL = 0>
-__device__ __forceinline__ void paired_main_body(const PairedArgs& a, double* sh_s, int* sh_z) {
+__device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z) {
   double lsum = 0.0;
   int zeros = 0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_main; i += a.main_blocks * kBlock) {
-    const int4 r1 = a.m[0].first[i];
-    const int4 r2 = a.m[1].first[i];
-    const uint32_t l12 = a.len12[i];
-    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-    double acc = 0.0;
-    bool skip = false;
-    if (ABL == 1) { a.probs[i] = (double)(r1.y + r2.y + L1 + L2); lsum += (double)r1.x; continue; }
-    if (ABL == 2) {
-      const int4 o1 = r1.x >= 0 ? a.m[0].occ[r1.x] : make_int4(0, 0, -1, 0);
-      const int4 o2 = r2.x >= 0 ? a.m[1].occ[r2.x] : make_int4(0, 0, -1, 0);
-      a.probs[i] = (double)(r1.y + o1.x + r2.y + o2.x + L1 + L2); lsum += (double)(o1.z + o2.w); continue;
-    }
-    const int extra = (int)(((unsigned)r1.z | (unsigned)r2.z) >> 9);  // >0 iff some mate has 2 records
-    if (extra == 0) {
-      const int4 o1 = r1.x >= 0 ? a.m[0].occ[r1.x] : make_int4(0, 0, -1, 0);
-      const int4 o2 = r2.x >= 0 ? a.m[1].occ[r2.x] : make_int4(0, 0, -1, 0);
-      skip = (o1.z >= 0 && o1.w < 0) || (o2.z >= 0 && o2.w < 0);
-      if (!skip && o1.z >= 0 && o1.z == o2.z && r1.y >= o1.y && r2.y >= o2.y)
-        acc = pair_term(a, make_cand(r1, o1, 0), make_cand(r2, o2, 0), L1, L2);
-    } else {
-      RegCands<2> x, y;
-      const bool m1 = load_cands<2>(a.m[0], r1, x), m2 = load_cands<2>(a.m[1], r2, y);
-      skip = m1 || m2;
-      if (!skip) acc = score_regs<2>(a, x, y, L1, L2);
-    }
-    if (ABL == 3) { a.probs[i] = acc; lsum += acc; continue; }
-    if (!skip) finish_read(a, i, acc, L1, L2, lsum, zeros);
-  }
+  if (lb < a.blocks0) paired_compact_body<ABL>(a, lb, lsum, zeros);
+  else if (lb < a.blocks01) paired_regs_body<2, ABL>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
+  else paired_regs_body<4, ABL>(a, lb, a.n01, a.n_main, a.blocks01, a.main_blocks, lsum, zeros);
   block_reduce(lsum, zeros, sh_s, sh_z);
   if (TICKET) {
-    grid_finish(lsum, zeros, blockIdx.x, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out,
+    grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out,
                 a.cov_bits ? -1.0 : 0.0, a.n_reads, sh_s, sh_z);
   } else if (threadIdx.x == 0) {
-    a.part_sum[blockIdx.x] = lsum;
-    a.part_zero[blockIdx.x] = zeros;
+    a.part_sum[lb] = lsum;
+    a.part_zero[lb] = zeros;
   }
 }
 
@@ -364,9 +471,10 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
   int zeros = 0;
   for (int item = wave_global; item < n_items; item += n_waves) {  // fixed item -> wave assignment
     const int i = item < n_static ? a.n_main + item : a.ovf_items[item - n_static];
-    const int4 r1 = a.m[0].first[i];
-    const int4 r2 = a.m[1].first[i];
-    const uint32_t l12 = a.len12[i];
+    int4 r1, r2;
+    uint32_t l12;
+    if (i < a.n0) { r1 = rec8_to_quad(a.rec8[0][i]); r2 = rec8_to_quad(a.rec8[1][i]); l12 = a.len_combo[a.len_code[i]]; }
+    else { r1 = a.m[0].first[i - a.n0]; r2 = a.m[1].first[i - a.n0]; l12 = a.len12[i - a.n0]; }
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     int4* c1 = cand[wave][0];
     int4* c2 = cand[wave][1];
@@ -427,8 +535,12 @@ __global__ __launch_bounds__(kBlock) void paired_score_kernel(PairedArgs a) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
   __shared__ int4 cand[kBlock / 64][2][kOvfCap];
-  if ((int)blockIdx.x < a.main_blocks) paired_main_body<TICKET, ABL>(a, sh_s, sh_z);
-  else paired_overflow_body<TICKET>(a, (int)blockIdx.x - a.main_blocks, a.total_blocks - a.main_blocks, sh_s, sh_z, cand);
+  // Logical block ids are [compact][<= 2 records][<= 4 records][overflow]; they are handed out in
+  // REVERSE dispatch order so that the few long-latency blocks (overflow, multi-record classes)
+  // start first and hide under the compact stream instead of forming a tail.
+  const int lb = a.total_blocks - 1 - (int)blockIdx.x;
+  if (lb < a.main_blocks) paired_main_body<TICKET, ABL>(a, lb, sh_s, sh_z);
+  else paired_overflow_body<TICKET>(a, lb - a.main_blocks, a.total_blocks - a.main_blocks, sh_s, sh_z, cand);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -31,5 +31,9 @@ for rnd in range(6):
         wall[si].append((time.perf_counter() - t0) / 40 * 1e6)
         ks = ctx.kernel_stats(reset=True)
         res[si].append(ks["device_us"] / max(1, ks["launches"]))
+prof = np.zeros(8)
+for i in range(40):
+    ctx.calc_prob(variants[i % 8]); prof += ctx.debug_profile()
+print('profile us [pass1, tables, ovf+occ8, pack, h2d_enq, launch, bytes, wait]:', np.round(prof / 40, 1))
 for si, st in enumerate(settings):
     print(st, "kernel_us median %.2f min %.2f | step_us median %.1f min %.1f" % (np.median(res[si]), min(res[si]), np.median(wall[si]), min(wall[si])))
