@@ -175,6 +175,18 @@ def main():
         kern_us = ks["device_us"] / launches
         bytes_per_launch = ks["algo_bytes"] / launches
         achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        # HBM traffic per launch: not measurable from inside the process; taken from the committed rocprofv3
+        # --pmc passes of this same command (profiles/*pmc_traffic.json), FETCH_SIZE doubled per the guide
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]
+            tj = json.load(open(f))
+            if args.workload == "cfg3":
+                traffic = tj["kernels"]["paired_score_kernel"]["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(f, ROOT)
+        except Exception:
+            pass
         out = {
             "metric": "reads_per_sec_scored", "value": value, "unit": "reads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -183,8 +195,12 @@ def main():
                                              "8 rotating path sets, window cache warm", "pairs_per_gpu": n_pairs_rank,
                        "genome_bp": wl.genome_len, "parallelism": f"reads sharded over {world} GPU(s), 1 all-reduce of 32 B/step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "paired_score_kernel", "kernel_us": kern_us, "algo_bytes_per_launch": bytes_per_launch},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "paired_score_kernel", "kernel_us": kern_us, "algo_bytes_per_launch": bytes_per_launch,
+                         "timing": "HIP events recorded on the launch stream around every paired_score_kernel launch of the "
+                                   "timed region (includes ~3-5 us of dispatch latency per launch that rocprofv3's "
+                                   "kernel-trace duration does not)",
+                         "traffic_source": traffic_src},
             "log_likelihood": last[0], "prime_s": prime_s,
             "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
             "timing_last_step_us": ctx.last_timing(),
