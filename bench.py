@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "tiny"])
     ap.add_argument("--cpu-sample-pairs", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (process group, side stream, "
+                    "all-reduce) even with one rank -- rehearsal of the N > 1 path on a 1-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -93,7 +95,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = synth.WORKLOADS[args.workload]
@@ -120,7 +125,7 @@ def main():
 
     def step(paths):
         pending, tl = ctx.eval_begin(paths)
-        if world == 1:
+        if not use_dist:
             part = ctx.eval_finish()  # kernels + 32-B D2H + stream sync inside the library: CalcProb is blocking
         else:
             if pending:
@@ -147,7 +152,7 @@ def main():
     ctx.set_event_timing(True)
     ctx.kernel_stats(reset=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -155,14 +160,14 @@ def main():
     for i in range(args.steps):
         last = step(variants[i % len(variants)])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ks = ctx.kernel_stats(reset=True)
     ctx.set_event_timing(False)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -218,7 +223,7 @@ def main():
             out["ll_max_rel_delta_vs_cpu"] = max(abs(a - b) / abs(b) for a, b in zip(gpu_vals, cpu_vals))
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

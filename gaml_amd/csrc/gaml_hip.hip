@@ -88,7 +88,9 @@ struct PairedSet {
   ShortMate mate[2];
   PairTables pt;                      // device order + compact / 16-byte record tables (cold path)
   MateDev dev[2];
-  DevBuf rec8[2], len_code, len_combo, inl[2];
+  DevBuf rec8[2], len_code, len_combo, inl[2], combo_tabs, lt, ltz;
+  double lt_two_T = -1;   // 2T the memo table was last built for (-1: stale)
+  int lt_codes = 0;
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
   int last_total_blocks = 0;
   bool last_host_partials = false;
@@ -98,8 +100,8 @@ struct PairedSet {
   std::vector<int32_t> ovf_items;
   hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;
   PairedPlanner planner;
-  std::vector<Occ> scratch_occ[2];
-  std::vector<uint64_t> occ8[2];
+  OccImage image[2];                 // persistent host images of the occurrence tables, patched per call
+  std::vector<Occ> scratch_occ[2];   // debug dumps only
   Reducer red;
   std::vector<double> ins_tab, floor_tab, logfloor_tab, covthr_tab;
   bool tabs_uploaded = false;
@@ -138,7 +140,6 @@ struct PacbioSet {
 };
 
 struct PairedPrep {
-  OccTable occ[2];
   int64_t assembled_records = 0;  // records the reference would touch in GetPositionsOnlyPath
   std::vector<int32_t> path_base, start_off, starts;
   int32_t total_bits = 0;
@@ -258,6 +259,19 @@ int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
 
 // layout of one OccTable inside an arena
 struct OccLayout { size_t direct, multi_off, multi, end; };
+OccLayout layout_image(const OccImage& t, size_t at) {
+  OccLayout l;
+  l.direct = at;
+  l.multi_off = (l.direct + std::max<size_t>(1, t.direct.size()) * sizeof(OccQuad) + 15) & ~(size_t)15;
+  l.multi = (l.multi_off + t.multi_off.size() * sizeof(int32_t) + 15) & ~(size_t)15;
+  l.end = (l.multi + std::max<size_t>(1, t.multi.size()) * sizeof(OccQuad) + 15) & ~(size_t)15;
+  return l;
+}
+void pack_image(const OccImage& t, const OccLayout& l, char* base) {
+  if (!t.direct.empty()) memcpy(base + l.direct, t.direct.data(), t.direct.size() * sizeof(OccQuad));
+  memcpy(base + l.multi_off, t.multi_off.data(), t.multi_off.size() * sizeof(int32_t));
+  if (!t.multi.empty()) memcpy(base + l.multi, t.multi.data(), t.multi.size() * sizeof(OccQuad));
+}
 OccLayout layout_occ(const OccTable& t, size_t at) {
   OccLayout l;
   l.direct = at;
@@ -377,7 +391,10 @@ void prepare_paired_structure(gaml_hip_ctx* c, PairedSet& s, const std::vector<W
 // pass 2: position-filter thresholds (need the windows' global largest positions) + device tables
 void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
   (void)c;
+  static const bool trace = getenv("GAML_HIP_TRACE_HOST") != nullptr;
+  const double q0 = now_us();
   s.planner.finish(s.mate);
+  const double q1 = now_us();
   const PlanView& v = s.planner.view();
   const bool cov = s.cfg.penalty_constant > 0;
   // coverage bitmap layout + contig starts (events of type 1, graph.cc:1826,1833-1835)
@@ -391,12 +408,13 @@ void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
     p.path_base.push_back(p.path_base.back() + (cov ? bits : 0));
   }
   p.total_bits = p.path_base.back();
+  const double q2 = now_us();
   p.assembled_records = 0;
   for (int mt = 0; mt < 2; mt++) {
-    s.planner.flat_occurrences(mt, s.scratch_occ[mt]);
-    build_occ_table(s.mate[mt].wins.size(), s.scratch_occ[mt], p.occ[mt]);  // sized to the final window count
+    s.image[mt].build(s.mate[mt].wins.size(), v, mt);  // sized to the final window count
     for (const PathMemo* pm : v.paths) p.assembled_records += pm->assembled[mt];
   }
+  if (trace) fprintf(stderr, "pass2: finish %.1f us, starts %.1f us, images %.1f us\n", q1 - q0, q2 - q1, now_us() - q2);
 }
 
 void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p) {
@@ -439,11 +457,27 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     HIP_TRY(c, up(s.len_code, s.pt.len_code.data(), s.pt.len_code.size()));
     HIP_TRY(c, up(s.len_combo, s.pt.len_combo.data(), s.pt.len_combo.size() * sizeof(uint32_t)));
     HIP_TRY(c, up(s.len12, s.pt.len12.data(), s.pt.len12.size() * sizeof(uint32_t)));
+    // per length-combination tables of the compact path: [pe mate 0 | pe mate 1 | floor | logfloor | covthr]
+    {
+      const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
+      std::vector<double> t(nc * 64 * 2 + nc * 3, 0.0);
+      for (size_t ci = 0; ci < s.pt.len_combo.size(); ci++) {
+        const int L[2] = {(int)(s.pt.len_combo[ci] & 0xffff), (int)(s.pt.len_combo[ci] >> 16)};
+        for (int mt = 0; mt < 2; mt++)
+          for (int e = 0; e < 64 && e <= L[mt]; e++)
+            t[(size_t)mt * nc * 64 + ci * 64 + e] = s.mate[mt].mismatch_pow[e] * s.mate[mt].match_pow[L[mt] - e];  // graph.cc:1859-1863
+        t[2 * nc * 64 + ci] = s.floor_tab[L[0] + L[1]];
+        t[2 * nc * 64 + nc + ci] = s.logfloor_tab[L[0] + L[1]];
+        t[2 * nc * 64 + 2 * nc + ci] = s.covthr_tab[L[1]];
+      }
+      HIP_TRY(c, up(s.combo_tabs, t.data(), t.size() * sizeof(double)));
+      s.lt_two_T = -1;
+    }
   }
 
   const bool cov = s.cfg.penalty_constant > 0;
-  OccLayout l0 = layout_occ(p.occ[0], 0);
-  OccLayout l1 = layout_occ(p.occ[1], l0.end);
+  OccLayout l0 = layout_image(s.image[0], 0);
+  OccLayout l1 = layout_image(s.image[1], l0.end);
   size_t meta = l1.end;
   size_t pb_off = meta, so_off = 0, st_off = 0, total = meta;
   if (cov) {
@@ -459,11 +493,8 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     if (s.ovf_stamp.size() != (size_t)s.mate[0].n_local()) s.ovf_stamp.assign(s.mate[0].n_local(), 0);
     if (++s.ovf_serial == 0) { std::fill(s.ovf_stamp.begin(), s.ovf_stamp.end(), 0); s.ovf_serial = 1; }
     for (int mt = 0; mt < 2; mt++) {
-      if (p.occ[mt].multi.empty()) continue;
       const ShortMate& m = s.mate[mt];
-      for (size_t w = 0; w < p.occ[mt].direct.size(); w++) {
-        const OccQuad& q = p.occ[mt].direct[w];
-        if (q.path < 0 || q.rank >= 0) continue;
+      for (int32_t w : s.image[mt].general_wids) {
         const Window& win = m.wins[w];
         for (int64_t k = win.first; k < win.first + win.count; k++) {
           const int32_t slot_i = s.pt.slot_of_read[m.pool[k].read_id];
@@ -477,20 +508,19 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   total = align16(ov_off + std::max<size_t>(1, s.ovf_items.size()) * sizeof(int32_t));
   size_t o8_off[2];
   for (int mt = 0; mt < 2; mt++) {
-    build_occ8(p.occ[mt], s.occ8[mt]);
     o8_off[mt] = total;
-    total = align16(total + std::max<size_t>(1, s.occ8[mt].size()) * sizeof(uint64_t));
+    total = align16(total + std::max<size_t>(1, s.image[mt].occ8.size()) * sizeof(uint64_t));
   }
   const double tp1 = now_us();
   c->prof[2] = tp1 - t_after_host;  // overflow list + occ8
   void* host = nullptr;
   int slot = stage_acquire(c, s.stage, total, &host);
   if (slot < 0) return slot;
-  pack_occ(p.occ[0], l0, (char*)host);
-  pack_occ(p.occ[1], l1, (char*)host);
+  pack_image(s.image[0], l0, (char*)host);
+  pack_image(s.image[1], l1, (char*)host);
   if (!s.ovf_items.empty()) memcpy((char*)host + ov_off, s.ovf_items.data(), s.ovf_items.size() * sizeof(int32_t));
   for (int mt = 0; mt < 2; mt++)
-    if (!s.occ8[mt].empty()) memcpy((char*)host + o8_off[mt], s.occ8[mt].data(), s.occ8[mt].size() * sizeof(uint64_t));
+    if (!s.image[mt].occ8.empty()) memcpy((char*)host + o8_off[mt], s.image[mt].occ8.data(), s.image[mt].occ8.size() * sizeof(uint64_t));
   if (cov) {
     memcpy((char*)host + pb_off, p.path_base.data(), p.path_base.size() * sizeof(int32_t));
     memcpy((char*)host + so_off, p.start_off.data(), p.start_off.size() * sizeof(int32_t));
@@ -558,8 +588,30 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     a.inl[mt] = s.inl[mt].as<int4>();
     a.occ8[mt] = (const unsigned long long*)(arena + o8_off[mt]);
   }
+  {
+    const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
+    const double* ct = s.combo_tabs.as<double>();
+    a.pe[0] = ct; a.pe[1] = ct + nc * 64; a.floor_c = ct + 2 * nc * 64; a.logfloor_c = a.floor_c + nc; a.covthr_c = a.logfloor_c + nc;
+  }
   a.len_code = s.len_code.as<unsigned char>();
   a.len_combo = s.len_combo.as<uint32_t>();
+  // memo of floor + log over the values a single-term pair can take; rebuilt only when 2T (or the
+  // tables) changed. Floor must be positive for the "no alignment -> floored" shortcut.
+  a.lt = nullptr; a.ltz = nullptr; a.lt_codes = 0;
+  if (c->knobs[4] == 0 && !s.pt.len_combo.empty() && s.ins_tab.size() > 0) {
+    const int codes = (int)std::min<size_t>(s.pt.len_combo.size(), 4);
+    const size_t entries = (size_t)codes * 49 * s.ins_tab.size();
+    if (entries <= ((size_t)1 << 24)) {
+      if (s.lt_two_T != a.two_T || s.lt_codes != codes) {
+        if (entries * 8 > s.lt.cap || entries > s.ltz.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.lt.reserve(entries * 8)); HIP_TRY(c, s.ltz.reserve(entries)); }
+        hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
+                           a.pe[0], a.pe[1], a.ins_tab, a.ins_n, a.floor_c, a.logfloor_c, codes, a.two_T, s.lt.as<double>(), s.ltz.as<unsigned char>());
+        HIP_TRY(c, hipGetLastError());
+        s.lt_two_T = a.two_T; s.lt_codes = codes;
+      }
+      a.lt = s.lt.as<double>(); a.ltz = s.ltz.as<unsigned char>(); a.lt_codes = codes;
+    }
+  }
   a.ovf_items = (const int*)(arena + ov_off);
   a.n_ovf_items = (int)s.ovf_items.size();
   const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size();
@@ -983,7 +1035,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); }
-      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
+      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->lt.release(); s->ltz.release(); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
       s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->cov_meta.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); s->bad_host.release(); drop_stage(s->stage);
     }
@@ -1384,7 +1436,7 @@ int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* c, int rs, int mate, int32_t* o
   SetRef h = c->handles[rs];
   const std::vector<Occ>* v = nullptr;
   if (h.kind == 0) v = &c->singles[h.idx]->last_occ;
-  else if (h.kind == 1 && (mate == 0 || mate == 1)) v = &c->paireds[h.idx]->scratch_occ[mate];
+  else if (h.kind == 1 && (mate == 0 || mate == 1)) { PairedSet& ps = *c->paireds[h.idx]; ps.planner.flat_occurrences(mate, ps.scratch_occ[mate]); v = &ps.scratch_occ[mate]; }
   if (!v) return -1;
   for (int64_t i = 0; i < (int64_t)v->size() && i < cap; i++) {
     const Occ& o = (*v)[i];

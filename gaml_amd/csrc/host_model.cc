@@ -844,6 +844,60 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
   }
 }
 
+static inline uint64_t occ8_pack(const OccQuad& q, bool general) {
+  int32_t mp = q.min_pos < -32768 ? -32768 : q.min_pos;
+  return (uint64_t)(uint32_t)q.shift | ((uint64_t)(uint16_t)(int16_t)mp << 32) | ((uint64_t)(q.path & 0x7fff) << 48) |
+         ((uint64_t)(general ? 1 : 0) << 63);
+}
+
+void OccImage::build(size_t n_windows, const PlanView& view, int mate) {
+  if (direct.size() < n_windows) {
+    direct.resize(n_windows, OccQuad{0, 0, -1, 0});
+    occ8.resize(n_windows, kNoRec8);
+    cnt_.resize(n_windows, 0);
+    list_of_.resize(n_windows, -1);
+    stamp_.resize(n_windows, 0);
+  }
+  for (int32_t w : touched_) { direct[w] = OccQuad{0, 0, -1, 0}; occ8[w] = kNoRec8; }
+  touched_.clear();
+  if (++serial_ == 0) { std::fill(stamp_.begin(), stamp_.end(), 0); serial_ = 1; }
+  // how often does each window occur in this path set
+  for (const PathMemo* pm : view.paths)
+    for (const Occ& o : pm->occ[mate]) {
+      if (stamp_[o.wid] != serial_) { stamp_[o.wid] = serial_; cnt_[o.wid] = 0; list_of_[o.wid] = -1; touched_.push_back(o.wid); }
+      cnt_[o.wid]++;
+    }
+  multi_off.assign(1, 0);
+  multi.clear();
+  general_wids.clear();
+  pending_.clear();
+  int32_t rank0 = 0;
+  for (size_t slot = 0; slot < view.paths.size(); slot++) {
+    const PathMemo& pm = *view.paths[slot];
+    for (const Occ& o : pm.occ[mate]) {
+      OccQuad q{o.shift, o.min_pos, (int32_t)slot, rank0 + o.rank};
+      // one occurrence that the 8-byte form can hold -> direct entry; anything else -> a list
+      if (cnt_[o.wid] == 1 && q.path < 32767 && q.min_pos <= 32767) { direct[o.wid] = q; occ8[o.wid] = occ8_pack(q, false); }
+      else pending_.push_back(Pending{o.wid, q});
+    }
+    rank0 += (int32_t)pm.occ[mate].size();
+  }
+  if (!pending_.empty()) {
+    // lists in order of first appearance, entries in visiting (rank) order
+    for (const Pending& pe : pending_)
+      if (list_of_[pe.wid] < 0) {
+        list_of_[pe.wid] = (int32_t)multi_off.size() - 1;
+        multi_off.push_back(multi_off.back() + cnt_[pe.wid]);
+        general_wids.push_back(pe.wid);
+        direct[pe.wid] = OccQuad{0, 0, pe.q.path, -(list_of_[pe.wid] + 1)};
+        occ8[pe.wid] = occ8_pack(pe.q, true);
+      }
+    multi.resize(multi_off.back());
+    std::vector<int32_t> fill(multi_off.size(), 0);
+    for (const Pending& pe : pending_) { int32_t l = list_of_[pe.wid]; multi[multi_off[l] + fill[l]++] = pe.q; }
+  }
+}
+
 void build_occ8(const OccTable& t, std::vector<uint64_t>& out) {
   out.resize(t.direct.size());
   for (size_t w = 0; w < t.direct.size(); w++) {

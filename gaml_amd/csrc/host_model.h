@@ -196,6 +196,25 @@ void build_occ8(const OccTable& t, std::vector<uint64_t>& out);
 
 void split_contigs(const Walk& path, std::vector<std::pair<int32_t, int32_t>>& ctg_ranges, std::vector<int32_t>& gaps);
 
+struct PlanView;
+// Host image of one mate's device occurrence tables (16-byte direct table + lists + 8-byte table),
+// kept between evaluations and patched: only the entries of windows that occurred in the previous
+// or occur in the current path set are touched, O(occurrences) per call instead of O(windows).
+struct OccImage {
+  std::vector<OccQuad> direct;
+  std::vector<uint64_t> occ8;
+  std::vector<int32_t> multi_off;
+  std::vector<OccQuad> multi;
+  std::vector<int32_t> general_wids;  // windows whose entry sends their reads to the general path
+  void build(size_t n_windows, const PlanView& view, int mate);
+ private:
+  std::vector<int32_t> touched_, cnt_, list_of_;
+  std::vector<uint32_t> stamp_;
+  uint32_t serial_ = 0;
+  struct Pending { int32_t wid; OccQuad q; };
+  std::vector<Pending> pending_;
+};
+
 // ---------------------------------------------------------------------------------------------
 // PairedPlanner: everything the host does for one paired read set per CalcProb, memoised per
 // distinct path. Replaces the reference's per-call GetChanges + hash-map position assembly

@@ -45,6 +45,18 @@ struct PairedArgs {
   const unsigned char* len_code;
   const uint32_t* len_combo;
   const unsigned long long* occ8[2];
+  // per length-combination tables of the compact path (host libm, indexed by len_code):
+  const double* pe[2];       // [code*64 + e] = mismatch^e * match^(L-e)  (the product of graph.cc:1859-1863)
+  const double* floor_c;     // [code] exp(c + k (L1+L2)); logfloor_c = log of it; covthr_c = exp(c + k 2 L2)
+  const double* logfloor_c;
+  const double* covthr_c;
+  // memoised floor/log of single-term pairs: the value of a pair with one alignment per mate depends
+  // only on (length code, edit 1, edit 2, insert distance) -- a few 10^4 combinations per evaluation.
+  // logterm_kernel evaluates the reference's floor + log once per combination (same device log on
+  // the same f64 value as the per-pair path), the compact path then looks the result up.
+  const double* lt;          // [((code*7 + e1)*7 + e2)*ins_n + dist] = floored ? log(floor) : log(term / 2T); null: off
+  const unsigned char* ltz;  // same index: 1 if floored
+  int lt_codes;              // codes covered (< lt_codes), edits < 7
   const int4* inl[2];        // inline records of the register classes: [2t + k] (class 1), [2 n1 + 4 t2 + k] (class 2)
   int n0;                    // first[] / extra[] / len12[] hold slots >= n0, indexed slot - n0
   int blocks0;               // blocks [0, blocks0): compact path; [blocks0, blocks01): <= 2 records; [blocks01, main_blocks): <= 4
@@ -315,10 +327,61 @@ __device__ __forceinline__ int4 rec8_to_quad(unsigned long long r) {  // 8-byte 
 // occurrence entries of a wave's lanes are mostly the same address (broadcast).
 struct Compact1 {  // one class-0 pair in flight
   unsigned long long r1, r2, o1, o2;
-  int L1, L2;
+  int L1, L2, lc;
 };
 
-__device__ __forceinline__ double compact_score(const PairedArgs& a, const Compact1& c, bool& skip) {
+// pair term of the compact path: same arithmetic as pair_term, the per-read error probability comes
+// from the per-length-combination product table
+__device__ __forceinline__ double pair_term_compact(const PairedArgs& a, const Cand& x, const Cand& y, int lc, int L1, int L2, int& dist) {
+  if (x.orient == y.orient) return 0.0;
+  if (x.pos < y.pos) {
+    if (x.orient != 0 || y.orient != 1) return 0.0;
+    dist = y.pos - x.pos + L2;
+  } else {
+    if (x.orient != 1 || y.orient != 0) return 0.0;
+    dist = x.pos - y.pos + L1;
+  }
+  const double p1 = a.pe[0][lc * 64 + x.edit];
+  const double p2 = a.pe[1][lc * 64 + y.edit];
+  const double ip = (unsigned)dist < (unsigned)a.ins_n ? a.ins_tab[dist] : 0.0;
+  const double t = p1 * p2 * ip;
+  if (a.cov_bits && t > a.covthr_c[lc]) {
+    int base = a.path_base[x.path];
+    mark_bit(a.cov_bits, base + max(x.pos, y.pos));
+    mark_bit(a.cov_bits, base + min(x.pos, y.pos));
+  }
+  return t;
+}
+
+// one thread per (length code, edit 1, edit 2, distance): GetTotalProb's per-read step
+// (graph.cc:1504-1513) for every value a single-term pair can take in this evaluation
+__global__ __launch_bounds__(kBlock) void logterm_kernel(const double* pe0, const double* pe1, const double* ins_tab, int ins_n,
+                                                        const double* floor_c, const double* logfloor_c, int codes, double two_T,
+                                                        double* lt, unsigned char* ltz) {
+  const int total = codes * 49 * ins_n;
+  for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+    const int dist = idx % ins_n;
+    const int q = idx / ins_n;
+    const int e2 = q % 7, e1 = (q / 7) % 7, code = q / 49;
+    const double t = pe0[code * 64 + e1] * pe1[code * 64 + e2] * ins_tab[dist];  // as pair_term_compact
+    const double p = t / two_T;
+    const bool floored = p < floor_c[code];
+    lt[idx] = floored ? logfloor_c[code] : log(p);
+    ltz[idx] = floored ? 1 : 0;
+  }
+}
+
+__device__ __forceinline__ void finish_read_compact(const PairedArgs& a, int i, double acc, int lc, int lt_idx, double& lsum, int& zeros) {
+  a.probs[i] = acc;
+  if (lt_idx >= 0) { lsum += a.lt[lt_idx]; zeros += a.ltz[lt_idx]; return; }  // memoised floor/log of this exact value
+  if (acc == 0.0) { zeros++; lsum += a.logfloor_c[lc]; return; }              // 0 / 2T < floor (floor > 0)
+  const double p = acc / a.two_T;
+  if (p < a.floor_c[lc]) { zeros++; lsum += a.logfloor_c[lc]; }
+  else lsum += log(p);
+}
+
+__device__ __forceinline__ double compact_score(const PairedArgs& a, const Compact1& c, bool& skip, int& lt_idx) {
+  lt_idx = -1;
   // a record in a window that needs the general path (occurs several times, ...): the host put
   // this pair on the overflow list
   skip = (c.o1 != kNone8 && (c.o1 >> 63)) || (c.o2 != kNone8 && (c.o2 >> 63));
@@ -328,7 +391,11 @@ __device__ __forceinline__ double compact_score(const PairedArgs& a, const Compa
   Cand x, y;
   x.path = (int)(c.o1 >> 48); x.pos = p1 + (int)(unsigned)c.o1; x.edit = (int)((c.r1 >> 52) & 63); x.orient = (int)((c.r1 >> 58) & 1);
   y.path = x.path; y.pos = p2 + (int)(unsigned)c.o2; y.edit = (int)((c.r2 >> 52) & 63); y.orient = (int)((c.r2 >> 58) & 1);
-  return pair_term(a, x, y, c.L1, c.L2);
+  int dist = -1;
+  const double t = pair_term_compact(a, x, y, c.lc, c.L1, c.L2, dist);
+  if (a.lt && dist >= 0 && dist < a.ins_n && c.lc < a.lt_codes && x.edit < 7 && y.edit < 7)
+    lt_idx = ((c.lc * 7 + x.edit) * 7 + y.edit) * a.ins_n + dist;
+  return t;
 }
 
 template <int ABL>
@@ -346,6 +413,7 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
     const unsigned char lc1 = two ? a.len_code[i1] : 0;
     const uint32_t l0 = a.len_combo[lc0], l1 = a.len_combo[lc1];
     c0.L1 = l0 & 0xffff; c0.L2 = l0 >> 16; c1.L1 = l1 & 0xffff; c1.L2 = l1 >> 16;
+    c0.lc = lc0; c1.lc = lc1;
     if (ABL == 1 || ABL == 4) {
       a.probs[i0] = (double)(int)(c0.r1 + c0.r2 + c0.L1); lsum += (double)(int)c0.r1;
       if (two) { a.probs[i1] = (double)(int)(c1.r1 + c1.r2 + c1.L1); lsum += (double)(int)c1.r1; }
@@ -361,11 +429,12 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
       continue;
     }
     bool s0, s1;
-    const double acc0 = compact_score(a, c0, s0);
-    const double acc1 = compact_score(a, c1, s1);
+    int k0, k1;
+    const double acc0 = compact_score(a, c0, s0, k0);
+    const double acc1 = compact_score(a, c1, s1, k1);
     if (ABL == 3) { a.probs[i0] = acc0; lsum += acc0; if (two) { a.probs[i1] = acc1; lsum += acc1; } continue; }
-    if (!s0) finish_read(a, i0, acc0, c0.L1, c0.L2, lsum, zeros);
-    if (two && !s1) finish_read(a, i1, acc1, c1.L1, c1.L2, lsum, zeros);
+    if (!s0) finish_read_compact(a, i0, acc0, c0.lc, k0, lsum, zeros);
+    if (two && !s1) finish_read_compact(a, i1, acc1, c1.lc, k1, lsum, zeros);
   }
 }
 
