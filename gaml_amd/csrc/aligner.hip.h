@@ -1,0 +1,252 @@
+// aligner.hip.h -- window alignment on the GPU (the cold path of CalcProb: reference
+// AlignSubpathInternal graph.cc:839-899, ReadIndexMinHash::GetMinHashWithPoses / GetReadCandsWithPoses
+// graph.cc:1289-1348, ProcessHit graph.cc:730-837). Same accept set, error counts and positions as
+// the host aligner in host_model.cc (tests/test_gpu_aligner.py compares them record by record).
+//
+// Three kernels per batch of windows:
+//   span_maxima_kernel   one block per (window, strand): scrambled 15-mer codes of the window
+//                        string, sliding maximum over read-length spans, emission where it changes
+//   candidates_kernel    one lane per emitted span: bucket of the max-hash index -> candidates
+//   extend_kernel        one lane per candidate: locate the seed in the read, then the reference's
+//                        0-1 BFS as a FIFO of chain heads with a per-diagonal visited bitset
+// Records leave as (window, position, edit distance, read, strand, order) and are sorted / deduplicated
+// per window on the host exactly like the host aligner does.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gaml {
+
+constexpr int kAlnBlock = 256;
+constexpr int kAlnSeed = 15;
+constexpr int kAlnMaxRead = 254;  // visited bitset: 4 x 64 bits per diagonal
+
+struct AlnWindow { int32_t str_off, len, offset; };   // window string in the batch buffer; offset = trimmed prefix (graph.cc:850)
+
+struct AlnSpan { uint32_t hash; int32_t pos, win, strand, order; };  // emitted (hash, index of the seed's last base)
+struct AlnCand { int32_t win, strand, order, seed_end, read; };
+struct AlnHit { int32_t win, pos, edit, read, strand, order; };       // edit < 0: no alignment
+
+__device__ __forceinline__ uint32_t aln_code(char c) {  // graph.h:326-331 (G0 A1 T2 C3; anything else 0)
+  return c == 'A' ? 1u : c == 'T' ? 2u : c == 'C' ? 3u : 0u;
+}
+__device__ __forceinline__ char aln_comp(char c) {  // graph.h:58-64
+  return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+}
+// base j of the window string on the given strand (strand 1 = reverse complement, graph.h:66-72)
+__device__ __forceinline__ char aln_wbase(const char* s, int W, int strand, int j) {
+  return strand == 0 ? s[j] : aln_comp(s[W - 1 - j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. sliding maximum (graph.cc:1289-1323). hbuf = scratch for the codes, one uint32 per window base
+//    and strand. Emission rule: at i == R-1 and wherever the span maximum differs from the previous
+//    span's; the position is the EARLIEST seed attaining the maximum.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kAlnBlock) void span_maxima_kernel(const char* wstr, const AlnWindow* wins, int n_win, int R,
+                                                               uint32_t* hbuf, const int64_t* hbuf_off, AlnSpan* spans,
+                                                               unsigned* n_spans, unsigned cap_spans) {
+  const int w = blockIdx.x >> 1, strand = blockIdx.x & 1;
+  if (w >= n_win) return;
+  const AlnWindow win = wins[w];
+  const char* s = wstr + win.str_off;
+  const int W = win.len;
+  uint32_t* h = hbuf + hbuf_off[w] + (int64_t)strand * W;
+  // scrambled code of the 15-mer ENDING at j
+  for (int j = threadIdx.x; j < W; j += kAlnBlock) {
+    uint32_t code = 0;
+    if (j >= kAlnSeed - 1) {
+      for (int k = j - kAlnSeed + 1; k <= j; k++) code = (code << 2) | aln_code(aln_wbase(s, W, strand, k));
+      code ^= 0x2204abcdu;
+    }
+    h[j] = code;
+  }
+  __syncthreads();
+  __shared__ int sh_cnt[kAlnBlock];
+  __shared__ unsigned sh_base;
+  const int first_i = R - 1 > kAlnSeed ? R - 1 : kAlnSeed;  // the reference's loop starts at i = kIndexKmer
+  int emitted_before = 0;                                  // spans this (window, strand) emitted in earlier chunks
+  for (int base = first_i; base < W; base += kAlnBlock) {
+    const int i = base + threadIdx.x;
+    uint32_t m = 0, mprev = 0;
+    int p = -1;
+    bool emit = false;
+    if (i < W) {
+      const int lo = i - R + kAlnSeed > kAlnSeed - 1 ? i - R + kAlnSeed : kAlnSeed - 1;
+      for (int j = lo; j <= i; j++) { const uint32_t v = h[j]; if (p < 0 || v > m) { m = v; p = j; } }  // strictly greater: earliest maximum
+      if (i == R - 1) emit = true;
+      else {
+        const int lo2 = (i - 1) - R + kAlnSeed > kAlnSeed - 1 ? (i - 1) - R + kAlnSeed : kAlnSeed - 1;
+        for (int j = lo2; j <= i - 1; j++) { uint32_t v = h[j]; if (v > mprev) mprev = v; }
+        // previous span's maximum == what the reference last emitted, except before the first emission
+        // (i-1 < R-1 can only happen when R-1 < kAlnSeed; the host path handles such short reads)
+        emit = m != mprev;
+      }
+    }
+    // ordered compaction inside the block
+    sh_cnt[threadIdx.x] = emit ? 1 : 0;
+    __syncthreads();
+    for (int d = 1; d < kAlnBlock; d <<= 1) {
+      int t = threadIdx.x >= d ? sh_cnt[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh_cnt[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const int total = sh_cnt[kAlnBlock - 1];
+    if (threadIdx.x == 0) sh_base = total ? atomicAdd(n_spans, (unsigned)total) : 0;
+    __syncthreads();
+    if (emit) {
+      const unsigned at = sh_base + sh_cnt[threadIdx.x] - 1;
+      if (at < cap_spans) spans[at] = AlnSpan{m, p, w, strand, emitted_before + sh_cnt[threadIdx.x] - 1};
+    }
+    emitted_before += total;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. candidates: every read of the bucket whose key is the span's hash (graph.cc:1329-1347)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kAlnBlock) void candidates_kernel(const AlnSpan* spans, const unsigned* n_spans, unsigned cap_spans,
+                                                              const uint64_t* bucket_hash, const int32_t* bucket_off,
+                                                              const int32_t* bucket_reads, int n_buckets, AlnCand* cands,
+                                                              unsigned* n_cands, unsigned cap_cands) {
+  const unsigned n = *n_spans < cap_spans ? *n_spans : cap_spans;
+  for (unsigned t = blockIdx.x * kAlnBlock + threadIdx.x; t < n; t += gridDim.x * kAlnBlock) {
+    const AlnSpan sp = spans[t];
+    int lo = 0, hi = n_buckets;  // lower_bound
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (bucket_hash[mid] < (uint64_t)sp.hash) lo = mid + 1; else hi = mid; }
+    if (lo >= n_buckets || bucket_hash[lo] != (uint64_t)sp.hash) continue;
+    const int b0 = bucket_off[lo], b1 = bucket_off[lo + 1];
+    const unsigned at = atomicAdd(n_cands, (unsigned)(b1 - b0));
+    for (int k = b0; k < b1; k++) {
+      const unsigned o = at + (unsigned)(k - b0);
+      if (o < cap_cands) cands[o] = AlnCand{sp.win, sp.strand, sp.order, sp.pos, bucket_reads[k]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. seed extension (ProcessHit graph.cc:753-837). A popped state slides down its diagonal while
+//    bases match and the next cell is unvisited (the reference pushes such a step to the FRONT of its
+//    deque, so it is popped next); at the first mismatch it appends its <= 3 successors at cost + 1.
+//    Heads leave the FIFO in non-decreasing cost; cost > 3 ends the search. Visited cells: one
+//    256-bit set per diagonal shift in [-4, 4].
+// ---------------------------------------------------------------------------------------------
+struct AlnSearch {
+  uint32_t q[128];        // heads: r+1 (10 bits) | diag+4 (4 bits) | cost (3 bits)
+  uint64_t vis[9][4];
+  int qn;
+  __device__ __forceinline__ void reset() {
+    qn = 0;
+    for (int k = 0; k < 9; k++) for (int t = 0; t < 4; t++) vis[k][t] = 0;
+  }
+  __device__ __forceinline__ bool mark(int diag, int r) {  // true if (diag, r) was unvisited
+    const int b = r + 1;
+    const uint64_t m = 1ull << (b & 63);
+    uint64_t& w = vis[diag + 4][b >> 6];
+    if (w & m) return false;
+    w |= m;
+    return true;
+  }
+  __device__ __forceinline__ void push(int d, int diag, int r) { if (qn < 128) q[qn++] = (uint32_t)(r + 1) | ((uint32_t)(diag + 4) << 10) | ((uint32_t)d << 14); }
+};
+
+// rd(i): base i of the read as aligned (strand 1: reverse complement of the stored read)
+__device__ __forceinline__ char aln_rbase(const char* read, int R, int strand, int i) {
+  return strand == 0 ? read[i] : aln_comp(read[R - 1 - i]);
+}
+
+__global__ __launch_bounds__(64) void extend_kernel(const AlnCand* cands, const unsigned* n_cands, unsigned cap_cands,
+                                                    const char* wstr, const AlnWindow* wins, const char* reads,
+                                                    const int64_t* read_off, AlnHit* hits) {
+  const unsigned n = *n_cands < cap_cands ? *n_cands : cap_cands;
+  const unsigned t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= n) return;
+  const AlnCand c = cands[t];
+  AlnHit out{c.win, 0, -1, c.read, c.strand, c.order};
+  const AlnWindow win = wins[c.win];
+  const char* ws = wstr + win.str_off;  // ProcessHit always works on the FORWARD window string
+  const int W = win.len;
+  const char* rd = reads + read_off[c.read];
+  const int R = (int)(read_off[c.read + 1] - read_off[c.read]);
+  // seed start in the forward window string (graph.cc:866-872)
+  const int win_pos = c.strand == 0 ? c.seed_end - kAlnSeed + 1 : W - (c.seed_end + 1);
+  // first position of the (oriented) read carrying the window's seed (graph.cc:873-879)
+  int read_pos = -1;
+  for (int i = 0; i + kAlnSeed <= R && read_pos < 0; i++) {
+    bool same = true;
+    for (int k = 0; k < kAlnSeed && same; k++) same = aln_rbase(rd, R, c.strand, i + k) == ws[win_pos + k];
+    if (same) read_pos = i;
+  }
+  if (read_pos < 0 || R > kAlnMaxRead) { hits[t] = out; return; }
+  AlnSearch S;
+  // ---- forward (graph.cc:761-793)
+  int fwd = -1, end_pos = -1;
+  S.reset();
+  S.push(0, 0, read_pos + kAlnSeed);
+  for (int qi = 0; qi < S.qn && fwd < 0; qi++) {
+    const uint32_t e = S.q[qi];
+    const int d = (int)(e >> 14), diag = (int)((e >> 10) & 15) - 4;
+    int r = (int)(e & 1023) - 1;
+    int g = win_pos + (r - read_pos) + diag;
+    if (d > 3) { hits[t] = out; return; }
+    while (true) {
+      if (r == R) { fwd = d; end_pos = g - 1; break; }
+      const char wc = g < W ? ws[g] : '\0';  // the reference reads the string terminator at g == W
+      if (wc == aln_rbase(rd, R, c.strand, r)) {
+        if (g + 1 < W || r + 1 == R) {
+          if (!S.mark(diag, r + 1)) break;
+          g++; r++;
+          continue;
+        }
+        break;
+      }
+      if (g + 1 < W) {
+        if (S.mark(diag, r + 1)) S.push(d + 1, diag, r + 1);          // substitution
+        if (S.mark(diag + 1, r)) S.push(d + 1, diag + 1, r);          // window base skipped
+      }
+      if (S.mark(diag - 1, r + 1)) S.push(d + 1, diag - 1, r + 1);    // read base skipped
+      break;
+    }
+  }
+  if (fwd < 0) { hits[t] = out; return; }
+  // ---- backward (graph.cc:794-835)
+  int bwd = -1, begin_pos = -1;
+  if (win_pos == 0) {
+    if (read_pos < 6) bwd = read_pos;
+  } else {
+    S.reset();
+    S.push(0, 0, read_pos - 1);
+    for (int qi = 0; qi < S.qn && bwd < 0; qi++) {
+      const uint32_t e = S.q[qi];
+      const int d = (int)(e >> 14), diag = (int)((e >> 10) & 15) - 4;
+      int r = (int)(e & 1023) - 1;
+      int g = win_pos + (r - read_pos) + diag;
+      if (d > 3) { hits[t] = out; return; }
+      while (true) {
+        if (r == -1) { bwd = d; begin_pos = g + 1; break; }
+        if (ws[g] == aln_rbase(rd, R, c.strand, r)) {
+          if (g - 1 >= 0 || r - 1 == -1) {
+            if (!S.mark(diag, r - 1)) break;
+            g--; r--;
+            continue;
+          }
+          break;
+        }
+        if (g - 1 >= 0) {
+          if (S.mark(diag, r - 1)) S.push(d + 1, diag, r - 1);
+          if (S.mark(diag - 1, r)) S.push(d + 1, diag - 1, r);
+        }
+        if (S.mark(diag + 1, r - 1)) S.push(d + 1, diag + 1, r - 1);
+        break;
+      }
+    }
+  }
+  if (bwd < 0) { hits[t] = out; return; }
+  out.pos = begin_pos + 1 + win.offset;  // graph.cc:890
+  out.edit = fwd + bwd;
+  hits[t] = out;
+}
+
+}  // namespace gaml

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "aligner.hip.h"
 #include "host_model.h"
 #include "kernels.hip.h"
 
@@ -77,8 +78,19 @@ struct Reducer {  // per read set: partials + ticket + 2-double result
   void release() { part_sum.release(); part_zero.release(); ticket.release(); out.release(); }
 };
 
+struct AlignDev {  // device copies the GPU aligner needs: reads (1 byte per base) + the max-hash index
+  DevBuf reads, read_off, bucket_hash, bucket_off, bucket_reads;
+  bool uploaded = false;
+  void release() { reads.release(); read_off.release(); bucket_hash.release(); bucket_off.release(); bucket_reads.release(); }
+};
+struct AlignScratch {  // per context, grown on demand
+  DevBuf wstr, wins, hbuf, hbuf_off, spans, cands, hits, counters;
+  void release() { wstr.release(); wins.release(); hbuf.release(); hbuf_off.release(); spans.release(); cands.release(); hits.release(); counters.release(); }
+};
+
 struct MateDev {
   DevBuf first, extra, pows;  // pows = mismatch_pow | match_pow
+  AlignDev aln;
   uint64_t uploaded_generation = ~0ull;
   size_t pow_n = 0;
 };
@@ -160,6 +172,9 @@ struct gaml_hip_ctx {
   std::vector<std::unique_ptr<PacbioSet>> pacbios;
   std::vector<SetRef> handles;  // creation order -> (kind, index)
   int32_t rank = 0, world = 1;
+  AlignScratch aln_scratch;
+  int64_t aln_windows = 0, aln_candidates = 0;  // GPU aligner statistics
+  double aln_us = 0;
   int knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
   int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;
@@ -891,6 +906,117 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// GPU window alignment of every pending window of one mate (cold path). Falls back to the host
+// aligner for inputs the kernels do not cover (reads shorter than 16 or longer than 254 bases,
+// mixed read lengths are fine). Records are identical to the host aligner's.
+// ---------------------------------------------------------------------------------------
+int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
+  if (m.pending.empty()) return 0;
+  if (c->device < 0 || c->knobs[5] == 1 || m.index_read_len < 16 || m.max_len > kAlnMaxRead || m.n_local() == 0 ||
+      m.bucket_hash.empty()) {
+    m.flush_pending_cpu(c->g);
+    return 0;
+  }
+  const double t0 = now_us();
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!d.uploaded) {
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+      hipError_t e = b.reserve(std::max<size_t>(16, bytes));
+      return (e != hipSuccess || bytes == 0) ? e : hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIP_TRY(c, up(d.reads, m.bases.data(), m.bases.size()));
+    HIP_TRY(c, up(d.read_off, m.roff.data(), m.roff.size() * sizeof(int64_t)));
+    HIP_TRY(c, up(d.bucket_hash, m.bucket_hash.data(), m.bucket_hash.size() * sizeof(uint64_t)));
+    HIP_TRY(c, up(d.bucket_off, m.bucket_off.data(), m.bucket_off.size() * sizeof(int32_t)));
+    HIP_TRY(c, up(d.bucket_reads, m.bucket_reads.data(), m.bucket_reads.size() * sizeof(int32_t)));
+    d.uploaded = true;
+  }
+  AlignScratch& S = c->aln_scratch;
+  const int nw = (int)m.pending.size();
+  // window strings (graph.cc:846-857), concatenated
+  std::string wstr;
+  std::vector<AlnWindow> wins(nw);
+  std::vector<int64_t> hoff(nw);
+  int64_t hbuf_total = 0;
+  for (int k = 0; k < nw; k++) {
+    int32_t off = 0;
+    std::string ws = m.window_string(c->g, *m.win_walk[m.pending[k]], &off);
+    wins[k] = AlnWindow{(int32_t)wstr.size(), (int32_t)ws.size(), off};
+    hoff[k] = hbuf_total;
+    hbuf_total += 2 * (int64_t)ws.size();
+    wstr += ws;
+  }
+  HIP_TRY(c, S.wstr.reserve(std::max<size_t>(16, wstr.size())));
+  HIP_TRY(c, S.wins.reserve(nw * sizeof(AlnWindow)));
+  HIP_TRY(c, S.hbuf_off.reserve(nw * sizeof(int64_t)));
+  HIP_TRY(c, S.hbuf.reserve(std::max<int64_t>(16, hbuf_total * 4)));
+  HIP_TRY(c, S.counters.reserve(16));
+  if (!wstr.empty()) HIP_TRY(c, hipMemcpy(S.wstr.p, wstr.data(), wstr.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(S.wins.p, wins.data(), nw * sizeof(AlnWindow), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(S.hbuf_off.p, hoff.data(), nw * sizeof(int64_t), hipMemcpyHostToDevice));
+  size_t cap_spans = std::max<size_t>(1 << 16, wstr.size());        // a span per window base and strand at most ~2x
+  size_t cap_cands = std::max<size_t>(1 << 18, 8 * wstr.size());
+  unsigned counts[2] = {0, 0};
+  for (int attempt = 0; attempt < 6; attempt++) {
+    HIP_TRY(c, S.spans.reserve(cap_spans * sizeof(AlnSpan)));
+    HIP_TRY(c, S.cands.reserve(cap_cands * sizeof(AlnCand)));
+    HIP_TRY(c, hipMemset(S.counters.p, 0, 16));
+    hipLaunchKernelGGL(span_maxima_kernel, dim3(2 * nw), dim3(kAlnBlock), 0, 0, S.wstr.as<char>(), S.wins.as<AlnWindow>(), nw,
+                       m.index_read_len, S.hbuf.as<uint32_t>(), S.hbuf_off.as<int64_t>(), S.spans.as<AlnSpan>(),
+                       S.counters.as<unsigned>(), (unsigned)cap_spans);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(candidates_kernel, dim3(256), dim3(kAlnBlock), 0, 0, S.spans.as<AlnSpan>(), S.counters.as<unsigned>(),
+                       (unsigned)cap_spans, d.bucket_hash.as<uint64_t>(), d.bucket_off.as<int32_t>(), d.bucket_reads.as<int32_t>(),
+                       (int)m.bucket_hash.size(), S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1, (unsigned)cap_cands);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpy(counts, S.counters.p, sizeof(counts), hipMemcpyDeviceToHost));
+    if (counts[0] <= cap_spans && counts[1] <= cap_cands) break;
+    cap_spans = std::max<size_t>(cap_spans, (size_t)counts[0] + 16);
+    cap_cands = std::max<size_t>(cap_cands, (size_t)counts[1] + 16);
+    if (attempt == 5) { m.flush_pending_cpu(c->g); return 0; }
+  }
+  const unsigned nc = counts[1];
+  std::vector<AlnHit> hits(nc);
+  if (nc) {
+    HIP_TRY(c, S.hits.reserve((size_t)nc * sizeof(AlnHit)));
+    hipLaunchKernelGGL(extend_kernel, dim3((nc + 63) / 64), dim3(64), 0, 0, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1,
+                       (unsigned)cap_cands, S.wstr.as<char>(), S.wins.as<AlnWindow>(), d.reads.as<char>(), d.read_off.as<int64_t>(),
+                       S.hits.as<AlnHit>());
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpy(hits.data(), S.hits.p, (size_t)nc * sizeof(AlnHit), hipMemcpyDeviceToHost));
+  }
+  // per window: sort by (position, read), the first alignment found for a key survives
+  // (graph.cc:841, 891, 895-897); per read its candidates are visited forward-strand spans first
+  std::vector<AlnHit> ok;
+  ok.reserve(nc);
+  for (const AlnHit& h : hits) if (h.edit >= 0) ok.push_back(h);
+  std::sort(ok.begin(), ok.end(), [](const AlnHit& a, const AlnHit& b) {
+    if (a.win != b.win) return a.win < b.win;
+    if (a.pos != b.pos) return a.pos < b.pos;
+    if (a.read != b.read) return a.read < b.read;
+    if (a.strand != b.strand) return a.strand < b.strand;
+    return a.order < b.order;
+  });
+  size_t at = 0;
+  std::vector<gaml_aligment> recs;
+  for (int k = 0; k < nw; k++) {
+    recs.clear();
+    size_t begin = at;
+    while (at < ok.size() && ok[at].win == k) {
+      if (at == begin || ok[at].pos != ok[at - 1].pos || ok[at].read != ok[at - 1].read)
+        recs.push_back(gaml_aligment{ok[at].pos, ok[at].edit, ok[at].read, ok[at].strand});
+      at++;
+    }
+    m.finalize_window(m.pending[k], recs);
+  }
+  m.pending.clear();
+  c->aln_windows += nw;
+  c->aln_candidates += nc;
+  c->aln_us += now_us() - t0;
+  return 0;
+}
+
 std::vector<ShortMate*> filter_mates(gaml_hip_ctx* c) {  // mates whose windows feed a position filter, in handle order
   std::vector<ShortMate*> v;
   for (auto& h : c->handles)
@@ -915,6 +1041,9 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
   for (size_t i = 0; i < c->paireds.size(); i++) {
     c->pending_prep[i].reset(new PairedPrep());
     prepare_paired_structure(c, *c->paireds[i], c->pending_paths, *c->pending_prep[i]);
+    // windows registered by pass 1 get their records now, all at once (GPU aligner when there is a device)
+    for (int mt = 0; mt < 2; mt++)
+      if (int e = gpu_align_pending(c, c->paireds[i]->mate[mt], c->paireds[i]->dev[mt].aln)) return e;
   }
   int64_t n = 0;
   for (ShortMate* m : filter_mates(c)) {
@@ -1034,13 +1163,13 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     auto drop_stage = [](Staging& s) { for (int k = 0; k < kRing; k++) { s.host[k].release(); if (s.done[k]) (void)hipEventDestroy(s.done[k]); } };
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
-      for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); }
+      for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
       s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->lt.release(); s->ltz.release(); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
       s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->cov_meta.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); s->bad_host.release(); drop_stage(s->stage);
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage); }
-    c->packed.release(); c->packed_host.release();
+    c->packed.release(); c->packed_host.release(); c->aln_scratch.release();
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -1108,6 +1237,7 @@ int gaml_hip_add_paired(gaml_hip_ctx* c, const gaml_paired_cfg* cfg, int32_t n, 
   s->cfg = *cfg;
   init_mate(c, s->mate[0], cfg->mismatch_prob, n, b1, o1);
   init_mate(c, s->mate[1], cfg->mismatch_prob, n, b2, o2);
+  s->mate[0].defer_alignment = s->mate[1].defer_alignment = true;  // batched: see gpu_align_pending
   if (s->mate[0].max_len > 65535 || s->mate[1].max_len > 65535) return fail(c, GAML_HIP_EINVAL, "paired reads longer than 65535 bases");
   c->paireds.push_back(std::move(s));
   c->handles.push_back(SetRef{1, (int)c->paireds.size() - 1});
@@ -1402,6 +1532,7 @@ int64_t gaml_hip_window_records(gaml_hip_ctx* c, int rs, int mate, const int32_t
   if (!m || !subpath || len <= 0) return -2;
   int32_t id = m->find(Walk(subpath, subpath + len));
   if (id < 0) return -1;
+  if (m->wins[id].pending) m->flush_pending_cpu(c->g);
   const Window& w = m->wins[id];
   for (int64_t i = 0; i < w.count && i < cap; i++) {
     out[i] = m->pool[w.first + i];
@@ -1414,6 +1545,11 @@ int64_t gaml_hip_align_window(gaml_hip_ctx* c, int rs, int mate, const int32_t* 
   ShortMate* m = mate_of(c, rs, mate);
   if (!m || !subpath || len <= 0 || !c->have_graph) return -2;
   int32_t id = m->align(c->g, Walk(subpath, subpath + len));
+  if (m->wins[id].pending) {
+    SetRef h = c->handles[rs];
+    if (h.kind == 1) { if (gpu_align_pending(c, *m, c->paireds[h.idx]->dev[mate].aln)) return -3; }
+    else m->flush_pending_cpu(c->g);
+  }
   return m->wins[id].count;
 }
 
@@ -1423,7 +1559,13 @@ int gaml_hip_debug_prepare(gaml_hip_ctx* c, const int32_t* flat, const int64_t* 
   std::vector<Walk> paths = unflatten(flat, offs, n_paths);
   for (auto& h : scoring_order(c)) {
     if (h.kind == 0) { std::vector<Occ> occs; prepare_single_host(c, *c->singles[h.idx], paths, occs); }
-    else if (h.kind == 1) { PairedPrep p; prepare_paired_host(c, *c->paireds[h.idx], paths, p); }
+    else if (h.kind == 1) {
+      PairedPrep p;
+      PairedSet& ps = *c->paireds[h.idx];
+      prepare_paired_structure(c, ps, paths, p);
+      for (int mt = 0; mt < 2; mt++) if (int e = gpu_align_pending(c, ps.mate[mt], ps.dev[mt].aln)) return e;
+      prepare_paired_tables_host(c, ps, p);
+    }
   }
   if (c->peers == 1) {
     for (ShortMate* m : filter_mates(c)) m->unsynced.clear();
@@ -1451,6 +1593,14 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wi
   const Walk& w = *m->win_walk[wid];
   for (int32_t i = 0; i < (int32_t)w.size() && i < cap; i++) out[i] = w[i];
   return (int32_t)w.size();
+}
+
+int gaml_hip_aligner_stats(gaml_hip_ctx* c, int64_t* windows, int64_t* candidates, double* microseconds) {
+  if (!c) return GAML_HIP_EINVAL;
+  if (windows) *windows = c->aln_windows;
+  if (candidates) *candidates = c->aln_candidates;
+  if (microseconds) *microseconds = c->aln_us;
+  return GAML_HIP_OK;
 }
 
 int gaml_hip_debug_profile(gaml_hip_ctx* c, double* out8) {

@@ -292,25 +292,29 @@ static void revcomp_into(const char* s, int32_t n, std::string& out) {
 int32_t ShortMate::add_window(const Walk& w, std::vector<gaml_aligment>& recs) {
   auto it = win_id.find(w);
   if (it != win_id.end()) return it->second;  // re-alignment would give the same records
-  Window win;
-  win.first = (int64_t)pool.size();
-  win.count = (int32_t)recs.size();
-  for (auto& r : recs) win.max_pos = std::max(win.max_pos, r.position);
-  win.global_max_pos = win.max_pos;
-  pool.insert(pool.end(), recs.begin(), recs.end());
   int32_t id = (int32_t)wins.size();
-  unsynced.push_back(id);
-  added_log.push_back(id);
-  wins.push_back(win);
+  wins.push_back(Window());
   auto ins = win_id.emplace(w, id);
   win_walk.push_back(&ins.first->first);
+  unsynced.push_back(id);
+  added_log.push_back(id);
   generation++;
+  finalize_window(id, recs);
   return id;
 }
 
-int32_t ShortMate::align(const GraphStore& g, const Walk& w) {
-  int32_t existing = find(w);
-  if (existing >= 0) return existing;
+void ShortMate::finalize_window(int32_t wid, std::vector<gaml_aligment>& recs) {
+  Window& win = wins[wid];
+  win.first = (int64_t)pool.size();
+  win.count = (int32_t)recs.size();
+  win.max_pos = INT_MIN;
+  for (auto& r : recs) win.max_pos = std::max(win.max_pos, r.position);
+  win.global_max_pos = win.max_pos;
+  win.pending = false;
+  pool.insert(pool.end(), recs.begin(), recs.end());
+}
+
+void ShortMate::cpu_align_records(const GraphStore& g, const Walk& w, std::vector<gaml_aligment>& recs) const {
   int32_t offset = 0;
   std::string ws = window_string(g, w, &offset), rc;
   revcomp_into(ws.data(), (int32_t)ws.size(), rc);
@@ -339,7 +343,7 @@ int32_t ShortMate::align(const GraphStore& g, const Walk& w) {
         int32_t read_pos = -1;
         for (int32_t i = 0; i + kSeed <= R; i++)
           if (memcmp(rs + i, ws.data() + win_pos, kSeed) == 0) { read_pos = i; break; }
-        if (read_pos < 0) continue;  // cannot happen: the bucket key is a seed of this read
+        if (read_pos < 0) continue;  // cannot happen for ACGT windows: the bucket key is a seed of this read
         Extension e;
         if (extend_seed(win_pos, read_pos, rs, R, ws.data(), W, &e))
           hits.push_back(Hit{e.begin + 1 + offset, e.errs, rid, strand, order++});
@@ -354,14 +358,41 @@ int32_t ShortMate::align(const GraphStore& g, const Walk& w) {
     if (a.read != b.read) return a.read < b.read;
     return a.order < b.order;
   });
-  std::vector<gaml_aligment> recs;
+  recs.clear();
   recs.reserve(hits.size());
   for (size_t i = 0; i < hits.size(); i++) {
     if (i > 0 && hits[i].pos == hits[i - 1].pos && hits[i].read == hits[i - 1].read) continue;
     recs.push_back(gaml_aligment{hits[i].pos, hits[i].edit, hits[i].read, hits[i].orient});
   }
+}
+
+int32_t ShortMate::align(const GraphStore& g, const Walk& w) {
+  int32_t existing = find(w);
+  if (existing >= 0) return existing;
   windows_aligned++;
-  return add_window(w, recs);
+  // register first: what the registration rules and the placements look at is cache membership
+  int32_t id = (int32_t)wins.size();
+  wins.push_back(Window());
+  wins[id].pending = true;
+  auto ins = win_id.emplace(w, id);
+  win_walk.push_back(&ins.first->first);
+  unsynced.push_back(id);
+  added_log.push_back(id);
+  generation++;
+  if (defer_alignment) { pending.push_back(id); return id; }
+  std::vector<gaml_aligment> recs;
+  cpu_align_records(g, w, recs);
+  finalize_window(id, recs);
+  return id;
+}
+
+void ShortMate::flush_pending_cpu(const GraphStore& g) {
+  std::vector<gaml_aligment> recs;
+  for (int32_t id : pending) {
+    cpu_align_records(g, *win_walk[id], recs);
+    finalize_window(id, recs);
+  }
+  pending.clear();
 }
 
 // ---------------------------------------------------------------------------------------

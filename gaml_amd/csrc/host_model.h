@@ -53,6 +53,7 @@ struct Window {
   int32_t max_pos = INT_MIN;  // largest record position among THIS shard's reads (INT_MIN when empty)
   int32_t global_max_pos = INT_MIN;  // ... among all shards' reads (== max_pos until exchanged)
   bool active = false;        // has occurred in a scored path set: its records are on the device
+  bool pending = false;       // registered, records not computed yet (batched alignment)
 };
 
 // One occurrence of a window in the path set being scored.
@@ -104,8 +105,15 @@ struct ShortMate {
   void build_index();
   int32_t find(const Walk& w) const { auto it = win_id.find(w); return it == win_id.end() ? -1 : it->second; }
   int32_t add_window(const Walk& w, std::vector<gaml_aligment>& recs_sorted_local);
-  // the library's own aligner (AlignSubpathInternal graph.cc:839-899)
+  // the library's own aligner (AlignSubpathInternal graph.cc:839-899). With defer_alignment the
+  // window is only registered (cache membership is what the registration rules look at); its
+  // records are computed later for the whole batch: flush_pending_cpu, or the GPU aligner.
   int32_t align(const GraphStore& g, const Walk& w);
+  bool defer_alignment = false;
+  std::vector<int32_t> pending;          // registered windows without records, in id order
+  void cpu_align_records(const GraphStore& g, const Walk& w, std::vector<gaml_aligment>& recs) const;
+  void finalize_window(int32_t wid, std::vector<gaml_aligment>& recs_sorted_local);
+  void flush_pending_cpu(const GraphStore& g);
   std::string window_string(const GraphStore& g, const Walk& w, int32_t* offset) const;
 };
 
