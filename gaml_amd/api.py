@@ -112,6 +112,7 @@ def _load():
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
     L.gaml_hip_debug_profile.argtypes = [vp, _f64p]
+    L.gaml_hip_debug_table_stats.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_aligner_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.gaml_hip_last_timing.argtypes = [vp, _f64p]
     L.gaml_hip_set_event_timing.argtypes = [vp, C.c_int]
@@ -342,6 +343,11 @@ class Context:
             buf = np.zeros(n, np.int32)
             _lib.gaml_hip_debug_window_walk(self._h, rs, mate, wid, buf, n)
         return [int(x) for x in buf[:n]]
+
+    def debug_table_stats(self, rs):
+        out = np.zeros(3, np.int64)
+        self._check(_lib.gaml_hip_debug_table_stats(self._h, rs, out))
+        return {"full_rebuilds": int(out[0]), "delta_updates": int(out[1]), "dirty_pairs": int(out[2])}
 
     def aligner_stats(self):
         w, k, us = C.c_int64(), C.c_int64(), C.c_double()

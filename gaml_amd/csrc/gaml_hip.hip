@@ -103,6 +103,13 @@ struct PairedSet {
   DevBuf rec8[2], len_code, len_combo, inl[2], combo_tabs, lt, ltz;
   double lt_two_T = -1;   // 2T the memo table was last built for (-1: stale)
   int lt_codes = 0;
+  // delta since the last full table build: pairs whose record lists gained records of newly
+  // activated windows. Their complete lists (device-table order: window id, position) travel with
+  // every evaluation; a full rebuild folds them back in when they become too many.
+  struct DirtyPair { int32_t slot; std::vector<RecQuad> recs[2]; };
+  std::vector<DirtyPair> dirty;
+  std::unordered_map<int32_t, int32_t> dirty_index;  // slot -> index in `dirty`
+  int64_t full_rebuilds = 0, delta_updates = 0;
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
   int last_total_blocks = 0;
   bool last_host_partials = false;
@@ -443,8 +450,62 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   prepare_paired_tables_host(c, s, p);  // pass 2 (pass 1 ran in eval_begin)
   const double t_after_host = now_us();
   c->prof[1] = t_after_host - tp0;  // thresholds + occurrence tables
-  if (s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation ||
-      s.dev[0].pow_n == 0) {
+  bool need_full = s.dev[0].pow_n == 0;
+  if (!need_full && (s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation)) {
+    // Windows were activated since the tables were built. Few new records: keep the tables, put the
+    // affected pairs on the delta list. Many: rebuild.
+    const int64_t np = s.mate[0].n_local();
+    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / 64);
+    size_t new_records = 0;
+    for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
+    if (s.dirty.size() + new_records > limit) need_full = true;
+    else {
+      auto base_records = [&](int32_t slot, int mt, std::vector<RecQuad>& out) {
+        // the pair's records as the device tables hold them (activated before the last full build)
+        const int64_t n0s = s.pt.class_count[0];
+        if (slot < n0s) {
+          const uint64_t r = s.pt.rec8[mt][slot];
+          if (r != kNoRec8) out.push_back(RecQuad{(int32_t)(r & 0xffffff), (int32_t)((r >> 24) & 0xfffffff), (int32_t)((r >> 52) & 63) | ((int32_t)((r >> 58) & 1) << 8), 0});
+        } else {
+          const RecQuad& f = s.pt.rm[mt].first[slot - n0s];
+          if (f.wid >= 0) {
+            const int cnt1 = 1 + (int)((uint32_t)f.flags >> 9);
+            for (int q = 0; q < cnt1; q++) { RecQuad r = q == 0 ? f : s.pt.rm[mt].extra[f.link + q - 1]; r.flags &= 0x1ff; r.link = 0; out.push_back(r); }
+          }
+        }
+      };
+      for (int mt = 0; mt < 2; mt++) {
+        const ShortMate& m = s.mate[mt];
+        for (int32_t w : m.activated_log) {
+          const Window& win = m.wins[w];
+          for (int64_t k = win.first; k < win.first + win.count; k++) {
+            const gaml_aligment& r = m.pool[k];
+            const int32_t slot = s.pt.slot_of_read[r.read_id];
+            auto it = s.dirty_index.find(slot);
+            if (it == s.dirty_index.end()) {
+              it = s.dirty_index.emplace(slot, (int32_t)s.dirty.size()).first;
+              s.dirty.emplace_back();
+              s.dirty.back().slot = slot;
+              base_records(slot, 0, s.dirty.back().recs[0]);
+              base_records(slot, 1, s.dirty.back().recs[1]);
+            }
+            auto& lst = s.dirty[it->second].recs[mt];
+            RecQuad q{w, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
+            // keep the device-table order: (window id, position)
+            auto pos = std::upper_bound(lst.begin(), lst.end(), q, [](const RecQuad& x, const RecQuad& y) { return x.wid != y.wid ? x.wid < y.wid : x.pos < y.pos; });
+            lst.insert(pos, q);
+          }
+        }
+      }
+      for (int mt = 0; mt < 2; mt++) { s.mate[mt].activated_log.clear(); s.dev[mt].uploaded_generation = s.mate[mt].active_generation; }
+      s.delta_updates++;
+    }
+  }
+  if (need_full) {
+    s.dirty.clear();
+    s.dirty_index.clear();
+    s.full_rebuilds++;
+    for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
     // cold path: the set of activated windows of either mate changed -> new device order of the
     // pairs, record tables rebuilt on the host and uploaded
     build_pair_tables(s.mate[0], s.mate[1], s.pt);
@@ -513,7 +574,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
         const Window& win = m.wins[w];
         for (int64_t k = win.first; k < win.first + win.count; k++) {
           const int32_t slot_i = s.pt.slot_of_read[m.pool[k].read_id];
-          if (slot_i < n_main_slots && s.ovf_stamp[slot_i] != s.ovf_serial) { s.ovf_stamp[slot_i] = s.ovf_serial; s.ovf_items.push_back(slot_i); }
+          if (slot_i < n_main_slots && s.ovf_stamp[slot_i] != s.ovf_serial && !s.dirty_index.count(slot_i)) { s.ovf_stamp[slot_i] = s.ovf_serial; s.ovf_items.push_back(slot_i); }
         }
       }
     }
@@ -526,6 +587,20 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     o8_off[mt] = total;
     total = align16(total + std::max<size_t>(1, s.image[mt].occ8.size()) * sizeof(uint64_t));
   }
+  // delta pairs: slots, per-mate offsets, records
+  const size_t nd = s.dirty.size();
+  size_t ds_off = total, dofs_off[2] = {0, 0}, drec_off[2] = {0, 0};
+  size_t drec_n[2] = {0, 0};
+  if (nd) {
+    total = align16(ds_off + nd * sizeof(int32_t));
+    for (int mt = 0; mt < 2; mt++) {
+      for (const auto& d : s.dirty) drec_n[mt] += d.recs[mt].size();
+      dofs_off[mt] = total;
+      total = align16(total + (nd + 1) * sizeof(int32_t));
+      drec_off[mt] = total;
+      total = align16(total + std::max<size_t>(1, drec_n[mt]) * sizeof(RecQuad));
+    }
+  }
   const double tp1 = now_us();
   c->prof[2] = tp1 - t_after_host;  // overflow list + occ8
   void* host = nullptr;
@@ -536,6 +611,22 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   if (!s.ovf_items.empty()) memcpy((char*)host + ov_off, s.ovf_items.data(), s.ovf_items.size() * sizeof(int32_t));
   for (int mt = 0; mt < 2; mt++)
     if (!s.image[mt].occ8.empty()) memcpy((char*)host + o8_off[mt], s.image[mt].occ8.data(), s.image[mt].occ8.size() * sizeof(uint64_t));
+  if (nd) {
+    int32_t* ds = (int32_t*)((char*)host + ds_off);
+    for (size_t k = 0; k < nd; k++) ds[k] = s.dirty[k].slot;
+    for (int mt = 0; mt < 2; mt++) {
+      int32_t* of = (int32_t*)((char*)host + dofs_off[mt]);
+      RecQuad* rc = (RecQuad*)((char*)host + drec_off[mt]);
+      int32_t at = 0;
+      for (size_t k = 0; k < nd; k++) {
+        of[k] = at;
+        const auto& l = s.dirty[k].recs[mt];
+        if (!l.empty()) memcpy(rc + at, l.data(), l.size() * sizeof(RecQuad));
+        at += (int32_t)l.size();
+      }
+      of[nd] = at;
+    }
+  }
   if (cov) {
     memcpy((char*)host + pb_off, p.path_base.data(), p.path_base.size() * sizeof(int32_t));
     memcpy((char*)host + so_off, p.start_off.data(), p.start_off.size() * sizeof(int32_t));
@@ -629,7 +720,10 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   }
   a.ovf_items = (const int*)(arena + ov_off);
   a.n_ovf_items = (int)s.ovf_items.size();
-  const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size();
+  a.n_dirty = (int)nd;
+  a.dirty_slots = (const int*)(arena + ds_off);
+  for (int mt = 0; mt < 2; mt++) { a.dirty_off[mt] = (const int*)(arena + dofs_off[mt]); a.dirty_recs[mt] = (const int4*)(arena + drec_off[mt]); }
+  const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size() + (int64_t)nd;
   const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : kMaxBlocks;
   // the compact path handles 2 pairs per lane and iteration
   const int blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
@@ -649,6 +743,12 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     const int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
     s.last_total_blocks = a.total_blocks;
     const int dyn_lds = c->knobs[1];  // experiment: occupancy limiter
+    if (nd) {
+      hipLaunchKernelGGL(mark_dirty_kernel, dim3((unsigned)std::min<size_t>((nd + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
+                         a.dirty_slots, (int)nd, s.rec8[0].as<unsigned long long>(), a.n0, s.inl[0].as<int4>(), a.n01, a.n_main,
+                         s.dev[0].first.as<int4>());
+      HIP_TRY(c, hipGetLastError());
+    }
     const dim3 grid(a.total_blocks), block(kBlock);
     if (c->knobs[3] == 1) hipLaunchKernelGGL((paired_score_kernel<false, 1>), grid, block, dyn_lds, st, a);
     else if (c->knobs[3] == 2) hipLaunchKernelGGL((paired_score_kernel<false, 2>), grid, block, dyn_lds, st, a);
@@ -1593,6 +1693,13 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wi
   const Walk& w = *m->win_walk[wid];
   for (int32_t i = 0; i < (int32_t)w.size() && i < cap; i++) out[i] = w[i];
   return (int32_t)w.size();
+}
+
+int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out3) {
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out3) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  out3[0] = s.full_rebuilds; out3[1] = s.delta_updates; out3[2] = (int64_t)s.dirty.size();
+  return GAML_HIP_OK;
 }
 
 int gaml_hip_aligner_stats(gaml_hip_ctx* c, int64_t* windows, int64_t* candidates, double* microseconds) {

@@ -87,6 +87,7 @@ struct ShortMate {
   std::vector<gaml_aligment> pool;       // read_id = LOCAL id inside the shard
   std::vector<int32_t> unsynced;         // windows added since the last max-position exchange (sharded runs)
   std::vector<int32_t> added_log;        // windows added since the planner last looked (memo invalidation)
+  std::vector<int32_t> activated_log;    // windows activated since the device tables last took them in
   uint64_t generation = 0;               // bumped whenever a window is added
   uint64_t active_generation = 0;        // bumped whenever a window is activated (device table stale)
   int64_t active_records = 0;            // records of activated windows
@@ -96,7 +97,7 @@ struct ShortMate {
   // Only windows that occurred in some scored path set are kept in the device record table.
   void activate(int32_t wid) {
     Window& w = wins[wid];
-    if (!w.active) { w.active = true; active_records += w.count; if (w.count) active_generation++; }
+    if (!w.active) { w.active = true; active_records += w.count; if (w.count) { active_generation++; activated_log.push_back(wid); } }
   }
 
   int64_t n_local() const { return hi - lo; }

@@ -66,6 +66,13 @@ struct PairedArgs {
   const int* ovf_items;      // host-built list: slots < n_main that touch a window occurring several times
   int n_ovf_items;           // the overflow kernel scores slots [n_main, n) and this list
   int main_blocks, total_blocks;  // grid sizes: partial slots [0, main_blocks) main, then overflow
+  // Delta: pairs whose record lists changed since the device tables were built (newly activated
+  // windows). Their slots carry a DIRTY mark in the tables; their complete record lists travel with
+  // every evaluation and the overflow path scores them.
+  int n_dirty;
+  const int* dirty_slots;     // [n_dirty]
+  const int* dirty_off[2];    // [n_dirty + 1] per mate
+  const int4* dirty_recs[2];  // {wid, pos, edit | orient<<8, 0}
   double* part_sum;          // per-block partials: main kernel blocks, then overflow kernel blocks
   int* part_zero;
   unsigned* ticket;          // zero before first launch; the last block resets it
@@ -82,12 +89,27 @@ __device__ __forceinline__ Cand make_cand(const int4& r, const int4& o, int k) {
   return c;
 }
 
+// where a read's records come from: the record tables (first record + link to the rest) ...
+struct TableSrc {
+  const MateView* v;
+  int4 r0;
+  __device__ __forceinline__ int count() const { return r0.x < 0 ? 0 : 1 + (int)((unsigned)r0.z >> 9); }
+  __device__ __forceinline__ int4 get(int k) const { return k == 0 ? r0 : v->extra[r0.w + k - 1]; }
+};
+// ... or an explicit list (delta pairs)
+struct ListSrc {
+  const int4* recs;
+  int cnt;
+  __device__ __forceinline__ int count() const { return cnt; }
+  __device__ __forceinline__ int4 get(int k) const { return recs[k]; }
+};
+
 // visit every (record, occurrence) combination of one read of one mate, in (record, occurrence) order
-template <class F>
-__device__ __forceinline__ void for_each_cand(const MateView& v, const int4& r0, F f) {
-  const int cnt = 1 + (int)((unsigned)r0.z >> 9);
+template <class Src, class F>
+__device__ __forceinline__ void for_each_cand_src(const MateView& v, const Src& src, F f) {
+  const int cnt = src.count();
   for (int k = 0; k < cnt; k++) {
-    int4 r = k == 0 ? r0 : v.extra[r0.w + k - 1];
+    int4 r = src.get(k);
     if (r.x < 0) continue;
     int4 o = v.occ[r.x];
     if (o.z < 0) continue;  // window not part of the scored paths
@@ -99,18 +121,26 @@ __device__ __forceinline__ void for_each_cand(const MateView& v, const int4& r0,
     }
   }
 }
+template <class F>
+__device__ __forceinline__ void for_each_cand(const MateView& v, const int4& r0, F f) {
+  for_each_cand_src(v, TableSrc{&v, r0}, f);
+}
 
 // The reference keeps, per path and read, one alignment per path position: a later record at the
 // same position overwrites the earlier one (graph.cc:583-592). "Later" = visited later = larger
 // (occurrence rank, record index). A candidate is live iff it is valid and no later valid
 // candidate of the same read/mate shares its (path, position).
-__device__ __forceinline__ bool is_live(const MateView& v, const int4& r0, const Cand& c) {
+template <class Src>
+__device__ __forceinline__ bool is_live_src(const MateView& v, const Src& src, const Cand& c) {
   if (!c.valid) return false;
   bool live = true;
-  for_each_cand(v, r0, [&](const Cand& d) {
+  for_each_cand_src(v, src, [&](const Cand& d) {
     if (d.valid && d.path == c.path && d.pos == c.pos && (d.rank > c.rank || (d.rank == c.rank && d.k > c.k))) live = false;
   });
   return live;
+}
+__device__ __forceinline__ bool is_live(const MateView& v, const int4& r0, const Cand& c) {
+  return is_live_src(v, TableSrc{&v, r0}, c);
 }
 
 __device__ __forceinline__ void mark_bit(uint32_t* bits, int bit) {
@@ -142,17 +172,21 @@ __device__ __forceinline__ double pair_term(const PairedArgs& a, const Cand& x, 
 
 // reads with several records and/or windows that occur several times: fully general, one
 // thread, quadratic; only the last resort of the overflow kernel (more than kOvfCap candidates)
-__device__ __forceinline__ double paired_general(const PairedArgs& a, const int4& r1, const int4& r2, int L1, int L2) {
+template <class Src>
+__device__ __forceinline__ double paired_general_src(const PairedArgs& a, const Src& s1, const Src& s2, int L1, int L2) {
   double acc = 0.0;
-  for_each_cand(a.m[0], r1, [&](const Cand& x) {
-    if (!is_live(a.m[0], r1, x)) return;
-    for_each_cand(a.m[1], r2, [&](const Cand& y) {
+  for_each_cand_src(a.m[0], s1, [&](const Cand& x) {
+    if (!is_live_src(a.m[0], s1, x)) return;
+    for_each_cand_src(a.m[1], s2, [&](const Cand& y) {
       if (y.path != x.path) return;
-      if (!is_live(a.m[1], r2, y)) return;
+      if (!is_live_src(a.m[1], s2, y)) return;
       acc += pair_term(a, x, y, L1, L2);
     });
   });
   return acc;
+}
+__device__ __forceinline__ double paired_general(const PairedArgs& a, const int4& r1, const int4& r2, int L1, int L2) {
+  return paired_general_src(a, TableSrc{&a.m[0], r1}, TableSrc{&a.m[1], r2}, L1, L2);
 }
 
 // wave (64 lanes) + block reduction of (double, int); result valid in thread 0
@@ -314,9 +348,11 @@ __device__ __forceinline__ double score_regs(const PairedArgs& a, const RegCands
 // the overflow list (same rule on both sides: any record, either mate, whose window entry has
 // path >= 0 and rank < 0).
 constexpr unsigned long long kNone8 = ~0ull;
+constexpr unsigned long long kDirty8 = ~0ull - 1;  // class-0 slot whose records moved to the delta lists
+constexpr int kDirtyWid = -2;                      // same mark in the 16-byte tables
 
 __device__ __forceinline__ int4 rec8_to_quad(unsigned long long r) {  // 8-byte record -> the 16-byte form
-  if (r == kNone8) return make_int4(-1, 0, 0, 0);
+  if (r == kNone8 || r == kDirty8) return make_int4(r == kDirty8 ? kDirtyWid : -1, 0, 0, 0);
   return make_int4((int)(r & 0xffffff), (int)((r >> 24) & 0xfffffff), (int)((r >> 52) & 63) | ((int)((r >> 58) & 1) << 8), 0);
 }
 
@@ -419,6 +455,9 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
       if (two) { a.probs[i1] = (double)(int)(c1.r1 + c1.r2 + c1.L1); lsum += (double)(int)c1.r1; }
       continue;
     }
+    const bool d0 = c0.r1 == kDirty8, d1 = c1.r1 == kDirty8;  // scored by the overflow path from the delta lists
+    if (d0) { c0.r1 = kNone8; c0.r2 = kNone8; }
+    if (d1) { c1.r1 = kNone8; c1.r2 = kNone8; }
     c0.o1 = c0.r1 != kNone8 ? a.occ8[0][c0.r1 & 0xffffff] : kNone8;
     c0.o2 = c0.r2 != kNone8 ? a.occ8[1][c0.r2 & 0xffffff] : kNone8;
     c1.o1 = c1.r1 != kNone8 ? a.occ8[0][c1.r1 & 0xffffff] : kNone8;
@@ -433,8 +472,8 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
     const double acc0 = compact_score(a, c0, s0, k0);
     const double acc1 = compact_score(a, c1, s1, k1);
     if (ABL == 3) { a.probs[i0] = acc0; lsum += acc0; if (two) { a.probs[i1] = acc1; lsum += acc1; } continue; }
-    if (!s0) finish_read_compact(a, i0, acc0, c0.lc, k0, lsum, zeros);
-    if (two && !s1) finish_read_compact(a, i1, acc1, c1.lc, k1, lsum, zeros);
+    if (!s0 && !d0) finish_read_compact(a, i0, acc0, c0.lc, k0, lsum, zeros);
+    if (two && !s1 && !d1) finish_read_compact(a, i1, acc1, c1.lc, k1, lsum, zeros);
   }
 }
 
@@ -449,6 +488,7 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
     const uint32_t l12 = a.len12[t];
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     const size_t at = K == 2 ? (size_t)2 * (i - a.n0) : (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01);
+    if (a.inl[0][at].x == kDirtyWid) continue;  // scored by the overflow path from the delta lists
     RegCands<K> x, y;
     const bool m1 = load_cands_inline<K>(a.m[0], a.inl[0] + at, x), m2 = load_cands_inline<K>(a.m[1], a.inl[1] + at, y);
     if (m1 || m2) continue;  // on the host's overflow list
@@ -528,6 +568,37 @@ __device__ __forceinline__ int wave_gather(const MateView& v, const int4& r0, in
   return total;
 }
 
+// same as wave_gather, the records given as an explicit list (delta pairs)
+__device__ __forceinline__ int wave_gather_list(const MateView& v, const int4* recs, int cnt, int4* lds, int lane) {
+  int total = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int k = base + lane;
+    int mine = 0;
+    int4 r = make_int4(-1, 0, 0, 0), o = make_int4(0, 0, -1, 0);
+    if (k < cnt) {
+      r = recs[k];
+      if (r.x >= 0) o = v.occ[r.x];
+      if (o.z >= 0) mine = o.w >= 0 ? 1 : v.multi_off[-o.w] - v.multi_off[-o.w - 1];
+    }
+    int incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const int wave_total = __shfl(incl, 63, 64);
+    const int at = total + incl - mine;
+    if (total + wave_total > kOvfCap) return -1;
+    if (mine == 1 && o.w >= 0) {
+      lds[at] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | ((r.y >= o.y) ? 0x200 : 0), o.w);
+    } else if (mine > 0) {
+      const int s = -o.w - 1;
+      for (int q = 0; q < mine; q++) {
+        const int4 oo = v.multi[v.multi_off[s] + q];
+        lds[at + q] = make_int4(oo.z, r.y + oo.x, (r.z & 0x1ff) | ((r.y >= oo.y) ? 0x200 : 0), oo.w);
+      }
+    }
+    total += wave_total;
+  }
+  return total;
+}
+
 template <bool TICKET>
 __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ovf_block, int ovf_blocks, double* sh_s, int* sh_z,
                                                      int4 (*cand)[2][kOvfCap]) {
@@ -535,23 +606,39 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
   const int wave_global = ovf_block * (kBlock / 64) + wave;
   const int n_waves = ovf_blocks * (kBlock / 64);
   const int n_static = a.n - a.n_main;
-  const int n_items = n_static + a.n_ovf_items;
+  const int n_listed = n_static + a.n_ovf_items;
+  const int n_items = n_listed + a.n_dirty;
   double lsum = 0.0;
   int zeros = 0;
   for (int item = wave_global; item < n_items; item += n_waves) {  // fixed item -> wave assignment
-    const int i = item < n_static ? a.n_main + item : a.ovf_items[item - n_static];
+    const bool is_dirty = item >= n_listed;
+    const int dj = item - n_listed;
+    const int i = is_dirty ? a.dirty_slots[dj] : item < n_static ? a.n_main + item : a.ovf_items[item - n_static];
     int4 r1, r2;
     uint32_t l12;
     if (i < a.n0) { r1 = rec8_to_quad(a.rec8[0][i]); r2 = rec8_to_quad(a.rec8[1][i]); l12 = a.len_combo[a.len_code[i]]; }
     else { r1 = a.m[0].first[i - a.n0]; r2 = a.m[1].first[i - a.n0]; l12 = a.len12[i - a.n0]; }
+    if (!is_dirty && r1.x == kDirtyWid) continue;  // a class-3 pair that is on the delta list: scored there
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     int4* c1 = cand[wave][0];
     int4* c2 = cand[wave][1];
-    const int n1 = wave_gather(a.m[0], r1, c1, lane);
-    const int n2 = wave_gather(a.m[1], r2, c2, lane);
+    int n1, n2;
+    if (is_dirty) {
+      n1 = wave_gather_list(a.m[0], a.dirty_recs[0] + a.dirty_off[0][dj], a.dirty_off[0][dj + 1] - a.dirty_off[0][dj], c1, lane);
+      n2 = wave_gather_list(a.m[1], a.dirty_recs[1] + a.dirty_off[1][dj], a.dirty_off[1][dj + 1] - a.dirty_off[1][dj], c2, lane);
+    } else {
+      n1 = wave_gather(a.m[0], r1, c1, lane);
+      n2 = wave_gather(a.m[1], r2, c2, lane);
+    }
     double acc = 0.0;
     if (n1 < 0 || n2 < 0) {
-      if (lane == 0) acc = paired_general(a, r1, r2, L1, L2);
+      // more candidates than the LDS staging holds: fully general per-lane loop
+      if (lane == 0) {
+        if (is_dirty)
+          acc = paired_general_src(a, ListSrc{a.dirty_recs[0] + a.dirty_off[0][dj], a.dirty_off[0][dj + 1] - a.dirty_off[0][dj]},
+                                   ListSrc{a.dirty_recs[1] + a.dirty_off[1][dj], a.dirty_off[1][dj + 1] - a.dirty_off[1][dj]}, L1, L2);
+        else acc = paired_general(a, r1, r2, L1, L2);
+      }
     } else {
       __builtin_amdgcn_wave_barrier();
       // overwrite rule: candidate is live iff valid and no later-ranked valid twin (same path, pos)
@@ -767,6 +854,20 @@ __global__ __launch_bounds__(kBlock) void pacbio_score_kernel(PacbioArgs a) {
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
   grid_finish(lsum, zeros, blockIdx.x, gridDim.x, a.part_sum, a.part_zero, a.ticket, a.out, a.bad_bases, a.n_reads, sh_s, sh_z);
+}
+
+// mark the slots of delta pairs in the record tables (idempotent; runs before the scoring kernel)
+__global__ __launch_bounds__(kBlock) void mark_dirty_kernel(const int* slots, int n, unsigned long long* rec8_0, int n0, int4* inl_0,
+                                                            int n01, int n_main, int4* first_0) {
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) {
+    const int s = slots[t];
+    if (s < n0) rec8_0[s] = kDirty8;
+    else {
+      if (s < n01) inl_0[(size_t)2 * (s - n0)].x = kDirtyWid;
+      else if (s < n_main) inl_0[(size_t)2 * (n01 - n0) + (size_t)4 * (s - n01)].x = kDirtyWid;
+      first_0[s - n0].x = kDirtyWid;
+    }
+  }
 }
 
 // bad_bases of a paired set with coverage penalty: u64 counter of the sweep -> its partial slot

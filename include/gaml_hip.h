@@ -189,6 +189,9 @@ int gaml_hip_debug_prepare(gaml_hip_ctx* ctx, const int32_t* paths, const int64_
 int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int32_t* out5, int64_t cap);
 /* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
+/* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list}.
+ * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables). */
+int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out3);
 /* GPU window aligner (cold path): windows aligned on the device so far, seed candidates extended, wall time.
  * Knob 5 = 1 (gaml_hip_debug_set_knob) forces the host aligner. */
 int gaml_hip_aligner_stats(gaml_hip_ctx* ctx, int64_t* windows, int64_t* candidates, double* microseconds);
@@ -197,7 +200,7 @@ int gaml_hip_aligner_stats(gaml_hip_ctx* ctx, int64_t* windows, int64_t* candida
  * [6] bytes uploaded, [7] wait for the device */
 int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
 /* tuning experiments (tools/kbench.py): 0 = compact-path grid cap, 1 = dynamic LDS bytes, 2 = finish mode (1 ticket,
- * 2 finisher kernel), 3 = timing-only ablation, 4 = 1: no floor/log memo, 5 = 1: host window aligner */
+ * 2 finisher kernel), 3 = timing-only ablation, 4 = 1: no floor/log memo, 5 = 1: host window aligner, 6 = 1: no delta list */
 int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
 /* pairs per record-count class of the device table {<=1, <=2, <=4, more} (paired sets) */
 int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);

@@ -1,0 +1,113 @@
+"""The call pattern of the simulated-annealing loop (reference gaml.cc:148-339 and the CalcProb calls
+inside moves.cc): a long sequence of slightly different path sets, new junction windows appearing
+all the time, speculative evaluations interleaved with re-evaluations of earlier sets. Every value
+is checked against the oracle evaluated with a fresh ScoringState on the same cache history."""
+import numpy as np
+import pytest
+
+from gaml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _moves(rng, paths, g):
+    """One random edit of the kind GAML's move generators make."""
+    paths = [list(p) for p in paths]
+    kind = rng.integers(0, 6)
+    i = int(rng.integers(0, len(paths)))
+    p = paths[i]
+    if kind == 0 and len(p) > 3:  # BreakPath
+        c = int(rng.integers(1, len(p) - 1))
+        paths[i:i + 1] = [p[:c], p[c:]]
+    elif kind == 1 and len(paths) > 1:  # join two paths, sometimes over a gap (ExtendPaths / FixGapLength)
+        j = int(rng.integers(0, len(paths)))
+        if j != i:
+            gap = [-int(rng.integers(20, 400))] if rng.random() < 0.5 else []
+            q = paths[j]
+            paths[i] = p + gap + q
+            del paths[j]
+    elif kind == 2:  # reverse a path (the same sequence on the other strand)
+        paths[i] = [x ^ 1 if x >= 0 else x for x in reversed(p)]
+    elif kind == 3 and len(p) > 6:  # LocalChange: drop a short stretch, bridge it by a gap
+        a = int(rng.integers(1, len(p) - 4))
+        b = a + int(rng.integers(1, 3))
+        removed = sum(g.node_len(x) if x >= 0 else -x for x in p[a:b])
+        paths[i] = p[:a] + [-max(1, removed)] + p[b:]
+    elif kind == 4 and len(p) > 4:  # duplicate a node (repeat resolution attempts)
+        a = int(rng.integers(1, len(p) - 1))
+        if p[a] >= 0:
+            paths[i] = p[:a] + [p[a]] + p[a:]
+    elif kind == 5 and len(p) > 2:  # trim an end
+        paths[i] = p[1:] if rng.random() < 0.5 else p[:-1]
+    return [q for q in paths if q]
+
+
+@pytest.mark.parametrize("penalty", [0.0, 0.0002])
+def test_long_random_walk_of_path_sets_matches_oracle(penalty):
+    from gaml_amd import api
+    import oracle_py as op
+    G, n, seed = 120_000, 6000, 91
+    genome = synth.plant_repeats(synth.make_genome(G, seed), 3, 800, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(600, 4000), short_rng=(25, 330)))
+    pr = synth.make_paired_reads(genome, n, 100, 240.0, 24.0, 0.01, seed)
+    gb, go = g.packed()
+    ctx = api.Context(device=0)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_paired(api.paired_cfg(240.0, 24.0, penalty_constant=penalty), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    ors = orc.add_paired(*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2), 0.01, op.paired_cfg(240.0, 24.0, penalty_constant=penalty))
+    rng = np.random.default_rng(5)
+    walk = synth.genome_walk(g)
+    cur = [[x] for x in walk if g.node_len(x) > 500]  # the reference's start state (gaml.cc:1002-1005)
+    history = []
+    worst = 0.0
+    for it in range(120):
+        new = _moves(rng, cur, g)
+        got, zeros, tl = ctx.calc_prob(new)
+        want, wz, wtl = orc.calc_prob(new, fresh=True)
+        assert tl == wtl and zeros.tolist() == wz.tolist(), it
+        _, wbad = orc.paired_probs(ors)
+        assert ctx.bad_bases(rs) == (wbad if penalty > 0 else 0), it
+        worst = max(worst, abs(got - want) / abs(want))
+        history.append((new, got))
+        if rng.random() < 0.6:  # accept
+            cur = new
+        if it % 10 == 9:  # a move generator re-evaluating an earlier candidate (moves.cc:705-793)
+            old_paths, old_val = history[int(rng.integers(0, len(history)))]
+            again, _, _ = ctx.calc_prob(old_paths)
+            want_again, _, _ = orc.calc_prob(old_paths, fresh=True)
+            assert abs(again - want_again) <= 1e-9 * abs(want_again)
+    assert worst <= 1e-9
+    # per-read state of the last evaluation too
+    np.testing.assert_allclose(ctx.read_probs(rs), orc.paired_probs(ors)[0], rtol=4e-16, atol=0)
+    assert ctx.window_count(rs, 0) == orc.L.orc_window_count(orc.h, ors, 0)
+
+
+def test_delta_list_equals_full_rebuild():
+    """Newly activated windows go to a delta list instead of rebuilding the device tables; both
+    routes must give the same per-read probabilities and likelihoods."""
+    from gaml_amd import api
+    G, n, seed = 150_000, 40_000, 93
+    genome = synth.plant_repeats(synth.make_genome(G, seed), 2, 700, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(600, 4000), short_rng=(25, 330)))
+    pr = synth.make_paired_reads(genome, n, 100, 240.0, 24.0, 0.01, seed)
+    ctxs = []
+    for no_delta in (0, 1):
+        c = api.Context(device=0)
+        c.debug_set_knob(6, no_delta)
+        c.set_graph(*g.packed())
+        c.add_paired(api.paired_cfg(240.0, 24.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+        ctxs.append(c)
+    rng = np.random.default_rng(11)
+    cur = [synth.genome_walk(g)]
+    for it in range(60):
+        cur = _moves(rng, cur, g)
+        a = ctxs[0].calc_prob(cur)
+        b = ctxs[1].calc_prob(cur)
+        assert a[1].tolist() == b[1].tolist() and a[2] == b[2]
+        assert abs(a[0] - b[0]) <= 1e-13 * abs(b[0]), it
+        np.testing.assert_allclose(ctxs[0].read_probs(0), ctxs[1].read_probs(0), rtol=4e-16, atol=0)
+    st0, st1 = ctxs[0].debug_table_stats(0), ctxs[1].debug_table_stats(0)
+    assert st0["delta_updates"] > 5 and st0["full_rebuilds"] < st1["full_rebuilds"]
+    assert st1["delta_updates"] == 0 and st1["dirty_pairs"] == 0
