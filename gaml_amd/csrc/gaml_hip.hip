@@ -110,6 +110,8 @@ struct PairedSet {
   std::vector<DirtyPair> dirty;
   std::unordered_map<int32_t, int32_t> dirty_index;  // slot -> index in `dirty`
   int64_t full_rebuilds = 0, delta_updates = 0;
+  size_t dirty_marked = 0;   // delta pairs whose slots already carry the mark on the device
+  int quiet_calls = 0;       // evaluations since the last window activation
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
   int last_total_blocks = 0;
   bool last_host_partials = false;
@@ -451,6 +453,10 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   const double t_after_host = now_us();
   c->prof[1] = t_after_host - tp0;  // thresholds + occurrence tables
   bool need_full = s.dev[0].pow_n == 0;
+  const bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
+  s.quiet_calls = activated_now ? 0 : s.quiet_calls + 1;
+  // the cache has settled (no activation for a while) but pairs still sit on the slower delta path: fold them in
+  if (!need_full && !activated_now && !s.dirty.empty() && s.quiet_calls >= 16 && c->knobs[6] != 2) need_full = true;
   if (!need_full && (s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation)) {
     // Windows were activated since the tables were built. Few new records: keep the tables, put the
     // affected pairs on the delta list. Many: rebuild.
@@ -504,6 +510,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   if (need_full) {
     s.dirty.clear();
     s.dirty_index.clear();
+    s.dirty_marked = 0;
     s.full_rebuilds++;
     for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
     // cold path: the set of activated windows of either mate changed -> new device order of the
@@ -743,11 +750,13 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     const int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
     s.last_total_blocks = a.total_blocks;
     const int dyn_lds = c->knobs[1];  // experiment: occupancy limiter
-    if (nd) {
-      hipLaunchKernelGGL(mark_dirty_kernel, dim3((unsigned)std::min<size_t>((nd + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
-                         a.dirty_slots, (int)nd, s.rec8[0].as<unsigned long long>(), a.n0, s.inl[0].as<int4>(), a.n01, a.n_main,
-                         s.dev[0].first.as<int4>());
+    if (nd > s.dirty_marked) {  // marks stay on the device until the next full build: only new delta pairs need one
+      const size_t fresh = nd - s.dirty_marked;
+      hipLaunchKernelGGL(mark_dirty_kernel, dim3((unsigned)std::min<size_t>((fresh + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
+                         a.dirty_slots + s.dirty_marked, (int)fresh, s.rec8[0].as<unsigned long long>(), a.n0, s.inl[0].as<int4>(), a.n01,
+                         a.n_main, s.dev[0].first.as<int4>());
       HIP_TRY(c, hipGetLastError());
+      s.dirty_marked = nd;
     }
     const dim3 grid(a.total_blocks), block(kBlock);
     if (c->knobs[3] == 1) hipLaunchKernelGGL((paired_score_kernel<false, 1>), grid, block, dyn_lds, st, a);
