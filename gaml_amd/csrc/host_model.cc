@@ -798,19 +798,32 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
     if (m <= 1 && lc[i] >= 0 && one[0][i] != kNoRec8 - 1 && one[1][i] != kNoRec8 - 1) return 0;
     return m <= 2 ? 1 : m <= 4 ? 2 : 3;
   };
-  std::vector<int32_t> order(n);
-  for (int64_t i = 0; i < n; i++) order[i] = (int32_t)i;
+  // device order: class 0 by (window of mate 1, window of mate 2, read id), other classes by
+  // (class, read id). Two stable counting passes (least significant key first), O(pairs + windows).
   std::vector<uint8_t> cl(n);
   for (int64_t i = 0; i < n; i++) cl[i] = (uint8_t)cls(i);
-  // class 0 by (window of mate 1, window of mate 2, read id); other classes by (class, read id)
-  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-    if (cl[x] != cl[y]) return cl[x] < cl[y];
-    if (cl[x] != 0) return false;
-    uint32_t wx1 = (uint32_t)(one[0][x] & 0xffffff), wy1 = (uint32_t)(one[0][y] & 0xffffff);
-    if (wx1 != wy1) return wx1 < wy1;
-    uint32_t wx2 = (uint32_t)(one[1][x] & 0xffffff), wy2 = (uint32_t)(one[1][y] & 0xffffff);
-    return wx2 < wy2;
-  });
+  const uint32_t nw1 = (uint32_t)a.wins.size() + 2, nw2 = (uint32_t)b.wins.size() + 2;
+  auto key2 = [&](int32_t i) -> uint32_t {  // window of mate 2 (class 0 only); "no record" sorts last
+    if (cl[i] != 0) return 0;
+    return one[1][i] == kNoRec8 ? nw2 - 1 : (uint32_t)(one[1][i] & 0xffffff);
+  };
+  auto key1 = [&](int32_t i) -> uint32_t {  // (class, window of mate 1)
+    if (cl[i] != 0) return nw1 + cl[i];
+    return one[0][i] == kNoRec8 ? nw1 - 1 : (uint32_t)(one[0][i] & 0xffffff);
+  };
+  std::vector<int32_t> order(n), tmp(n);
+  {
+    std::vector<int32_t> cnt(nw2 + 1, 0);
+    for (int64_t i = 0; i < n; i++) cnt[key2((int32_t)i) + 1]++;
+    for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+    for (int64_t i = 0; i < n; i++) tmp[cnt[key2((int32_t)i)]++] = (int32_t)i;
+  }
+  {
+    std::vector<int32_t> cnt(nw1 + 6, 0);
+    for (int64_t i = 0; i < n; i++) cnt[key1(tmp[i]) + 1]++;
+    for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+    for (int64_t i = 0; i < n; i++) order[cnt[key1(tmp[i])]++] = tmp[i];
+  }
   for (int c = 0; c < 4; c++) out.class_count[c] = 0;
   out.slot_of_read.assign(n, 0);
   out.read_of_slot.assign(n, 0);
