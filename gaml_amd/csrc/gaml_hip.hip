@@ -1175,6 +1175,16 @@ int eval_finish(gaml_hip_ctx* c, void* d_partials, hipStream_t st) {
     if (!m->unsynced.empty())
       return fail(c, GAML_HIP_ESTATE, "sharded context: new windows were aligned; exchange their largest positions "
                                       "(gaml_hip_eval_pending_maxpos -> all-reduce(max) -> gaml_hip_eval_apply_maxpos) before finishing");
+  if (c->peers > 1) {
+    // the coverage penalty depends on the union of all ranks' well-aligned pairs per path position
+    // (graph.cc:1893-1919) / of all reads' intervals (graph.cc:3226-3250): a per-rank value would be wrong
+    for (auto& ps : c->paireds)
+      if (ps->cfg.penalty_constant > 0)
+        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded context: the cross-rank coverage bitmap exchange is not implemented");
+    for (auto& ps : c->pacbios)
+      if (ps->cfg.penalty_constant > 0)
+        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded PacBio set is not implemented");
+  }
   const std::vector<Walk>& paths = c->pending_paths;
   const int32_t total_len = c->pending_total_len;
   auto order = scoring_order(c);

@@ -1,0 +1,146 @@
+"""Edge cases of the paired path against the oracle: ragged read lengths, non-ACGT bases, empty
+inputs, very many paths (path ids beyond the compact 15-bit field), long single-node windows,
+unusual scoring parameters."""
+import numpy as np
+import pytest
+
+from gaml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack_ragged(reads):
+    offs = np.zeros(len(reads) + 1, np.int64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    return np.ascontiguousarray(np.concatenate(reads) if reads else np.zeros(0, np.uint8)), offs
+
+
+def _both(gb, go, r1, r2, cfg_kw, mean, sd):
+    from gaml_amd import api
+    import oracle_py as op
+    ctx = api.Context(device=0)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_paired(api.paired_cfg(mean, sd, **cfg_kw), *r1, *r2)
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    ors = orc.add_paired(*r1, *r2, cfg_kw.get("mismatch_prob", 0.01), op.paired_cfg(mean, sd, **{k: v for k, v in cfg_kw.items() if k != "mismatch_prob"}))
+    return ctx, rs, orc, ors
+
+
+def _agree(ctx, rs, orc, ors, paths, tol=1e-9):
+    got, zeros, tl = ctx.calc_prob(paths)
+    want, wz, wtl = orc.calc_prob(paths, fresh=True)
+    assert tl == wtl and zeros.tolist() == wz.tolist()
+    wprobs, wbad = orc.paired_probs(ors)
+    np.testing.assert_allclose(ctx.read_probs(rs), wprobs, rtol=4e-16, atol=0)
+    assert abs(got - want) <= tol * abs(want)
+
+
+def test_ragged_read_lengths_and_non_acgt_bases():
+    G, n, seed = 70_000, 3000, 101
+    rng = np.random.default_rng(seed)
+    genome = synth.make_genome(G, seed)
+    genome[30_000:30_040] = ord("N")  # a run of N inside a node
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(700, 4000)))
+    pr = synth.make_paired_reads(genome, n, 120, 300.0, 30.0, 0.01, seed)
+    # trim reads to ragged lengths (the index assumes the LAST read's length, graph.cc:1286), sprinkle N
+    m1 = [pr.mate1[i, : int(rng.integers(90, 121))].copy() for i in range(n)]
+    m2 = [pr.mate2[i, : int(rng.integers(90, 121))].copy() for i in range(n)]
+    for lst in (m1, m2):
+        for i in rng.integers(0, n, 60):
+            lst[i][int(rng.integers(0, len(lst[i])))] = ord("N")
+    ctx, rs, orc, ors = _both(*g.packed(), _pack_ragged(m1), _pack_ragged(m2), {}, 300.0, 30.0)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 2
+    for paths in ([walk], [walk[:k], walk[k:]], [[x] for x in walk]):
+        _agree(ctx, rs, orc, ors, paths)
+    assert ctx.aligner_stats()["windows"] > 0  # the GPU aligner handled the ragged set
+
+
+def test_more_than_300_distinct_length_combinations():
+    """Beyond 256 (L1, L2) combinations pairs leave the compact class; results must not change."""
+    G, n, seed = 40_000, 2500, 103
+    rng = np.random.default_rng(seed)
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(700, 3000)))
+    pr = synth.make_paired_reads(genome, n, 150, 320.0, 30.0, 0.01, seed)
+    m1 = [pr.mate1[i, : 100 + (i % 37)].copy() for i in range(n)]
+    m2 = [pr.mate2[i, : 100 + (i % 41)].copy() for i in range(n)]
+    m1[-1] = pr.mate1[-1, :136].copy(); m2[-1] = pr.mate2[-1, :140].copy()
+    ctx, rs, orc, ors = _both(*g.packed(), _pack_ragged(m1), _pack_ragged(m2), {}, 320.0, 30.0)
+    _agree(ctx, rs, orc, ors, [synth.genome_walk(g)])
+    cls = ctx.debug_class_counts(rs)
+    assert cls[0] > 0 and cls[1] > 0
+
+
+def test_many_paths_beyond_compact_path_id():
+    """> 32767 paths: occurrence entries whose path id does not fit 15 bits take the general route."""
+    G, n, seed = 60_000, 1500, 105
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(700, 3000)))
+    pr = synth.make_paired_reads(genome, n, 100, 250.0, 25.0, 0.01, seed)
+    ctx, rs, orc, ors = _both(*g.packed(), synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2), {}, 250.0, 25.0)
+    walk = synth.genome_walk(g)
+    paths = [[]] * 33_000 + [walk]  # the interesting path has index 33000
+    _agree(ctx, rs, orc, ors, paths)
+    # and a window that occurs in 300 paths at once (lists longer than the 128-candidate LDS staging)
+    short = [x for x in walk if g.node_len(x) < 200][0]
+    _agree(ctx, rs, orc, ors, [[short]] * 300 + [walk])
+
+
+def test_long_single_node_windows_and_one_node_graph():
+    G, n, seed = 150_000, 4000, 107
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, [100_000, 50_000])  # two very long nodes, no short ones
+    pr = synth.make_paired_reads(genome, n, 150, 300.0, 30.0, 0.01, seed)
+    ctx, rs, orc, ors = _both(*g.packed(), synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2), {}, 300.0, 30.0)
+    for paths in ([[0, 2]], [[0], [2]], [[3, 1]], [[2, 0]]):
+        _agree(ctx, rs, orc, ors, paths)
+
+
+def test_empty_inputs():
+    from gaml_amd import api
+    G, seed = 20_000, 109
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(700, 3000)))
+    pr = synth.make_paired_reads(genome, 400, 100, 250.0, 25.0, 0.01, seed)
+    ctx, rs, orc, ors = _both(*g.packed(), synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2), {}, 250.0, 25.0)
+    for paths in ([], [[]], [[], []], [[-100]], [[-5], []]):
+        _agree(ctx, rs, orc, ors, paths, tol=1e-12)
+    # a context without read sets scores 0
+    c2 = api.Context(device=0)
+    c2.set_graph(*g.packed())
+    v, z, tl = c2.calc_prob([synth.genome_walk(g)])
+    assert v == 0.0 and len(z) == 0 and tl == G
+    with pytest.raises(api.GamlHipError):
+        c2.calc_prob([[10_000_000]])  # node outside the graph
+    # a paired set with zero reads
+    c3 = api.Context(device=0)
+    c3.set_graph(*g.packed())
+    e = np.zeros(0, np.uint8), np.zeros(1, np.int64)
+    c3.add_paired(api.paired_cfg(250.0, 25.0), *e, *e)
+    part, _ = c3.calc_partials([synth.genome_walk(g)])
+    assert part[0].tolist() == [0.0, 0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("kw,mean,sd", [
+    (dict(min_prob_per_base=0.0, min_prob_start=-80.0, penalty_constant=0.00013, penalty_step=3000.0), 3700.0, 350.0),  # example.cfg rs2
+    (dict(mismatch_prob=0.05, min_prob_per_base=-1.0, weight=0.3), 220.0, 10.0),
+    (dict(min_prob_start=80.0, min_prob_per_base=0.0), 180.0, 20.0),  # example.cfg rs1: floor above every probability
+])
+def test_unusual_scoring_parameters(kw, mean, sd):
+    G, n, seed = 80_000, 3000, 111
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(700, 5000)))
+    pr = synth.make_paired_reads(genome, n, 100, mean, sd, kw.get("mismatch_prob", 0.01), seed)
+    ctx, rs, orc, ors = _both(*g.packed(), synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2), kw, mean, sd)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 2
+    for paths in ([walk], [walk[:k] + [-500] + walk[k + 3:]], [walk[:k], walk[k:]]):
+        got, zeros, tl = ctx.calc_prob(paths)
+        want, wz, wtl = orc.calc_prob(paths, fresh=True)
+        _, wbad = orc.paired_probs(ors)
+        assert zeros.tolist() == wz.tolist() and tl == wtl
+        if kw.get("penalty_constant", 0) > 0:
+            assert ctx.bad_bases(rs) == wbad
+        assert abs(got - want) <= 1e-9 * abs(want)

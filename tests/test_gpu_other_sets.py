@@ -236,3 +236,17 @@ def test_read_sharding_on_one_gpu_sums_to_the_whole():
     acc[2] = 0.0
     got, z = last.combine_partials(acc, tl)
     assert z.tolist() == wz.tolist() and abs(got - want) <= 1e-12 * abs(want)
+
+
+def test_sharded_context_refuses_coverage_penalty():
+    from gaml_amd import api
+    genome, g = _graph(30_000, 61, long_rng=(900, 3000))
+    pr = synth.make_paired_reads(genome, 600, 100, 250.0, 25.0, 0.01, 61)
+    c = api.Context(device=0, rank=0, world=2)
+    c.set_graph(*g.packed())
+    c.add_paired(api.paired_cfg(250.0, 25.0, penalty_constant=0.001), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    pending, _ = c.eval_begin([synth.genome_walk(g)])
+    c.eval_apply_maxpos(c.eval_pending_maxpos())
+    with pytest.raises(api.GamlHipError) as e:
+        c.eval_finish()
+    assert e.value.code == api.ESTATE and "coverage" in str(e.value)
