@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <climits>
+#include <limits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -115,7 +118,7 @@ struct PairedSet {
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
   int last_total_blocks = 0;
   bool last_host_partials = false;
-  DevBuf len12, probs, tabs, occ_arena, cov_bits, cov_meta, bad;
+  DevBuf len12, probs, tabs, occ_arena, cov_bits, bad;
   std::vector<uint32_t> ovf_stamp;  // per slot: evaluation serial that last put it on the overflow list
   uint32_t ovf_serial = 0;
   std::vector<int32_t> ovf_items;
@@ -128,7 +131,6 @@ struct PairedSet {
   bool tabs_uploaded = false;
   int64_t last_bad_bases = 0;
   Staging stage;
-  PinBuf bad_host;
 };
 
 struct SingleSet {
@@ -399,7 +401,6 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
   HIP_TRY(c, s.probs.reserve(std::max<size_t>(1, n) * sizeof(double)));
   HIP_TRY(c, s.red.init());
   HIP_TRY(c, s.bad.reserve(sizeof(unsigned long long)));
-  HIP_TRY(c, s.bad_host.reserve(sizeof(unsigned long long)));
   s.tabs_uploaded = true;
   return 0;
 }
@@ -749,6 +750,13 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     if (c->event_timing) { if (int e = take_events(c, &ev)) return e; HIP_TRY(c, hipEventRecord(ev->first, st)); }
     const int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
     s.last_total_blocks = a.total_blocks;
+    if (c->host_results) {
+      // sentinels: the host can tell when every block's partial has landed without waiting for the
+      // runtime's completion signal (fetch_partials)
+      double* hs = (double*)s.h_part_sum.p;
+      int* hz = (int*)s.h_part_zero.p;
+      for (int b2 = 0; b2 < a.total_blocks; b2++) { hs[b2] = std::numeric_limits<double>::quiet_NaN(); hz[b2] = INT_MIN; }
+    }
     const int dyn_lds = c->knobs[1];  // experiment: occupancy limiter
     if (nd > s.dirty_marked) {  // marks stay on the device until the next full build: only new delta pairs need one
       const size_t fresh = nd - s.dirty_marked;
@@ -1284,8 +1292,8 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
       s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->lt.release(); s->ltz.release(); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
-      s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->cov_meta.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
-      s->red.release(); s->bad_host.release(); drop_stage(s->stage);
+      s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
+      s->red.release(); drop_stage(s->stage);
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage); }
     c->packed.release(); c->packed_host.release(); c->aln_scratch.release();
@@ -1555,7 +1563,28 @@ static void finisher_order_sum(const double* ps, const int* pz, int n, double* s
 static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
   // the kernels wrote into pinned host memory: nothing to copy, only to wait for
   const double t0 = now_us();
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // When paired scorers without coverage penalty are all there is, the per-block partials ARE the
+  // result: spin on their sentinels instead of waiting for the stream's completion signal (saves the
+  // runtime's ~6 us wake-up, tools/latency_probe.hip). Bounded; any doubt -> a real stream sync.
+  bool spin = c->knobs[7] == 0 && !c->handles.empty();
+  for (auto& h : c->handles) if (h.kind != 1) spin = false;
+  for (auto& ps : c->paireds) if (ps->cfg.penalty_constant > 0 || !ps->last_host_partials || ps->last_total_blocks == 0) spin = false;
+  if (spin) {
+    const double deadline = t0 + 2e6;
+    for (auto& ps : c->paireds) {
+      const volatile double* hs = (const volatile double*)ps->h_part_sum.p;
+      const volatile int* hz = (const volatile int*)ps->h_part_zero.p;
+      int done = 0;
+      while (done < ps->last_total_blocks) {
+        if (hs[done] == hs[done] && hz[done] != INT_MIN) { done++; continue; }  // NaN != NaN
+        __builtin_ia32_pause();
+        if ((done & 63) == 0 && now_us() > deadline) { spin = false; break; }
+      }
+      if (!spin) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!spin) HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->t_dev_wall_us += now_us() - t0;
   c->prof[7] = now_us() - t0;  // wait for the device
   {
@@ -1574,7 +1603,7 @@ static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
   }
   memcpy(partials_out, c->packed_host.p, c->handles.size() * 4 * sizeof(double));
   c->t_kernel_us = 0;
-  if (int e2 = collect_events(c)) return e2;
+  if (!spin) { if (int e2 = collect_events(c)) return e2; }  // after a spin the events are collected lazily (gaml_hip_kernel_stats)
   // bookkeeping for gaml_hip_bad_bases
   auto order = scoring_order(c);
   for (size_t k = 0; k < order.size(); k++)

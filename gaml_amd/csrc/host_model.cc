@@ -705,25 +705,6 @@ void PairedPlanner::flat_occurrences(int mate, std::vector<Occ>& out) const {
 // ---------------------------------------------------------------------------------------
 // device tables
 // ---------------------------------------------------------------------------------------
-void pair_device_order(const ShortMate& a, const ShortMate& b, std::vector<int32_t>& slot_of_read,
-                       std::vector<int32_t>& read_of_slot, int64_t class_count[4]) {
-  const int64_t n = a.n_local();
-  std::vector<int32_t> k1(n, 0), k2(n, 0);
-  for (const Window& w : a.wins) if (w.active) for (int64_t k = w.first; k < w.first + w.count; k++) k1[a.pool[k].read_id]++;
-  for (const Window& w : b.wins) if (w.active) for (int64_t k = w.first; k < w.first + w.count; k++) k2[b.pool[k].read_id]++;
-  auto cls = [&](int64_t i) { int m = std::max(k1[i], k2[i]); return m <= 1 ? 0 : m <= 2 ? 1 : m <= 4 ? 2 : 3; };
-  int64_t start[5] = {0, 0, 0, 0, 0};
-  for (int64_t i = 0; i < n; i++) start[cls(i) + 1]++;
-  for (int c = 0; c < 4; c++) { class_count[c] = start[c + 1]; start[c + 1] += start[c]; }
-  slot_of_read.assign(n, 0);
-  read_of_slot.assign(n, 0);
-  for (int64_t i = 0; i < n; i++) {
-    int32_t s = (int32_t)start[cls(i)]++;
-    slot_of_read[i] = s;
-    read_of_slot[s] = (int32_t)i;
-  }
-}
-
 void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_read, ReadMajor& out) {
   const int64_t n = m.n_local();
   auto slot = [&](int32_t read) { return slot_of_read ? (*slot_of_read)[read] : read; };
@@ -939,18 +920,6 @@ void OccImage::build(size_t n_windows, const PlanView& view, int mate) {
     multi.resize(multi_off.back());
     std::vector<int32_t> fill(multi_off.size(), 0);
     for (const Pending& pe : pending_) { int32_t l = list_of_[pe.wid]; multi[multi_off[l] + fill[l]++] = pe.q; }
-  }
-}
-
-void build_occ8(const OccTable& t, std::vector<uint64_t>& out) {
-  out.resize(t.direct.size());
-  for (size_t w = 0; w < t.direct.size(); w++) {
-    const OccQuad& q = t.direct[w];
-    if (q.path < 0) { out[w] = kNoRec8; continue; }  // window not in the path set
-    const bool general = q.rank < 0 || q.path >= 32767 || q.min_pos > 32767;
-    int32_t mp = q.min_pos < -32768 ? -32768 : q.min_pos;
-    out[w] = (uint64_t)(uint32_t)q.shift | ((uint64_t)(uint16_t)(int16_t)mp << 32) | ((uint64_t)(q.path & 0x7fff) << 48) |
-             ((uint64_t)(general ? 1 : 0) << 63);
   }
 }
 

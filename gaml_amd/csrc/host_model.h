@@ -157,12 +157,6 @@ struct ReadMajor {
 };
 // slot_of_read maps a local read id to its device slot (identity when null)
 void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_read, ReadMajor& out);
-// Device order of the pairs of a paired set: stable by record-count class so that the lanes of a
-// wave take the same code path: 0 = at most one record per mate, 1 = at most 2, 2 = at most 4,
-// 3 = more (goes to the overflow kernel).
-void pair_device_order(const ShortMate& a, const ShortMate& b, std::vector<int32_t>& slot_of_read,
-                       std::vector<int32_t>& read_of_slot, int64_t class_count[4]);
-
 // Compact tables of class 0 (at most one record per mate, everything within the packed ranges):
 //   rec8  = window id (24 bits) | position in window (28) | edit distance (6) | orientation (1);
 //           all ones = the mate has no record
@@ -200,8 +194,6 @@ struct OccTable {
   std::vector<OccQuad> multi;
 };
 void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& out);
-// 8-byte occurrence entries for the compact path (from the 16-byte table)
-void build_occ8(const OccTable& t, std::vector<uint64_t>& out);
 
 void split_contigs(const Walk& path, std::vector<std::pair<int32_t, int32_t>>& ctg_ranges, std::vector<int32_t>& gaps);
 

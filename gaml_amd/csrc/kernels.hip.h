@@ -258,34 +258,7 @@ struct RegCands {
   bool valid[K], live[K];
 };
 
-template <int K>
-__device__ __forceinline__ bool load_cands(const MateView& v, const int4& r0, RegCands<K>& c) {
-  const int cnt = r0.x < 0 ? 0 : 1 + (int)((unsigned)r0.z >> 9);
-  int4 r[K], o[K];
-  bool multi = false;
-#pragma unroll
-  for (int k = 0; k < K; k++) r[k] = (k == 0) ? r0 : (k < cnt ? v.extra[r0.w + k - 1] : make_int4(-1, 0, 0, 0));
-#pragma unroll
-  for (int k = 0; k < K; k++) o[k] = (k < cnt && r[k].x >= 0) ? v.occ[r[k].x] : make_int4(0, 0, -1, 0);
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    multi |= (o[k].z >= 0 && o[k].w < 0);
-    c.path[k] = o[k].z; c.pos[k] = r[k].y + o[k].x; c.ef[k] = r[k].z & 0x1ff; c.rank[k] = o[k].w;
-    c.valid[k] = (k < cnt) && o[k].z >= 0 && r[k].y >= o[k].y;
-  }
-#pragma unroll
-  for (int i = 0; i < K; i++) {
-    bool lv = c.valid[i];
-#pragma unroll
-    for (int j = 0; j < K; j++)
-      if (j != i) lv = lv && !(c.valid[j] && c.path[j] == c.path[i] && c.pos[j] == c.pos[i] &&
-                               (c.rank[j] > c.rank[i] || (c.rank[j] == c.rank[i] && j > i)));
-    c.live[i] = lv;
-  }
-  return multi;
-}
-
-// same, from K inline records (all K loads independent: no link hop)
+// K inline records -> register candidates incl. the overwrite rule (all K loads independent)
 template <int K>
 __device__ __forceinline__ bool load_cands_inline(const MateView& v, const int4* rec, RegCands<K>& c) {
   int4 r[K], o[K];
