@@ -151,6 +151,11 @@ def main():
 
     ctx.set_event_timing(True)
     ctx.kernel_stats(reset=True)
+    # a step is ~70 us: one generation-2 pass of Python's garbage collector over the interpreter's
+    # (torch-sized) object graph costs ~40 ms, i.e. hundreds of steps -- keep it out of the timed loop
+    import gc
+    gc.collect()
+    gc.disable()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -164,6 +169,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     ks = ctx.kernel_stats(reset=True)
     ctx.set_event_timing(False)
 

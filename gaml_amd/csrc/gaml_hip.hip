@@ -273,6 +273,7 @@ int collect_events(gaml_hip_ctx* c) {
 }
 
 int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
+  if (c->ev_used == c->ev_pool.size() && c->ev_pool.size() >= 2048) { if (int e = collect_events(c)) return e; }
   if (c->ev_used == c->ev_pool.size()) {
     hipEvent_t a, b;
     HIP_TRY(c, hipEventCreate(&a));
@@ -732,7 +733,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   a.dirty_slots = (const int*)(arena + ds_off);
   for (int mt = 0; mt < 2; mt++) { a.dirty_off[mt] = (const int*)(arena + dofs_off[mt]); a.dirty_recs[mt] = (const int4*)(arena + drec_off[mt]); }
   const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size() + (int64_t)nd;
-  const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : kMaxBlocks;
+  const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : 768;  // 3 blocks per CU, ~2-3 pipelined iterations per lane at cfg3 (tools/kbench.py sweep)
   // the compact path handles 2 pairs per lane and iteration
   const int blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
   const int blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, kMaxBlocks));
@@ -1784,6 +1785,17 @@ int gaml_hip_last_timing(const gaml_hip_ctx* c, double* out3) {
 int gaml_hip_set_event_timing(gaml_hip_ctx* c, int on) {
   if (!c) return GAML_HIP_EINVAL;
   c->event_timing = on != 0;
+  if (c->event_timing && c->device >= 0) {
+    // event pairs are collected lazily (gaml_hip_kernel_stats); create a pool up front so that no
+    // hipEventCreate lands inside a caller's timed region
+    HIP_TRY(c, hipSetDevice(c->device));
+    while (c->ev_pool.size() < 2048) {
+      hipEvent_t a, b;
+      HIP_TRY(c, hipEventCreate(&a));
+      HIP_TRY(c, hipEventCreate(&b));
+      c->ev_pool.emplace_back(a, b);
+    }
+  }
   return GAML_HIP_OK;
 }
 int gaml_hip_kernel_stats(gaml_hip_ctx* c, int reset, int64_t* launches, double* device_us, double* algo_bytes) {

@@ -407,46 +407,62 @@ __device__ __forceinline__ double compact_score(const PairedArgs& a, const Compa
   return t;
 }
 
+__device__ __forceinline__ void compact_load(const PairedArgs& a, int i, bool ok, Compact1& c) {
+  c.r1 = ok ? a.rec8[0][i] : kNone8;
+  c.r2 = ok ? a.rec8[1][i] : kNone8;
+  c.lc = ok ? a.len_code[i] : 0;
+}
+
 template <int ABL>
 __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb, double& lsum, int& zeros) {
-  // Two pairs per lane and iteration: the 6 record/length loads of both pairs are issued together,
-  // then the 4 occurrence lookups, so one round of memory latency serves two pairs.
+  // Two pairs per lane and iteration, software pipelined: the record loads of iteration k+1 are
+  // issued before iteration k's occurrence lookups and arithmetic, so a lane always has one round of
+  // streaming loads in flight while it computes.
   const int stride = a.blocks0 * kBlock;
-  for (int i0 = lb * kBlock + threadIdx.x; i0 < a.n0; i0 += 2 * stride) {
+  int i0 = lb * kBlock + threadIdx.x;
+  if (i0 >= a.n0) return;
+  Compact1 c0, c1;
+  compact_load(a, i0, true, c0);
+  compact_load(a, i0 + stride, i0 + stride < a.n0, c1);
+  while (true) {
     const int i1 = i0 + stride;
     const bool two = i1 < a.n0;
-    Compact1 c0, c1;
-    c0.r1 = a.rec8[0][i0]; c0.r2 = a.rec8[1][i0];
-    const unsigned char lc0 = a.len_code[i0];
-    c1.r1 = two ? a.rec8[0][i1] : kNone8; c1.r2 = two ? a.rec8[1][i1] : kNone8;
-    const unsigned char lc1 = two ? a.len_code[i1] : 0;
-    const uint32_t l0 = a.len_combo[lc0], l1 = a.len_combo[lc1];
+    const int j0 = i0 + 2 * stride;
+    const bool more = j0 < a.n0;
+    Compact1 n0v, n1v;  // next iteration's records: issued now, consumed after this iteration's work
+    compact_load(a, j0, more, n0v);
+    compact_load(a, j0 + stride, j0 + stride < a.n0, n1v);
+    const uint32_t l0 = a.len_combo[c0.lc], l1 = a.len_combo[c1.lc];
     c0.L1 = l0 & 0xffff; c0.L2 = l0 >> 16; c1.L1 = l1 & 0xffff; c1.L2 = l1 >> 16;
-    c0.lc = lc0; c1.lc = lc1;
     if (ABL == 1 || ABL == 4) {
       a.probs[i0] = (double)(int)(c0.r1 + c0.r2 + c0.L1); lsum += (double)(int)c0.r1;
       if (two) { a.probs[i1] = (double)(int)(c1.r1 + c1.r2 + c1.L1); lsum += (double)(int)c1.r1; }
-      continue;
+    } else {
+      const bool d0 = c0.r1 == kDirty8, d1 = c1.r1 == kDirty8;  // scored by the overflow path from the delta lists
+      if (d0) { c0.r1 = kNone8; c0.r2 = kNone8; }
+      if (d1) { c1.r1 = kNone8; c1.r2 = kNone8; }
+      c0.o1 = c0.r1 != kNone8 ? a.occ8[0][c0.r1 & 0xffffff] : kNone8;
+      c0.o2 = c0.r2 != kNone8 ? a.occ8[1][c0.r2 & 0xffffff] : kNone8;
+      c1.o1 = c1.r1 != kNone8 ? a.occ8[0][c1.r1 & 0xffffff] : kNone8;
+      c1.o2 = c1.r2 != kNone8 ? a.occ8[1][c1.r2 & 0xffffff] : kNone8;
+      if (ABL == 2) {
+        a.probs[i0] = (double)(int)(c0.o1 + c0.o2); lsum += (double)(int)(c0.o1 + c0.o2);
+        if (two) { a.probs[i1] = (double)(int)(c1.o1 + c1.o2); lsum += (double)(int)(c1.o1 + c1.o2); }
+      } else {
+        bool s0, s1;
+        int k0, k1;
+        const double acc0 = compact_score(a, c0, s0, k0);
+        const double acc1 = compact_score(a, c1, s1, k1);
+        if (ABL == 3) { a.probs[i0] = acc0; lsum += acc0; if (two) { a.probs[i1] = acc1; lsum += acc1; } }
+        else {
+          if (!s0 && !d0) finish_read_compact(a, i0, acc0, c0.lc, k0, lsum, zeros);
+          if (two && !s1 && !d1) finish_read_compact(a, i1, acc1, c1.lc, k1, lsum, zeros);
+        }
+      }
     }
-    const bool d0 = c0.r1 == kDirty8, d1 = c1.r1 == kDirty8;  // scored by the overflow path from the delta lists
-    if (d0) { c0.r1 = kNone8; c0.r2 = kNone8; }
-    if (d1) { c1.r1 = kNone8; c1.r2 = kNone8; }
-    c0.o1 = c0.r1 != kNone8 ? a.occ8[0][c0.r1 & 0xffffff] : kNone8;
-    c0.o2 = c0.r2 != kNone8 ? a.occ8[1][c0.r2 & 0xffffff] : kNone8;
-    c1.o1 = c1.r1 != kNone8 ? a.occ8[0][c1.r1 & 0xffffff] : kNone8;
-    c1.o2 = c1.r2 != kNone8 ? a.occ8[1][c1.r2 & 0xffffff] : kNone8;
-    if (ABL == 2) {
-      a.probs[i0] = (double)(int)(c0.o1 + c0.o2); lsum += (double)(int)(c0.o1 + c0.o2);
-      if (two) { a.probs[i1] = (double)(int)(c1.o1 + c1.o2); lsum += (double)(int)(c1.o1 + c1.o2); }
-      continue;
-    }
-    bool s0, s1;
-    int k0, k1;
-    const double acc0 = compact_score(a, c0, s0, k0);
-    const double acc1 = compact_score(a, c1, s1, k1);
-    if (ABL == 3) { a.probs[i0] = acc0; lsum += acc0; if (two) { a.probs[i1] = acc1; lsum += acc1; } continue; }
-    if (!s0 && !d0) finish_read_compact(a, i0, acc0, c0.lc, k0, lsum, zeros);
-    if (two && !s1 && !d1) finish_read_compact(a, i1, acc1, c1.lc, k1, lsum, zeros);
+    if (!more) break;
+    c0 = n0v; c1 = n1v;
+    i0 = j0;
   }
 }
 
