@@ -80,6 +80,16 @@ def _load():
     L.gaml_hip_set_presharded.argtypes = [vp, C.c_int32]
     L.gaml_hip_put_window_records.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
     L.gaml_hip_put_pacbio_records.argtypes = [vp, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
+    L.gaml_hip_add_pacbio_reads.argtypes = [vp, C.POINTER(SingleCfg), C.c_int32, _u8p, _i64p, C.c_char_p]
+    L.gaml_hip_pacbio_missing.argtypes = [vp, C.c_int, _i32p, C.c_int32, _i32p, C.c_int32]
+    L.gaml_hip_pacbio_missing.restype = C.c_int32
+    L.gaml_hip_pacbio_ingest_sam.argtypes = [vp, C.c_int, _i32p, C.c_int32, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.gaml_hip_pacbio_records.argtypes = [vp, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
+    L.gaml_hip_pacbio_records.restype = C.c_int64
+    L.gaml_hip_pacbio_dp_stats.argtypes = [vp, C.c_int, _f64p]
+    L.gaml_hip_debug_sam_logprob.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int64, C.c_double, C.POINTER(C.c_double)]
+    L.gaml_hip_debug_sam_band.argtypes = [C.c_char_p, C.c_int64, C.c_int32, _i32p, _i32p, _i32p, _i32p, C.c_int32]
+    L.gaml_hip_debug_sam_band.restype = C.c_int32
     L.gaml_hip_calc_prob.argtypes = [vp, _i32p, _i64p, C.c_int32, C.POINTER(C.c_double), _i32p, C.POINTER(C.c_int32)]
     L.gaml_hip_calc_partials.argtypes = [vp, _i32p, _i64p, C.c_int32, _f64p, C.POINTER(C.c_int32)]
     L.gaml_hip_combine_partials.argtypes = [vp, _f64p, C.c_int32, C.POINTER(C.c_double), _i32p]
@@ -201,6 +211,47 @@ class Context:
     def add_pacbio(self, cfg: SingleCfg, lens) -> int:
         lens = np.ascontiguousarray(lens, np.int32)
         return self._check(_lib.gaml_hip_add_pacbio(self._h, C.byref(cfg), len(lens), lens))
+
+    def add_pacbio_reads(self, cfg: SingleCfg, bases, offs, names) -> int:
+        bases = np.ascontiguousarray(bases, np.uint8); offs = np.ascontiguousarray(offs, np.int64)
+        joined = ("\n".join(names) + "\n").encode()
+        return self._check(_lib.gaml_hip_add_pacbio_reads(self._h, C.byref(cfg), len(offs) - 1, bases, offs, joined))
+
+    def pacbio_missing(self, rs, path):
+        path = np.ascontiguousarray(path, np.int32)
+        n = self._check(_lib.gaml_hip_pacbio_missing(self._h, rs, path, len(path), np.zeros(2, np.int32), 0))
+        out = np.zeros(2 * max(1, n), np.int32)
+        self._check(_lib.gaml_hip_pacbio_missing(self._h, rs, path, len(path), out, n))
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+    def pacbio_ingest_sam(self, rs, path, sam_text: str) -> int:
+        path = np.ascontiguousarray(path, np.int32)
+        raw = sam_text.encode()
+        filed = C.c_int64(0)
+        self._check(_lib.gaml_hip_pacbio_ingest_sam(self._h, rs, path, len(path), raw, len(raw), C.byref(filed)))
+        return filed.value
+
+    def pacbio_records(self, rs, walk):
+        walk = np.ascontiguousarray(walk, np.int32)
+        n = _lib.gaml_hip_pacbio_records(self._h, rs, walk, len(walk), None, 0)
+        if n == -1:
+            return None
+        self._check(int(n))
+        recs = np.zeros(max(1, n), PACBIO_ALIGMENT)
+        _lib.gaml_hip_pacbio_records(self._h, rs, walk, len(walk), recs.ctypes.data, n)
+        return recs[:n]
+
+    def debug_sam_logprob(self, target: str, read: str, sam_line: str, mismatch: float) -> float:
+        t, r, l = target.encode(), read.encode(), sam_line.encode()
+        out = C.c_double(0)
+        self._check(_lib.gaml_hip_debug_sam_logprob(self._h, t, len(t), r, len(r), l, len(l), mismatch, C.byref(out)))
+        return out.value
+
+    def pacbio_dp_stats(self, rs):
+        out = np.zeros(8)
+        self._check(_lib.gaml_hip_pacbio_dp_stats(self._h, rs, out))
+        keys = ["records", "jobs", "rows", "cells", "kernel_ms", "host_prepare_ms", "device_ms", "scratch_bytes"]
+        return dict(zip(keys, (float(x) for x in out)))
 
     def add_single_fastq(self, cfg, f) -> int:
         return self._check(_lib.gaml_hip_add_single_fastq(self._h, C.byref(cfg), f.encode()))
@@ -379,3 +430,16 @@ class Context:
         n, us, b = C.c_int64(), C.c_double(), C.c_double()
         _lib.gaml_hip_kernel_stats(self._h, 1 if reset else 0, C.byref(n), C.byref(us), C.byref(b))
         return {"launches": n.value, "device_us": us.value, "algo_bytes": b.value}
+
+
+def debug_sam_band(sam_line: str, total_len: int):
+    """Host-only: (fields dict, row0, lo[], hi[]) of one SAM line as the library parses / bands it."""
+    raw = sam_line.encode()
+    f = np.zeros(10, np.int32); r0 = np.zeros(1, np.int32)
+    n = _lib.gaml_hip_debug_sam_band(raw, len(raw), total_len, f, r0, np.zeros(1, np.int32), np.zeros(1, np.int32), 0)
+    if n < 0:
+        raise GamlHipError(f"malformed SAM line ({n})")
+    lo = np.zeros(n, np.int32); hi = np.zeros(n, np.int32)
+    _lib.gaml_hip_debug_sam_band(raw, len(raw), total_len, f, r0, lo, hi, n)
+    keys = ["flags", "len", "posstart", "posend", "sstart", "send", "slen", "tstart", "tend", "edit_dist"]
+    return dict(zip(keys, (int(x) for x in f))), int(r0[0]), lo, hi

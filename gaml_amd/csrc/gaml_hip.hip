@@ -19,6 +19,7 @@
 #include "aligner.hip.h"
 #include "host_model.h"
 #include "kernels.hip.h"
+#include "pacbio_dp.hip.h"
 
 using namespace gaml;
 
@@ -146,6 +147,11 @@ struct SingleSet {
   Staging stage;
 };
 
+struct DpDev {  // device buffers of the PacBio banded DP
+  DevBuf path, jobs, lo, hi, scratch, out;
+  void release() { path.release(); jobs.release(); lo.release(); hi.release(); scratch.release(); out.release(); }
+};
+
 struct PacbioSet {
   gaml_single_cfg cfg;
   int64_t n_global = 0, lo = 0, hi = 0;
@@ -160,6 +166,15 @@ struct PacbioSet {
   Reducer red;
   int64_t last_bad_bases = 0;
   Staging stage;
+  // cache-miss side (SAM ingestion): bases of this shard's reads and the name -> global id map
+  bool have_reads = false;
+  std::string bases;
+  std::vector<int64_t> base_off;  // local read i = bases[base_off[i], base_off[i+1])
+  std::unordered_map<std::string, int32_t> name_id;
+  DevBuf d_bases;
+  DpDev dp;
+  bool bases_uploaded = false;
+  double dp_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct PairedPrep {
@@ -186,7 +201,7 @@ struct gaml_hip_ctx {
   AlignScratch aln_scratch;
   int64_t aln_windows = 0, aln_candidates = 0;  // GPU aligner statistics
   double aln_us = 0;
-  int knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
+  int knobs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
   int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;
   // timing
@@ -1296,7 +1311,8 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
       s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); drop_stage(s->stage);
     }
-    for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage); }
+    for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage);
+      s->d_bases.release(); s->dp.release(); }
     c->packed.release(); c->packed_host.release(); c->aln_scratch.release();
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1388,6 +1404,36 @@ int gaml_hip_add_pacbio(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, 
   return (int)c->handles.size() - 1;
 }
 
+int gaml_hip_add_pacbio_reads(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, const char* bases, const int64_t* offs,
+                              const char* names) {
+  if (!c || !cfg || n < 0 || !offs || (n > 0 && (!bases || !names))) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  for (int64_t i = offs[0]; i < offs[n]; i++)
+    if (bases[i] == '\n' || bases[i] == '-') return fail(c, GAML_HIP_EINVAL, "a PacBio read holds a separator or gap character");
+  std::vector<int32_t> lens(n);
+  for (int32_t i = 0; i < n; i++) {
+    if (offs[i + 1] < offs[i] || offs[i + 1] - offs[i] > INT32_MAX) return fail(c, GAML_HIP_EINVAL, "bad read offsets");
+    lens[i] = (int32_t)(offs[i + 1] - offs[i]);
+  }
+  int h = gaml_hip_add_pacbio(c, cfg, n, lens.data());
+  if (h < 0) return h;
+  PacbioSet& s = *c->pacbios[c->handles[h].idx];
+  s.have_reads = true;
+  s.base_off.assign(1, 0);
+  for (int64_t i = s.lo; i < s.hi; i++) {
+    s.bases.append(bases + offs[i], bases + offs[i + 1]);
+    s.base_off.push_back((int64_t)s.bases.size());
+  }
+  // read ids in order of first appearance (GetReadId graph.h:410-420); names are '\n'-separated
+  const char* p = names;
+  for (int32_t i = 0; i < n; i++) {
+    const char* e = strchr(p, '\n');
+    std::string name = e ? std::string(p, e) : std::string(p);
+    p = e ? e + 1 : p + name.size();
+    s.name_id[name] = i;
+  }
+  return h;
+}
+
 int gaml_hip_add_single_fastq(gaml_hip_ctx* c, const gaml_single_cfg* cfg, const char* fastq) {
   if (!c || !cfg || !fastq) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   std::string bases, err; std::vector<int64_t> offs;
@@ -1403,11 +1449,10 @@ int gaml_hip_add_paired_fastq(gaml_hip_ctx* c, const gaml_paired_cfg* cfg, const
 }
 int gaml_hip_add_pacbio_fastq(gaml_hip_ctx* c, const gaml_single_cfg* cfg, const char* fastq) {
   if (!c || !cfg || !fastq) return fail(c, GAML_HIP_EINVAL, "bad arguments");
-  std::string bases, err; std::vector<int64_t> offs;
-  if (!read_fastq(fastq, bases, offs, &err)) return fail(c, GAML_HIP_EINVAL, err);
-  std::vector<int32_t> lens(offs.size() - 1);
-  for (size_t i = 0; i + 1 < offs.size(); i++) lens[i] = (int32_t)(offs[i + 1] - offs[i]);
-  return gaml_hip_add_pacbio(c, cfg, (int32_t)lens.size(), lens.data());
+  std::string bases, err, joined; std::vector<int64_t> offs; std::vector<std::string> names;
+  if (!read_fastq(fastq, bases, offs, &err, &names)) return fail(c, GAML_HIP_EINVAL, err);
+  for (auto& nm : names) { joined += nm; joined += '\n'; }
+  return gaml_hip_add_pacbio_reads(c, cfg, (int32_t)offs.size() - 1, bases.data(), offs.data(), joined.c_str());
 }
 
 static ShortMate* mate_of(gaml_hip_ctx* c, int readset, int mate) {
@@ -1456,6 +1501,275 @@ int gaml_hip_put_pacbio_records(gaml_hip_ctx* c, int readset, const int32_t* sub
   }
   s.generation++;
   return GAML_HIP_OK;
+}
+
+namespace {
+PacbioSet* pacbio_of(gaml_hip_ctx* c, int readset) {
+  if (!c || readset < 0 || readset >= (int)c->handles.size() || c->handles[readset].kind != 2) return nullptr;
+  return c->pacbios[c->handles[readset].idx].get();
+}
+// path string + node boundaries of a (normalised) path (graph.cc:2412-2431, 2662-2688)
+void pacbio_path_string(const gaml_hip_ctx* c, const Walk& path, std::string* seq, std::vector<int32_t>& begins, std::vector<int32_t>& ends) {
+  int64_t len = 0;
+  begins.clear(); ends.clear();
+  for (int32_t x : path) {
+    begins.push_back((int32_t)len);
+    if (x < 0) { if (seq) seq->append((size_t)-x, 'N'); len += -x; }
+    else { if (seq) seq->append(c->g.seq(x), c->g.seq(x) + c->g.len(x)); len += c->g.len(x); }
+    ends.push_back((int32_t)len);
+  }
+}
+// upload one batch of DP jobs, run the banded DP kernel, fetch the log probabilities
+int run_pacbio_dp(gaml_hip_ctx* c, DpDev& d, const std::string& both, const unsigned char* d_reads, const std::vector<DpJob>& jobs,
+                  const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, int64_t scratch, double log_match, double log_mismatch,
+                  double* logp, float* kernel_ms) {
+  hipStream_t st = c->stream;
+  HIP_TRY(c, d.path.reserve(both.size()));
+  HIP_TRY(c, d.jobs.reserve(jobs.size() * sizeof(DpJob)));
+  HIP_TRY(c, d.lo.reserve(lo.size() * sizeof(int32_t)));
+  HIP_TRY(c, d.hi.reserve(hi.size() * sizeof(int32_t)));
+  HIP_TRY(c, d.scratch.reserve(std::max<size_t>(1, (size_t)scratch) * sizeof(double)));
+  HIP_TRY(c, d.out.reserve(jobs.size() * sizeof(double)));
+  HIP_TRY(c, hipMemcpy(d.path.p, both.data(), both.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(d.jobs.p, jobs.data(), jobs.size() * sizeof(DpJob), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(d.lo.p, lo.data(), lo.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(d.hi.p, hi.data(), hi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  DpArgs a;
+  a.path = d.path.as<unsigned char>(); a.path_len = (int32_t)both.size();
+  a.reads = d_reads;
+  a.jobs = d.jobs.as<DpJob>(); a.lo = d.lo.as<int32_t>(); a.hi = d.hi.as<int32_t>();
+  a.scratch = d.scratch.as<double>(); a.out = d.out.as<double>();
+  a.n_jobs = (int32_t)jobs.size();
+  a.log_match = log_match; a.log_mismatch = log_mismatch;
+  hipEvent_t ev0, ev1;
+  HIP_TRY(c, hipEventCreate(&ev0));
+  HIP_TRY(c, hipEventCreate(&ev1));
+  HIP_TRY(c, hipEventRecord(ev0, st));
+  const int lanes = c->knobs[8] == 16 ? 16 : 8;
+  const int64_t threads = (int64_t)jobs.size() * lanes;
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  if (lanes == 16) hipLaunchKernelGGL(pacbio_dp_kernel<16>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(pacbio_dp_kernel<8>, dim3(grid), dim3(256), 0, st, a);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(ev1, st));
+  HIP_TRY(c, hipMemcpyAsync(logp, d.out.p, jobs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  HIP_TRY(c, hipEventElapsedTime(kernel_ms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  return GAML_HIP_OK;
+}
+}  // namespace
+
+int32_t gaml_hip_pacbio_missing(gaml_hip_ctx* c, int readset, const int32_t* path_in, int32_t n, int32_t* ranges, int32_t cap) {
+  PacbioSet* sp = pacbio_of(c, readset);
+  if (!sp || !path_in || n <= 0 || cap < 0 || (cap > 0 && !ranges)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph");
+  Walk path(path_in, path_in + n);
+  for (auto& x : path) {
+    if (x >= c->g.n()) return fail(c, GAML_HIP_EINVAL, "node id out of range");
+    if (x >= 0) x = c->g.norm[x];
+  }
+  std::vector<int32_t> begins, ends;
+  pacbio_path_string(c, path, nullptr, begins, ends);
+  std::vector<std::pair<int32_t, int32_t>> missing;  // graph.cc:2438-2454
+  Walk sub;
+  for (int32_t i = 0; i < n; i++) {
+    sub.clear();
+    for (int32_t j = i; j < n; j++) {
+      sub.push_back(path[j]);
+      if (!sp->walk_id.count(sub)) missing.emplace_back(i, j);
+      if ((ends[j] - begins[i]) - (ends[i] - begins[i]) > sp->max_len) break;
+    }
+  }
+  std::sort(missing.begin(), missing.end());
+  int32_t out = 0, mb = -1, me = -1;  // merge overlapping index ranges (graph.cc:2455-2478)
+  auto emit = [&]() { if (out < cap) { ranges[2 * out] = mb; ranges[2 * out + 1] = me; } out++; };
+  for (auto& m : missing) {
+    if (mb < 0) { mb = m.first; me = m.second; continue; }
+    if (m.first > me) { emit(); mb = m.first; me = m.second; }
+    me = std::max(me, m.second);
+  }
+  if (mb >= 0) emit();
+  return out;
+}
+
+int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path_in, int32_t n, const char* sam, int64_t sam_len,
+                               int64_t* filed_out) {
+  PacbioSet* sp = pacbio_of(c, readset);
+  if (!sp || !path_in || n <= 0 || sam_len < 0 || (sam_len > 0 && !sam)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph");
+  PacbioSet& s = *sp;
+  if (!s.have_reads) return fail(c, GAML_HIP_ESTATE, "read set was added without bases (use gaml_hip_add_pacbio_reads)");
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "the alignment DP needs a HIP device: this context is host-only");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const double t0 = now_us();
+  Walk path(path_in, path_in + n);
+  for (auto& x : path) {
+    if (x >= c->g.n()) return fail(c, GAML_HIP_EINVAL, "node id out of range");
+    if (x >= 0) x = c->g.norm[x];  // the scorer normalises before it looks up sub-walks (graph.cc:3180)
+  }
+  std::string seq;
+  std::vector<int32_t> begins, ends;
+  pacbio_path_string(c, path, &seq, begins, ends);
+  if (2 * (int64_t)seq.size() + 1 > INT32_MAX) return fail(c, GAML_HIP_EINVAL, "path too long");
+  const int32_t seq_len = (int32_t)seq.size();
+  std::string both = seq;  // path + separator + reverse complement (graph.cc:2687-2688)
+  both += '\n';
+  for (int32_t i = seq_len - 1; i >= 0; i--) {
+    char ch = seq[i];
+    both += ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;  // ReverseBase graph.h:58-64
+  }
+  // sub-walks this call may file under (graph.cc:2724-2743): new ones get an (empty) cache entry,
+  // ones cached before are left alone
+  std::unordered_map<Walk, int32_t, WalkHasher> starts;
+  std::unordered_map<Walk, int32_t, WalkHasher> fresh;  // -> cache id
+  {
+    Walk sub;
+    for (int32_t i = 0; i < n; i++) {
+      sub.clear();
+      for (int32_t j = i; j < n; j++) {
+        sub.push_back(path[j]);
+        if (!s.walk_id.count(sub)) {
+          const int32_t id = (int32_t)s.recs.size();
+          s.walk_id.emplace(sub, id);
+          s.recs.emplace_back();
+          fresh.emplace(sub, id);
+        }
+        starts[sub] = i;
+        if ((ends[j] - begins[i]) - (ends[i] - begins[i]) > s.max_len) break;
+      }
+    }
+    s.generation++;
+  }
+  // SAM lines -> DP jobs for the records that will be filed (graph.cc:2746-2786)
+  struct Filed { int32_t walk, pos, pos_end, read_local; };
+  std::vector<Filed> filed;
+  std::vector<DpJob> jobs;
+  std::vector<int32_t> lo, hi;
+  int64_t scratch = 0, records = 0, cells = 0;
+  SamRecord rec;
+  DpBand band;
+  for (const char* p = sam, *end = sam + sam_len; p < end;) {
+    const char* e = (const char*)memchr(p, '\n', (size_t)(end - p));
+    const char* le = e ? e : end;
+    if (le > p && *p != '@') {
+      if (!parse_sam_record(p, le, (int32_t)both.size(), rec)) return fail(c, GAML_HIP_EINVAL, "SAM line with fewer than 10 columns");
+      records++;
+      auto id = s.name_id.find(rec.name);
+      if (id == s.name_id.end()) return fail(c, GAML_HIP_EINVAL, "SAM record names a read that is not in the read set: " + rec.name);  // assert graph.cc:2751
+      const int32_t ib = (int32_t)(std::lower_bound(ends.begin(), ends.end(), std::max(0, rec.tstart - 5)) - ends.begin());
+      const int32_t ie = (int32_t)(std::lower_bound(ends.begin(), ends.end(), std::min(rec.tstart + rec.len + 5, seq_len)) - ends.begin());
+      if (ib < n && ie < n && ie >= ib && id->second >= s.lo && id->second < s.hi) {
+        Walk sub(path.begin() + ib, path.begin() + ie + 1);
+        auto st = starts.find(sub);
+        auto fr = fresh.find(sub);
+        if (st != starts.end() && st->second == ib && fr != fresh.end()) {
+          const int32_t local = (int32_t)(id->second - s.lo);
+          const int32_t pos_begin = ib > 0 ? ends[ib - 1] : 0;
+          filed.push_back(Filed{fr->second, rec.tstart - pos_begin, rec.tend - pos_begin, local});
+          pacbio_dp_band(rec.cigar, band);
+          DpJob j;
+          j.read_off = s.base_off[local];
+          j.read_len = (int32_t)(s.base_off[local + 1] - s.base_off[local]);
+          j.band_off = (int64_t)lo.size();
+          j.scratch_off = scratch;
+          j.posstart = rec.posstart;
+          j.row0 = band.row0;
+          j.n_rows = (int32_t)band.lo.size();
+          j.max_width = band.max_width;
+          j.pad = 0;
+          scratch += 2 * (int64_t)band.max_width;
+          lo.insert(lo.end(), band.lo.begin(), band.lo.end());
+          hi.insert(hi.end(), band.hi.begin(), band.hi.end());
+          for (size_t r = 0; r < band.lo.size(); r++) cells += band.hi[r] - band.lo[r] + 1;
+          jobs.push_back(j);
+        }
+      }
+    }
+    if (!e) break;
+    p = e + 1;
+  }
+  const double t1 = now_us();
+  float kernel_ms = 0;
+  std::vector<double> logp(jobs.size());
+  if (!jobs.empty()) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!s.bases_uploaded) {
+      HIP_TRY(c, s.d_bases.reserve(std::max<size_t>(1, s.bases.size())));
+      HIP_TRY(c, hipMemcpy(s.d_bases.p, s.bases.data(), s.bases.size(), hipMemcpyHostToDevice));
+      s.bases_uploaded = true;
+    }
+    if (int e = run_pacbio_dp(c, s.dp, both, s.d_bases.as<unsigned char>(), jobs, lo, hi, scratch, s.log_match, s.log_mismatch, logp.data(), &kernel_ms))
+      return e;
+  }
+  for (size_t i = 0; i < filed.size(); i++) {
+    gaml_pacbio_aligment r;
+    r.position = filed[i].pos; r.position_end = filed[i].pos_end; r.read_id = filed[i].read_local; r.logprob = logp[i];
+    s.recs[filed[i].walk].push_back(r);
+  }
+  s.generation++;
+  if (filed_out) *filed_out = (int64_t)filed.size();
+  s.dp_stats[0] = (double)records; s.dp_stats[1] = (double)jobs.size(); s.dp_stats[2] = (double)lo.size();
+  s.dp_stats[3] = (double)cells; s.dp_stats[4] = kernel_ms; s.dp_stats[5] = (t1 - t0) * 1e-3; s.dp_stats[6] = (now_us() - t1) * 1e-3;
+  s.dp_stats[7] = (double)scratch * 8;
+  return GAML_HIP_OK;
+}
+
+int32_t gaml_hip_debug_sam_band(const char* sam_line, int64_t len, int32_t total_len, int32_t* fields10, int32_t* row0, int32_t* lo,
+                                int32_t* hi, int32_t cap) {
+  if (!sam_line || !fields10 || !row0) return GAML_HIP_EINVAL;
+  SamRecord a;
+  if (!parse_sam_record(sam_line, sam_line + len, total_len, a)) return GAML_HIP_EINVAL;
+  const int32_t f[10] = {a.flags, a.len, a.posstart, a.posend, a.sstart, a.send, a.slen, a.tstart, a.tend, a.edit_dist};
+  memcpy(fields10, f, sizeof(f));
+  DpBand b;
+  pacbio_dp_band(a.cigar, b);
+  *row0 = b.row0;
+  const int32_t n = (int32_t)b.lo.size();
+  if (n <= cap && lo && hi) { memcpy(lo, b.lo.data(), n * sizeof(int32_t)); memcpy(hi, b.hi.data(), n * sizeof(int32_t)); }
+  return n;
+}
+
+int gaml_hip_debug_sam_logprob(gaml_hip_ctx* c, const char* target, int32_t target_len, const char* read, int32_t read_len,
+                               const char* sam_line, int64_t sam_len, double mismatch_prob, double* logprob_out) {
+  if (!c || !target || target_len <= 0 || !read || read_len < 0 || !sam_line || !logprob_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "no device");
+  SamRecord rec;
+  if (!parse_sam_record(sam_line, sam_line + sam_len, target_len, rec)) return fail(c, GAML_HIP_EINVAL, "SAM line with fewer than 10 columns");
+  DpBand band;
+  pacbio_dp_band(rec.cigar, band);
+  DpJob j;
+  j.read_off = 0; j.read_len = read_len; j.band_off = 0; j.scratch_off = 0; j.posstart = rec.posstart; j.row0 = band.row0;
+  j.n_rows = (int32_t)band.lo.size(); j.max_width = band.max_width; j.pad = 0;
+  DpDev dev;
+  DevBuf d_read;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, d_read.reserve(std::max(1, read_len)));
+  HIP_TRY(c, hipMemcpy(d_read.p, read, read_len, hipMemcpyHostToDevice));
+  float ms = 0;
+  int e = run_pacbio_dp(c, dev, std::string(target, target + target_len), d_read.as<unsigned char>(), std::vector<DpJob>(1, j), band.lo, band.hi,
+                        2 * (int64_t)band.max_width, std::log(1.0 - 4 * mismatch_prob), std::log(mismatch_prob), logprob_out, &ms);
+  dev.release();
+  d_read.release();
+  return e;
+}
+
+int gaml_hip_pacbio_dp_stats(gaml_hip_ctx* c, int readset, double* out8) {
+  PacbioSet* sp = pacbio_of(c, readset);
+  if (!sp || !out8) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  memcpy(out8, sp->dp_stats, sizeof(sp->dp_stats));
+  return GAML_HIP_OK;
+}
+
+int64_t gaml_hip_pacbio_records(gaml_hip_ctx* c, int readset, const int32_t* subpath, int32_t len, gaml_pacbio_aligment* out, int64_t cap) {
+  PacbioSet* sp = pacbio_of(c, readset);
+  if (!sp || !subpath || len <= 0 || cap < 0 || (cap > 0 && !out)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  auto it = sp->walk_id.find(Walk(subpath, subpath + len));
+  if (it == sp->walk_id.end()) return -1;
+  const auto& v = sp->recs[it->second];
+  for (int64_t i = 0; i < (int64_t)v.size() && i < cap; i++) { out[i] = v[i]; out[i].read_id += (int32_t)sp->lo; }
+  return (int64_t)v.size();
 }
 
 int gaml_hip_eval_begin(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths, int64_t* pending_out,
@@ -1766,7 +2080,7 @@ int gaml_hip_debug_profile(gaml_hip_ctx* c, double* out8) {
 }
 
 int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
-  if (!c || knob < 0 || knob >= 8) return GAML_HIP_EINVAL;
+  if (!c || knob < 0 || knob >= 10) return GAML_HIP_EINVAL;
   c->knobs[knob] = value;
   return GAML_HIP_OK;
 }

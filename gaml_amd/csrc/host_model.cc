@@ -957,7 +957,8 @@ void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& o
 // FASTQ (graph.cc:1366-1415): 4 lines per record, name = first blank-separated token after
 // the first character; a repeated name overwrites the earlier read of that id.
 // ---------------------------------------------------------------------------------------
-bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t>& offs, std::string* err) {
+bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t>& offs, std::string* err,
+                std::vector<std::string>* names) {
   std::ifstream f(file.c_str());
   if (!f.is_open()) { if (err) *err = "cannot open reads file " + file; return false; }
   std::unordered_map<std::string, int64_t> ids;
@@ -969,7 +970,7 @@ bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t
     if (cut != std::string::npos) name.resize(cut);
     std::getline(f, s);
     auto it = ids.find(name);
-    if (it == ids.end()) { ids.emplace(name, (int64_t)reads.size()); reads.push_back(s); }
+    if (it == ids.end()) { ids.emplace(name, (int64_t)reads.size()); reads.push_back(s); if (names) names->push_back(name); }
     else reads[it->second] = s;
     std::getline(f, l);
     std::getline(f, l);
@@ -978,6 +979,137 @@ bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t
   offs.assign(1, 0);
   for (auto& r : reads) { bases += r; offs.push_back((int64_t)bases.size()); }
   return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// SAM record (ParseAligment graph.cc:2945-3021, ParseCigar :3023-3038)
+// ---------------------------------------------------------------------------------------
+bool parse_sam_record(const char* b, const char* e, int32_t total_len, SamRecord& a) {
+  std::vector<std::pair<const char*, const char*>> col;
+  for (const char* p = b;;) {
+    const char* t = (const char*)memchr(p, '\t', (size_t)(e - p));
+    if (!t) { col.emplace_back(p, e); break; }
+    col.emplace_back(p, t);
+    p = t + 1;
+  }
+  if (col.size() < 10) return false;
+  auto num = [&](size_t i, size_t skip = 0) {  // atoi of a column (leading digits, 0 when none)
+    std::string s(col[i].first + std::min<size_t>(skip, (size_t)(col[i].second - col[i].first)), col[i].second);
+    return (int32_t)atoi(s.c_str());
+  };
+  a = SamRecord();
+  {  // name = QNAME up to its LAST '/' (empty when there is none; :2951-2957)
+    const char* cut = col[0].first;
+    for (const char* p = col[0].first; p < col[0].second; p++) if (*p == '/') cut = p;
+    a.name.assign(col[0].first, cut);
+  }
+  a.flags = num(1);
+  int32_t posstart = num(3);
+  a.len = num(8);
+  int32_t posend = posstart + a.len;
+  a.slen = a.send = (int32_t)(col[9].second - col[9].first);
+  a.sstart = 0;
+  a.edit_dist = 100000;
+  for (size_t i = 11; i < col.size(); i++) {  // "XS:i:<v>" etc.; the value starts at character 5
+    if (col[i].second - col[i].first < 2) continue;
+    const char t0 = col[i].first[0], t1 = col[i].first[1];
+    const int32_t v = (col[i].second - col[i].first > 5) ? num(i, 5) : 0;
+    if (t0 == 'X' && t1 == 'S') a.sstart = v - 1;
+    if (t0 == 'X' && t1 == 'E') a.send = v - 1;
+    if (t0 == 'X' && t1 == 'Q') a.slen = v;
+    if (t0 == 'N' && t1 == 'M') a.edit_dist = v;
+  }
+  a.tstart = posstart;
+  a.tend = posend;
+  {  // CIGAR: a count is whatever atoi reads from the end of the previous M/I/D operation
+    const char* from = col[5].first;
+    for (const char* p = col[5].first; p < col[5].second; p++) {
+      if (*p == 'M' || *p == 'I' || *p == 'D') {
+        a.cigar.emplace_back((int32_t)atoi(std::string(from, p).c_str()), *p);
+        from = p + 1;
+      }
+    }
+  }
+  if (a.flags & 16) {
+    const int32_t span = posend - posstart;
+    posstart = total_len - posend;
+    posend = posstart + span;
+    std::reverse(a.cigar.begin(), a.cigar.end());
+  }
+  if (a.send != a.slen) a.cigar.emplace_back(a.slen - a.send, 'I');
+  if (a.sstart != 0) {
+    const int32_t head = std::min(a.sstart, posstart), rest = a.sstart - head;
+    a.cigar.insert(a.cigar.begin(), std::make_pair(head, 'I'));
+    if (rest) a.cigar.insert(a.cigar.begin(), std::make_pair(rest, 'I'));
+  }
+  a.posstart = posstart;
+  a.posend = posend;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// DP band (graph.cc:2183-2235). The reference materialises the cell list and closes it twice
+// (Uniquify :2153-2173); the set is a union of row intervals, so the same set is computed here
+// from per-row first/last columns of the CIGAR path.
+// ---------------------------------------------------------------------------------------
+void pacbio_dp_band(const std::vector<std::pair<int32_t, char>>& cigar, DpBand& out) {
+  // the CIGAR path: row r is entered at column enter[r] and left at column leave[r]
+  std::vector<int32_t> enter(1, 0), leave;
+  int64_t total = 0, lead = 0, trail = 0;
+  bool seen_other = false;
+  int32_t col = 0;
+  for (const auto& op : cigar) {
+    const int32_t n = std::max(0, op.first);
+    if (n == 0) continue;
+    total += n;
+    if (op.second == 'I') {
+      col += n;
+      if (!seen_other) lead += n;
+      trail += n;
+    } else {
+      seen_other = true;
+      trail = 0;
+      for (int32_t k = 0; k < n; k++) {
+        leave.push_back(col);
+        if (op.second == 'M') col++;
+        enter.push_back(col);
+      }
+    }
+  }
+  leave.push_back(col);
+  const int32_t row_f = (int32_t)enter.size() - 1, col_f = col;
+  // clip boxes (GetCigarEnds :2138-2151, capped at 200 :2181-2182); none when the CIGAR is all 'I'
+  const int32_t bl = seen_other ? (int32_t)std::min<int64_t>(lead, 200) : 0;
+  const int32_t el = seen_other ? (int32_t)std::min<int64_t>(trail + 1, 200) : 0;
+  const int32_t r_first = bl > 0 ? -bl : 0;
+  const int32_t r_last = std::max(std::max(row_f, row_f + el - 1), bl > 0 ? 2 : 0);
+  const int32_t n1 = r_last - r_first + 1;
+  std::vector<int32_t> lo1(n1, INT32_MAX), hi1(n1, INT32_MIN);
+  auto add = [&](int32_t r, int32_t a, int32_t b) {
+    lo1[r - r_first] = std::min(lo1[r - r_first], a);
+    hi1[r - r_first] = std::max(hi1[r - r_first], b);
+  };
+  add(0, 0, 0);
+  if (bl > 0) for (int32_t r = -bl; r < 3; r++) add(r, 0, bl - 1);
+  for (int32_t r = 0; r <= row_f; r++) add(r, enter[r], leave[r]);
+  for (int32_t r = row_f; r < row_f + el; r++) add(r, col_f - el, col_f);
+  // widen by 2 in both directions
+  out.row0 = r_first - 2;
+  const int32_t n2 = n1 + 4;
+  out.lo.assign(n2, 0);
+  out.hi.assign(n2, 0);
+  out.max_width = 0;
+  for (int32_t i = 0; i < n2; i++) {
+    int32_t a = INT32_MAX, b = INT32_MIN;
+    for (int32_t k = i - 4; k <= i; k++) {  // first-pass rows (i-2)-2 .. (i-2)+2 in lo1 indexing
+      if (k < 0 || k >= n1) continue;
+      a = std::min(a, lo1[k]);
+      b = std::max(b, hi1[k]);
+    }
+    out.lo[i] = a - 2;
+    out.hi[i] = b + 2;
+    out.max_width = std::max(out.max_width, out.hi[i] - out.lo[i] + 1);
+  }
 }
 
 }  // namespace gaml

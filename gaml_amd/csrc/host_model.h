@@ -272,6 +272,33 @@ class PairedPlanner {
 };
 int32_t walk_length(const GraphStore& g, const Walk& w);
 
-bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t>& offs, std::string* err);
+bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t>& offs, std::string* err,
+                std::vector<std::string>* names = nullptr);
+
+// ---------------------------------------------------------------------------------------
+// PacBio cache-miss side: SAM record -> banded-DP job (host part; the DP itself runs on the GPU)
+// ---------------------------------------------------------------------------------------
+// One SAM alignment as the reference reads it (PacbioAligmentData graph.h:499-514, ParseAligment
+// graph.cc:2945-3021): QNAME up to its last '/', FLAG, POS, CIGAR (M/I/D only), column 9 length,
+// SEQ length, tags XS/XE/XQ/NM. Reverse-strand records (FLAG & 16) are moved to the second half of
+// "path + separator + reverse complement" (total_len = 2|path| + 1); soft-clipped read ends become
+// insertions so that the DP covers the whole read.
+struct SamRecord {
+  std::string name;
+  int32_t flags = 0, len = 0, posstart = 0, posend = 0, sstart = 0, send = 0, slen = 0, tstart = 0, tend = 0, edit_dist = 0;
+  std::vector<std::pair<int32_t, char>> cigar;
+};
+// false: fewer than 10 tab-separated columns (the reference would index past the end)
+bool parse_sam_record(const char* begin, const char* end, int32_t total_len, SamRecord& out);
+
+// Cell set of AligmentProbability (graph.cc:2183-2235) as one column interval per DP row:
+// rows row0 .. row0+lo.size()-1, row r covers columns lo[r-row0] .. hi[r-row0]. The set is the
+// CIGAR path plus the two clip boxes (<= 200), closed to full row intervals, widened by 2 in both
+// directions and closed again.
+struct DpBand {
+  int32_t row0 = 0, max_width = 0;
+  std::vector<int32_t> lo, hi;
+};
+void pacbio_dp_band(const std::vector<std::pair<int32_t, char>>& cigar, DpBand& out);
 
 }  // namespace gaml

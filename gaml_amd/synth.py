@@ -247,6 +247,115 @@ def make_pacbio_records(g: Graph, walk: list[int], n_reads: int, read_len: int, 
     return PacbioRecords(lens, walks, recs, logps)
 
 
+def revcomp_str(s: str) -> str:
+    return revcomp(np.frombuffer(s.encode(), np.uint8)).tobytes().decode()
+
+
+def walk_string(g: Graph, walk: list[int]) -> str:
+    """Path string as the PacBio code builds it (reference graph.cc:2662-2686): gaps become N runs."""
+    return "".join(g.seqs[x].tobytes().decode() if x >= 0 else "N" * (-x) for x in walk)
+
+
+@dataclass
+class PacbioSam:
+    reads: list       # fastq orientation
+    names: list       # fastq names ("r<i>"); the SAM QNAME is "<name>/0_<len>" like BLASR writes it
+    sam: str          # SAM text (header line + one line per alignment)
+    n_records: int
+
+
+def make_pacbio_sam(g: Graph, walk: list[int], n_reads: int, read_len: int, seed: int, sub=0.05, ins=0.06, dele=0.04,
+                    clip_frac=0.3, rev_frac=0.5, secondary=0.25, max_clip=60) -> PacbioSam:
+    """Synthetic stand-in for BLASR's SAM output on ``walk`` (parity at the BLASR boundary
+    is pinned by fixing the SAM text).  Every read is cut from the path string (either strand),
+    mutated with substitutions / insertions / deletions, optionally padded with unaligned ends
+    (reported through the XS/XE/XQ tags like BLASR's soft clips); the CIGAR is the true edit
+    script.  Coordinates follow the reference's reading of the file (ParseAligment
+    graph.cc:2945-3021: POS is used as a 0-based offset, column 9 is the reference span, reverse
+    strand records are mirrored into the second half of path + separator + reverse complement).
+    A fraction of reads gets a second, wrong-place record (low probability) as BLASR's extra
+    candidates would."""
+    rng = np.random.default_rng(seed + 11)
+    seq = walk_string(g, walk)
+    both = seq + "\n" + revcomp_str(seq)
+    total_len = len(both)
+    S = len(seq)
+    acgt = "ACGT"
+    reads, names, lines = [], [], ["@HD\tVN:1.0"]
+
+    def mutate(tpl: str):
+        out, ops = [], []
+        for ch in tpl:
+            while rng.random() < ins:
+                out.append(acgt[int(rng.integers(4))]); ops.append("I")
+            u = rng.random()
+            if u < dele:
+                ops.append("D")
+            else:
+                out.append(acgt[int(rng.integers(4))] if u < dele + sub else ch); ops.append("M")
+        # a local alignment starts and ends with a matched column
+        shift = 0  # path bases dropped in front
+        while ops and ops[0] != "M":
+            if ops[0] == "I":
+                out.pop(0)
+            else:
+                shift += 1
+            ops.pop(0)
+        while ops and ops[-1] != "M":
+            if ops[-1] == "I":
+                out.pop()
+            ops.pop()
+        return "".join(out), ops, shift
+
+    def rle(ops):
+        res, i = [], 0
+        while i < len(ops):
+            j = i
+            while j < len(ops) and ops[j] == ops[i]:
+                j += 1
+            res.append(f"{j - i}{ops[i]}"); i = j
+        return res
+
+    def emit(rid, name, read, clip_l, clip_r, ops, start_in_both):
+        """One SAM line for `read` whose aligned part (read[clip_l:len-clip_r]) follows `ops` from
+        both[start_in_both]."""
+        span = sum(1 for o in ops if o != "I")
+        aligned_len = len(read) - clip_l - clip_r
+        if start_in_both <= S:  # forward half
+            flag, pos, cig = 0, start_in_both, rle(ops)
+        else:                   # mirrored: posstart' = total_len - posend
+            flag, pos, cig = 16, total_len - start_in_both - span, list(reversed(rle(ops)))
+        tags = [f"NM:i:{sum(1 for o in ops if o != 'M')}"]
+        if clip_l or clip_r:
+            tags += [f"XS:i:{clip_l + 1}", f"XE:i:{clip_l + aligned_len + 1}", f"XQ:i:{len(read)}"]
+        seq_col = "A" * (aligned_len if (clip_l or clip_r) else len(read))  # only its length is read
+        lines.append("\t".join([f"{name}/0_{len(read)}", str(flag), "path", str(pos), "254", "".join(cig), "*", "0",
+                                 str(span), seq_col, "*"] + tags))
+
+    n_rec = 0
+    for rid in range(n_reads):
+        L = int(min(read_len, S - 50))
+        L = max(20, int(L * rng.uniform(0.6, 1.0)))
+        rev = rng.random() < rev_frac
+        t0 = int(rng.integers(0, S - L))
+        start = t0 + (S + 1 if rev else 0)
+        core, ops, lead_trim = mutate(both[start:start + L])
+        clip_l = int(rng.integers(1, max_clip)) if rng.random() < clip_frac else 0
+        clip_r = int(rng.integers(1, max_clip)) if rng.random() < clip_frac else 0
+        read = "".join(acgt[int(x)] for x in rng.integers(0, 4, clip_l)) + core + "".join(acgt[int(x)] for x in rng.integers(0, 4, clip_r))
+        name = f"r{rid}"
+        reads.append(read); names.append(name)
+        emit(rid, name, read, clip_l, clip_r, ops, start + lead_trim)
+        n_rec += 1
+        if rng.random() < secondary:
+            # a wrong-place candidate with the same edit script shape (low probability)
+            span = sum(1 for o in ops if o != "I")
+            t1 = int(rng.integers(0, S - span - 1))
+            emit(rid, name, read, clip_l, clip_r, ops, t1 + (S + 1 if rng.random() < 0.5 else 0))
+            n_rec += 1
+    return PacbioSam(reads, names, "\n".join(lines) + "\n", n_rec)
+
+
 def all_subwalks_for_pacbio(g: Graph, walk: list[int], max_read_len: int) -> list[list[int]]:
     """Every sub-walk the PacBio scorer looks up for ``walk`` (reference graph.cc:2438-2454)."""
     node_len = [g.node_len(x) if x >= 0 else -x for x in walk]

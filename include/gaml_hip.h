@@ -115,6 +115,45 @@ int gaml_hip_put_window_records(gaml_hip_ctx* ctx, int readset, int mate, const 
 int gaml_hip_put_pacbio_records(gaml_hip_ctx* ctx, int readset, const int32_t* subpath, int32_t subpath_len,
                                 const gaml_pacbio_aligment* recs, int64_t n);
 
+/* ---- PacBio cache-miss side: BLASR's SAM output -> cached alignment records -------------------
+ * The reference, on a path with an uncached sub-walk, writes the path to a file, runs BLASR and
+ * turns every SAM line into a cached record (PacbioReadSet::GetReadProbabilitiesSlow
+ * graph.cc:2650-2795): ParseAligment (:2945-3021), the banded sum-over-alignments probability
+ * AligmentProbability (:2175-2297, on the GPU here) and the filing rule (:2760-2782).  Running
+ * BLASR stays with the caller; these three entry points are the rest.
+ *
+ * gaml_hip_add_pacbio_reads: like gaml_hip_add_pacbio but keeps the read bases (read_seq_,
+ *   PacbioReadSet::PreprocessReads graph.cc:1416-1439) and the read names (GetReadId graph.h:410-420);
+ *   `names` = n names, each followed by '\n'.  Reads may not hold '\n' or '-'.
+ * gaml_hip_pacbio_missing: the index ranges [begin, end] of `path` the reference would hand to
+ *   BLASR (merged ranges of uncached sub-walks, GetReadProbabilities graph.cc:2438-2478); writes
+ *   up to `cap` pairs to ranges_out and returns the number of ranges.
+ * gaml_hip_pacbio_ingest_sam: `path` is the sub-path that was aligned (as given to BLASR:
+ *   path string + separator + reverse complement), `sam` the SAM text ('@' lines are skipped).
+ *   Every sub-walk of the path that was not cached before gets a cache entry; a record is filed
+ *   under the sub-walk it spans exactly as the reference does.  Unknown read names and lines
+ *   with fewer than 10 columns are errors (the reference asserts / reads out of range). */
+int gaml_hip_add_pacbio_reads(gaml_hip_ctx* ctx, const gaml_single_cfg* cfg, int32_t n_reads, const char* bases,
+                              const int64_t* offsets, const char* names);
+int32_t gaml_hip_pacbio_missing(gaml_hip_ctx* ctx, int readset, const int32_t* path, int32_t path_len, int32_t* ranges_out,
+                                int32_t cap);
+int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* ctx, int readset, const int32_t* path, int32_t path_len, const char* sam,
+                               int64_t sam_len, int64_t* filed_out);
+/* cached records of one sub-walk (global read ids); -1 when the sub-walk is not cached */
+int64_t gaml_hip_pacbio_records(gaml_hip_ctx* ctx, int readset, const int32_t* subpath, int32_t subpath_len,
+                                gaml_pacbio_aligment* out, int64_t cap);
+/* last ingest: {SAM records, DP jobs, DP rows, DP cells, kernel ms, host prepare ms, upload+kernel+download ms, scratch bytes} */
+int gaml_hip_pacbio_dp_stats(gaml_hip_ctx* ctx, int readset, double* out8);
+/* host-only introspection (no device needed): how one SAM line is parsed
+ * ({flags,len,posstart,posend,sstart,send,slen,tstart,tend,edit_dist}) and which DP cells it gets
+ * (rows row0.., one column interval per row). Returns the number of rows, <0 on a malformed line. */
+/* the banded DP of one SAM line against an explicit target string ("path + '\n' + reverse
+ * complement") and read, on the GPU: what AligmentProbability (graph.cc:2175-2297) returns, as a log */
+int gaml_hip_debug_sam_logprob(gaml_hip_ctx* ctx, const char* target, int32_t target_len, const char* read, int32_t read_len,
+                               const char* sam_line, int64_t sam_len, double mismatch_prob, double* logprob_out);
+int32_t gaml_hip_debug_sam_band(const char* sam_line, int64_t len, int32_t total_len, int32_t* fields10, int32_t* row0,
+                                int32_t* lo, int32_t* hi, int32_t cap);
+
 /* ---- the hot path ------------------------------------------------------------------ */
 /* ProbCalculator::CalcProb(paths, zeros, total_len) (prob_calculator.h:63-109):
  * paths = flattened node ids (>= 0) / gaps (< 0), path_offs[n_paths+1].

@@ -797,8 +797,7 @@ void fill_rows(std::vector<std::pair<int, int>>& x) {
 }
 }  // namespace
 
-LogD LongReadSet::alignment_probability(const std::string& s1, const std::string& s2, const SamAlignment& a,
-                                        int band) const {
+std::vector<std::pair<int, int>> LongReadSet::dp_cells(const SamAlignment& a, int band) {
   std::string cig;  // ExpandCigar :2129-2136
   for (auto& c : a.cigar) cig.append((size_t)std::max(0, c.first), c.second);
   int bl = 0, el = 0;  // GetCigarEnds :2138-2151 (values left untouched if the cigar is all 'I')
@@ -820,6 +819,12 @@ LogD LongReadSet::alignment_probability(const std::string& s1, const std::string
     for (int i = -band; i <= band; i++) for (int j = -band; j <= band; j++) halo.push_back(std::make_pair(e.first + i, e.second + j));
   cells.insert(cells.end(), halo.begin(), halo.end());
   fill_rows(cells);
+  return cells;
+}
+
+LogD LongReadSet::alignment_probability(const std::string& s1, const std::string& s2, const SamAlignment& a,
+                                        int band) const {
+  std::vector<std::pair<int, int>> cells = dp_cells(a, band);
 
   int off = cells[0].first, nrows = cells.back().first - off + 1;  // :2223-2235
   std::vector<int> row_lo(nrows, cells.back().second + 1000000);
@@ -848,6 +853,54 @@ LogD LongReadSet::alignment_probability(const std::string& s1, const std::string
     if (c == (int)s2.size()) ret = ld_add(ret, cur);
   }
   return ret;
+}
+
+int LongReadSet::ingest_sam(const Graph& g, const std::vector<int>& path, const std::vector<std::string>& sam_lines) {
+  // path string and node boundaries (graph.cc:2662-2688)
+  std::string seq;
+  std::vector<int> ends, begins;
+  if (path[0] >= 0) seq = g.seq[path[0]]; else seq.assign((size_t)-path[0], 'N');
+  ends.push_back((int)seq.size());
+  begins.push_back(0);
+  for (size_t i = 1; i < path.size(); i++) {
+    begins.push_back((int)seq.size());
+    if (path[i] < 0) seq.append((size_t)-path[i], 'N'); else seq += g.seq[path[i]];
+    ends.push_back((int)seq.size());
+  }
+  const std::string seqall = seq + '\n' + revcomp(seq);  // kContigSeparator graph.cc:30, 2687-2688
+  // sub-walks this call may file under (graph.cc:2724-2743)
+  std::unordered_map<std::vector<int>, int, WalkHash> starts;
+  std::unordered_set<std::vector<int>, WalkHash> dont_save;
+  for (size_t i = 0; i < path.size(); i++) {
+    std::vector<int> sub;
+    for (size_t j = i; j < path.size(); j++) {
+      sub.push_back(path[j]);
+      int sub_len = ends[j] - begins[i], first_len = ends[i] - begins[i];
+      if (cache.count(sub)) dont_save.insert(sub); else cache[sub].clear();
+      starts[sub] = (int)i;
+      if (sub_len - first_len > max_len) break;
+    }
+  }
+  int filed = 0;
+  for (const std::string& l : sam_lines) {  // graph.cc:2746-2786
+    if (l.empty() || l[0] == '@') continue;
+    SamAlignment a = parse_sam_line(l, (int)seqall.size());
+    auto it = name_to_id.find(a.name);
+    if (it == name_to_id.end()) continue;  // the reference asserts (:2751)
+    const int read_id = it->second;
+    LogD prob = alignment_probability(seqall, reads[read_id], a, 2);
+    int it_begin = (int)(std::lower_bound(ends.begin(), ends.end(), std::max(0, a.tstart - 5)) - ends.begin());
+    int it_end = (int)(std::lower_bound(ends.begin(), ends.end(), std::min(a.tstart + a.len + 5, (int)seq.size())) - ends.begin());
+    if (it_begin >= (int)path.size() || it_end >= (int)path.size()) continue;  // asserted in the reference (:2767-2770)
+    std::vector<int> sub(path.begin() + it_begin, path.begin() + it_end + 1);
+    int pos_begin = it_begin > 0 ? ends[it_begin - 1] : 0;
+    auto st = starts.find(sub);
+    if (st != starts.end() && st->second == it_begin && dont_save.count(sub) == 0) {
+      cache[sub].push_back(LongRec{a.tstart - pos_begin, a.tend - pos_begin, read_id, prob});
+      filed++;
+    }
+  }
+  return filed;
 }
 
 // ---------------------------------------------------------------------------

@@ -229,6 +229,7 @@ struct LongReadSet {
   LogD match_p, mismatch_p;        // logdouble(match_prob), logdouble(mismatch_prob) graph.h:446-449
   std::vector<int> lens;
   std::vector<std::string> reads;  // read_seq_ (only the banded DP needs bases)
+  std::unordered_map<std::string, int> name_to_id;  // read_map_
   int max_len = 0;
   std::unordered_map<std::vector<int>, std::vector<LongRec>, WalkHash> cache;
   long cache_misses = 0;
@@ -248,6 +249,11 @@ struct LongReadSet {
   static std::vector<std::pair<int, char>> parse_cigar(const std::string& c);
   static SamAlignment parse_sam_line(const std::string& line, int total_len, bool do_reverse = true);
   LogD pair_match(char a, char b) const;  // MatchProbability graph.h:555-564
+  // GetReadProbabilitiesSlow (graph.cc:2650-2795) from the point where BLASR's SAM output exists:
+  // every SAM line -> banded alignment probability -> record filed under the sub-walk it spans.
+  // Returns the number of records filed.
+  int ingest_sam(const Graph& g, const std::vector<int>& path, const std::vector<std::string>& sam_lines);
+  static std::vector<std::pair<int, int>> dp_cells(const SamAlignment& a, int band = 2);  // cell list graph.cc:2183-2221
   LogD alignment_probability(const std::string& s1, const std::string& s2, const SamAlignment& a,
                              int band = 2) const;
 };

@@ -137,6 +137,57 @@ int orc_pacbio_put(void* p, int set, const int32_t* walk, int walk_len_, const i
   for (int i = 0; i < nrec; i++) dst.push_back(LongRec{rec3[3 * i], rec3[3 * i + 1], rec3[3 * i + 2], LogD::from_log(logp[i])});
   return (int)dst.size();
 }
+// PacBio set with read bases + names (needed for SAM ingestion)
+int orc_add_pacbio_reads(void* p, int n, const char* bases, const int64_t* offs, const char* names_nl, double mismatch, const double* cfg) {
+  Session* s = S(p);
+  s->longs.emplace_back(new LongReadSet());
+  LongReadSet* r = s->longs.back().get();
+  r->set_params(1.0 - 4 * mismatch, mismatch);
+  const char* nm = names_nl;
+  for (int i = 0; i < n; i++) {
+    r->reads.emplace_back(bases + offs[i], bases + offs[i + 1]);
+    r->lens.push_back((int)(offs[i + 1] - offs[i]));
+    const char* e = strchr(nm, '\n');
+    std::string name = e ? std::string(nm, e) : std::string(nm);
+    nm = e ? e + 1 : nm + name.size();
+    r->name_to_id[name] = i;
+  }
+  r->finalize();
+  SingleCfg c; c.penalty_constant = cfg[0]; c.step = cfg[1]; c.min_prob_per_base = cfg[2]; c.min_prob_start = cfg[3]; c.weight = cfg[4];
+  s->calc.pacbio.push_back(std::make_pair(c, r));
+  s->sets.push_back(std::make_pair(2, (int)s->calc.pacbio.size() - 1));
+  return (int)s->sets.size() - 1;
+}
+int orc_pacbio_ingest_sam(void* p, int set, const int32_t* path, int n, const char* sam_text) {
+  Session* s = S(p);
+  auto k = s->sets[set];
+  if (k.first != 2) return -1;
+  std::vector<std::string> lines;
+  const char* q = sam_text;
+  while (*q) { const char* e = strchr(q, '\n'); if (!e) { lines.emplace_back(q); break; } lines.emplace_back(q, e); q = e + 1; }
+  std::vector<int> w(path, path + n);
+  s->g.normalize_walk(w);  // CalcScoreForPacbio normalises before GetReadProbabilities (graph.cc:3180)
+  return s->calc.pacbio[k.second].second->ingest_sam(s->g, w, lines);
+}
+// dump the PacBio cache: for one sub-walk, (pos, pos_end, read) triples + log-probabilities; -1 if absent
+int orc_pacbio_records(void* p, int set, const int32_t* walk, int n, int32_t* rec3, double* logp, int cap) {
+  Session* s = S(p);
+  LongReadSet* r = s->calc.pacbio[s->sets[set].second].second;
+  auto it = r->cache.find(std::vector<int>(walk, walk + n));
+  if (it == r->cache.end()) return -1;
+  int cnt = (int)it->second.size();
+  for (int i = 0; i < cnt && i < cap; i++) { rec3[3 * i] = it->second[i].pos; rec3[3 * i + 1] = it->second[i].pos_end; rec3[3 * i + 2] = it->second[i].read; logp[i] = it->second[i].prob.lv; }
+  return cnt;
+}
+long orc_pacbio_keys(void* p, int set, int32_t* out, long cap) {
+  LongReadSet* r = S(p)->calc.pacbio[S(p)->sets[set].second].second;
+  long need = 0;
+  for (auto& e : r->cache) {
+    if (need + 1 + (long)e.first.size() <= cap) { out[need] = (int32_t)e.first.size(); for (size_t i = 0; i < e.first.size(); i++) out[need + 1 + i] = e.first[i]; }
+    need += 1 + (long)e.first.size();
+  }
+  return need;
+}
 long orc_pacbio_misses(void* p, int set) { return S(p)->calc.pacbio[S(p)->sets[set].second].second->cache_misses; }
 
 int orc_num_sets(void* p) { return (int)S(p)->sets.size(); }
@@ -307,6 +358,21 @@ double orc_sam_alignment_logprob(const char* sam_line, const char* target_all, c
   SamAlignment a = LongReadSet::parse_sam_line(sam_line, (int)t.size(), true);
   if (out_tstart_tend) { out_tstart_tend[0] = a.tstart; out_tstart_tend[1] = a.tend; }
   return r.alignment_probability(t, read, a, band).lv;
+}
+
+// parsed SAM fields {flags,len,posstart,posend,sstart,send,slen,tstart,tend,edit_dist} + the DP cell
+// set as one column interval per row; returns the number of rows (needed size when > cap)
+int orc_sam_band(const char* sam_line, int total_len, int32_t* fields10, int32_t* row0, int32_t* lo, int32_t* hi, int cap) {
+  SamAlignment a = LongReadSet::parse_sam_line(sam_line, total_len, true);
+  int32_t f[10] = {a.flags, a.len, a.posstart, a.posend, a.sstart, a.send, a.slen, a.tstart, a.tend, a.edit_dist};
+  memcpy(fields10, f, sizeof(f));
+  std::vector<std::pair<int, int>> cells = LongReadSet::dp_cells(a, 2);
+  int r0 = cells.front().first, n = cells.back().first - r0 + 1;
+  *row0 = r0;
+  if (n > cap) return n;
+  for (int i = 0; i < n; i++) { lo[i] = 1 << 30; hi[i] = -(1 << 30); }
+  for (auto& e : cells) { lo[e.first - r0] = std::min(lo[e.first - r0], e.second); hi[e.first - r0] = std::max(hi[e.first - r0], e.second); }
+  return n;
 }
 
 // ---- config-file driven set-up (gaml.cc main :935-1017 minus the optimiser) ------------

@@ -43,6 +43,11 @@ def _load():
     L.orc_add_paired.argtypes = [C.c_void_p, C.c_int, _u8p, _i64p, _u8p, _i64p, C.c_double, _f64p]
     L.orc_add_pacbio.argtypes = [C.c_void_p, C.c_int, _i32p, C.c_double, _f64p]
     L.orc_pacbio_put.argtypes = [C.c_void_p, C.c_int, _i32p, C.c_int, _i32p, _f64p, C.c_int]
+    L.orc_add_pacbio_reads.argtypes = [C.c_void_p, C.c_int, _u8p, _i64p, C.c_char_p, C.c_double, _f64p]
+    L.orc_pacbio_ingest_sam.argtypes = [C.c_void_p, C.c_int, _i32p, C.c_int, C.c_char_p]
+    L.orc_pacbio_records.argtypes = [C.c_void_p, C.c_int, _i32p, C.c_int, _i32p, _f64p, C.c_int]
+    L.orc_pacbio_keys.argtypes = [C.c_void_p, C.c_int, _i32p, C.c_long]
+    L.orc_pacbio_keys.restype = C.c_long
     L.orc_pacbio_misses.argtypes = [C.c_void_p, C.c_int]
     L.orc_pacbio_misses.restype = C.c_long
     L.orc_num_sets.argtypes = [C.c_void_p]
@@ -79,6 +84,7 @@ def _load():
     L.orc_invert_walk.argtypes = [_i32p, C.c_int, _i32p]
     L.orc_sam_alignment_logprob.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_int, _i32p]
     L.orc_sam_alignment_logprob.restype = C.c_double
+    L.orc_sam_band.argtypes = [C.c_char_p, C.c_int, _i32p, _i32p, _i32p, _i32p, C.c_int]
     L.orc_load_config.argtypes = [C.c_void_p, C.c_char_p]
     L.orc_config_order.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.orc_config_paired_values.argtypes = [C.c_char_p, C.c_char_p, _f64p]
@@ -194,6 +200,31 @@ class Oracle:
         return self.L.orc_pacbio_put(self.h, rs, walk, len(walk), rec3.reshape(-1) if rec3.size else np.zeros(3, np.int32),
                                      logp if logp.size else np.zeros(1), len(logp))
 
+    def add_pacbio_reads(self, bases, offs, names, mismatch, cfg):
+        return self.L.orc_add_pacbio_reads(self.h, len(offs) - 1, bases, offs, ("\n".join(names) + "\n").encode(), mismatch, cfg)
+
+    def pacbio_ingest_sam(self, rs, path, sam_text: str):
+        path = np.ascontiguousarray(path, np.int32)
+        return self.L.orc_pacbio_ingest_sam(self.h, rs, path, len(path), sam_text.encode())
+
+    def pacbio_keys(self, rs):
+        need = self.L.orc_pacbio_keys(self.h, rs, np.zeros(1, np.int32), 0)
+        buf = np.zeros(max(1, need), np.int32)
+        self.L.orc_pacbio_keys(self.h, rs, buf, need)
+        keys, i = [], 0
+        while i < need:
+            n = int(buf[i]); keys.append(tuple(int(x) for x in buf[i + 1:i + 1 + n])); i += 1 + n
+        return keys
+
+    def pacbio_records(self, rs, walk):
+        walk = np.ascontiguousarray(walk, np.int32)
+        n = self.L.orc_pacbio_records(self.h, rs, walk, len(walk), np.zeros(3, np.int32), np.zeros(1), 0)
+        if n < 0:
+            return None
+        rec = np.zeros(3 * max(1, n), np.int32); lp = np.zeros(max(1, n))
+        self.L.orc_pacbio_records(self.h, rs, walk, len(walk), rec, lp, n)
+        return rec.reshape(-1, 3)[:n], lp[:n]
+
     def pacbio_misses(self, rs):
         return self.L.orc_pacbio_misses(self.h, rs)
 
@@ -298,3 +329,17 @@ def window_hashes(seq: str, read_len: int):
     p = np.zeros(cap, np.int32)
     n = lib().orc_window_hashes(seq.encode(), read_len, h, p, cap)
     return [(int(h[i]), int(p[i])) for i in range(n)]
+
+
+def sam_band(sam_line: str, total_len: int):
+    """(fields dict, row0, lo[], hi[]) of one SAM line as the oracle parses / bands it."""
+    f = np.zeros(10, np.int32); r0 = np.zeros(1, np.int32)
+    n = lib().orc_sam_band(sam_line.encode(), total_len, f, r0, np.zeros(1, np.int32), np.zeros(1, np.int32), 0)
+    lo = np.zeros(n, np.int32); hi = np.zeros(n, np.int32)
+    lib().orc_sam_band(sam_line.encode(), total_len, f, r0, lo, hi, n)
+    keys = ["flags", "len", "posstart", "posend", "sstart", "send", "slen", "tstart", "tend", "edit_dist"]
+    return dict(zip(keys, (int(x) for x in f))), int(r0[0]), lo, hi
+
+
+def sam_alignment_logprob(sam_line: str, target_all: str, read: str, mismatch: float, band: int = 2):
+    return float(lib().orc_sam_alignment_logprob(sam_line.encode(), target_all.encode(), read.encode(), mismatch, band, np.zeros(2, np.int32)))
