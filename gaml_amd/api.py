@@ -7,7 +7,9 @@ raises GamlHipError(ENODEVICE).
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -56,7 +58,33 @@ class GamlHipError(RuntimeError):
         self.code = code
 
 
+def _bind_to_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64 / libhsa-runtime64;
+    libgaml_hip.so links the system ones.  Loaded after torch, the dynamic linker resolves our
+    dependency to torch's copy (same SONAME) and all is well; loaded BEFORE torch, the process ends
+    up with two runtimes and the second one to initialise finds no device.  So when PyTorch is
+    installed, load its runtime first (without importing torch) and let ours bind to it.
+    GAML_HIP_SYSTEM_RUNTIME=1 skips this."""
+    if os.environ.get("GAML_HIP_SYSTEM_RUNTIME") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def _load():
+    _bind_to_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no fallback implementation)")
