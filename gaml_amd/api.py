@@ -115,7 +115,8 @@ def _load():
     L.gaml_hip_pacbio_records.argtypes = [vp, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
     L.gaml_hip_pacbio_records.restype = C.c_int64
     L.gaml_hip_pacbio_dp_stats.argtypes = [vp, C.c_int, _f64p]
-    L.gaml_hip_debug_sam_logprob.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int64, C.c_double, C.POINTER(C.c_double)]
+    L.gaml_hip_debug_sam_logprob.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int64, C.c_double, C.POINTER(C.c_double), vp, vp, C.c_int32]
+    L.gaml_hip_debug_sam_shape.argtypes = [C.c_char_p, C.c_int64, C.c_int32, _i32p, C.c_void_p, C.c_int32]
     L.gaml_hip_debug_sam_band.argtypes = [C.c_char_p, C.c_int64, C.c_int32, _i32p, _i32p, _i32p, _i32p, C.c_int32]
     L.gaml_hip_debug_sam_band.restype = C.c_int32
     L.gaml_hip_calc_prob.argtypes = [vp, _i32p, _i64p, C.c_int32, C.POINTER(C.c_double), _i32p, C.POINTER(C.c_int32)]
@@ -269,11 +270,16 @@ class Context:
         _lib.gaml_hip_pacbio_records(self._h, rs, walk, len(walk), recs.ctypes.data, n)
         return recs[:n]
 
-    def debug_sam_logprob(self, target: str, read: str, sam_line: str, mismatch: float) -> float:
+    def debug_sam_logprob(self, target: str, read: str, sam_line: str, mismatch: float, with_band=False):
         t, r, l = target.encode(), read.encode(), sam_line.encode()
         out = C.c_double(0)
-        self._check(_lib.gaml_hip_debug_sam_logprob(self._h, t, len(t), r, len(r), l, len(l), mismatch, C.byref(out)))
-        return out.value
+        n = self._check(_lib.gaml_hip_debug_sam_logprob(self._h, t, len(t), r, len(r), l, len(l), mismatch, C.byref(out), None, None, 0))
+        if not with_band:
+            return out.value
+        lo = np.zeros(n, np.int32); hi = np.zeros(n, np.int32)
+        self._check(_lib.gaml_hip_debug_sam_logprob(self._h, t, len(t), r, len(r), l, len(l), mismatch, C.byref(out), lo.ctypes.data,
+                                                    hi.ctypes.data, n))
+        return out.value, lo, hi
 
     def pacbio_dp_stats(self, rs):
         out = np.zeros(8)
@@ -466,8 +472,21 @@ def debug_sam_band(sam_line: str, total_len: int):
     f = np.zeros(10, np.int32); r0 = np.zeros(1, np.int32)
     n = _lib.gaml_hip_debug_sam_band(raw, len(raw), total_len, f, r0, np.zeros(1, np.int32), np.zeros(1, np.int32), 0)
     if n < 0:
-        raise GamlHipError(f"malformed SAM line ({n})")
+        raise GamlHipError(n, "malformed SAM line")
     lo = np.zeros(n, np.int32); hi = np.zeros(n, np.int32)
     _lib.gaml_hip_debug_sam_band(raw, len(raw), total_len, f, r0, lo, hi, n)
     keys = ["flags", "len", "posstart", "posend", "sstart", "send", "slen", "tstart", "tend", "edit_dist"]
     return dict(zip(keys, (int(x) for x in f))), int(r0[0]), lo, hi
+
+
+def debug_sam_shape(sam_line: str, total_len: int):
+    """Host-only: the per-alignment inputs of the DP kernel (shape dict, run-length CIGAR as (len, code) pairs)."""
+    raw = sam_line.encode()
+    f = np.zeros(6, np.int32)
+    n = _lib.gaml_hip_debug_sam_shape(raw, len(raw), total_len, f, None, 0)
+    if n < 0:
+        raise GamlHipError(n, "malformed SAM line")
+    ops = np.zeros(max(1, n), np.uint32)
+    _lib.gaml_hip_debug_sam_shape(raw, len(raw), total_len, f, ops.ctypes.data, n)
+    keys = ["n_ops", "row_f", "col_f", "bl", "el", "max_width"]
+    return dict(zip(keys, (int(x) for x in f))), [(int(o) >> 2, "MID"[int(o) & 3]) for o in ops[:n]]

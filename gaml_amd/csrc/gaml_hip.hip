@@ -148,8 +148,8 @@ struct SingleSet {
 };
 
 struct DpDev {  // device buffers of the PacBio banded DP
-  DevBuf path, jobs, lo, hi, scratch, out;
-  void release() { path.release(); jobs.release(); lo.release(); hi.release(); scratch.release(); out.release(); }
+  DevBuf path, jobs, ops, scratch, out, dbg;
+  void release() { path.release(); jobs.release(); ops.release(); scratch.release(); out.release(); dbg.release(); }
 };
 
 struct PacbioSet {
@@ -1521,42 +1521,49 @@ void pacbio_path_string(const gaml_hip_ctx* c, const Walk& path, std::string* se
 }
 // upload one batch of DP jobs, run the banded DP kernel, fetch the log probabilities
 int run_pacbio_dp(gaml_hip_ctx* c, DpDev& d, const std::string& both, const unsigned char* d_reads, const std::vector<DpJob>& jobs,
-                  const std::vector<int32_t>& lo, const std::vector<int32_t>& hi, int64_t scratch, double log_match, double log_mismatch,
-                  double* logp, float* kernel_ms) {
+                  const std::vector<uint32_t>& ops, int64_t scratch, double log_match, double log_mismatch, double* logp,
+                  float* kernel_ms, int64_t* cells_out, int32_t* dbg_lo = nullptr, int32_t* dbg_hi = nullptr, int32_t dbg_rows = 0) {
   hipStream_t st = c->stream;
+  const size_t nj = jobs.size();
   HIP_TRY(c, d.path.reserve(both.size()));
-  HIP_TRY(c, d.jobs.reserve(jobs.size() * sizeof(DpJob)));
-  HIP_TRY(c, d.lo.reserve(lo.size() * sizeof(int32_t)));
-  HIP_TRY(c, d.hi.reserve(hi.size() * sizeof(int32_t)));
+  HIP_TRY(c, d.jobs.reserve(nj * sizeof(DpJob)));
+  HIP_TRY(c, d.ops.reserve(std::max<size_t>(1, ops.size()) * sizeof(uint32_t)));
   HIP_TRY(c, d.scratch.reserve(std::max<size_t>(1, (size_t)scratch) * sizeof(double)));
-  HIP_TRY(c, d.out.reserve(jobs.size() * sizeof(double)));
+  HIP_TRY(c, d.out.reserve(nj * (sizeof(double) + sizeof(long long))));
   HIP_TRY(c, hipMemcpy(d.path.p, both.data(), both.size(), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(d.jobs.p, jobs.data(), jobs.size() * sizeof(DpJob), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(d.lo.p, lo.data(), lo.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(d.hi.p, hi.data(), hi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(d.jobs.p, jobs.data(), nj * sizeof(DpJob), hipMemcpyHostToDevice));
+  if (!ops.empty()) HIP_TRY(c, hipMemcpy(d.ops.p, ops.data(), ops.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (dbg_rows > 0) HIP_TRY(c, d.dbg.reserve(2 * (size_t)dbg_rows * sizeof(int32_t)));
   DpArgs a;
   a.path = d.path.as<unsigned char>(); a.path_len = (int32_t)both.size();
   a.reads = d_reads;
-  a.jobs = d.jobs.as<DpJob>(); a.lo = d.lo.as<int32_t>(); a.hi = d.hi.as<int32_t>();
-  a.scratch = d.scratch.as<double>(); a.out = d.out.as<double>();
-  a.n_jobs = (int32_t)jobs.size();
+  a.jobs = d.jobs.as<DpJob>(); a.ops = d.ops.as<uint32_t>();
+  a.scratch = d.scratch.as<double>(); a.out = d.out.as<double>(); a.cells = (long long*)(d.out.as<double>() + nj);
+  a.dbg_lo = dbg_rows > 0 ? d.dbg.as<int32_t>() : nullptr;
+  a.dbg_hi = dbg_rows > 0 ? d.dbg.as<int32_t>() + dbg_rows : nullptr;
+  a.n_jobs = (int32_t)nj;
   a.log_match = log_match; a.log_mismatch = log_mismatch;
   hipEvent_t ev0, ev1;
   HIP_TRY(c, hipEventCreate(&ev0));
   HIP_TRY(c, hipEventCreate(&ev1));
   HIP_TRY(c, hipEventRecord(ev0, st));
-  const int lanes = c->knobs[8] == 16 ? 16 : 8;
-  const int64_t threads = (int64_t)jobs.size() * lanes;
-  const unsigned grid = (unsigned)((threads + 255) / 256);
-  if (lanes == 16) hipLaunchKernelGGL(pacbio_dp_kernel<16>, dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(pacbio_dp_kernel<8>, dim3(grid), dim3(256), 0, st, a);
+  constexpr int kLanes = 16;  // lanes per alignment: 14 columns per chunk cover a typical row in one step
+  const unsigned grid = (unsigned)(((int64_t)nj * kLanes + 255) / 256);
+  hipLaunchKernelGGL(pacbio_dp_kernel<kLanes>, dim3(grid), dim3(256), 0, st, a);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(ev1, st));
-  HIP_TRY(c, hipMemcpyAsync(logp, d.out.p, jobs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  std::vector<long long> cells(nj);
+  HIP_TRY(c, hipMemcpyAsync(logp, d.out.p, nj * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(cells.data(), a.cells, nj * sizeof(long long), hipMemcpyDeviceToHost, st));
+  if (dbg_rows > 0) {
+    HIP_TRY(c, hipMemcpyAsync(dbg_lo, a.dbg_lo, dbg_rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(dbg_hi, a.dbg_hi, dbg_rows * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(c, hipStreamSynchronize(st));
   HIP_TRY(c, hipEventElapsedTime(kernel_ms, ev0, ev1));
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
+  if (cells_out) { *cells_out = 0; for (long long v : cells) *cells_out += v; }
   return GAML_HIP_OK;
 }
 }  // namespace
@@ -1646,10 +1653,9 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path
   struct Filed { int32_t walk, pos, pos_end, read_local; };
   std::vector<Filed> filed;
   std::vector<DpJob> jobs;
-  std::vector<int32_t> lo, hi;
-  int64_t scratch = 0, records = 0, cells = 0;
+  std::vector<uint32_t> ops;
+  int64_t scratch = 0, records = 0, cells = 0, rows = 0;
   SamRecord rec;
-  DpBand band;
   for (const char* p = sam, *end = sam + sam_len; p < end;) {
     const char* e = (const char*)memchr(p, '\n', (size_t)(end - p));
     const char* le = e ? e : end;
@@ -1668,21 +1674,18 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path
           const int32_t local = (int32_t)(id->second - s.lo);
           const int32_t pos_begin = ib > 0 ? ends[ib - 1] : 0;
           filed.push_back(Filed{fr->second, rec.tstart - pos_begin, rec.tend - pos_begin, local});
-          pacbio_dp_band(rec.cigar, band);
+          DpShape shape;
           DpJob j;
+          j.ops_off = (int64_t)ops.size();
+          pacbio_dp_ops(rec.cigar, ops, shape);
           j.read_off = s.base_off[local];
           j.read_len = (int32_t)(s.base_off[local + 1] - s.base_off[local]);
-          j.band_off = (int64_t)lo.size();
           j.scratch_off = scratch;
           j.posstart = rec.posstart;
-          j.row0 = band.row0;
-          j.n_rows = (int32_t)band.lo.size();
-          j.max_width = band.max_width;
-          j.pad = 0;
-          scratch += 2 * (int64_t)band.max_width;
-          lo.insert(lo.end(), band.lo.begin(), band.lo.end());
-          hi.insert(hi.end(), band.hi.begin(), band.hi.end());
-          for (size_t r = 0; r < band.lo.size(); r++) cells += band.hi[r] - band.lo[r] + 1;
+          j.n_ops = shape.n_ops; j.row_f = shape.row_f; j.col_f = shape.col_f; j.bl = shape.bl; j.el = shape.el;
+          j.max_width = shape.max_width;
+          scratch += 2 * (int64_t)shape.max_width;
+          rows += shape.row_f + std::max(shape.el, 1) + 4 + shape.bl;
           jobs.push_back(j);
         }
       }
@@ -1700,7 +1703,7 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path
       HIP_TRY(c, hipMemcpy(s.d_bases.p, s.bases.data(), s.bases.size(), hipMemcpyHostToDevice));
       s.bases_uploaded = true;
     }
-    if (int e = run_pacbio_dp(c, s.dp, both, s.d_bases.as<unsigned char>(), jobs, lo, hi, scratch, s.log_match, s.log_mismatch, logp.data(), &kernel_ms))
+    if (int e = run_pacbio_dp(c, s.dp, both, s.d_bases.as<unsigned char>(), jobs, ops, scratch, s.log_match, s.log_mismatch, logp.data(), &kernel_ms, &cells))
       return e;
   }
   for (size_t i = 0; i < filed.size(); i++) {
@@ -1710,7 +1713,7 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path
   }
   s.generation++;
   if (filed_out) *filed_out = (int64_t)filed.size();
-  s.dp_stats[0] = (double)records; s.dp_stats[1] = (double)jobs.size(); s.dp_stats[2] = (double)lo.size();
+  s.dp_stats[0] = (double)records; s.dp_stats[1] = (double)jobs.size(); s.dp_stats[2] = (double)rows;
   s.dp_stats[3] = (double)cells; s.dp_stats[4] = kernel_ms; s.dp_stats[5] = (t1 - t0) * 1e-3; s.dp_stats[6] = (now_us() - t1) * 1e-3;
   s.dp_stats[7] = (double)scratch * 8;
   return GAML_HIP_OK;
@@ -1732,27 +1735,48 @@ int32_t gaml_hip_debug_sam_band(const char* sam_line, int64_t len, int32_t total
 }
 
 int gaml_hip_debug_sam_logprob(gaml_hip_ctx* c, const char* target, int32_t target_len, const char* read, int32_t read_len,
-                               const char* sam_line, int64_t sam_len, double mismatch_prob, double* logprob_out) {
-  if (!c || !target || target_len <= 0 || !read || read_len < 0 || !sam_line || !logprob_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
-  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "no device");
+                               const char* sam_line, int64_t sam_len, double mismatch_prob, double* logprob_out, int32_t* band_lo,
+                               int32_t* band_hi, int32_t band_cap) {
+  if (!c || !target || target_len <= 0 || !read || read_len < 0 || !sam_line || !logprob_out || band_cap < 0)
+    return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "the alignment DP needs a HIP device: this context is host-only");
   SamRecord rec;
   if (!parse_sam_record(sam_line, sam_line + sam_len, target_len, rec)) return fail(c, GAML_HIP_EINVAL, "SAM line with fewer than 10 columns");
-  DpBand band;
-  pacbio_dp_band(rec.cigar, band);
+  std::vector<uint32_t> ops;
+  DpShape shape;
+  pacbio_dp_ops(rec.cigar, ops, shape);
   DpJob j;
-  j.read_off = 0; j.read_len = read_len; j.band_off = 0; j.scratch_off = 0; j.posstart = rec.posstart; j.row0 = band.row0;
-  j.n_rows = (int32_t)band.lo.size(); j.max_width = band.max_width; j.pad = 0;
+  j.read_off = 0; j.ops_off = 0; j.scratch_off = 0; j.read_len = read_len; j.posstart = rec.posstart;
+  j.n_ops = shape.n_ops; j.row_f = shape.row_f; j.col_f = shape.col_f; j.bl = shape.bl; j.el = shape.el; j.max_width = shape.max_width;
+  const int32_t r_first = shape.bl > 0 ? -shape.bl : 0;
+  const int32_t r_last = std::max(std::max(shape.row_f, shape.row_f + shape.el - 1), shape.bl > 0 ? 2 : 0);
+  const int32_t n_rows = r_last - r_first + 5;
+  const bool want_band = band_lo && band_hi && band_cap >= n_rows;
   DpDev dev;
   DevBuf d_read;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, d_read.reserve(std::max(1, read_len)));
   HIP_TRY(c, hipMemcpy(d_read.p, read, read_len, hipMemcpyHostToDevice));
   float ms = 0;
-  int e = run_pacbio_dp(c, dev, std::string(target, target + target_len), d_read.as<unsigned char>(), std::vector<DpJob>(1, j), band.lo, band.hi,
-                        2 * (int64_t)band.max_width, std::log(1.0 - 4 * mismatch_prob), std::log(mismatch_prob), logprob_out, &ms);
+  int e = run_pacbio_dp(c, dev, std::string(target, target + target_len), d_read.as<unsigned char>(), std::vector<DpJob>(1, j), ops,
+                        2 * (int64_t)shape.max_width, std::log(1.0 - 4 * mismatch_prob), std::log(mismatch_prob), logprob_out, &ms, nullptr,
+                        band_lo, band_hi, want_band ? n_rows : 0);
   dev.release();
   d_read.release();
-  return e;
+  return e ? e : n_rows;
+}
+
+int gaml_hip_debug_sam_shape(const char* sam_line, int64_t len, int32_t total_len, int32_t* out6, uint32_t* ops, int32_t cap) {
+  if (!sam_line || !out6) return GAML_HIP_EINVAL;
+  SamRecord a;
+  if (!parse_sam_record(sam_line, sam_line + len, total_len, a)) return GAML_HIP_EINVAL;
+  std::vector<uint32_t> v;
+  DpShape sh;
+  pacbio_dp_ops(a.cigar, v, sh);
+  const int32_t f[6] = {sh.n_ops, sh.row_f, sh.col_f, sh.bl, sh.el, sh.max_width};
+  memcpy(out6, f, sizeof(f));
+  if (ops && cap >= sh.n_ops) memcpy(ops, v.data(), v.size() * sizeof(uint32_t));
+  return sh.n_ops;
 }
 
 int gaml_hip_pacbio_dp_stats(gaml_hip_ctx* c, int readset, double* out8) {

@@ -1112,4 +1112,41 @@ void pacbio_dp_band(const std::vector<std::pair<int32_t, char>>& cigar, DpBand& 
   }
 }
 
+void pacbio_dp_ops(const std::vector<std::pair<int32_t, char>>& cigar, std::vector<uint32_t>& ops, DpShape& out) {
+  const size_t first = ops.size();
+  int64_t rows = 0, cols = 0, lead = 0, trail = 0;
+  bool seen_other = false;
+  int64_t top[5] = {0, 0, 0, 0, 0};  // the five longest insertion runs, descending
+  auto close_run = [&](int64_t run) {
+    for (int i = 0; i < 5; i++) if (run > top[i]) { for (int k = 4; k > i; k--) top[k] = top[k - 1]; top[i] = run; break; }
+  };
+  int64_t run = 0;
+  for (const auto& op : cigar) {
+    const int64_t n = std::max(0, op.first);
+    if (n == 0) continue;
+    if (op.second == 'I') {
+      if (ops.size() > first && (ops.back() & 3u) == 1u) ops.back() += (uint32_t)(n << 2);
+      else ops.push_back((uint32_t)(n << 2) | 1u);
+      cols += n; run += n; trail += n;
+      if (!seen_other) lead += n;
+    } else {
+      if (run) { close_run(run); run = 0; }
+      seen_other = true;
+      trail = 0;
+      ops.push_back((uint32_t)(n << 2) | (op.second == 'M' ? 0u : 2u));
+      rows += n;
+      if (op.second == 'M') cols += n;
+    }
+  }
+  if (run) close_run(run);
+  out.n_ops = (int32_t)(ops.size() - first);
+  out.row_f = (int32_t)rows;
+  out.col_f = (int32_t)cols;
+  out.bl = seen_other ? (int32_t)std::min<int64_t>(lead, 200) : 0;      // GetCigarEnds graph.cc:2138-2151, cap :2181-2182
+  out.el = seen_other ? (int32_t)std::min<int64_t>(trail + 1, 200) : 0;
+  // a widened row spans at most five consecutive path rows (4 steps + their insertion runs) or a clip box
+  const int64_t five = 5 + top[0] + top[1] + top[2] + top[3] + top[4];
+  out.max_width = (int32_t)std::min<int64_t>(INT32_MAX, std::max<int64_t>(std::max<int64_t>(out.bl, out.el + 1), five) + 6);
+}
+
 }  // namespace gaml

@@ -301,4 +301,13 @@ struct DpBand {
 };
 void pacbio_dp_band(const std::vector<std::pair<int32_t, char>>& cigar, DpBand& out);
 
+// What the DP kernel needs instead of the materialised band: the run-length CIGAR (appended to
+// `ops` as (length << 2) | code, code 0 = M, 1 = I, 2 = D; consecutive insertions merged, empty
+// operations dropped), the end of the CIGAR path, the clip boxes, and an upper bound of the row
+// width (the kernel derives the band itself).
+struct DpShape {
+  int32_t n_ops = 0, row_f = 0, col_f = 0, bl = 0, el = 0, max_width = 0;
+};
+void pacbio_dp_ops(const std::vector<std::pair<int32_t, char>>& cigar, std::vector<uint32_t>& ops, DpShape& out);
+
 }  // namespace gaml

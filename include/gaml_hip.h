@@ -142,15 +142,22 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* ctx, int readset, const int32_t* pa
 /* cached records of one sub-walk (global read ids); -1 when the sub-walk is not cached */
 int64_t gaml_hip_pacbio_records(gaml_hip_ctx* ctx, int readset, const int32_t* subpath, int32_t subpath_len,
                                 gaml_pacbio_aligment* out, int64_t cap);
-/* last ingest: {SAM records, DP jobs, DP rows, DP cells, kernel ms, host prepare ms, upload+kernel+download ms, scratch bytes} */
+/* last ingest: {SAM records, DP jobs, DP rows, DP cells, kernel ms (HIP events), host parse+prepare ms,
+ * upload+kernel+download ms, scratch bytes} */
 int gaml_hip_pacbio_dp_stats(gaml_hip_ctx* ctx, int readset, double* out8);
 /* host-only introspection (no device needed): how one SAM line is parsed
  * ({flags,len,posstart,posend,sstart,send,slen,tstart,tend,edit_dist}) and which DP cells it gets
  * (rows row0.., one column interval per row). Returns the number of rows, <0 on a malformed line. */
 /* the banded DP of one SAM line against an explicit target string ("path + '\n' + reverse
- * complement") and read, on the GPU: what AligmentProbability (graph.cc:2175-2297) returns, as a log */
+ * complement") and read, on the GPU: what AligmentProbability (graph.cc:2175-2297) returns, as a
+ * log.  Returns the number of DP rows (<0: error); when band_lo/band_hi hold at least that many
+ * entries they receive the column interval per row that the kernel derived from the CIGAR. */
 int gaml_hip_debug_sam_logprob(gaml_hip_ctx* ctx, const char* target, int32_t target_len, const char* read, int32_t read_len,
-                               const char* sam_line, int64_t sam_len, double mismatch_prob, double* logprob_out);
+                               const char* sam_line, int64_t sam_len, double mismatch_prob, double* logprob_out,
+                               int32_t* band_lo, int32_t* band_hi, int32_t band_cap);
+/* host-only: what the DP kernel is given for one SAM line: {n_ops, row_f, col_f, bl, el, max_width}
+ * and the run-length CIGAR ((length << 2) | code, 0 = M, 1 = I, 2 = D). Returns n_ops, <0 on a malformed line. */
+int gaml_hip_debug_sam_shape(const char* sam_line, int64_t len, int32_t total_len, int32_t* out6, uint32_t* ops, int32_t cap);
 int32_t gaml_hip_debug_sam_band(const char* sam_line, int64_t len, int32_t total_len, int32_t* fields10, int32_t* row0,
                                 int32_t* lo, int32_t* hi, int32_t cap);
 

@@ -124,19 +124,20 @@ QUIRKS = [
 ]
 
 
-@pytest.mark.parametrize("lanes", [8, 16])
-def test_dp_kernel_on_odd_records(lanes):
+def test_dp_kernel_on_odd_records():
     rng = np.random.default_rng(3)
     half = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 400))
     target = half + "\n" + synth.revcomp_str(half)
     ctx = api.Context()
-    ctx.debug_set_knob(8, lanes)
     for line in QUIRKS:
         f = line.split("\t")
         n = 700 if "XQ:i:700" in line else 250 if "XQ:i:250" in line else 255 if "250I" in line else len(f[9])
         read = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
         want = O.sam_alignment_logprob(line, target, read, MISMATCH)
-        got = ctx.debug_sam_logprob(target, read, line, MISMATCH)
+        got, lo, hi = ctx.debug_sam_logprob(target, read, line, MISMATCH, with_band=True)
+        # the band the kernel derives from the run-length CIGAR is the oracle's cell set
+        _, _, olo, ohi = O.sam_band(line, len(target))
+        assert np.array_equal(lo, olo) and np.array_equal(hi, ohi), line
         if np.isinf(want):
             assert got == want, line
         else:
@@ -148,7 +149,9 @@ def test_dp_kernel_on_odd_records(lanes):
     for line in ps.sam.split("\n")[1:-1]:
         read = rd[line.split("\t")[0].split("/")[0]]
         want = O.sam_alignment_logprob(line, target, read, MISMATCH)
-        got = ctx.debug_sam_logprob(target, read, line, MISMATCH)
+        got, lo, hi = ctx.debug_sam_logprob(target, read, line, MISMATCH, with_band=True)
+        _, _, olo, ohi = O.sam_band(line, len(target))
+        assert np.array_equal(lo, olo) and np.array_equal(hi, ohi), line
         assert abs(got - want) <= RTOL * abs(want), (line, got, want)
 
 

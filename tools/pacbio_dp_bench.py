@@ -1,5 +1,5 @@
 """Time the PacBio cache-miss side (SAM -> banded DP -> records): GPU through the C ABI vs the
-CPU oracle on a sample.  python tools/pacbio_dp_bench.py [n_reads] [read_len] [lanes]"""
+CPU oracle on a sample.  python tools/pacbio_dp_bench.py [n_reads] [read_len]"""
 import sys
 import time
 
@@ -11,7 +11,6 @@ from oracle import oracle_py as O  # noqa: E402
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 read_len = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 G = 1_000_000
 gen = synth.make_genome(G, 1)
 g = synth.make_graph(gen, synth.cut_lengths(G, 1))
@@ -24,7 +23,6 @@ rb = np.frombuffer("".join(ps.reads).encode(), np.uint8)
 ro = np.zeros(len(ps.reads) + 1, np.int64)
 ro[1:] = np.cumsum([len(r) for r in ps.reads])
 ctx = api.Context()
-ctx.debug_set_knob(8, lanes)
 ctx.set_graph(bases, offs)
 rs = ctx.add_pacbio_reads(api.single_cfg(min_prob_per_base=-1.0, mismatch_prob=0.15), rb, ro, ps.names)
 for rep in range(2):  # second round: fresh context state is not needed, re-ingest under a new set
