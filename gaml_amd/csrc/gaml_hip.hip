@@ -104,7 +104,7 @@ struct PairedSet {
   ShortMate mate[2];
   PairTables pt;                      // device order + compact / 16-byte record tables (cold path)
   MateDev dev[2];
-  DevBuf rec8[2], len_code, len_combo, inl[2], combo_tabs, lt, ltz;
+  DevBuf rec8[2], len_code, len_combo, inl[2], combo_tabs, memo;
   double lt_two_T = -1;   // 2T the memo table was last built for (-1: stale)
   int lt_codes = 0;
   // delta since the last full table build: pairs whose record lists gained records of newly
@@ -727,19 +727,19 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   a.len_combo = s.len_combo.as<uint32_t>();
   // memo of floor + log over the values a single-term pair can take; rebuilt only when 2T (or the
   // tables) changed. Floor must be positive for the "no alignment -> floored" shortcut.
-  a.lt = nullptr; a.ltz = nullptr; a.lt_codes = 0;
+  a.memo = nullptr; a.lt_codes = 0;
   if (c->knobs[4] == 0 && !s.pt.len_combo.empty() && s.ins_tab.size() > 0) {
     const int codes = (int)std::min<size_t>(s.pt.len_combo.size(), 4);
     const size_t entries = (size_t)codes * 49 * s.ins_tab.size();
     if (entries <= ((size_t)1 << 24)) {
       if (s.lt_two_T != a.two_T || s.lt_codes != codes) {
-        if (entries * 8 > s.lt.cap || entries > s.ltz.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.lt.reserve(entries * 8)); HIP_TRY(c, s.ltz.reserve(entries)); }
+        if (entries * sizeof(double2) > s.memo.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.memo.reserve(entries * sizeof(double2))); }
         hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
-                           a.pe[0], a.pe[1], a.ins_tab, a.ins_n, a.floor_c, a.logfloor_c, codes, a.two_T, s.lt.as<double>(), s.ltz.as<unsigned char>());
+                           a.pe[0], a.pe[1], a.ins_tab, a.ins_n, a.floor_c, a.logfloor_c, codes, a.two_T, s.memo.as<double2>());
         HIP_TRY(c, hipGetLastError());
         s.lt_two_T = a.two_T; s.lt_codes = codes;
       }
-      a.lt = s.lt.as<double>(); a.ltz = s.ltz.as<unsigned char>(); a.lt_codes = codes;
+      a.memo = s.memo.as<double2>(); a.lt_codes = codes;
     }
   }
   a.ovf_items = (const int*)(arena + ov_off);
@@ -1307,7 +1307,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
-      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->lt.release(); s->ltz.release(); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
+      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
       s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); drop_stage(s->stage);
     }

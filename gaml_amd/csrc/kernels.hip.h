@@ -54,8 +54,9 @@ struct PairedArgs {
   // only on (length code, edit 1, edit 2, insert distance) -- a few 10^4 combinations per evaluation.
   // logterm_kernel evaluates the reference's floor + log once per combination (same device log on
   // the same f64 value as the per-pair path), the compact path then looks the result up.
-  const double* lt;          // [((code*7 + e1)*7 + e2)*ins_n + dist] = floored ? log(floor) : log(term / 2T); null: off
-  const unsigned char* ltz;  // same index: 1 if floored
+  // memo[((code*7 + e1)*7 + e2)*ins_n + dist] = {pair term (sign bit set when the read is floored),
+  // floored ? log(floor) : log(term / 2T)}; null: off
+  const double2* memo;
   int lt_codes;              // codes covered (< lt_codes), edits < 7
   const int4* inl[2];        // inline records of the register classes: [2t + k] (class 1), [2 n1 + 4 t2 + k] (class 2)
   int n0;                    // first[] / extra[] / len12[] hold slots >= n0, indexed slot - n0
@@ -339,72 +340,96 @@ struct Compact1 {  // one class-0 pair in flight
   int L1, L2, lc;
 };
 
-// pair term of the compact path: same arithmetic as pair_term, the per-read error probability comes
-// from the per-length-combination product table
-__device__ __forceinline__ double pair_term_compact(const PairedArgs& a, const Cand& x, const Cand& y, int lc, int L1, int L2, int& dist) {
-  if (x.orient == y.orient) return 0.0;
-  if (x.pos < y.pos) {
-    if (x.orient != 0 || y.orient != 1) return 0.0;
-    dist = y.pos - x.pos + L2;
-  } else {
-    if (x.orient != 1 || y.orient != 0) return 0.0;
-    dist = x.pos - y.pos + L1;
-  }
-  const double p1 = a.pe[0][lc * 64 + x.edit];
-  const double p2 = a.pe[1][lc * 64 + y.edit];
-  const double ip = (unsigned)dist < (unsigned)a.ins_n ? a.ins_tab[dist] : 0.0;
-  const double t = p1 * p2 * ip;
-  if (a.cov_bits && t > a.covthr_c[lc]) {
-    int base = a.path_base[x.path];
-    mark_bit(a.cov_bits, base + max(x.pos, y.pos));
-    mark_bit(a.cov_bits, base + min(x.pos, y.pos));
-  }
-  return t;
-}
-
-// one thread per (length code, edit 1, edit 2, distance): GetTotalProb's per-read step
-// (graph.cc:1504-1513) for every value a single-term pair can take in this evaluation
+// one thread per (length code, edit 1, edit 2, distance): the pair term (graph.cc:1858-1882) and
+// GetTotalProb's per-read step (graph.cc:1504-1513) for every value a single-term pair can take in
+// this evaluation. Same operations in the same order as the per-pair path, so the looked-up values
+// are the per-pair values.
 __global__ __launch_bounds__(kBlock) void logterm_kernel(const double* pe0, const double* pe1, const double* ins_tab, int ins_n,
                                                         const double* floor_c, const double* logfloor_c, int codes, double two_T,
-                                                        double* lt, unsigned char* ltz) {
+                                                        double2* memo) {
   const int total = codes * 49 * ins_n;
   for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
     const int dist = idx % ins_n;
     const int q = idx / ins_n;
     const int e2 = q % 7, e1 = (q / 7) % 7, code = q / 49;
-    const double t = pe0[code * 64 + e1] * pe1[code * 64 + e2] * ins_tab[dist];  // as pair_term_compact
+    const double t = pe0[code * 64 + e1] * pe1[code * 64 + e2] * ins_tab[dist];  // as compact_term_tables
     const double p = t / two_T;
     const bool floored = p < floor_c[code];
-    lt[idx] = floored ? logfloor_c[code] : log(p);
-    ltz[idx] = floored ? 1 : 0;
+    memo[idx] = make_double2(floored ? -t : t, floored ? logfloor_c[code] : log(p));
   }
 }
 
-__device__ __forceinline__ void finish_read_compact(const PairedArgs& a, int i, double acc, int lc, int lt_idx, double& lsum, int& zeros) {
+__device__ __forceinline__ void finish_read_compact(const PairedArgs& a, int i, double acc, int lc, double& lsum, int& zeros) {
   a.probs[i] = acc;
-  if (lt_idx >= 0) { lsum += a.lt[lt_idx]; zeros += a.ltz[lt_idx]; return; }  // memoised floor/log of this exact value
-  if (acc == 0.0) { zeros++; lsum += a.logfloor_c[lc]; return; }              // 0 / 2T < floor (floor > 0)
+  if (acc == 0.0) { zeros++; lsum += a.logfloor_c[lc]; return; }  // 0 / 2T < floor (floor > 0)
   const double p = acc / a.two_T;
   if (p < a.floor_c[lc]) { zeros++; lsum += a.logfloor_c[lc]; }
   else lsum += log(p);
 }
 
-__device__ __forceinline__ double compact_score(const PairedArgs& a, const Compact1& c, bool& skip, int& lt_idx) {
-  lt_idx = -1;
+// Everything about a class-0 pair that needs no table: does it score at all (both mates occur on
+// the same path, position filter graph.cc:577, orientation rule graph.cc:1864-1876), the
+// candidates, the insert distance and the memo index (-1: not covered by the memo).
+struct CompactPrep {
+  Cand x, y;
+  int dist, memo_idx;
+  bool skip, scores;
+};
+__device__ __forceinline__ void compact_prep(const PairedArgs& a, const Compact1& c, CompactPrep& q) {
+  q.memo_idx = -1; q.dist = -1; q.scores = false;
   // a record in a window that needs the general path (occurs several times, ...): the host put
   // this pair on the overflow list
-  skip = (c.o1 != kNone8 && (c.o1 >> 63)) || (c.o2 != kNone8 && (c.o2 >> 63));
-  if (skip || c.o1 == kNone8 || c.o2 == kNone8 || ((c.o1 ^ c.o2) >> 48) != 0) return 0.0;  // both occur, same path
+  q.skip = (c.o1 != kNone8 && (c.o1 >> 63)) || (c.o2 != kNone8 && (c.o2 >> 63));
+  if (q.skip || c.o1 == kNone8 || c.o2 == kNone8 || ((c.o1 ^ c.o2) >> 48) != 0) return;  // both occur, same path
   const int p1 = (int)((c.r1 >> 24) & 0xfffffff), p2 = (int)((c.r2 >> 24) & 0xfffffff);
-  if (p1 < (int)(short)(c.o1 >> 32) || p2 < (int)(short)(c.o2 >> 32)) return 0.0;  // position filter (graph.cc:577)
-  Cand x, y;
+  if (p1 < (int)(short)(c.o1 >> 32) || p2 < (int)(short)(c.o2 >> 32)) return;  // position filter (graph.cc:577)
+  Cand& x = q.x; Cand& y = q.y;
   x.path = (int)(c.o1 >> 48); x.pos = p1 + (int)(unsigned)c.o1; x.edit = (int)((c.r1 >> 52) & 63); x.orient = (int)((c.r1 >> 58) & 1);
   y.path = x.path; y.pos = p2 + (int)(unsigned)c.o2; y.edit = (int)((c.r2 >> 52) & 63); y.orient = (int)((c.r2 >> 58) & 1);
-  int dist = -1;
-  const double t = pair_term_compact(a, x, y, c.lc, c.L1, c.L2, dist);
-  if (a.lt && dist >= 0 && dist < a.ins_n && c.lc < a.lt_codes && x.edit < 7 && y.edit < 7)
-    lt_idx = ((c.lc * 7 + x.edit) * 7 + y.edit) * a.ins_n + dist;
-  return t;
+  if (x.orient == y.orient) return;
+  if (x.pos < y.pos) {
+    if (x.orient != 0 || y.orient != 1) return;
+    q.dist = y.pos - x.pos + c.L2;
+  } else {
+    if (x.orient != 1 || y.orient != 0) return;
+    q.dist = x.pos - y.pos + c.L1;
+  }
+  q.scores = true;
+  if (a.memo && q.dist >= 0 && q.dist < a.ins_n && c.lc < a.lt_codes && x.edit < 7 && y.edit < 7)
+    q.memo_idx = ((c.lc * 7 + x.edit) * 7 + y.edit) * a.ins_n + q.dist;
+}
+
+// the pair term when the memo does not cover it: same arithmetic as pair_term, the per-read error
+// probability comes from the per-length-combination product table
+__device__ __forceinline__ double compact_term_tables(const PairedArgs& a, const Compact1& c, const CompactPrep& q) {
+  const double p1 = a.pe[0][c.lc * 64 + q.x.edit];
+  const double p2 = a.pe[1][c.lc * 64 + q.y.edit];
+  const double ip = (unsigned)q.dist < (unsigned)a.ins_n ? a.ins_tab[q.dist] : 0.0;
+  return p1 * p2 * ip;
+}
+
+__device__ __forceinline__ void compact_cover(const PairedArgs& a, const Compact1& c, const CompactPrep& q, double t) {
+  if (a.cov_bits && t > a.covthr_c[c.lc]) {  // coverage events at both ends (use_all_to_cov, graph.cc:1883-1888)
+    const int base = a.path_base[q.x.path];
+    mark_bit(a.cov_bits, base + max(q.x.pos, q.y.pos));
+    mark_bit(a.cov_bits, base + min(q.x.pos, q.y.pos));
+  }
+}
+
+// one scored class-0 pair: per-read probability out, floor / log into the running sums
+__device__ __forceinline__ void compact_finish(const PairedArgs& a, int i, const Compact1& c, const CompactPrep& q, double2 m,
+                                               double& lsum, int& zeros) {
+  if (q.memo_idx >= 0) {
+    const double t = fabs(m.x);
+    compact_cover(a, c, q, t);
+    a.probs[i] = t;
+    lsum += m.y;
+    zeros += (int)(__double2hiint(m.x) < 0);  // sign bit: floored (also for a term of exactly zero)
+    return;
+  }
+  double t = 0.0;
+  if (q.scores) { t = compact_term_tables(a, c, q); compact_cover(a, c, q, t); }
+  finish_read_compact(a, i, t, c.lc, lsum, zeros);
 }
 
 __device__ __forceinline__ void compact_load(const PairedArgs& a, int i, bool ok, Compact1& c) {
@@ -449,14 +474,16 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
         a.probs[i0] = (double)(int)(c0.o1 + c0.o2); lsum += (double)(int)(c0.o1 + c0.o2);
         if (two) { a.probs[i1] = (double)(int)(c1.o1 + c1.o2); lsum += (double)(int)(c1.o1 + c1.o2); }
       } else {
-        bool s0, s1;
-        int k0, k1;
-        const double acc0 = compact_score(a, c0, s0, k0);
-        const double acc1 = compact_score(a, c1, s1, k1);
-        if (ABL == 3) { a.probs[i0] = acc0; lsum += acc0; if (two) { a.probs[i1] = acc1; lsum += acc1; } }
+        CompactPrep q0, q1;
+        compact_prep(a, c0, q0);
+        compact_prep(a, c1, q1);
+        // both memo entries are requested before anything is stored
+        const double2 m0 = q0.memo_idx >= 0 ? a.memo[q0.memo_idx] : make_double2(0.0, 0.0);
+        const double2 m1 = q1.memo_idx >= 0 ? a.memo[q1.memo_idx] : make_double2(0.0, 0.0);
+        if (ABL == 3) { a.probs[i0] = fabs(m0.x); lsum += m0.x; if (two) { a.probs[i1] = fabs(m1.x); lsum += m1.x; } }
         else {
-          if (!s0 && !d0) finish_read_compact(a, i0, acc0, c0.lc, k0, lsum, zeros);
-          if (two && !s1 && !d1) finish_read_compact(a, i1, acc1, c1.lc, k1, lsum, zeros);
+          if (!q0.skip && !d0) compact_finish(a, i0, c0, q0, m0, lsum, zeros);
+          if (two && !q1.skip && !d1) compact_finish(a, i1, c1, q1, m1, lsum, zeros);
         }
       }
     }
@@ -481,6 +508,34 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
     RegCands<K> x, y;
     const bool m1 = load_cands_inline<K>(a.m[0], a.inl[0] + at, x), m2 = load_cands_inline<K>(a.m[1], a.inl[1] + at, y);
     if (m1 || m2) continue;  // on the host's overflow list
+    // Junction duplicates: the overwrite rule usually leaves one alignment per mate, i.e. one pair
+    // term -- the value the compact path looks up in the memo (same table, same index).
+    if (a.memo) {
+      int n1 = 0, n2 = 0;
+      Compact1 c;
+      CompactPrep q;
+      q.x.path = -1; q.x.pos = 0; q.x.edit = 0; q.x.orient = 0; q.y = q.x;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        if (x.live[k]) { n1++; q.x.path = x.path[k]; q.x.pos = x.pos[k]; q.x.edit = x.ef[k] & 0xff; q.x.orient = x.ef[k] >> 8; }
+        if (y.live[k]) { n2++; q.y.path = y.path[k]; q.y.pos = y.pos[k]; q.y.edit = y.ef[k] & 0xff; q.y.orient = y.ef[k] >> 8; }
+      }
+      int code = -1;
+#pragma unroll
+      for (int k = 3; k >= 0; k--) if (k < a.lt_codes && a.len_combo[k] == l12) code = k;
+      if (n1 == 1 && n2 == 1 && q.x.path == q.y.path && code >= 0 && q.x.orient != q.y.orient && q.x.edit < 7 && q.y.edit < 7) {
+        const bool fwd = q.x.pos < q.y.pos;  // orientation rule and insert distance (graph.cc:1864-1876)
+        const bool ok = fwd ? (q.x.orient == 0) : (q.x.orient == 1);
+        const int dist = fwd ? q.y.pos - q.x.pos + L2 : q.x.pos - q.y.pos + L1;
+        if (ok && dist >= 0 && dist < a.ins_n) {
+          c.lc = code; c.L1 = L1; c.L2 = L2;
+          q.dist = dist; q.scores = true; q.skip = false;
+          q.memo_idx = ((code * 7 + q.x.edit) * 7 + q.y.edit) * a.ins_n + dist;
+          compact_finish(a, i, c, q, a.memo[q.memo_idx], lsum, zeros);
+          continue;
+        }
+      }
+    }
     const double acc = score_regs<K>(a, x, y, L1, L2);
     finish_read(a, i, acc, L1, L2, lsum, zeros);
   }

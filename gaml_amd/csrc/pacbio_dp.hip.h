@@ -101,6 +101,7 @@ struct BandWalk {
 
 template <int G>
 __global__ __launch_bounds__(256) void pacbio_dp_kernel(DpArgs a) {
+  static_assert(G == 8 || G == 16, "the scan uses g^1..g^8");
   constexpr int kLdsWidth = 32;
   constexpr double kShift = 600.0;  // chunk maximum maps to e^600: sums of 16 stay finite, e^-1300 below it is still normal
   __shared__ double lds_rows[256 / G][2][kLdsWidth];
@@ -111,14 +112,12 @@ __global__ __launch_bounds__(256) void pacbio_dp_kernel(DpArgs a) {
   const DpJob jb = a.jobs[job];
   const double ninf = -__builtin_huge_val();
   const unsigned char* rd = a.reads + jb.read_off;
-  double* gbuf[2] = {a.scratch + jb.scratch_off, a.scratch + jb.scratch_off + jb.max_width};
-  double* lbuf[2] = {&lds_rows[grp][0][0], &lds_rows[grp][1][0]};
+  double* const gbuf0 = a.scratch + jb.scratch_off;
+  double* const lbuf0 = &lds_rows[grp][0][0];
   const int n = jb.read_len;
   const double match = exp(a.log_match), mismatch = exp(a.log_mismatch);  // linear MatchProbability values (graph.h:555-564)
-  double gpow[5];  // g^(1,2,4,8,16), g = MatchProbability('-', base) = mismatch: a read base is never '-' or the separator
-  gpow[0] = mismatch;
-#pragma unroll
-  for (int k = 1; k < 5; k++) gpow[k] = gpow[k - 1] * gpow[k - 1];
+  // g^(1,2,4,8), g = MatchProbability('-', base) = mismatch: a read base is never '-' or the separator
+  const double g1 = mismatch, g2 = g1 * g1, g4 = g2 * g2, g8 = g4 * g4;
 
   BandWalk bw;
   bw.ops = a.ops + jb.ops_off; bw.n_ops = jb.n_ops; bw.k = 0; bw.used = 0; bw.col = 0;
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(256) void pacbio_dp_kernel(DpArgs a) {
 
   double ret = ninf;
   long long cells = 0;
-  const double* prev = gbuf[0];
+  const double* prev = gbuf0;
   int plo = 0, phi = -1;  // column interval of the previous row (empty before the first row)
   for (int r = r_first - 2, ri = 0; r <= r_last + 2; r++, ri++) {
     const int lo = min(min(min(wl0, wl1), min(wl2, wl3)), wl4) - 2;
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(256) void pacbio_dp_kernel(DpArgs a) {
     else { wl4 = INT_MAX; wh4 = INT_MIN; }
     if (a.dbg_lo && job == 0 && j == 0) { a.dbg_lo[ri] = lo; a.dbg_hi[ri] = hi; }
     cells += hi - lo + 1;
-    double* cur = (hi - lo + 1 <= kLdsWidth) ? lbuf[ri & 1] : gbuf[ri & 1];
+    double* cur = (hi - lo + 1 <= kLdsWidth) ? lbuf0 + (ri & 1) * kLdsWidth : gbuf0 + (ri & 1) * (int64_t)jb.max_width;
     const int gi = r + jb.posstart - 1;  // path base of this row (graph.cc:2252)
     const bool row_ok = gi >= 0 && gi < a.path_len;
     const unsigned char pc = row_ok ? a.path[gi] : (unsigned char)0;
@@ -177,9 +176,10 @@ __global__ __launch_bounds__(256) void pacbio_dp_kernel(DpArgs a) {
           const double seed_lin = __shfl(e, 0, G);
           if (j == 1) v = seed_lin;
 #pragma unroll
-          for (int o = 1, k = 0; o < G; o <<= 1, k++) {
+          for (int o = 1; o < G; o <<= 1) {
             const double t = __shfl_up(v, o, G);
-            if (j >= o) v = v + t * gpow[k];
+            const double gp = o == 1 ? g1 : o == 2 ? g2 : o == 4 ? g4 : g8;
+            if (j >= o) v = v + t * gp;
           }
           if (v > 0.0) out = log(v) + sh;
         }

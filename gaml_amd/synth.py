@@ -387,6 +387,8 @@ WORKLOADS = {
     "cfg2": Workload("cfg2: 1 Mbp, 30x 2x150 paired, insert 300+-30", 1_000_000, 100_000),
     "cfg3": Workload("cfg3: 5 Mbp, 50x 2x150 paired, insert 300+-30", 5_000_000, 833_333),
     "tiny": Workload("tiny: 60 kbp, 2x150 paired", 60_000, 3_000),
+    # not a BASELINE config: the cfg3 recipe at 8x the size, to see where the scoring kernel's bandwidth levels off
+    "cfg3x8": Workload("cfg3x8: 40 Mbp, 50x 2x150 paired, insert 300+-30", 40_000_000, 6_666_664),
 }
 
 

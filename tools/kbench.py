@@ -37,3 +37,4 @@ for i in range(40):
 print('profile us [pass1, tables, ovf+occ8, pack, h2d_enq, launch, bytes, wait]:', np.round(prof / 40, 1))
 for si, st in enumerate(settings):
     print(st, "kernel_us median %.2f min %.2f | step_us median %.1f min %.1f" % (np.median(res[si]), min(res[si]), np.median(wall[si]), min(wall[si])))
+print("class counts [0: <=1 record/mate, 1: <=2, 2: <=4, 3: overflow]:", ctx.debug_class_counts(rs), "table stats:", ctx.debug_table_stats(rs))
