@@ -117,26 +117,20 @@ def main():
     rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), b1, o1, b2, o2)
     n_pairs_rank = wl.n_pairs
 
-    # N > 1: the kernels run on a torch side stream (a real, non-null HIP stream) so that the
-    # all-reduce and the D2H copy are ordered after them
-    side = torch.cuda.Stream()
-    d_part = torch.zeros(4, dtype=torch.float64, device="cuda")
+    # N > 1: gaml_amd.dist.ShardedScorer runs the kernels on a torch side stream (a real, non-null HIP
+    # stream) so that the all-reduce and the D2H copy are ordered after them
+    scorer = None
+    if use_dist:
+        from gaml_amd.dist import ShardedScorer
+        scorer = ShardedScorer(ctx)
     torch.cuda.synchronize()
 
     def step(paths):
+        if scorer is not None:
+            prob, zeros, _ = scorer.calc_prob(paths)  # cold path: maxima exchange; every step: one all-reduce(sum) of 4 f64
+            return prob, zeros
         pending, tl = ctx.eval_begin(paths)
-        if not use_dist:
-            part = ctx.eval_finish()  # kernels + 32-B D2H + stream sync inside the library: CalcProb is blocking
-        else:
-            if pending:
-                # cold path only: newly aligned windows -> all ranks exchange their largest record positions
-                mx = torch.from_numpy(ctx.eval_pending_maxpos().copy()).cuda()
-                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                ctx.eval_apply_maxpos(mx.cpu().numpy())
-            with torch.cuda.stream(side):
-                ctx.eval_finish_async(d_part.data_ptr(), side.cuda_stream)
-                dist.all_reduce(d_part, op=dist.ReduceOp.SUM)  # the one collective of the hot path
-                part = d_part.cpu().numpy()  # blocking
+        part = ctx.eval_finish()  # kernels + 32-B D2H + stream sync inside the library: CalcProb is blocking
         prob, zeros = ctx.combine_partials(part, tl)
         return prob, zeros
 

@@ -130,6 +130,10 @@ def _load():
     L.gaml_hip_eval_finish.argtypes = [vp, _f64p]
     L.gaml_hip_eval_finish_async.argtypes = [vp, vp, vp]
     L.gaml_hip_sync.argtypes = [vp]
+    L.gaml_hip_eval_score_async.argtypes = [vp, vp, vp]
+    L.gaml_hip_eval_score_async.restype = C.c_int32
+    L.gaml_hip_eval_coverage_export_async.argtypes = [vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64), vp]
+    L.gaml_hip_eval_coverage_finish_async.argtypes = [vp, C.c_int32, vp, C.c_int32, C.c_int32, vp]
     L.gaml_hip_num_readsets.argtypes = [vp]
     L.gaml_hip_readset_kind.argtypes = [vp, C.c_int]
     L.gaml_hip_readset_reads.argtypes = [vp, C.c_int]
@@ -359,6 +363,24 @@ class Context:
 
     def sync(self):
         self._check(_lib.gaml_hip_sync(self._h))
+
+    # sharded evaluation with a coverage penalty: scoring, then the coverage maps of all ranks, then the sweeps
+    def eval_score_async(self, d_partials_ptr: int, stream_ptr: int = 0) -> int:
+        return self._check(_lib.gaml_hip_eval_score_async(self._h, C.c_void_p(d_partials_ptr), C.c_void_p(stream_ptr)))
+
+    def eval_coverage_bytes(self, i: int) -> int:
+        n = C.c_int64(0)
+        self._check(_lib.gaml_hip_eval_coverage_export_async(self._h, i, None, 0, C.byref(n), None))
+        return n.value
+
+    def eval_coverage_export_async(self, i: int, dst_ptr: int, cap: int, stream_ptr: int = 0) -> int:
+        n = C.c_int64(0)
+        self._check(_lib.gaml_hip_eval_coverage_export_async(self._h, i, C.c_void_p(dst_ptr), cap, C.byref(n), C.c_void_p(stream_ptr)))
+        return n.value
+
+    def eval_coverage_finish_async(self, i: int, maps_ptr: int, n_maps: int, contribute: bool, stream_ptr: int = 0):
+        self._check(_lib.gaml_hip_eval_coverage_finish_async(self._h, i, C.c_void_p(maps_ptr), n_maps, 1 if contribute else 0,
+                                                             C.c_void_p(stream_ptr)))
 
     def combine_partials(self, partials, total_len):
         part = np.ascontiguousarray(partials, np.float64).reshape(-1)

@@ -221,6 +221,10 @@ struct gaml_hip_ctx {
   double pending_host_us = 0;
   double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // phase stamps of the last blocking call (us): see gaml_hip_debug_profile
   bool host_results = false;  // blocking call: kernels write their results into pinned host memory, no D2H copy
+  // sharded evaluation with a coverage penalty: sweeps wait for the other ranks' coverage maps
+  bool defer_cov = false;
+  struct PendingCov { int paired_idx; CovArgs args; double* out4; };
+  std::vector<PendingCov> pending_cov;
 };
 
 namespace {
@@ -800,7 +804,22 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     s.last_total_blocks = 0;
     if (!c->host_results) HIP_TRY(c, hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
   }
-  if (cov && n > 0 && p.total_bits > 0) {
+  if (cov && c->defer_cov) {
+    // the sweep needs the union of all ranks' coverage marks: gaml_hip_eval_coverage_finish_async runs it
+    CovArgs ca;
+    ca.bits = s.cov_bits.as<uint32_t>();
+    ca.path_base = (const int*)(arena + pb_off);
+    ca.start_off = (const int*)(arena + so_off);
+    ca.starts = (const int*)(arena + st_off);
+    ca.n_paths = (int)paths.size();
+    ca.total_words = p.total_bits / 32;
+    ca.cov_move = s.cfg.step;
+    ca.far = s.cfg.insert_mean + 5 * s.cfg.insert_std;
+    ca.bad = s.bad.as<unsigned long long>();
+    int idx = 0;
+    for (size_t i = 0; i < c->paireds.size(); i++) if (c->paireds[i].get() == &s) idx = (int)i;
+    c->pending_cov.push_back(gaml_hip_ctx::PendingCov{idx, ca, out4});
+  } else if (cov && n > 0 && p.total_bits > 0) {
     CovArgs ca;
     ca.bits = s.cov_bits.as<uint32_t>();
     ca.path_base = (const int*)(arena + pb_off);
@@ -814,8 +833,8 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     hipLaunchKernelGGL(coverage_sweep_kernel, dim3(grid_for(ca.total_words)), dim3(kBlock), 0, st, ca);
     HIP_TRY(c, hipGetLastError());
   }
-  if (cov && n > 0) {
-    hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), out4);
+  if (cov && n > 0 && !c->defer_cov) {
+    hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), out4, 1.0);
     HIP_TRY(c, hipGetLastError());
   }
   c->prof[5] = now_us() - tp2 - c->prof[4];  // kernel launches
@@ -1203,8 +1222,13 @@ int eval_finish(gaml_hip_ctx* c, void* d_partials, hipStream_t st) {
     // the coverage penalty depends on the union of all ranks' well-aligned pairs per path position
     // (graph.cc:1893-1919) / of all reads' intervals (graph.cc:3226-3250): a per-rank value would be wrong
     for (auto& ps : c->paireds)
+      if (ps->cfg.penalty_constant > 0 && !c->defer_cov)
+        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded context: the coverage maps of all ranks must be merged "
+                                        "(gaml_hip_eval_score_async -> gaml_hip_eval_coverage_export_async -> all-gather -> "
+                                        "gaml_hip_eval_coverage_finish_async)");
+    for (auto& ps : c->singles)
       if (ps->cfg.penalty_constant > 0)
-        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded context: the cross-rank coverage bitmap exchange is not implemented");
+        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded single-end set is not implemented");
     for (auto& ps : c->pacbios)
       if (ps->cfg.penalty_constant > 0)
         return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded PacBio set is not implemented");
@@ -1833,6 +1857,49 @@ int gaml_hip_eval_finish_async(gaml_hip_ctx* c, void* d_partials, void* stream) 
   if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
   return eval_finish(c, d_partials, stream ? (hipStream_t)stream : c->stream);
+}
+
+int32_t gaml_hip_eval_score_async(gaml_hip_ctx* c, void* d_partials, void* stream) {
+  if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
+  c->pending_cov.clear();
+  c->defer_cov = c->peers > 1;
+  const int e = eval_finish(c, d_partials, stream ? (hipStream_t)stream : c->stream);
+  c->defer_cov = false;
+  if (e) { c->pending_cov.clear(); return e; }
+  return (int32_t)c->pending_cov.size();
+}
+
+int gaml_hip_eval_coverage_export_async(gaml_hip_ctx* c, int32_t i, void* dst, int64_t cap, int64_t* bytes_out, void* stream) {
+  if (!c || i < 0 || i >= (int32_t)c->pending_cov.size() || !bytes_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  const int64_t bytes = (int64_t)c->pending_cov[i].args.total_words * 4;
+  *bytes_out = bytes;
+  if (!dst) return GAML_HIP_OK;  // size query
+  if (cap < bytes) return fail(c, GAML_HIP_EINVAL, "coverage map does not fit the destination");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (bytes > 0) HIP_TRY(c, hipMemcpyAsync(dst, c->pending_cov[i].args.bits, (size_t)bytes, hipMemcpyDeviceToDevice, stream ? (hipStream_t)stream : c->stream));
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* c, int32_t i, const void* maps, int32_t n_maps, int32_t contribute, void* stream) {
+  if (!c || i < 0 || i >= (int32_t)c->pending_cov.size() || n_maps < 0 || (n_maps > 0 && !maps)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const gaml_hip_ctx::PendingCov& pc = c->pending_cov[i];
+  PairedSet& s = *c->paireds[pc.paired_idx];
+  if (pc.args.total_words > 0) {
+    if (n_maps > 0) {
+      hipLaunchKernelGGL(or_maps_kernel, dim3(grid_for(pc.args.total_words)), dim3(kBlock), 0, st, s.cov_bits.as<uint32_t>(),
+                         (const uint32_t*)maps, n_maps, pc.args.total_words);
+      HIP_TRY(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(coverage_sweep_kernel, dim3(grid_for(pc.args.total_words)), dim3(kBlock), 0, st, pc.args);
+    HIP_TRY(c, hipGetLastError());
+  }
+  // every rank computes the same bad_bases; one of them contributes it to the all-reduce(sum) of the partials
+  hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), pc.out4, contribute ? 1.0 : 0.0);
+  HIP_TRY(c, hipGetLastError());
+  return GAML_HIP_OK;
 }
 
 int gaml_hip_sync(gaml_hip_ctx* c) {

@@ -915,8 +915,19 @@ __global__ __launch_bounds__(kBlock) void mark_dirty_kernel(const int* slots, in
 }
 
 // bad_bases of a paired set with coverage penalty: u64 counter of the sweep -> its partial slot
-__global__ void store_bad_bases_kernel(const unsigned long long* bad, double* out4) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) out4[2] = (double)*bad;
+// (scale 0: a rank other than 0 of a sharded evaluation -- the all-reduce(sum) of the partials must
+// count the value once)
+__global__ void store_bad_bases_kernel(const unsigned long long* bad, double* out4, double scale) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out4[2] = scale * (double)*bad;
+}
+
+// union of the coverage maps of all ranks: own |= maps[0] | maps[1] | ...
+__global__ __launch_bounds__(kBlock) void or_maps_kernel(uint32_t* own, const uint32_t* maps, int n_maps, int words) {
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < words; w += gridDim.x * kBlock) {
+    uint32_t v = own[w];
+    for (int k = 0; k < n_maps; k++) v |= maps[(size_t)k * words + w];
+    own[w] = v;
+  }
 }
 
 }  // namespace gaml

@@ -1,0 +1,59 @@
+"""One process per GPU: the collectives around a sharded likelihood evaluation.
+
+The C ABI knows nothing about process groups; this module is the plumbing a multi-GPU caller needs,
+written once over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm):
+
+  cold path only   all-reduce(max) of the largest record position of every newly aligned window
+                   (the reference's `max_pos - 5` filter, graph.cc:577, is a maximum over ALL reads)
+  penalty > 0 only all-gather of the per-rank coverage maps of each paired set, then every rank
+                   sweeps the union (bad_bases, graph.cc:1893-1919)
+  every step       ONE all-reduce(sum) of 4 f64 per read set {sum of logs, floored reads, bad_bases, reads}
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import api
+
+
+class ShardedScorer:
+    """CalcProb over a context that holds one shard of every read set. All ranks call calc_prob with
+    the same paths and get the same value."""
+
+    def __init__(self, ctx: api.Context, group=None, stream: "torch.cuda.Stream | None" = None):
+        self.ctx = ctx
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        # a real (non-null) HIP stream: kernels, collectives and the D2H copy are ordered on it
+        self.stream = stream or torch.cuda.Stream()
+        self.d_part = torch.zeros(4 * max(1, ctx.num_readsets()), dtype=torch.float64, device="cuda")
+        self._maps = None
+        self._gathered = None
+
+    def calc_prob(self, paths):
+        ctx = self.ctx
+        pending, total_len = ctx.eval_begin(paths)
+        if pending:
+            mx = torch.from_numpy(ctx.eval_pending_maxpos().copy()).cuda()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+            ctx.eval_apply_maxpos(mx.cpu().numpy())
+        with torch.cuda.stream(self.stream):
+            sp = self.stream.cuda_stream
+            n_maps = ctx.eval_score_async(self.d_part.data_ptr(), sp)
+            for i in range(n_maps):
+                nbytes = ctx.eval_coverage_bytes(i)
+                if self._maps is None or self._maps.numel() < nbytes:
+                    self._maps = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+                    self._gathered = torch.empty(nbytes * self.world, dtype=torch.uint8, device="cuda")
+                own = self._maps[:nbytes]
+                gathered = self._gathered[: nbytes * self.world]
+                ctx.eval_coverage_export_async(i, own.data_ptr(), nbytes, sp)
+                dist.all_gather_into_tensor(gathered, own, group=self.group)
+                ctx.eval_coverage_finish_async(i, gathered.data_ptr(), self.world, self.rank == 0, sp)
+            dist.all_reduce(self.d_part, op=dist.ReduceOp.SUM, group=self.group)  # the one collective of the hot path
+            part = self.d_part.cpu().numpy()  # blocking
+        prob, zeros = ctx.combine_partials(part, total_len)
+        return prob, zeros, total_len

@@ -200,6 +200,25 @@ int gaml_hip_eval_finish_async(gaml_hip_ctx* ctx, void* d_partials, void* hip_st
 /* wait for everything enqueued on the library's private stream */
 int gaml_hip_sync(gaml_hip_ctx* ctx);
 
+/* Sharded evaluation with a coverage penalty (penalty_constant > 0 on a paired set; SURVEY 8e "the one
+ * non-separable piece").  bad_bases (graph.cc:1893-1919) is a function of the union of every rank's
+ * well-aligned pair positions, so the sweep has to wait for the other ranks' coverage maps:
+ *   n = gaml_hip_eval_score_async(ctx, d_partials, stream)   instead of gaml_hip_eval_finish_async:
+ *       scoring kernels of all read sets; returns how many coverage maps await the exchange (0: done);
+ *   for i < n:
+ *     gaml_hip_eval_coverage_export_async(ctx, i, dst, cap, &bytes, stream)   copy this rank's map (one bit
+ *         per path base, same size on every rank) into caller memory, e.g. a torch tensor (dst NULL: size only);
+ *     all-gather the maps (RCCL);
+ *     gaml_hip_eval_coverage_finish_async(ctx, i, maps, n_maps, contribute, stream)   OR the n_maps gathered
+ *         maps into this rank's, run the sweep, store bad_bases into the partials: the value where
+ *         `contribute` is non-zero (exactly one rank, e.g. rank 0), 0 elsewhere, so that the
+ *         all-reduce(sum) of the partials counts it once.
+ * Single-end and PacBio sets with a penalty on a sharded context are refused (GAML_HIP_ESTATE). */
+int32_t gaml_hip_eval_score_async(gaml_hip_ctx* ctx, void* d_partials, void* stream);
+int gaml_hip_eval_coverage_export_async(gaml_hip_ctx* ctx, int32_t i, void* dst, int64_t cap, int64_t* bytes_out, void* stream);
+int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* ctx, int32_t i, const void* maps, int32_t n_maps, int32_t contribute,
+                                        void* stream);
+
 /* Device-resident form for callers that already own a HIP stream (e.g. torch): enqueue the
  * whole evaluation on `stream` and leave the 4*n_sets partials in device memory at
  * d_partials (f64). No host synchronisation. `hip_stream` must be a real stream handle the caller

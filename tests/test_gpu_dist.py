@@ -1,0 +1,56 @@
+"""gaml_amd.dist.ShardedScorer over a real RCCL process group (one rank: the pool's boxes have one GPU;
+the driver runs N = 2, 4, 8 at round end). The context is told that a peer exists (presharded=2), so
+the whole protocol runs: maxima exchange on the cold path, coverage-map all-gather for the penalty,
+all-reduce of the partials. With the peer holding no reads the result must equal the plain context's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from gaml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_scorer_single_rank_group():
+    import torch
+    import torch.distributed as dist
+    from gaml_amd import api
+    from gaml_amd.dist import ShardedScorer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        genome = synth.make_genome(60_000, 71)
+        g = synth.make_graph(genome, synth.cut_lengths(60_000, 71, long_rng=(900, 4000)))
+        pr = synth.make_paired_reads(genome, 1200, 100, 250.0, 25.0, 0.01, 71)
+        args = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+        walk = synth.genome_walk(g)
+        for penalty in (0.0, 0.0007):
+            cfg = api.paired_cfg(250.0, 25.0, penalty_constant=penalty, penalty_step=40.0)
+            plain = api.Context(device=0)
+            plain.set_graph(*g.packed())
+            plain.add_paired(cfg, *args)
+            ctx = api.Context(device=0, presharded=2)
+            ctx.set_graph(*g.packed())
+            ctx.add_paired(cfg, *args)
+            scorer = ShardedScorer(ctx)
+            for paths in ([walk], [walk[:6], walk[6:]], [walk[3:]]):
+                want, wz, tl = plain.calc_prob(paths)
+                got, z, tl2 = scorer.calc_prob(paths)
+                assert tl == tl2 and z.tolist() == wz.tolist()
+                assert abs(got - want) <= 1e-12 * abs(want), (penalty, got, want)
+            if penalty:
+                assert plain.bad_bases(0) > 0
+    finally:
+        dist.destroy_process_group()

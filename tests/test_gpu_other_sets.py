@@ -250,3 +250,66 @@ def test_sharded_context_refuses_coverage_penalty():
     with pytest.raises(api.GamlHipError) as e:
         c.eval_finish()
     assert e.value.code == api.ESTATE and "coverage" in str(e.value)
+
+
+def test_sharded_coverage_penalty_merges_the_ranks_maps():
+    """penalty_constant > 0 on a sharded paired set (the one non-separable piece): bad_bases
+    depends on the union of all ranks' coverage marks. Three shards on one GPU play the ranks; the
+    all-gather a multi-process run does over RCCL is a torch.cat here. Low coverage, so that every
+    shard alone sees gaps the union does not have."""
+    import torch
+    from gaml_amd import api
+    genome, g = _graph(60_000, 67, long_rng=(900, 4000))
+    pr = synth.make_paired_reads(genome, 1500, 100, 250.0, 25.0, 0.01, 67)
+    gb, go = g.packed()
+    args = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    walk = synth.genome_walk(g)
+    paths = [walk[:9], walk[9:]]
+    cfg = dict(penalty_constant=0.0007, penalty_step=40.0)
+    whole = api.Context(device=0)
+    whole.set_graph(gb, go)
+    whole.add_paired(api.paired_cfg(250.0, 25.0, **cfg), *args)
+    want, wz, tl = whole.calc_prob(paths)
+    bad_whole = whole.bad_bases(0)
+    assert bad_whole > 0
+    shards = []
+    for r in range(3):
+        c = api.Context(device=0, rank=r, world=3)
+        c.set_graph(gb, go)
+        c.add_paired(api.paired_cfg(250.0, 25.0, **cfg), *args)
+        shards.append(c)
+    pend = [c.eval_begin(paths) for c in shards]
+    reduced = np.maximum.reduce([c.eval_pending_maxpos() for c in shards])
+    for c in shards:
+        c.eval_apply_maxpos(reduced)
+    stream = torch.cuda.current_stream().cuda_stream
+    parts = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in shards]
+    maps = []
+    for c, p in zip(shards, parts):
+        assert c.eval_score_async(p.data_ptr(), stream) == 1
+        nbytes = c.eval_coverage_bytes(0)
+        m = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        assert c.eval_coverage_export_async(0, m.data_ptr(), nbytes, stream) == nbytes
+        maps.append(m)
+    assert len({m.numel() for m in maps}) == 1
+    gathered = torch.cat(maps)  # what all_gather_into_tensor leaves on every rank
+    for r, (c, p) in enumerate(zip(shards, parts)):
+        c.eval_coverage_finish_async(0, gathered.data_ptr(), 3, r == 0, stream)
+    torch.cuda.synchronize()
+    own_bad = [float(p[2]) for p in parts]
+    assert own_bad[0] == bad_whole and own_bad[1] == 0.0 and own_bad[2] == 0.0
+    acc = torch.stack(parts).sum(0).cpu().numpy()  # the all-reduce(sum)
+    got, z = shards[2].combine_partials(acc, tl)
+    assert z.tolist() == wz.tolist() and abs(got - want) <= 1e-12 * abs(want)
+    # each shard alone would have counted more uncovered bases
+    lone = api.Context(device=0)
+    lone.set_graph(gb, go)
+    n = pr.mate1.shape[0]
+    lone.add_paired(api.paired_cfg(250.0, 25.0, **cfg), *synth.pack_reads(pr.mate1[: n // 3]), *synth.pack_reads(pr.mate2[: n // 3]))
+    lone.calc_prob(paths)
+    assert lone.bad_bases(0) > bad_whole
+    # without the exchange the sharded context still refuses
+    c = shards[0]
+    c.eval_begin(paths)
+    with pytest.raises(api.GamlHipError):
+        c.eval_finish()
