@@ -210,6 +210,22 @@ def main():
             "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
             "timing_last_step_us": ctx.last_timing(),
         }
+        if not use_dist:
+            # extra, outside the timed region: the same 8 path sets through gaml_hip_calc_prob_batch
+            #  -- what a move generator gets that compares several candidate assemblies
+            bp = api.BatchPaths(variants_py)
+            bvals = [b[0] for b in ctx.calc_prob_batch(bp)]
+            assert all(abs(a - b) <= 1e-12 * abs(b) for a, b in zip(bvals, vals)), (bvals, vals)
+            calls = max(4, args.steps // (8 * 4))
+            gc.disable()
+            tb = time.perf_counter()
+            for _ in range(calls):
+                ctx.calc_prob_batch(bp)
+            tb = time.perf_counter() - tb
+            gc.enable()
+            out["batched"] = {"api": "gaml_hip_calc_prob_batch", "sets_per_call": len(variants_py), "calls": calls,
+                              "ms_per_set": 1e3 * tb / (calls * len(variants_py)),
+                              "reads_per_sec": total_reads * calls * len(variants_py) / tb}
         if not args.no_cpu_baseline:
             sample = min(args.cpu_sample_pairs, n_pairs_rank)
             cb, cpu_vals, _, _ = cpu_baseline(gb, go, b1, o1, b2, o2, sample, wl.read_len, variants_py)

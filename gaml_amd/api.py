@@ -52,6 +52,21 @@ def paired_cfg(insert_mean, insert_std, penalty_constant=0.0, penalty_step=50.0,
                      min_prob_start, weight, mismatch_prob)
 
 
+class BatchPaths:
+    """Several path sets in the ABI's concatenated form (built once by callers that re-score them)."""
+
+    def __init__(self, path_sets):
+        allp = [p for ps in path_sets for p in ps]
+        self.flat = np.array([x for p in allp for x in p], dtype=np.int32) if allp else np.zeros(0, np.int32)
+        if self.flat.size == 0:
+            self.flat = np.zeros(1, np.int32)
+        self.offs = np.zeros(len(allp) + 1, np.int64)
+        self.offs[1:] = np.cumsum([len(p) for p in allp])
+        self.set_offs = np.zeros(len(path_sets) + 1, np.int32)
+        self.set_offs[1:] = np.cumsum([len(ps) for ps in path_sets])
+        self.n_sets = len(path_sets)
+
+
 class GamlHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"gaml_hip error {code}: {msg}")
@@ -120,6 +135,7 @@ def _load():
     L.gaml_hip_debug_sam_band.argtypes = [C.c_char_p, C.c_int64, C.c_int32, _i32p, _i32p, _i32p, _i32p, C.c_int32]
     L.gaml_hip_debug_sam_band.restype = C.c_int32
     L.gaml_hip_calc_prob.argtypes = [vp, _i32p, _i64p, C.c_int32, C.POINTER(C.c_double), _i32p, C.POINTER(C.c_int32)]
+    L.gaml_hip_calc_prob_batch.argtypes = [vp, C.c_int32, _i32p, _i64p, _i32p, _f64p, vp, vp]
     L.gaml_hip_calc_partials.argtypes = [vp, _i32p, _i64p, C.c_int32, _f64p, C.POINTER(C.c_int32)]
     L.gaml_hip_combine_partials.argtypes = [vp, _f64p, C.c_int32, C.POINTER(C.c_double), _i32p]
     L.gaml_hip_calc_partials_async.argtypes = [vp, _i32p, _i64p, C.c_int32, vp, vp, C.POINTER(C.c_int32)]
@@ -321,6 +337,20 @@ class Context:
         zeros = np.zeros(2 * max(1, self.num_readsets()), np.int32)
         self._check(_lib.gaml_hip_calc_prob(self._h, flat, offs, len(paths), C.byref(prob), zeros, C.byref(tl)))
         return prob.value, zeros.reshape(-1, 2)[: self.num_readsets()].copy(), tl.value
+
+    def calc_prob_batch(self, path_sets):
+        """[(prob, zeros, total_len)] of several path sets in one call (gaml_hip_calc_prob_batch)."""
+        if isinstance(path_sets, BatchPaths):
+            b = path_sets
+        else:
+            b = BatchPaths(path_sets)
+        ns = max(1, self.num_readsets())
+        probs = np.zeros(max(1, b.n_sets))
+        zeros = np.zeros(max(1, b.n_sets) * 2 * ns, np.int32)
+        tls = np.zeros(max(1, b.n_sets), np.int32)
+        self._check(_lib.gaml_hip_calc_prob_batch(self._h, b.n_sets, b.flat, b.offs, b.set_offs, probs, zeros.ctypes.data, tls.ctypes.data))
+        z = zeros.reshape(-1, ns, 2)[:, : self.num_readsets()]
+        return [(float(probs[i]), z[i].copy(), int(tls[i])) for i in range(b.n_sets)]
 
     def calc_partials(self, paths):
         flat, offs = _flat(paths)

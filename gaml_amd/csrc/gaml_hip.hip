@@ -213,6 +213,8 @@ struct gaml_hip_ctx {
   double stat_device_us = 0, stat_algo_bytes = 0;
   DevBuf packed;  // 4 doubles per read set
   PinBuf packed_host;
+  DevBuf batch_dev;  // gaml_hip_calc_prob_batch: 4 doubles per read set and path set
+  PinBuf batch_host;
   // evaluation in progress (between eval_begin and eval_finish)
   bool pending_open = false;
   std::vector<Walk> pending_paths;
@@ -1337,7 +1339,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage);
       s->d_bases.release(); s->dp.release(); }
-    c->packed.release(); c->packed_host.release(); c->aln_scratch.release();
+    c->packed.release(); c->packed_host.release(); c->batch_dev.release(); c->batch_host.release(); c->aln_scratch.release();
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -2032,6 +2034,40 @@ int gaml_hip_calc_prob(gaml_hip_ctx* c, const int32_t* paths, const int64_t* off
   if (e) return e;
   if (total_len_out) *total_len_out = tl;
   return combine(c, partials.data(), prob_out, zeros_out, tl);
+}
+
+int gaml_hip_calc_prob_batch(gaml_hip_ctx* c, int32_t n_sets, const int32_t* paths, const int64_t* offs, const int32_t* set_offs,
+                             double* probs_out, int32_t* zeros_out, int32_t* total_lens_out) {
+  if (!c || n_sets < 0 || !set_offs || !probs_out || (n_sets > 0 && !offs)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->world != 1 || c->peers != 1)
+    return fail(c, GAML_HIP_ESTATE, "sharded context: run the gaml_hip_eval_* protocol per path set and all-reduce the partials of the batch at once");
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
+  if (n_sets == 0) return GAML_HIP_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t ns = std::max<size_t>(1, c->handles.size());
+  const size_t doubles = (size_t)n_sets * 4 * ns;
+  if (doubles * sizeof(double) > c->batch_dev.cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, c->batch_dev.reserve(doubles * sizeof(double))); }
+  HIP_TRY(c, c->batch_host.reserve(doubles * sizeof(double)));
+  std::vector<int32_t> tls(n_sets, 0);
+  // every evaluation is enqueued behind the previous one on the library's stream; the host prepares
+  // set i+1 (window placement, occurrence tables, staging) while the device scores set i
+  for (int32_t i = 0; i < n_sets; i++) {
+    const int32_t p0 = set_offs[i], p1 = set_offs[i + 1];
+    if (p1 < p0) return fail(c, GAML_HIP_EINVAL, "set offsets must not decrease");
+    // path offsets of the set stay absolute: eval_begin reads paths[offs[k] .. offs[k+1])
+    if (int e = evaluate(c, paths, offs + p0, p1 - p0, c->batch_dev.as<double>() + (size_t)i * 4 * ns, c->stream, &tls[i])) {
+      (void)hipStreamSynchronize(c->stream);
+      return e;
+    }
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->batch_host.p, c->batch_dev.p, doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const double* res = (const double*)c->batch_host.p;
+  for (int32_t i = 0; i < n_sets; i++) {
+    if (int e = combine(c, res + (size_t)i * 4 * ns, &probs_out[i], zeros_out ? zeros_out + (size_t)i * 2 * ns : nullptr, tls[i])) return e;
+    if (total_lens_out) total_lens_out[i] = tls[i];
+  }
+  return GAML_HIP_OK;
 }
 
 int gaml_hip_num_readsets(const gaml_hip_ctx* c) { return c ? (int)c->handles.size() : 0; }

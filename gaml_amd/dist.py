@@ -33,27 +33,47 @@ class ShardedScorer:
         self._maps = None
         self._gathered = None
 
-    def calc_prob(self, paths):
+    def _enqueue(self, paths, d_part):
+        """Everything of one evaluation up to (not including) the all-reduce of its partials."""
         ctx = self.ctx
         pending, total_len = ctx.eval_begin(paths)
         if pending:
             mx = torch.from_numpy(ctx.eval_pending_maxpos().copy()).cuda()
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
             ctx.eval_apply_maxpos(mx.cpu().numpy())
+        sp = self.stream.cuda_stream
+        n_maps = ctx.eval_score_async(d_part.data_ptr(), sp)
+        for i in range(n_maps):
+            nbytes = ctx.eval_coverage_bytes(i)
+            if self._maps is None or self._maps.numel() < nbytes:
+                self._maps = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+                self._gathered = torch.empty(nbytes * self.world, dtype=torch.uint8, device="cuda")
+            own = self._maps[:nbytes]
+            gathered = self._gathered[: nbytes * self.world]
+            ctx.eval_coverage_export_async(i, own.data_ptr(), nbytes, sp)
+            dist.all_gather_into_tensor(gathered, own, group=self.group)
+            ctx.eval_coverage_finish_async(i, gathered.data_ptr(), self.world, self.rank == 0, sp)
+        return total_len
+
+    def calc_prob(self, paths):
         with torch.cuda.stream(self.stream):
-            sp = self.stream.cuda_stream
-            n_maps = ctx.eval_score_async(self.d_part.data_ptr(), sp)
-            for i in range(n_maps):
-                nbytes = ctx.eval_coverage_bytes(i)
-                if self._maps is None or self._maps.numel() < nbytes:
-                    self._maps = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-                    self._gathered = torch.empty(nbytes * self.world, dtype=torch.uint8, device="cuda")
-                own = self._maps[:nbytes]
-                gathered = self._gathered[: nbytes * self.world]
-                ctx.eval_coverage_export_async(i, own.data_ptr(), nbytes, sp)
-                dist.all_gather_into_tensor(gathered, own, group=self.group)
-                ctx.eval_coverage_finish_async(i, gathered.data_ptr(), self.world, self.rank == 0, sp)
+            total_len = self._enqueue(paths, self.d_part)
             dist.all_reduce(self.d_part, op=dist.ReduceOp.SUM, group=self.group)  # the one collective of the hot path
             part = self.d_part.cpu().numpy()  # blocking
-        prob, zeros = ctx.combine_partials(part, total_len)
+        prob, zeros = self.ctx.combine_partials(part, total_len)
         return prob, zeros, total_len
+
+    def calc_prob_batch(self, path_sets):
+        """Several path sets whose values are only compared afterwards: evaluations
+        enqueued back to back, ONE all-reduce over all their partials, one device->host copy."""
+        k = self.d_part.numel()
+        buf = torch.zeros(len(path_sets) * k, dtype=torch.float64, device="cuda")
+        with torch.cuda.stream(self.stream):
+            tls = [self._enqueue(paths, buf[i * k:(i + 1) * k]) for i, paths in enumerate(path_sets)]
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            part = buf.cpu().numpy().reshape(len(path_sets), k)
+        out = []
+        for i, tl in enumerate(tls):
+            prob, zeros = self.ctx.combine_partials(part[i], tl)
+            out.append((prob, zeros, tl))
+        return out

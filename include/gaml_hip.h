@@ -227,6 +227,22 @@ int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* ctx, int32_t i, const void
 int gaml_hip_calc_partials_async(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths,
                                  void* d_partials, void* hip_stream, int32_t* total_len_out);
 
+/* Batched speculative scoring.  The move generators evaluate several near-identical
+ * path sets and keep the best (moves.cc:107-113 LocalChange2, 694-800 FixGapLength, 1156-1305
+ * FixRepForNode2): n_sets independent CalcProb calls whose results are only compared afterwards.
+ * This entry point takes them in one call: the evaluations are enqueued back to back on the
+ * library's stream, the host prepares set i+1 while the device scores set i, and there is ONE
+ * synchronisation and ONE device->host copy for the whole batch.  Results (and the window cache
+ * afterwards) are those of n_sets gaml_hip_calc_prob calls in the same order.
+ *   paths / path_offs : all paths of all sets, concatenated (path k = paths[path_offs[k] .. path_offs[k+1]))
+ *   set_offs[n_sets+1]: set i = paths set_offs[i] .. set_offs[i+1]-1
+ *   probs_out[n_sets]; zeros_out[n_sets * 2 * num_readsets] and total_lens_out[n_sets] may be NULL.
+ * Not for sharded contexts (GAML_HIP_ESTATE): there the batch is a loop over the gaml_hip_eval_*
+ * protocol with one all-reduce over all sets' partials (gaml_amd/dist.py: ShardedScorer.calc_prob_batch). */
+int gaml_hip_calc_prob_batch(gaml_hip_ctx* ctx, int32_t n_sets, const int32_t* paths, const int64_t* path_offs,
+                             const int32_t* set_offs, double* probs_out, int32_t* zeros_out, int32_t* total_lens_out);
+
+
 /* ---- introspection (tests, bench, logging) ----------------------------------------- */
 int gaml_hip_num_readsets(const gaml_hip_ctx* ctx);
 int gaml_hip_readset_kind(const gaml_hip_ctx* ctx, int readset);   /* 0 single, 1 paired, 2 pacbio */

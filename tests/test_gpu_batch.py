@@ -1,0 +1,74 @@
+"""gaml_hip_calc_prob_batch: several path sets in one call give the values of as many
+single calls in the same order -- including on a cold cache, where set i's newly aligned windows are
+visible to set i+1 exactly as in a sequence of CalcProb calls -- and the oracle's values."""
+import numpy as np
+import pytest
+
+from gaml_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(penalty=0.0):
+    from gaml_amd import api
+    genome = synth.make_genome(120_000, 83)
+    g = synth.make_graph(genome, synth.cut_lengths(120_000, 83, long_rng=(900, 4000)))
+    pr = synth.make_paired_reads(genome, 9000, 150, 300.0, 30.0, 0.01, 83)
+    sr = synth.make_single_reads(genome, 2000, 100, 0.01, 83)
+    walk = synth.genome_walk(g)
+    rng = np.random.default_rng(5)
+    sets = []
+    for k in range(9):  # speculative edits of one assembly: cuts, a dropped node, a reversed piece
+        cut = int(rng.integers(2, len(walk) - 2))
+        if k % 3 == 0:
+            sets.append([walk[:cut], walk[cut:]])
+        elif k % 3 == 1:
+            sets.append([walk[:cut] + walk[cut + 1:]])
+        else:
+            sets.append([walk[:cut], [x ^ 1 for x in reversed(walk[cut:])]])
+    sets.append([])  # an empty assembly is a valid argument too
+
+    def make():
+        c = api.Context(device=0)
+        c.set_graph(*g.packed())
+        c.add_paired(api.paired_cfg(300.0, 30.0, penalty_constant=penalty), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+        c.add_single(api.single_cfg(), *synth.pack_reads(sr))
+        return c
+    return g, pr, sr, sets, make
+
+
+@pytest.mark.parametrize("penalty", [0.0, 0.0005])
+def test_batch_equals_single_calls_cold_and_warm(penalty):
+    g, pr, sr, sets, make = _setup(penalty)
+    one, many = make(), make()
+    want = [one.calc_prob(s) for s in sets]          # cold: windows get aligned along the way
+    got = many.calc_prob_batch(sets)
+    assert len(got) == len(sets)
+    for w, b in zip(want, got):
+        assert b[2] == w[2] and b[1].tolist() == w[1].tolist()
+        assert abs(b[0] - w[0]) <= 1e-13 * abs(w[0])
+    for a, b in zip(many.calc_prob_batch(sets), [one.calc_prob(s) for s in sets]):  # warm
+        assert a[2] == b[2] and a[1].tolist() == b[1].tolist() and abs(a[0] - b[0]) <= 1e-13 * abs(b[0])
+    assert many.calc_prob_batch([]) == []
+
+
+def test_batch_against_the_oracle():
+    import oracle_py as op
+    g, pr, sr, sets, make = _setup()
+    o = op.Oracle()
+    o.set_graph(*g.packed())
+    o.add_paired(*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2), 0.01, op.paired_cfg(300.0, 30.0))
+    o.add_single(*synth.pack_reads(sr), 0.01, op.single_cfg())
+    got = make().calc_prob_batch(sets[:4])
+    for s, b in zip(sets[:4], got):
+        w = o.calc_prob(s)
+        assert b[1].tolist() == w[1].tolist() and b[2] == w[2]
+        assert abs(b[0] - w[0]) <= 1e-9 * abs(w[0])  # LL tolerance of the north star: 1e-6 relative
+
+
+def test_batch_refused_on_sharded_context():
+    from gaml_amd import api
+    c = api.Context(device=0, rank=0, world=2)
+    with pytest.raises(api.GamlHipError) as e:
+        c.calc_prob_batch([[[0]]])
+    assert e.value.code == api.ESTATE

@@ -52,5 +52,10 @@ def test_sharded_scorer_single_rank_group():
                 assert abs(got - want) <= 1e-12 * abs(want), (penalty, got, want)
             if penalty:
                 assert plain.bad_bases(0) > 0
+            sets = [[walk], [walk[:6], walk[6:]], [walk[3:]], [walk]]
+            single = [plain.calc_prob(p) for p in sets]
+            for got, want in zip(scorer.calc_prob_batch(sets), single):
+                assert got[2] == want[2] and got[1].tolist() == want[1].tolist()
+                assert abs(got[0] - want[0]) <= 1e-12 * abs(want[0])
     finally:
         dist.destroy_process_group()
