@@ -12,7 +12,10 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <unistd.h>
 #include <fstream>
+#include <iterator>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -163,6 +166,9 @@ inline void PrepareReadSetFromConfig(unordered_map<string, unordered_map<string,
   }
 }
 
+// gaml.cc:30,84: where the BLASR binary lives (config key blasr_path)
+inline string& BlasrPath() { static string p = "blasr/alignment/bin"; return p; }
+
 // ---- ProbCalculator (prob_calculator.h:37-124) --------------------------------------------------
 class ProbCalculator {
  public:
@@ -174,6 +180,7 @@ class ProbCalculator {
 
   double CalcProb(vector<vector<int>>& paths, vector<pair<int, int>>& zeros, int& total_len) {
     if (!ctx_ && !Build()) { fprintf(stderr, "gaml_hip: %s\n", err_.c_str()); exit(1); }
+    if (!FillPacbioCache(paths)) { fprintf(stderr, "gaml_hip: %s\n", err_.c_str()); exit(1); }
     vector<int32_t> flat;
     vector<int64_t> offs(1, 0);
     for (auto& p : paths) { flat.insert(flat.end(), p.begin(), p.end()); offs.push_back((int64_t)flat.size()); }
@@ -224,6 +231,7 @@ class ProbCalculator {
       gaml_single_cfg c{e.first.penalty_constant, e.first.step, e.first.min_prob_per_base, e.first.min_prob_start, e.first.weight, e.second->mismatch_prob_};
       int h = gaml_hip_add_pacbio_fastq(ctx_, &c, e.second->filename().c_str());
       if (h < 0) return Fail();
+      pacbio_handles_.push_back(h);
       e.second->reads_num_ = (int)gaml_hip_readset_reads(ctx_, h);
       if (!e.second->records_file.empty() && !LoadPacbioRecords(h, e.second->records_file)) return false;
     }
@@ -242,7 +250,62 @@ class ProbCalculator {
     }
     return true;
   }
+  // The cache-miss side of the PacBio scorer (GetReadProbabilities graph.cc:2438-2478 ->
+  // GetReadProbabilitiesSlow :2650-2795): every stretch of a path with an uncached sub-walk is
+  // written out, BLASR aligns the reads to it, and the SAM lines become cached records. The
+  // library says which stretches (gaml_hip_pacbio_missing) and turns SAM text into records
+  // (gaml_hip_pacbio_ingest_sam: ParseAligment + AligmentProbability on the GPU + filing rule);
+  // running the external aligner stays here, with the reference's command line (:2705-2715).
+  bool FillPacbioCache(const vector<vector<int>>& paths) {
+    for (size_t k = 0; k < pacbio_handles_.size(); k++) {
+      const int h = pacbio_handles_[k];
+      for (auto& path : paths) {
+        if (path.empty()) continue;
+        vector<int32_t> p(path.begin(), path.end()), ranges(2 * path.size() + 2);
+        int32_t n = gaml_hip_pacbio_missing(ctx_, h, p.data(), (int32_t)p.size(), ranges.data(), (int32_t)ranges.size() / 2);
+        if (n < 0) return Fail();
+        for (int32_t r = 0; r < n; r++) {
+          vector<int32_t> sub(p.begin() + ranges[2 * r], p.begin() + ranges[2 * r + 1] + 1);
+          string sam;
+          if (!RunBlasr(pacbio_reads[k].second->filename(), sub, sam)) return false;
+          int64_t filed = 0;
+          if (gaml_hip_pacbio_ingest_sam(ctx_, h, sub.data(), (int32_t)sub.size(), sam.data(), (int64_t)sam.size(), &filed)) return Fail();
+          printf("pb slow: %d nodes, %lld records filed\n", (int)sub.size(), (long long)filed);
+        }
+      }
+    }
+    return true;
+  }
+  bool RunBlasr(const string& reads_file, const vector<int32_t>& sub, string& sam) {
+    // (the reference uses tmpnam, graph.cc:2653-2658; a private directory avoids its race)
+    char dir[] = "/tmp/gaml_hip_pbXXXXXX";
+    if (!mkdtemp(dir)) { err_ = "mkdtemp failed"; return false; }
+    const string fas = string(dir) + "/path.fas", out = string(dir) + "/blasr.sam";
+    FILE* f = fopen(fas.c_str(), "w");
+    if (!f) { err_ = "cannot write " + fas; rmdir(dir); return false; }
+    fprintf(f, ">tmp\n");
+    for (int32_t x : sub) {
+      if (x < 0) for (int j = 0; j < -x; j++) fputc('N', f);
+      else fputs(gr.nodes[x].c_str(), f);
+    }
+    fputc('\n', f);
+    fclose(f);
+    string cmd = BlasrPath() + "/blasr " + reads_file + " " + fas +
+                 " -sam -sdpTupleSize 8 -guidedAlignBandSize 100 -nCandidates 50 -minMatch 11 -nproc 16 >" + out;
+    printf("command %s\n", cmd.c_str());
+    int rc = system(cmd.c_str());
+    std::ifstream fi(out);
+    bool ok = rc == 0 && fi.is_open();
+    if (ok) sam.assign(std::istreambuf_iterator<char>(fi), std::istreambuf_iterator<char>());
+    else err_ = "the aligner command failed: " + cmd;
+    fi.close();
+    remove(fas.c_str());
+    remove(out.c_str());
+    rmdir(dir);
+    return ok;
+  }
   bool Fail() { err_ = gaml_hip_last_error(ctx_); return false; }
+  vector<int> pacbio_handles_;
   gaml_hip_ctx* ctx_ = nullptr;
   int device_;
   string err_;

@@ -15,6 +15,7 @@ int main(int argc, char** argv) {
   unordered_map<string, unordered_map<string, string>> read_set_configs;
   if (!LoadConfig(argv[1], configs, read_set_configs)) { printf("Load config failed\n"); return 1; }
   if (!configs.count("graph")) { fprintf(stderr, "Missing graph in config\n"); return 1; }
+  if (configs.count("blasr_path")) BlasrPath() = configs["blasr_path"];  // gaml.cc:84
   vector<pair<SingleReadConfig, ReadSet*>> single_reads;
   vector<pair<PairedReadConfig, pair<ReadSet*, ReadSet*>>> paired_reads;
   vector<pair<SingleReadConfig, PacbioReadSet*>> pacbio_reads;

@@ -18,6 +18,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
 
 #include "gaml_hip.h"
 #include "graph.h"    // the reference's
@@ -64,6 +67,7 @@ class ProbCalculator {
     // the reference constructs ProbCalculator before PrepareReads (gaml.cc:1010 vs 1017): the
     // device context is built on first use, when the FASTQ files are known to be final
     if (!ctx_) Build();
+    FillPacbioCache(pathso);
     vector<int32_t> flat;
     vector<int64_t> offs(1, 0);
     for (size_t i = 0; i < pathso.size(); i++) {
@@ -127,6 +131,7 @@ class ProbCalculator {
       gaml_single_cfg g = {c.penalty_constant, c.step, c.min_prob_per_base, c.min_prob_start, c.weight, exp(rs->mismatch_prob_.logval)};
       int h = gaml_hip_add_pacbio_fastq(ctx_, &g, rs->filename_.c_str());
       if (h < 0) Die("gaml_hip_add_pacbio_fastq");
+      pacbio_handles_.push_back(h);
       // hand over what BLASR + AligmentProbability already left in the PacBio cache (graph.h:587)
       for (auto it = rs->aligment_cache_.begin(); it != rs->aligment_cache_.end(); ++it) {
         vector<gaml_pacbio_aligment> recs;
@@ -140,6 +145,61 @@ class ProbCalculator {
       }
     }
   }
+  // Cache-miss side of the PacBio scorer. The reference's GetReadProbabilities (graph.cc:2438-2478)
+  // hands every stretch of a path with an uncached sub-walk to GetReadProbabilitiesSlow
+  // (:2650-2795), which writes the stretch to a file, runs BLASR, and turns each SAM line into a
+  // cached record on the CPU. Here the library names the stretches (gaml_hip_pacbio_missing) and
+  // turns the SAM text into records (gaml_hip_pacbio_ingest_sam: ParseAligment, AligmentProbability
+  // on the GPU, filing rule); running BLASR stays here, with the reference's files, read filter
+  // (anchors) and command line (:2652-2715).
+  void FillPacbioCache(const vector<vector<int> >& paths) {
+    for (size_t k = 0; k < pacbio_handles_.size(); k++) {
+      PacbioReadSet* rs = pacbio_reads[k].second;
+      for (size_t pi = 0; pi < paths.size(); pi++) {
+        if (paths[pi].empty()) continue;
+        vector<int32_t> p(paths[pi].begin(), paths[pi].end()), ranges(2 * p.size() + 2);
+        int32_t n = gaml_hip_pacbio_missing(ctx_, pacbio_handles_[k], &p[0], (int32_t)p.size(), &ranges[0], (int32_t)ranges.size() / 2);
+        if (n < 0) Die("gaml_hip_pacbio_missing");
+        for (int32_t r = 0; r < n; r++) {
+          vector<int32_t> sub(p.begin() + ranges[2 * r], p.begin() + ranges[2 * r + 1] + 1);
+          string sam = RunBlasr(rs, sub);
+          int64_t filed = 0;
+          if (gaml_hip_pacbio_ingest_sam(ctx_, pacbio_handles_[k], &sub[0], (int32_t)sub.size(), sam.data(), (int64_t)sam.size(), &filed))
+            Die("gaml_hip_pacbio_ingest_sam");
+        }
+      }
+    }
+  }
+  string RunBlasr(PacbioReadSet* rs, const vector<int32_t>& sub) {
+    extern string gBlasrPath;  // gaml.cc:30
+    char tmpname1[L_tmpnam + 6], tmpname2[L_tmpnam + 6], tmpname3[L_tmpnam];
+    tmpnam(tmpname1); strcat(tmpname1, ".fas");
+    tmpnam(tmpname2); strcat(tmpname2, ".fq");
+    tmpnam(tmpname3);
+    FILE* f = fopen(tmpname1, "w");
+    fprintf(f, ">tmp\n");
+    for (size_t i = 0; i < sub.size(); i++) {
+      if (sub[i] < 0) for (int j = 0; j < -sub[i]; j++) fputc('N', f);
+      else fputs(gr.nodes[sub[i]]->s.c_str(), f);
+    }
+    fputc('\n', f);
+    fclose(f);
+    string reads_filename = rs->filename_;
+    unordered_set<int> read_filter;  // reads anchored on the stretch's nodes (graph.cc:2690-2701)
+    for (size_t i = 0; i < sub.size(); i++)
+      if (sub[i] >= 0)
+        for (auto it = rs->anchors_cache_[sub[i]].begin(); it != rs->anchors_cache_[sub[i]].end(); ++it) read_filter.insert(*it);
+    if (!read_filter.empty()) { rs->FilterReads(tmpname2, read_filter); reads_filename = tmpname2; }
+    string cmd = gBlasrPath + "/blasr " + reads_filename + " " + tmpname1 +
+                 " -sam -sdpTupleSize 8 -guidedAlignBandSize 100 -nCandidates 50 -minMatch 11 -nproc 16 >" + tmpname3;
+    if (system(cmd.c_str()) != 0) Die("blasr");
+    ifstream fi(tmpname3);
+    string sam((std::istreambuf_iterator<char>(fi)), std::istreambuf_iterator<char>());
+    remove(tmpname1);
+    remove(tmpname3);
+    return sam;
+  }
+  vector<int> pacbio_handles_;
   gaml_hip_ctx* ctx_;
 };
 

@@ -71,3 +71,62 @@ def test_gaml_score_fails_loudly_without_a_gpu(tmp_path, built):
     assert out.returncode != 0
     assert "no HIP device" in out.stderr or "HIP" in out.stderr
     assert "start prob" not in out.stdout
+
+
+@pytest.mark.gpu
+def test_cfg4_style_run_with_an_external_aligner(tmp_path):
+    """BASELINE config 4 in miniature: a paired set (weight 1) + PacBio reads (weight 0.5, mismatch_prob
+    0.15) whose alignment cache is empty, so the first CalcProb has to run the external aligner exactly
+    like the reference (graph.cc:2705-2715). `blasr_path` points at a stand-in that prints a prepared
+    SAM file (parity at the BLASR boundary is pinned by fixing the SAM text); the oracle is
+    fed the same text."""
+    import stat
+    import oracle_py as op
+    d = str(tmp_path)
+    G, seed = 40_000, 91
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(1200, 4000)))
+    synth.write_lastgraph(os.path.join(d, "LastGraph"), g)
+    pr = synth.make_paired_reads(genome, 2000, 150, 300.0, 30.0, 0.01, seed)
+    synth.write_fastq(os.path.join(d, "a_1.fastq"), pr.mate1, "p", 1)
+    synth.write_fastq(os.path.join(d, "a_2.fastq"), pr.mate2, "p", 2)
+    walk = synth.genome_walk(g)
+    ps = synth.make_pacbio_sam(g, walk, 80, 1500, seed)
+    with open(os.path.join(d, "pb.fastq"), "w") as f:
+        for name, read in zip(ps.names, ps.reads):
+            f.write(f"@{name} extra words\n{read}\n+\n{'I' * len(read)}\n")
+    tool = os.path.join(d, "tools")
+    os.makedirs(tool)
+    with open(os.path.join(tool, "prepared.sam"), "w") as f:
+        f.write(ps.sam)
+    with open(os.path.join(tool, "blasr"), "w") as f:
+        f.write('#!/bin/sh\ncat "$(dirname "$0")/prepared.sam"\n')
+    os.chmod(os.path.join(tool, "blasr"), os.stat(os.path.join(tool, "blasr")).st_mode | stat.S_IEXEC)
+    sets = [dict(name="il", type="paired", filename1=os.path.join(d, "a_1.fastq"), filename2=os.path.join(d, "a_2.fastq"),
+                 insert_mean=300, insert_std=30),
+            dict(name="pb", type="pacbio", filename=os.path.join(d, "pb.fastq"), weight=0.5, mismatch_prob=0.15, min_prob_per_base=-1.0)]
+    synth.write_config(os.path.join(d, "run.cfg"), os.path.join(d, "LastGraph"), sets, extra={"blasr_path": tool})
+    with open(os.path.join(d, "x.walks"), "w") as f:
+        pos, parts = 0, []
+        for x in walk:
+            parts.append(f"{x}({pos})")
+            pos += g.node_len(x)
+        f.write(">tmp0-" + "-".join(parts) + "\n")
+    out = subprocess.run([CLI, os.path.join(d, "run.cfg"), os.path.join(d, "x.walks")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "records filed" in out.stdout
+    m = re.search(r"start prob (\S+) len (\d+) low prob reads(.*)", out.stdout)
+    got, tl = float(m.group(1)), int(m.group(2))
+    zeros = [[int(a), int(b)] for a, b in re.findall(r"(\d+)/(\d+)", m.group(3))]
+    orc = op.Oracle()
+    orc.set_graph(*g.packed())
+    orc.add_paired(*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2), 0.01, op.paired_cfg(300.0, 30.0))
+    rb = np.frombuffer("".join(ps.reads).encode(), np.uint8)
+    ro = np.zeros(len(ps.reads) + 1, np.int64)
+    ro[1:] = np.cumsum([len(r) for r in ps.reads])
+    ors = orc.add_pacbio_reads(rb, ro, ps.names, 0.15, op.single_cfg(min_prob_per_base=-1.0, weight=0.5))
+    assert orc.pacbio_ingest_sam(ors, walk, ps.sam) > 0
+    want, wz, wtl = orc.calc_prob([walk])
+    assert tl == wtl and zeros == wz.tolist()
+    assert wz[1][0] < wz[1][1] // 2  # most long reads score above the floor: the cache really got filled
+    assert abs(got - want) <= 1e-9 * abs(want)
