@@ -146,6 +146,7 @@ def _load():
     L.gaml_hip_eval_finish.argtypes = [vp, _f64p]
     L.gaml_hip_eval_finish_async.argtypes = [vp, vp, vp]
     L.gaml_hip_sync.argtypes = [vp]
+    L.gaml_hip_compact_tables.argtypes = [vp]
     L.gaml_hip_eval_score_async.argtypes = [vp, vp, vp]
     L.gaml_hip_eval_score_async.restype = C.c_int32
     L.gaml_hip_eval_coverage_export_async.argtypes = [vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64), vp]
@@ -393,6 +394,9 @@ class Context:
 
     def sync(self):
         self._check(_lib.gaml_hip_sync(self._h))
+
+    def compact_tables(self):
+        self._check(_lib.gaml_hip_compact_tables(self._h))
 
     # sharded evaluation with a coverage penalty: scoring, then the coverage maps of all ranks, then the sweeps
     def eval_score_async(self, d_partials_ptr: int, stream_ptr: int = 0) -> int:

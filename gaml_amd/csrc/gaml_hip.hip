@@ -115,7 +115,13 @@ struct PairedSet {
   std::unordered_map<int32_t, int32_t> dirty_index;  // slot -> index in `dirty`
   int64_t full_rebuilds = 0, delta_updates = 0;
   size_t dirty_marked = 0;   // delta pairs whose slots already carry the mark on the device
+  // the delta lists live in their own device buffer and travel only when they changed
+  uint64_t dirty_gen = 0, delta_uploaded_gen = ~0ull;
+  DevBuf delta_dev;
+  Staging stage_delta;
+  size_t delta_off[5] = {0, 0, 0, 0, 0};  // slots, offsets mate 0, records mate 0, offsets mate 1, records mate 1
   int quiet_calls = 0;       // evaluations since the last window activation
+  bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
   int last_total_blocks = 0;
   bool last_host_partials = false;
@@ -201,6 +207,8 @@ struct gaml_hip_ctx {
   AlignScratch aln_scratch;
   int64_t aln_windows = 0, aln_candidates = 0;  // GPU aligner statistics
   double aln_us = 0;
+  double aln_stage_us[5] = {0, 0, 0, 0, 0};  // window strings + upload, spans + candidates, extension, D2H of hits, sort + finalize
+  int64_t aln_batches = 0;
   int knobs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
   int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;
@@ -479,12 +487,17 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   const bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
   s.quiet_calls = activated_now ? 0 : s.quiet_calls + 1;
   // the cache has settled (no activation for a while) but pairs still sit on the slower delta path: fold them in
-  if (!need_full && !activated_now && !s.dirty.empty() && s.quiet_calls >= 16 && c->knobs[6] != 2) need_full = true;
+  // A rebuild costs ~30 ms at 833 k pairs, a pair on the delta path ~1-2 ns per evaluation. In an
+  // annealing run new junction windows appear every few calls, so folding after a short quiet spell
+  // (as an earlier version did after 16 calls) rebuilt 8 times per 1000 iterations for nothing;
+  // 64 quiet calls mean the path set has stopped producing new windows (steady re-scoring).
+  if (!need_full && !activated_now && !s.dirty.empty() && (s.quiet_calls >= 64 || s.compact_requested) && c->knobs[6] != 2) need_full = true;
+  s.compact_requested = false;
   if (!need_full && (s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation)) {
     // Windows were activated since the tables were built. Few new records: keep the tables, put the
     // affected pairs on the delta list. Many: rebuild.
     const int64_t np = s.mate[0].n_local();
-    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / 64);
+    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / 16);
     size_t new_records = 0;
     for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
     if (s.dirty.size() + new_records > limit) need_full = true;
@@ -518,6 +531,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
               base_records(slot, 0, s.dirty.back().recs[0]);
               base_records(slot, 1, s.dirty.back().recs[1]);
             }
+            s.dirty_gen++;
             auto& lst = s.dirty[it->second].recs[mt];
             RecQuad q{w, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
             // keep the device-table order: (window id, position)
@@ -534,6 +548,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     s.dirty.clear();
     s.dirty_index.clear();
     s.dirty_marked = 0;
+    s.dirty_gen++;
     s.full_rebuilds++;
     for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
     // cold path: the set of activated windows of either mate changed -> new device order of the
@@ -617,20 +632,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     o8_off[mt] = total;
     total = align16(total + std::max<size_t>(1, s.image[mt].occ8.size()) * sizeof(uint64_t));
   }
-  // delta pairs: slots, per-mate offsets, records
   const size_t nd = s.dirty.size();
-  size_t ds_off = total, dofs_off[2] = {0, 0}, drec_off[2] = {0, 0};
-  size_t drec_n[2] = {0, 0};
-  if (nd) {
-    total = align16(ds_off + nd * sizeof(int32_t));
-    for (int mt = 0; mt < 2; mt++) {
-      for (const auto& d : s.dirty) drec_n[mt] += d.recs[mt].size();
-      dofs_off[mt] = total;
-      total = align16(total + (nd + 1) * sizeof(int32_t));
-      drec_off[mt] = total;
-      total = align16(total + std::max<size_t>(1, drec_n[mt]) * sizeof(RecQuad));
-    }
-  }
   const double tp1 = now_us();
   c->prof[2] = tp1 - t_after_host;  // overflow list + occ8
   void* host = nullptr;
@@ -641,22 +643,6 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   if (!s.ovf_items.empty()) memcpy((char*)host + ov_off, s.ovf_items.data(), s.ovf_items.size() * sizeof(int32_t));
   for (int mt = 0; mt < 2; mt++)
     if (!s.image[mt].occ8.empty()) memcpy((char*)host + o8_off[mt], s.image[mt].occ8.data(), s.image[mt].occ8.size() * sizeof(uint64_t));
-  if (nd) {
-    int32_t* ds = (int32_t*)((char*)host + ds_off);
-    for (size_t k = 0; k < nd; k++) ds[k] = s.dirty[k].slot;
-    for (int mt = 0; mt < 2; mt++) {
-      int32_t* of = (int32_t*)((char*)host + dofs_off[mt]);
-      RecQuad* rc = (RecQuad*)((char*)host + drec_off[mt]);
-      int32_t at = 0;
-      for (size_t k = 0; k < nd; k++) {
-        of[k] = at;
-        const auto& l = s.dirty[k].recs[mt];
-        if (!l.empty()) memcpy(rc + at, l.data(), l.size() * sizeof(RecQuad));
-        at += (int32_t)l.size();
-      }
-      of[nd] = at;
-    }
-  }
   if (cov) {
     memcpy((char*)host + pb_off, p.path_base.data(), p.path_base.size() * sizeof(int32_t));
     memcpy((char*)host + so_off, p.start_off.data(), p.start_off.size() * sizeof(int32_t));
@@ -670,6 +656,39 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   c->prof[6] = (double)total;
   HIP_TRY(c, hipMemcpyAsync(s.occ_arena.p, host, total, hipMemcpyHostToDevice, st));
   if (int e = stage_release(c, s.stage, slot, st)) return e;
+  // delta pairs: slots, per-mate offsets, records -- uploaded only when the lists changed (new windows
+  // were activated); otherwise the device copy of the previous evaluation is still right
+  if (nd && s.delta_uploaded_gen != s.dirty_gen) {
+    size_t dn[2] = {0, 0};
+    for (const auto& d : s.dirty) { dn[0] += d.recs[0].size(); dn[1] += d.recs[1].size(); }
+    size_t dt = 0;
+    s.delta_off[0] = dt; dt = align16(dt + nd * sizeof(int32_t));
+    for (int mt = 0; mt < 2; mt++) {
+      s.delta_off[1 + 2 * mt] = dt; dt = align16(dt + (nd + 1) * sizeof(int32_t));
+      s.delta_off[2 + 2 * mt] = dt; dt = align16(dt + std::max<size_t>(1, dn[mt]) * sizeof(RecQuad));
+    }
+    void* dh = nullptr;
+    int dslot = stage_acquire(c, s.stage_delta, dt, &dh);
+    if (dslot < 0) return dslot;
+    int32_t* ds = (int32_t*)((char*)dh + s.delta_off[0]);
+    for (size_t k = 0; k < nd; k++) ds[k] = s.dirty[k].slot;
+    for (int mt = 0; mt < 2; mt++) {
+      int32_t* of = (int32_t*)((char*)dh + s.delta_off[1 + 2 * mt]);
+      RecQuad* rc = (RecQuad*)((char*)dh + s.delta_off[2 + 2 * mt]);
+      int32_t at = 0;
+      for (size_t k = 0; k < nd; k++) {
+        of[k] = at;
+        const auto& l = s.dirty[k].recs[mt];
+        if (!l.empty()) memcpy(rc + at, l.data(), l.size() * sizeof(RecQuad));
+        at += (int32_t)l.size();
+      }
+      of[nd] = at;
+    }
+    if (dt > s.delta_dev.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.delta_dev.reserve(dt + dt / 2)); }
+    HIP_TRY(c, hipMemcpyAsync(s.delta_dev.p, dh, dt, hipMemcpyHostToDevice, st));  // stream order: after the kernels that read the old lists
+    if (int e = stage_release(c, s.stage_delta, dslot, st)) return e;
+    s.delta_uploaded_gen = s.dirty_gen;
+  }
   c->prof[4] = now_us() - tp2;  // H2D enqueue
 
   const int64_t n = s.mate[0].n_local();
@@ -751,8 +770,9 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   a.ovf_items = (const int*)(arena + ov_off);
   a.n_ovf_items = (int)s.ovf_items.size();
   a.n_dirty = (int)nd;
-  a.dirty_slots = (const int*)(arena + ds_off);
-  for (int mt = 0; mt < 2; mt++) { a.dirty_off[mt] = (const int*)(arena + dofs_off[mt]); a.dirty_recs[mt] = (const int4*)(arena + drec_off[mt]); }
+  const char* delta = (const char*)s.delta_dev.p;
+  a.dirty_slots = (const int*)(delta + s.delta_off[0]);
+  for (int mt = 0; mt < 2; mt++) { a.dirty_off[mt] = (const int*)(delta + s.delta_off[1 + 2 * mt]); a.dirty_recs[mt] = (const int4*)(delta + s.delta_off[2 + 2 * mt]); }
   const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size() + (int64_t)nd;
   const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : 768;  // 3 blocks per CU, ~2-3 pipelined iterations per lane at cfg3 (tools/kbench.py sweep)
   // the compact path handles 2 pairs per lane and iteration
@@ -1109,6 +1129,7 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
   if (!wstr.empty()) HIP_TRY(c, hipMemcpy(S.wstr.p, wstr.data(), wstr.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(S.wins.p, wins.data(), nw * sizeof(AlnWindow), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(S.hbuf_off.p, hoff.data(), nw * sizeof(int64_t), hipMemcpyHostToDevice));
+  const double t1 = now_us();
   size_t cap_spans = std::max<size_t>(1 << 16, wstr.size());        // a span per window base and strand at most ~2x
   size_t cap_cands = std::max<size_t>(1 << 18, 8 * wstr.size());
   unsigned counts[2] = {0, 0};
@@ -1130,6 +1151,8 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
     cap_cands = std::max<size_t>(cap_cands, (size_t)counts[1] + 16);
     if (attempt == 5) { m.flush_pending_cpu(c->g); return 0; }
   }
+  const double t2 = now_us();
+  double t3 = t2;
   const unsigned nc = counts[1];
   std::vector<AlnHit> hits(nc);
   if (nc) {
@@ -1138,8 +1161,11 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
                        (unsigned)cap_cands, S.wstr.as<char>(), S.wins.as<AlnWindow>(), d.reads.as<char>(), d.read_off.as<int64_t>(),
                        S.hits.as<AlnHit>());
     HIP_TRY(c, hipGetLastError());
+    if (c->knobs[9]) { HIP_TRY(c, hipDeviceSynchronize()); t3 = now_us(); }
     HIP_TRY(c, hipMemcpy(hits.data(), S.hits.p, (size_t)nc * sizeof(AlnHit), hipMemcpyDeviceToHost));
   }
+  const double t4 = now_us();
+  if (!c->knobs[9]) t3 = t4;
   // per window: sort by (position, read), the first alignment found for a key survives
   // (graph.cc:841, 891, 895-897); per read its candidates are visited forward-strand spans first
   std::vector<AlnHit> ok;
@@ -1167,7 +1193,10 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
   m.pending.clear();
   c->aln_windows += nw;
   c->aln_candidates += nc;
-  c->aln_us += now_us() - t0;
+  const double t5 = now_us();
+  c->aln_us += t5 - t0;
+  c->aln_stage_us[0] += t1 - t0; c->aln_stage_us[1] += t2 - t1; c->aln_stage_us[2] += t3 - t2; c->aln_stage_us[3] += t4 - t3; c->aln_stage_us[4] += t5 - t4;
+  c->aln_batches++;
   return 0;
 }
 
@@ -1333,7 +1362,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
-      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
+      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->delta_dev.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
       s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); drop_stage(s->stage);
     }
@@ -2143,6 +2172,12 @@ int64_t gaml_hip_align_window(gaml_hip_ctx* c, int rs, int mate, const int32_t* 
   return m->wins[id].count;
 }
 
+int gaml_hip_compact_tables(gaml_hip_ctx* c) {
+  if (!c) return GAML_HIP_EINVAL;
+  for (auto& ps : c->paireds) ps->compact_requested = true;
+  return GAML_HIP_OK;
+}
+
 int gaml_hip_debug_prepare(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t n_paths) {
   if (!c || n_paths < 0 || (n_paths > 0 && (!flat || !offs))) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
@@ -2197,6 +2232,9 @@ int gaml_hip_aligner_stats(gaml_hip_ctx* c, int64_t* windows, int64_t* candidate
   if (windows) *windows = c->aln_windows;
   if (candidates) *candidates = c->aln_candidates;
   if (microseconds) *microseconds = c->aln_us;
+  if (getenv("GAML_HIP_TRACE_ALIGNER"))
+    fprintf(stderr, "aligner: %lld batches; us: strings+upload %.0f, spans+candidates %.0f, extension %.0f, hits D2H %.0f, sort+finalize %.0f\n",
+            (long long)c->aln_batches, c->aln_stage_us[0], c->aln_stage_us[1], c->aln_stage_us[2], c->aln_stage_us[3], c->aln_stage_us[4]);
   return GAML_HIP_OK;
 }
 

@@ -200,6 +200,13 @@ int gaml_hip_eval_finish_async(gaml_hip_ctx* ctx, void* d_partials, void* hip_st
 /* wait for everything enqueued on the library's private stream */
 int gaml_hip_sync(gaml_hip_ctx* ctx);
 
+/* Maintenance hint.  Windows aligned after the device record tables of a paired set were built are
+ * scored from delta lists (slightly slower per pair); the library folds them into the tables by
+ * itself when they grow past 1/16 of the pairs or after 64 evaluations without a new window.  This
+ * call asks for the fold at the next evaluation -- e.g. after a warm-up phase, before a long run of
+ * re-scoring.  Results do not change (only the order of the final sum, i.e. last bits). */
+int gaml_hip_compact_tables(gaml_hip_ctx* ctx);
+
 /* Sharded evaluation with a coverage penalty (penalty_constant > 0 on a paired set; SURVEY 8e "the one
  * non-separable piece").  bad_bases (graph.cc:1893-1919) is a function of the union of every rank's
  * well-aligned pair positions, so the sweep has to wait for the other ranks' coverage maps:

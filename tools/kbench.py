@@ -13,7 +13,8 @@ ctx = api.Context(device=0)
 ctx.set_graph(*g.packed())
 rs = ctx.add_paired(api.paired_cfg(300.0, 30.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
 variants = [api.FlatPaths(v) for v in bench.path_variants(synth.genome_walk(g))]
-[ctx.calc_prob(v) for v in variants]  # prime: activates every window (device order settles)
+[ctx.calc_prob(v) for v in variants]  # prime: activates every window
+ctx.compact_tables()  # fold the delta lists into the device tables (device order settles)
 ref = [ctx.calc_prob(v)[0] for v in variants]
 settings = eval(sys.argv[2]) if len(sys.argv) > 2 else [{}]
 ctx.set_event_timing(True)

@@ -17,11 +17,14 @@ genome = synth.make_genome(wl.genome_len, wl.seed)
 g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
 pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
 ctx = api.Context(device=0)
+if os.environ.get("GAML_HIP_TRACE_ALIGNER"):
+    ctx.debug_set_knob(9, 1)  # separate the extension kernel from its D2H copy in the stage timings
 ctx.set_graph(*g.packed())
 rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
 walk = synth.genome_walk(g)
 start = [[x] for x in walk if g.node_len(x) > 500]  # gaml.cc:1002-1005
 t0 = time.time(); v0 = ctx.calc_prob(start); t_first = time.time() - t0
+print('after the first call:', ctx.aligner_stats(), flush=True)
 rng = np.random.default_rng(7)
 seq, cur = [], start
 for it in range(iters):
