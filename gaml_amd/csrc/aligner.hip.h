@@ -133,36 +133,86 @@ __global__ __launch_bounds__(kAlnBlock) void candidates_kernel(const AlnSpan* sp
 //    Heads leave the FIFO in non-decreasing cost; cost > 3 ends the search. Visited cells: one
 //    256-bit set per diagonal shift in [-4, 4].
 // ---------------------------------------------------------------------------------------------
-struct AlnSearch {
-  uint32_t q[128];        // heads: r+1 (10 bits) | diag+4 (4 bits) | cost (3 bits)
-  uint64_t vis[9][4];
-  int qn;
-  __device__ __forceinline__ void reset() {
-    qn = 0;
-    for (int k = 0; k < 9; k++) for (int t = 0; t < 4; t++) vis[k][t] = 0;
-  }
-  __device__ __forceinline__ bool mark(int diag, int r) {  // true if (diag, r) was unvisited
-    const int b = r + 1;
-    const uint64_t m = 1ull << (b & 63);
-    uint64_t& w = vis[diag + 4][b >> 6];
-    if (w & m) return false;
-    w |= m;
-    return true;
-  }
-  __device__ __forceinline__ void push(int d, int diag, int r) { if (qn < 128) q[qn++] = (uint32_t)(r + 1) | ((uint32_t)(diag + 4) << 10) | ((uint32_t)d << 14); }
+// One WAVE per candidate. A single lane running the search serially spends ~0.5 us per visited
+// cell (dependent LDS / memory operations of a lone wave), i.e. ~0.3 ms per launch whatever the batch
+// size; but nearly all cells of a search are runs of matching bases along one diagonal. The wave
+// compares 64 cells of the current diagonal at once (one ballot finds the first cell where the run
+// stops and why), marks the run in the visited set with a handful of word operations, and only the
+// bookkeeping at a mismatch (<= 3 successors) is scalar. Same states, same order, same visited
+// semantics as the FIFO-of-chain-heads search above, so the same records.
+constexpr int kAlnQueue = 128;                 // heads: r+1 (8 bits) | diag+4 (4 bits) | cost (3 bits)
+constexpr int kAlnWinSeg = kAlnMaxRead + 18;   // window bases a search can touch (read length + 2 x 4 diagonals + slack)
+constexpr int kAlnWaves = 4;                   // candidates per block
+struct AlnWaveLds {
+  unsigned char rd[kAlnMaxRead + 2];           // the read as aligned (strand applied)
+  unsigned char ws[kAlnWinSeg + 2];            // window segment, 0 beyond the window's end
+  unsigned char seed[16];
+  uint32_t vis[9 * 8];                         // 256-bit visited set per diagonal shift in [-4, 4]; bit = read index + 1
+  unsigned short q[kAlnQueue];
 };
 
-// rd(i): base i of the read as aligned (strand 1: reverse complement of the stored read)
-__device__ __forceinline__ char aln_rbase(const char* read, int R, int strand, int i) {
-  return strand == 0 ? read[i] : aln_comp(read[R - 1 - i]);
+__device__ __forceinline__ void aln_lds_sync() {  // LDS traffic of ONE wave: in order in hardware, keep the compiler from reordering
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(64) void extend_kernel(const AlnCand* cands, const unsigned* n_cands, unsigned cap_cands,
-                                                    const char* wstr, const AlnWindow* wins, const char* reads,
-                                                    const int64_t* read_off, AlnHit* hits) {
+struct AlnWaveSearch {
+  AlnWaveLds& L;
+  const int lane;
+  int qn;
+  __device__ __forceinline__ AlnWaveSearch(AlnWaveLds& l, int ln) : L(l), lane(ln), qn(0) {}
+  __device__ __forceinline__ void reset() {
+    qn = 0;
+    L.vis[lane] = 0;
+    if (lane < 8) L.vis[64 + lane] = 0;
+    aln_lds_sync();
+  }
+  // wave-uniform arguments: true if (diag, r) was unvisited (then it is marked)
+  __device__ __forceinline__ bool mark(int diag, int r) {
+    const int b = r + 1;
+    const uint32_t m = 1u << (b & 31);
+    const int w = (diag + 4) * 8 + (b >> 5);
+    const uint32_t old = L.vis[w];
+    if (old & m) return false;
+    if (lane == 0) L.vis[w] = old | m;
+    aln_lds_sync();
+    return true;
+  }
+  __device__ __forceinline__ void push(int d, int diag, int r) {
+    if (qn < kAlnQueue) {
+      if (lane == 0) L.q[qn] = (unsigned short)((r + 1) | ((diag + 4) << 8) | (d << 12));
+      qn++;
+    }
+  }
+  __device__ __forceinline__ bool visited(int diag, int r) const {  // per-lane r
+    const int b = r + 1;
+    return (L.vis[(diag + 4) * 8 + (b >> 5)] >> (b & 31)) & 1u;
+  }
+  // mark read indices [r_lo, r_hi] (inclusive) of one diagonal: lanes 0..7 own one word each
+  __device__ __forceinline__ void mark_range(int diag, int r_lo, int r_hi) {
+    if (lane < 8 && r_hi >= r_lo) {
+      const int lo = r_lo + 1, hi = r_hi + 1;  // bit range, inclusive
+      const int w0 = 32 * lane;
+      const int a = max(lo, w0), b = min(hi, w0 + 31);
+      if (a <= b) {
+        const uint32_t m = (b - a == 31 ? 0xffffffffu : ((1u << (b - a + 1)) - 1u)) << (a - w0);
+        L.vis[(diag + 4) * 8 + lane] |= m;
+      }
+    }
+    aln_lds_sync();
+  }
+};
+
+__global__ __launch_bounds__(64 * kAlnWaves) void extend_kernel(const AlnCand* cands, const unsigned* n_cands, unsigned cap_cands,
+                                                                const char* wstr, const AlnWindow* wins, const char* reads,
+                                                                const int64_t* read_off, AlnHit* hits) {
+  __shared__ AlnWaveLds lds_all[kAlnWaves];
   const unsigned n = *n_cands < cap_cands ? *n_cands : cap_cands;
-  const unsigned t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= n) return;
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned t = blockIdx.x * kAlnWaves + (threadIdx.x >> 6);  // candidate of this wave
+  if (t >= n) return;                                              // whole waves leave together
+  AlnWaveLds& L = lds_all[threadIdx.x >> 6];
   const AlnCand c = cands[t];
   AlnHit out{c.win, 0, -1, c.read, c.strand, c.order};
   const AlnWindow win = wins[c.win];
@@ -170,47 +220,81 @@ __global__ __launch_bounds__(64) void extend_kernel(const AlnCand* cands, const 
   const int W = win.len;
   const char* rd = reads + read_off[c.read];
   const int R = (int)(read_off[c.read + 1] - read_off[c.read]);
+  if (R > kAlnMaxRead || R < kAlnSeed) { if (lane == 0) hits[t] = out; return; }
   // seed start in the forward window string (graph.cc:866-872)
   const int win_pos = c.strand == 0 ? c.seed_end - kAlnSeed + 1 : W - (c.seed_end + 1);
-  // first position of the (oriented) read carrying the window's seed (graph.cc:873-879)
-  int read_pos = -1;
-  for (int i = 0; i + kAlnSeed <= R && read_pos < 0; i++) {
-    bool same = true;
-    for (int k = 0; k < kAlnSeed && same; k++) same = aln_rbase(rd, R, c.strand, i + k) == ws[win_pos + k];
-    if (same) read_pos = i;
+  // the read as aligned: strand 1 = reverse complement of the stored read (graph.cc:873-876); coalesced
+  for (int b = lane; b < R; b += 64) {
+    const char ch = rd[b];
+    if (c.strand == 0) L.rd[b] = (unsigned char)ch;
+    else L.rd[R - 1 - b] = (unsigned char)aln_comp(ch);
   }
-  if (read_pos < 0 || R > kAlnMaxRead) { hits[t] = out; return; }
-  AlnSearch S;
+  if (lane < kAlnSeed) L.seed[lane] = (unsigned char)ws[win_pos + lane];
+  aln_lds_sync();
+  // first position of the (oriented) read carrying the window's seed (graph.cc:873-879): 64 positions at a time
+  int read_pos = -1;
+  for (int base = 0; base + kAlnSeed <= R && read_pos < 0; base += 64) {
+    const int i = base + lane;
+    bool same = i + kAlnSeed <= R;
+#pragma unroll
+    for (int k = 0; k < kAlnSeed; k++) same = same && L.rd[min(i + k, kAlnMaxRead)] == L.seed[k];
+    const unsigned long long hit = __ballot(same);
+    if (hit) read_pos = base + (__ffsll((long long)hit) - 1);
+  }
+  if (read_pos < 0) { if (lane == 0) hits[t] = out; return; }
+  // window bases the search can touch: g = win_pos + (r - read_pos) + diag, r in [-1, R], |diag| <= 4
+  const int g0 = max(0, win_pos - read_pos - 6);
+  const int seg = min(kAlnWinSeg, win_pos + (R - read_pos) + 6 - g0);
+  for (int b = lane; b < seg; b += 64) L.ws[b] = (unsigned char)(g0 + b < W ? ws[g0 + b] : '\0');  // the reference reads the terminator at g == W
+  aln_lds_sync();
+  auto wbase = [&](int g) -> unsigned char { const int i = g - g0; return (i >= 0 && i < seg) ? L.ws[i] : (unsigned char)'\0'; };
+  AlnWaveSearch S(L, lane);
   // ---- forward (graph.cc:761-793)
-  int fwd = -1, end_pos = -1;
+  int fwd = -1;
   S.reset();
   S.push(0, 0, read_pos + kAlnSeed);
+  aln_lds_sync();
   for (int qi = 0; qi < S.qn && fwd < 0; qi++) {
-    const uint32_t e = S.q[qi];
-    const int d = (int)(e >> 14), diag = (int)((e >> 10) & 15) - 4;
-    int r = (int)(e & 1023) - 1;
+    const uint32_t e = L.q[qi];
+    const int d = (int)(e >> 12), diag = (int)((e >> 8) & 15) - 4;
+    int r = (int)(e & 255) - 1;
     int g = win_pos + (r - read_pos) + diag;
-    if (d > 3) { hits[t] = out; return; }
+    if (d > 3) { if (lane == 0) hits[t] = out; return; }
     while (true) {
-      if (r == R) { fwd = d; end_pos = g - 1; break; }
-      const char wc = g < W ? ws[g] : '\0';  // the reference reads the string terminator at g == W
-      if (wc == aln_rbase(rd, R, c.strand, r)) {
-        if (g + 1 < W || r + 1 == R) {
-          if (!S.mark(diag, r + 1)) break;
-          g++; r++;
-          continue;
+      // lane k looks at cell (g + k, r + k) of the diagonal
+      const int rr = r + lane, gg = g + lane;
+      const bool at_end = rr == R;
+      bool stop = at_end, mism = false;
+      if (rr < R) {
+        const bool match = wbase(gg) == L.rd[rr];
+        const bool may_advance = gg + 1 < W || rr + 1 == R;
+        mism = !match;
+        stop = !match || !may_advance || S.visited(diag, rr + 1);
+      }
+      const unsigned long long stops = __ballot(stop && rr <= R);
+      if (!stops) {  // 64 matching, unvisited cells: the run goes on
+        S.mark_range(diag, r + 1, r + 64);
+        g += 64; r += 64;
+        continue;
+      }
+      const int k = __ffsll((long long)stops) - 1;
+      S.mark_range(diag, r + 1, r + k);  // the cells the run moved into
+      const bool end_here = (__ballot(at_end) >> k) & 1ull;
+      const bool mism_here = (__ballot(mism) >> k) & 1ull;
+      g += k; r += k;
+      if (end_here) { fwd = d; break; }
+      if (mism_here) {
+        if (g + 1 < W) {
+          if (S.mark(diag, r + 1)) S.push(d + 1, diag, r + 1);          // substitution
+          if (S.mark(diag + 1, r)) S.push(d + 1, diag + 1, r);          // window base skipped
         }
-        break;
+        if (S.mark(diag - 1, r + 1)) S.push(d + 1, diag - 1, r + 1);    // read base skipped
+        aln_lds_sync();
       }
-      if (g + 1 < W) {
-        if (S.mark(diag, r + 1)) S.push(d + 1, diag, r + 1);          // substitution
-        if (S.mark(diag + 1, r)) S.push(d + 1, diag + 1, r);          // window base skipped
-      }
-      if (S.mark(diag - 1, r + 1)) S.push(d + 1, diag - 1, r + 1);    // read base skipped
-      break;
+      break;  // mismatch handled, or the run ended at the window's edge / a visited cell
     }
   }
-  if (fwd < 0) { hits[t] = out; return; }
+  if (fwd < 0) { if (lane == 0) hits[t] = out; return; }
   // ---- backward (graph.cc:794-835)
   int bwd = -1, begin_pos = -1;
   if (win_pos == 0) {
@@ -218,35 +302,52 @@ __global__ __launch_bounds__(64) void extend_kernel(const AlnCand* cands, const 
   } else {
     S.reset();
     S.push(0, 0, read_pos - 1);
+    aln_lds_sync();
     for (int qi = 0; qi < S.qn && bwd < 0; qi++) {
-      const uint32_t e = S.q[qi];
-      const int d = (int)(e >> 14), diag = (int)((e >> 10) & 15) - 4;
-      int r = (int)(e & 1023) - 1;
+      const uint32_t e = L.q[qi];
+      const int d = (int)(e >> 12), diag = (int)((e >> 8) & 15) - 4;
+      int r = (int)(e & 255) - 1;
       int g = win_pos + (r - read_pos) + diag;
-      if (d > 3) { hits[t] = out; return; }
+      if (d > 3) { if (lane == 0) hits[t] = out; return; }
       while (true) {
-        if (r == -1) { bwd = d; begin_pos = g + 1; break; }
-        if (ws[g] == aln_rbase(rd, R, c.strand, r)) {
-          if (g - 1 >= 0 || r - 1 == -1) {
-            if (!S.mark(diag, r - 1)) break;
-            g--; r--;
-            continue;
+        // lane k looks at cell (g - k, r - k)
+        const int rr = r - lane, gg = g - lane;
+        const bool at_end = rr == -1;
+        bool stop = at_end, mism = false;
+        if (rr >= 0) {
+          const bool match = wbase(gg) == L.rd[rr];
+          const bool may_advance = gg - 1 >= 0 || rr - 1 == -1;
+          mism = !match;
+          stop = !match || !may_advance || S.visited(diag, rr - 1);
+        }
+        const unsigned long long stops = __ballot(stop && rr >= -1);
+        if (!stops) {
+          S.mark_range(diag, r - 64, r - 1);
+          g -= 64; r -= 64;
+          continue;
+        }
+        const int k = __ffsll((long long)stops) - 1;
+        S.mark_range(diag, r - k, r - 1);
+        const bool end_here = (__ballot(at_end) >> k) & 1ull;
+        const bool mism_here = (__ballot(mism) >> k) & 1ull;
+        g -= k; r -= k;
+        if (end_here) { bwd = d; begin_pos = g + 1; break; }
+        if (mism_here) {
+          if (g - 1 >= 0) {
+            if (S.mark(diag, r - 1)) S.push(d + 1, diag, r - 1);
+            if (S.mark(diag - 1, r)) S.push(d + 1, diag - 1, r);
           }
-          break;
+          if (S.mark(diag + 1, r - 1)) S.push(d + 1, diag + 1, r - 1);
+          aln_lds_sync();
         }
-        if (g - 1 >= 0) {
-          if (S.mark(diag, r - 1)) S.push(d + 1, diag, r - 1);
-          if (S.mark(diag - 1, r)) S.push(d + 1, diag - 1, r);
-        }
-        if (S.mark(diag + 1, r - 1)) S.push(d + 1, diag + 1, r - 1);
         break;
       }
     }
   }
-  if (bwd < 0) { hits[t] = out; return; }
+  if (bwd < 0) { if (lane == 0) hits[t] = out; return; }
   out.pos = begin_pos + 1 + win.offset;  // graph.cc:890
   out.edit = fwd + bwd;
-  hits[t] = out;
+  if (lane == 0) hits[t] = out;
 }
 
 }  // namespace gaml

@@ -14,6 +14,7 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "aligner.hip.h"
@@ -1125,7 +1126,7 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
   HIP_TRY(c, S.wins.reserve(nw * sizeof(AlnWindow)));
   HIP_TRY(c, S.hbuf_off.reserve(nw * sizeof(int64_t)));
   HIP_TRY(c, S.hbuf.reserve(std::max<int64_t>(16, hbuf_total * 4)));
-  HIP_TRY(c, S.counters.reserve(16));
+  HIP_TRY(c, S.counters.reserve(256));
   if (!wstr.empty()) HIP_TRY(c, hipMemcpy(S.wstr.p, wstr.data(), wstr.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(S.wins.p, wins.data(), nw * sizeof(AlnWindow), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(S.hbuf_off.p, hoff.data(), nw * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -1157,37 +1158,61 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
   std::vector<AlnHit> hits(nc);
   if (nc) {
     HIP_TRY(c, S.hits.reserve((size_t)nc * sizeof(AlnHit)));
-    hipLaunchKernelGGL(extend_kernel, dim3((nc + 63) / 64), dim3(64), 0, 0, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1,
+    hipLaunchKernelGGL(extend_kernel, dim3((nc + kAlnWaves - 1) / kAlnWaves), dim3(64 * kAlnWaves), 0, 0, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1,
                        (unsigned)cap_cands, S.wstr.as<char>(), S.wins.as<AlnWindow>(), d.reads.as<char>(), d.read_off.as<int64_t>(),
                        S.hits.as<AlnHit>());
     HIP_TRY(c, hipGetLastError());
-    if (c->knobs[9]) { HIP_TRY(c, hipDeviceSynchronize()); t3 = now_us(); }
+    if (c->knobs[9]) {
+      HIP_TRY(c, hipDeviceSynchronize()); t3 = now_us();
+    }
     HIP_TRY(c, hipMemcpy(hits.data(), S.hits.p, (size_t)nc * sizeof(AlnHit), hipMemcpyDeviceToHost));
   }
   const double t4 = now_us();
   if (!c->knobs[9]) t3 = t4;
   // per window: sort by (position, read), the first alignment found for a key survives
-  // (graph.cc:841, 891, 895-897); per read its candidates are visited forward-strand spans first
-  std::vector<AlnHit> ok;
-  ok.reserve(nc);
-  for (const AlnHit& h : hits) if (h.edit >= 0) ok.push_back(h);
-  std::sort(ok.begin(), ok.end(), [](const AlnHit& a, const AlnHit& b) {
-    if (a.win != b.win) return a.win < b.win;
-    if (a.pos != b.pos) return a.pos < b.pos;
-    if (a.read != b.read) return a.read < b.read;
-    if (a.strand != b.strand) return a.strand < b.strand;
-    return a.order < b.order;
-  });
-  size_t at = 0;
+  // (graph.cc:841, 891, 895-897); per read its candidates are visited forward-strand spans first.
+  // Hits are bucketed by window first (counting sort), then every window is sorted on its own --
+  // large batches on a few host threads.
+  std::vector<int64_t> wstart(nw + 1, 0);
+  for (const AlnHit& h : hits) if (h.edit >= 0) wstart[h.win + 1]++;
+  for (int k = 0; k < nw; k++) wstart[k + 1] += wstart[k];
+  std::vector<AlnHit> ok((size_t)wstart[nw]);
+  {
+    std::vector<int64_t> fill(wstart.begin(), wstart.end() - 1);
+    for (const AlnHit& h : hits) if (h.edit >= 0) ok[(size_t)fill[h.win]++] = h;
+  }
+  auto sort_range = [&](int k0, int k1) {
+    for (int k = k0; k < k1; k++)
+      std::sort(ok.begin() + wstart[k], ok.begin() + wstart[k + 1], [](const AlnHit& a, const AlnHit& b) {
+        if (a.pos != b.pos) return a.pos < b.pos;
+        if (a.read != b.read) return a.read < b.read;
+        if (a.strand != b.strand) return a.strand < b.strand;
+        return a.order < b.order;
+      });
+  };
+  const int n_threads = ok.size() > (size_t)200000 ? (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  if (n_threads > 1) {
+    // contiguous window ranges of about equal hit counts
+    std::vector<std::thread> pool;
+    int k0 = 0;
+    for (int t = 0; t < n_threads; t++) {
+      const int64_t target = wstart[nw] * (t + 1) / n_threads;
+      int k1 = k0;
+      while (k1 < nw && wstart[k1 + 1] <= target) k1++;
+      if (t == n_threads - 1) k1 = nw;
+      pool.emplace_back(sort_range, k0, k1);
+      k0 = k1;
+    }
+    for (auto& th : pool) th.join();
+  } else {
+    sort_range(0, nw);
+  }
   std::vector<gaml_aligment> recs;
   for (int k = 0; k < nw; k++) {
     recs.clear();
-    size_t begin = at;
-    while (at < ok.size() && ok[at].win == k) {
-      if (at == begin || ok[at].pos != ok[at - 1].pos || ok[at].read != ok[at - 1].read)
+    for (int64_t at = wstart[k]; at < wstart[k + 1]; at++)
+      if (at == wstart[k] || ok[at].pos != ok[at - 1].pos || ok[at].read != ok[at - 1].read)
         recs.push_back(gaml_aligment{ok[at].pos, ok[at].edit, ok[at].read, ok[at].strand});
-      at++;
-    }
     m.finalize_window(m.pending[k], recs);
   }
   m.pending.clear();
