@@ -35,10 +35,12 @@ for it in range(iters):
 flat = [api.FlatPaths(p) for p in seq]
 t0 = time.time(); vals = []
 per = []
+prof = []
 for f in flat:
-    t1 = time.perf_counter(); vals.append(ctx.calc_prob(f)[0]); per.append(time.perf_counter() - t1)
+    t1 = time.perf_counter(); vals.append(ctx.calc_prob(f)[0]); per.append(time.perf_counter() - t1); prof.append(ctx.debug_profile())
 t_gpu = time.time() - t0
 per = np.array(per) * 1e3
+print("median profile us [pass1, tables, ovf+occ8, pack, h2d_enq, launch, bytes, wait]:", np.round(np.median(np.array(prof), axis=0), 1))
 print(f"first CalcProb (start state, cold): {t_first:.2f} s  value {v0[0]:.6f}")
 print(f"{iters} SA-pattern CalcProb calls: {t_gpu:.2f} s total, per call median {np.median(per):.3f} ms, p90 {np.percentile(per, 90):.3f} ms, max {per.max():.1f} ms")
 print("aligner:", ctx.aligner_stats(), "tables:", ctx.debug_table_stats(rs), "windows:", ctx.window_count(rs, 0), "paths now:", len(cur))
