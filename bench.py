@@ -129,10 +129,9 @@ def main():
         if scorer is not None:
             prob, zeros, _ = scorer.calc_prob(paths)  # cold path: maxima exchange; every step: one all-reduce(sum) of 4 f64
             return prob, zeros
-        pending, tl = ctx.eval_begin(paths)
-        part = ctx.eval_finish()  # kernels + 32-B D2H + stream sync inside the library: CalcProb is blocking
-        prob, zeros = ctx.combine_partials(part, tl)
-        return prob, zeros
+        # ONE ABI call, like the reference's CalcProb(paths): registration, kernels, the per-block partials
+        # land in pinned host memory, the library adds them up and returns the value (blocking)
+        return ctx.score(paths), None
 
     # prime: align every window any variant needs (cold path, untimed), then warm-up steps
     t0 = time.time()

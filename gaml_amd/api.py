@@ -197,6 +197,7 @@ class FlatPaths:
     def __init__(self, paths):
         self.flat, self.offs = _flat(paths)
         self.n = len(paths)
+        self.flat_ptr, self.offs_ptr = self.flat.ctypes.data, self.offs.ctypes.data  # for Context.score
 
     def __len__(self):
         return self.n
@@ -227,6 +228,7 @@ class Context:
         elif presharded != 1:
             self._check(_lib.gaml_hip_set_presharded(self._h, presharded))
         self.rank, self.world = rank, world
+        self._fast = None
 
     def close(self):
         if self._h:
@@ -338,6 +340,29 @@ class Context:
         zeros = np.zeros(2 * max(1, self.num_readsets()), np.int32)
         self._check(_lib.gaml_hip_calc_prob(self._h, flat, offs, len(paths), C.byref(prob), zeros, C.byref(tl)))
         return prob.value, zeros.reshape(-1, 2)[: self.num_readsets()].copy(), tl.value
+
+    def score(self, fp: "FlatPaths") -> float:
+        """gaml_hip_calc_prob with the least Python around it (what a C++ caller's `CalcProb(paths)` costs):
+        prebuilt FlatPaths, raw pointers, preallocated outputs. zeros / total_len of the call stay in
+        self.last_zeros / self.last_total_len."""
+        if self._fast is None:
+            proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
+            self._fast = proto(("gaml_hip_calc_prob", _lib))
+            self._prob, self._tl = C.c_double(), C.c_int32()
+            self._zeros = np.zeros(2 * max(1, self.num_readsets()), np.int32)
+            self._out_ptrs = (C.addressof(self._prob), self._zeros.ctypes.data, C.addressof(self._tl))
+        rc = self._fast(self._h, fp.flat_ptr, fp.offs_ptr, fp.n, *self._out_ptrs)
+        if rc < 0:
+            self._check(rc)
+        return self._prob.value
+
+    @property
+    def last_zeros(self):
+        return self._zeros.reshape(-1, 2)[: self.num_readsets()].copy()
+
+    @property
+    def last_total_len(self):
+        return self._tl.value
 
     def calc_prob_batch(self, path_sets):
         """[(prob, zeros, total_len)] of several path sets in one call (gaml_hip_calc_prob_batch)."""
