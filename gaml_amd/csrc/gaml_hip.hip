@@ -210,7 +210,7 @@ struct gaml_hip_ctx {
   double aln_us = 0;
   double aln_stage_us[5] = {0, 0, 0, 0, 0};  // window strings + upload, spans + candidates, extension, D2H of hits, sort + finalize
   int64_t aln_batches = 0;
-  int knobs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
+  int knobs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
   int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;
   // timing
@@ -778,7 +778,10 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : 768;  // 3 blocks per CU, ~2-3 pipelined iterations per lane at cfg3 (tools/kbench.py sweep)
   // the compact path handles 2 pairs per lane and iteration
   const int blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
-  const int blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, kMaxBlocks));
+  // the 2-record class: at most 3/4 block per CU next to the compact stream, lanes take 1-2 pairs (software pipelined);
+  // more blocks only crowd the compact class out (tools/kbench.py sweep: 312 blocks 16.4 us, 192 blocks 15.0 us)
+  const int cap1 = c->knobs[10] > 0 ? c->knobs[10] : 192;
+  const int blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, cap1));
   const int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>((n_main - n01 + kBlock - 1) / kBlock, kMaxBlocks / 4));
   const int main_blocks = blocks0 + blocks1 + blocks2;
   a.blocks0 = blocks0;
@@ -2270,7 +2273,7 @@ int gaml_hip_debug_profile(gaml_hip_ctx* c, double* out8) {
 }
 
 int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
-  if (!c || knob < 0 || knob >= 10) return GAML_HIP_EINVAL;
+  if (!c || knob < 0 || knob >= 12) return GAML_HIP_EINVAL;
   c->knobs[knob] = value;
   return GAML_HIP_OK;
 }

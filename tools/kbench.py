@@ -22,7 +22,7 @@ res = {i: [] for i in range(len(settings))}
 wall = {i: [] for i in range(len(settings))}
 for rnd in range(6):
     for si, st in enumerate(settings):
-        for k in range(8):
+        for k in range(12):
             ctx.debug_set_knob(k, st.get(k, 0))
         ctx.kernel_stats(reset=True)
         t0 = time.perf_counter()
