@@ -32,6 +32,25 @@ class ShardedScorer:
         self.d_part = torch.zeros(4 * max(1, ctx.num_readsets()), dtype=torch.float64, device="cuda")
         self._maps = None
         self._gathered = None
+        # RCCL works on device tensors; gloo (tests: several ranks sharing one GPU, or CPU-only collectives)
+        # does not support every collective on them, so there the buffers take a detour through the host
+        self._host_collectives = dist.get_backend(group) == "gloo"
+
+    def _all_reduce(self, t, op):
+        if self._host_collectives:
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op, group=self.group)
+
+    def _all_gather(self, out, own):
+        if self._host_collectives:
+            parts = [torch.empty(own.numel(), dtype=own.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, own.cpu(), group=self.group)
+            out.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(out, own, group=self.group)
 
     def _enqueue(self, paths, d_part):
         """Everything of one evaluation up to (not including) the all-reduce of its partials."""
@@ -39,7 +58,7 @@ class ShardedScorer:
         pending, total_len = ctx.eval_begin(paths)
         if pending:
             mx = torch.from_numpy(ctx.eval_pending_maxpos().copy()).cuda()
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+            self._all_reduce(mx, dist.ReduceOp.MAX)
             ctx.eval_apply_maxpos(mx.cpu().numpy())
         sp = self.stream.cuda_stream
         n_maps = ctx.eval_score_async(d_part.data_ptr(), sp)
@@ -51,14 +70,14 @@ class ShardedScorer:
             own = self._maps[:nbytes]
             gathered = self._gathered[: nbytes * self.world]
             ctx.eval_coverage_export_async(i, own.data_ptr(), nbytes, sp)
-            dist.all_gather_into_tensor(gathered, own, group=self.group)
+            self._all_gather(gathered, own)
             ctx.eval_coverage_finish_async(i, gathered.data_ptr(), self.world, self.rank == 0, sp)
         return total_len
 
     def calc_prob(self, paths):
         with torch.cuda.stream(self.stream):
             total_len = self._enqueue(paths, self.d_part)
-            dist.all_reduce(self.d_part, op=dist.ReduceOp.SUM, group=self.group)  # the one collective of the hot path
+            self._all_reduce(self.d_part, dist.ReduceOp.SUM)  # the one collective of the hot path
             part = self.d_part.cpu().numpy()  # blocking
         prob, zeros = self.ctx.combine_partials(part, total_len)
         return prob, zeros, total_len
@@ -70,7 +89,7 @@ class ShardedScorer:
         buf = torch.zeros(len(path_sets) * k, dtype=torch.float64, device="cuda")
         with torch.cuda.stream(self.stream):
             tls = [self._enqueue(paths, buf[i * k:(i + 1) * k]) for i, paths in enumerate(path_sets)]
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(buf, dist.ReduceOp.SUM)
             part = buf.cpu().numpy().reshape(len(path_sets), k)
         out = []
         for i, tl in enumerate(tls):

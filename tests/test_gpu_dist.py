@@ -59,3 +59,65 @@ def test_sharded_scorer_single_rank_group():
                 assert abs(got[0] - want[0]) <= 1e-12 * abs(want[0])
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out_dir, penalty):
+    """One of `world` processes sharing the single GPU of the test box. Collectives run over gloo (RCCL
+    refuses two ranks on one device); everything else -- one context per process holding its shard,
+    maxima exchange, coverage maps, partial sums -- is the multi-GPU path as it runs on a node."""
+    import json
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gaml_amd import api, synth
+    from gaml_amd.dist import ShardedScorer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        genome = synth.make_genome(60_000, 73)
+        g = synth.make_graph(genome, synth.cut_lengths(60_000, 73, long_rng=(900, 4000)))
+        pr = synth.make_paired_reads(genome, 1501, 100, 250.0, 25.0, 0.01, 73)  # odd: uneven shards
+        walk = synth.genome_walk(g)
+        ctx = api.Context(device=0, rank=rank, world=world)
+        ctx.set_graph(*g.packed())
+        ctx.add_paired(api.paired_cfg(250.0, 25.0, penalty_constant=penalty, penalty_step=40.0),
+                       *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+        scorer = ShardedScorer(ctx)
+        sets = [[walk], [walk[:6], walk[6:]], [walk[3:]], [walk[:6], [x ^ 1 for x in reversed(walk[6:])]]]
+        single = [scorer.calc_prob(p) for p in sets]          # cold: windows aligned, maxima exchanged
+        batch = scorer.calc_prob_batch(sets)                  # warm, one all-reduce for the four sets
+        res = {"single": [[v[0], v[1].tolist(), v[2]] for v in single], "batch": [[v[0], v[1].tolist(), v[2]] for v in batch]}
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+            json.dump(res, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("penalty", [0.0, 0.0007])
+def test_two_processes_share_the_reads(tmp_path, penalty):
+    import json
+    import torch.multiprocessing as mp
+    from gaml_amd import api
+    world, port = 2, _free_port()
+    mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path), penalty), nprocs=world, join=True)
+    ranks = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    assert ranks[0] == ranks[1]  # every rank ends up with the same values
+    # the unsharded context on the same inputs
+    genome = synth.make_genome(60_000, 73)
+    g = synth.make_graph(genome, synth.cut_lengths(60_000, 73, long_rng=(900, 4000)))
+    pr = synth.make_paired_reads(genome, 1501, 100, 250.0, 25.0, 0.01, 73)
+    walk = synth.genome_walk(g)
+    plain = api.Context(device=0)
+    plain.set_graph(*g.packed())
+    plain.add_paired(api.paired_cfg(250.0, 25.0, penalty_constant=penalty, penalty_step=40.0),
+                     *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    sets = [[walk], [walk[:6], walk[6:]], [walk[3:]], [walk[:6], [x ^ 1 for x in reversed(walk[6:])]]]
+    for k, p in enumerate(sets):
+        want, wz, tl = plain.calc_prob(p)
+        for kind in ("single", "batch"):
+            got, z, tl2 = ranks[0][kind][k]
+            assert tl2 == tl and z == wz.tolist()
+            assert abs(got - want) <= 1e-12 * abs(want), (kind, k, got, want)
