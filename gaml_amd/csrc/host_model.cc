@@ -984,8 +984,21 @@ bool read_fastq(const std::string& file, std::string& bases, std::vector<int64_t
 // ---------------------------------------------------------------------------------------
 // SAM record (ParseAligment graph.cc:2945-3021, ParseCigar :3023-3038)
 // ---------------------------------------------------------------------------------------
+namespace {
+// atoi over a character range: leading white space, optional sign, digits; 0 when there are none
+inline int32_t atoi_range(const char* p, const char* e) {
+  while (p < e && (*p == ' ' || (*p >= '\t' && *p <= '\r'))) p++;
+  bool neg = false;
+  if (p < e && (*p == '-' || *p == '+')) { neg = *p == '-'; p++; }
+  int64_t v = 0;
+  while (p < e && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); if (v > INT32_MAX) v = INT32_MAX; p++; }
+  return (int32_t)(neg ? -v : v);
+}
+}  // namespace
+
 bool parse_sam_record(const char* b, const char* e, int32_t total_len, SamRecord& a) {
-  std::vector<std::pair<const char*, const char*>> col;
+  thread_local std::vector<std::pair<const char*, const char*>> col;
+  col.clear();
   for (const char* p = b;;) {
     const char* t = (const char*)memchr(p, '\t', (size_t)(e - p));
     if (!t) { col.emplace_back(p, e); break; }
@@ -994,10 +1007,9 @@ bool parse_sam_record(const char* b, const char* e, int32_t total_len, SamRecord
   }
   if (col.size() < 10) return false;
   auto num = [&](size_t i, size_t skip = 0) {  // atoi of a column (leading digits, 0 when none)
-    std::string s(col[i].first + std::min<size_t>(skip, (size_t)(col[i].second - col[i].first)), col[i].second);
-    return (int32_t)atoi(s.c_str());
+    return atoi_range(col[i].first + std::min<size_t>(skip, (size_t)(col[i].second - col[i].first)), col[i].second);
   };
-  a = SamRecord();
+  a.name.clear(); a.cigar.clear();  // (the caller's record is reused: no reallocation per line)
   {  // name = QNAME up to its LAST '/' (empty when there is none; :2951-2957)
     const char* cut = col[0].first;
     for (const char* p = col[0].first; p < col[0].second; p++) if (*p == '/') cut = p;
@@ -1025,7 +1037,7 @@ bool parse_sam_record(const char* b, const char* e, int32_t total_len, SamRecord
     const char* from = col[5].first;
     for (const char* p = col[5].first; p < col[5].second; p++) {
       if (*p == 'M' || *p == 'I' || *p == 'D') {
-        a.cigar.emplace_back((int32_t)atoi(std::string(from, p).c_str()), *p);
+        a.cigar.emplace_back(atoi_range(from, p), *p);
         from = p + 1;
       }
     }
