@@ -156,8 +156,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
+    stamps = [0.0] * (args.steps + 1)
+    stamps[0] = t0
     for i in range(args.steps):
         last = step(variants[i % len(variants)])
+        stamps[i + 1] = time.perf_counter()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -206,6 +209,9 @@ def main():
                                    "timed region (includes ~3-5 us of dispatch latency per launch that rocprofv3's "
                                    "kernel-trace duration does not)",
                          "traffic_source": traffic_src},
+            "step_us_distribution": (lambda d: {"p50": float(np.percentile(d, 50)), "p90": float(np.percentile(d, 90)),
+                                                "p99": float(np.percentile(d, 99)), "max": float(d.max())})(
+                np.diff(np.array(stamps)) * 1e6),
             "log_likelihood": last[0], "prime_s": prime_s,
             "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
             "timing_last_step_us": ctx.last_timing(),

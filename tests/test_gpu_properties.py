@@ -82,3 +82,46 @@ def test_cfg3_full_size_shards_and_roundtrip():
         c.close()
     assert acc[1] == part[0][1] and acc[3] == wl.n_pairs
     assert abs(acc[0] - part[0][0]) <= 1e-12 * abs(part[0][0])
+
+
+def test_cfg4_two_read_sets_full_size():
+    """BASELINE config 4: 1 Mbp assembly, 100,000 pairs 2x150 (weight 1) + 5 kbp PacBio reads (weight 0.5,
+    mismatch_prob 0.15) whose alignments arrive as SAM text and go through the GPU alignment DP.
+    The oracle runs on the same inputs (all long reads; the short-read part on the full set)."""
+    import time
+    from gaml_amd import api
+    import oracle_py as op
+    wl = synth.WORKLOADS["cfg2"]
+    genome = synth.make_genome(wl.genome_len, wl.seed)
+    g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
+    pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
+    walk = synth.genome_walk(g)
+    ps = synth.make_pacbio_sam(g, walk, 300, 5000, 17)
+    rb = np.frombuffer("".join(ps.reads).encode(), np.uint8)
+    ro = np.zeros(len(ps.reads) + 1, np.int64)
+    ro[1:] = np.cumsum([len(r) for r in ps.reads])
+    pargs = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    ctx = api.Context(device=0)
+    ctx.set_graph(*g.packed())
+    ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *pargs)
+    pb = ctx.add_pacbio_reads(api.single_cfg(weight=0.5, mismatch_prob=0.15, min_prob_per_base=-1.0), rb, ro, ps.names)
+    assert ctx.pacbio_missing(pb, walk) == [(0, len(walk) - 1)]
+    t0 = time.time()
+    filed = ctx.pacbio_ingest_sam(pb, walk, ps.sam)
+    t_ingest = time.time() - t0
+    assert ctx.pacbio_missing(pb, walk) == []
+    paths_list = ([walk], [walk[:100], walk[100:]])
+    got = [ctx.calc_prob(p) for p in paths_list]
+    orc = op.Oracle()
+    orc.set_graph(*g.packed())
+    orc.add_paired(*pargs, 0.01, op.paired_cfg(wl.insert_mean, wl.insert_std))
+    ob = orc.add_pacbio_reads(rb, ro, ps.names, 0.15, op.single_cfg(weight=0.5, min_prob_per_base=-1.0))
+    t0 = time.time()
+    assert orc.pacbio_ingest_sam(ob, walk, ps.sam) == filed
+    t_cpu = time.time() - t0
+    print(f"cfg4 PacBio ingest: {filed} records, GPU path {t_ingest * 1e3:.0f} ms, oracle {t_cpu:.1f} s")
+    for p, gp in zip(paths_list, got):
+        want, wz, wtl = orc.calc_prob(p)
+        assert gp[2] == wtl and gp[1].tolist() == wz.tolist()
+        assert abs(gp[0] - want) <= 1e-9 * abs(want)  # north star: 1e-6 relative
+    assert wz[1][0] < wz[1][1] // 4  # most long reads are above their floor: the PacBio term is live
