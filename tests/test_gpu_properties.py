@@ -125,3 +125,38 @@ def test_cfg4_two_read_sets_full_size():
         assert gp[2] == wtl and gp[1].tolist() == wz.tolist()
         assert abs(gp[0] - want) <= 1e-9 * abs(want)  # north star: 1e-6 relative
     assert wz[1][0] < wz[1][1] // 4  # most long reads are above their floor: the PacBio term is live
+
+
+def test_cfg5_annealing_pattern_at_full_size_is_history_independent():
+    """BASELINE config 5's call pattern at cfg3 size: 150 edited path sets in a row (new junction windows
+    aligned on the fly, delta lists growing, tables rebuilt when due). CalcProb must stay a pure function
+    of the path set: at checkpoints the long-lived context agrees with a context that has never seen
+    anything else (same windows get aligned there from scratch), and the batch entry point agrees with
+    single calls."""
+    from gaml_amd import api
+    from test_gpu_sa_pattern import _moves
+    wl = synth.WORKLOADS["cfg3"]
+    g, pr, ctx, rs = _ctx(wl)
+    walk = synth.genome_walk(g)
+    cur = [[x] for x in walk if g.node_len(x) > 500]  # the reference's starting state (gaml.cc:1002-1005)
+    rng = np.random.default_rng(11)
+    ctx.calc_prob(cur)
+    seq = []
+    for it in range(150):
+        new = _moves(rng, cur, g)
+        seq.append(new)
+        if rng.random() < 0.6:
+            cur = new
+    vals = [ctx.calc_prob(p) for p in seq]
+    stats = ctx.debug_table_stats(rs)
+    assert stats["delta_updates"] > 5  # the delta path really ran
+    fresh = api.Context(device=0)
+    fresh.set_graph(*g.packed())
+    fresh.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    for k in (149, 60, 5):
+        want = fresh.calc_prob(seq[k])
+        assert vals[k][2] == want[2] and vals[k][1].tolist() == want[1].tolist()
+        assert abs(vals[k][0] - want[0]) <= 1e-12 * abs(want[0]), (k, vals[k][0], want[0])
+    again = ctx.calc_prob_batch([seq[149], seq[60], seq[5]])
+    for b, k in zip(again, (149, 60, 5)):
+        assert abs(b[0] - vals[k][0]) <= 1e-12 * abs(vals[k][0])
