@@ -116,11 +116,16 @@ struct PairedSet {
   std::unordered_map<int32_t, int32_t> dirty_index;  // slot -> index in `dirty`
   int64_t full_rebuilds = 0, delta_updates = 0;
   size_t dirty_marked = 0;   // delta pairs whose slots already carry the mark on the device
-  // the delta lists live in their own device buffer and travel only when they changed
-  uint64_t dirty_gen = 0, delta_uploaded_gen = ~0ull;
-  DevBuf delta_dev;
+  // The delta lists live on the device at a fixed stride (4 records per mate and pair, longer lists in
+  // a small spill CSR); an evaluation that changed some of them uploads a patch for just those pairs.
+  std::vector<int32_t> dirty_touched;   // indices into `dirty` changed since the last upload
+  std::vector<int32_t> spill_of;        // per dirty pair: index in spill_pairs or -1
+  std::vector<int32_t> spill_pairs;     // dirty indices with more than 4 records on a mate
+  bool spill_changed = false;
+  size_t delta_cap = 0;                 // pairs the device store holds
+  DevBuf dl_slot, dl_spill, dl_rec[2], dl_patch, delta_dev /* spill CSR */;
   Staging stage_delta;
-  size_t delta_off[5] = {0, 0, 0, 0, 0};  // slots, offsets mate 0, records mate 0, offsets mate 1, records mate 1
+  size_t delta_off[4] = {0, 0, 0, 0};   // spill CSR: offsets mate 0, records mate 0, offsets mate 1, records mate 1
   int quiet_calls = 0;       // evaluations since the last window activation
   bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
@@ -488,7 +493,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   const bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
   s.quiet_calls = activated_now ? 0 : s.quiet_calls + 1;
   // the cache has settled (no activation for a while) but pairs still sit on the slower delta path: fold them in
-  // A rebuild costs ~30 ms at 833 k pairs, a pair on the delta path ~1-2 ns per evaluation. In an
+  // A rebuild costs ~30 ms at 833 k pairs, a pair on the delta path ~0.4 ns per evaluation (one lane per pair). In an
   // annealing run new junction windows appear every few calls, so folding after a short quiet spell
   // (as an earlier version did after 16 calls) rebuilt 8 times per 1000 iterations for nothing;
   // 64 quiet calls mean the path set has stopped producing new windows (steady re-scoring).
@@ -498,7 +503,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     // Windows were activated since the tables were built. Few new records: keep the tables, put the
     // affected pairs on the delta list. Many: rebuild.
     const int64_t np = s.mate[0].n_local();
-    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / 16);
+    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / 8);
     size_t new_records = 0;
     for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
     if (s.dirty.size() + new_records > limit) need_full = true;
@@ -532,7 +537,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
               base_records(slot, 0, s.dirty.back().recs[0]);
               base_records(slot, 1, s.dirty.back().recs[1]);
             }
-            s.dirty_gen++;
+            s.dirty_touched.push_back(it->second);
             auto& lst = s.dirty[it->second].recs[mt];
             RecQuad q{w, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
             // keep the device-table order: (window id, position)
@@ -549,12 +554,14 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     s.dirty.clear();
     s.dirty_index.clear();
     s.dirty_marked = 0;
-    s.dirty_gen++;
+    s.dirty_touched.clear(); s.spill_of.clear(); s.spill_pairs.clear(); s.spill_changed = false;
     s.full_rebuilds++;
     for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
     // cold path: the set of activated windows of either mate changed -> new device order of the
     // pairs, record tables rebuilt on the host and uploaded
+    const double tb0 = now_us();
     build_pair_tables(s.mate[0], s.mate[1], s.pt);
+    const double tb1 = now_us();
     HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old tables
     auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
       hipError_t e = d.reserve(std::max<size_t>(16, bytes));
@@ -595,6 +602,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
       HIP_TRY(c, up(s.combo_tabs, t.data(), t.size() * sizeof(double)));
       s.lt_two_T = -1;
     }
+    if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "rebuild: tables on the host %.1f ms, uploads %.1f ms\n", (tb1 - tb0) * 1e-3, (now_us() - tb1) * 1e-3);
   }
 
   const bool cov = s.cfg.penalty_constant > 0;
@@ -657,38 +665,78 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   c->prof[6] = (double)total;
   HIP_TRY(c, hipMemcpyAsync(s.occ_arena.p, host, total, hipMemcpyHostToDevice, st));
   if (int e = stage_release(c, s.stage, slot, st)) return e;
-  // delta pairs: slots, per-mate offsets, records -- uploaded only when the lists changed (new windows
-  // were activated); otherwise the device copy of the previous evaluation is still right
-  if (nd && s.delta_uploaded_gen != s.dirty_gen) {
-    size_t dn[2] = {0, 0};
-    for (const auto& d : s.dirty) { dn[0] += d.recs[0].size(); dn[1] += d.recs[1].size(); }
-    size_t dt = 0;
-    s.delta_off[0] = dt; dt = align16(dt + nd * sizeof(int32_t));
-    for (int mt = 0; mt < 2; mt++) {
-      s.delta_off[1 + 2 * mt] = dt; dt = align16(dt + (nd + 1) * sizeof(int32_t));
-      s.delta_off[2 + 2 * mt] = dt; dt = align16(dt + std::max<size_t>(1, dn[mt]) * sizeof(RecQuad));
+  // delta pairs: a patch for the pairs whose lists changed in this evaluation (new windows were activated)
+  if (!s.dirty_touched.empty()) {
+    const int64_t np_all = s.mate[0].n_local();
+    if (s.delta_cap == 0) {  // sized once for the largest delta the rebuild policy allows: the store is never reallocated
+      s.delta_cap = (size_t)std::max<int64_t>(4096, np_all / 8) + 4096;
+      HIP_TRY(c, s.dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
+      HIP_TRY(c, s.dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
+      for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
     }
-    void* dh = nullptr;
-    int dslot = stage_acquire(c, s.stage_delta, dt, &dh);
-    if (dslot < 0) return dslot;
-    int32_t* ds = (int32_t*)((char*)dh + s.delta_off[0]);
-    for (size_t k = 0; k < nd; k++) ds[k] = s.dirty[k].slot;
-    for (int mt = 0; mt < 2; mt++) {
-      int32_t* of = (int32_t*)((char*)dh + s.delta_off[1 + 2 * mt]);
-      RecQuad* rc = (RecQuad*)((char*)dh + s.delta_off[2 + 2 * mt]);
-      int32_t at = 0;
-      for (size_t k = 0; k < nd; k++) {
-        of[k] = at;
-        const auto& l = s.dirty[k].recs[mt];
-        if (!l.empty()) memcpy(rc + at, l.data(), l.size() * sizeof(RecQuad));
-        at += (int32_t)l.size();
+    if (nd > s.delta_cap) return fail(c, GAML_HIP_ESTATE, "delta store overflow (rebuild policy violated)");
+    std::sort(s.dirty_touched.begin(), s.dirty_touched.end());
+    s.dirty_touched.erase(std::unique(s.dirty_touched.begin(), s.dirty_touched.end()), s.dirty_touched.end());
+    s.spill_of.resize(nd, -1);
+    const size_t np_patch = s.dirty_touched.size();
+    void* ph = nullptr;
+    int pslot = stage_acquire(c, s.stage_delta, np_patch * sizeof(DeltaPatch), &ph);
+    if (pslot < 0) return pslot;
+    DeltaPatch* patch = (DeltaPatch*)ph;
+    for (size_t t = 0; t < np_patch; t++) {
+      const int32_t dj = s.dirty_touched[t];
+      const auto& d = s.dirty[dj];
+      DeltaPatch& pe = patch[t];
+      pe.dj = dj; pe.slot = d.slot; pe.pad = 0;
+      const bool lng = d.recs[0].size() > 4 || d.recs[1].size() > 4;
+      if (lng) {
+        if (s.spill_of[dj] < 0) { s.spill_of[dj] = (int32_t)s.spill_pairs.size(); s.spill_pairs.push_back(dj); }
+        s.spill_changed = true;
       }
-      of[nd] = at;
+      pe.spill = s.spill_of[dj];
+      for (int mt = 0; mt < 2; mt++)
+        for (int k = 0; k < 4; k++) {
+          const RecQuad none{-1, 0, 0, 0};
+          const RecQuad& r = (!lng && k < (int)d.recs[mt].size()) ? d.recs[mt][k] : none;
+          pe.rec[mt][k] = make_int4(r.wid, r.pos, r.flags, r.link);
+        }
     }
-    if (dt > s.delta_dev.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.delta_dev.reserve(dt + dt / 2)); }
-    HIP_TRY(c, hipMemcpyAsync(s.delta_dev.p, dh, dt, hipMemcpyHostToDevice, st));  // stream order: after the kernels that read the old lists
-    if (int e = stage_release(c, s.stage_delta, dslot, st)) return e;
-    s.delta_uploaded_gen = s.dirty_gen;
+    HIP_TRY(c, s.dl_patch.reserve(np_patch * sizeof(DeltaPatch) + 1));
+    HIP_TRY(c, hipMemcpyAsync(s.dl_patch.p, ph, np_patch * sizeof(DeltaPatch), hipMemcpyHostToDevice, st));
+    if (int e = stage_release(c, s.stage_delta, pslot, st)) return e;
+    hipLaunchKernelGGL(apply_delta_patch_kernel, dim3((unsigned)std::min<size_t>((np_patch + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
+                       (const DeltaPatch*)s.dl_patch.p, (int)np_patch, s.dl_slot.as<int>(), s.dl_spill.as<int>(), s.dl_rec[0].as<int4>(), s.dl_rec[1].as<int4>());
+    HIP_TRY(c, hipGetLastError());
+    s.dirty_touched.clear();
+    if (s.spill_changed) {  // the few long lists: CSR rebuilt as a whole
+      const size_t ns = s.spill_pairs.size();
+      size_t dn[2] = {0, 0};
+      for (int32_t dj : s.spill_pairs) { dn[0] += s.dirty[dj].recs[0].size(); dn[1] += s.dirty[dj].recs[1].size(); }
+      size_t dt = 0;
+      for (int mt = 0; mt < 2; mt++) {
+        s.delta_off[2 * mt] = dt; dt = align16(dt + (ns + 1) * sizeof(int32_t));
+        s.delta_off[2 * mt + 1] = dt; dt = align16(dt + std::max<size_t>(1, dn[mt]) * sizeof(RecQuad));
+      }
+      void* dh = nullptr;
+      int dslot = stage_acquire(c, s.stage_delta, dt, &dh);
+      if (dslot < 0) return dslot;
+      for (int mt = 0; mt < 2; mt++) {
+        int32_t* of = (int32_t*)((char*)dh + s.delta_off[2 * mt]);
+        RecQuad* rc = (RecQuad*)((char*)dh + s.delta_off[2 * mt + 1]);
+        int32_t at = 0;
+        for (size_t k = 0; k < ns; k++) {
+          of[k] = at;
+          const auto& l = s.dirty[s.spill_pairs[k]].recs[mt];
+          if (!l.empty()) memcpy(rc + at, l.data(), l.size() * sizeof(RecQuad));
+          at += (int32_t)l.size();
+        }
+        of[ns] = at;
+      }
+      if (dt > s.delta_dev.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.delta_dev.reserve(dt + dt / 2)); }
+      HIP_TRY(c, hipMemcpyAsync(s.delta_dev.p, dh, dt, hipMemcpyHostToDevice, st));  // stream order: after the kernels that read the old lists
+      if (int e = stage_release(c, s.stage_delta, dslot, st)) return e;
+      s.spill_changed = false;
+    }
   }
   c->prof[4] = now_us() - tp2;  // H2D enqueue
 
@@ -772,9 +820,14 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   a.n_ovf_items = (int)s.ovf_items.size();
   a.n_dirty = (int)nd;
   const char* delta = (const char*)s.delta_dev.p;
-  a.dirty_slots = (const int*)(delta + s.delta_off[0]);
-  for (int mt = 0; mt < 2; mt++) { a.dirty_off[mt] = (const int*)(delta + s.delta_off[1 + 2 * mt]); a.dirty_recs[mt] = (const int4*)(delta + s.delta_off[2 + 2 * mt]); }
-  const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size() + (int64_t)nd;
+  a.dirty_slots = s.dl_slot.as<int>();
+  a.dirty_spill = s.dl_spill.as<int>();
+  for (int mt = 0; mt < 2; mt++) {
+    a.dirty_recs[mt] = s.dl_rec[mt].as<int4>();
+    a.spill_off[mt] = (const int*)(delta + s.delta_off[2 * mt]);
+    a.spill_recs[mt] = (const int4*)(delta + s.delta_off[2 * mt + 1]);
+  }
+  const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size();  // wave-per-pair items (delta pairs: lane per pair in the main range)
   const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : 768;  // 3 blocks per CU, ~2-3 pipelined iterations per lane at cfg3 (tools/kbench.py sweep)
   // the compact path handles 2 pairs per lane and iteration
   const int blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
@@ -783,9 +836,12 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   const int cap1 = c->knobs[10] > 0 ? c->knobs[10] : 192;
   const int blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, cap1));
   const int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>((n_main - n01 + kBlock - 1) / kBlock, kMaxBlocks / 4));
-  const int main_blocks = blocks0 + blocks1 + blocks2;
+  // delta pairs: one lane per pair behind the table classes (they used to go through the wave-per-pair path)
+  const int blocks_d = nd ? (int)std::min<int64_t>(((int64_t)nd + kBlock - 1) / kBlock, 1024) : 0;
+  const int main_blocks = blocks0 + blocks1 + blocks2 + blocks_d;
   a.blocks0 = blocks0;
   a.blocks01 = blocks0 + blocks1;
+  a.blocks012 = blocks0 + blocks1 + blocks2;
   const int ovf_blocks = ovf_total > 0 ? (int)std::min<int64_t>((ovf_total + 3) / 4, kOvfMaxBlocks) : 0;
   a.main_blocks = main_blocks;
   a.total_blocks = main_blocks + ovf_blocks;
@@ -1390,7 +1446,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
-      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->delta_dev.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
+      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
       s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); drop_stage(s->stage);
     }

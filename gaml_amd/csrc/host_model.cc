@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <thread>
 
 namespace gaml {
 
@@ -738,13 +739,33 @@ void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_re
   out.built_generation = m.active_generation;
 }
 
+namespace {
+// run fn(lo, hi) over [0, n) on a few host threads (ranges are disjoint; small inputs stay on the caller)
+template <class F>
+void parallel_ranges(int64_t n, F fn) {
+  const int nt = n < (1 << 16) ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+  if (nt == 1) { fn((int64_t)0, n); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; t++) pool.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
+  for (auto& th : pool) th.join();
+}
+template <class F>
+void parallel_mates(bool parallel, F fn) {  // fn(0) and fn(1) touch different arrays
+  if (!parallel) { fn(0); fn(1); return; }
+  std::thread other(fn, 1);
+  fn(0);
+  other.join();
+}
+}  // namespace
+
 void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) {
   const int64_t n = a.n_local();
   const ShortMate* mates[2] = {&a, &b};
   // per read: record count over ACTIVE windows, and the single record when there is exactly one
   std::vector<int32_t> k[2];
   std::vector<uint64_t> one[2];
-  for (int mt = 0; mt < 2; mt++) {
+  const bool big = n >= (1 << 16);
+  parallel_mates(big, [&](int mt) {
     k[mt].assign(n, 0);
     one[mt].assign(n, kNoRec8);
     const ShortMate& m = *mates[mt];
@@ -758,14 +779,16 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
                                                                                  : kNoRec8 - 1;  // does not fit: not class 0
       }
     }
-  }
+  });
   // length combos
   std::unordered_map<uint32_t, int32_t> combo_id;
   out.len_combo.clear();
   auto combo_of = [&](int64_t i) { return (uint32_t)a.lens[i] | ((uint32_t)b.lens[i] << 16); };
   std::vector<int32_t> lc(n, -1);
+  uint32_t last_c = 0; int32_t last_id = -2;
   for (int64_t i = 0; i < n; i++) {
     uint32_t c = combo_of(i);
+    if (last_id != -2 && c == last_c) { lc[i] = last_id; continue; }  // reads of one library mostly share their lengths
     auto it = combo_id.find(c);
     if (it == combo_id.end()) {
       if (out.len_combo.size() >= 256) continue;  // lc stays -1: not class 0
@@ -773,6 +796,7 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
       out.len_combo.push_back(c);
     }
     lc[i] = it->second;
+    last_c = c; last_id = it->second;
   }
   auto cls = [&](int64_t i) {
     int m = std::max(k[0][i], k[1][i]);
@@ -782,7 +806,7 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
   // device order: class 0 by (window of mate 1, window of mate 2, read id), other classes by
   // (class, read id). Two stable counting passes (least significant key first), O(pairs + windows).
   std::vector<uint8_t> cl(n);
-  for (int64_t i = 0; i < n; i++) cl[i] = (uint8_t)cls(i);
+  parallel_ranges(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) cl[i] = (uint8_t)cls(i); });
   const uint32_t nw1 = (uint32_t)a.wins.size() + 2, nw2 = (uint32_t)b.wins.size() + 2;
   auto key2 = [&](int32_t i) -> uint32_t {  // window of mate 2 (class 0 only); "no record" sorts last
     if (cl[i] != 0) return 0;
@@ -808,24 +832,27 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
   for (int c = 0; c < 4; c++) out.class_count[c] = 0;
   out.slot_of_read.assign(n, 0);
   out.read_of_slot.assign(n, 0);
-  for (int64_t s = 0; s < n; s++) {
-    out.read_of_slot[s] = order[s];
-    out.slot_of_read[order[s]] = (int32_t)s;
-    out.class_count[cl[order[s]]]++;
-  }
+  for (int64_t i = 0; i < n; i++) out.class_count[cl[i]]++;
+  parallel_ranges(n, [&](int64_t lo, int64_t hi) {
+    for (int64_t s = lo; s < hi; s++) { out.read_of_slot[s] = order[s]; out.slot_of_read[order[s]] = (int32_t)s; }
+  });
   const int64_t n0 = out.class_count[0];
-  for (int mt = 0; mt < 2; mt++) {
-    out.rec8[mt].resize(n0);
-    for (int64_t s = 0; s < n0; s++) out.rec8[mt][s] = one[mt][order[s]];
-  }
+  for (int mt = 0; mt < 2; mt++) out.rec8[mt].resize(n0);
   out.len_code.resize(n0);
-  for (int64_t s = 0; s < n0; s++) out.len_code[s] = (uint8_t)lc[order[s]];
+  parallel_ranges(n0, [&](int64_t lo, int64_t hi) {
+    for (int64_t s = lo; s < hi; s++) {
+      const int32_t r = order[s];
+      out.rec8[0][s] = one[0][r];
+      out.rec8[1][s] = one[1][r];
+      out.len_code[s] = (uint8_t)lc[r];
+    }
+  });
   out.len12.resize(n - n0);
   for (int64_t s = n0; s < n; s++) out.len12[s - n0] = combo_of(order[s]);
   // 16-byte tables of the remaining slots, indexed slot - n0
   std::vector<int32_t> slot16(n, -1);
   for (int64_t s = n0; s < n; s++) slot16[order[s]] = (int32_t)(s - n0);
-  for (int mt = 0; mt < 2; mt++) {
+  parallel_mates(big, [&](int mt) {
     const ShortMate& m = *mates[mt];
     ReadMajor& rm = out.rm[mt];
     const int64_t n16 = n - n0;
@@ -866,7 +893,7 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
         dst[q] = r;
       }
     }
-  }
+  });
 }
 
 static inline uint64_t occ8_pack(const OccQuad& q, bool general) {

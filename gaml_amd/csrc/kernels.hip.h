@@ -60,8 +60,8 @@ struct PairedArgs {
   int lt_codes;              // codes covered (< lt_codes), edits < 7
   const int4* inl[2];        // inline records of the register classes: [2t + k] (class 1), [2 n1 + 4 t2 + k] (class 2)
   int n0;                    // first[] / extra[] / len12[] hold slots >= n0, indexed slot - n0
-  int blocks0;               // blocks [0, blocks0): compact path; [blocks0, blocks01): <= 2 records; [blocks01, main_blocks): <= 4
-  int blocks01;
+  int blocks0;               // blocks [0, blocks0): compact path; [blocks0, blocks01): <= 2 records; [blocks01, blocks012): <= 4;
+  int blocks01, blocks012;   // [blocks012, main_blocks): delta pairs (lane per pair)
   int n01;                   // slots [n0, n01): class 1 (<= 2 records per mate); [n01, n_main): class 2 (<= 4)
   int n_main;                // the lane-per-pair paths score slots [0, n_main)
   const int* ovf_items;      // host-built list: slots < n_main that touch a window occurring several times
@@ -71,9 +71,11 @@ struct PairedArgs {
   // windows). Their slots carry a DIRTY mark in the tables; their complete record lists travel with
   // every evaluation and the overflow path scores them.
   int n_dirty;
-  const int* dirty_slots;     // [n_dirty]
-  const int* dirty_off[2];    // [n_dirty + 1] per mate
-  const int4* dirty_recs[2];  // {wid, pos, edit | orient<<8, 0}
+  const int* dirty_slots;     // [n_dirty] slot of the pair in the tables
+  const int4* dirty_recs[2];  // [4 * n_dirty] per mate: the pair's complete record list {wid, pos, edit | orient<<8, 0}, padded with wid = -1
+  const int* dirty_spill;     // [n_dirty] -1, or the pair's index in the spill lists (more than 4 records on a mate)
+  const int* spill_off[2];    // CSR of the spill lists
+  const int4* spill_recs[2];
   double* part_sum;          // per-block partials: main kernel blocks, then overflow kernel blocks
   int* part_zero;
   unsigned* ticket;          // zero before first launch; the last block resets it
@@ -261,11 +263,9 @@ struct RegCands {
 
 // K inline records -> register candidates incl. the overwrite rule (all K loads independent)
 template <int K>
-__device__ __forceinline__ bool load_cands_inline(const MateView& v, const int4* rec, RegCands<K>& c) {
-  int4 r[K], o[K];
+__device__ __forceinline__ bool cands_from_records(const MateView& v, const int4 (&r)[K], RegCands<K>& c) {
+  int4 o[K];
   bool multi = false;
-#pragma unroll
-  for (int k = 0; k < K; k++) r[k] = rec[k];
 #pragma unroll
   for (int k = 0; k < K; k++) o[k] = r[k].x >= 0 ? v.occ[r[k].x] : make_int4(0, 0, -1, 0);
 #pragma unroll
@@ -284,6 +284,13 @@ __device__ __forceinline__ bool load_cands_inline(const MateView& v, const int4*
     c.live[i] = lv;
   }
   return multi;
+}
+template <int K>
+__device__ __forceinline__ bool load_cands_inline(const MateView& v, const int4* rec, RegCands<K>& c) {
+  int4 r[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) r[k] = rec[k];
+  return cands_from_records<K>(v, r, c);
 }
 
 template <int K>
@@ -493,21 +500,11 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
   }
 }
 
-// Classes 1 and 2: at most K = 2 / 4 records per mate, 16-byte records, overwrite rule in registers.
-// Slots [slot_lo, slot_hi), blocks [block_lo, block_hi).
-template <int K, int ABL>
-__device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
-                                                 double& lsum, int& zeros) {
-  if (ABL >= 1 && ABL != 4) return;  // ablations 1,2,3,5: compact classes alone; 4: compact stream-only + these classes in full
-  for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
-    const int t = i - a.n0;
-    const uint32_t l12 = a.len12[t];
-    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-    const size_t at = K == 2 ? (size_t)2 * (i - a.n0) : (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01);
-    if (a.inl[0][at].x == kDirtyWid) continue;  // scored by the overflow path from the delta lists
-    RegCands<K> x, y;
-    const bool m1 = load_cands_inline<K>(a.m[0], a.inl[0] + at, x), m2 = load_cands_inline<K>(a.m[1], a.inl[1] + at, y);
-    if (m1 || m2) continue;  // on the host's overflow list
+// up to K live candidates per mate in registers -> per-read probability, floor / log, running sums
+template <int K>
+__device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int i, uint32_t l12, const RegCands<K>& x, const RegCands<K>& y,
+                                                       double& lsum, int& zeros) {
+  const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     // Junction duplicates: the overwrite rule usually leaves one alignment per mate, i.e. one pair
     // term -- the value the compact path looks up in the memo (same table, same index).
     if (a.memo) {
@@ -532,12 +529,74 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
           q.dist = dist; q.scores = true; q.skip = false;
           q.memo_idx = ((code * 7 + q.x.edit) * 7 + q.y.edit) * a.ins_n + dist;
           compact_finish(a, i, c, q, a.memo[q.memo_idx], lsum, zeros);
-          continue;
+          return;
         }
       }
     }
     const double acc = score_regs<K>(a, x, y, L1, L2);
     finish_read(a, i, acc, L1, L2, lsum, zeros);
+}
+
+// Classes 1 and 2: at most K = 2 / 4 records per mate, 16-byte records, overwrite rule in registers.
+// Slots [slot_lo, slot_hi), blocks [block_lo, block_hi).
+template <int K, int ABL>
+__device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
+                                                 double& lsum, int& zeros) {
+  if (ABL >= 1 && ABL != 4) return;  // ablations 1,2,3,5: compact classes alone; 4: compact stream-only + these classes in full
+  for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
+    const int t = i - a.n0;
+    const uint32_t l12 = a.len12[t];
+    const size_t at = K == 2 ? (size_t)2 * (i - a.n0) : (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01);
+    if (a.inl[0][at].x == kDirtyWid) continue;  // scored by the overflow path from the delta lists
+    RegCands<K> x, y;
+    const bool m1 = load_cands_inline<K>(a.m[0], a.inl[0] + at, x), m2 = load_cands_inline<K>(a.m[1], a.inl[1] + at, y);
+    if (m1 || m2) continue;  // on the host's overflow list
+    score_cands_and_finish<K>(a, i, l12, x, y, lsum, zeros);
+  }
+}
+
+// Delta pairs (pairs that gained records since the tables were built): one LANE per pair, records from
+// the delta lists. Up to 4 records per mate go through the register path of class 2; longer lists and
+// pairs touching a window that occurs several times take the fully general per-lane loop (rare).
+__device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, int delta_blocks, double& lsum, int& zeros) {
+  for (int dj = db * kBlock + threadIdx.x; dj < a.n_dirty; dj += delta_blocks * kBlock) {
+    const int i = a.dirty_slots[dj];
+    const int sp = a.dirty_spill[dj];
+    const uint32_t l12 = i < a.n0 ? a.len_combo[a.len_code[i]] : a.len12[i - a.n0];
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    if (sp >= 0) {  // a long list: fully general per-lane loop
+      const int b0 = a.spill_off[0][sp], b1 = a.spill_off[1][sp];
+      const double acc = paired_general_src(a, ListSrc{a.spill_recs[0] + b0, a.spill_off[0][sp + 1] - b0},
+                                            ListSrc{a.spill_recs[1] + b1, a.spill_off[1][sp + 1] - b1}, L1, L2);
+      finish_read(a, i, acc, L1, L2, lsum, zeros);
+      continue;
+    }
+    int4 r0[4], r1[4];
+    int c0 = 0, c1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      r0[k] = a.dirty_recs[0][4 * (size_t)dj + k];
+      r1[k] = a.dirty_recs[1][4 * (size_t)dj + k];
+      c0 += r0[k].x >= 0; c1 += r1[k].x >= 0;
+    }
+    RegCands<4> x, y;
+    const bool m0 = cands_from_records<4>(a.m[0], r0, x), m1 = cands_from_records<4>(a.m[1], r1, y);
+    if (!(m0 || m1)) { score_cands_and_finish<4>(a, i, l12, x, y, lsum, zeros); continue; }
+    // a window that occurs several times in this path set: general loop over the same records
+    const double acc = paired_general_src(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
+    finish_read(a, i, acc, L1, L2, lsum, zeros);
+  }
+}
+
+// delta store maintenance: one thread per patched pair writes its slot, spill index and padded records
+struct DeltaPatch { int dj, slot, spill, pad; int4 rec[2][4]; };
+__global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const DeltaPatch* patch, int n, int* slots, int* spill, int4* rec0, int4* rec1) {
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) {
+    const DeltaPatch p = patch[t];
+    slots[p.dj] = p.slot;
+    spill[p.dj] = p.spill;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { rec0[4 * (size_t)p.dj + k] = p.rec[0][k]; rec1[4 * (size_t)p.dj + k] = p.rec[1][k]; }
   }
 }
 
@@ -547,7 +606,8 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
   int zeros = 0;
   if (lb < a.blocks0) paired_compact_body<ABL>(a, lb, lsum, zeros);
   else if (lb < a.blocks01) paired_regs_body<2, ABL>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
-  else paired_regs_body<4, ABL>(a, lb, a.n01, a.n_main, a.blocks01, a.main_blocks, lsum, zeros);
+  else if (lb < a.blocks012) paired_regs_body<4, ABL>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
+  else paired_delta_body(a, lb - a.blocks012, a.main_blocks - a.blocks012, lsum, zeros);
   block_reduce(lsum, zeros, sh_s, sh_z);
   if (TICKET) {
     grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out,
@@ -612,37 +672,6 @@ __device__ __forceinline__ int wave_gather(const MateView& v, const int4& r0, in
   return total;
 }
 
-// same as wave_gather, the records given as an explicit list (delta pairs)
-__device__ __forceinline__ int wave_gather_list(const MateView& v, const int4* recs, int cnt, int4* lds, int lane) {
-  int total = 0;
-  for (int base = 0; base < cnt; base += 64) {
-    const int k = base + lane;
-    int mine = 0;
-    int4 r = make_int4(-1, 0, 0, 0), o = make_int4(0, 0, -1, 0);
-    if (k < cnt) {
-      r = recs[k];
-      if (r.x >= 0) o = v.occ[r.x];
-      if (o.z >= 0) mine = o.w >= 0 ? 1 : v.multi_off[-o.w] - v.multi_off[-o.w - 1];
-    }
-    int incl = mine;
-    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-    const int wave_total = __shfl(incl, 63, 64);
-    const int at = total + incl - mine;
-    if (total + wave_total > kOvfCap) return -1;
-    if (mine == 1 && o.w >= 0) {
-      lds[at] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | ((r.y >= o.y) ? 0x200 : 0), o.w);
-    } else if (mine > 0) {
-      const int s = -o.w - 1;
-      for (int q = 0; q < mine; q++) {
-        const int4 oo = v.multi[v.multi_off[s] + q];
-        lds[at + q] = make_int4(oo.z, r.y + oo.x, (r.z & 0x1ff) | ((r.y >= oo.y) ? 0x200 : 0), oo.w);
-      }
-    }
-    total += wave_total;
-  }
-  return total;
-}
-
 template <bool TICKET>
 __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ovf_block, int ovf_blocks, double* sh_s, int* sh_z,
                                                      int4 (*cand)[2][kOvfCap]) {
@@ -651,38 +680,25 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
   const int n_waves = ovf_blocks * (kBlock / 64);
   const int n_static = a.n - a.n_main;
   const int n_listed = n_static + a.n_ovf_items;
-  const int n_items = n_listed + a.n_dirty;
+  const int n_items = n_listed;  // delta pairs: paired_delta_body
   double lsum = 0.0;
   int zeros = 0;
   for (int item = wave_global; item < n_items; item += n_waves) {  // fixed item -> wave assignment
-    const bool is_dirty = item >= n_listed;
-    const int dj = item - n_listed;
-    const int i = is_dirty ? a.dirty_slots[dj] : item < n_static ? a.n_main + item : a.ovf_items[item - n_static];
+    const int i = item < n_static ? a.n_main + item : a.ovf_items[item - n_static];
     int4 r1, r2;
     uint32_t l12;
     if (i < a.n0) { r1 = rec8_to_quad(a.rec8[0][i]); r2 = rec8_to_quad(a.rec8[1][i]); l12 = a.len_combo[a.len_code[i]]; }
     else { r1 = a.m[0].first[i - a.n0]; r2 = a.m[1].first[i - a.n0]; l12 = a.len12[i - a.n0]; }
-    if (!is_dirty && r1.x == kDirtyWid) continue;  // a class-3 pair that is on the delta list: scored there
+    if (r1.x == kDirtyWid) continue;  // a class-3 pair that is on the delta list: scored there
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     int4* c1 = cand[wave][0];
     int4* c2 = cand[wave][1];
-    int n1, n2;
-    if (is_dirty) {
-      n1 = wave_gather_list(a.m[0], a.dirty_recs[0] + a.dirty_off[0][dj], a.dirty_off[0][dj + 1] - a.dirty_off[0][dj], c1, lane);
-      n2 = wave_gather_list(a.m[1], a.dirty_recs[1] + a.dirty_off[1][dj], a.dirty_off[1][dj + 1] - a.dirty_off[1][dj], c2, lane);
-    } else {
-      n1 = wave_gather(a.m[0], r1, c1, lane);
-      n2 = wave_gather(a.m[1], r2, c2, lane);
-    }
+    const int n1 = wave_gather(a.m[0], r1, c1, lane);
+    const int n2 = wave_gather(a.m[1], r2, c2, lane);
     double acc = 0.0;
     if (n1 < 0 || n2 < 0) {
       // more candidates than the LDS staging holds: fully general per-lane loop
-      if (lane == 0) {
-        if (is_dirty)
-          acc = paired_general_src(a, ListSrc{a.dirty_recs[0] + a.dirty_off[0][dj], a.dirty_off[0][dj + 1] - a.dirty_off[0][dj]},
-                                   ListSrc{a.dirty_recs[1] + a.dirty_off[1][dj], a.dirty_off[1][dj + 1] - a.dirty_off[1][dj]}, L1, L2);
-        else acc = paired_general(a, r1, r2, L1, L2);
-      }
+      if (lane == 0) acc = paired_general(a, r1, r2, L1, L2);
     } else {
       __builtin_amdgcn_wave_barrier();
       // overwrite rule: candidate is live iff valid and no later-ranked valid twin (same path, pos)

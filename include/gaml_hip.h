@@ -202,7 +202,7 @@ int gaml_hip_sync(gaml_hip_ctx* ctx);
 
 /* Maintenance hint.  Windows aligned after the device record tables of a paired set were built are
  * scored from delta lists (slightly slower per pair); the library folds them into the tables by
- * itself when they grow past 1/16 of the pairs or after 64 evaluations without a new window.  This
+ * itself when they grow past 1/8 of the pairs or after 64 evaluations without a new window.  This
  * call asks for the fold at the next evaluation -- e.g. after a warm-up phase, before a long run of
  * re-scoring.  Results do not change (only the order of the final sum, i.e. last bits). */
 int gaml_hip_compact_tables(gaml_hip_ctx* ctx);
