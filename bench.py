@@ -73,8 +73,8 @@ def cpu_baseline(gb, go, b1, o1, b2, o2, sample_pairs, read_len, variants, budge
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "tiny"])
     ap.add_argument("--cpu-sample-pairs", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
