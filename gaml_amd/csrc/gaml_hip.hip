@@ -828,12 +828,13 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     a.spill_recs[mt] = (const int4*)(delta + s.delta_off[2 * mt + 1]);
   }
   const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size();  // wave-per-pair items (delta pairs: lane per pair in the main range)
-  const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : 768;  // 3 blocks per CU, ~2-3 pipelined iterations per lane at cfg3 (tools/kbench.py sweep)
+  // 3 blocks per CU and ~2-3 pipelined iterations per lane at cfg3 (tools/kbench.py sweep); larger sets get more blocks, up to 8 per CU
+  const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : (int)std::min<int64_t>(kMaxBlocks, std::max<int64_t>(768, n0 / 2900));
   // the compact path handles 2 pairs per lane and iteration
   const int blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
-  // the 2-record class: at most 3/4 block per CU next to the compact stream, lanes take 1-2 pairs (software pipelined);
+  // the 2-record class: a quarter of the compact class's blocks (3/4 block per CU at cfg3), lanes take 1-2 pairs;
   // more blocks only crowd the compact class out (tools/kbench.py sweep: 312 blocks 16.4 us, 192 blocks 15.0 us)
-  const int cap1 = c->knobs[10] > 0 ? c->knobs[10] : 192;
+  const int cap1 = c->knobs[10] > 0 ? c->knobs[10] : cap0 / 4;
   const int blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, cap1));
   const int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>((n_main - n01 + kBlock - 1) / kBlock, kMaxBlocks / 4));
   // delta pairs: one lane per pair behind the table classes (they used to go through the wave-per-pair path)
