@@ -94,12 +94,20 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # Rehearsal of N > 1 on a box with fewer GPUs than ranks (never used by the driver): GAML_BENCH_SHARE_GPU=1
+    # puts every rank on cuda:0 and runs the collectives over gloo (RCCL refuses two ranks on one device).
+    share_gpu = os.environ.get("GAML_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = synth.WORKLOADS[args.workload]
     # same genome + graph on every rank; each rank draws its own reads (its shard of the N x larger read set)
@@ -154,13 +162,17 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    import contextlib
+    # N > 1: the scorer's side stream is made current once for the whole loop (not once per step)
+    loop_ctx = torch.cuda.stream(scorer.stream) if scorer is not None else contextlib.nullcontext()
     t0 = time.perf_counter()
     last = None
     stamps = [0.0] * (args.steps + 1)
     stamps[0] = t0
-    for i in range(args.steps):
-        last = step(variants[i % len(variants)])
-        stamps[i + 1] = time.perf_counter()
+    with loop_ctx:
+        for i in range(args.steps):
+            last = step(variants[i % len(variants)])
+            stamps[i + 1] = time.perf_counter()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -171,7 +183,7 @@ def main():
     ctx.set_event_timing(False)
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

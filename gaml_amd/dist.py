@@ -30,6 +30,8 @@ class ShardedScorer:
         # a real (non-null) HIP stream: kernels, collectives and the D2H copy are ordered on it
         self.stream = stream or torch.cuda.Stream()
         self.d_part = torch.zeros(4 * max(1, ctx.num_readsets()), dtype=torch.float64, device="cuda")
+        self.h_part = torch.zeros(4 * max(1, ctx.num_readsets()), dtype=torch.float64).pin_memory()
+        self._h_np = self.h_part.numpy()
         self._maps = None
         self._gathered = None
         # RCCL works on device tensors; gloo (tests: several ranks sharing one GPU, or CPU-only collectives)
@@ -75,11 +77,16 @@ class ShardedScorer:
         return total_len
 
     def calc_prob(self, paths):
-        with torch.cuda.stream(self.stream):
-            total_len = self._enqueue(paths, self.d_part)
-            self._all_reduce(self.d_part, dist.ReduceOp.SUM)  # the one collective of the hot path
-            part = self.d_part.cpu().numpy()  # blocking
-        prob, zeros = self.ctx.combine_partials(part, total_len)
+        """Blocking, like CalcProb. (Callers in a tight loop may wrap the loop in `with torch.cuda.stream(
+        scorer.stream)` themselves: the context manager costs a few microseconds per entry.)"""
+        if torch.cuda.current_stream() != self.stream:
+            with torch.cuda.stream(self.stream):
+                return self.calc_prob(paths)
+        total_len = self._enqueue(paths, self.d_part)
+        self._all_reduce(self.d_part, dist.ReduceOp.SUM)  # the one collective of the hot path
+        self.h_part.copy_(self.d_part, non_blocking=True)  # pinned: no staging allocation, one stream sync
+        self.stream.synchronize()
+        prob, zeros = self.ctx.combine_partials(self._h_np, total_len)
         return prob, zeros, total_len
 
     def calc_prob_batch(self, path_sets):
