@@ -1342,9 +1342,7 @@ int eval_finish(gaml_hip_ctx* c, void* d_partials, hipStream_t st) {
         return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded context: the coverage maps of all ranks must be merged "
                                         "(gaml_hip_eval_score_async -> gaml_hip_eval_coverage_export_async -> all-gather -> "
                                         "gaml_hip_eval_coverage_finish_async)");
-    for (auto& ps : c->singles)
-      if (ps->cfg.penalty_constant > 0)
-        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded single-end set is not implemented");
+    // (single-end sets: bad_bases is identically 0 in the reference, graph.cc:1701-1733 -- nothing to exchange)
     for (auto& ps : c->pacbios)
       if (ps->cfg.penalty_constant > 0)
         return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded PacBio set is not implemented");

@@ -220,7 +220,8 @@ int gaml_hip_compact_tables(gaml_hip_ctx* ctx);
  *         maps into this rank's, run the sweep, store bad_bases into the partials: the value where
  *         `contribute` is non-zero (exactly one rank, e.g. rank 0), 0 elsewhere, so that the
  *         all-reduce(sum) of the partials counts it once.
- * Single-end and PacBio sets with a penalty on a sharded context are refused (GAML_HIP_ESTATE). */
+ * Single-end sets need no exchange (their bad_bases is identically 0 in the reference, graph.cc:1701-1733);
+ * a PacBio set with a penalty on a sharded context is refused (GAML_HIP_ESTATE). */
 int32_t gaml_hip_eval_score_async(gaml_hip_ctx* ctx, void* d_partials, void* stream);
 int gaml_hip_eval_coverage_export_async(gaml_hip_ctx* ctx, int32_t i, void* dst, int64_t cap, int64_t* bytes_out, void* stream);
 int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* ctx, int32_t i, const void* maps, int32_t n_maps, int32_t contribute,
