@@ -241,6 +241,15 @@ struct gaml_hip_ctx {
   bool defer_cov = false;
   struct PendingCov { int paired_idx; CovArgs args; double* out4; };
   std::vector<PendingCov> pending_cov;
+  // same for a PacBio set: the interval events of the other ranks' reads are missing (host lists)
+  struct PendingPacbio {
+    int pacbio_idx;
+    double* out4;
+    std::vector<int32_t> tl;                                            // per path
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> node_events;  // per path: the events every rank has
+    std::vector<int32_t> own;                                           // this rank's record events: (path, position, value) triples
+  };
+  std::vector<PendingPacbio> pending_pb;
 };
 
 namespace {
@@ -1011,6 +1020,24 @@ int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths,
 }
 
 // ---------------------------------------------------------------------------------------
+// integer event sweep of one path (graph.cc:3226-3250): sorted events, multiset of open intervals
+int64_t pacbio_sweep(std::vector<std::pair<int32_t, int32_t>>& events, int32_t tl, double step) {
+  int64_t bad = 0;
+  std::sort(events.begin(), events.end());
+  std::multiset<int32_t> open;
+  for (size_t j = 0; j < events.size(); j++) {
+    if (events[j].second == 1) open.insert(events[j].first);
+    else { auto it = open.find(events[j].first + events[j].second); if (it != open.end()) open.erase(it); }
+    int32_t good = tl - 250;
+    if (!open.empty()) good = (int32_t)(*open.begin() + step);
+    if (j + 1 < events.size()) good = std::min(events[j + 1].first, good);
+    good = std::min(good, tl - 250);
+    int32_t from = std::max(2500, events[j].first);
+    if (good > from) bad += good - from;
+  }
+  return bad;
+}
+
 // PacBio read set (CalcScoreForPacbio graph.cc:3171-3261)
 // ---------------------------------------------------------------------------------------
 int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_in, hipStream_t st, double* out4) {
@@ -1025,7 +1052,11 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
   std::vector<int32_t> count(s.recs.size(), 0);
   int64_t bad_bases = 0;
   const bool cov = s.cfg.penalty_constant > 0;
+  const bool defer = cov && c->defer_cov;  // sharded: the sweep waits for the other ranks' events
+  gaml_hip_ctx::PendingPacbio pend;
+  int32_t path_no = -1;
   for (Walk path : paths_in) {
+    path_no++;
     for (auto& x : path) if (x >= 0) x = c->g.norm[x];  // NormalizePath graph.h:268-273
     const int32_t m = (int32_t)path.size();
     std::vector<int32_t> begins(m), ends(m);
@@ -1037,6 +1068,7 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
     }
     const int32_t tl = len;
     std::vector<std::pair<int32_t, int32_t>> events;
+    size_t n_node_events = 0;
     if (cov) {
       events.emplace_back(-1000, 1); events.emplace_back(2000, -3000);  // graph.cc:3198-3199
       int32_t pp = 0;
@@ -1044,6 +1076,7 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
         if (e >= 0) { int32_t cl = c->g.len(e); events.emplace_back(pp, 1); events.emplace_back(pp + cl, -cl); pp += cl; }
         else pp += -e;
       }
+      n_node_events = events.size();
     }
     Walk sub;
     for (int32_t i = 0; i < m; i++) {  // graph.cc:2438-2454
@@ -1068,22 +1101,13 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
         if ((ends[j] - begins[i]) - (ends[i] - begins[i]) > s.max_len) break;
       }
     }
-    if (cov) {
-      // NOTE: with sharding each rank only sees its own reads' intervals; the coverage penalty of a
-      // PacBio set is therefore only evaluated unsharded (world == 1). Integer event sweep,
-      // graph.cc:3226-3250.
-      std::sort(events.begin(), events.end());
-      std::multiset<int32_t> open;
-      for (size_t j = 0; j < events.size(); j++) {
-        if (events[j].second == 1) open.insert(events[j].first);
-        else { auto it = open.find(events[j].first + events[j].second); if (it != open.end()) open.erase(it); }
-        int32_t good = tl - 250;
-        if (!open.empty()) good = (int32_t)(*open.begin() + s.cfg.step);
-        if (j + 1 < events.size()) good = std::min(events[j + 1].first, good);
-        good = std::min(good, tl - 250);
-        int32_t from = std::max(2500, events[j].first);
-        if (good > from) bad_bases += good - from;
-      }
+    if (defer) {
+      pend.tl.push_back(tl);
+      for (size_t j = n_node_events; j < events.size(); j++) { pend.own.push_back(path_no); pend.own.push_back(events[j].first); pend.own.push_back(events[j].second); }
+      events.resize(n_node_events);
+      pend.node_events.push_back(std::move(events));
+    } else if (cov) {
+      bad_bases += pacbio_sweep(events, tl, s.cfg.step);
     }
   }
   s.last_bad_bases = bad_bases;
@@ -1126,6 +1150,11 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
   a.part_sum = s.red.part_sum.as<double>(); a.part_zero = s.red.part_zero.as<int>();
   a.ticket = s.red.ticket.as<unsigned>(); a.out = out4;
   a.n_reads = (double)n; a.bad_bases = (double)bad_bases;
+  if (defer) {
+    pend.out4 = out4;
+    for (size_t i = 0; i < c->pacbios.size(); i++) if (c->pacbios[i].get() == &s) pend.pacbio_idx = (int)i;
+    c->pending_pb.push_back(std::move(pend));
+  }
   if (n > 0) {
     int64_t threads = n * 64;  // one wave per read
     hipLaunchKernelGGL(pacbio_score_kernel, dim3(grid_for(threads)), dim3(kBlock), 0, st, a);
@@ -1344,8 +1373,9 @@ int eval_finish(gaml_hip_ctx* c, void* d_partials, hipStream_t st) {
                                         "gaml_hip_eval_coverage_finish_async)");
     // (single-end sets: bad_bases is identically 0 in the reference, graph.cc:1701-1733 -- nothing to exchange)
     for (auto& ps : c->pacbios)
-      if (ps->cfg.penalty_constant > 0)
-        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded PacBio set is not implemented");
+      if (ps->cfg.penalty_constant > 0 && !c->defer_cov)
+        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded PacBio set: the interval events of all ranks must be merged "
+                                        "(gaml_hip_eval_score_async -> gaml_hip_eval_pacbio_events -> all-gather -> gaml_hip_eval_pacbio_finish_async)");
   }
   const std::vector<Walk>& paths = c->pending_paths;
   const int32_t total_len = c->pending_total_len;
@@ -1977,11 +2007,40 @@ int32_t gaml_hip_eval_score_async(gaml_hip_ctx* c, void* d_partials, void* strea
   if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
   c->pending_cov.clear();
+  c->pending_pb.clear();
   c->defer_cov = c->peers > 1;
   const int e = eval_finish(c, d_partials, stream ? (hipStream_t)stream : c->stream);
   c->defer_cov = false;
-  if (e) { c->pending_cov.clear(); return e; }
+  if (e) { c->pending_cov.clear(); c->pending_pb.clear(); return e; }
   return (int32_t)c->pending_cov.size();
+}
+
+int32_t gaml_hip_eval_pacbio_pending(gaml_hip_ctx* c) { return c ? (int32_t)c->pending_pb.size() : GAML_HIP_EINVAL; }
+
+int64_t gaml_hip_eval_pacbio_events(gaml_hip_ctx* c, int32_t i, int32_t* out, int64_t cap) {
+  if (!c || i < 0 || i >= (int32_t)c->pending_pb.size() || cap < 0 || (cap > 0 && !out)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  const auto& own = c->pending_pb[i].own;
+  if ((int64_t)own.size() <= cap && !own.empty()) memcpy(out, own.data(), own.size() * sizeof(int32_t));
+  return (int64_t)own.size();
+}
+
+int gaml_hip_eval_pacbio_finish_async(gaml_hip_ctx* c, int32_t i, const int32_t* events, int64_t n_values, int32_t contribute, void* stream) {
+  if (!c || i < 0 || i >= (int32_t)c->pending_pb.size() || n_values < 0 || n_values % 3 != 0 || (n_values > 0 && !events))
+    return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  gaml_hip_ctx::PendingPacbio& pb = c->pending_pb[i];
+  PacbioSet& s = *c->pacbios[pb.pacbio_idx];
+  const int32_t n_paths = (int32_t)pb.tl.size();
+  for (int64_t k = 0; k < n_values; k += 3) {
+    if (events[k] < 0 || events[k] >= n_paths) return fail(c, GAML_HIP_EINVAL, "event names a path that is not in this evaluation");
+    pb.node_events[events[k]].emplace_back(events[k + 1], events[k + 2]);
+  }
+  int64_t bad = 0;
+  for (int32_t p = 0; p < n_paths; p++) bad += pacbio_sweep(pb.node_events[p], pb.tl[p], s.cfg.step);
+  s.last_bad_bases = bad;
+  hipLaunchKernelGGL(store_double_kernel, dim3(1), dim3(64), 0, stream ? (hipStream_t)stream : c->stream, pb.out4 + 2, contribute ? (double)bad : 0.0);
+  HIP_TRY(c, hipGetLastError());
+  return GAML_HIP_OK;
 }
 
 int gaml_hip_eval_coverage_export_async(gaml_hip_ctx* c, int32_t i, void* dst, int64_t cap, int64_t* bytes_out, void* stream) {

@@ -61,6 +61,14 @@ def test_sharded_scorer_single_rank_group():
         dist.destroy_process_group()
 
 
+def _long_reads(g, walk):
+    ps = synth.make_pacbio_sam(g, walk, 31, 2500, 79, secondary=0.0)
+    rb = np.frombuffer("".join(ps.reads).encode(), np.uint8)
+    ro = np.zeros(len(ps.reads) + 1, np.int64)
+    ro[1:] = np.cumsum([len(r) for r in ps.reads])
+    return ps, rb, ro
+
+
 def _two_rank_worker(rank, world, port, out_dir, penalty):
     """One of `world` processes sharing the single GPU of the test box. Collectives run over gloo (RCCL
     refuses two ranks on one device); everything else -- one context per process holding its shard,
@@ -85,6 +93,10 @@ def _two_rank_worker(rank, world, port, out_dir, penalty):
         ctx.set_graph(*g.packed())
         ctx.add_paired(api.paired_cfg(250.0, 25.0, penalty_constant=penalty, penalty_step=40.0),
                        *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+        ps, rb, ro = _long_reads(g, walk)
+        pb = ctx.add_pacbio_reads(api.single_cfg(penalty_constant=4 * penalty, penalty_step=30.0, min_prob_per_base=-1.0, weight=0.5,
+                                                 mismatch_prob=0.15), rb, ro, ps.names)
+        ctx.pacbio_ingest_sam(pb, walk, ps.sam)
         scorer = ShardedScorer(ctx)
         sets = [[walk], [walk[:6], walk[6:]], [walk[3:]], [walk[:6], [x ^ 1 for x in reversed(walk[6:])]]]
         single = [scorer.calc_prob(p) for p in sets]          # cold: windows aligned, maxima exchanged
@@ -114,6 +126,10 @@ def test_two_processes_share_the_reads(tmp_path, penalty):
     plain.set_graph(*g.packed())
     plain.add_paired(api.paired_cfg(250.0, 25.0, penalty_constant=penalty, penalty_step=40.0),
                      *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    ps, rb, ro = _long_reads(g, walk)
+    pb = plain.add_pacbio_reads(api.single_cfg(penalty_constant=4 * penalty, penalty_step=30.0, min_prob_per_base=-1.0, weight=0.5,
+                                               mismatch_prob=0.15), rb, ro, ps.names)
+    plain.pacbio_ingest_sam(pb, walk, ps.sam)
     sets = [[walk], [walk[:6], walk[6:]], [walk[3:]], [walk[:6], [x ^ 1 for x in reversed(walk[6:])]]]
     for k, p in enumerate(sets):
         want, wz, tl = plain.calc_prob(p)

@@ -313,3 +313,51 @@ def test_sharded_coverage_penalty_merges_the_ranks_maps():
     c.eval_begin(paths)
     with pytest.raises(api.GamlHipError):
         c.eval_finish()
+
+
+def test_sharded_pacbio_penalty_merges_the_ranks_intervals():
+    """A PacBio set with penalty_constant > 0 on sharded contexts: bad_bases (graph.cc:3198-3250) sweeps the
+    alignment intervals of ALL reads, so the ranks exchange their interval events. Three shards on one GPU
+    play the ranks; sparse long reads leave uncovered stretches that only the union closes."""
+    import torch
+    from gaml_amd import api
+    genome, g = _graph(60_000, 77, long_rng=(1500, 5000))
+    walk = synth.genome_walk(g)
+    ps = synth.make_pacbio_sam(g, walk, 45, 2500, 77, secondary=0.0)
+    rb = np.frombuffer("".join(ps.reads).encode(), np.uint8)
+    ro = np.zeros(len(ps.reads) + 1, np.int64)
+    ro[1:] = np.cumsum([len(r) for r in ps.reads])
+    cfg = api.single_cfg(penalty_constant=0.003, penalty_step=30.0, min_prob_per_base=-1.0, mismatch_prob=0.15)
+    paths = [walk[:7], walk[7:]]
+
+    def make(rank=0, world=1):
+        c = api.Context(device=0, rank=rank, world=world)
+        c.set_graph(*g.packed())
+        rs = c.add_pacbio_reads(cfg, rb, ro, ps.names)
+        c.pacbio_ingest_sam(rs, walk, ps.sam)  # every rank files its own reads' records
+        return c, rs
+    whole, wrs = make()
+    want, wz, tl = whole.calc_prob(paths)
+    bad_whole = whole.bad_bases(wrs)
+    assert bad_whole > 0
+    shards = [make(r, 3)[0] for r in range(3)]
+    stream = torch.cuda.current_stream().cuda_stream
+    parts = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in shards]
+    own = []
+    for c, p in zip(shards, parts):
+        c.eval_begin(paths)
+        assert c.eval_score_async(p.data_ptr(), stream) == 0 and c.eval_pacbio_pending() == 1
+        own.append(c.eval_pacbio_events(0))
+    assert all(len(e) % 3 == 0 for e in own) and sum(len(e) for e in own) > 0
+    merged = np.concatenate(own)  # what the all-gather leaves on every rank
+    for r, c in enumerate(shards):
+        c.eval_pacbio_finish_async(0, merged, r == 1, stream)  # any one rank may contribute
+    torch.cuda.synchronize()
+    assert [float(p[2]) for p in parts] == [0.0, float(bad_whole), 0.0]
+    acc = torch.stack(parts).sum(0).cpu().numpy()
+    got, z = shards[0].combine_partials(acc, tl)
+    assert z.tolist() == wz.tolist() and abs(got - want) <= 1e-12 * abs(want)
+    c = shards[1]
+    c.eval_begin(paths)
+    with pytest.raises(api.GamlHipError):
+        c.eval_finish()  # without the exchange the sharded context refuses
