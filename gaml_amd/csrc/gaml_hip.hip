@@ -1547,8 +1547,11 @@ int gaml_hip_add_paired(gaml_hip_ctx* c, const gaml_paired_cfg* cfg, int32_t n, 
   if (!c || !cfg || n < 0 || !o1 || !o2) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   std::unique_ptr<PairedSet> s(new PairedSet());
   s->cfg = *cfg;
-  init_mate(c, s->mate[0], cfg->mismatch_prob, n, b1, o1);
-  init_mate(c, s->mate[1], cfg->mismatch_prob, n, b2, o2);
+  {  // the two mates' read indexes are independent: build them side by side
+    std::thread second([&] { init_mate(c, s->mate[1], cfg->mismatch_prob, n, b2, o2); });
+    init_mate(c, s->mate[0], cfg->mismatch_prob, n, b1, o1);
+    second.join();
+  }
   s->mate[0].defer_alignment = s->mate[1].defer_alignment = true;  // batched: see gpu_align_pending
   if (s->mate[0].max_len > 65535 || s->mate[1].max_len > 65535) return fail(c, GAML_HIP_EINVAL, "paired reads longer than 65535 bases");
   c->paireds.push_back(std::move(s));

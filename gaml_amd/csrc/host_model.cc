@@ -2,6 +2,7 @@
 #include "host_model.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -69,9 +70,13 @@ void split_contigs(const Walk& path, std::vector<std::pair<int32_t, int32_t>>& r
 // ---------------------------------------------------------------------------------------
 // seed code / max-hash
 // ---------------------------------------------------------------------------------------
-static inline uint32_t base_code(char c) {  // graph.h:326-331 (G0 A1 T2 C3; anything else 0)
-  switch (c) { case 'A': return 1; case 'T': return 2; case 'C': return 3; default: return 0; }
-}
+// graph.h:326-331 (G0 A1 T2 C3; anything else 0) as a table: a switch on random bases mispredicts every other time
+struct BaseCodeTable {
+  uint8_t v[256];
+  constexpr BaseCodeTable() : v() { v[(unsigned char)'A'] = 1; v[(unsigned char)'T'] = 2; v[(unsigned char)'C'] = 3; }
+};
+static constexpr BaseCodeTable kBaseCode{};
+static inline uint32_t base_code(char c) { return kBaseCode.v[(unsigned char)c]; }
 static inline uint64_t scramble(uint64_t code) { return code ^ 0x2204abcdull; }  // graph.cc:1245
 static const uint64_t kSeedMask = (1ull << (2 * kSeed)) - 1;
 
@@ -216,6 +221,25 @@ bool extend_seed(int32_t win_pos, int32_t read_pos, const char* read, int32_t R,
 // ---------------------------------------------------------------------------------------
 // ShortMate
 // ---------------------------------------------------------------------------------------
+namespace {
+// run fn(lo, hi) over [0, n) on a few host threads (ranges are disjoint; small inputs stay on the caller)
+template <class F>
+void parallel_ranges(int64_t n, F fn) {
+  const int nt = n < (1 << 16) ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+  if (nt == 1) { fn((int64_t)0, n); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; t++) pool.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
+  for (auto& th : pool) th.join();
+}
+template <class F>
+void parallel_mates(bool parallel, F fn) {  // fn(0) and fn(1) touch different arrays
+  if (!parallel) { fn(0); fn(1); return; }
+  std::thread other(fn, 1);
+  fn(0);
+  other.join();
+}
+}  // namespace
+
 void ShortMate::set_reads(int64_t n_global_, int64_t lo_, int64_t hi_, const char* b, const int64_t* offs) {
   n_global = n_global_; lo = lo_; hi = hi_;
   int64_t n = hi - lo;
@@ -237,27 +261,46 @@ void ShortMate::set_reads(int64_t n_global_, int64_t lo_, int64_t hi_, const cha
     match_pow[i] = std::pow(match, (double)i);
     mismatch_pow[i] = std::pow(mismatch, (double)i);
   }
+  static const bool trace = getenv("GAML_HIP_TRACE_HOST") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   build_index();
+  if (trace) fprintf(stderr, "set_reads: index over %lld reads built in %.0f ms\n", (long long)n,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
 
 static bool only_acgt(const char* s, int32_t n) {  // CheckRead graph.cc:1271-1278
-  for (int32_t i = 0; i < n; i++) if (s[i] != 'A' && s[i] != 'C' && s[i] != 'G' && s[i] != 'T') return false;
-  return true;
+  unsigned bad = 0;
+  for (int32_t i = 0; i < n; i++) bad |= (unsigned)(kBaseCode.v[(unsigned char)s[i]] == 0 && s[i] != 'G');
+  return bad == 0;
 }
 
 void ShortMate::build_index() {
   // bucket = reads whose maximum scrambled 15-mer code equals the key (graph.cc:1280-1287);
   // flat sorted arrays instead of a hash map of vectors.
   int64_t n = n_local();
+  const auto t0h = std::chrono::steady_clock::now();
+  std::vector<uint64_t> hash(n);
+  std::vector<uint8_t> ok(n);
+  parallel_ranges(n, [&](int64_t lo_i, int64_t hi_i) {  // the per-read work (136 rolling codes per 150-base read)
+    for (int64_t i = lo_i; i < hi_i; i++) {
+      ok[i] = lens[i] >= kSeed && only_acgt(read(i), lens[i]);
+      if (ok[i]) hash[i] = read_max_hash(read(i), lens[i]);
+    }
+  });
+  static const bool trace = getenv("GAML_HIP_TRACE_HOST") != nullptr;
+  const auto t1 = std::chrono::steady_clock::now();
   std::vector<std::pair<uint64_t, int32_t>> keyed;
   keyed.reserve(n);
   index_read_len = 0;
   for (int64_t i = 0; i < n; i++) {
-    if (lens[i] < kSeed || !only_acgt(read(i), lens[i])) continue;
-    keyed.emplace_back(read_max_hash(read(i), lens[i]), (int32_t)i);
+    if (!ok[i]) continue;
+    keyed.emplace_back(hash[i], (int32_t)i);
     index_read_len = lens[i];
   }
+  const auto t2 = std::chrono::steady_clock::now();
   std::sort(keyed.begin(), keyed.end());
+  if (trace) fprintf(stderr, "build_index: hash %.0f ms, gather %.0f ms, sort %.0f ms\n", std::chrono::duration<double, std::milli>(t1 - t0h).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
   bucket_hash.clear(); bucket_off.clear(); bucket_reads.clear();
   bucket_reads.reserve(keyed.size());
   for (size_t i = 0; i < keyed.size(); i++) {
@@ -738,25 +781,6 @@ void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_re
   out.total_records = m.active_records;
   out.built_generation = m.active_generation;
 }
-
-namespace {
-// run fn(lo, hi) over [0, n) on a few host threads (ranges are disjoint; small inputs stay on the caller)
-template <class F>
-void parallel_ranges(int64_t n, F fn) {
-  const int nt = n < (1 << 16) ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
-  if (nt == 1) { fn((int64_t)0, n); return; }
-  std::vector<std::thread> pool;
-  for (int t = 0; t < nt; t++) pool.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
-  for (auto& th : pool) th.join();
-}
-template <class F>
-void parallel_mates(bool parallel, F fn) {  // fn(0) and fn(1) touch different arrays
-  if (!parallel) { fn(0); fn(1); return; }
-  std::thread other(fn, 1);
-  fn(0);
-  other.join();
-}
-}  // namespace
 
 void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) {
   const int64_t n = a.n_local();
