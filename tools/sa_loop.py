@@ -20,7 +20,10 @@ ctx = api.Context(device=0)
 if os.environ.get("GAML_HIP_TRACE_ALIGNER"):
     ctx.debug_set_knob(9, 1)  # separate the extension kernel from its D2H copy in the stage timings
 ctx.set_graph(*g.packed())
-rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+_args = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+_t = time.time()
+rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *_args)
+print(f'add_paired (read index of both mates): {time.time() - _t:.2f} s', flush=True)
 walk = synth.genome_walk(g)
 start = [[x] for x in walk if g.node_len(x) > 500]  # gaml.cc:1002-1005
 t0 = time.time(); v0 = ctx.calc_prob(start); t_first = time.time() - t0
