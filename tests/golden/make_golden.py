@@ -158,9 +158,68 @@ def oracle_pins():
     return out
 
 
+def pacbio_sam_pins():
+    """Regression pins (NOT reference output) for the PacBio cache-miss side: parsed SAM fields, the DP band
+    and the alignment log probability of hand-made and synthetic SAM lines, and the records one ingest files."""
+    half = "".join("ACGT"[int(x)] for x in np.random.default_rng(3).integers(0, 4, 400))
+    target = half + "\n" + synth.revcomp_str(half)
+    rng = np.random.default_rng(4)
+    lines = [
+        "q/1\t0\tp\t10\t1\t5S10M\t*\t0\t10\tACGTACGTAC\t*",
+        "q/1\t16\tp\t10\t1\t3I4M2D3M\t*\t0\t9\tACGTACGTAC\t*\tNM:i:3",
+        "q/1\t0\tp\t3\t1\t10I\t*\t0\t0\tACGTACGTAC\t*",
+        "q/1\t0\tp\t2\t1\t5M\t*\t0\t5\tACGTA\t*\tXS:i:300\tXE:i:305\tXQ:i:700",
+        "q/1\t16\tp\t100\t1\t5M0D3M\t*\t0\t8\tACGTACGT\t*\tXS:i:4\tXE:i:12\tXQ:i:250",
+        "q/1\t0\tp\t395\t1\t8M\t*\t0\t8\tACGTACGT\t*",
+    ]
+    g1 = synth.make_graph(np.frombuffer(half.encode(), np.uint8), [400])
+    ps1 = synth.make_pacbio_sam(g1, [0], 6, 300, 8)
+    rd1 = dict(zip(ps1.names, ps1.reads))
+    cases = []
+    for line in lines:
+        n = 700 if "XQ:i:700" in line else 250 if "XQ:i:250" in line else len(line.split("\t")[9])
+        cases.append((line, "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))))
+    for line in ps1.sam.split("\n")[1:-1]:
+        cases.append((line, rd1[line.split("\t")[0].split("/")[0]]))
+    out = {"target": target, "mismatch_prob": 0.15, "lines": []}
+    for line, read in cases:
+        f, r0, lo, hi = op.sam_band(line, len(target))
+        lp = op.sam_alignment_logprob(line, target, read, 0.15)
+        out["lines"].append({"sam": line, "read": read, "fields": f, "row0": r0, "rows": len(lo), "lo_head": [int(x) for x in lo[:8]],
+                             "hi_head": [int(x) for x in hi[:8]], "lo_sum": int(lo.sum()), "hi_sum": int(hi.sum()),
+                             "logprob": hexf(lp) if np.isfinite(lp) else "-inf"})
+    # one ingest on a small graph: which sub-walks get entries, and what is filed under them
+    genome = synth.make_genome(20_000, 12)
+    g = synth.make_graph(genome, synth.cut_lengths(20_000, 12, long_rng=(1200, 3000)))
+    walk = synth.genome_walk(g)
+    ps = synth.make_pacbio_sam(g, walk, 12, 700, 12)
+    rb = np.frombuffer("".join(ps.reads).encode(), np.uint8)
+    ro = np.zeros(len(ps.reads) + 1, np.int64)
+    ro[1:] = np.cumsum([len(r) for r in ps.reads])
+    o = op.Oracle()
+    o.set_graph(*g.packed())
+    rs = o.add_pacbio_reads(rb, ro, ps.names, 0.15, op.single_cfg(min_prob_per_base=-1.0))
+    filed = o.pacbio_ingest_sam(rs, walk, ps.sam)
+    recs = {}
+    for k in sorted(o.pacbio_keys(rs)):
+        rec, lp = o.pacbio_records(rs, list(k))
+        if len(rec):
+            recs[" ".join(map(str, k))] = {"rec": rec.tolist(), "logp": [hexf(float(x)) for x in lp]}
+    v, z, tl = o.calc_prob([walk])
+    out["ingest"] = {"genome_seed": 12, "genome_len": 20_000, "long_rng": [1200, 3000], "n_reads": 12, "read_len": 700, "sam_seed": 12,
+                     "filed": int(filed), "n_keys": len(o.pacbio_keys(rs)), "records": recs, "prob": hexf(v), "zeros": z.tolist(), "total_len": int(tl)}
+    return out
+
+
 if __name__ == "__main__":
-    with open(os.path.join(HERE, "ref_logdouble.json"), "w") as f:
-        json.dump(ref_logdouble(), f, indent=0)
-    with open(os.path.join(HERE, "oracle_pins.json"), "w") as f:
-        json.dump(oracle_pins(), f, indent=0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sam":  # only the PacBio SAM pins (the other fixtures stay as they are)
+        with open(os.path.join(HERE, "pacbio_sam_pins.json"), "w") as f:
+            json.dump(pacbio_sam_pins(), f, indent=0)
+    else:
+        with open(os.path.join(HERE, "ref_logdouble.json"), "w") as f:
+            json.dump(ref_logdouble(), f, indent=0)
+        with open(os.path.join(HERE, "oracle_pins.json"), "w") as f:
+            json.dump(oracle_pins(), f, indent=0)
+        with open(os.path.join(HERE, "pacbio_sam_pins.json"), "w") as f:
+            json.dump(pacbio_sam_pins(), f, indent=0)
     print("wrote", os.listdir(HERE))

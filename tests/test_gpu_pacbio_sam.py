@@ -181,3 +181,42 @@ def test_errors_are_loud():
     lens_only = ctx.add_pacbio(api.single_cfg(mismatch_prob=MISMATCH), [100, 100])
     with pytest.raises(api.GamlHipError):
         ctx.pacbio_ingest_sam(lens_only, walk, ps.sam)
+
+
+def test_golden_pins_through_the_c_abi():
+    """The committed fixtures of tests/golden/pacbio_sam_pins.json, product side: SAM fields and band exact,
+    log probabilities to 1e-9, filed records exact."""
+    import json
+    import os
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pacbio_sam_pins.json")))
+    target = pins["target"]
+    ctx = api.Context()
+    for c in pins["lines"]:
+        f, r0, lo, hi = api.debug_sam_band(c["sam"], len(target))
+        assert f == c["fields"] and r0 == c["row0"] and len(lo) == c["rows"]
+        assert int(lo.sum()) == c["lo_sum"] and int(hi.sum()) == c["hi_sum"]
+        got, dlo, dhi = ctx.debug_sam_logprob(target, c["read"], c["sam"], pins["mismatch_prob"], with_band=True)
+        assert np.array_equal(dlo, lo) and np.array_equal(dhi, hi)
+        if c["logprob"] == "-inf":
+            assert got == -np.inf
+        else:
+            want = float.fromhex(c["logprob"])
+            assert abs(got - want) <= RTOL * abs(want)
+    ing = pins["ingest"]
+    genome = synth.make_genome(ing["genome_len"], ing["genome_seed"])
+    g = synth.make_graph(genome, synth.cut_lengths(ing["genome_len"], ing["genome_seed"], long_rng=tuple(ing["long_rng"])))
+    walk = synth.genome_walk(g)
+    ps = synth.make_pacbio_sam(g, walk, ing["n_reads"], ing["read_len"], ing["sam_seed"])
+    rb = np.frombuffer("".join(ps.reads).encode(), np.uint8)
+    ro = np.zeros(len(ps.reads) + 1, np.int64)
+    ro[1:] = np.cumsum([len(r) for r in ps.reads])
+    c2 = api.Context()
+    c2.set_graph(*g.packed())
+    rs = c2.add_pacbio_reads(api.single_cfg(min_prob_per_base=-1.0, mismatch_prob=0.15), rb, ro, ps.names)
+    assert c2.pacbio_ingest_sam(rs, walk, ps.sam) == ing["filed"]
+    for key, want in ing["records"].items():
+        got = c2.pacbio_records(rs, [int(x) for x in key.split()])
+        assert np.array_equal(np.stack([got["position"], got["position_end"], got["read_id"]], 1), np.array(want["rec"]))
+        np.testing.assert_allclose(got["logprob"], [float.fromhex(x) for x in want["logp"]], rtol=RTOL, atol=0)
+    v, z, tl = c2.calc_prob([walk])
+    assert abs(v - float.fromhex(ing["prob"])) <= RTOL * abs(v) and z.tolist() == ing["zeros"] and tl == ing["total_len"]

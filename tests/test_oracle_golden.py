@@ -210,3 +210,107 @@ def test_config_quirks(tmp_path):
     buf = C.create_string_buffer(64)
     op.lib().orc_config_order(str(cfg).encode(), buf, 64)
     assert sorted(buf.value.decode().strip(",").split(",")) == ["rs1", "rs2"]
+
+
+def test_alignment_dp_against_explicit_path_enumeration():
+    """AligmentProbability (reference graph.cc:2175-2297) sums, over every monotone path through the banded
+    cell set that starts in column 0 and ends in column |read|, the product of MatchProbability along the
+    path. Enumerate those paths one by one (exponential, so tiny inputs) and compare with the oracle's
+    dynamic programme -- an answer that does not share the DP's bookkeeping."""
+    import math
+    from oracle_py import sam_band, sam_alignment_logprob
+    mism = 0.15
+    match = 1.0 - 4 * mism
+
+    def pm(a, b):
+        if a == "\n" or b == "\n":
+            return 0.0
+        return match if a == b else mism
+
+    half = "ACGTTGCAAGCT"
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    target = half + "\n" + "".join(comp[ch] for ch in reversed(half))
+    cases = [
+        ("q/1\t0\tp\t3\t1\t4M\t*\t0\t4\tTTGC\t*", "TTGC"),
+        ("q/1\t0\tp\t2\t1\t2M1I2M\t*\t0\t4\tGTATG\t*", "GTATG"),
+        ("q/1\t0\tp\t4\t1\t2M1D2M\t*\t0\t5\tTGAA\t*", "TGAA"),
+        ("q/1\t16\tp\t2\t1\t3M\t*\t0\t3\tAGC\t*", "GCT"),           # mirrored into the reverse-complement half
+        ("q/1\t0\tp\t10\t1\t4M\t*\t0\t4\tGCTA\t*", "GCTA"),          # runs into the separator: those rows contribute nothing
+        ("q/1\t0\tp\t5\t1\t2M\t*\t0\t2\tGC\t*\tXS:i:2\tXE:i:4\tXQ:i:4", "AGCT"),  # soft clips on both ends
+    ]
+    for line, read in cases:
+        f, r0, lo, hi = sam_band(line, len(target))
+        n = len(read)
+        cells = {(r0 + i, c) for i in range(len(lo)) for c in range(int(lo[i]), int(hi[i]) + 1)}
+
+        def usable(r, c):  # a cell the DP computes (graph.cc:2246-2255)
+            gi = r + f["posstart"] - 1
+            return (r, c) in cells and 1 <= c <= n and 0 <= gi < len(target)
+
+        total = 0.0
+
+        def walk(r, c, w):
+            nonlocal total
+            if c == n:
+                total += w  # every computed cell of the last column is summed (graph.cc:2279-2281)
+            for dr, dc in ((1, 1), (1, 0), (0, 1)):
+                rr, cc = r + dr, c + dc
+                if not usable(rr, cc):
+                    continue
+                g = target[rr + f["posstart"] - 1]
+                step = pm(g, read[cc - 1]) if (dr, dc) == (1, 1) else pm(g, "-") if (dr, dc) == (1, 0) else pm("-", read[cc - 1])
+                if step > 0.0:
+                    walk(rr, cc, w * step)
+
+        for (r, c) in sorted(cells):
+            if c == 0:  # free start in column 0: value 1, never recomputed
+                for dr, dc in ((1, 1), (0, 1)):
+                    rr, cc = r + dr, c + dc
+                    if usable(rr, cc):
+                        g = target[rr + f["posstart"] - 1]
+                        step = pm(g, read[cc - 1]) if dr else pm("-", read[cc - 1])
+                        if step > 0.0:
+                            walk(rr, cc, step)
+        got = sam_alignment_logprob(line, target, read, mism)
+        assert total > 0.0 and math.isfinite(got), line
+        assert abs(got - math.log(total)) <= 1e-10 * abs(got), (line, got, math.log(total))
+
+
+def test_pacbio_sam_pins():
+    """tests/golden/pacbio_sam_pins.json (regression pins made by tests/golden/make_golden.py sam): parsed
+    fields, band and log probability per SAM line, and what one ingest files."""
+    import json
+    import os
+    import oracle_py as op2
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pacbio_sam_pins.json")))
+    target = pins["target"]
+    for c in pins["lines"]:
+        f, r0, lo, hi = op2.sam_band(c["sam"], len(target))
+        assert f == c["fields"] and r0 == c["row0"] and len(lo) == c["rows"]
+        assert [int(x) for x in lo[:8]] == c["lo_head"] and [int(x) for x in hi[:8]] == c["hi_head"]
+        assert int(lo.sum()) == c["lo_sum"] and int(hi.sum()) == c["hi_sum"]
+        lp = op2.sam_alignment_logprob(c["sam"], target, c["read"], pins["mismatch_prob"])
+        if c["logprob"] == "-inf":
+            assert lp == -np.inf
+        else:
+            want = float.fromhex(c["logprob"])
+            assert abs(lp - want) <= 1e-13 * abs(want)
+    ing = pins["ingest"]
+    genome = synth.make_genome(ing["genome_len"], ing["genome_seed"])
+    g = synth.make_graph(genome, synth.cut_lengths(ing["genome_len"], ing["genome_seed"], long_rng=tuple(ing["long_rng"])))
+    walk = synth.genome_walk(g)
+    ps = synth.make_pacbio_sam(g, walk, ing["n_reads"], ing["read_len"], ing["sam_seed"])
+    rb = np.frombuffer("".join(ps.reads).encode(), np.uint8)
+    ro = np.zeros(len(ps.reads) + 1, np.int64)
+    ro[1:] = np.cumsum([len(r) for r in ps.reads])
+    o = op2.Oracle()
+    o.set_graph(*g.packed())
+    rs = o.add_pacbio_reads(rb, ro, ps.names, 0.15, op2.single_cfg(min_prob_per_base=-1.0))
+    assert o.pacbio_ingest_sam(rs, walk, ps.sam) == ing["filed"]
+    assert len(o.pacbio_keys(rs)) == ing["n_keys"]
+    for key, want in ing["records"].items():
+        rec, lp = o.pacbio_records(rs, [int(x) for x in key.split()])
+        assert rec.tolist() == want["rec"]
+        np.testing.assert_allclose(lp, [float.fromhex(x) for x in want["logp"]], rtol=1e-13, atol=0)
+    v, z, tl = o.calc_prob([walk])
+    assert abs(v - float.fromhex(ing["prob"])) <= 1e-13 * abs(v) and z.tolist() == ing["zeros"] and tl == ing["total_len"]
