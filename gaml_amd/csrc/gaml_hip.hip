@@ -471,11 +471,15 @@ void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
   p.path_base.assign(1, 0);
   p.start_off.assign(1, 0);
   p.starts.clear();
-  for (const PathMemo* pm : v.paths) {
-    p.starts.insert(p.starts.end(), pm->starts.begin(), pm->starts.end());
-    p.start_off.push_back((int32_t)p.starts.size());
-    int32_t bits = ((pm->length + 64 + 31) / 32) * 32;  // one bit per path position, padded to words (+ slack)
-    p.path_base.push_back(p.path_base.back() + (cov ? bits : 0));
+  if (cov) {  // only the coverage sweep reads these
+    p.path_base.reserve(v.paths.size() + 1);
+    p.start_off.reserve(v.paths.size() + 1);
+    for (const PathMemo* pm : v.paths) {
+      p.starts.insert(p.starts.end(), pm->starts.begin(), pm->starts.end());
+      p.start_off.push_back((int32_t)p.starts.size());
+      int32_t bits = ((pm->length + 64 + 31) / 32) * 32;  // one bit per path position, padded to words (+ slack)
+      p.path_base.push_back(p.path_base.back() + bits);
+    }
   }
   p.total_bits = p.path_base.back();
   const double q2 = now_us();
@@ -1327,7 +1331,10 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
   if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
   if (n_paths < 0 || (n_paths > 0 && (!flat || !offs))) return fail(c, GAML_HIP_EINVAL, "bad path arguments");
   const double t0 = now_us();
-  c->pending_paths = unflatten(flat, offs, n_paths);
+  // (the vectors of the previous evaluation are reused: a path set of ~900 short paths would otherwise cost
+  // ~900 allocations per call)
+  c->pending_paths.resize((size_t)n_paths);
+  for (int32_t i = 0; i < n_paths; i++) c->pending_paths[i].assign(flat + offs[i], flat + offs[i + 1]);
   for (auto& p : c->pending_paths)
     for (int32_t x : p)
       if (x >= c->g.n()) return fail(c, GAML_HIP_EINVAL, "path refers to a node outside the graph");
