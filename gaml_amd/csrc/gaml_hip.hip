@@ -1827,49 +1827,90 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path
     }
     s.generation++;
   }
-  // SAM lines -> DP jobs for the records that will be filed (graph.cc:2746-2786)
+  // SAM lines -> DP jobs for the records that will be filed (graph.cc:2746-2786). Lines are independent:
+  // large inputs are cut at line boundaries into one chunk per host thread; chunk results are joined in
+  // order, so records are filed in SAM order as in the reference.
   struct Filed { int32_t walk, pos, pos_end, read_local; };
+  struct Chunk {
+    std::vector<Filed> filed;
+    std::vector<DpJob> jobs;
+    std::vector<uint32_t> ops;
+    int64_t records = 0, rows = 0;
+    int err = 0;
+    std::string msg;
+  };
+  const int32_t both_len = (int32_t)both.size();
+  auto parse_chunk = [&](const char* cb, const char* ce, Chunk& out) {
+    SamRecord rec;
+    for (const char* p = cb; p < ce;) {
+      const char* e = (const char*)memchr(p, '\n', (size_t)(ce - p));
+      const char* le = e ? e : ce;
+      if (le > p && *p != '@') {
+        if (!parse_sam_record(p, le, both_len, rec)) { out.err = GAML_HIP_EINVAL; out.msg = "SAM line with fewer than 10 columns"; return; }
+        out.records++;
+        auto id = s.name_id.find(rec.name);
+        if (id == s.name_id.end()) { out.err = GAML_HIP_EINVAL; out.msg = "SAM record names a read that is not in the read set: " + rec.name; return; }  // assert graph.cc:2751
+        const int32_t ib = (int32_t)(std::lower_bound(ends.begin(), ends.end(), std::max(0, rec.tstart - 5)) - ends.begin());
+        const int32_t ie = (int32_t)(std::lower_bound(ends.begin(), ends.end(), std::min(rec.tstart + rec.len + 5, seq_len)) - ends.begin());
+        if (ib < n && ie < n && ie >= ib && id->second >= s.lo && id->second < s.hi) {
+          Walk sub(path.begin() + ib, path.begin() + ie + 1);
+          auto st = starts.find(sub);
+          auto fr = fresh.find(sub);
+          if (st != starts.end() && st->second == ib && fr != fresh.end()) {
+            const int32_t local = (int32_t)(id->second - s.lo);
+            const int32_t pos_begin = ib > 0 ? ends[ib - 1] : 0;
+            out.filed.push_back(Filed{fr->second, rec.tstart - pos_begin, rec.tend - pos_begin, local});
+            DpShape shape;
+            DpJob j;
+            j.ops_off = (int64_t)out.ops.size();  // chunk-relative until the chunks are joined
+            pacbio_dp_ops(rec.cigar, out.ops, shape);
+            j.read_off = s.base_off[local];
+            j.read_len = (int32_t)(s.base_off[local + 1] - s.base_off[local]);
+            j.scratch_off = 0;
+            j.posstart = rec.posstart;
+            j.n_ops = shape.n_ops; j.row_f = shape.row_f; j.col_f = shape.col_f; j.bl = shape.bl; j.el = shape.el;
+            j.max_width = shape.max_width;
+            out.rows += shape.row_f + std::max(shape.el, 1) + 4 + shape.bl;
+            out.jobs.push_back(j);
+          }
+        }
+      }
+      if (!e) break;
+      p = e + 1;
+    }
+  };
+  const int n_chunks = sam_len < (1 << 20) ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+  std::vector<Chunk> chunks(n_chunks);
+  {
+    std::vector<const char*> cut(n_chunks + 1, sam + sam_len);
+    cut[0] = sam;
+    for (int k = 1; k < n_chunks; k++) {  // the next line start at or after the k-th share of the text
+      const char* at = sam + sam_len * k / n_chunks;
+      const char* nl = at < sam + sam_len ? (const char*)memchr(at, '\n', (size_t)(sam + sam_len - at)) : nullptr;
+      cut[k] = nl ? nl + 1 : sam + sam_len;
+      if (cut[k] < cut[k - 1]) cut[k] = cut[k - 1];
+    }
+    std::vector<std::thread> pool;
+    for (int k = 1; k < n_chunks; k++) pool.emplace_back(parse_chunk, cut[k], cut[k + 1], std::ref(chunks[k]));
+    parse_chunk(cut[0], cut[1], chunks[0]);
+    for (auto& th : pool) th.join();
+  }
   std::vector<Filed> filed;
   std::vector<DpJob> jobs;
   std::vector<uint32_t> ops;
   int64_t scratch = 0, records = 0, cells = 0, rows = 0;
-  SamRecord rec;
-  for (const char* p = sam, *end = sam + sam_len; p < end;) {
-    const char* e = (const char*)memchr(p, '\n', (size_t)(end - p));
-    const char* le = e ? e : end;
-    if (le > p && *p != '@') {
-      if (!parse_sam_record(p, le, (int32_t)both.size(), rec)) return fail(c, GAML_HIP_EINVAL, "SAM line with fewer than 10 columns");
-      records++;
-      auto id = s.name_id.find(rec.name);
-      if (id == s.name_id.end()) return fail(c, GAML_HIP_EINVAL, "SAM record names a read that is not in the read set: " + rec.name);  // assert graph.cc:2751
-      const int32_t ib = (int32_t)(std::lower_bound(ends.begin(), ends.end(), std::max(0, rec.tstart - 5)) - ends.begin());
-      const int32_t ie = (int32_t)(std::lower_bound(ends.begin(), ends.end(), std::min(rec.tstart + rec.len + 5, seq_len)) - ends.begin());
-      if (ib < n && ie < n && ie >= ib && id->second >= s.lo && id->second < s.hi) {
-        Walk sub(path.begin() + ib, path.begin() + ie + 1);
-        auto st = starts.find(sub);
-        auto fr = fresh.find(sub);
-        if (st != starts.end() && st->second == ib && fr != fresh.end()) {
-          const int32_t local = (int32_t)(id->second - s.lo);
-          const int32_t pos_begin = ib > 0 ? ends[ib - 1] : 0;
-          filed.push_back(Filed{fr->second, rec.tstart - pos_begin, rec.tend - pos_begin, local});
-          DpShape shape;
-          DpJob j;
-          j.ops_off = (int64_t)ops.size();
-          pacbio_dp_ops(rec.cigar, ops, shape);
-          j.read_off = s.base_off[local];
-          j.read_len = (int32_t)(s.base_off[local + 1] - s.base_off[local]);
-          j.scratch_off = scratch;
-          j.posstart = rec.posstart;
-          j.n_ops = shape.n_ops; j.row_f = shape.row_f; j.col_f = shape.col_f; j.bl = shape.bl; j.el = shape.el;
-          j.max_width = shape.max_width;
-          scratch += 2 * (int64_t)shape.max_width;
-          rows += shape.row_f + std::max(shape.el, 1) + 4 + shape.bl;
-          jobs.push_back(j);
-        }
-      }
+  for (Chunk& ch : chunks) {
+    if (ch.err) return fail(c, ch.err, ch.msg);
+    records += ch.records; rows += ch.rows;
+    const int64_t ops_base = (int64_t)ops.size();
+    ops.insert(ops.end(), ch.ops.begin(), ch.ops.end());
+    filed.insert(filed.end(), ch.filed.begin(), ch.filed.end());
+    for (DpJob j : ch.jobs) {
+      j.ops_off += ops_base;
+      j.scratch_off = scratch;
+      scratch += 2 * (int64_t)j.max_width;
+      jobs.push_back(j);
     }
-    if (!e) break;
-    p = e + 1;
   }
   const double t1 = now_us();
   float kernel_ms = 0;
