@@ -429,7 +429,7 @@ __device__ __forceinline__ void compact_finish(const PairedArgs& a, int i, const
   if (q.memo_idx >= 0) {
     const double t = fabs(m.x);
     compact_cover(a, c, q, t);
-    a.probs[i] = t;
+    __builtin_nontemporal_store(t, &a.probs[i]);  // written once, read by nobody on the hot path: keep it out of the caches
     lsum += m.y;
     zeros += (int)(__double2hiint(m.x) < 0);  // sign bit: floored (also for a term of exactly zero)
     return;
