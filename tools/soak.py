@@ -56,7 +56,7 @@ for seed in range(200, 200 + n_seeds):
             assert ctx.bad_bases(rs) == (wbad if penalty > 0 else 0), (seed, it)
             worst = max(worst, abs(gv[0] - wv[0]) / abs(wv[0]))
             if it % 25 == 0:
-                np.testing.assert_allclose(ctx.read_probs(rs), orc.paired_probs(ors)[0], rtol=4e-16, atol=0)
+                np.testing.assert_allclose(ctx.read_probs(rs), orc.paired_probs(ors)[0], rtol=1e-15, atol=0)  # a read with several terms: a few ulp (order of its sum)
         if rng.random() < 0.6:
             cur = new
     st = ctx.debug_table_stats(rs)
