@@ -561,8 +561,9 @@ class Context:
         _lib.gaml_hip_last_timing(self._h, out)
         return {"host_us": out[0], "device_wall_us": out[1], "kernel_us": out[2]}
 
-    def set_event_timing(self, on: bool):
-        _lib.gaml_hip_set_event_timing(self._h, 1 if on else 0)
+    def set_event_timing(self, on):
+        """False / 0: off; True / 1: every scoring launch; k > 1: every k-th launch."""
+        _lib.gaml_hip_set_event_timing(self._h, int(on))
 
     def kernel_stats(self, reset=False):
         n, us, b = C.c_int64(), C.c_double(), C.c_double()

@@ -1,6 +1,7 @@
 // gaml_hip.hip -- context, device memory, launches and the C ABI of libgaml_hip.so.
 // The kernels are in kernels.hip.h, the host data model in host_model.{h,cc}.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -220,6 +221,8 @@ struct gaml_hip_ctx {
   std::string err;
   // timing
   bool event_timing = false;
+  int event_every = 1;    // time every k-th scoring launch (attached events cost ~10 us of host time per launch)
+  int64_t event_tick = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // one pair per scoring launch of a call
   size_t ev_used = 0;
   double t_host_us = 0, t_dev_wall_us = 0, t_kernel_us = 0;
@@ -863,7 +866,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (n > 0) {
     // HIP events bracket the dominant kernel only (bench.py's roofline; rocprofv3 must agree)
-    if (c->event_timing) { if (int e = take_events(c, &ev)) return e; }
+    if (c->event_timing && (c->event_tick++ % c->event_every) == 0) { if (int e = take_events(c, &ev)) return e; }
     const int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
     s.last_total_blocks = a.total_blocks;
     if (c->host_results) {
@@ -883,18 +886,25 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
       s.dirty_marked = nd;
     }
     const dim3 grid(a.total_blocks), block(kBlock);
-    // the start event goes in right before the launch: host work between the two enqueues (sentinels, marks)
-    // would otherwise sit inside the measured interval as idle GPU time
-    if (ev) HIP_TRY(c, hipEventRecord(ev->first, st));
-    if (c->knobs[3] == 1) hipLaunchKernelGGL((paired_score_kernel<false, 1>), grid, block, dyn_lds, st, a);
-    else if (c->knobs[3] == 2) hipLaunchKernelGGL((paired_score_kernel<false, 2>), grid, block, dyn_lds, st, a);
-    else if (c->knobs[3] == 3) hipLaunchKernelGGL((paired_score_kernel<false, 3>), grid, block, dyn_lds, st, a);
-    else if (c->knobs[3] == 4) hipLaunchKernelGGL((paired_score_kernel<false, 4>), grid, block, dyn_lds, st, a);
-    else if (c->knobs[3] == 5) hipLaunchKernelGGL((paired_score_kernel<false, 5>), grid, block, dyn_lds, st, a);
-    else if (fin_mode) hipLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, a);
-    else hipLaunchKernelGGL((paired_score_kernel<true, 0>), grid, block, dyn_lds, st, a);
+    // Timed launches attach the two events to the dispatch itself (hipExtLaunchKernelGGL: the events carry
+    // the kernel's own begin / end stamps, what rocprofv3's kernel trace reports). Separate hipEventRecord
+    // markers around the launch would add the marker packets' processing to the interval: an EMPTY kernel
+    // of this grid reads 6 us that way (tools/stream_floor.hip).
+    if (ev && c->knobs[3] == 0) {
+      if (fin_mode) hipExtLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, ev->first, ev->second, 0, a);
+      else hipExtLaunchKernelGGL((paired_score_kernel<true, 0>), grid, block, dyn_lds, st, ev->first, ev->second, 0, a);
+    } else {
+      if (ev) HIP_TRY(c, hipEventRecord(ev->first, st));
+      if (c->knobs[3] == 1) hipLaunchKernelGGL((paired_score_kernel<false, 1>), grid, block, dyn_lds, st, a);
+      else if (c->knobs[3] == 2) hipLaunchKernelGGL((paired_score_kernel<false, 2>), grid, block, dyn_lds, st, a);
+      else if (c->knobs[3] == 3) hipLaunchKernelGGL((paired_score_kernel<false, 3>), grid, block, dyn_lds, st, a);
+      else if (c->knobs[3] == 4) hipLaunchKernelGGL((paired_score_kernel<false, 4>), grid, block, dyn_lds, st, a);
+      else if (c->knobs[3] == 5) hipLaunchKernelGGL((paired_score_kernel<false, 5>), grid, block, dyn_lds, st, a);
+      else if (fin_mode) hipLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, a);
+      else hipLaunchKernelGGL((paired_score_kernel<true, 0>), grid, block, dyn_lds, st, a);
+      if (ev) HIP_TRY(c, hipEventRecord(ev->second, st));
+    }
     HIP_TRY(c, hipGetLastError());
-    if (ev) HIP_TRY(c, hipEventRecord(ev->second, st));
     if (fin_mode == 1) {
       hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, a.total_blocks, out4, cov ? -1.0 : 0.0, (double)n);
       HIP_TRY(c, hipGetLastError());
@@ -938,8 +948,10 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   }
   c->prof[5] = now_us() - tp2 - c->prof[4];  // kernel launches
   // SURVEY.md 8d accounting: 16 B per record, 8 B read lengths, 8 B probability written, per pair
-  c->stat_algo_bytes += 16.0 * (double)p.assembled_records + 16.0 * (double)n;
-  c->stat_launches++;
+  if (!c->event_timing || ev) {  // with timing on, the statistics describe the timed launches
+    c->stat_algo_bytes += 16.0 * (double)p.assembled_records + 16.0 * (double)n;
+    c->stat_launches++;
+  }
   c->t_host_us += t_after_host;  // caller subtracts the start stamp
   return 0;
 }
@@ -2460,6 +2472,8 @@ int gaml_hip_last_timing(const gaml_hip_ctx* c, double* out3) {
 int gaml_hip_set_event_timing(gaml_hip_ctx* c, int on) {
   if (!c) return GAML_HIP_EINVAL;
   c->event_timing = on != 0;
+  c->event_every = on > 1 ? on : 1;
+  c->event_tick = 0;
   if (c->event_timing && c->device >= 0) {
     // event pairs are collected lazily (gaml_hip_kernel_stats); create a pool up front so that no
     // hipEventCreate lands inside a caller's timed region
