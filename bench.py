@@ -152,7 +152,7 @@ def main():
     for i in range(args.warmup):
         step(variants[i % len(variants)])
 
-    ctx.set_event_timing(8)  # every 8th launch: events attached to a dispatch cost ~10 us of host time each
+    ctx.set_event_timing(8)  # every 8th launch: events attached to a dispatch cost ~4 us of host time each
     ctx.kernel_stats(reset=True)
     # a step is ~70 us: one generation-2 pass of Python's garbage collector over the interpreter's
     # (torch-sized) object graph costs ~40 ms, i.e. hundreds of steps -- keep it out of the timed loop

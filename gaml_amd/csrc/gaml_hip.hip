@@ -221,7 +221,7 @@ struct gaml_hip_ctx {
   std::string err;
   // timing
   bool event_timing = false;
-  int event_every = 1;    // time every k-th scoring launch (attached events cost ~10 us of host time per launch)
+  int event_every = 1;    // time every k-th scoring launch (attached events cost ~4 us of host time per launch)
   int64_t event_tick = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // one pair per scoring launch of a call
   size_t ev_used = 0;

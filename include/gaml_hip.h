@@ -310,7 +310,7 @@ int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);
 int gaml_hip_last_timing(const gaml_hip_ctx* ctx, double* out3);
 /* HIP event timing of the dominant kernel (default off): on = 1 times every scoring launch, on = k > 1
  * every k-th. The two events are attached to the dispatch itself (hipExtLaunchKernelGGL), so they hold the
- * kernel's own begin / end stamps -- what rocprofv3's kernel trace reports -- at ~10 us of extra host time per
+ * kernel's own begin / end stamps -- what rocprofv3's kernel trace reports -- at ~4 us of extra host time per
  * timed launch; sampling keeps that out of a throughput measurement. gaml_hip_kernel_stats then describes the
  * timed launches (count, summed device time, summed algorithmic bytes). */
 int gaml_hip_set_event_timing(gaml_hip_ctx* ctx, int on);
