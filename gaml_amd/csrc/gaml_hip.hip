@@ -815,6 +815,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   }
   a.len_code = s.len_code.as<unsigned char>();
   a.len_combo = s.len_combo.as<uint32_t>();
+  a.n_codes = (int)std::min<size_t>(256, s.pt.len_combo.size());
   // memo of floor + log over the values a single-term pair can take; rebuilt only when 2T (or the
   // tables) changed. Floor must be positive for the "no alignment -> floored" shortcut.
   a.memo = nullptr; a.lt_codes = 0;

@@ -44,6 +44,7 @@ struct PairedArgs {
   const unsigned long long* rec8[2];
   const unsigned char* len_code;
   const uint32_t* len_combo;
+  int n_codes;               // entries of len_combo / floor_c / logfloor_c (<= 256)
   const unsigned long long* occ8[2];
   // per length-combination tables of the compact path (host libm, indexed by len_code):
   const double* pe[2];       // [code*64 + e] = mismatch^e * match^(L-e)  (the product of graph.cc:1859-1863)
@@ -604,8 +605,17 @@ template <bool TICKET, int ABL = 0>
 __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z) {
   double lsum = 0.0;
   int zeros = 0;
-  if (lb < a.blocks0) paired_compact_body<ABL>(a, lb, lsum, zeros);
-  else if (lb < a.blocks01) paired_regs_body<2, ABL>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
+  if (lb < a.blocks0) {
+    // the per-length-combination tables of the compact class (<= 256 entries each) are looked up once or twice
+    // per pair, each time behind another load: from LDS they cost an LDS access instead of an L2 round trip
+    __shared__ uint32_t sh_combo[256];
+    __shared__ double sh_floor[256], sh_logfloor[256];
+    for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_floor[k] = a.floor_c[k]; sh_logfloor[k] = a.logfloor_c[k]; }
+    __syncthreads();
+    PairedArgs b = a;
+    b.len_combo = sh_combo; b.floor_c = sh_floor; b.logfloor_c = sh_logfloor;
+    paired_compact_body<ABL>(b, lb, lsum, zeros);
+  } else if (lb < a.blocks01) paired_regs_body<2, ABL>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
   else if (lb < a.blocks012) paired_regs_body<4, ABL>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
   else paired_delta_body(a, lb - a.blocks012, a.main_blocks - a.blocks012, lsum, zeros);
   block_reduce(lsum, zeros, sh_s, sh_z);
