@@ -234,6 +234,8 @@ class Context:
             self._check(_lib.gaml_hip_set_presharded(self._h, presharded))
         self.rank, self.world = rank, world
         self._fast = None
+        self._fast_begin = None
+        self._fast_combine = None
 
     def close(self):
         if self._h:
@@ -359,6 +361,33 @@ class Context:
         rc = self._fast(self._h, fp.flat_ptr, fp.offs_ptr, fp.n, *self._out_ptrs)
         if rc < 0:
             self._check(rc)
+        return self._prob.value
+
+    # lean forms of the two-phase calls for tight loops (gaml_amd.dist): raw pointers, preallocated outputs
+    def eval_begin_fast(self, fp: "FlatPaths"):
+        if self._fast_begin is None:
+            proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
+            self._fast_begin = proto(("gaml_hip_eval_begin", _lib))
+            self._pending, self._tl2 = C.c_int64(), C.c_int32()
+            self._begin_out = (C.addressof(self._pending), C.addressof(self._tl2))
+        rc = self._fast_begin(self._h, fp.flat_ptr, fp.offs_ptr, fp.n, *self._begin_out)
+        if rc < 0:
+            self._check(rc)
+        return self._pending.value, self._tl2.value
+
+    def combine_fast(self, partials_ptr: int, total_len: int) -> float:
+        """gaml_hip_combine_partials on a host buffer given by address; zeros stay in self.last_zeros."""
+        if self._fast_combine is None:
+            proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p)
+            self._fast_combine = proto(("gaml_hip_combine_partials", _lib))
+            if self._fast is None:
+                self._prob, self._tl = C.c_double(), C.c_int32()
+                self._zeros = np.zeros(2 * max(1, self.num_readsets()), np.int32)
+            self._combine_out = (C.addressof(self._prob), self._zeros.ctypes.data)
+        rc = self._fast_combine(self._h, partials_ptr, total_len, *self._combine_out)
+        if rc < 0:
+            self._check(rc)
+        self._tl.value = total_len
         return self._prob.value
 
     @property

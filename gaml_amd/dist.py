@@ -32,6 +32,9 @@ class ShardedScorer:
         self.d_part = torch.zeros(4 * max(1, ctx.num_readsets()), dtype=torch.float64, device="cuda")
         self.h_part = torch.zeros(4 * max(1, ctx.num_readsets()), dtype=torch.float64).pin_memory()
         self._h_np = self.h_part.numpy()
+        self._h_ptr = self.h_part.data_ptr()
+        self._d_ptr = self.d_part.data_ptr()
+        self._has_pacbio = any(ctx.readset_kind(i) == 2 for i in range(ctx.num_readsets()))
         self._maps = None
         self._gathered = None
         # RCCL works on device tensors; gloo (tests: several ranks sharing one GPU, or CPU-only collectives)
@@ -57,7 +60,7 @@ class ShardedScorer:
     def _enqueue(self, paths, d_part):
         """Everything of one evaluation up to (not including) the all-reduce of its partials."""
         ctx = self.ctx
-        pending, total_len = ctx.eval_begin(paths)
+        pending, total_len = ctx.eval_begin_fast(paths) if isinstance(paths, api.FlatPaths) else ctx.eval_begin(paths)
         if pending:
             mx = torch.from_numpy(ctx.eval_pending_maxpos().copy()).cuda()
             self._all_reduce(mx, dist.ReduceOp.MAX)
@@ -74,7 +77,7 @@ class ShardedScorer:
             ctx.eval_coverage_export_async(i, own.data_ptr(), nbytes, sp)
             self._all_gather(gathered, own)
             ctx.eval_coverage_finish_async(i, gathered.data_ptr(), self.world, self.rank == 0, sp)
-        for i in range(ctx.eval_pacbio_pending()):  # PacBio sets with a penalty: interval events of all ranks (host lists)
+        for i in range(ctx.eval_pacbio_pending() if self._has_pacbio else 0):  # PacBio sets with a penalty: interval events of all ranks (host lists)
             own = torch.from_numpy(ctx.eval_pacbio_events(i).copy())
             sizes = torch.zeros(self.world, dtype=torch.int64)
             sizes[self.rank] = own.numel()
@@ -106,8 +109,17 @@ class ShardedScorer:
         self._all_reduce(self.d_part, dist.ReduceOp.SUM)  # the one collective of the hot path
         self.h_part.copy_(self.d_part, non_blocking=True)  # pinned: no staging allocation, one stream sync
         self.stream.synchronize()
-        prob, zeros = self.ctx.combine_partials(self._h_np, total_len)
-        return prob, zeros, total_len
+        prob = self.ctx.combine_fast(self._h_ptr, total_len)
+        return prob, self.ctx.last_zeros, total_len
+
+    def score(self, fp: "api.FlatPaths") -> float:
+        """calc_prob for tight loops: prebuilt FlatPaths in, the value out (floored counts: ctx.last_zeros). The
+        caller keeps `with torch.cuda.stream(scorer.stream)` around its loop."""
+        total_len = self._enqueue(fp, self.d_part)
+        self._all_reduce(self.d_part, dist.ReduceOp.SUM)
+        self.h_part.copy_(self.d_part, non_blocking=True)
+        self.stream.synchronize()
+        return self.ctx.combine_fast(self._h_ptr, total_len)
 
     def calc_prob_batch(self, path_sets):
         """Several path sets whose values are only compared afterwards: evaluations
