@@ -350,4 +350,27 @@ __global__ __launch_bounds__(64 * kAlnWaves) void extend_kernel(const AlnCand* c
   if (lane == 0) hits[t] = out;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 4. large batches: put the hits in the host's order on the device -- (window, position, read, strand,
+//    order), failed extensions last -- with two stable radix sorts (the whole key does not fit 64 bits).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hit_keys_kernel(const AlnHit* hits, unsigned n, unsigned long long* key_minor,
+                                                       unsigned long long* key_major, unsigned* idx, unsigned* n_ok) {
+  for (unsigned t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+    const AlnHit h = hits[t];
+    idx[t] = t;
+    if (h.edit < 0) { key_minor[t] = ~0ull; key_major[t] = ~0ull; continue; }
+    key_minor[t] = ((unsigned long long)(unsigned)h.read << 25) | ((unsigned long long)(h.strand & 1) << 24) | (unsigned long long)(h.order & 0xffffff);
+    key_major[t] = ((unsigned long long)(unsigned)h.win << 32) | (unsigned long long)(unsigned)h.pos;
+    atomicAdd(n_ok, 1u);
+  }
+}
+__global__ __launch_bounds__(256) void gather_u64_kernel(const unsigned long long* src, const unsigned* idx, unsigned n, unsigned long long* dst) {
+  for (unsigned t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) dst[t] = src[idx[t]];
+}
+__global__ __launch_bounds__(256) void gather_hits_kernel(const AlnHit* src, const unsigned* idx, unsigned n, AlnHit* dst) {
+  for (unsigned t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) dst[t] = src[idx[t]];
+}
+
 }  // namespace gaml

@@ -2,6 +2,7 @@
 // The kernels are in kernels.hip.h, the host data model in host_model.{h,cc}.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -91,7 +92,9 @@ struct AlignDev {  // device copies the GPU aligner needs: reads (1 byte per bas
 };
 struct AlignScratch {  // per context, grown on demand
   DevBuf wstr, wins, hbuf, hbuf_off, spans, cands, hits, counters;
-  void release() { wstr.release(); wins.release(); hbuf.release(); hbuf_off.release(); spans.release(); cands.release(); hits.release(); counters.release(); }
+  DevBuf sort_keys, sort_idx, sort_tmp, hits_sorted;  // large batches: hits ordered on the device
+  void release() { wstr.release(); wins.release(); hbuf.release(); hbuf_off.release(); spans.release(); cands.release(); hits.release(); counters.release();
+                   sort_keys.release(); sort_idx.release(); sort_tmp.release(); hits_sorted.release(); }
 };
 
 struct MateDev {
@@ -1265,6 +1268,7 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
   double t3 = t2;
   const unsigned nc = counts[1];
   std::vector<AlnHit> hits(nc);
+  bool device_sorted = false;
   if (nc) {
     HIP_TRY(c, S.hits.reserve((size_t)nc * sizeof(AlnHit)));
     hipLaunchKernelGGL(extend_kernel, dim3((nc + kAlnWaves - 1) / kAlnWaves), dim3(64 * kAlnWaves), 0, 0, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1,
@@ -1274,7 +1278,46 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
     if (c->knobs[9]) {
       HIP_TRY(c, hipDeviceSynchronize()); t3 = now_us();
     }
-    HIP_TRY(c, hipMemcpy(hits.data(), S.hits.p, (size_t)nc * sizeof(AlnHit), hipMemcpyDeviceToHost));
+    // Large batches: order the hits on the device (window, position, read, strand, order; failed extensions
+    // last) and fetch only the successful ones; the host then only walks them. Keys: read < 2^31, order < 2^24.
+    if (nc >= 200000 && c->knobs[5] != 2) {
+      const size_t n = nc;
+      HIP_TRY(c, S.sort_keys.reserve(4 * n * sizeof(unsigned long long)));   // minor | major | two alternates
+      HIP_TRY(c, S.sort_idx.reserve(2 * n * sizeof(unsigned)));
+      HIP_TRY(c, S.hits_sorted.reserve(n * sizeof(AlnHit)));
+      unsigned long long* k_minor = S.sort_keys.as<unsigned long long>();
+      unsigned long long* k_major = k_minor + n;
+      unsigned long long* k_alt = k_major + n;
+      unsigned long long* k_alt2 = k_alt + n;
+      unsigned* idx = S.sort_idx.as<unsigned>();
+      unsigned* idx_alt = idx + n;
+      unsigned* n_ok = S.counters.as<unsigned>() + 2;
+      HIP_TRY(c, hipMemset(n_ok, 0, sizeof(unsigned)));
+      const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+      hipLaunchKernelGGL(hit_keys_kernel, dim3(grid), dim3(256), 0, 0, S.hits.as<AlnHit>(), (unsigned)n, k_minor, k_major, idx, n_ok);
+      HIP_TRY(c, hipGetLastError());
+      size_t tmp_bytes = 0;
+      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_minor, k_alt, idx, idx_alt, (int)n, 0, 56, (hipStream_t)0));
+      HIP_TRY(c, S.sort_tmp.reserve(tmp_bytes));
+      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(S.sort_tmp.p, tmp_bytes, k_minor, k_alt, idx, idx_alt, (int)n, 0, 56, (hipStream_t)0));
+      // second, stable pass by (window, position): the major keys in the order of the first pass
+      hipLaunchKernelGGL(gather_u64_kernel, dim3(grid), dim3(256), 0, 0, k_major, idx_alt, (unsigned)n, k_alt);
+      HIP_TRY(c, hipGetLastError());
+      size_t tmp2 = 0;
+      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, k_alt, k_alt2, idx_alt, idx, (int)n, 0, 64, (hipStream_t)0));
+      HIP_TRY(c, S.sort_tmp.reserve(tmp2));
+      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(S.sort_tmp.p, tmp2, k_alt, k_alt2, idx_alt, idx, (int)n, 0, 64, (hipStream_t)0));
+      hipLaunchKernelGGL(gather_hits_kernel, dim3(grid), dim3(256), 0, 0, S.hits.as<AlnHit>(), idx, (unsigned)n, S.hits_sorted.as<AlnHit>());
+      HIP_TRY(c, hipGetLastError());
+      unsigned ok_count = 0;
+      HIP_TRY(c, hipMemcpy(&ok_count, n_ok, sizeof(unsigned), hipMemcpyDeviceToHost));
+      if (c->knobs[9]) t3 = now_us();
+      hits.resize(ok_count);
+      if (ok_count) HIP_TRY(c, hipMemcpy(hits.data(), S.hits_sorted.p, (size_t)ok_count * sizeof(AlnHit), hipMemcpyDeviceToHost));
+      device_sorted = true;
+    } else {
+      HIP_TRY(c, hipMemcpy(hits.data(), S.hits.p, (size_t)nc * sizeof(AlnHit), hipMemcpyDeviceToHost));
+    }
   }
   const double t4 = now_us();
   if (!c->knobs[9]) t3 = t4;
@@ -1285,36 +1328,41 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
   std::vector<int64_t> wstart(nw + 1, 0);
   for (const AlnHit& h : hits) if (h.edit >= 0) wstart[h.win + 1]++;
   for (int k = 0; k < nw; k++) wstart[k + 1] += wstart[k];
-  std::vector<AlnHit> ok((size_t)wstart[nw]);
-  {
-    std::vector<int64_t> fill(wstart.begin(), wstart.end() - 1);
-    for (const AlnHit& h : hits) if (h.edit >= 0) ok[(size_t)fill[h.win]++] = h;
-  }
-  auto sort_range = [&](int k0, int k1) {
-    for (int k = k0; k < k1; k++)
-      std::sort(ok.begin() + wstart[k], ok.begin() + wstart[k + 1], [](const AlnHit& a, const AlnHit& b) {
-        if (a.pos != b.pos) return a.pos < b.pos;
-        if (a.read != b.read) return a.read < b.read;
-        if (a.strand != b.strand) return a.strand < b.strand;
-        return a.order < b.order;
-      });
-  };
-  const int n_threads = ok.size() > (size_t)200000 ? (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
-  if (n_threads > 1) {
-    // contiguous window ranges of about equal hit counts
-    std::vector<std::thread> pool;
-    int k0 = 0;
-    for (int t = 0; t < n_threads; t++) {
-      const int64_t target = wstart[nw] * (t + 1) / n_threads;
-      int k1 = k0;
-      while (k1 < nw && wstart[k1 + 1] <= target) k1++;
-      if (t == n_threads - 1) k1 = nw;
-      pool.emplace_back(sort_range, k0, k1);
-      k0 = k1;
-    }
-    for (auto& th : pool) th.join();
+  std::vector<AlnHit> ok;
+  if (device_sorted) {
+    ok.swap(hits);  // already (window, position, read, strand, order), successful extensions only
   } else {
-    sort_range(0, nw);
+    ok.resize((size_t)wstart[nw]);
+    {
+      std::vector<int64_t> fill(wstart.begin(), wstart.end() - 1);
+      for (const AlnHit& h : hits) if (h.edit >= 0) ok[(size_t)fill[h.win]++] = h;
+    }
+    auto sort_range = [&](int k0, int k1) {
+      for (int k = k0; k < k1; k++)
+        std::sort(ok.begin() + wstart[k], ok.begin() + wstart[k + 1], [](const AlnHit& a, const AlnHit& b) {
+          if (a.pos != b.pos) return a.pos < b.pos;
+          if (a.read != b.read) return a.read < b.read;
+          if (a.strand != b.strand) return a.strand < b.strand;
+          return a.order < b.order;
+        });
+    };
+    const int n_threads = ok.size() > (size_t)200000 ? (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (n_threads > 1) {
+      // contiguous window ranges of about equal hit counts
+      std::vector<std::thread> pool;
+      int k0 = 0;
+      for (int t = 0; t < n_threads; t++) {
+        const int64_t target = wstart[nw] * (t + 1) / n_threads;
+        int k1 = k0;
+        while (k1 < nw && wstart[k1 + 1] <= target) k1++;
+        if (t == n_threads - 1) k1 = nw;
+        pool.emplace_back(sort_range, k0, k1);
+        k0 = k1;
+      }
+      for (auto& th : pool) th.join();
+    } else {
+      sort_range(0, nw);
+    }
   }
   std::vector<gaml_aligment> recs;
   for (int k = 0; k < nw; k++) {
