@@ -1280,7 +1280,7 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
     }
     // Large batches: order the hits on the device (window, position, read, strand, order; failed extensions
     // last) and fetch only the successful ones; the host then only walks them. Keys: read < 2^31, order < 2^24.
-    if (nc >= 200000 && c->knobs[5] != 2) {
+    if (nc >= 100000 && c->knobs[5] != 2) {
       const size_t n = nc;
       HIP_TRY(c, S.sort_keys.reserve(4 * n * sizeof(unsigned long long)));   // minor | major | two alternates
       HIP_TRY(c, S.sort_idx.reserve(2 * n * sizeof(unsigned)));

@@ -73,5 +73,13 @@ def test_gpu_aligner_speed_and_parity_at_cfg2():
         t0 = time.time()
         out[name] = (ctx.calc_prob([walk]), time.time() - t0, ctx)
     assert out["gpu"][0][0] == out["cpu"][0][0] and out["gpu"][0][1].tolist() == out["cpu"][0][1].tolist()
+    # > 100,000 seed candidates per mate: the hits were ordered on the device (two radix sorts); same records
+    assert out["gpu"][2].aligner_stats()["candidates"] > 300_000
+    for w in ([walk[0]], [walk[4]], walk[0:3], walk[6:9], [walk[-1]]):
+        for mate in (0, 1):
+            a, b = out["gpu"][2].window_records(0, mate, w), out["cpu"][2].window_records(0, mate, w)
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert a.tobytes() == b.tobytes()
     print(f"cold CalcProb cfg2: gpu aligner {out['gpu'][1]:.3f} s ({out['gpu'][2].aligner_stats()}), host aligner {out['cpu'][1]:.3f} s")
     assert out["gpu"][1] < out["cpu"][1]
