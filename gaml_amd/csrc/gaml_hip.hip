@@ -1364,6 +1364,7 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
       sort_range(0, nw);
     }
   }
+  m.pool.reserve(m.pool.size() + ok.size());  // one growth step for the whole batch
   std::vector<gaml_aligment> recs;
   for (int k = 0; k < nw; k++) {
     recs.clear();
