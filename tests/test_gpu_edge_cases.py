@@ -144,3 +144,45 @@ def test_unusual_scoring_parameters(kw, mean, sd):
         if kw.get("penalty_constant", 0) > 0:
             assert ctx.bad_bases(rs) == wbad
         assert abs(got - want) <= 1e-9 * abs(want)
+
+
+def test_compact_tables_and_sampled_event_timing():
+    """Maintenance and measurement entry points: gaml_hip_compact_tables folds the delta store at the next
+    evaluation without changing values beyond the order of the final sum; gaml_hip_set_event_timing(k) times
+    every k-th scoring launch and gaml_hip_kernel_stats then describes exactly the timed launches."""
+    from gaml_amd import api
+    genome = synth.make_genome(150_000, 97)
+    g = synth.make_graph(genome, synth.cut_lengths(150_000, 97, long_rng=(600, 4000)))
+    pr = synth.make_paired_reads(genome, 40_000, 100, 240.0, 24.0, 0.01, 97)
+    ctx = api.Context(device=0)
+    ctx.set_graph(*g.packed())
+    rs = ctx.add_paired(api.paired_cfg(240.0, 24.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    walk = synth.genome_walk(g)
+    sets = [[walk], [walk[:9], walk[9:]], [walk[:20], walk[20:]], [walk[:5], walk[5:30], walk[30:]]]
+    first = [ctx.calc_prob(s)[0] for s in sets]          # later sets activate junction windows: delta pairs
+    st = ctx.debug_table_stats(rs)
+    assert st["dirty_pairs"] > 0 and st["delta_updates"] > 0
+    ctx.compact_tables()
+    again = [ctx.calc_prob(s)[0] for s in sets]
+    st2 = ctx.debug_table_stats(rs)
+    assert st2["dirty_pairs"] == 0 and st2["full_rebuilds"] == st["full_rebuilds"] + 1
+    for a, b in zip(first, again):
+        assert abs(a - b) <= 1e-13 * abs(a)
+    # sampled timing
+    ctx.set_event_timing(4)
+    ctx.kernel_stats(reset=True)
+    for i in range(20):
+        ctx.calc_prob(sets[i % 4])
+    ks = ctx.kernel_stats(reset=True)
+    assert ks["launches"] == 5 and ks["device_us"] > 0 and ks["algo_bytes"] > 0
+    ctx.set_event_timing(1)
+    for i in range(6):
+        ctx.calc_prob(sets[i % 4])
+    ks = ctx.kernel_stats(reset=True)
+    assert ks["launches"] == 6
+    per_launch_us = ks["device_us"] / ks["launches"]
+    assert 1.0 < per_launch_us < 1000.0
+    ctx.set_event_timing(0)
+    for i in range(3):
+        ctx.calc_prob(sets[i % 4])
+    assert ctx.kernel_stats(reset=True)["device_us"] == 0.0
