@@ -251,7 +251,7 @@ def main():
             out["batched"] = {"api": "gaml_hip_calc_prob_batch", "sets_per_call": len(variants_py), "calls": calls,
                               "ms_per_set": 1e3 * tb / (calls * len(variants_py)),
                               "reads_per_sec": total_reads * calls * len(variants_py) / tb}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is taken on rank 0 at N = 1 only
             sample = min(args.cpu_sample_pairs, n_pairs_rank)
             cb, cpu_vals, _, _ = cpu_baseline(gb, go, b1, o1, b2, o2, sample, wl.read_len, variants_py)
             out["cpu_baseline"] = cb
