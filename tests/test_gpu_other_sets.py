@@ -361,3 +361,39 @@ def test_sharded_pacbio_penalty_merges_the_ranks_intervals():
     c.eval_begin(paths)
     with pytest.raises(api.GamlHipError):
         c.eval_finish()  # without the exchange the sharded context refuses
+
+
+def test_external_aligner_records_score_like_the_internal_aligner():
+    """The reference can take its per-window alignments from an external aligner (Bowtie2 branch,
+    graph.cc:924-1033); gaml_hip_put_window_records is that entry. A context fed every window's records from
+    outside (here: copied from a context that aligned them itself) must score identically and align nothing."""
+    from gaml_amd import api
+    genome, g = _graph(90_000, 83, long_rng=(800, 4000))
+    pr = synth.make_paired_reads(genome, 7000, 100, 250.0, 25.0, 0.01, 83)
+    args = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    walk = synth.genome_walk(g)
+    paths = [walk[:12], walk[12:]]
+    own = api.Context(device=0)
+    own.set_graph(*g.packed())
+    rs = own.add_paired(api.paired_cfg(250.0, 25.0, penalty_constant=0.0002), *args)
+    want = own.calc_prob(paths)
+    fed = api.Context(device=0)
+    fed.set_graph(*g.packed())
+    rs2 = fed.add_paired(api.paired_cfg(250.0, 25.0, penalty_constant=0.0002), *args)
+    n_put = 0
+    for mate in (0, 1):
+        for wid in range(own.window_count(rs, mate)):
+            key = own.debug_window_walk(rs, mate, wid)
+            r = own.window_records(rs, mate, key)
+            recs = np.zeros(len(r), api.ALIGMENT)
+            if len(r):
+                recs["position"], recs["edit_dist"], recs["read_id"], recs["orientation"] = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+            fed.put_window_records(rs2, mate, key, recs)
+            n_put += 1
+    assert n_put > 20
+    got = fed.calc_prob(paths)
+    assert fed.aligner_stats()["windows"] == 0  # nothing was aligned by the library
+    assert got[2] == want[2] and got[1].tolist() == want[1].tolist()
+    assert abs(got[0] - want[0]) <= 1e-13 * abs(want[0])
+    assert fed.bad_bases(rs2) == own.bad_bases(rs)
+    np.testing.assert_array_equal(fed.read_probs(rs2), own.read_probs(rs))
