@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgaml_hip.so")
+LIB_PATH = os.environ.get("GAML_HIP_LIB") or os.path.join(_HERE, "libgaml_hip.so")  # override: A/B builds (tools/)
 
 OK, EINVAL, ENODEVICE, EHIP, ESTATE = 0, -1, -2, -3, -4
 

@@ -136,9 +136,7 @@ struct PairedSet {
   int last_total_blocks = 0;
   bool last_host_partials = false;
   DevBuf len12, probs, tabs, occ_arena, cov_bits, bad;
-  std::vector<uint32_t> ovf_stamp;  // per slot: evaluation serial that last put it on the overflow list
-  uint32_t ovf_serial = 0;
-  std::vector<int32_t> ovf_items;
+  DevBuf gen_bits;  // one bit per table-class slot: needs paired_general_kernel (written by the main kernel)
   hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;
   PairedPlanner planner;
   OccImage image[2];                 // persistent host images of the occurrence tables, patched per call
@@ -634,27 +632,9 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     st_off = align16(so_off + p.start_off.size() * sizeof(int32_t));
     total = align16(st_off + p.starts.size() * sizeof(int32_t));
   }
-  // pairs (main-kernel slots) with a record in a window that occurs several times: the main kernel
-  // skips them, the overflow kernel scores them. O(records of such windows); empty for most path sets.
-  {
-    const int64_t n_main_slots = s.pt.class_count[0] + s.pt.class_count[1] + s.pt.class_count[2];
-    s.ovf_items.clear();
-    if (s.ovf_stamp.size() != (size_t)s.mate[0].n_local()) s.ovf_stamp.assign(s.mate[0].n_local(), 0);
-    if (++s.ovf_serial == 0) { std::fill(s.ovf_stamp.begin(), s.ovf_stamp.end(), 0); s.ovf_serial = 1; }
-    for (int mt = 0; mt < 2; mt++) {
-      const ShortMate& m = s.mate[mt];
-      for (int32_t w : s.image[mt].general_wids) {
-        const Window& win = m.wins[w];
-        for (int64_t k = win.first; k < win.first + win.count; k++) {
-          const int32_t slot_i = s.pt.slot_of_read[m.pool[k].read_id];
-          if (slot_i < n_main_slots && s.ovf_stamp[slot_i] != s.ovf_serial && !s.dirty_index.count(slot_i)) { s.ovf_stamp[slot_i] = s.ovf_serial; s.ovf_items.push_back(slot_i); }
-        }
-      }
-    }
-    std::sort(s.ovf_items.begin(), s.ovf_items.end());  // fixed item order = fixed summation order
-  }
-  const size_t ov_off = total;
-  total = align16(ov_off + std::max<size_t>(1, s.ovf_items.size()) * sizeof(int32_t));
+  // (Pairs with a record in a window that occurs several times: the main kernel notes them in a bitmap and
+  // paired_general_kernel scores them, see below. An earlier version listed them here on the host,
+  // O(records of such windows) per call -- 2.6 ms per call once an annealing run had produced many repeated nodes.)
   size_t o8_off[2];
   for (int mt = 0; mt < 2; mt++) {
     o8_off[mt] = total;
@@ -668,7 +648,6 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   if (slot < 0) return slot;
   pack_image(s.image[0], l0, (char*)host);
   pack_image(s.image[1], l1, (char*)host);
-  if (!s.ovf_items.empty()) memcpy((char*)host + ov_off, s.ovf_items.data(), s.ovf_items.size() * sizeof(int32_t));
   for (int mt = 0; mt < 2; mt++)
     if (!s.image[mt].occ8.empty()) memcpy((char*)host + o8_off[mt], s.image[mt].occ8.data(), s.image[mt].occ8.size() * sizeof(uint64_t));
   if (cov) {
@@ -836,8 +815,6 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
       a.memo = s.memo.as<double2>(); a.lt_codes = codes;
     }
   }
-  a.ovf_items = (const int*)(arena + ov_off);
-  a.n_ovf_items = (int)s.ovf_items.size();
   a.n_dirty = (int)nd;
   const char* delta = (const char*)s.delta_dev.p;
   a.dirty_slots = s.dl_slot.as<int>();
@@ -847,7 +824,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     a.spill_off[mt] = (const int*)(delta + s.delta_off[2 * mt]);
     a.spill_recs[mt] = (const int4*)(delta + s.delta_off[2 * mt + 1]);
   }
-  const int64_t ovf_total = (n - n_main) + (int64_t)s.ovf_items.size();  // wave-per-pair items (delta pairs: lane per pair in the main range)
+  const int64_t ovf_total = n - n_main;  // wave-per-pair items (delta pairs: lane per pair in the main range)
   // 3 blocks per CU and ~2-3 pipelined iterations per lane at cfg3 (tools/kbench.py sweep); larger sets get more blocks, up to 8 per CU
   const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : (int)std::min<int64_t>(kMaxBlocks, std::max<int64_t>(768, n0 / 2900));
   // the compact path handles 2 pairs per lane and iteration
@@ -866,19 +843,34 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   const int ovf_blocks = ovf_total > 0 ? (int)std::min<int64_t>((ovf_total + 3) / 4, kOvfMaxBlocks) : 0;
   a.main_blocks = main_blocks;
   a.total_blocks = main_blocks + ovf_blocks;
+  // some window occurs several times in this path set (or needs the long occurrence form): second launch over
+  // the pairs the main kernel notes
+  const bool gen_pass = n_main > 0 && c->knobs[3] == 0 && (!s.image[0].general_wids.empty() || !s.image[1].general_wids.empty());
+  a.gen_bits = nullptr; a.gen_w1 = a.gen_w2 = 0;
+  int gen_blocks = 0;
+  if (gen_pass) {
+    const int64_t w0 = (n0 + 63) / 64, w1 = (n01 - n0 + 63) / 64, w2 = (n_main - n01 + 63) / 64;
+    const size_t bytes = (size_t)(w0 + w1 + w2) * sizeof(unsigned long long);
+    if (bytes > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(bytes + bytes / 4)); }
+    a.gen_bits = s.gen_bits.as<unsigned long long>();
+    a.gen_w1 = (int)w0; a.gen_w2 = (int)(w0 + w1);
+    gen_blocks = (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, kMaxBlocks);
+  }
 
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (n > 0) {
     // HIP events bracket the dominant kernel only (bench.py's roofline; rocprofv3 must agree)
     if (c->event_timing && (c->event_tick++ % c->event_every) == 0) { if (int e = take_events(c, &ev)) return e; }
-    const int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
-    s.last_total_blocks = a.total_blocks;
+    int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
+    if (fin_mode == 0 && gen_pass) fin_mode = 1;
+    const int n_partials = a.total_blocks + gen_blocks;
+    s.last_total_blocks = n_partials;
     if (c->host_results) {
       // sentinels: the host can tell when every block's partial has landed without waiting for the
       // runtime's completion signal (fetch_partials)
       double* hs = (double*)s.h_part_sum.p;
       int* hz = (int*)s.h_part_zero.p;
-      for (int b2 = 0; b2 < a.total_blocks; b2++) { hs[b2] = std::numeric_limits<double>::quiet_NaN(); hz[b2] = INT_MIN; }
+      for (int b2 = 0; b2 < n_partials; b2++) { hs[b2] = std::numeric_limits<double>::quiet_NaN(); hz[b2] = INT_MIN; }
     }
     const int dyn_lds = c->knobs[1];  // experiment: occupancy limiter
     if (nd > s.dirty_marked) {  // marks stay on the device until the next full build: only new delta pairs need one
@@ -895,7 +887,8 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     // markers around the launch would add the marker packets' processing to the interval: an EMPTY kernel
     // of this grid reads 6 us that way (tools/stream_floor.hip).
     if (ev && c->knobs[3] == 0) {
-      if (fin_mode) hipExtLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, ev->first, ev->second, 0, a);
+      if (gen_pass) hipExtLaunchKernelGGL((paired_score_kernel<false, 0, true>), grid, block, dyn_lds, st, ev->first, ev->second, 0, a);
+      else if (fin_mode) hipExtLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, ev->first, ev->second, 0, a);
       else hipExtLaunchKernelGGL((paired_score_kernel<true, 0>), grid, block, dyn_lds, st, ev->first, ev->second, 0, a);
     } else {
       if (ev) HIP_TRY(c, hipEventRecord(ev->first, st));
@@ -904,13 +897,18 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
       else if (c->knobs[3] == 3) hipLaunchKernelGGL((paired_score_kernel<false, 3>), grid, block, dyn_lds, st, a);
       else if (c->knobs[3] == 4) hipLaunchKernelGGL((paired_score_kernel<false, 4>), grid, block, dyn_lds, st, a);
       else if (c->knobs[3] == 5) hipLaunchKernelGGL((paired_score_kernel<false, 5>), grid, block, dyn_lds, st, a);
+      else if (gen_pass) hipLaunchKernelGGL((paired_score_kernel<false, 0, true>), grid, block, dyn_lds, st, a);
       else if (fin_mode) hipLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, a);
       else hipLaunchKernelGGL((paired_score_kernel<true, 0>), grid, block, dyn_lds, st, a);
       if (ev) HIP_TRY(c, hipEventRecord(ev->second, st));
     }
     HIP_TRY(c, hipGetLastError());
+    if (gen_pass) {
+      hipLaunchKernelGGL(paired_general_kernel, dim3(gen_blocks), dim3(kBlock), 0, st, a, a.total_blocks);
+      HIP_TRY(c, hipGetLastError());
+    }
     if (fin_mode == 1) {
-      hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, a.total_blocks, out4, cov ? -1.0 : 0.0, (double)n);
+      hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, n_partials, out4, cov ? -1.0 : 0.0, (double)n);
       HIP_TRY(c, hipGetLastError());
     }
   } else {

@@ -65,8 +65,13 @@ struct PairedArgs {
   int blocks01, blocks012;   // [blocks012, main_blocks): delta pairs (lane per pair)
   int n01;                   // slots [n0, n01): class 1 (<= 2 records per mate); [n01, n_main): class 2 (<= 4)
   int n_main;                // the lane-per-pair paths score slots [0, n_main)
-  const int* ovf_items;      // host-built list: slots < n_main that touch a window occurring several times
-  int n_ovf_items;           // the overflow kernel scores slots [n_main, n) and this list
+  // Pairs of the table classes with a record in a window that occurs several times (or whose occurrence does not
+  // fit the compact forms) need the fully general loop. The main kernel only NOTES them: one bit per slot, a
+  // 64-bit ballot per wave and iteration (class-relative slot index; every word of a class is written by exactly
+  // one wave, so nothing has to be zeroed); paired_general_kernel scores them in a second launch. Null when the
+  // host saw no such window in this path set -- then neither the notes nor the second launch exist.
+  unsigned long long* gen_bits;
+  int gen_w1, gen_w2;        // first word of class 1 / class 2 (class 0 starts at word 0)
   int main_blocks, total_blocks;  // grid sizes: partial slots [0, main_blocks) main, then overflow
   // Delta: pairs whose record lists changed since the device tables were built (newly activated
   // windows). Their slots carry a DIRTY mark in the tables; their complete record lists travel with
@@ -385,8 +390,7 @@ struct CompactPrep {
 };
 __device__ __forceinline__ void compact_prep(const PairedArgs& a, const Compact1& c, CompactPrep& q) {
   q.memo_idx = -1; q.dist = -1; q.scores = false;
-  // a record in a window that needs the general path (occurs several times, ...): the host put
-  // this pair on the overflow list
+  // a record in a window that needs the general path (occurs several times, ...): compact_general
   q.skip = (c.o1 != kNone8 && (c.o1 >> 63)) || (c.o2 != kNone8 && (c.o2 >> 63));
   if (q.skip || c.o1 == kNone8 || c.o2 == kNone8 || ((c.o1 ^ c.o2) >> 48) != 0) return;  // both occur, same path
   const int p1 = (int)((c.r1 >> 24) & 0xfffffff), p2 = (int)((c.r2 >> 24) & 0xfffffff);
@@ -424,6 +428,17 @@ __device__ __forceinline__ void compact_cover(const PairedArgs& a, const Compact
   }
 }
 
+// A class-0 pair with a record in a window that occurs several times in this path set (or whose occurrence
+// does not fit the 8-byte form): fully general loop over (record, occurrence) candidates, one lane per pair
+// (paired_general_kernel). Doing this inside the streaming loop cost the loop 1.2 us of 12 at cfg3 even when no
+// such pair exists (registers / code size), hence the second launch.
+__device__ __forceinline__ void compact_general(const PairedArgs& a, int i, double& lsum, int& zeros) {
+  const int lc = a.len_code[i];
+  const uint32_t l12 = a.len_combo[lc];
+  const double acc = paired_general(a, rec8_to_quad(a.rec8[0][i]), rec8_to_quad(a.rec8[1][i]), l12 & 0xffff, l12 >> 16);
+  finish_read_compact(a, i, acc, lc, lsum, zeros);
+}
+
 // one scored class-0 pair: per-read probability out, floor / log into the running sums
 __device__ __forceinline__ void compact_finish(const PairedArgs& a, int i, const Compact1& c, const CompactPrep& q, double2 m,
                                                double& lsum, int& zeros) {
@@ -446,7 +461,7 @@ __device__ __forceinline__ void compact_load(const PairedArgs& a, int i, bool ok
   c.lc = ok ? a.len_code[i] : 0;
 }
 
-template <int ABL>
+template <int ABL, bool GEN>
 __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb, double& lsum, int& zeros) {
   // Two pairs per lane and iteration, software pipelined: the record loads of iteration k+1 are
   // issued before iteration k's occurrence lookups and arithmetic, so a lane always has one round of
@@ -490,8 +505,12 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
         const double2 m1 = q1.memo_idx >= 0 ? a.memo[q1.memo_idx] : make_double2(0.0, 0.0);
         if (ABL == 3) { a.probs[i0] = fabs(m0.x); lsum += m0.x; if (two) { a.probs[i1] = fabs(m1.x); lsum += m1.x; } }
         else {
-          if (!q0.skip && !d0) compact_finish(a, i0, c0, q0, m0, lsum, zeros);
-          if (two && !q1.skip && !d1) compact_finish(a, i1, c1, q1, m1, lsum, zeros);
+          if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
+            const unsigned long long k0 = __ballot(q0.skip), k1 = __ballot(q1.skip);
+            if ((threadIdx.x & 63) == 0) { a.gen_bits[i0 >> 6] = k0; if (two) a.gen_bits[i1 >> 6] = k1; }
+          }
+          if (!d0 && !q0.skip) compact_finish(a, i0, c0, q0, m0, lsum, zeros);
+          if (two && !d1 && !q1.skip) compact_finish(a, i1, c1, q1, m1, lsum, zeros);
         }
       }
     }
@@ -540,19 +559,26 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
 
 // Classes 1 and 2: at most K = 2 / 4 records per mate, 16-byte records, overwrite rule in registers.
 // Slots [slot_lo, slot_hi), blocks [block_lo, block_hi).
-template <int K, int ABL>
+template <int K, int ABL, bool GEN>
 __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
                                                  double& lsum, int& zeros) {
   if (ABL >= 1 && ABL != 4) return;  // ablations 1,2,3,5: compact classes alone; 4: compact stream-only + these classes in full
+  unsigned long long* bits = GEN ? a.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2) : nullptr;
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
     const int t = i - a.n0;
     const uint32_t l12 = a.len12[t];
     const size_t at = K == 2 ? (size_t)2 * (i - a.n0) : (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01);
-    if (a.inl[0][at].x == kDirtyWid) continue;  // scored by the overflow path from the delta lists
-    RegCands<K> x, y;
-    const bool m1 = load_cands_inline<K>(a.m[0], a.inl[0] + at, x), m2 = load_cands_inline<K>(a.m[1], a.inl[1] + at, y);
-    if (m1 || m2) continue;  // on the host's overflow list
-    score_cands_and_finish<K>(a, i, l12, x, y, lsum, zeros);
+    bool general = false;  // a window that occurs several times: paired_general_kernel
+    if (a.inl[0][at].x != kDirtyWid) {  // else: scored from the delta lists (paired_delta_body)
+      RegCands<K> x, y;
+      const bool m1 = load_cands_inline<K>(a.m[0], a.inl[0] + at, x), m2 = load_cands_inline<K>(a.m[1], a.inl[1] + at, y);
+      general = m1 || m2;
+      if (!general) score_cands_and_finish<K>(a, i, l12, x, y, lsum, zeros);
+    }
+    if (GEN) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
+      const unsigned long long k = __ballot(general);
+      if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
+    }
   }
 }
 
@@ -601,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const DeltaPa
   }
 }
 
-template <bool TICKET, int ABL = 0>
+template <bool TICKET, int ABL, bool GEN>
 __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z) {
   double lsum = 0.0;
   int zeros = 0;
@@ -614,9 +640,9 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
     __syncthreads();
     PairedArgs b = a;
     b.len_combo = sh_combo; b.floor_c = sh_floor; b.logfloor_c = sh_logfloor;
-    paired_compact_body<ABL>(b, lb, lsum, zeros);
-  } else if (lb < a.blocks01) paired_regs_body<2, ABL>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
-  else if (lb < a.blocks012) paired_regs_body<4, ABL>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
+    paired_compact_body<ABL, GEN>(b, lb, lsum, zeros);
+  } else if (lb < a.blocks01) paired_regs_body<2, ABL, GEN>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
+  else if (lb < a.blocks012) paired_regs_body<4, ABL, GEN>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
   else paired_delta_body(a, lb - a.blocks012, a.main_blocks - a.blocks012, lsum, zeros);
   block_reduce(lsum, zeros, sh_s, sh_z);
   if (TICKET) {
@@ -639,9 +665,8 @@ __global__ __launch_bounds__(kBlock) void finish_partials_kernel(const double* p
   if (threadIdx.x == 0) { out[0] = ts; out[1] = (double)tz; if (bad_bases >= 0) out[2] = bad_bases; out[3] = n_reads; }
 }
 
-// Overflow kernel: one WAVE per pair, for the pairs the main kernel leaves out: slots [n_main, n)
-// (more than 2 records on a mate) and the host's list of pairs touching a window that occurs
-// several times. The wave gathers every (record, occurrence) candidate of both mates into LDS,
+// Overflow body: one WAVE per pair, for slots [n_main, n) (more than 4 records on a mate).
+// The wave gathers every (record, occurrence) candidate of both mates into LDS,
 // settles the overwrite rule in parallel and spreads the x * y pair terms over its lanes;
 // deterministic lane-strided + butterfly summation. It reads nothing the main kernel writes, so
 // both run concurrently (two streams); they share one ticket, and whichever block finishes last
@@ -688,17 +713,13 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = ovf_block * (kBlock / 64) + wave;
   const int n_waves = ovf_blocks * (kBlock / 64);
-  const int n_static = a.n - a.n_main;
-  const int n_listed = n_static + a.n_ovf_items;
-  const int n_items = n_listed;  // delta pairs: paired_delta_body
+  const int n_items = a.n - a.n_main;  // delta pairs: paired_delta_body; table-class pairs of repeated windows: paired_general_kernel
   double lsum = 0.0;
   int zeros = 0;
   for (int item = wave_global; item < n_items; item += n_waves) {  // fixed item -> wave assignment
-    const int i = item < n_static ? a.n_main + item : a.ovf_items[item - n_static];
-    int4 r1, r2;
-    uint32_t l12;
-    if (i < a.n0) { r1 = rec8_to_quad(a.rec8[0][i]); r2 = rec8_to_quad(a.rec8[1][i]); l12 = a.len_combo[a.len_code[i]]; }
-    else { r1 = a.m[0].first[i - a.n0]; r2 = a.m[1].first[i - a.n0]; l12 = a.len12[i - a.n0]; }
+    const int i = a.n_main + item;
+    const int4 r1 = a.m[0].first[i - a.n0], r2 = a.m[1].first[i - a.n0];
+    const uint32_t l12 = a.len12[i - a.n0];
     if (r1.x == kDirtyWid) continue;  // a class-3 pair that is on the delta list: scored there
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     int4* c1 = cand[wave][0];
@@ -756,7 +777,9 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
 // ONE launch for a paired read set: blocks [0, main_blocks) run the lane-per-pair path, blocks
 // [main_blocks, total_blocks) the wave-per-pair path (block-uniform branch). They share nothing
 // but read-only tables, so no ordering between them is needed.
-template <bool TICKET, int ABL = 0>
+// GEN: the path set has windows that occur several times -- note their pairs for paired_general_kernel. Without
+// such windows the notes are compiled out (they cost 0.3 us of 12 at cfg3 even when nothing is noted).
+template <bool TICKET, int ABL = 0, bool GEN = false>
 __global__ __launch_bounds__(kBlock) void paired_score_kernel(PairedArgs a) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
@@ -765,8 +788,33 @@ __global__ __launch_bounds__(kBlock) void paired_score_kernel(PairedArgs a) {
   // REVERSE dispatch order so that the few long-latency blocks (overflow, multi-record classes)
   // start first and hide under the compact stream instead of forming a tail.
   const int lb = a.total_blocks - 1 - (int)blockIdx.x;
-  if (lb < a.main_blocks) paired_main_body<TICKET, ABL>(a, lb, sh_s, sh_z);
+  if (lb < a.main_blocks) paired_main_body<TICKET, ABL, GEN>(a, lb, sh_s, sh_z);
   else paired_overflow_body<TICKET>(a, lb - a.main_blocks, a.total_blocks - a.main_blocks, sh_s, sh_z, cand);
+}
+
+// Second launch, only for path sets in which some window occurs several times: one lane per table-class slot,
+// the lanes whose bit the main kernel set run the fully general loop. Partials go behind the main kernel's
+// (slots [part_base, part_base + gridDim.x)); fixed slot -> lane assignment, so the sums are reproducible.
+__global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, int part_base) {
+  __shared__ double sh_s[kBlock / 64];
+  __shared__ int sh_z[kBlock / 64];
+  double lsum = 0.0;
+  int zeros = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_main; i += gridDim.x * kBlock) {
+    const int cls = i < a.n0 ? 0 : (i < a.n01 ? 1 : 2);
+    const int rel = cls == 0 ? i : (cls == 1 ? i - a.n0 : i - a.n01);
+    const unsigned long long word = a.gen_bits[(cls == 0 ? 0 : (cls == 1 ? a.gen_w1 : a.gen_w2)) + (rel >> 6)];
+    if (!((word >> (rel & 63)) & 1ull)) continue;
+    if (cls == 0) compact_general(a, i, lsum, zeros);
+    else {
+      const uint32_t l12 = a.len12[i - a.n0];
+      const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+      const double acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
+      finish_read(a, i, acc, L1, L2, lsum, zeros);
+    }
+  }
+  block_reduce(lsum, zeros, sh_s, sh_z);
+  if (threadIdx.x == 0) { a.part_sum[part_base + blockIdx.x] = lsum; a.part_zero[part_base + blockIdx.x] = zeros; }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -97,3 +97,22 @@ def test_no_reads_align():
     want, wzeros, wtl = orc.calc_prob(paths, fresh=True)
     assert zeros.tolist() == wzeros.tolist()
     assert abs(got - want) <= 1e-12 * abs(want)
+
+
+@pytest.mark.parametrize("penalty", [0.0, 0.5])
+def test_every_window_occurs_several_times(penalty):
+    # the whole genome walk three times (twice forward, once as the twin walk) plus stretches of it: every
+    # window occurs several times, so every pair of the table classes takes the general pass
+    # (paired_general_kernel); then the same paths once each, and back -- the noted pairs must not stick
+    g, ctx, rs, orc, ors = _setup(90_000, 6_000, 21, repeats=2, penalty=penalty)
+    walk = synth.genome_walk(g)
+    inv = [x ^ 1 for x in reversed(walk)]  # the twin walk
+    k = len(walk) // 3
+    many = [walk, list(walk), inv, walk[k:2 * k], walk[:k] + walk[:k]]
+    a, _ = _check(ctx, rs, orc, ors, many)
+    _check(ctx, rs, orc, ors, [walk])
+    b, _ = _check(ctx, rs, orc, ors, many)
+    assert a == b
+    if penalty == 0.0:  # the batch form sums the partials on the device (finisher kernel): same values
+        res = ctx.calc_prob_batch([many, [walk], many])
+        assert res[0][0] == a and res[2][0] == a
