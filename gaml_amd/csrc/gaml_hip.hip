@@ -886,22 +886,20 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
     // the kernel's own begin / end stamps, what rocprofv3's kernel trace reports). Separate hipEventRecord
     // markers around the launch would add the marker packets' processing to the interval: an EMPTY kernel
     // of this grid reads 6 us that way (tools/stream_floor.hip).
-    if (ev && c->knobs[3] == 0) {
-      if (gen_pass) hipExtLaunchKernelGGL((paired_score_kernel<false, 0, true>), grid, block, dyn_lds, st, ev->first, ev->second, 0, a);
-      else if (fin_mode) hipExtLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, ev->first, ev->second, 0, a);
-      else hipExtLaunchKernelGGL((paired_score_kernel<true, 0>), grid, block, dyn_lds, st, ev->first, ev->second, 0, a);
-    } else {
-      if (ev) HIP_TRY(c, hipEventRecord(ev->first, st));
-      if (c->knobs[3] == 1) hipLaunchKernelGGL((paired_score_kernel<false, 1>), grid, block, dyn_lds, st, a);
-      else if (c->knobs[3] == 2) hipLaunchKernelGGL((paired_score_kernel<false, 2>), grid, block, dyn_lds, st, a);
-      else if (c->knobs[3] == 3) hipLaunchKernelGGL((paired_score_kernel<false, 3>), grid, block, dyn_lds, st, a);
-      else if (c->knobs[3] == 4) hipLaunchKernelGGL((paired_score_kernel<false, 4>), grid, block, dyn_lds, st, a);
-      else if (c->knobs[3] == 5) hipLaunchKernelGGL((paired_score_kernel<false, 5>), grid, block, dyn_lds, st, a);
-      else if (gen_pass) hipLaunchKernelGGL((paired_score_kernel<false, 0, true>), grid, block, dyn_lds, st, a);
-      else if (fin_mode) hipLaunchKernelGGL((paired_score_kernel<false, 0>), grid, block, dyn_lds, st, a);
-      else hipLaunchKernelGGL((paired_score_kernel<true, 0>), grid, block, dyn_lds, st, a);
-      if (ev) HIP_TRY(c, hipEventRecord(ev->second, st));
+    hipEvent_t e0 = ev ? ev->first : nullptr, e1 = ev ? ev->second : nullptr;
+#define GAML_LAUNCH_SCORE(...) hipExtLaunchKernelGGL((paired_score_kernel<__VA_ARGS__>), grid, block, dyn_lds, st, e0, e1, 0, a)
+    switch (c->knobs[3]) {  // 1-5: timing-only ablations (tools/kbench.py)
+      case 1: GAML_LAUNCH_SCORE(false, 1); break;
+      case 2: GAML_LAUNCH_SCORE(false, 2); break;
+      case 3: GAML_LAUNCH_SCORE(false, 3); break;
+      case 4: GAML_LAUNCH_SCORE(false, 4); break;
+      case 5: GAML_LAUNCH_SCORE(false, 5); break;
+      default:
+        if (gen_pass) GAML_LAUNCH_SCORE(false, 0, true);
+        else if (fin_mode) GAML_LAUNCH_SCORE(false, 0);
+        else GAML_LAUNCH_SCORE(true, 0);
     }
+#undef GAML_LAUNCH_SCORE
     HIP_TRY(c, hipGetLastError());
     if (gen_pass) {
       hipLaunchKernelGGL(paired_general_kernel, dim3(gen_blocks), dim3(kBlock), 0, st, a, a.total_blocks);
