@@ -176,6 +176,7 @@ def _load():
     L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
+    L.gaml_hip_debug_timeline.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
     L.gaml_hip_debug_profile.argtypes = [vp, _f64p]
     L.gaml_hip_debug_table_stats.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_aligner_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -576,6 +577,12 @@ class Context:
         out = np.zeros(8, np.float64)
         _lib.gaml_hip_debug_profile(self._h, out)
         return out
+
+    def debug_timeline(self, rs: int, cap_waves: int = 1 << 16) -> np.ndarray:
+        """[waves, 8] wall-clock stamps (10 ns units) of the last evaluation run with knob 3 = 8."""
+        out = np.zeros((cap_waves, 8), np.uint64)
+        n = self._check(_lib.gaml_hip_debug_timeline(self._h, rs, out.ctypes.data, cap_waves))
+        return out[:n]
 
     def debug_set_knob(self, knob, value):
         self._check(_lib.gaml_hip_debug_set_knob(self._h, knob, value))

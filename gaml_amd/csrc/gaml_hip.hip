@@ -132,6 +132,7 @@ struct PairedSet {
   size_t delta_off[4] = {0, 0, 0, 0};   // spill CSR: offsets mate 0, records mate 0, offsets mate 1, records mate 1
   int quiet_calls = 0;       // evaluations since the last window activation
   bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
+  PinBuf h_timeline; int timeline_waves = 0;  // ablation 8 (tools/kernel_timeline.py)
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
   int last_total_blocks = 0;
   bool last_host_partials = false;
@@ -847,6 +848,17 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   // the pairs the main kernel notes
   const bool gen_pass = n_main > 0 && c->knobs[3] == 0 && (!s.image[0].general_wids.empty() || !s.image[1].general_wids.empty());
   a.gen_bits = nullptr; a.gen_w1 = a.gen_w2 = 0;
+  a.wide4 = c->knobs[11];
+  a.timeline = nullptr;
+  if (c->knobs[3] == 8) {  // in-kernel timeline (tools/kernel_timeline.py): stamps land in mapped host memory
+    HIP_TRY(c, s.h_timeline.reserve((size_t)(4 * kMaxBlocks + kOvfMaxBlocks + 256) * (kBlock / 64) * 8 * sizeof(unsigned long long)));
+    memset(s.h_timeline.p, 0, s.h_timeline.cap);
+    void* dp = nullptr;
+    HIP_TRY(c, hipHostGetDevicePointer(&dp, s.h_timeline.p, 0));
+    a.timeline = (unsigned long long*)dp;
+    s.timeline_waves = a.total_blocks * (kBlock / 64);
+  }
+
   int gen_blocks = 0;
   if (gen_pass) {
     const int64_t w0 = (n0 + 63) / 64, w1 = (n01 - n0 + 63) / 64, w2 = (n_main - n01 + 63) / 64;
@@ -894,6 +906,9 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
       case 3: GAML_LAUNCH_SCORE(false, 3); break;
       case 4: GAML_LAUNCH_SCORE(false, 4); break;
       case 5: GAML_LAUNCH_SCORE(false, 5); break;
+      case 6: GAML_LAUNCH_SCORE(false, 6); break;
+      case 7: GAML_LAUNCH_SCORE(false, 7); break;
+      case 8: GAML_LAUNCH_SCORE(false, 8); break;
       default:
         if (gen_pass) GAML_LAUNCH_SCORE(false, 0, true);
         else if (fin_mode) GAML_LAUNCH_SCORE(false, 0);
@@ -1543,7 +1558,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
-      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->len_code.release(); s->len_combo.release();
+      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release(); s->len_code.release(); s->len_combo.release();
       s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); drop_stage(s->stage);
     }
@@ -2496,6 +2511,15 @@ int gaml_hip_debug_profile(gaml_hip_ctx* c, double* out8) {
   if (!c || !out8) return GAML_HIP_EINVAL;
   for (int i = 0; i < 8; i++) out8[i] = c->prof[i];
   return GAML_HIP_OK;
+}
+
+int gaml_hip_debug_timeline(gaml_hip_ctx* c, int rs, unsigned long long* out, int64_t cap_waves) {
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  if (!s.h_timeline.p) return 0;
+  const int64_t n = std::min<int64_t>(cap_waves, s.timeline_waves);
+  memcpy(out, s.h_timeline.p, (size_t)n * 8 * sizeof(unsigned long long));
+  return (int)n;
 }
 
 int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {

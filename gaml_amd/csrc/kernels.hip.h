@@ -71,6 +71,8 @@ struct PairedArgs {
   // one wave, so nothing has to be zeroed); paired_general_kernel scores them in a second launch. Null when the
   // host saw no such window in this path set -- then neither the notes nor the second launch exist.
   unsigned long long* gen_bits;
+  int wide4;                 // knob 11 = 1: the two-pairs-per-iteration compact body instead of the four-wide one (tools/kbench.py)
+  unsigned long long* timeline;  // ablation 8: 8 wall-clock stamps (10 ns units) per wave of the grid
   int gen_w1, gen_w2;        // first word of class 1 / class 2 (class 0 starts at word 0)
   int main_blocks, total_blocks;  // grid sizes: partial slots [0, main_blocks) main, then overflow
   // Delta: pairs whose record lists changed since the device tables were built (newly activated
@@ -273,7 +275,9 @@ __device__ __forceinline__ bool cands_from_records(const MateView& v, const int4
   int4 o[K];
   bool multi = false;
 #pragma unroll
-  for (int k = 0; k < K; k++) o[k] = r[k].x >= 0 ? v.occ[r[k].x] : make_int4(0, 0, -1, 0);
+  for (int k = 0; k < K; k++) o[k] = v.occ[r[k].x >= 0 ? r[k].x : 0];  // unconditional (entry 0 always exists): the K loads go out back to back
+#pragma unroll
+  for (int k = 0; k < K; k++) if (r[k].x < 0) o[k] = make_int4(0, 0, -1, 0);
 #pragma unroll
   for (int k = 0; k < K; k++) {
     multi |= (o[k].z >= 0 && o[k].w < 0);
@@ -489,10 +493,11 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
       const bool d0 = c0.r1 == kDirty8, d1 = c1.r1 == kDirty8;  // scored by the overflow path from the delta lists
       if (d0) { c0.r1 = kNone8; c0.r2 = kNone8; }
       if (d1) { c1.r1 = kNone8; c1.r2 = kNone8; }
-      c0.o1 = c0.r1 != kNone8 ? a.occ8[0][c0.r1 & 0xffffff] : kNone8;
-      c0.o2 = c0.r2 != kNone8 ? a.occ8[1][c0.r2 & 0xffffff] : kNone8;
-      c1.o1 = c1.r1 != kNone8 ? a.occ8[0][c1.r1 & 0xffffff] : kNone8;
-      c1.o2 = c1.r2 != kNone8 ? a.occ8[1][c1.r2 & 0xffffff] : kNone8;
+      const unsigned long long wmask = ABL == 6 ? 0x0 : 0xffffff;  // ablation 6: every lookup at entry 0
+      c0.o1 = c0.r1 != kNone8 ? a.occ8[0][c0.r1 & wmask] : kNone8;
+      c0.o2 = c0.r2 != kNone8 ? a.occ8[1][c0.r2 & wmask] : kNone8;
+      c1.o1 = c1.r1 != kNone8 ? a.occ8[0][c1.r1 & wmask] : kNone8;
+      c1.o2 = c1.r2 != kNone8 ? a.occ8[1][c1.r2 & wmask] : kNone8;
       if (ABL == 2) {
         a.probs[i0] = (double)(int)(c0.o1 + c0.o2); lsum += (double)(int)(c0.o1 + c0.o2);
         if (two) { a.probs[i1] = (double)(int)(c1.o1 + c1.o2); lsum += (double)(int)(c1.o1 + c1.o2); }
@@ -501,6 +506,7 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
         compact_prep(a, c0, q0);
         compact_prep(a, c1, q1);
         // both memo entries are requested before anything is stored
+        if (ABL == 7) { if (q0.memo_idx >= 0) q0.memo_idx = threadIdx.x; if (q1.memo_idx >= 0) q1.memo_idx = 256 + threadIdx.x; }  // ablation 7: coalesced memo reads
         const double2 m0 = q0.memo_idx >= 0 ? a.memo[q0.memo_idx] : make_double2(0.0, 0.0);
         const double2 m1 = q1.memo_idx >= 0 ? a.memo[q1.memo_idx] : make_double2(0.0, 0.0);
         if (ABL == 3) { a.probs[i0] = fabs(m0.x); lsum += m0.x; if (two) { a.probs[i1] = fabs(m1.x); lsum += m1.x; } }
@@ -518,6 +524,122 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
     c0 = n0v; c1 = n1v;
     i0 = j0;
   }
+}
+
+// Class 0 without coverage marks, memo present: FOUR pairs per lane, stage by stage -- all record loads, then all
+// occurrence lookups, then all memo entries, then the stores -- every load unconditional (clamped index), so a
+// stage is one round trip per lane whatever the pair count. Between the stages a pair is one word of state:
+//   >= 0: memo index; kPairZero - code: scores nothing (no alignment of a mate in this path set, filtered, wrong
+//   orientation): probability 0, floored; kPairOther: everything else (window occurring several times, dirty slot,
+//   term outside the memo), settled after the stores from the tables again (rare).
+// Pairs and their order per lane are those of paired_compact_body (slot = base + k * stride), so both give the
+// same sums bit for bit.
+constexpr int kPairZero = -1, kPairOther = -(1 << 20);
+// compact_prep without branches, on the 32-bit halves of the 8-byte record / occurrence words (the scoring kernel
+// is issue-bound at cfg3: the branchy 64-bit form was 156 instructions per pair, a third of a wave's lifetime)
+__device__ __forceinline__ int compact_state(const PairedArgs& a, uint2 r1, uint2 r2, uint2 o1, uint2 o2, unsigned lc, bool in_range,
+                                             bool& skip) {
+  const bool v1 = r1.y != ~0u, v2 = r2.y != ~0u;           // a record (not kNone8 / kDirty8)
+  const bool w1 = v1 & (o1.y != ~0u), w2 = v2 & (o2.y != ~0u);  // ... whose window occurs in this path set
+  skip = in_range & ((w1 & ((int)o1.y < 0)) | (w2 & ((int)o2.y < 0)));  // a window that needs the general path
+  const uint32_t l12 = a.len_combo[lc];
+  const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+  const int p1 = (int)(__funnelshift_r(r1.x, r1.y, 24) & 0xfffffffu), p2 = (int)(__funnelshift_r(r2.x, r2.y, 24) & 0xfffffffu);
+  const int x = p1 + (int)o1.x, y = p2 + (int)o2.x;
+  const unsigned or1 = (r1.y >> 26) & 1u, or2 = (r2.y >> 26) & 1u;
+  const bool fwd = x < y;
+  const int dist = fwd ? y - x + L2 : x - y + L1;            // graph.cc:1864-1876
+  const bool scores = w1 & w2 & !skip & (((o1.y ^ o2.y) >> 16) == 0)  // both occur, same path
+                      & (p1 >= (int)(short)(o1.y & 0xffffu)) & (p2 >= (int)(short)(o2.y & 0xffffu))  // position filter (graph.cc:577)
+                      & (or1 != or2) & (or1 == (fwd ? 0u : 1u));
+  const unsigned e1 = (r1.y >> 20) & 63u, e2 = (r2.y >> 20) & 63u;
+  const bool in_memo = scores & ((unsigned)dist < (unsigned)a.ins_n) & (lc < (unsigned)a.lt_codes) & (e1 < 7u) & (e2 < 7u);
+  const int idx = (int)((lc * 7u + e1) * 7u + e2) * a.ins_n + dist;
+  int state = in_memo ? idx : ((skip | scores) ? kPairOther : kPairZero - (int)lc);
+  if (!in_range || (r1.y == ~0u && r1.x == 0xfffffffeu)) state = kPairOther - 1;  // no pair here / dirty slot (paired_delta_body)
+  return state;
+}
+
+template <bool GEN, bool TL = false>
+__device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb, double& lsum, int& zeros) {
+  const unsigned stride = (unsigned)a.blocks0 * kBlock, n0 = (unsigned)a.n0;
+  unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
+#define GAML_STAMP(slot, dep) if (TL) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[slot] = (unsigned long long)wall_clock64() + ((dep) == 0x12345u ? 1 : 0); }
+  // 32-bit byte offsets from uniform bases: one address register per load instead of a 64-bit add (tables < 4 GB)
+  const char* const rec0 = (const char*)a.rec8[0];
+  const char* const rec1 = (const char*)a.rec8[1];
+  const char* const occ0 = (const char*)a.occ8[0];
+  const char* const occ1 = (const char*)a.occ8[1];
+  const char* const memo = (const char*)a.memo;
+  char* const probs = (char*)a.probs;
+  for (unsigned base = (unsigned)lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
+    uint2 r1[4], r2[4], o1[4], o2[4];
+    unsigned lc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
+      r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); lc[k] = a.len_code[ic];
+    }
+    GAML_STAMP(2, r1[0].x ^ r1[1].x ^ r1[2].x ^ r1[3].x ^ r2[0].x ^ r2[3].x)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      o1[k] = *(const uint2*)(occ0 + (r1[k].y != ~0u ? (r1[k].x & 0xffffffu) : 0u) * 8u);
+      o2[k] = *(const uint2*)(occ1 + (r2[k].y != ~0u ? (r2[k].x & 0xffffffu) : 0u) * 8u);
+    }
+    GAML_STAMP(3, o1[0].x ^ o1[1].x ^ o1[2].x ^ o1[3].x ^ o2[0].x ^ o2[3].x)
+    int state[4];
+    unsigned skip_bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      bool skip;
+      state[k] = compact_state(a, r1[k], r2[k], o1[k], o2[k], lc[k], base + k * stride < n0, skip);
+      skip_bits |= (unsigned)skip << k;
+    }
+    double2 m[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
+    GAML_STAMP(4, (unsigned)(__double2loint(m[0].x) ^ __double2loint(m[1].x) ^ __double2loint(m[2].x) ^ __double2loint(m[3].x)))
+    if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned long long w = __ballot((skip_bits >> k) & 1u);
+        if ((threadIdx.x & 63) == 0 && base + k * stride < n0) a.gen_bits[(base + k * stride) >> 6] = w;
+      }
+    }
+    bool other = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      double* const out = (double*)(probs + (base + k * stride) * 8u);
+      if (state[k] >= 0) {  // as compact_finish
+        __builtin_nontemporal_store(fabs(m[k].x), out);
+        lsum += m[k].y;
+        zeros += (int)(__double2hiint(m[k].x) < 0);
+      } else if (state[k] > kPairOther) {  // as finish_read_compact(acc = 0)
+        __builtin_nontemporal_store(0.0, out);
+        zeros++;
+        lsum += a.logfloor_c[kPairZero - state[k]];
+      } else other |= state[k] == kPairOther && !((skip_bits >> k) & 1u);
+    }
+    GAML_STAMP(5, 0u)
+    if (__any(other)) {
+      // scores, but outside the memo (edit count or insert distance beyond the table): from the tables, as paired_compact_body
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) {
+        if (state[k] != kPairOther || ((skip_bits >> k) & 1u)) continue;
+        const int i = (int)(base + k * stride);
+        Compact1 d;
+        compact_load(a, i, true, d);
+        d.o1 = d.r1 != kNone8 ? a.occ8[0][d.r1 & 0xffffff] : kNone8;
+        d.o2 = d.r2 != kNone8 ? a.occ8[1][d.r2 & 0xffffff] : kNone8;
+        const uint32_t l = a.len_combo[d.lc];
+        d.L1 = l & 0xffff; d.L2 = l >> 16;
+        CompactPrep q;
+        compact_prep(a, d, q);
+        compact_finish(a, i, d, q, make_double2(0.0, 0.0), lsum, zeros);
+      }
+    }
+  }
+#undef GAML_STAMP
 }
 
 // up to K live candidates per mate in registers -> per-read probability, floor / log, running sums
@@ -562,19 +684,22 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
 template <int K, int ABL, bool GEN>
 __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
                                                  double& lsum, int& zeros) {
-  if (ABL >= 1 && ABL != 4) return;  // ablations 1,2,3,5: compact classes alone; 4: compact stream-only + these classes in full
+  if (ABL >= 1 && ABL != 4 && ABL != 8) return;  // ablations 1,2,3,5: compact classes alone; 4: compact stream-only + these classes in full; 8: timeline
   unsigned long long* bits = GEN ? a.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2) : nullptr;
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
     const int t = i - a.n0;
     const uint32_t l12 = a.len12[t];
     const size_t at = K == 2 ? (size_t)2 * (i - a.n0) : (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01);
-    bool general = false;  // a window that occurs several times: paired_general_kernel
-    if (a.inl[0][at].x != kDirtyWid) {  // else: scored from the delta lists (paired_delta_body)
-      RegCands<K> x, y;
-      const bool m1 = load_cands_inline<K>(a.m[0], a.inl[0] + at, x), m2 = load_cands_inline<K>(a.m[1], a.inl[1] + at, y);
-      general = m1 || m2;
-      if (!general) score_cands_and_finish<K>(a, i, l12, x, y, lsum, zeros);
-    }
+    // all 2K records first, then all 2K occurrence entries: two round trips, not one per record (a conditional
+    // load per record, each behind its own wait, made this class's blocks the longest chain of the launch)
+    int4 r1[K], r2[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { r1[k] = a.inl[0][at + k]; r2[k] = a.inl[1][at + k]; }
+    RegCands<K> x, y;
+    const bool m1 = cands_from_records<K>(a.m[0], r1, x), m2 = cands_from_records<K>(a.m[1], r2, y);
+    const bool dirty = r1[0].x == kDirtyWid;  // scored from the delta lists (paired_delta_body)
+    const bool general = !dirty && (m1 || m2);  // a window that occurs several times: paired_general_kernel
+    if (!dirty && !general) score_cands_and_finish<K>(a, i, l12, x, y, lsum, zeros);
     if (GEN) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
       const unsigned long long k = __ballot(general);
       if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
@@ -631,6 +756,8 @@ template <bool TICKET, int ABL, bool GEN>
 __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z) {
   double lsum = 0.0;
   int zeros = 0;
+  unsigned long long* tl = ABL == 8 ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
+  if (ABL == 8 && (threadIdx.x & 63) == 0) { tl[0] = wall_clock64(); tl[7] = lb < a.blocks0 ? 0 : (lb < a.blocks01 ? 1 : 2); }
   if (lb < a.blocks0) {
     // the per-length-combination tables of the compact class (<= 256 entries each) are looked up once or twice
     // per pair, each time behind another load: from LDS they cost an LDS access instead of an L2 round trip
@@ -640,11 +767,16 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
     __syncthreads();
     PairedArgs b = a;
     b.len_combo = sh_combo; b.floor_c = sh_floor; b.logfloor_c = sh_logfloor;
-    paired_compact_body<ABL, GEN>(b, lb, lsum, zeros);
+    if (ABL == 8 && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
+    const bool wide = a.memo && !a.cov_bits && a.wide4 == 0;  // block-uniform: memo present, no coverage marks to set
+    if (ABL == 8) paired_compact4_body<GEN, true>(b, lb, lsum, zeros);
+    else if ((ABL == 0 || ABL == 5) && wide) paired_compact4_body<GEN>(b, lb, lsum, zeros);
+    else paired_compact_body<ABL, GEN>(b, lb, lsum, zeros);
   } else if (lb < a.blocks01) paired_regs_body<2, ABL, GEN>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
   else if (lb < a.blocks012) paired_regs_body<4, ABL, GEN>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
   else paired_delta_body(a, lb - a.blocks012, a.main_blocks - a.blocks012, lsum, zeros);
   block_reduce(lsum, zeros, sh_s, sh_z);
+  if (ABL == 8 && (threadIdx.x & 63) == 0) tl[6] = wall_clock64();
   if (TICKET) {
     grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out,
                 a.cov_bits ? -1.0 : 0.0, a.n_reads, sh_s, sh_z);

@@ -300,6 +300,11 @@ int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
 /* tuning experiments (tools/kbench.py): 0 = compact-path grid cap, 1 = dynamic LDS bytes, 2 = finish mode (1 ticket,
  * 2 finisher kernel), 3 = timing-only ablation, 4 = 1: no floor/log memo, 5 = 1: host window aligner, 6 = 1: no delta list,
  * 7 = 1: always wait with hipStreamSynchronize (no spinning on the pinned partials) */
+/* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
+ * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
+ * number of waves copied. Tuning aid (tools/kernel_timeline.py). */
+int gaml_hip_debug_timeline(gaml_hip_ctx* ctx, int rs, unsigned long long* out, int64_t cap_waves);
+
 int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
 /* pairs per record-count class of the device table {<=1, <=2, <=4, more} (paired sets) */
 int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);

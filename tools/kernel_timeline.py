@@ -1,0 +1,46 @@
+"""Where does a wave of the scoring kernel spend its time?  Ablation 8 stamps the wall clock (10 ns units) at the
+stage boundaries of every wave; this prints per class the distribution of each stage, relative to the first wave's
+entry.  python tools/kernel_timeline.py [cfg3]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gaml_amd import synth, api
+import bench
+
+wl = synth.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg3"]
+genome = synth.make_genome(wl.genome_len, wl.seed)
+g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
+pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
+ctx = api.Context(device=0)
+ctx.set_graph(*g.packed())
+rs = ctx.add_paired(api.paired_cfg(300.0, 30.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+variants = [api.FlatPaths(v) for v in bench.path_variants(synth.genome_walk(g))]
+[ctx.calc_prob(v) for v in variants]
+ctx.compact_tables()
+[ctx.calc_prob(v) for v in variants]
+for k, v in eval(sys.argv[2]).items() if len(sys.argv) > 2 else []:
+    ctx.debug_set_knob(k, v)
+ctx.debug_set_knob(3, 8)
+names = ["entry", "tables->LDS", "records in", "occurrences in", "memo in", "stores out", "block reduced"]
+for rep in range(3):
+    for i in range(8):
+        ctx.calc_prob(variants[i])
+    t = ctx.debug_timeline(rs).astype(np.int64)
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    print(f"--- evaluation {rep}: {len(t)} waves, last block reduced at {(t[:, 6].max() - t0) / 100:.2f} us after the first entry")
+    for cls, label in ((0, "compact"), (1, "2-record"), (2, "4-record")):
+        w = t[t[:, 7] == cls]
+        if not len(w):
+            continue
+        print(f"  class {label}: {len(w)} waves")
+        cols = range(7) if cls == 0 else (0, 6)
+        prev = None
+        for c in cols:
+            abs_us = (w[:, c] - t0) / 100
+            line = f"    {names[c]:>15}: at {np.median(abs_us):6.2f} us (min {abs_us.min():5.2f}, p90 {np.percentile(abs_us, 90):5.2f}, max {abs_us.max():5.2f})"
+            if prev is not None:
+                d = (w[:, c] - w[:, prev]) / 100
+                line += f"   stage {np.median(d):5.2f} us (p90 {np.percentile(d, 90):5.2f})"
+            print(line)
+            prev = c
