@@ -541,7 +541,8 @@ __device__ __forceinline__ int compact_state(const PairedArgs& a, uint2 r1, uint
                                              bool& skip) {
   const bool v1 = r1.y != ~0u, v2 = r2.y != ~0u;           // a record (not kNone8 / kDirty8)
   const bool w1 = v1 & (o1.y != ~0u), w2 = v2 & (o2.y != ~0u);  // ... whose window occurs in this path set
-  skip = in_range & ((w1 & ((int)o1.y < 0)) | (w2 & ((int)o2.y < 0)));  // a window that needs the general path
+  const bool here = in_range & !(r1.y == ~0u && r1.x == 0xfffffffeu);  // a pair, and not a dirty slot (those: paired_delta_body)
+  skip = here & ((w1 & ((int)o1.y < 0)) | (w2 & ((int)o2.y < 0)));  // a window that needs the general path
   const uint32_t l12 = a.len_combo[lc];
   const int L1 = l12 & 0xffff, L2 = l12 >> 16;
   const int p1 = (int)(__funnelshift_r(r1.x, r1.y, 24) & 0xfffffffu), p2 = (int)(__funnelshift_r(r2.x, r2.y, 24) & 0xfffffffu);
@@ -556,7 +557,7 @@ __device__ __forceinline__ int compact_state(const PairedArgs& a, uint2 r1, uint
   const bool in_memo = scores & ((unsigned)dist < (unsigned)a.ins_n) & (lc < (unsigned)a.lt_codes) & (e1 < 7u) & (e2 < 7u);
   const int idx = (int)((lc * 7u + e1) * 7u + e2) * a.ins_n + dist;
   int state = in_memo ? idx : ((skip | scores) ? kPairOther : kPairZero - (int)lc);
-  if (!in_range || (r1.y == ~0u && r1.x == 0xfffffffeu)) state = kPairOther - 1;  // no pair here / dirty slot (paired_delta_body)
+  if (!here) state = kPairOther - 1;
   return state;
 }
 
