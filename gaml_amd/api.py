@@ -176,7 +176,8 @@ def _load():
     L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
-    L.gaml_hip_debug_timeline.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
+    if hasattr(L, "gaml_hip_debug_timeline"):  # absent from older A/B builds loaded through GAML_HIP_LIB
+        L.gaml_hip_debug_timeline.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
     L.gaml_hip_debug_profile.argtypes = [vp, _f64p]
     L.gaml_hip_debug_table_stats.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_aligner_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]

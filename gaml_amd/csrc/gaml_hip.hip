@@ -1375,7 +1375,8 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
       sort_range(0, nw);
     }
   }
-  m.pool.reserve(m.pool.size() + ok.size());  // one growth step for the whole batch
+  if (m.pool.capacity() < m.pool.size() + ok.size())  // one growth step for the whole batch -- geometric: an exact reserve per
+    m.pool.reserve(std::max(m.pool.size() + ok.size(), m.pool.capacity() + m.pool.capacity() / 2));  // small batch copied the 45 MB pool every time
   std::vector<gaml_aligment> recs;
   for (int k = 0; k < nw; k++) {
     recs.clear();
