@@ -49,16 +49,18 @@ struct DevBuf {
 };
 struct PinBuf {
   void* p = nullptr;
+  void* dev = nullptr;  // the same memory as the device sees it
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    if (p) { (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
     size_t want = std::max(bytes + bytes / 4, (size_t)4096);
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);  // device-visible: kernels may write results here
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);  // device-visible: kernels read / write it directly
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, p, 0);
     if (e == hipSuccess) cap = want;
     return e;
   }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
 };
 
 constexpr int kRing = 4;  // staging slots, so that async callers may run ahead of the device
@@ -144,6 +146,7 @@ struct PairedSet {
   std::vector<Occ> scratch_occ[2];   // debug dumps only
   Reducer red;
   std::vector<double> ins_tab, floor_tab, logfloor_tab, covthr_tab;
+  bool floor_positive = true;  // every floor exp(c + k s) > 0 (else "probability 0 is floored" does not hold: no memo / shortcut paths)
   bool tabs_uploaded = false;
   int64_t last_bad_bases = 0;
   Staging stage;
@@ -299,8 +302,29 @@ int stage_acquire(gaml_hip_ctx* c, Staging& s, size_t bytes, void** host) {
   return k;
 }
 int stage_release(gaml_hip_ctx* c, Staging& s, int k, hipStream_t st) {
+  // a blocking call returns after the device is done with the slot: no event (a marker packet and ~1.5 us of host time)
+  if (c->host_results) return 0;
   HIP_TRY(c, hipEventRecord(s.done[k], st));
   s.armed[k] = true;
+  return 0;
+}
+
+// Staged host data -> device memory by a small kernel that reads the pinned slot directly. Per blocking step 3 us
+// faster end to end than hipMemcpyAsync on the same stream (tools/xcd_start_probe.hip: 31.3 vs 34.2 us for copy +
+// kernel + sync).
+__global__ __launch_bounds__(kBlock) void stage_copy_kernel(const int4* __restrict__ src, int4* __restrict__ dst, int n16) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n16; i += gridDim.x * kBlock) dst[i] = src[i];
+}
+int stage_upload(gaml_hip_ctx* c, Staging& s, int k, void* dst, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  if (c->knobs[8] == 1 || (bytes & 15) || bytes > ((size_t)1 << 30)) {
+    HIP_TRY(c, hipMemcpyAsync(dst, s.host[k].p, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+  }
+  const int n16 = (int)(bytes / 16);
+  hipLaunchKernelGGL(stage_copy_kernel, dim3((unsigned)std::min(64, (n16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                     (const int4*)s.host[k].dev, (int4*)dst, n16);
+  HIP_TRY(c, hipGetLastError());
   return 0;
 }
 
@@ -430,6 +454,7 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
   for (int v = 0; v <= smax; v++) {
     s.floor_tab[v] = std::exp(c0 + k0 * v);          // graph.cc:1506-1507
     s.logfloor_tab[v] = std::log(s.floor_tab[v]);    // graph.cc:1510-1512 on a floored read
+    if (!(s.floor_tab[v] > 0.0)) s.floor_positive = false;  // exp underflow: the reference then takes log(0) for a read without alignment
   }
   s.covthr_tab.resize(s.mate[1].max_len + 1);
   for (int v = 0; v <= s.mate[1].max_len; v++) s.covthr_tab[v] = std::exp(c0 + k0 * (v + v));  // graph.cc:1855-1857
@@ -662,7 +687,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   const double tp2 = now_us();
   c->prof[3] = tp2 - tp1;  // staging memcpy
   c->prof[6] = (double)total;
-  HIP_TRY(c, hipMemcpyAsync(s.occ_arena.p, host, total, hipMemcpyHostToDevice, st));
+  if (int e = stage_upload(c, s.stage, slot, s.occ_arena.p, total, st)) return e;
   if (int e = stage_release(c, s.stage, slot, st)) return e;
   // delta pairs: a patch for the pairs whose lists changed in this evaluation (new windows were activated)
   if (!s.dirty_touched.empty()) {
@@ -701,7 +726,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
         }
     }
     HIP_TRY(c, s.dl_patch.reserve(np_patch * sizeof(DeltaPatch) + 1));
-    HIP_TRY(c, hipMemcpyAsync(s.dl_patch.p, ph, np_patch * sizeof(DeltaPatch), hipMemcpyHostToDevice, st));
+    if (int e = stage_upload(c, s.stage_delta, pslot, s.dl_patch.p, np_patch * sizeof(DeltaPatch), st)) return e;
     if (int e = stage_release(c, s.stage_delta, pslot, st)) return e;
     hipLaunchKernelGGL(apply_delta_patch_kernel, dim3((unsigned)std::min<size_t>((np_patch + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
                        (const DeltaPatch*)s.dl_patch.p, (int)np_patch, s.dl_slot.as<int>(), s.dl_spill.as<int>(), s.dl_rec[0].as<int4>(), s.dl_rec[1].as<int4>());
@@ -732,7 +757,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
         of[ns] = at;
       }
       if (dt > s.delta_dev.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.delta_dev.reserve(dt + dt / 2)); }
-      HIP_TRY(c, hipMemcpyAsync(s.delta_dev.p, dh, dt, hipMemcpyHostToDevice, st));  // stream order: after the kernels that read the old lists
+      if (int e = stage_upload(c, s.stage_delta, dslot, s.delta_dev.p, dt, st)) return e;  // stream order: after the kernels that read the old lists
       if (int e = stage_release(c, s.stage_delta, dslot, st)) return e;
       s.spill_changed = false;
     }
@@ -802,7 +827,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   // memo of floor + log over the values a single-term pair can take; rebuilt only when 2T (or the
   // tables) changed. Floor must be positive for the "no alignment -> floored" shortcut.
   a.memo = nullptr; a.lt_codes = 0;
-  if (c->knobs[4] == 0 && !s.pt.len_combo.empty() && s.ins_tab.size() > 0) {
+  if (c->knobs[4] == 0 && s.floor_positive && !s.pt.len_combo.empty() && s.ins_tab.size() > 0) {
     const int codes = (int)std::min<size_t>(s.pt.len_combo.size(), 4);
     const size_t entries = (size_t)codes * 49 * s.ins_tab.size();
     if (entries <= ((size_t)1 << 24)) {

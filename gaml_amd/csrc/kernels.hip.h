@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void logterm_kernel(const double* pe0, cons
 
 __device__ __forceinline__ void finish_read_compact(const PairedArgs& a, int i, double acc, int lc, double& lsum, int& zeros) {
   a.probs[i] = acc;
-  if (acc == 0.0) { zeros++; lsum += a.logfloor_c[lc]; return; }  // 0 / 2T < floor (floor > 0)
+  if (acc == 0.0 && a.floor_c[lc] > 0.0) { zeros++; lsum += a.logfloor_c[lc]; return; }  // 0 / 2T < floor
   const double p = acc / a.two_T;
   if (p < a.floor_c[lc]) { zeros++; lsum += a.logfloor_c[lc]; }
   else lsum += log(p);

@@ -24,7 +24,7 @@ ctx.debug_set_knob(3, 8)
 names = ["entry", "tables->LDS", "records in", "occurrences in", "memo in", "stores out", "block reduced"]
 for rep in range(3):
     for i in range(8):
-        ctx.calc_prob(variants[i])
+        ctx.calc_prob(variants[0 if os.environ.get("SAME_PATHS") else i])  # SAME_PATHS=1: 2T constant, so no memo rebuild before the launch
     t = ctx.debug_timeline(rs).astype(np.int64)
     t = t[t[:, 0] > 0]
     t0 = t[:, 0].min()
@@ -44,3 +44,10 @@ for rep in range(3):
                 line += f"   stage {np.median(d):5.2f} us (p90 {np.percentile(d, 90):5.2f})"
             print(line)
             prev = c
+    if rep == 2:  # dispatch order: when does block b enter?
+        full = ctx.debug_timeline(rs).astype(np.int64)
+        nb = len(full) // 4
+        ent = (full[: nb * 4, 0].reshape(nb, 4).min(axis=1) - t0) / 100
+        print("  entry time by blockIdx:", ", ".join(f"{b}: {ent[b]:.2f}" for b in (0, 1, 2, 3, 8, 16, 64, 128, 256, 512, 768, nb - 2, nb - 1) if b < nb))
+        order = np.argsort(ent)
+        print("  first blocks to enter:", order[:16].tolist(), " last:", order[-8:].tolist())
