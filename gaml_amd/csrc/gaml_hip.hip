@@ -528,6 +528,22 @@ void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>&
 
 int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p, int32_t total_len, hipStream_t st, double* out4) {
   if (int e = prepare_paired_tables(c, s)) return e;
+  // The memo depends on this call's path set only through 2T: when the tables it is built from exist already
+  // (no rebuild since the last memo), its kernel goes out NOW and runs while the host builds the occurrence images.
+  // (A rebuild further down resets lt_two_T; the regular place below then builds it again.)
+  {
+    const double two_T = (double)(2 * (total_len == 0 ? 1 : total_len));
+    if (s.lt_two_T >= 0 && s.lt_two_T != two_T && s.lt_codes > 0 && s.memo.p && s.dev[0].pow_n != 0 && c->knobs[4] == 0) {
+      const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
+      const double* ct = s.combo_tabs.as<double>();
+      const size_t entries = (size_t)s.lt_codes * 49 * s.ins_tab.size();
+      hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
+                         ct, ct + nc * 64, s.tabs.as<double>(), (int)s.ins_tab.size(), ct + 2 * nc * 64, ct + 2 * nc * 64 + nc, s.lt_codes, two_T,
+                         s.memo.as<double2>());
+      HIP_TRY(c, hipGetLastError());
+      s.lt_two_T = two_T;
+    }
+  }
   const double tp0 = now_us();
   prepare_paired_tables_host(c, s, p);  // pass 2 (pass 1 ran in eval_begin)
   const double t_after_host = now_us();
