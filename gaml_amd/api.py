@@ -176,6 +176,9 @@ def _load():
     L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
+    if hasattr(L, "gaml_hip_fetch_async"):
+        L.gaml_hip_fetch_async.argtypes = [vp, C.c_void_p, C.c_int32, C.c_void_p]
+        L.gaml_hip_fetch_wait.argtypes = [vp, C.c_void_p, C.c_int32]
     if hasattr(L, "gaml_hip_debug_timeline"):  # absent from older A/B builds loaded through GAML_HIP_LIB
         L.gaml_hip_debug_timeline.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
     L.gaml_hip_debug_profile.argtypes = [vp, _f64p]
@@ -376,6 +379,17 @@ class Context:
         if rc < 0:
             self._check(rc)
         return self._pending.value, self._tl2.value
+
+    def fetch_async(self, d_ptr: int, n_doubles: int, stream: int = 0):
+        """gaml_hip_fetch_async: device doubles -> the context's pinned block, behind everything enqueued on `stream`."""
+        rc = _lib.gaml_hip_fetch_async(self._h, d_ptr, n_doubles, stream)
+        if rc < 0:
+            self._check(rc)
+
+    def fetch_wait(self, out_ptr: int, n_doubles: int):
+        rc = _lib.gaml_hip_fetch_wait(self._h, out_ptr, n_doubles)
+        if rc < 0:
+            self._check(rc)
 
     def combine_fast(self, partials_ptr: int, total_len: int) -> float:
         """gaml_hip_combine_partials on a host buffer given by address; zeros stay in self.last_zeros."""

@@ -235,6 +235,9 @@ struct gaml_hip_ctx {
   double stat_device_us = 0, stat_algo_bytes = 0;
   DevBuf packed;  // 4 doubles per read set
   PinBuf packed_host;
+  PinBuf fetch_host;            // gaml_hip_fetch_async / _wait: [sequence word | 63 x pad | doubles]
+  unsigned long long fetch_seq = 0;
+  hipStream_t fetch_stream = nullptr;
   DevBuf batch_dev;  // gaml_hip_calc_prob_batch: 4 doubles per read set and path set
   PinBuf batch_host;
   // evaluation in progress (between eval_begin and eval_finish)
@@ -2241,6 +2244,52 @@ int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* c, int32_t i, const void* 
   // every rank computes the same bad_bases; one of them contributes it to the all-reduce(sum) of the partials
   hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), pc.out4, contribute ? 1.0 : 0.0);
   HIP_TRY(c, hipGetLastError());
+  return GAML_HIP_OK;
+}
+
+// Device results -> host without a D2H copy command and without the runtime's completion wake-up: a one-block kernel
+// writes the values and then a sequence word into mapped pinned memory; the host polls the word.
+__global__ void fetch_kernel(const double* src, int n, double* dst, unsigned long long* seq_word, unsigned long long seq) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence_system(); *(volatile unsigned long long*)seq_word = seq; }
+}
+
+int gaml_hip_fetch_async(gaml_hip_ctx* c, const void* d_src, int32_t n_doubles, void* stream) {
+  if (!c || !d_src || n_doubles <= 0) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "no device");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t bytes = 512 + (size_t)n_doubles * sizeof(double);
+  if (bytes > c->fetch_host.cap) {
+    HIP_TRY(c, c->fetch_host.reserve(bytes));
+    memset(c->fetch_host.p, 0, c->fetch_host.cap);
+  }
+  c->fetch_stream = stream ? (hipStream_t)stream : c->stream;
+  c->fetch_seq++;
+  char* dev = (char*)c->fetch_host.dev;
+  hipLaunchKernelGGL(fetch_kernel, dim3(1), dim3(64), 0, c->fetch_stream, (const double*)d_src, (int)n_doubles, (double*)(dev + 512),
+                     (unsigned long long*)dev, c->fetch_seq);
+  HIP_TRY(c, hipGetLastError());
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_fetch_wait(gaml_hip_ctx* c, double* out, int32_t n_doubles) {
+  if (!c || !out || n_doubles <= 0 || !c->fetch_host.p) return fail(c, GAML_HIP_EINVAL, "bad arguments / no fetch in flight");
+  volatile unsigned long long* word = (volatile unsigned long long*)c->fetch_host.p;
+  const double t0 = now_us();
+  bool seen = false;
+  while (now_us() - t0 < 2000.0) {  // bounded spin, then the runtime's wait
+    for (int k = 0; k < 64 && !seen; k++) seen = *word == c->fetch_seq;
+    if (seen) break;
+  }
+  if (!seen) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->fetch_stream));
+    if (*word != c->fetch_seq) return fail(c, GAML_HIP_ESTATE, "fetch kernel finished without publishing its sequence word");
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  memcpy(out, (const char*)c->fetch_host.p + 512, (size_t)n_doubles * sizeof(double));
   return GAML_HIP_OK;
 }
 

@@ -200,6 +200,14 @@ int gaml_hip_eval_finish_async(gaml_hip_ctx* ctx, void* d_partials, void* hip_st
 /* wait for everything enqueued on the library's private stream */
 int gaml_hip_sync(gaml_hip_ctx* ctx);
 
+/* Device values -> host at the end of a stream-ordered sequence (after the all-reduce of the partials, say) without a
+ * D2H copy command and without the runtime's completion wake-up: _async enqueues a one-block kernel on `hip_stream`
+ * (NULL: the library's stream) that writes n_doubles values from d_src and then a sequence word into mapped pinned
+ * memory; _wait polls that word (bounded; then hipStreamSynchronize) and copies the values out. One fetch in flight per
+ * context. Nothing in the reference corresponds to it (single process, host arithmetic). */
+int gaml_hip_fetch_async(gaml_hip_ctx* ctx, const void* d_src, int32_t n_doubles, void* hip_stream);
+int gaml_hip_fetch_wait(gaml_hip_ctx* ctx, double* out, int32_t n_doubles);
+
 /* Maintenance hint.  Windows aligned after the device record tables of a paired set were built are
  * scored from delta lists (slightly slower per pair); the library folds them into the tables by
  * itself when they grow past 1/8 of the pairs or after 64 evaluations without a new window.  This

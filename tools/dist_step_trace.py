@@ -27,10 +27,10 @@ with torch.cuda.stream(sc.stream):
         t0 = time.perf_counter(); pending, tl = ctx.eval_begin(v)
         t1 = time.perf_counter(); ctx.eval_score_async(sc.d_part.data_ptr(), sp)
         t2 = time.perf_counter(); dist.all_reduce(sc.d_part, op=dist.ReduceOp.SUM)
-        t3 = time.perf_counter(); sc.h_part.copy_(sc.d_part, non_blocking=True)
-        t4 = time.perf_counter(); sc.stream.synchronize()
+        t3 = time.perf_counter(); sc.ctx.fetch_async(sc._d_ptr, sc._n_part, sc.stream.cuda_stream)
+        t4 = time.perf_counter(); sc.ctx.fetch_wait(sc._h_ptr, sc._n_part)
         t5 = time.perf_counter()
         if i >= 100:
             seg += [t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4]; n += 1
-print("us per step: eval_begin %.1f, eval_score_async %.1f, all_reduce enqueue %.1f, copy enqueue %.1f, stream sync %.1f, total %.1f" % (*(seg / n * 1e6), seg.sum() / n * 1e6))
+print("us per step: eval_begin %.1f, eval_score_async %.1f, all_reduce enqueue %.1f, fetch enqueue %.1f, fetch wait %.1f, total %.1f" % (*(seg / n * 1e6), seg.sum() / n * 1e6))
 dist.destroy_process_group()
