@@ -186,3 +186,42 @@ def test_compact_tables_and_sampled_event_timing():
     for i in range(3):
         ctx.calc_prob(sets[i % 4])
     assert ctx.kernel_stats(reset=True)["device_us"] == 0.0
+
+
+def test_floor_that_underflows_to_zero():
+    """min_prob_per_base so low that exp(c + k * (L1 + L2)) is 0.0 in f64: a pair without a scoring alignment has
+    probability 0, which is NOT below a floor of 0, so the reference adds log(0) = -inf and counts no floored read
+    (graph.cc:1504-1513). The memo and the "probability 0 is floored" shortcuts must stand down."""
+    G, n, seed = 60_000, 2500, 131
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(700, 5000)))
+    pr = synth.make_paired_reads(genome, n, 100, 250.0, 25.0, 0.01, seed)
+    kw = dict(min_prob_per_base=-5.0, min_prob_start=-10.0)  # exp(-10 - 5 * 200) = 0
+    ctx, rs, orc, ors = _both(*g.packed(), synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2), kw, 250.0, 25.0)
+    walk = synth.genome_walk(g)
+    for paths in ([walk], [walk[: len(walk) // 2]]):  # the half walk leaves pairs without any alignment
+        got, zeros, tl = ctx.calc_prob(paths)
+        want, wz, wtl = orc.calc_prob(paths, fresh=True)
+        assert tl == wtl and zeros.tolist() == wz.tolist()
+        np.testing.assert_allclose(ctx.read_probs(rs), orc.paired_probs(ors)[0], rtol=4e-16, atol=0)
+        assert got == want or abs(got - want) <= 1e-9 * abs(want)  # -inf == -inf on the half walk
+    assert want == -np.inf
+
+
+def test_upload_paths_agree():
+    """The per-call tables reach the device through a copy kernel reading the pinned staging slot; knob 8 = 1 selects
+    the hipMemcpyAsync route (also what odd sizes fall back to). Same values bit for bit."""
+    from gaml_amd import api
+    genome = synth.make_genome(90_000, 141)
+    g = synth.make_graph(genome, synth.cut_lengths(90_000, 141, long_rng=(600, 4000)))
+    pr = synth.make_paired_reads(genome, 9_000, 100, 240.0, 24.0, 0.01, 141)
+    ctx = api.Context(device=0)
+    ctx.set_graph(*g.packed())
+    ctx.add_paired(api.paired_cfg(240.0, 24.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    walk = synth.genome_walk(g)
+    sets = [[walk], [walk[:9], walk[9:]], [walk[:20] + [-40] + walk[22:]]]
+    [ctx.calc_prob(s) for s in sets]
+    a = [ctx.calc_prob(s)[0] for s in sets]
+    ctx.debug_set_knob(8, 1)
+    b = [ctx.calc_prob(s)[0] for s in sets]
+    assert a == b
