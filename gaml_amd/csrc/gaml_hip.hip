@@ -362,16 +362,16 @@ int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
 
 // layout of one OccTable inside an arena
 struct OccLayout { size_t direct, multi_off, multi, end; };
-OccLayout layout_image(const OccImage& t, size_t at) {
+OccLayout layout_image(const OccImage& t, size_t at) {  // `direct` holds the 12-byte entries here
   OccLayout l;
   l.direct = at;
-  l.multi_off = (l.direct + std::max<size_t>(1, t.direct.size()) * sizeof(OccQuad) + 15) & ~(size_t)15;
+  l.multi_off = (l.direct + std::max<size_t>(1, t.occ12.size()) * sizeof(Occ12) + 15) & ~(size_t)15;
   l.multi = (l.multi_off + t.multi_off.size() * sizeof(int32_t) + 15) & ~(size_t)15;
   l.end = (l.multi + std::max<size_t>(1, t.multi.size()) * sizeof(OccQuad) + 15) & ~(size_t)15;
   return l;
 }
 void pack_image(const OccImage& t, const OccLayout& l, char* base) {
-  if (!t.direct.empty()) memcpy(base + l.direct, t.direct.data(), t.direct.size() * sizeof(OccQuad));
+  if (!t.occ12.empty()) memcpy(base + l.direct, t.occ12.data(), t.occ12.size() * sizeof(Occ12));
   memcpy(base + l.multi_off, t.multi_off.data(), t.multi_off.size() * sizeof(int32_t));
   if (!t.multi.empty()) memcpy(base + l.multi, t.multi.data(), t.multi.size() * sizeof(OccQuad));
 }
@@ -414,6 +414,7 @@ MateView view_of(const MateDev& d, const char* arena, const OccLayout& l) {
   v.first = d.first.as<int4>();
   v.extra = d.extra.as<int4>();
   v.occ = (const int4*)(arena + l.direct);
+  v.occ12 = nullptr;
   v.multi_off = (const int*)(arena + l.multi_off);
   v.multi = (const int4*)(arena + l.multi);
   v.mism_pow = d.pows.as<double>();
@@ -680,11 +681,6 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   // (Pairs with a record in a window that occurs several times: the main kernel notes them in a bitmap and
   // paired_general_kernel scores them, see below. An earlier version listed them here on the host,
   // O(records of such windows) per call -- 2.6 ms per call once an annealing run had produced many repeated nodes.)
-  size_t o8_off[2];
-  for (int mt = 0; mt < 2; mt++) {
-    o8_off[mt] = total;
-    total = align16(total + std::max<size_t>(1, s.image[mt].occ8.size()) * sizeof(uint64_t));
-  }
   const size_t nd = s.dirty.size();
   const double tp1 = now_us();
   c->prof[2] = tp1 - t_after_host;  // overflow list + occ8
@@ -693,8 +689,6 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   if (slot < 0) return slot;
   pack_image(s.image[0], l0, (char*)host);
   pack_image(s.image[1], l1, (char*)host);
-  for (int mt = 0; mt < 2; mt++)
-    if (!s.image[mt].occ8.empty()) memcpy((char*)host + o8_off[mt], s.image[mt].occ8.data(), s.image[mt].occ8.size() * sizeof(uint64_t));
   if (cov) {
     memcpy((char*)host + pb_off, p.path_base.data(), p.path_base.size() * sizeof(int32_t));
     memcpy((char*)host + so_off, p.start_off.data(), p.start_off.size() * sizeof(int32_t));
@@ -833,7 +827,9 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   for (int mt = 0; mt < 2; mt++) {
     a.rec8[mt] = s.rec8[mt].as<unsigned long long>();
     a.inl[mt] = s.inl[mt].as<int4>();
-    a.occ8[mt] = (const unsigned long long*)(arena + o8_off[mt]);
+    a.m[mt].occ12 = (const Occ12*)a.m[mt].occ;  // paired sets: 12-byte entries instead of the 16-byte image
+    a.m[mt].occ = nullptr;
+    a.occ12[mt] = a.m[mt].occ12;
   }
   {
     const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());

@@ -927,14 +927,13 @@ static inline uint64_t occ8_pack(const OccQuad& q, bool general) {
 }
 
 void OccImage::build(size_t n_windows, const PlanView& view, int mate) {
-  if (direct.size() < n_windows) {
-    direct.resize(n_windows, OccQuad{0, 0, -1, 0});
-    occ8.resize(n_windows, kNoRec8);
+  if (occ12.size() < n_windows) {
+    occ12.resize(n_windows, Occ12{~0u, ~0u, 0});
     cnt_.resize(n_windows, 0);
     list_of_.resize(n_windows, -1);
     stamp_.resize(n_windows, 0);
   }
-  for (int32_t w : touched_) { direct[w] = OccQuad{0, 0, -1, 0}; occ8[w] = kNoRec8; }
+  for (int32_t w : touched_) occ12[w] = Occ12{~0u, ~0u, 0};
   touched_.clear();
   if (++serial_ == 0) { std::fill(stamp_.begin(), stamp_.end(), 0); serial_ = 1; }
   // how often does each window occur in this path set
@@ -953,7 +952,7 @@ void OccImage::build(size_t n_windows, const PlanView& view, int mate) {
     for (const Occ& o : pm.occ[mate]) {
       OccQuad q{o.shift, o.min_pos, (int32_t)slot, rank0 + o.rank};
       // one occurrence that the 8-byte form can hold -> direct entry; anything else -> a list
-      if (cnt_[o.wid] == 1 && q.path < 32767 && q.min_pos <= 32767) { direct[o.wid] = q; occ8[o.wid] = occ8_pack(q, false); }
+      if (cnt_[o.wid] == 1 && q.path < 32767 && q.min_pos <= 32767) { const uint64_t e = occ8_pack(q, false); occ12[o.wid] = Occ12{(uint32_t)e, (uint32_t)(e >> 32), q.rank}; }
       else pending_.push_back(Pending{o.wid, q});
     }
     rank0 += (int32_t)pm.occ[mate].size();
@@ -965,8 +964,8 @@ void OccImage::build(size_t n_windows, const PlanView& view, int mate) {
         list_of_[pe.wid] = (int32_t)multi_off.size() - 1;
         multi_off.push_back(multi_off.back() + cnt_[pe.wid]);
         general_wids.push_back(pe.wid);
-        direct[pe.wid] = OccQuad{0, 0, pe.q.path, -(list_of_[pe.wid] + 1)};
-        occ8[pe.wid] = occ8_pack(pe.q, true);
+        const uint64_t e = occ8_pack(OccQuad{0, 0, 0, 0}, true);  // only the flag is read (the occurrences are in the list); never all ones
+        occ12[pe.wid] = Occ12{(uint32_t)e, (uint32_t)(e >> 32), -(list_of_[pe.wid] + 1)};  //
       }
     multi.resize(multi_off.back());
     std::vector<int32_t> fill(multi_off.size(), 0);

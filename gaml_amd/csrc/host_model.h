@@ -198,12 +198,17 @@ void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& o
 void split_contigs(const Walk& path, std::vector<std::pair<int32_t, int32_t>>& ctg_ranges, std::vector<int32_t>& gaps);
 
 struct PlanView;
-// Host image of one mate's device occurrence tables (16-byte direct table + lists + 8-byte table),
-// kept between evaluations and patched: only the entries of windows that occurred in the previous
-// or occur in the current path set are touched, O(occurrences) per call instead of O(windows).
+// Host image of one mate's device occurrence tables (8-byte entry + 4-byte rank per window, lists for windows
+// that occur several times), kept between evaluations and patched: only the entries of windows that occurred in
+// the previous or occur in the current path set are touched, O(occurrences) per call instead of O(windows).
+//   occ12 = {occ8, rank} interleaved; occ8: shift:32 | min_pos:16 | path:15 | general:1 (all ones: the window does not occur);
+//   rank: visiting rank of the one occurrence, or -(list + 1) for a general window (its occurrences are
+//         multi[multi_off[list] .. multi_off[list + 1])).
+// Together they carry what the 16-byte OccQuad of the single-end path carries, in 12 bytes (the per-call upload is
+// what the scoring launch waits for).
+struct Occ12 { uint32_t lo, hi; int32_t rank; };  // occ8 = lo | hi << 32, then the rank: ONE 12-byte load per occurrence
 struct OccImage {
-  std::vector<OccQuad> direct;
-  std::vector<uint64_t> occ8;
+  std::vector<Occ12> occ12;
   std::vector<int32_t> multi_off;
   std::vector<OccQuad> multi;
   std::vector<int32_t> general_wids;  // windows whose entry sends their reads to the general path

@@ -17,10 +17,14 @@ namespace gaml {
 constexpr int kBlock = 256;      // 4 waves of 64
 constexpr int kMaxBlocks = 2048; // 256 CUs x 8 blocks, grid-stride beyond (guide G11)
 
+// Occ12 (host_model.h): {lo, hi, rank}, 4-byte aligned: one dwordx3 load (register classes) or a dwordx2 of the first two words (class 0)
+__device__ __forceinline__ unsigned long long occ8_of(const Occ12* t, unsigned w) { const Occ12* e = t + w; return (unsigned long long)e->lo | ((unsigned long long)e->hi << 32); }
+
 struct MateView {
   const int4* first;      // per read: {wid | -1, pos, edit | orient<<8 | extra_count<<9, extra_start}
   const int4* extra;      // further records of reads that have more than one
-  const int4* occ;        // per window: {shift, min_pos, path | -1, rank | -(list+1)}
+  const int4* occ;        // per window: {shift, min_pos, path | -1, rank | -(list+1)} -- single-end sets; null for paired sets, which use
+  const Occ12* occ12;     //   {occ8 = shift:32 | min_pos:16 | path:15 | general:1 (all ones: does not occur), rank or -(list+1)}: 12 bytes
   const int* multi_off;   // windows occurring several times: list bounds
   const int4* multi;      //   ... and entries
   const double* mism_pow; // mismatch_prob^e
@@ -45,7 +49,7 @@ struct PairedArgs {
   const unsigned char* len_code;
   const uint32_t* len_combo;
   int n_codes;               // entries of len_combo / floor_c / logfloor_c (<= 256)
-  const unsigned long long* occ8[2];
+  const Occ12* occ12[2];     // = m[mt].occ12
   // per length-combination tables of the compact path (host libm, indexed by len_code):
   const double* pe[2];       // [code*64 + e] = mismatch^e * match^(L-e)  (the product of graph.cc:1859-1863)
   const double* floor_c;     // [code] exp(c + k (L1+L2)); logfloor_c = log of it; covthr_c = exp(c + k 2 L2)
@@ -93,6 +97,19 @@ struct PairedArgs {
 
 struct Cand { int path, pos, edit, orient, rank, k; bool valid; };
 
+// a window's occurrence entry in the 16-byte form from the paired sets' 8-byte entry + rank
+__device__ __forceinline__ int4 occ_from_compact(unsigned long long o, int rk) {
+  const int4 e = make_int4((int)(unsigned)o, (int)(short)(o >> 32), (int)((o >> 48) & 0x7fff), rk);
+  return o == ~0ull ? make_int4(0, 0, -1, 0) : e;
+}
+// ... from whichever image the read set has (uniform branch: for the loops that are not latency-critical; the
+// register classes read the compact image directly, their loads must not sit behind branches)
+__device__ __forceinline__ int4 mate_occ(const MateView& v, int w) {
+  if (v.occ) return v.occ[w];
+  const Occ12 e = v.occ12[w];
+  return occ_from_compact((unsigned long long)e.lo | ((unsigned long long)e.hi << 32), e.rank);
+}
+
 __device__ __forceinline__ Cand make_cand(const int4& r, const int4& o, int k) {
   Cand c;
   c.path = o.z; c.pos = r.y + o.x; c.edit = r.z & 0xff; c.orient = (r.z >> 8) & 1;
@@ -122,7 +139,7 @@ __device__ __forceinline__ void for_each_cand_src(const MateView& v, const Src& 
   for (int k = 0; k < cnt; k++) {
     int4 r = src.get(k);
     if (r.x < 0) continue;
-    int4 o = v.occ[r.x];
+    int4 o = mate_occ(v, r.x);
     if (o.z < 0) continue;  // window not part of the scored paths
     if (o.w >= 0) {
       f(make_cand(r, o, k));
@@ -274,8 +291,11 @@ template <int K>
 __device__ __forceinline__ bool cands_from_records(const MateView& v, const int4 (&r)[K], RegCands<K>& c) {
   int4 o[K];
   bool multi = false;
+  Occ12 e[K];
 #pragma unroll
-  for (int k = 0; k < K; k++) o[k] = v.occ[r[k].x >= 0 ? r[k].x : 0];  // unconditional (entry 0 always exists): the K loads go out back to back
+  for (int k = 0; k < K; k++) e[k] = v.occ12[r[k].x >= 0 ? r[k].x : 0];  // unconditional (entry 0 always exists): the K loads go out back to back (paired sets only)
+#pragma unroll
+  for (int k = 0; k < K; k++) o[k] = occ_from_compact((unsigned long long)e[k].lo | ((unsigned long long)e[k].hi << 32), e[k].rank);
 #pragma unroll
   for (int k = 0; k < K; k++) if (r[k].x < 0) o[k] = make_int4(0, 0, -1, 0);
 #pragma unroll
@@ -494,10 +514,10 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
       if (d0) { c0.r1 = kNone8; c0.r2 = kNone8; }
       if (d1) { c1.r1 = kNone8; c1.r2 = kNone8; }
       const unsigned long long wmask = ABL == 6 ? 0x0 : 0xffffff;  // ablation 6: every lookup at entry 0
-      c0.o1 = c0.r1 != kNone8 ? a.occ8[0][c0.r1 & wmask] : kNone8;
-      c0.o2 = c0.r2 != kNone8 ? a.occ8[1][c0.r2 & wmask] : kNone8;
-      c1.o1 = c1.r1 != kNone8 ? a.occ8[0][c1.r1 & wmask] : kNone8;
-      c1.o2 = c1.r2 != kNone8 ? a.occ8[1][c1.r2 & wmask] : kNone8;
+      c0.o1 = c0.r1 != kNone8 ? occ8_of(a.occ12[0], (unsigned)(c0.r1 & wmask)) : kNone8;
+      c0.o2 = c0.r2 != kNone8 ? occ8_of(a.occ12[1], (unsigned)(c0.r2 & wmask)) : kNone8;
+      c1.o1 = c1.r1 != kNone8 ? occ8_of(a.occ12[0], (unsigned)(c1.r1 & wmask)) : kNone8;
+      c1.o2 = c1.r2 != kNone8 ? occ8_of(a.occ12[1], (unsigned)(c1.r2 & wmask)) : kNone8;
       if (ABL == 2) {
         a.probs[i0] = (double)(int)(c0.o1 + c0.o2); lsum += (double)(int)(c0.o1 + c0.o2);
         if (two) { a.probs[i1] = (double)(int)(c1.o1 + c1.o2); lsum += (double)(int)(c1.o1 + c1.o2); }
@@ -569,8 +589,8 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
   // 32-bit byte offsets from uniform bases: one address register per load instead of a 64-bit add (tables < 4 GB)
   const char* const rec0 = (const char*)a.rec8[0];
   const char* const rec1 = (const char*)a.rec8[1];
-  const char* const occ0 = (const char*)a.occ8[0];
-  const char* const occ1 = (const char*)a.occ8[1];
+  const char* const occ0 = (const char*)a.occ12[0];
+  const char* const occ1 = (const char*)a.occ12[1];
   const char* const memo = (const char*)a.memo;
   char* const probs = (char*)a.probs;
   for (unsigned base = (unsigned)lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
@@ -584,8 +604,9 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
     GAML_STAMP(2, r1[0].x ^ r1[1].x ^ r1[2].x ^ r1[3].x ^ r2[0].x ^ r2[3].x)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      o1[k] = *(const uint2*)(occ0 + (r1[k].y != ~0u ? (r1[k].x & 0xffffffu) : 0u) * 8u);
-      o2[k] = *(const uint2*)(occ1 + (r2[k].y != ~0u ? (r2[k].x & 0xffffffu) : 0u) * 8u);
+      const Occ12* e1 = (const Occ12*)(occ0 + (r1[k].y != ~0u ? (r1[k].x & 0xffffffu) : 0u) * 12u);  // the entry's first two words
+      const Occ12* e2 = (const Occ12*)(occ1 + (r2[k].y != ~0u ? (r2[k].x & 0xffffffu) : 0u) * 12u);
+      o1[k] = make_uint2(e1->lo, e1->hi); o2[k] = make_uint2(e2->lo, e2->hi);
     }
     GAML_STAMP(3, o1[0].x ^ o1[1].x ^ o1[2].x ^ o1[3].x ^ o2[0].x ^ o2[3].x)
     int state[4];
@@ -630,8 +651,8 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
         const int i = (int)(base + k * stride);
         Compact1 d;
         compact_load(a, i, true, d);
-        d.o1 = d.r1 != kNone8 ? a.occ8[0][d.r1 & 0xffffff] : kNone8;
-        d.o2 = d.r2 != kNone8 ? a.occ8[1][d.r2 & 0xffffff] : kNone8;
+        d.o1 = d.r1 != kNone8 ? occ8_of(a.occ12[0], (unsigned)(d.r1 & 0xffffff)) : kNone8;
+        d.o2 = d.r2 != kNone8 ? occ8_of(a.occ12[1], (unsigned)(d.r2 & 0xffffff)) : kNone8;
         const uint32_t l = a.len_combo[d.lc];
         d.L1 = l & 0xffff; d.L2 = l >> 16;
         CompactPrep q;
@@ -817,7 +838,7 @@ __device__ __forceinline__ int wave_gather(const MateView& v, const int4& r0, in
     int4 r = make_int4(-1, 0, 0, 0), o = make_int4(0, 0, -1, 0);
     if (k < cnt) {
       r = k == 0 ? r0 : v.extra[r0.w + k - 1];
-      if (r.x >= 0) o = v.occ[r.x];
+      if (r.x >= 0) { const Occ12 e = v.occ12[r.x]; o = occ_from_compact((unsigned long long)e.lo | ((unsigned long long)e.hi << 32), e.rank); }  // (paired sets only)
       if (o.z >= 0) mine = o.w >= 0 ? 1 : v.multi_off[-o.w] - v.multi_off[-o.w - 1];
     }
     // exclusive prefix sum of `mine` over the wave
@@ -913,7 +934,7 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
 // GEN: the path set has windows that occur several times -- note their pairs for paired_general_kernel. Without
 // such windows the notes are compiled out (they cost 0.3 us of 12 at cfg3 even when nothing is noted).
 template <bool TICKET, int ABL = 0, bool GEN = false>
-__global__ __launch_bounds__(kBlock) void paired_score_kernel(PairedArgs a) {
+__global__ __launch_bounds__(kBlock, 5) void paired_score_kernel(PairedArgs a) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
   __shared__ int4 cand[kBlock / 64][2][kOvfCap];
