@@ -131,7 +131,11 @@ def main():
     in_loop = [False]
     if use_dist:
         from gaml_amd.dist import ShardedScorer
-        scorer = ShardedScorer(ctx)
+        # one node (the driver's launch): the partials are summed through shared memory after a blocking evaluation;
+        # GAML_BENCH_EXCHANGE=rccl keeps them on the device (finisher kernel -> RCCL all-reduce -> fetch)
+        single_node = int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world
+        exchange = os.environ.get("GAML_BENCH_EXCHANGE", "shm" if single_node else "rccl")
+        scorer = ShardedScorer(ctx, host_exchange=("/gaml_bench_%s" % os.environ.get("MASTER_PORT", "0")) if exchange == "shm" else None)
     torch.cuda.synchronize()
 
     def step(paths):
@@ -219,7 +223,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl.name + f"; {n_pairs_rank} pairs per GPU, whole true genome as 1-2 walks, "
                                              "8 rotating path sets, window cache warm", "pairs_per_gpu": n_pairs_rank,
-                       "genome_bp": wl.genome_len, "parallelism": f"reads sharded over {world} GPU(s), 1 all-reduce of 32 B/step"},
+                       "genome_bp": wl.genome_len, "parallelism": f"reads sharded over {world} GPU(s), 1 all-reduce of 32 B/step"
+                       + ("" if scorer is None else (" through shared memory (one node; blocking evaluation per rank)" if scorer._host_exchange else " over RCCL"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "paired_score_kernel", "kernel_us": kern_us, "algo_bytes_per_launch": bytes_per_launch,
@@ -265,6 +270,8 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(out), flush=True)
     if use_dist:
+        if scorer is not None:
+            scorer.close()  # unlinks the shared-memory name (rank 0)
         dist.destroy_process_group()
 
 

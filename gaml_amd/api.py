@@ -176,6 +176,10 @@ def _load():
     L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
+    if hasattr(L, "gaml_hip_shm_exchange_open"):
+        L.gaml_hip_shm_exchange_open.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
+        L.gaml_hip_shm_allreduce_sum.argtypes = [vp, C.c_void_p, C.c_int32]
+        L.gaml_hip_shm_exchange_close.argtypes = [vp, C.c_int32]
     if hasattr(L, "gaml_hip_fetch_async"):
         L.gaml_hip_fetch_async.argtypes = [vp, C.c_void_p, C.c_int32, C.c_void_p]
         L.gaml_hip_fetch_wait.argtypes = [vp, C.c_void_p, C.c_int32]
@@ -379,6 +383,26 @@ class Context:
         if rc < 0:
             self._check(rc)
         return self._pending.value, self._tl2.value
+
+    def shm_exchange_open(self, name: str, rank: int, world: int, cap_doubles: int):
+        """gaml_hip_shm_exchange_open: single-node sum of host-resident partials through POSIX shared memory."""
+        self._check(_lib.gaml_hip_shm_exchange_open(self._h, name.encode(), rank, world, cap_doubles))
+
+    def shm_allreduce_sum(self, ptr: int, n_doubles: int):
+        rc = _lib.gaml_hip_shm_allreduce_sum(self._h, ptr, n_doubles)
+        if rc < 0:
+            self._check(rc)
+
+    def shm_exchange_close(self, unlink_name: bool = False):
+        self._check(_lib.gaml_hip_shm_exchange_close(self._h, 1 if unlink_name else 0))
+
+    def eval_finish_fast(self, out_ptr: int):
+        """gaml_hip_eval_finish (blocking) into a host buffer given by address."""
+        if getattr(self, "_fast_finish", None) is None:
+            self._fast_finish = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)(("gaml_hip_eval_finish", _lib))
+        rc = self._fast_finish(self._h, out_ptr)
+        if rc < 0:
+            self._check(rc)
 
     def fetch_async(self, d_ptr: int, n_doubles: int, stream: int = 0):
         """gaml_hip_fetch_async: device doubles -> the context's pinned block, behind everything enqueued on `stream`."""

@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <chrono>
 #include <climits>
 #include <limits>
@@ -235,6 +238,8 @@ struct gaml_hip_ctx {
   double stat_device_us = 0, stat_algo_bytes = 0;
   DevBuf packed;  // 4 doubles per read set
   PinBuf packed_host;
+  // gaml_hip_shm_exchange_*: the ranks of one node add up their (host-resident) partials through a POSIX shared-memory block
+  char* shm_base = nullptr; size_t shm_bytes = 0; int shm_rank = 0, shm_world = 0, shm_cap = 0; unsigned long long shm_step = 0; std::string shm_name;
   PinBuf fetch_host;            // gaml_hip_fetch_async / _wait: [sequence word | 63 x pad | doubles]
   unsigned long long fetch_seq = 0;
   hipStream_t fetch_stream = nullptr;
@@ -1591,6 +1596,7 @@ int gaml_hip_create(gaml_hip_ctx** out, int device) {
 }
 
 void gaml_hip_destroy(gaml_hip_ctx* c) {
+  if (c && c->shm_base) { munmap(c->shm_base, c->shm_bytes); c->shm_base = nullptr; }
   if (!c) return;
   if (c->device >= 0) {
     (void)hipSetDevice(c->device);
@@ -2240,6 +2246,65 @@ int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* c, int32_t i, const void* 
   // every rank computes the same bad_bases; one of them contributes it to the all-reduce(sum) of the partials
   hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), pc.out4, contribute ? 1.0 : 0.0);
   HIP_TRY(c, hipGetLastError());
+  return GAML_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side exchange for one node (the hot path's one collective is a sum of 4 doubles per read set).
+// A blocking evaluation leaves a rank's partials in host memory; adding them up across the ranks of a node through
+// shared memory costs ~1 us, against ~30 us for device partials -> finisher kernel -> RCCL all-reduce -> fetch.
+// Block layout: [parity 0 | parity 1] x [rank] x {sequence word, 7 words pad, cap doubles}; a rank publishes its
+// values and then the step number; everybody adds the slots in rank order (same bits on every rank). A rank can be
+// at most one step ahead of the slowest (it needs everyone's step-k values to finish step k): two parities suffice.
+// ---------------------------------------------------------------------------------------------
+static size_t shm_slot_bytes(int cap) { return 64 + (((size_t)cap * sizeof(double) + 63) & ~(size_t)63); }
+
+int gaml_hip_shm_exchange_open(gaml_hip_ctx* c, const char* name, int32_t rank, int32_t world, int32_t cap_doubles) {
+  if (!c || !name || world < 1 || rank < 0 || rank >= world || cap_doubles < 1) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->shm_base) return fail(c, GAML_HIP_ESTATE, "exchange already open");
+  const size_t bytes = 2 * (size_t)world * shm_slot_bytes(cap_doubles);
+  int fd = shm_open(name, O_RDWR | O_CREAT, 0600);
+  if (fd < 0) return fail(c, GAML_HIP_ESTATE, std::string("shm_open ") + name + " failed");
+  if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); return fail(c, GAML_HIP_ESTATE, "ftruncate on the shared block failed"); }  // new pages read as zero: sequence 0 = nothing published
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return fail(c, GAML_HIP_ESTATE, "mmap of the shared block failed");
+  c->shm_base = (char*)p; c->shm_bytes = bytes; c->shm_rank = rank; c->shm_world = world; c->shm_cap = cap_doubles; c->shm_step = 0; c->shm_name = name;
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_shm_exchange_close(gaml_hip_ctx* c, int32_t unlink_name) {
+  if (!c) return GAML_HIP_EINVAL;
+  if (c->shm_base) munmap(c->shm_base, c->shm_bytes);
+  if (unlink_name && !c->shm_name.empty()) shm_unlink(c->shm_name.c_str());
+  c->shm_base = nullptr; c->shm_bytes = 0; c->shm_name.clear();
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_shm_allreduce_sum(gaml_hip_ctx* c, double* inout, int32_t n) {
+  if (!c || !inout || n < 1) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (!c->shm_base) return fail(c, GAML_HIP_ESTATE, "exchange not open");
+  if (n > c->shm_cap) return fail(c, GAML_HIP_EINVAL, "more values than the exchange was opened for");
+  const unsigned long long step = ++c->shm_step;
+  const size_t slot = shm_slot_bytes(c->shm_cap);
+  char* half = c->shm_base + (step & 1) * (size_t)c->shm_world * slot;
+  char* mine = half + (size_t)c->shm_rank * slot;
+  memcpy(mine + 64, inout, (size_t)n * sizeof(double));
+  __atomic_store_n((unsigned long long*)mine, step, __ATOMIC_RELEASE);
+  const double t0 = now_us();
+  for (int r = 0; r < c->shm_world; r++) {
+    const unsigned long long* seq = (const unsigned long long*)(half + (size_t)r * slot);
+    unsigned spins = 0;
+    while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != step) {
+      if ((++spins & 1023) == 0 && now_us() - t0 > 30e6) return fail(c, GAML_HIP_ESTATE, "shared-memory exchange: a rank did not arrive within 30 s");
+      __builtin_ia32_pause();
+    }
+  }
+  for (int k = 0; k < n; k++) inout[k] = 0.0;
+  for (int r = 0; r < c->shm_world; r++) {  // rank order on every rank: identical sums
+    const double* v = (const double*)(half + (size_t)r * slot + 64);
+    for (int k = 0; k < n; k++) inout[k] += v[k];
+  }
   return GAML_HIP_OK;
 }
 

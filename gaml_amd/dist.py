@@ -22,7 +22,12 @@ class ShardedScorer:
     """CalcProb over a context that holds one shard of every read set. All ranks call calc_prob with
     the same paths and get the same value."""
 
-    def __init__(self, ctx: api.Context, group=None, stream: "torch.cuda.Stream | None" = None):
+    def __init__(self, ctx: api.Context, group=None, stream: "torch.cuda.Stream | None" = None, host_exchange: "str | None" = None):
+        """host_exchange: name of a POSIX shared-memory block ("/gaml_<something>", the same on every rank) when all
+        ranks run on ONE node and no read set has a coverage penalty: each step is then a blocking evaluation (partials
+        land in host memory) + a ~1 us sum through shared memory, instead of finisher kernel -> RCCL all-reduce of 32
+        bytes -> fetch (about 30 us of dependent dispatches). RCCL stays the exchange for everything else: window
+        maxima on the cold path, coverage maps, PacBio events -- and for the partials when host_exchange is None."""
         self.ctx = ctx
         self.group = group
         self.rank = dist.get_rank(group)
@@ -41,6 +46,28 @@ class ShardedScorer:
         # does not support every collective on them, so there the buffers take a detour through the host
         self._host_collectives = dist.get_backend(group) == "gloo"
         self._n_part = self.d_part.numel()
+        self._host_exchange = host_exchange
+        if host_exchange:
+            ctx.shm_exchange_open(host_exchange, self.rank, self.world, self._n_part)
+            dist.barrier(group=group)  # everybody has mapped the block before anybody publishes
+
+    def close(self):
+        if self._host_exchange:
+            dist.barrier(group=self.group)
+            self.ctx.shm_exchange_close(unlink_name=self.rank == 0)
+            self._host_exchange = None
+
+    def _score_host(self, fp):
+        """Blocking evaluation + shared-memory sum (single node, no coverage penalty)."""
+        ctx = self.ctx
+        pending, total_len = ctx.eval_begin_fast(fp) if isinstance(fp, api.FlatPaths) else ctx.eval_begin(fp)
+        if pending:  # cold path: new windows were aligned -- their largest positions are a maximum over all ranks' reads
+            mx = torch.from_numpy(ctx.eval_pending_maxpos().copy()).cuda()
+            self._all_reduce(mx, dist.ReduceOp.MAX)
+            ctx.eval_apply_maxpos(mx.cpu().numpy())
+        ctx.eval_finish_fast(self._h_ptr)
+        ctx.shm_allreduce_sum(self._h_ptr, self._n_part)
+        return total_len
 
     def _fetch(self):
         """Reduced partials -> self.h_part: a one-block kernel publishes them in mapped pinned memory behind the
@@ -110,6 +137,10 @@ class ShardedScorer:
     def calc_prob(self, paths):
         """Blocking, like CalcProb. (Callers in a tight loop may wrap the loop in `with torch.cuda.stream(
         scorer.stream)` themselves: the context manager costs a few microseconds per entry.)"""
+        if self._host_exchange:
+            total_len = self._score_host(paths)
+            prob = self.ctx.combine_fast(self._h_ptr, total_len)
+            return prob, self.ctx.last_zeros, total_len
         if torch.cuda.current_stream() != self.stream:
             with torch.cuda.stream(self.stream):
                 return self.calc_prob(paths)
@@ -122,6 +153,8 @@ class ShardedScorer:
     def score(self, fp: "api.FlatPaths") -> float:
         """calc_prob for tight loops: prebuilt FlatPaths in, the value out (floored counts: ctx.last_zeros). The
         caller keeps `with torch.cuda.stream(scorer.stream)` around its loop."""
+        if self._host_exchange:
+            return self.ctx.combine_fast(self._h_ptr, self._score_host(fp))
         total_len = self._enqueue(fp, self.d_part)
         self._all_reduce(self.d_part, dist.ReduceOp.SUM)
         self._fetch()

@@ -200,6 +200,17 @@ int gaml_hip_eval_finish_async(gaml_hip_ctx* ctx, void* d_partials, void* hip_st
 /* wait for everything enqueued on the library's private stream */
 int gaml_hip_sync(gaml_hip_ctx* ctx);
 
+/* Single-node exchange of the partials through POSIX shared memory (new; the reference is one process). After a
+ * BLOCKING evaluation (gaml_hip_eval_finish / gaml_hip_calc_partials) a rank's partials are host values; the ranks of
+ * one node add them up here in ~1 us instead of sending them back through the device for an RCCL all-reduce of 32
+ * bytes (~30 us of dependent dispatches). Every rank opens the same `name` (e.g. "/gaml_<port>") with its rank and
+ * the world size; _allreduce_sum is collective, sums in rank order (identical bits on every rank) and waits at most
+ * 30 s for the others. Not for read sets with penalty_constant > 0 on a sharded context (those need the coverage
+ * exchange of gaml_hip_eval_score_async). _close(unlink_name = 1) on one rank removes the name. */
+int gaml_hip_shm_exchange_open(gaml_hip_ctx* ctx, const char* name, int32_t rank, int32_t world, int32_t cap_doubles);
+int gaml_hip_shm_allreduce_sum(gaml_hip_ctx* ctx, double* inout, int32_t n_doubles);
+int gaml_hip_shm_exchange_close(gaml_hip_ctx* ctx, int32_t unlink_name);
+
 /* Device values -> host at the end of a stream-ordered sequence (after the all-reduce of the partials, say) without a
  * D2H copy command and without the runtime's completion wake-up: _async enqueues a one-block kernel on `hip_stream`
  * (NULL: the library's stream) that writes n_doubles values from d_src and then a sequence word into mapped pinned

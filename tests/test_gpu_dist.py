@@ -102,6 +102,11 @@ def _two_rank_worker(rank, world, port, out_dir, penalty):
         single = [scorer.calc_prob(p) for p in sets]          # cold: windows aligned, maxima exchanged
         batch = scorer.calc_prob_batch(sets)                  # warm, one all-reduce for the four sets
         res = {"single": [[v[0], v[1].tolist(), v[2]] for v in single], "batch": [[v[0], v[1].tolist(), v[2]] for v in batch]}
+        if penalty == 0.0:
+            # the single-node exchange: blocking evaluation per rank + sum through shared memory (gaml_hip_shm_*)
+            host = ShardedScorer(ctx, host_exchange=f"/gaml_test_{port}")
+            res["host_exchange"] = [[v[0], v[1].tolist(), v[2]] for v in (host.calc_prob(p) for p in sets)]
+            host.close()
         with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
             json.dump(res, f)
     finally:
@@ -117,6 +122,8 @@ def test_two_processes_share_the_reads(tmp_path, penalty):
     mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path), penalty), nprocs=world, join=True)
     ranks = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
     assert ranks[0] == ranks[1]  # every rank ends up with the same values
+    if penalty == 0.0:  # two ranks: a + b either way, so the shared-memory exchange gives the collective's bits
+        assert ranks[0]["host_exchange"] == ranks[0]["single"]
     # the unsharded context on the same inputs
     genome = synth.make_genome(60_000, 73)
     g = synth.make_graph(genome, synth.cut_lengths(60_000, 73, long_rng=(900, 4000)))
