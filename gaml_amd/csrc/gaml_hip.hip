@@ -2263,7 +2263,8 @@ int gaml_hip_shm_exchange_open(gaml_hip_ctx* c, const char* name, int32_t rank, 
   if (!c || !name || world < 1 || rank < 0 || rank >= world || cap_doubles < 1) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   if (c->shm_base) return fail(c, GAML_HIP_ESTATE, "exchange already open");
   const size_t bytes = 2 * (size_t)world * shm_slot_bytes(cap_doubles);
-  int fd = shm_open(name, O_RDWR | O_CREAT, 0600);
+  if (rank == 0) shm_unlink(name);  // a block left behind by a crashed run would carry old step numbers: rank 0 starts a fresh one (it opens FIRST)
+  int fd = shm_open(name, rank == 0 ? (O_RDWR | O_CREAT | O_EXCL) : O_RDWR, 0600);
   if (fd < 0) return fail(c, GAML_HIP_ESTATE, std::string("shm_open ") + name + " failed");
   if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); return fail(c, GAML_HIP_ESTATE, "ftruncate on the shared block failed"); }  // new pages read as zero: sequence 0 = nothing published
   void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);

@@ -48,7 +48,11 @@ class ShardedScorer:
         self._n_part = self.d_part.numel()
         self._host_exchange = host_exchange
         if host_exchange:
-            ctx.shm_exchange_open(host_exchange, self.rank, self.world, self._n_part)
+            if self.rank == 0:
+                ctx.shm_exchange_open(host_exchange, 0, self.world, self._n_part)  # creates a fresh block
+            dist.barrier(group=group)
+            if self.rank != 0:
+                ctx.shm_exchange_open(host_exchange, self.rank, self.world, self._n_part)
             dist.barrier(group=group)  # everybody has mapped the block before anybody publishes
 
     def close(self):

@@ -204,7 +204,8 @@ int gaml_hip_sync(gaml_hip_ctx* ctx);
  * BLOCKING evaluation (gaml_hip_eval_finish / gaml_hip_calc_partials) a rank's partials are host values; the ranks of
  * one node add them up here in ~1 us instead of sending them back through the device for an RCCL all-reduce of 32
  * bytes (~30 us of dependent dispatches). Every rank opens the same `name` (e.g. "/gaml_<port>") with its rank and
- * the world size; _allreduce_sum is collective, sums in rank order (identical bits on every rank) and waits at most
+ * the world size -- rank 0 FIRST (it replaces whatever block of that name exists), the others after a barrier of the
+ * caller's; _allreduce_sum is collective, sums in rank order (identical bits on every rank) and waits at most
  * 30 s for the others. Not for read sets with penalty_constant > 0 on a sharded context (those need the coverage
  * exchange of gaml_hip_eval_score_async). _close(unlink_name = 1) on one rank removes the name. */
 int gaml_hip_shm_exchange_open(gaml_hip_ctx* ctx, const char* name, int32_t rank, int32_t world, int32_t cap_doubles);
