@@ -67,8 +67,28 @@ def _worker(rank, world, port, out_dir):
     ors = orc.add_paired(*synth.pack_reads(pr.mate1[lo:hi]), *synth.pack_reads(pr.mate2[lo:hi]), 0.01, op.paired_cfg(250.0, 25.0))
     mean_log, zeros, tl = orc.calc_prob(paths, fresh=True)
     part = torch.tensor([mean_log * (hi - lo), float(zeros[0][0]), 0.0, float(hi - lo)], dtype=torch.float64)
+    mine_part = part.clone()
     dist.all_reduce(part, op=dist.ReduceOp.SUM)  # the single collective of the path
     prob, z = ctx.combine_partials(part.numpy(), tl)
+    # the single-node carrier of the same sum: POSIX shared memory (gaml_hip_shm_*), rank 0 opens first
+    name = f"/gaml_cpu_test_{port}"
+    if rank == 0:
+        ctx.shm_exchange_open(name, 0, world, 4)
+    dist.barrier()
+    if rank != 0:
+        ctx.shm_exchange_open(name, rank, world, 4)
+    dist.barrier()
+    everyone = [torch.empty_like(mine_part) for _ in range(world)]
+    dist.all_gather(everyone, mine_part)
+    for step in range(300):  # many rounds: the two parities of the block get reused, ranks run ahead of each other
+        v = (mine_part + step).numpy().copy()
+        ctx.shm_allreduce_sum(v.ctypes.data, 4)
+        want = torch.zeros(4, dtype=torch.float64)
+        for r in range(world):  # rank order, as the exchange adds them
+            want = want + (everyone[r] + step)
+        assert v.tolist() == want.tolist(), (rank, step)
+    dist.barrier()
+    ctx.shm_exchange_close(unlink_name=rank == 0)
 
     if rank == 0:
         full = op.Oracle()
