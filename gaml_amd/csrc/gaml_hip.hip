@@ -1071,7 +1071,7 @@ int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths,
   if (slot < 0) return slot;
   pack_occ(occ, l0, (char*)host);
   if (l0.end > s.occ_arena.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.occ_arena.reserve(l0.end)); }
-  HIP_TRY(c, hipMemcpyAsync(s.occ_arena.p, host, l0.end, hipMemcpyHostToDevice, st));
+  if (int e = stage_upload(c, s.stage, slot, s.occ_arena.p, l0.end, st)) return e;
   if (int e = stage_release(c, s.stage, slot, st)) return e;
   const int64_t n = s.mate.n_local();
   SingleArgs a;
@@ -1211,13 +1211,13 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
     }
     s.uploaded_generation = s.generation;
   }
-  size_t bytes = std::max<size_t>(1, count.size()) * sizeof(int32_t);
+  size_t bytes = align16(std::max<size_t>(1, count.size()) * sizeof(int32_t));  // whole 16-byte units: the copy kernel moves int4s
   void* host = nullptr;
   int slot = stage_acquire(c, s.stage, bytes, &host);
   if (slot < 0) return slot;
   if (!count.empty()) memcpy(host, count.data(), count.size() * sizeof(int32_t));
   if (bytes > s.walk_count.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.walk_count.reserve(bytes)); }
-  HIP_TRY(c, hipMemcpyAsync(s.walk_count.p, host, bytes, hipMemcpyHostToDevice, st));
+  if (int e = stage_upload(c, s.stage, slot, s.walk_count.p, bytes, st)) return e;
   if (int e = stage_release(c, s.stage, slot, st)) return e;
   PacbioArgs a;
   a.rec_off = s.rec_off.as<int>(); a.rec_walk = s.rec_walk.as<int>(); a.rec_logp = s.rec_logp.as<double>();
