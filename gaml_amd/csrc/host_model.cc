@@ -936,31 +936,43 @@ void OccImage::build(size_t n_windows, const PlanView& view, int mate) {
   for (int32_t w : touched_) occ12[w] = Occ12{~0u, ~0u, 0};
   touched_.clear();
   if (++serial_ == 0) { std::fill(stamp_.begin(), stamp_.end(), 0); serial_ = 1; }
-  // how often does each window occur in this path set
-  for (const PathMemo* pm : view.paths)
-    for (const Occ& o : pm->occ[mate]) {
-      if (stamp_[o.wid] != serial_) { stamp_[o.wid] = serial_; cnt_[o.wid] = 0; list_of_[o.wid] = -1; touched_.push_back(o.wid); }
-      cnt_[o.wid]++;
-    }
   multi_off.assign(1, 0);
   multi.clear();
   general_wids.clear();
   pending_.clear();
+  // ONE pass over the occurrences (it used to be a counting pass + a filling pass): a window's first occurrence is
+  // written as a direct entry straight away; a second occurrence moves the first one to the pending list (the entry
+  // holds everything a list entry needs: a filter threshold clamped at -32768 filters like the exact one, positions
+  // are >= 0). list_of_: -1 = direct entry so far, -2 = on the pending list.
   int32_t rank0 = 0;
   for (size_t slot = 0; slot < view.paths.size(); slot++) {
     const PathMemo& pm = *view.paths[slot];
     for (const Occ& o : pm.occ[mate]) {
-      OccQuad q{o.shift, o.min_pos, (int32_t)slot, rank0 + o.rank};
-      // one occurrence that the 8-byte form can hold -> direct entry; anything else -> a list
-      if (cnt_[o.wid] == 1 && q.path < 32767 && q.min_pos <= 32767) { const uint64_t e = occ8_pack(q, false); occ12[o.wid] = Occ12{(uint32_t)e, (uint32_t)(e >> 32), q.rank}; }
-      else pending_.push_back(Pending{o.wid, q});
+      const OccQuad q{o.shift, o.min_pos, (int32_t)slot, rank0 + o.rank};
+      const int32_t w = o.wid;
+      if (stamp_[w] != serial_) {  // first occurrence of this window in this path set
+        stamp_[w] = serial_; cnt_[w] = 1; touched_.push_back(w);
+        if (q.path < 32767 && q.min_pos <= 32767) {  // the 8-byte form can hold it
+          const uint64_t e = occ8_pack(q, false);
+          occ12[w] = Occ12{(uint32_t)e, (uint32_t)(e >> 32), q.rank};
+          list_of_[w] = -1;
+        } else { pending_.push_back(Pending{w, q}); list_of_[w] = -2; }
+        continue;
+      }
+      if (list_of_[w] == -1) {  // second occurrence: the first one leaves its direct entry
+        const Occ12& f = occ12[w];
+        pending_.push_back(Pending{w, OccQuad{(int32_t)f.lo, (int32_t)(int16_t)(f.hi & 0xffff), (int32_t)((f.hi >> 16) & 0x7fff), f.rank}});
+        list_of_[w] = -2;
+      }
+      pending_.push_back(Pending{w, q});
+      cnt_[w]++;
     }
     rank0 += (int32_t)pm.occ[mate].size();
   }
   if (!pending_.empty()) {
     // lists in order of first appearance, entries in visiting (rank) order
     for (const Pending& pe : pending_)
-      if (list_of_[pe.wid] < 0) {
+      if (list_of_[pe.wid] == -2) {
         list_of_[pe.wid] = (int32_t)multi_off.size() - 1;
         multi_off.push_back(multi_off.back() + cnt_[pe.wid]);
         general_wids.push_back(pe.wid);
