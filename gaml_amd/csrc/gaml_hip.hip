@@ -537,22 +537,6 @@ void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>&
 
 int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p, int32_t total_len, hipStream_t st, double* out4) {
   if (int e = prepare_paired_tables(c, s)) return e;
-  // The memo depends on this call's path set only through 2T: when the tables it is built from exist already
-  // (no rebuild since the last memo), its kernel goes out NOW and runs while the host builds the occurrence images.
-  // (A rebuild further down resets lt_two_T; the regular place below then builds it again.)
-  {
-    const double two_T = (double)(2 * (total_len == 0 ? 1 : total_len));
-    if (s.lt_two_T >= 0 && s.lt_two_T != two_T && s.lt_codes > 0 && s.memo.p && s.dev[0].pow_n != 0 && c->knobs[4] == 0) {
-      const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
-      const double* ct = s.combo_tabs.as<double>();
-      const size_t entries = (size_t)s.lt_codes * 49 * s.ins_tab.size();
-      hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
-                         ct, ct + nc * 64, s.tabs.as<double>(), (int)s.ins_tab.size(), ct + 2 * nc * 64, ct + 2 * nc * 64 + nc, s.lt_codes, two_T,
-                         s.memo.as<double2>());
-      HIP_TRY(c, hipGetLastError());
-      s.lt_two_T = two_T;
-    }
-  }
   const double tp0 = now_us();
   prepare_paired_tables_host(c, s, p);  // pass 2 (pass 1 ran in eval_begin)
   const double t_after_host = now_us();
@@ -705,8 +689,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   const double tp2 = now_us();
   c->prof[3] = tp2 - tp1;  // staging memcpy
   c->prof[6] = (double)total;
-  if (int e = stage_upload(c, s.stage, slot, s.occ_arena.p, total, st)) return e;
-  if (int e = stage_release(c, s.stage, slot, st)) return e;
+  // (the arena upload itself goes out further down, in one launch with the memo: prep_kernel)
   // delta pairs: a patch for the pairs whose lists changed in this evaluation (new windows were activated)
   if (!s.dirty_touched.empty()) {
     const int64_t np_all = s.mate[0].n_local();
@@ -847,19 +830,40 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   // memo of floor + log over the values a single-term pair can take; rebuilt only when 2T (or the
   // tables) changed. Floor must be positive for the "no alignment -> floored" shortcut.
   a.memo = nullptr; a.lt_codes = 0;
+  int memo_codes = 0;  // > 0: the memo has to be (re)built for this evaluation
   if (c->knobs[4] == 0 && s.floor_positive && !s.pt.len_combo.empty() && s.ins_tab.size() > 0) {
     const int codes = (int)std::min<size_t>(s.pt.len_combo.size(), 4);
     const size_t entries = (size_t)codes * 49 * s.ins_tab.size();
     if (entries <= ((size_t)1 << 24)) {
       if (s.lt_two_T != a.two_T || s.lt_codes != codes) {
         if (entries * sizeof(double2) > s.memo.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.memo.reserve(entries * sizeof(double2))); }
-        hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
-                           a.pe[0], a.pe[1], a.ins_tab, a.ins_n, a.floor_c, a.logfloor_c, codes, a.two_T, s.memo.as<double2>());
-        HIP_TRY(c, hipGetLastError());
+        memo_codes = codes;
         s.lt_two_T = a.two_T; s.lt_codes = codes;
       }
       a.memo = s.memo.as<double2>(); a.lt_codes = codes;
     }
+  }
+  // per-call tables -> arena and the memo, ONE launch (prep_kernel); odd sizes / knob 8 = 1: hipMemcpyAsync + logterm_kernel
+  {
+    const bool fused = c->knobs[8] != 1 && (total & 15) == 0 && total <= ((size_t)1 << 30);
+    const size_t entries = (size_t)memo_codes * 49 * s.ins_tab.size();
+    if (fused) {
+      const int n16 = (int)(total / 16);
+      const int copy_blocks = std::max(1, std::min(64, (n16 + kBlock - 1) / kBlock));
+      const int memo_blocks = memo_codes ? (int)std::min<size_t>((entries + kBlock - 1) / kBlock, 128) : 0;
+      hipLaunchKernelGGL(prep_kernel, dim3(copy_blocks + memo_blocks), dim3(kBlock), 0, st, (const int4*)s.stage.host[slot].dev,
+                         (int4*)s.occ_arena.p, n16, copy_blocks, a.pe[0], a.pe[1], a.ins_tab, a.ins_n, a.floor_c, a.logfloor_c, memo_codes,
+                         a.two_T, s.memo.as<double2>());
+      HIP_TRY(c, hipGetLastError());
+    } else {
+      if (int e = stage_upload(c, s.stage, slot, s.occ_arena.p, total, st)) return e;
+      if (memo_codes) {
+        hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
+                           a.pe[0], a.pe[1], a.ins_tab, a.ins_n, a.floor_c, a.logfloor_c, memo_codes, a.two_T, s.memo.as<double2>());
+        HIP_TRY(c, hipGetLastError());
+      }
+    }
+    if (int e = stage_release(c, s.stage, slot, st)) return e;
   }
   a.n_dirty = (int)nd;
   const char* delta = (const char*)s.delta_dev.p;
