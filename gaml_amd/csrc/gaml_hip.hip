@@ -672,7 +672,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths,
   // O(records of such windows) per call -- 2.6 ms per call once an annealing run had produced many repeated nodes.)
   const size_t nd = s.dirty.size();
   const double tp1 = now_us();
-  c->prof[2] = tp1 - t_after_host;  // overflow list + occ8
+  c->prof[2] = tp1 - t_after_host;  // layout only (the host-built overflow list is gone)
   void* host = nullptr;
   int slot = stage_acquire(c, s.stage, total, &host);
   if (slot < 0) return slot;

@@ -354,10 +354,9 @@ __device__ __forceinline__ double score_regs(const PairedArgs& a, const RegCands
 }
 
 // Main kernel: one lane per read pair, pairs pre-sorted by record-count class so that a wave is
-// homogeneous; covers the pairs with at most 2 records per mate (slots [0, n_main)). A pair that
-// touches a window occurring several times in the path set is skipped here: the host put it on
-// the overflow list (same rule on both sides: any record, either mate, whose window entry has
-// path >= 0 and rank < 0).
+// homogeneous; covers the pairs with at most 4 records per mate (slots [0, n_main)). A pair that
+// touches a window occurring several times in the path set (any record, either mate, whose window entry
+// carries the general flag / rank < 0) is only NOTED here (gen_bits) and scored by paired_general_kernel.
 constexpr unsigned long long kNone8 = ~0ull;
 constexpr unsigned long long kDirty8 = ~0ull - 1;  // class-0 slot whose records moved to the delta lists
 constexpr int kDirtyWid = -2;                      // same mark in the 16-byte tables

@@ -314,12 +314,13 @@ int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out3);
  * Knob 5 = 1 (gaml_hip_debug_set_knob) forces the host aligner. */
 int gaml_hip_aligner_stats(gaml_hip_ctx* ctx, int64_t* windows, int64_t* candidates, double* microseconds);
 /* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner), [1] thresholds +
- * occurrence tables, [2] overflow list + 8-byte table, [3] staging memcpy, [4] H2D enqueue, [5] kernel launches,
- * [6] bytes uploaded, [7] wait for the device */
+ * occurrence tables, [2] (unused, 0), [3] packing the staging slot, [4] delta uploads, [5] kernel launches (prep kernel:
+ * table copy + memo; scoring kernel), [6] bytes of per-call tables, [7] wait for the device */
 int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
 /* tuning experiments (tools/kbench.py): 0 = compact-path grid cap, 1 = dynamic LDS bytes, 2 = finish mode (1 ticket,
  * 2 finisher kernel), 3 = timing-only ablation, 4 = 1: no floor/log memo, 5 = 1: host window aligner, 6 = 1: no delta list,
- * 7 = 1: always wait with hipStreamSynchronize (no spinning on the pinned partials) */
+ * 7 = 1: always wait with hipStreamSynchronize (no spinning on the pinned partials), 8 = 1: per-call uploads by
+ * hipMemcpyAsync instead of the copy kernels, 11 = 1: two-pairs-per-iteration compact body */
 /* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
  * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
  * number of waves copied. Tuning aid (tools/kernel_timeline.py). */
