@@ -9,6 +9,10 @@
 __global__ __launch_bounds__(256) void copy_k(const int4* src, int4* dst, int n16) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
 }
+__global__ __launch_bounds__(256) void copy_nt_k(const int4* src, int4* dst, int n16) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) { const int4 v = src[i]; int* d = (int*)(dst + i); __builtin_nontemporal_store(v.x, d); __builtin_nontemporal_store(v.y, d + 1); __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3); }
+}
+__global__ void tiny_k(int* p) { if (p[0] == 123456789) p[1] = 1; }
 struct Big { unsigned long long* stamps; int* xcc; int spin_ticks; long pad[72]; };
 template <int LDS>
 __global__ __launch_bounds__(256) void kbig(Big b) {
@@ -45,15 +49,18 @@ int main() {
   hipStream_t s2; hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
   void* dbuf; hipMalloc(&dbuf, 200000); void* hbuf; hipHostMalloc(&hbuf, 200000, 0);
   void* hdev; hipHostGetDevicePointer(&hdev, hbuf, 0);
-  for (int mode = 0; mode < 6; mode++) {
+  for (int mode = 0; mode < 9; mode++) {
     const int spin = 500;
-    printf("mode %d: %s\n", mode, mode == 0 ? "small arguments" : mode == 1 ? "600-byte arguments + 21 KB LDS" : mode == 2 ? "+ a 190 KB H2D copy in front of every launch" : mode == 3 ? "small arguments, H2D copy in front" : mode == 4 ? "600-byte arguments, copy KERNEL (reads pinned host memory) in front" : "600-byte arguments, hipMemcpyAsync on a second stream + event wait");
+    printf("mode %d: %s\n", mode, mode == 0 ? "small arguments" : mode == 1 ? "600-byte arguments + 21 KB LDS" : mode == 2 ? "+ a 190 KB H2D copy in front of every launch" : mode == 3 ? "small arguments, H2D copy in front" : mode == 4 ? "600-byte arguments, copy KERNEL (reads pinned host memory) in front" : mode == 5 ? "600-byte arguments, hipMemcpyAsync on a second stream + event wait" : mode == 6 ? "copy kernel with non-temporal stores in front" : mode == 7 ? "a one-block kernel that writes nothing in front" : "copy kernel with 8 blocks in front");
     std::vector<float> dur, wall;
     for (int it = 0; it < 50; it++) {
       const auto w0 = std::chrono::steady_clock::now();
       Big big{dst, dxc, spin, {}};
       if (mode == 2 || mode == 3) hipMemcpyAsync(dbuf, hbuf, 190000, hipMemcpyHostToDevice, s);
       if (mode == 4) hipLaunchKernelGGL(copy_k, dim3(48), dim3(256), 0, s, (const int4*)hdev, (int4*)dbuf, 190000 / 16);
+      if (mode == 6) hipLaunchKernelGGL(copy_nt_k, dim3(48), dim3(256), 0, s, (const int4*)hdev, (int4*)dbuf, 190000 / 16);
+      if (mode == 7) hipLaunchKernelGGL(tiny_k, dim3(1), dim3(64), 0, s, (int*)dbuf);
+      if (mode == 8) hipLaunchKernelGGL(copy_k, dim3(8), dim3(256), 0, s, (const int4*)hdev, (int4*)dbuf, 190000 / 16);
       if (mode == 5) { hipMemcpyAsync(dbuf, hbuf, 190000, hipMemcpyHostToDevice, s2); hipEventRecord(ec, s2); hipStreamWaitEvent(s, ec, 0); }
       if (mode == 0 || mode == 3) hipExtLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, s, e0, e1, 0, dst, dxc, spin);
       else hipExtLaunchKernelGGL(kbig<1>, dim3(blocks), dim3(256), 0, s, e0, e1, 0, big);
