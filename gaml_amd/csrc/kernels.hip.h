@@ -578,13 +578,12 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
 constexpr int kPairZero = -1, kPairOther = -(1 << 20);
 // compact_prep without branches, on the 32-bit halves of the 8-byte record / occurrence words (the scoring kernel
 // is issue-bound at cfg3: the branchy 64-bit form was 156 instructions per pair, a third of a wave's lifetime)
-__device__ __forceinline__ int compact_state(const PairedArgs& a, uint2 r1, uint2 r2, uint2 o1, uint2 o2, unsigned lc, bool in_range,
-                                             bool& skip) {
+__device__ __forceinline__ int compact_state(const PairedArgs& a, uint2 r1, uint2 r2, uint2 o1, uint2 o2, unsigned lc, uint32_t l12,
+                                             bool in_range, bool& skip) {
   const bool v1 = r1.y != ~0u, v2 = r2.y != ~0u;           // a record (not kNone8 / kDirty8)
   const bool w1 = v1 & (o1.y != ~0u), w2 = v2 & (o2.y != ~0u);  // ... whose window occurs in this path set
   const bool here = in_range & !(r1.y == ~0u && r1.x == 0xfffffffeu);  // a pair, and not a dirty slot (those: paired_delta_body)
   skip = here & ((w1 & ((int)o1.y < 0)) | (w2 & ((int)o2.y < 0)));  // a window that needs the general path
-  const uint32_t l12 = a.len_combo[lc];
   const int L1 = l12 & 0xffff, L2 = l12 >> 16;
   const int p1 = (int)(__funnelshift_r(r1.x, r1.y, 24) & 0xfffffffu), p2 = (int)(__funnelshift_r(r2.x, r2.y, 24) & 0xfffffffu);
   const int x = p1 + (int)o1.x, y = p2 + (int)o2.x;
@@ -602,7 +601,9 @@ __device__ __forceinline__ int compact_state(const PairedArgs& a, uint2 r1, uint
   return state;
 }
 
-template <bool GEN, bool TL = false>
+// ONE: every pair has the same length combination (n_codes == 1, the usual case): no length-code loads, no LDS tables --
+// the combination and its log-floor are two uniform values.
+template <bool GEN, bool TL = false, bool ONE = false>
 __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb, double& lsum, int& zeros) {
   const unsigned stride = (unsigned)a.blocks0 * kBlock, n0 = (unsigned)a.n0;
   unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
@@ -614,13 +615,15 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
   const char* const occ1 = (const char*)a.occ12[1];
   const char* const memo = (const char*)a.memo;
   char* const probs = (char*)a.probs;
+  const uint32_t l12_one = ONE ? a.len_combo[0] : 0u;
+  const double logfloor_one = ONE ? a.logfloor_c[0] : 0.0;
   for (unsigned base = (unsigned)lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
     uint2 r1[4], r2[4], o1[4], o2[4];
     unsigned lc[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
-      r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); lc[k] = a.len_code[ic];
+      r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); lc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
     }
     GAML_STAMP(2, r1[0].x ^ r1[1].x ^ r1[2].x ^ r1[3].x ^ r2[0].x ^ r2[3].x)
 #pragma unroll
@@ -635,7 +638,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       bool skip;
-      state[k] = compact_state(a, r1[k], r2[k], o1[k], o2[k], lc[k], base + k * stride < n0, skip);
+      state[k] = compact_state(a, r1[k], r2[k], o1[k], o2[k], lc[k], ONE ? l12_one : a.len_combo[lc[k]], base + k * stride < n0, skip);
       skip_bits |= (unsigned)skip << k;
     }
     double2 m[4];
@@ -660,7 +663,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
       } else if (state[k] > kPairOther) {  // as finish_read_compact(acc = 0)
         __builtin_nontemporal_store(0.0, out);
         zeros++;
-        lsum += a.logfloor_c[kPairZero - state[k]];
+        lsum += ONE ? logfloor_one : a.logfloor_c[kPairZero - state[k]];
       } else other |= state[k] == kPairOther && !((skip_bits >> k) & 1u);
     }
     GAML_STAMP(5, 0u)
@@ -802,19 +805,23 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
   unsigned long long* tl = ABL == 8 ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
   if (ABL == 8 && (threadIdx.x & 63) == 0) { tl[0] = wall_clock64(); tl[7] = lb < a.blocks0 ? 0 : (lb < a.blocks01 ? 1 : 2); }
   if (lb < a.blocks0) {
-    // the per-length-combination tables of the compact class (<= 256 entries each) are looked up once or twice
-    // per pair, each time behind another load: from LDS they cost an LDS access instead of an L2 round trip
-    __shared__ uint32_t sh_combo[256];
-    __shared__ double sh_floor[256], sh_logfloor[256];
-    for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_floor[k] = a.floor_c[k]; sh_logfloor[k] = a.logfloor_c[k]; }
-    __syncthreads();
-    PairedArgs b = a;
-    b.len_combo = sh_combo; b.floor_c = sh_floor; b.logfloor_c = sh_logfloor;
-    if (ABL == 8 && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
     const bool wide = a.memo && !a.cov_bits && a.wide4 == 0;  // block-uniform: memo present, no coverage marks to set
-    if (ABL == 8) paired_compact4_body<GEN, true>(b, lb, lsum, zeros);
-    else if ((ABL == 0 || ABL == 5) && wide) paired_compact4_body<GEN>(b, lb, lsum, zeros);
-    else paired_compact_body<ABL, GEN>(b, lb, lsum, zeros);
+    if ((ABL == 0 || ABL == 5) && wide && a.n_codes == 1) {
+      paired_compact4_body<GEN, false, true>(a, lb, lsum, zeros);  // one length combination: no tables, no barrier
+    } else {
+      // the per-length-combination tables of the compact class (<= 256 entries each) are looked up once or twice
+      // per pair, each time behind another load: from LDS they cost an LDS access instead of an L2 round trip
+      __shared__ uint32_t sh_combo[256];
+      __shared__ double sh_floor[256], sh_logfloor[256];
+      for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_floor[k] = a.floor_c[k]; sh_logfloor[k] = a.logfloor_c[k]; }
+      __syncthreads();
+      PairedArgs b = a;
+      b.len_combo = sh_combo; b.floor_c = sh_floor; b.logfloor_c = sh_logfloor;
+      if (ABL == 8 && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
+      if (ABL == 8) paired_compact4_body<GEN, true>(b, lb, lsum, zeros);
+      else if ((ABL == 0 || ABL == 5) && wide) paired_compact4_body<GEN>(b, lb, lsum, zeros);
+      else paired_compact_body<ABL, GEN>(b, lb, lsum, zeros);
+    }
   } else if (lb < a.blocks01) paired_regs_body<2, ABL, GEN>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
   else if (lb < a.blocks012) paired_regs_body<4, ABL, GEN>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
   else paired_delta_body(a, lb - a.blocks012, a.main_blocks - a.blocks012, lsum, zeros);
