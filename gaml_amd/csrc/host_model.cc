@@ -783,6 +783,10 @@ void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_re
 }
 
 void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) {
+  static const bool trace_bpt = getenv("GAML_HIP_TRACE_HOST") != nullptr;
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_stage[8]; int n_stage = 0;
+  t_stage[n_stage++] = now_ms();
   const int64_t n = a.n_local();
   const ShortMate* mates[2] = {&a, &b};
   // per read: record count over ACTIVE windows, and the single record when there is exactly one
@@ -804,6 +808,7 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
       }
     }
   });
+  t_stage[n_stage++] = now_ms();
   // length combos
   std::unordered_map<uint32_t, int32_t> combo_id;
   out.len_combo.clear();
@@ -840,6 +845,7 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
     if (cl[i] != 0) return nw1 + cl[i];
     return one[0][i] == kNoRec8 ? nw1 - 1 : (uint32_t)(one[0][i] & 0xffffff);
   };
+  t_stage[n_stage++] = now_ms();
   std::vector<int32_t> order(n), tmp(n);
   {
     std::vector<int32_t> cnt(nw2 + 1, 0);
@@ -853,6 +859,7 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
     for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
     for (int64_t i = 0; i < n; i++) order[cnt[key1(tmp[i])]++] = tmp[i];
   }
+  t_stage[n_stage++] = now_ms();
   for (int c = 0; c < 4; c++) out.class_count[c] = 0;
   out.slot_of_read.assign(n, 0);
   out.read_of_slot.assign(n, 0);
@@ -873,6 +880,7 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
   });
   out.len12.resize(n - n0);
   for (int64_t s = n0; s < n; s++) out.len12[s - n0] = combo_of(order[s]);
+  t_stage[n_stage++] = now_ms();
   // 16-byte tables of the remaining slots, indexed slot - n0
   std::vector<int32_t> slot16(n, -1);
   for (int64_t s = n0; s < n; s++) slot16[order[s]] = (int32_t)(s - n0);
@@ -918,6 +926,10 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
       }
     }
   });
+  t_stage[n_stage++] = now_ms();
+  if (trace_bpt)
+    fprintf(stderr, "build_pair_tables: per-read counts %.1f ms, length codes + classes %.1f, two counting sorts %.1f, compact tables %.1f, 16-byte tables %.1f\n",
+            t_stage[1] - t_stage[0], t_stage[2] - t_stage[1], t_stage[3] - t_stage[2], t_stage[4] - t_stage[3], t_stage[5] - t_stage[4]);
 }
 
 static inline uint64_t occ8_pack(const OccQuad& q, bool general) {
