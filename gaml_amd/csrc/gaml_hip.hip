@@ -1426,13 +1426,53 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
   }
   if (m.pool.capacity() < m.pool.size() + ok.size())  // one growth step for the whole batch -- geometric: an exact reserve per
     m.pool.reserve(std::max(m.pool.size() + ok.size(), m.pool.capacity() + m.pool.capacity() / 2));  // small batch copied the 45 MB pool every time
-  std::vector<gaml_aligment> recs;
-  for (int k = 0; k < nw; k++) {
-    recs.clear();
-    for (int64_t at = wstart[k]; at < wstart[k + 1]; at++)
-      if (at == wstart[k] || ok[at].pos != ok[at - 1].pos || ok[at].read != ok[at - 1].read)
-        recs.push_back(gaml_aligment{ok[at].pos, ok[at].edit, ok[at].read, ok[at].strand});
-    m.finalize_window(m.pending[k], recs);
+  if (ok.size() >= (size_t)200000) {
+    // large batch (the cold first evaluation files ~2.8 M records): count the surviving records per window, then fill the
+    // pool segment and the window headers on a few threads (windows are independent; same result as the loop below)
+    const int n_threads = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<int> cut(n_threads + 1, nw);
+    cut[0] = 0;
+    for (int t = 1, k = 0; t < n_threads; t++) {  // contiguous window ranges of about equal hit counts
+      const int64_t target = wstart[nw] * t / n_threads;
+      while (k < nw && wstart[k + 1] <= target) k++;
+      cut[t] = k;
+    }
+    std::vector<int64_t> ustart(nw + 1, 0);
+    auto survives = [&](int k, int64_t at) { return at == wstart[k] || ok[at].pos != ok[at - 1].pos || ok[at].read != ok[at - 1].read; };
+    auto run = [&](auto fn) {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < n_threads; t++) pool.emplace_back(fn, cut[t], cut[t + 1]);
+      for (auto& th : pool) th.join();
+    };
+    run([&](int k0, int k1) {
+      for (int k = k0; k < k1; k++) { int64_t u = 0; for (int64_t at = wstart[k]; at < wstart[k + 1]; at++) u += survives(k, at); ustart[k + 1] = u; }
+    });
+    for (int k = 0; k < nw; k++) ustart[k + 1] += ustart[k];
+    const size_t base = m.pool.size();
+    m.pool.resize(base + (size_t)ustart[nw]);
+    run([&](int k0, int k1) {
+      for (int k = k0; k < k1; k++) {
+        Window& win = m.wins[m.pending[k]];  // as ShortMate::finalize_window
+        gaml_aligment* dst = m.pool.data() + base + ustart[k];
+        int32_t max_pos = INT_MIN;
+        for (int64_t at = wstart[k]; at < wstart[k + 1]; at++)
+          if (survives(k, at)) { *dst++ = gaml_aligment{ok[at].pos, ok[at].edit, ok[at].read, ok[at].strand}; max_pos = std::max(max_pos, ok[at].pos); }
+        win.first = (int64_t)(base + ustart[k]);
+        win.count = (int32_t)(ustart[k + 1] - ustart[k]);
+        win.max_pos = max_pos;
+        win.global_max_pos = max_pos;
+        win.pending = false;
+      }
+    });
+  } else {
+    std::vector<gaml_aligment> recs;
+    for (int k = 0; k < nw; k++) {
+      recs.clear();
+      for (int64_t at = wstart[k]; at < wstart[k + 1]; at++)
+        if (at == wstart[k] || ok[at].pos != ok[at - 1].pos || ok[at].read != ok[at - 1].read)
+          recs.push_back(gaml_aligment{ok[at].pos, ok[at].edit, ok[at].read, ok[at].strand});
+      m.finalize_window(m.pending[k], recs);
+    }
   }
   m.pending.clear();
   c->aln_windows += nw;

@@ -225,11 +225,41 @@ namespace {
 // run fn(lo, hi) over [0, n) on a few host threads (ranges are disjoint; small inputs stay on the caller)
 template <class F>
 void parallel_ranges(int64_t n, F fn) {
-  const int nt = n < (1 << 16) ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+  const int nt = n < (1 << 16) ? 1 : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
   if (nt == 1) { fn((int64_t)0, n); return; }
   std::vector<std::thread> pool;
   for (int t = 0; t < nt; t++) pool.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
   for (auto& th : pool) th.join();
+}
+// std::sort of a large vector on a few threads: sorted chunks, then rounds of pairwise merges (same result as
+// std::sort for a strict weak order over distinct elements; equal elements may end up in another order)
+template <class T>
+void parallel_sort(std::vector<T>& v) {
+  const size_t n = v.size();
+  unsigned nt = n < (1u << 17) ? 1u : std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+  while (nt & (nt - 1)) nt &= nt - 1;  // a power of two
+  if (nt <= 1) { std::sort(v.begin(), v.end()); return; }
+  std::vector<size_t> cut(nt + 1);
+  for (unsigned t = 0; t <= nt; t++) cut[t] = n * t / nt;
+  {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; t++) pool.emplace_back([&v, &cut, t] { std::sort(v.begin() + cut[t], v.begin() + cut[t + 1]); });
+    for (auto& th : pool) th.join();
+  }
+  std::vector<T> buf(n);
+  std::vector<T>* src = &v;
+  std::vector<T>* dst = &buf;
+  for (unsigned width = 1; width < nt; width *= 2) {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; t += 2 * width)
+      pool.emplace_back([src, dst, &cut, t, width] {
+        std::merge(src->begin() + cut[t], src->begin() + cut[t + width], src->begin() + cut[t + width], src->begin() + cut[t + 2 * width],
+                   dst->begin() + cut[t]);
+      });
+    for (auto& th : pool) th.join();
+    std::swap(src, dst);
+  }
+  if (src != &v) v.swap(*src);
 }
 template <class F>
 void parallel_mates(bool parallel, F fn) {  // fn(0) and fn(1) touch different arrays
@@ -298,7 +328,7 @@ void ShortMate::build_index() {
     index_read_len = lens[i];
   }
   const auto t2 = std::chrono::steady_clock::now();
-  std::sort(keyed.begin(), keyed.end());
+  parallel_sort(keyed);
   if (trace) fprintf(stderr, "build_index: hash %.0f ms, gather %.0f ms, sort %.0f ms\n", std::chrono::duration<double, std::milli>(t1 - t0h).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
   bucket_hash.clear(); bucket_off.clear(); bucket_reads.clear();
