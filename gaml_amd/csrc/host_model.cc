@@ -877,18 +877,26 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
   };
   t_stage[n_stage++] = now_ms();
   std::vector<int32_t> order(n), tmp(n);
-  {
-    std::vector<int32_t> cnt(nw2 + 1, 0);
-    for (int64_t i = 0; i < n; i++) cnt[key2((int32_t)i) + 1]++;
-    for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
-    for (int64_t i = 0; i < n; i++) tmp[cnt[key2((int32_t)i)]++] = (int32_t)i;
-  }
-  {
-    std::vector<int32_t> cnt(nw1 + 6, 0);
-    for (int64_t i = 0; i < n; i++) cnt[key1(tmp[i]) + 1]++;
-    for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
-    for (int64_t i = 0; i < n; i++) order[cnt[key1(tmp[i])]++] = tmp[i];
-  }
+  // one stable counting pass on a few threads: thread t counts and later scatters the t-th contiguous part of the input
+  // (offsets are prefix sums over (key, thread), so equal keys keep their input order)
+  auto counting_pass = [&](uint32_t n_keys, auto key_of_pos, auto item_of_pos, std::vector<int32_t>& dst) {
+    const int nt = n < (1 << 16) ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<int64_t>> cnt(nt, std::vector<int64_t>(n_keys, 0));
+    auto part = [&](int t) { return std::pair<int64_t, int64_t>(n * t / nt, n * (t + 1) / nt); };
+    auto run = [&](auto fn) {
+      if (nt == 1) { fn(0); return; }
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nt; t++) pool.emplace_back(fn, t);
+      for (auto& th : pool) th.join();
+    };
+    run([&](int t) { auto [lo, hi] = part(t); for (int64_t i = lo; i < hi; i++) cnt[t][key_of_pos(i)]++; });
+    int64_t at = 0;
+    for (uint32_t key = 0; key < n_keys; key++)
+      for (int t = 0; t < nt; t++) { const int64_t c = cnt[t][key]; cnt[t][key] = at; at += c; }
+    run([&](int t) { auto [lo, hi] = part(t); for (int64_t i = lo; i < hi; i++) dst[cnt[t][key_of_pos(i)]++] = item_of_pos(i); });
+  };
+  counting_pass(nw2 + 1, [&](int64_t i) { return key2((int32_t)i); }, [&](int64_t i) { return (int32_t)i; }, tmp);
+  counting_pass(nw1 + 6, [&](int64_t i) { return key1(tmp[i]); }, [&](int64_t i) { return tmp[i]; }, order);
   t_stage[n_stage++] = now_ms();
   for (int c = 0; c < 4; c++) out.class_count[c] = 0;
   out.slot_of_read.assign(n, 0);
