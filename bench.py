@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s scored by the MI355X likelihood path (BASELINE.json metric).
 
-A STEP is one ProbCalculator::CalcProb over the whole resident read shard: host builds the
-window-occurrence tables for the path set, the GPU rescoring every read pair from scratch
-(paired_score_kernel), the value comes back to the host (CalcProb is a blocking call in the
-reference, gaml.cc:284). Consecutive steps score DIFFERENT path sets (the genome walk broken at
-rotating points, as simulated-annealing moves do) so nothing can be reused from the previous
-step; the alignment-window cache is warm (all windows aligned before the timed region), which
-is the "warm from-scratch" evaluation SURVEY.md 8d defines as what the kernels replace.
+A STEP is one ProbCalculator::CalcProb over the whole read set: the host builds the window-occurrence tables for the
+path set, the GPU(s) rescore every read pair from scratch (paired_score_kernel), the value comes back to the host
+(CalcProb is a blocking call in the reference, gaml.cc:284). Consecutive steps score DIFFERENT path sets (the genome
+walk broken at rotating points, as simulated-annealing moves do) so nothing can be reused from the previous step; the
+alignment-window cache is warm (all windows aligned before the timed region): the "warm from-scratch" evaluation
+SURVEY.md 8d defines as what the kernels replace.
 
-N > 1: one process per GPU (torch.distributed / RCCL). Every rank holds its own shard of
-reads (weak scaling: 833,333 pairs per GPU), no data-path collective, one all-reduce(sum) of
-the 4 partial doubles per step.
+N = 1: BASELINE config 3's read set (5 Mbp, 833,333 pairs 2x150, insert 300+-30) on one GPU -- the configuration the
+north star's target is quoted on.
+N > 1 (one process per GPU, torch.distributed.run): BASELINE config 3 as stated -- the SAME 833,333 pairs (same seed as
+N = 1) split over the N GPUs by gaml_hip_set_shard ("scaling": "strong"), one in-library RCCL all-reduce(sum) of 4 f64
+per step on the library's stream (gaml_hip_comm_init_rank; the id travels over torch.distributed). `--scaling weak`
+(833,333 fresh pairs per GPU) and the other exchanges (GAML_BENCH_EXCHANGE=rccl-torch|shm) are explicitly labelled
+alternatives.
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
+import gc
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,7 +35,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
+
+
+def source_hash() -> str:
+    """What the committed rocprofv3 summaries must have been taken on to describe this run: the kernel sources + this file."""
+    h = hashlib.sha256()
+    for rel in ("bench.py", "gaml_amd/csrc/kernels.hip.h", "gaml_amd/csrc/gaml_hip.hip", "gaml_amd/csrc/ctx.hip.h",
+                "gaml_amd/csrc/multi.hip", "gaml_amd/csrc/host_model.cc", "gaml_amd/csrc/host_model.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def path_variants(walk, k=8):
@@ -43,31 +60,90 @@ def path_variants(walk, k=8):
     return out
 
 
-def cpu_baseline(gb, go, b1, o1, b2, o2, sample_pairs, read_len, variants, budget_s=10.0):
-    """Oracle (CPU restatement of the reference, 1 thread) timed on a bounded sample of the same
-    workload: the first `sample_pairs` pairs against the full graph, warm from-scratch CalcProb
-    (fresh ScoringState, window cache hot)."""
+def cpu_baseline(gb, go, b1, o1, b2, o2, pairs, read_len, variants, cfg, budget_s=10.0):
+    """Oracle (CPU restatement of the reference, 1 thread) on the same workload: `pairs` pairs (default: all of them)
+    against the full graph; one cold pass per path set (aligns every window), then warm from-scratch CalcProb calls
+    (fresh ScoringState, window cache hot -- what the GPU step replaces) for about `budget_s` seconds."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as op
     orc = op.Oracle()
     orc.set_graph(gb, go)
-    nb = sample_pairs * read_len
-    rs = orc.add_paired(b1[:nb], o1[:sample_pairs + 1], b2[:nb], o2[:sample_pairs + 1], 0.01, op.paired_cfg(300.0, 30.0))
+    nb = pairs * read_len
+    orc.add_paired(b1[:nb], o1[:pairs + 1], b2[:nb], o2[:pairs + 1], 0.01, op.paired_cfg(*cfg))
     t0 = time.time()
     vals = [orc.calc_prob(v, fresh=True)[0] for v in variants]  # cold: aligns every window
     cold_s = time.time() - t0
     n_eval, t_warm = 0, 0.0
-    while t_warm < budget_s and n_eval < 2000:  # ~10 s of CPU work (+ the cold pass): a bounded sample, not the full set
+    while (t_warm < budget_s or n_eval < 3) and n_eval < 2000:
         v = variants[n_eval % len(variants)]
         t0 = time.time()
         orc.calc_prob(v, fresh=True)
         t_warm += time.time() - t0
         n_eval += 1
-    reads_per_s = 2.0 * sample_pairs * n_eval / t_warm
-    return {"value": reads_per_s, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": f"first {sample_pairs} pairs of rank 0's reads vs the full graph, {n_eval} warm from-scratch "
-                      f"CalcProb calls ({t_warm:.1f} s); cold pass incl. window alignment {cold_s:.1f} s "
-                      f"({2.0 * sample_pairs * len(variants) / cold_s:.0f} reads/s)"}, vals, rs, orc
+    return {"value": 2.0 * pairs * n_eval / t_warm, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": f"{pairs} pairs vs the full graph, {n_eval} warm from-scratch CalcProb calls in {t_warm:.1f} s "
+                      f"({1e3 * t_warm / n_eval:.0f} ms each); cold pass over the {len(variants)} path sets incl. window "
+                      f"alignment {cold_s:.1f} s"}, vals
+
+
+def sa_pattern(ctx, rs, g, iters, api, synth):
+    """BASELINE config 5's call pattern on this GPU (untimed for the headline): the reference's start state, then
+    `iters` edited path sets, one blocking CalcProb each; new junction windows get aligned on the fly."""
+    start, seq = synth.sa_sequence(g, iters)
+    flat = [api.FlatPaths(p) for p in seq]
+    t0 = time.perf_counter()
+    ctx.calc_prob(start)
+    first_s = time.perf_counter() - t0
+    a0 = ctx.aligner_stats()
+    t_stats0 = ctx.debug_table_stats(rs)
+    per = np.zeros(len(flat))
+    gc.disable()
+    t0 = time.perf_counter()
+    for i, f in enumerate(flat):
+        t1 = time.perf_counter()
+        ctx.score(f)
+        per[i] = time.perf_counter() - t1
+    total = time.perf_counter() - t0
+    gc.enable()
+    a1 = ctx.aligner_stats()
+    t_stats1 = ctx.debug_table_stats(rs)
+    per *= 1e6
+    return {"iterations": iters, "paths_at_start": len(start), "total_s": total, "first_call_cold_s": first_s,
+            "us_median": float(np.median(per)), "us_p90": float(np.percentile(per, 90)), "us_p99": float(np.percentile(per, 99)),
+            "us_max": float(per.max()), "table_rebuilds": t_stats1["full_rebuilds"] - t_stats0["full_rebuilds"],
+            "delta_updates": t_stats1["delta_updates"] - t_stats0["delta_updates"],
+            "windows_aligned": a1["windows"] - a0["windows"], "aligner_ms": (a1["us"] - a0["us"]) * 1e-3,
+            "recipe": "gaml_amd.synth.sa_sequence(seed 7): BreakPath / join / reverse / LocalChange / duplicate / trim edits, 60 % accepted"}
+
+
+def inproc_child(args):
+    """`--inproc-devices 0,1,..`: ONE process, one context over those devices (gaml_hip_create_multi) -- what a gaml.cc
+    linked against the adapter header runs. Same read set and steps as the headline; prints its own JSON line."""
+    from gaml_amd import api, synth
+    devs = [int(x) for x in args.inproc_devices.split(",")]
+    wl = synth.WORKLOADS[args.workload]
+    genome = synth.make_genome(wl.genome_len, wl.seed)
+    g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
+    pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
+    ctx = api.Context(devices=devs)
+    ctx.set_graph(*g.packed())
+    ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    variants = [api.FlatPaths(v) for v in path_variants(synth.genome_walk(g))]
+    out = {"devices": devs, "shards": ctx.num_shards(), "note": ctx.last_error()}
+    for mode in (["rccl", "host"] if ctx.exchange() == "rccl" else ["host"]):
+        ctx.set_exchange(mode)
+        vals = [ctx.score(v) for v in variants]
+        ctx.compact_tables()
+        for i in range(args.warmup + 1):
+            ctx.score(variants[i % len(variants)])
+        gc.disable()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ctx.score(variants[i % len(variants)])
+        el = time.perf_counter() - t0
+        gc.enable()
+        out[mode] = {"ms_per_step": 1e3 * el / args.steps, "reads_per_sec": 2.0 * wl.n_pairs * args.steps / el, "log_likelihood": vals[0]}
+    print("INPROC " + json.dumps(out), flush=True)
 
 
 def main():
@@ -76,11 +152,22 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "tiny"])
-    ap.add_argument("--cpu-sample-pairs", type=int, default=100_000)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = BASELINE config 3's read set split over the GPUs (default); weak = a fresh read set of the same size per GPU")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs the CPU baseline scores (0 = the whole read set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (process group, side stream, "
-                    "all-reduce) even with one rank -- rehearsal of the N > 1 path on a 1-GPU box")
+    ap.add_argument("--no-sa", action="store_true", help="skip the annealing-pattern block (N = 1)")
+    ap.add_argument("--no-extras", action="store_true", help="timed region only (no kernel-timing pass, batch or annealing block): "
+                    "what the rocprofv3 --pmc passes run, so that the last --steps dispatches are the timed steps")
+    ap.add_argument("--sa-iters", type=int, default=1000)
+    ap.add_argument("--kernel-samples", type=int, default=256, help="launches of the separate kernel-timing pass")
+    ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (process group, communicator, all-reduce) "
+                    "with one rank -- rehearsal on a 1-GPU box")
+    ap.add_argument("--no-inproc", action="store_true", help="N > 1: skip the single-process multi-device run on rank 0")
+    ap.add_argument("--inproc-devices", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.inproc_devices:
+        return inproc_child(args)
 
     import torch
     import torch.distributed as dist
@@ -89,13 +176,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    # Rehearsal of N > 1 on a box with fewer GPUs than ranks (never used by the driver): GAML_BENCH_SHARE_GPU=1
-    # puts every rank on cuda:0 and runs the collectives over gloo (RCCL refuses two ranks on one device).
+    # Rehearsal of N > 1 on a box with fewer GPUs than ranks (never used by the driver): GAML_BENCH_SHARE_GPU=1 puts every
+    # rank on cuda:0; RCCL refuses two ranks on one device, so the collectives run over gloo / shared memory there.
     share_gpu = os.environ.get("GAML_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
@@ -110,72 +196,82 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = synth.WORKLOADS[args.workload]
-    # same genome + graph on every rank; each rank draws its own reads (its shard of the N x larger read set)
+    strong = args.scaling == "strong"
     genome = synth.make_genome(wl.genome_len, wl.seed)
     g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
-    pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed + 1000 * rank)
+    # strong: every rank draws the SAME read set (the N = 1 seed) and keeps its contiguous share; weak: its own set
+    read_seed = wl.seed if (strong or world == 1) else wl.seed + 1000 * rank
+    pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, read_seed)
     gb, go = g.packed()
     b1, o1 = synth.pack_reads(pr.mate1)
     b2, o2 = synth.pack_reads(pr.mate2)
     walk = synth.genome_walk(g)
-    variants = path_variants(walk)
+    variants_py = path_variants(walk)
+    cfg = (wl.insert_mean, wl.insert_std)
 
-    ctx = api.Context(device=local_rank, presharded=world)  # every rank hands over only its own reads
+    if strong and world > 1:
+        ctx = api.Context(device=local_rank, rank=rank, world=world)  # gaml_hip_set_shard: reads [N r/w, N (r+1)/w)
+    else:
+        ctx = api.Context(device=local_rank, presharded=world)  # every rank hands over only its own reads
     ctx.set_graph(gb, go)
-    rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), b1, o1, b2, o2)
-    n_pairs_rank = wl.n_pairs
+    rs = ctx.add_paired(api.paired_cfg(*cfg), b1, o1, b2, o2)
+    total_pairs = wl.n_pairs if (strong or world == 1) else wl.n_pairs * world
 
-    # N > 1: gaml_amd.dist.ShardedScorer runs the kernels on a torch side stream (a real, non-null HIP
-    # stream) so that the all-reduce and the D2H copy are ordered after them
-    scorer = None
-    in_loop = [False]
+    # ---- the exchange of the N > 1 path
+    scorer, exchange, fallback = None, "none", None
     if use_dist:
-        from gaml_amd.dist import ShardedScorer
-        # one node (the driver's launch): the partials are summed through shared memory after a blocking evaluation;
-        # GAML_BENCH_EXCHANGE=rccl keeps them on the device (finisher kernel -> RCCL all-reduce -> fetch)
-        single_node = int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world
-        exchange = os.environ.get("GAML_BENCH_EXCHANGE", "shm" if single_node else "rccl")
-        scorer = ShardedScorer(ctx, host_exchange=("/gaml_bench_%s" % os.environ.get("MASTER_PORT", "0")) if exchange == "shm" else None)
+        want = os.environ.get("GAML_BENCH_EXCHANGE", "shm" if share_gpu else "rccl")
+        if want == "rccl":
+            # the library's own communicator: rank 0 makes the id, torch.distributed carries the 128 bytes
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8)
+                if rank == 0:
+                    idt = torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8).clone()
+                if not share_gpu:
+                    idt = idt.cuda()
+                dist.broadcast(idt, src=0)
+                ctx.comm_init_rank(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                exchange = "rccl"
+            except Exception as e:  # keep the run alive on the well-trodden path, and say so
+                fallback = repr(e)
+                want = "rccl-torch"
+        if want in ("rccl-torch", "shm", "gloo"):
+            from gaml_amd.dist import ShardedScorer
+            shm = want == "shm"
+            scorer = ShardedScorer(ctx, host_exchange=("/gaml_bench_%s" % os.environ.get("MASTER_PORT", "0")) if shm else None)
+            exchange = "shm" if shm else ("gloo" if share_gpu else "rccl-torch")
     torch.cuda.synchronize()
 
-    def step(paths):
+    in_loop = [False]
+
+    def step(fp):
         if scorer is not None:
-            if in_loop[0]:  # the side stream is current: the lean form (cold path: maxima exchange; every step: one all-reduce(sum) of 4 f64)
-                return scorer.score(paths), None
-            prob, zeros, _ = scorer.calc_prob(paths)
-            return prob, zeros
-        # ONE ABI call, like the reference's CalcProb(paths): registration, kernels, the per-block partials
-        # land in pinned host memory, the library adds them up and returns the value (blocking)
-        return ctx.score(paths), None
+            return scorer.score(fp) if in_loop[0] else scorer.calc_prob(fp)[0]
+        # ONE ABI call, like the reference's CalcProb(paths): registration, kernels, (N > 1: the RCCL all-reduce on the
+        # library's stream,) the value back on the host (blocking)
+        return ctx.score(fp)
 
     # prime: align every window any variant needs (cold path, untimed), then warm-up steps
     t0 = time.time()
-    variants_py = variants
-    variants = [api.FlatPaths(v) for v in variants]  # the ABI's form, built once (as a C++ caller holds it)
-    vals = [step(v)[0] for v in variants]
+    variants = [api.FlatPaths(v) for v in variants_py]  # the ABI's form, built once (as a C++ caller holds it)
+    vals = [step(v) for v in variants]
     ctx.compact_tables()  # steady state: fold what the priming calls aligned into the device tables (the library would after 64 quiet calls)
     step(variants[0])     # ... which happens at the next evaluation: keep it out of the warm-up / timed steps
     prime_s = time.time() - t0
     for i in range(args.warmup):
         step(variants[i % len(variants)])
 
-    ctx.set_event_timing(8)  # every 8th launch: events attached to a dispatch cost ~4 us of host time each
-    ctx.kernel_stats(reset=True)
-    # a step is ~70 us: one generation-2 pass of Python's garbage collector over the interpreter's
-    # (torch-sized) object graph costs ~40 ms, i.e. hundreds of steps -- keep it out of the timed loop
-    import gc
+    # ---- the timed region: exactly --steps steps, no event timing, no garbage collector
     gc.collect()
     gc.disable()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    import contextlib
-    # N > 1: the scorer's side stream is made current once for the whole loop (not once per step)
-    loop_ctx = torch.cuda.stream(scorer.stream) if scorer is not None else contextlib.nullcontext()
-    t0 = time.perf_counter()
+    loop_ctx = torch.cuda.stream(scorer.stream) if (scorer is not None and not scorer._host_exchange) else contextlib.nullcontext()
+    stamps = np.zeros(args.steps + 1)
     last = None
-    stamps = [0.0] * (args.steps + 1)
+    t0 = time.perf_counter()
     stamps[0] = t0
     with loop_ctx:
         in_loop[0] = True
@@ -189,58 +285,109 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    ks = ctx.kernel_stats(reset=True)
-    ctx.set_event_timing(False)
-
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- separate pass: HIP events attached to EVERY scoring dispatch (not part of the throughput number)
+    ks = {"launches": 0, "device_us": 0.0, "algo_bytes": 0.0}
+    if not args.no_extras:
+        ctx.set_event_timing(1)
+        ctx.kernel_stats(reset=True)
+        with loop_ctx:
+            in_loop[0] = True
+            for i in range(args.kernel_samples):
+                step(variants[i % len(variants)])
+            in_loop[0] = False
+        torch.cuda.synchronize()
+        ks = ctx.kernel_stats(reset=True)
+        ctx.set_event_timing(False)
+
+    # ---- N > 1: the sharded value against the unsharded one (rank 0 scores the whole read set on its GPU)
+    ll_delta_n1 = None
+    if use_dist and (strong or world == 1) and not args.no_extras:
+        sharded = [step(v) for v in variants]
+        if rank == 0:
+            c1 = api.Context(device=local_rank)
+            c1.set_graph(gb, go)
+            c1.add_paired(api.paired_cfg(*cfg), b1, o1, b2, o2)
+            whole = [c1.score(v) for v in variants]
+            ll_delta_n1 = max(abs(a - b) / abs(b) for a, b in zip(sharded, whole))
+            c1.close()
+        dist.barrier()
+
+    # ---- N > 1: the same read set through ONE process that owns all N devices (what gaml.cc + the adapter header runs)
+    inproc = None
+    if world > 1 and rank == 0 and not args.no_inproc and not share_gpu:
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--inproc-devices", ",".join(str(i) for i in range(world)),
+                   "--workload", args.workload, "--steps", str(min(args.steps, 1000)), "--warmup", str(min(args.warmup, 50))]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT",
+                                                                    "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("INPROC ")]
+            inproc = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:
+            inproc = {"error": repr(e)}
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
-        total_reads = 2.0 * n_pairs_rank * world
+        total_reads = 2.0 * total_pairs
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_reads * args.steps / elapsed
         launches = max(1, ks["launches"])
         kern_us = ks["device_us"] / launches
         bytes_per_launch = ks["algo_bytes"] / launches
         achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
-        # HBM traffic per launch: not measurable from inside the process; taken from the committed rocprofv3
-        # --pmc passes of this same command (profiles/*pmc_traffic.json), FETCH_SIZE doubled per the guide
-        traffic, traffic_src = None, None
+        # HBM traffic per launch comes from rocprofv3 --pmc passes of this same command (counters cannot be read from
+        # inside the process): only a profile taken on THESE sources counts, otherwise null + traffic_stale
+        traffic, traffic_src, traffic_stale = None, None, None
         try:
             import glob
             f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]
             tj = json.load(open(f))
-            if args.workload == "cfg3":
+            traffic_src = os.path.relpath(f, ROOT)
+            traffic_stale = tj.get("source_hash") != source_hash()
+            if args.workload == "cfg3" and world == 1 and not traffic_stale:
                 traffic = tj["kernels"]["paired_score_kernel"]["hbm_bytes_per_launch"]
-                traffic_src = os.path.relpath(f, ROOT)
         except Exception:
             pass
+        d = np.diff(stamps) * 1e6
         out = {
             "metric": "reads_per_sec_scored", "value": value, "unit": "reads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl.name + f"; {n_pairs_rank} pairs per GPU, whole true genome as 1-2 walks, "
-                                             "8 rotating path sets, window cache warm", "pairs_per_gpu": n_pairs_rank,
-                       "genome_bp": wl.genome_len, "parallelism": f"reads sharded over {world} GPU(s), 1 all-reduce of 32 B/step"
-                       + ("" if scorer is None else (" through shared memory (one node; blocking evaluation per rank)" if scorer._host_exchange else " over RCCL"))},
+            "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl.name + f"; {total_pairs} pairs in all, whole true genome as 1-2 walks, 8 rotating path sets, "
+                                             "window cache warm", "pairs_total": total_pairs, "pairs_per_gpu": total_pairs // world,
+                       "genome_bp": wl.genome_len,
+                       "parallelism": f"reads sharded over {world} GPU(s)" + ("" if not use_dist else
+                                      {"rccl": ", one in-library RCCL all-reduce(sum) of 32 B per step on the scoring stream",
+                                       "rccl-torch": ", one torch.distributed (RCCL) all-reduce of 32 B per step",
+                                       "shm": ", partials summed through POSIX shared memory (one node; blocking evaluation per rank)",
+                                       "gloo": ", gloo all-reduce (rehearsal: ranks share one GPU)"}[exchange])},
+            "exchange": exchange, "rccl_ranks": world if exchange in ("rccl", "rccl-torch") else 0,
+            "ll_rel_delta_vs_n1": ll_delta_n1,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "paired_score_kernel", "kernel_us": kern_us, "algo_bytes_per_launch": bytes_per_launch,
-                         "timing": "HIP events attached to the dispatch (hipExtLaunchKernelGGL, on the launch stream) of every 8th "
-                                   "paired_score_kernel launch of the timed region: the kernel's own begin/end stamps, as in "
-                                   "rocprofv3's kernel trace",
-                         "timed_launches": int(launches),
-                         "traffic_source": traffic_src},
-            "step_us_distribution": (lambda d: {"p50": float(np.percentile(d, 50)), "p90": float(np.percentile(d, 90)),
-                                                "p99": float(np.percentile(d, 99)), "max": float(d.max())})(
-                np.diff(np.array(stamps)) * 1e6),
-            "log_likelihood": last[0], "prime_s": prime_s,
+                         "timing": "HIP events attached to the dispatch (hipExtLaunchKernelGGL, on the launch stream) of EVERY "
+                                   "paired_score_kernel launch of a separate pass after the timed region: the kernel's own begin/end "
+                                   "stamps, as in rocprofv3's kernel trace",
+                         "timed_launches": int(launches), "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "source_hash": source_hash()},
+            "step_us_distribution": {"p50": float(np.percentile(d, 50)), "p90": float(np.percentile(d, 90)),
+                                     "p99": float(np.percentile(d, 99)), "max": float(d.max())},
+            "log_likelihood": last, "prime_s": prime_s,
             "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
             "timing_last_step_us": ctx.last_timing(),
         }
-        if not use_dist:
+        if fallback:
+            out["exchange_fallback_reason"] = fallback
+        if inproc is not None:
+            out["inproc_multi"] = inproc
+        if not use_dist and not args.no_extras:
             # extra, outside the timed region: the same 8 path sets through gaml_hip_calc_prob_batch
             #  -- what a move generator gets that compares several candidate assemblies
             bp = api.BatchPaths(variants_py)
@@ -256,22 +403,29 @@ def main():
             out["batched"] = {"api": "gaml_hip_calc_prob_batch", "sets_per_call": len(variants_py), "calls": calls,
                               "ms_per_set": 1e3 * tb / (calls * len(variants_py)),
                               "reads_per_sec": total_reads * calls * len(variants_py) / tb}
+            if not args.no_sa:
+                out["sa_pattern"] = sa_pattern(ctx, rs, g, args.sa_iters, api, synth)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is taken on rank 0 at N = 1 only
-            sample = min(args.cpu_sample_pairs, n_pairs_rank)
-            cb, cpu_vals, _, _ = cpu_baseline(gb, go, b1, o1, b2, o2, sample, wl.read_len, variants_py)
+            pairs = min(args.cpu_sample_pairs or wl.n_pairs, wl.n_pairs)
+            cb, cpu_vals = cpu_baseline(gb, go, b1, o1, b2, o2, pairs, wl.read_len, variants_py, cfg)
             out["cpu_baseline"] = cb
-            # log-likelihood delta vs the CPU reference restatement on the same sample of reads
-            c2 = api.Context(device=local_rank)
-            c2.set_graph(gb, go)
-            nb = sample * wl.read_len
-            c2.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), b1[:nb], o1[:sample + 1], b2[:nb], o2[:sample + 1])
-            gpu_vals = [c2.calc_prob(v)[0] for v in variants]
+            # log-likelihood delta vs the CPU restatement of the reference on the same reads, every path set
+            if pairs == wl.n_pairs:
+                gpu_vals = vals
+            else:
+                c2 = api.Context(device=local_rank)
+                c2.set_graph(gb, go)
+                nb = pairs * wl.read_len
+                c2.add_paired(api.paired_cfg(*cfg), b1[:nb], o1[:pairs + 1], b2[:nb], o2[:pairs + 1])
+                gpu_vals = [c2.calc_prob(v)[0] for v in variants]
             out["ll_max_rel_delta_vs_cpu"] = max(abs(a - b) / abs(b) for a, b in zip(gpu_vals, cpu_vals))
+            out["ll_delta_pairs"] = pairs
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(out), flush=True)
     if use_dist:
         if scorer is not None:
             scorer.close()  # unlinks the shared-memory name (rank 0)
+        ctx.close()
         dist.destroy_process_group()
 
 

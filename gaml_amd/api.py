@@ -106,6 +106,13 @@ def _load():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.gaml_hip_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.gaml_hip_create_multi.argtypes = [C.POINTER(vp), _i32p, C.c_int32]
+    L.gaml_hip_create_from_env.argtypes = [C.POINTER(vp)]
+    L.gaml_hip_num_shards.argtypes = [vp]
+    L.gaml_hip_set_exchange.argtypes = [vp, C.c_int32]
+    L.gaml_hip_get_exchange.argtypes = [vp]
+    L.gaml_hip_comm_unique_id.argtypes = [vp]
+    L.gaml_hip_comm_init_rank.argtypes = [vp, vp, C.c_int32, C.c_int32]
     L.gaml_hip_destroy.argtypes = [vp]
     L.gaml_hip_destroy.restype = None
     L.gaml_hip_last_error.argtypes = [vp]
@@ -228,14 +235,32 @@ def _flat(paths):
     return flat, offs
 
 
+def comm_unique_id() -> bytes:
+    """128 bytes that rank 0 sends to every other rank before Context.comm_init_rank (ncclGetUniqueId)."""
+    buf = C.create_string_buffer(128)
+    rc = _lib.gaml_hip_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != OK:
+        raise GamlHipError(rc, "gaml_hip_comm_unique_id failed (RCCL not loadable?)")
+    return buf.raw
+
+
 class Context:
     """One graph + its read sets + their device state (one per process / GPU)."""
 
-    def __init__(self, device: int = 0, rank: int = 0, world: int = 1, presharded: int = 1):
+    def __init__(self, device: int = 0, rank: int = 0, world: int = 1, presharded: int = 1, devices=None):
+        """devices: a list of HIP ordinals -> ONE context over that many device shards in this process
+        (gaml_hip_create_multi); every method then acts on the whole read set."""
         self._h = C.c_void_p()
-        rc = _lib.gaml_hip_create(C.byref(self._h), device)
-        if rc != OK:
-            raise GamlHipError(rc, f"gaml_hip_create(device={device}) failed")
+        if devices is not None:
+            devs = np.ascontiguousarray(devices, np.int32)
+            rc = _lib.gaml_hip_create_multi(C.byref(self._h), devs, len(devs))
+            if rc != OK:
+                raise GamlHipError(rc, f"gaml_hip_create_multi(devices={list(devs)}) failed")
+            device = int(devs[0])
+        else:
+            rc = _lib.gaml_hip_create(C.byref(self._h), device)
+            if rc != OK:
+                raise GamlHipError(rc, f"gaml_hip_create(device={device}) failed")
         self.device = device
         if world != 1:
             self._check(_lib.gaml_hip_set_shard(self._h, rank, world))
@@ -261,6 +286,25 @@ class Context:
         if rc < 0:
             raise GamlHipError(rc, _lib.gaml_hip_last_error(self._h).decode())
         return rc
+
+    # ---- several GPUs
+    def num_shards(self) -> int:
+        return _lib.gaml_hip_num_shards(self._h)
+
+    def set_exchange(self, mode: str):
+        """'rccl' (all-reduce on the shards' streams) or 'host' (pinned-host partials summed in rank order)."""
+        self._check(_lib.gaml_hip_set_exchange(self._h, {"host": 0, "rccl": 1}[mode]))
+
+    def exchange(self) -> str:
+        return {0: "host", 1: "rccl"}[self._check(_lib.gaml_hip_get_exchange(self._h))]
+
+    def last_error(self) -> str:
+        return _lib.gaml_hip_last_error(self._h).decode()
+
+    def comm_init_rank(self, comm_id: bytes, rank: int, world: int):
+        """One process per GPU: join the library's RCCL communicator (id from comm_unique_id() of rank 0)."""
+        buf = C.create_string_buffer(bytes(comm_id), 128)
+        self._check(_lib.gaml_hip_comm_init_rank(self._h, C.cast(buf, C.c_void_p), rank, world))
 
     # ---- inputs
     def set_graph(self, bases: np.ndarray, offs: np.ndarray):

@@ -1,0 +1,277 @@
+// ctx.hip.h -- the library context: device / pinned buffers, per-read-set device state, gaml_hip_ctx.
+// Shared by gaml_hip.hip (the C ABI, launches) and multi.hip (several device shards in one process, RCCL).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <atomic>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <chrono>
+#include <climits>
+#include <limits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "aligner.hip.h"
+#include "host_model.h"
+#include "kernels.hip.h"
+#include "pacbio_dp.hip.h"
+#include "internal.h"
+
+
+namespace gaml {
+namespace detail {
+
+inline double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// grow-only device / pinned buffers
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    size_t want = std::max(bytes + bytes / 4, (size_t)256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return (T*)p; }
+};
+struct PinBuf {
+  void* p = nullptr;
+  void* dev = nullptr;  // the same memory as the device sees it
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
+    size_t want = std::max(bytes + bytes / 4, (size_t)4096);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);  // device-visible: kernels read / write it directly
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, p, 0);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
+};
+
+constexpr int kRing = 4;  // staging slots, so that async callers may run ahead of the device
+
+struct Staging {
+  PinBuf host[kRing];
+  hipEvent_t done[kRing] = {};
+  bool armed[kRing] = {};
+  int next = 0;
+};
+
+struct Reducer {  // per read set: partials + ticket + 2-double result
+  DevBuf part_sum, part_zero, ticket, out;
+  hipError_t init() {
+    hipError_t e;
+    if ((e = part_sum.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(double))) != hipSuccess) return e;
+    if ((e = part_zero.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(int))) != hipSuccess) return e;
+    if ((e = ticket.reserve(sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = out.reserve(4 * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMemset(ticket.p, 0, sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMemset(out.p, 0, 4 * sizeof(double))) != hipSuccess) return e;
+    return hipDeviceSynchronize();  // the scoring stream is non-blocking: make the zeroes land first
+  }
+  void release() { part_sum.release(); part_zero.release(); ticket.release(); out.release(); }
+};
+
+struct AlignDev {  // device copies the GPU aligner needs: reads (1 byte per base) + the max-hash index
+  DevBuf reads, read_off, bucket_hash, bucket_off, bucket_reads;
+  bool uploaded = false;
+  void release() { reads.release(); read_off.release(); bucket_hash.release(); bucket_off.release(); bucket_reads.release(); }
+};
+struct AlignScratch {  // per context, grown on demand
+  DevBuf wstr, wins, hbuf, hbuf_off, spans, cands, hits, counters;
+  DevBuf sort_keys, sort_idx, sort_tmp, hits_sorted;  // large batches: hits ordered on the device
+  void release() { wstr.release(); wins.release(); hbuf.release(); hbuf_off.release(); spans.release(); cands.release(); hits.release(); counters.release();
+                   sort_keys.release(); sort_idx.release(); sort_tmp.release(); hits_sorted.release(); }
+};
+
+struct MateDev {
+  DevBuf first, extra, pows;  // pows = mismatch_pow | match_pow
+  AlignDev aln;
+  uint64_t uploaded_generation = ~0ull;
+  size_t pow_n = 0;
+};
+
+struct PairedSet {
+  gaml_paired_cfg cfg;
+  ShortMate mate[2];
+  PairTables pt;                      // device order + compact / 16-byte record tables (cold path)
+  MateDev dev[2];
+  DevBuf rec8[2], len_code, len_combo, inl[2], combo_tabs, memo;
+  double lt_two_T = -1;   // 2T the memo table was last built for (-1: stale)
+  int lt_codes = 0;
+  // delta since the last full table build: pairs whose record lists gained records of newly
+  // activated windows. Their complete lists (device-table order: window id, position) travel with
+  // every evaluation; a full rebuild folds them back in when they become too many.
+  struct DirtyPair { int32_t slot; std::vector<RecQuad> recs[2]; };
+  std::vector<DirtyPair> dirty;
+  std::unordered_map<int32_t, int32_t> dirty_index;  // slot -> index in `dirty`
+  int64_t full_rebuilds = 0, delta_updates = 0;
+  size_t dirty_marked = 0;   // delta pairs whose slots already carry the mark on the device
+  // The delta lists live on the device at a fixed stride (4 records per mate and pair, longer lists in
+  // a small spill CSR); an evaluation that changed some of them uploads a patch for just those pairs.
+  std::vector<int32_t> dirty_touched;   // indices into `dirty` changed since the last upload
+  std::vector<int32_t> spill_of;        // per dirty pair: index in spill_pairs or -1
+  std::vector<int32_t> spill_pairs;     // dirty indices with more than 4 records on a mate
+  bool spill_changed = false;
+  size_t delta_cap = 0;                 // pairs the device store holds
+  DevBuf dl_slot, dl_spill, dl_rec[2], dl_patch, delta_dev /* spill CSR */;
+  Staging stage_delta;
+  size_t delta_off[4] = {0, 0, 0, 0};   // spill CSR: offsets mate 0, records mate 0, offsets mate 1, records mate 1
+  int quiet_calls = 0;       // evaluations since the last window activation
+  bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
+  PinBuf h_timeline; int timeline_waves = 0;  // ablation 8 (tools/kernel_timeline.py)
+  PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
+  int last_total_blocks = 0;
+  bool last_host_partials = false;
+  DevBuf len12, probs, tabs, occ_arena, cov_bits, bad;
+  DevBuf gen_bits;  // one bit per table-class slot: needs paired_general_kernel (written by the main kernel)
+  hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;
+  PairedPlanner planner;
+  OccImage image[2];                 // persistent host images of the occurrence tables, patched per call
+  std::vector<Occ> scratch_occ[2];   // debug dumps only
+  Reducer red;
+  std::vector<double> ins_tab, floor_tab, logfloor_tab, covthr_tab;
+  bool floor_positive = true;  // every floor exp(c + k s) > 0 (else "probability 0 is floored" does not hold: no memo / shortcut paths)
+  bool tabs_uploaded = false;
+  int64_t last_bad_bases = 0;
+  Staging stage;
+};
+
+struct SingleSet {
+  gaml_single_cfg cfg;
+  ShortMate mate;
+  ReadMajor rm;
+  MateDev dev;
+  DevBuf lens, probs, tabs, occ_arena;
+  std::vector<Occ> last_occ;
+  Reducer red;
+  std::vector<double> floor_tab, logfloor_tab;
+  bool tabs_uploaded = false;
+  Staging stage;
+};
+
+struct DpDev {  // device buffers of the PacBio banded DP
+  DevBuf path, jobs, ops, scratch, out, dbg;
+  void release() { path.release(); jobs.release(); ops.release(); scratch.release(); out.release(); dbg.release(); }
+};
+
+struct PacbioSet {
+  gaml_single_cfg cfg;
+  int64_t n_global = 0, lo = 0, hi = 0;
+  std::vector<int32_t> lens;  // shard
+  double log_match = 0, log_mismatch = 0;
+  std::unordered_map<Walk, int32_t, WalkHasher> walk_id;
+  std::vector<std::vector<gaml_pacbio_aligment>> recs;  // per sub-walk, local read ids
+  uint64_t generation = 0, uploaded_generation = ~0ull;
+  int32_t max_len = 0;
+  int64_t misses = 0;
+  DevBuf d_lens, rec_off, rec_walk, rec_logp, walk_count, logprobs;
+  Reducer red;
+  int64_t last_bad_bases = 0;
+  Staging stage;
+  // cache-miss side (SAM ingestion): bases of this shard's reads and the name -> global id map
+  bool have_reads = false;
+  std::string bases;
+  std::vector<int64_t> base_off;  // local read i = bases[base_off[i], base_off[i+1])
+  std::unordered_map<std::string, int32_t> name_id;
+  DevBuf d_bases;
+  DpDev dp;
+  bool bases_uploaded = false;
+  double dp_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+struct PairedPrep {
+  int64_t assembled_records = 0;  // records the reference would touch in GetPositionsOnlyPath
+  std::vector<int32_t> path_base, start_off, starts;
+  int32_t total_bits = 0;
+};
+
+struct SetRef { int kind, idx; };
+
+}  // namespace detail
+}  // namespace gaml
+
+using namespace gaml;          // (this header is private to the library's two HIP translation units)
+using namespace gaml::detail;
+
+struct gaml_hip_ctx {
+  gaml::MultiState* multi = nullptr;  // several device shards behind this context (gaml_hip_create_multi): every call is forwarded
+  gaml::CommState* comm = nullptr;    // RCCL communicator of a sharded context (gaml_hip_comm_init_rank / the shards of a multi context)
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipStream_t aux_stream = nullptr;  // the overflow kernel runs beside the main kernel
+  GraphStore g;
+  bool have_graph = false;
+  std::vector<std::unique_ptr<SingleSet>> singles;
+  std::vector<std::unique_ptr<PairedSet>> paireds;
+  std::vector<std::unique_ptr<PacbioSet>> pacbios;
+  std::vector<SetRef> handles;  // creation order -> (kind, index)
+  int32_t rank = 0, world = 1;
+  AlignScratch aln_scratch;
+  int64_t aln_windows = 0, aln_candidates = 0;  // GPU aligner statistics
+  double aln_us = 0;
+  double aln_stage_us[5] = {0, 0, 0, 0, 0};  // window strings + upload, spans + candidates, extension, D2H of hits, sort + finalize
+  int64_t aln_batches = 0;
+  int knobs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
+  int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
+  std::string err;
+  // timing
+  bool event_timing = false;
+  int event_every = 1;    // time every k-th scoring launch (attached events cost ~4 us of host time per launch)
+  int64_t event_tick = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // one pair per scoring launch of a call
+  size_t ev_used = 0;
+  double t_host_us = 0, t_dev_wall_us = 0, t_kernel_us = 0;
+  int64_t stat_launches = 0;
+  double stat_device_us = 0, stat_algo_bytes = 0;
+  DevBuf packed;  // 4 doubles per read set
+  PinBuf packed_host;
+  // gaml_hip_shm_exchange_*: the ranks of one node add up their (host-resident) partials through a POSIX shared-memory block
+  char* shm_base = nullptr; size_t shm_bytes = 0; int shm_rank = 0, shm_world = 0, shm_cap = 0; unsigned long long shm_step = 0; std::string shm_name;
+  PinBuf fetch_host;            // gaml_hip_fetch_async / _wait: [sequence word | 63 x pad | doubles]
+  unsigned long long fetch_seq = 0;
+  hipStream_t fetch_stream = nullptr;
+  DevBuf batch_dev;  // gaml_hip_calc_prob_batch: 4 doubles per read set and path set
+  PinBuf batch_host;
+  // evaluation in progress (between eval_begin and eval_finish)
+  bool pending_open = false;
+  std::vector<Walk> pending_paths;
+  int32_t pending_total_len = 0;
+  std::vector<std::unique_ptr<PairedPrep>> pending_prep;  // per paired set
+  double pending_host_us = 0;
+  double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // phase stamps of the last blocking call (us): see gaml_hip_debug_profile
+  bool host_results = false;  // blocking call: kernels write their results into pinned host memory, no D2H copy
+  // sharded evaluation with a coverage penalty: sweeps wait for the other ranks' coverage maps
+  bool defer_cov = false;
+  struct PendingCov { int paired_idx; CovArgs args; double* out4; };
+  std::vector<PendingCov> pending_cov;
+  // same for a PacBio set: the interval events of the other ranks' reads are missing (host lists)
+  struct PendingPacbio {
+    int pacbio_idx;
+    double* out4;
+    std::vector<int32_t> tl;                                            // per path
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> node_events;  // per path: the events every rank has
+    std::vector<int32_t> own;                                           // this rank's record events: (path, position, value) triples
+  };
+  std::vector<PendingPacbio> pending_pb;
+};

@@ -1,272 +1,9 @@
 // gaml_hip.hip -- context, device memory, launches and the C ABI of libgaml_hip.so.
 // The kernels are in kernels.hip.h, the host data model in host_model.{h,cc}.
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-#include <hipcub/hipcub.hpp>
-
-#include <algorithm>
-#include <atomic>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <unistd.h>
-#include <chrono>
-#include <climits>
-#include <limits>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <set>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "aligner.hip.h"
-#include "host_model.h"
-#include "kernels.hip.h"
-#include "pacbio_dp.hip.h"
+#include "ctx.hip.h"
 
 using namespace gaml;
-
-namespace {
-
-double now_us() {
-  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-// grow-only device / pinned buffers
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t reserve(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
-    size_t want = std::max(bytes + bytes / 4, (size_t)256);
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  template <class T> T* as() const { return (T*)p; }
-};
-struct PinBuf {
-  void* p = nullptr;
-  void* dev = nullptr;  // the same memory as the device sees it
-  size_t cap = 0;
-  hipError_t reserve(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) { (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
-    size_t want = std::max(bytes + bytes / 4, (size_t)4096);
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);  // device-visible: kernels read / write it directly
-    if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, p, 0);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
-};
-
-constexpr int kRing = 4;  // staging slots, so that async callers may run ahead of the device
-
-struct Staging {
-  PinBuf host[kRing];
-  hipEvent_t done[kRing] = {};
-  bool armed[kRing] = {};
-  int next = 0;
-};
-
-struct Reducer {  // per read set: partials + ticket + 2-double result
-  DevBuf part_sum, part_zero, ticket, out;
-  hipError_t init() {
-    hipError_t e;
-    if ((e = part_sum.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(double))) != hipSuccess) return e;
-    if ((e = part_zero.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(int))) != hipSuccess) return e;
-    if ((e = ticket.reserve(sizeof(unsigned))) != hipSuccess) return e;
-    if ((e = out.reserve(4 * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipMemset(ticket.p, 0, sizeof(unsigned))) != hipSuccess) return e;
-    if ((e = hipMemset(out.p, 0, 4 * sizeof(double))) != hipSuccess) return e;
-    return hipDeviceSynchronize();  // the scoring stream is non-blocking: make the zeroes land first
-  }
-  void release() { part_sum.release(); part_zero.release(); ticket.release(); out.release(); }
-};
-
-struct AlignDev {  // device copies the GPU aligner needs: reads (1 byte per base) + the max-hash index
-  DevBuf reads, read_off, bucket_hash, bucket_off, bucket_reads;
-  bool uploaded = false;
-  void release() { reads.release(); read_off.release(); bucket_hash.release(); bucket_off.release(); bucket_reads.release(); }
-};
-struct AlignScratch {  // per context, grown on demand
-  DevBuf wstr, wins, hbuf, hbuf_off, spans, cands, hits, counters;
-  DevBuf sort_keys, sort_idx, sort_tmp, hits_sorted;  // large batches: hits ordered on the device
-  void release() { wstr.release(); wins.release(); hbuf.release(); hbuf_off.release(); spans.release(); cands.release(); hits.release(); counters.release();
-                   sort_keys.release(); sort_idx.release(); sort_tmp.release(); hits_sorted.release(); }
-};
-
-struct MateDev {
-  DevBuf first, extra, pows;  // pows = mismatch_pow | match_pow
-  AlignDev aln;
-  uint64_t uploaded_generation = ~0ull;
-  size_t pow_n = 0;
-};
-
-struct PairedSet {
-  gaml_paired_cfg cfg;
-  ShortMate mate[2];
-  PairTables pt;                      // device order + compact / 16-byte record tables (cold path)
-  MateDev dev[2];
-  DevBuf rec8[2], len_code, len_combo, inl[2], combo_tabs, memo;
-  double lt_two_T = -1;   // 2T the memo table was last built for (-1: stale)
-  int lt_codes = 0;
-  // delta since the last full table build: pairs whose record lists gained records of newly
-  // activated windows. Their complete lists (device-table order: window id, position) travel with
-  // every evaluation; a full rebuild folds them back in when they become too many.
-  struct DirtyPair { int32_t slot; std::vector<RecQuad> recs[2]; };
-  std::vector<DirtyPair> dirty;
-  std::unordered_map<int32_t, int32_t> dirty_index;  // slot -> index in `dirty`
-  int64_t full_rebuilds = 0, delta_updates = 0;
-  size_t dirty_marked = 0;   // delta pairs whose slots already carry the mark on the device
-  // The delta lists live on the device at a fixed stride (4 records per mate and pair, longer lists in
-  // a small spill CSR); an evaluation that changed some of them uploads a patch for just those pairs.
-  std::vector<int32_t> dirty_touched;   // indices into `dirty` changed since the last upload
-  std::vector<int32_t> spill_of;        // per dirty pair: index in spill_pairs or -1
-  std::vector<int32_t> spill_pairs;     // dirty indices with more than 4 records on a mate
-  bool spill_changed = false;
-  size_t delta_cap = 0;                 // pairs the device store holds
-  DevBuf dl_slot, dl_spill, dl_rec[2], dl_patch, delta_dev /* spill CSR */;
-  Staging stage_delta;
-  size_t delta_off[4] = {0, 0, 0, 0};   // spill CSR: offsets mate 0, records mate 0, offsets mate 1, records mate 1
-  int quiet_calls = 0;       // evaluations since the last window activation
-  bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
-  PinBuf h_timeline; int timeline_waves = 0;  // ablation 8 (tools/kernel_timeline.py)
-  PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
-  int last_total_blocks = 0;
-  bool last_host_partials = false;
-  DevBuf len12, probs, tabs, occ_arena, cov_bits, bad;
-  DevBuf gen_bits;  // one bit per table-class slot: needs paired_general_kernel (written by the main kernel)
-  hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;
-  PairedPlanner planner;
-  OccImage image[2];                 // persistent host images of the occurrence tables, patched per call
-  std::vector<Occ> scratch_occ[2];   // debug dumps only
-  Reducer red;
-  std::vector<double> ins_tab, floor_tab, logfloor_tab, covthr_tab;
-  bool floor_positive = true;  // every floor exp(c + k s) > 0 (else "probability 0 is floored" does not hold: no memo / shortcut paths)
-  bool tabs_uploaded = false;
-  int64_t last_bad_bases = 0;
-  Staging stage;
-};
-
-struct SingleSet {
-  gaml_single_cfg cfg;
-  ShortMate mate;
-  ReadMajor rm;
-  MateDev dev;
-  DevBuf lens, probs, tabs, occ_arena;
-  std::vector<Occ> last_occ;
-  Reducer red;
-  std::vector<double> floor_tab, logfloor_tab;
-  bool tabs_uploaded = false;
-  Staging stage;
-};
-
-struct DpDev {  // device buffers of the PacBio banded DP
-  DevBuf path, jobs, ops, scratch, out, dbg;
-  void release() { path.release(); jobs.release(); ops.release(); scratch.release(); out.release(); dbg.release(); }
-};
-
-struct PacbioSet {
-  gaml_single_cfg cfg;
-  int64_t n_global = 0, lo = 0, hi = 0;
-  std::vector<int32_t> lens;  // shard
-  double log_match = 0, log_mismatch = 0;
-  std::unordered_map<Walk, int32_t, WalkHasher> walk_id;
-  std::vector<std::vector<gaml_pacbio_aligment>> recs;  // per sub-walk, local read ids
-  uint64_t generation = 0, uploaded_generation = ~0ull;
-  int32_t max_len = 0;
-  int64_t misses = 0;
-  DevBuf d_lens, rec_off, rec_walk, rec_logp, walk_count, logprobs;
-  Reducer red;
-  int64_t last_bad_bases = 0;
-  Staging stage;
-  // cache-miss side (SAM ingestion): bases of this shard's reads and the name -> global id map
-  bool have_reads = false;
-  std::string bases;
-  std::vector<int64_t> base_off;  // local read i = bases[base_off[i], base_off[i+1])
-  std::unordered_map<std::string, int32_t> name_id;
-  DevBuf d_bases;
-  DpDev dp;
-  bool bases_uploaded = false;
-  double dp_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-};
-
-struct PairedPrep {
-  int64_t assembled_records = 0;  // records the reference would touch in GetPositionsOnlyPath
-  std::vector<int32_t> path_base, start_off, starts;
-  int32_t total_bits = 0;
-};
-
-struct SetRef { int kind, idx; };
-
-}  // namespace
-
-struct gaml_hip_ctx {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  hipStream_t aux_stream = nullptr;  // the overflow kernel runs beside the main kernel
-  GraphStore g;
-  bool have_graph = false;
-  std::vector<std::unique_ptr<SingleSet>> singles;
-  std::vector<std::unique_ptr<PairedSet>> paireds;
-  std::vector<std::unique_ptr<PacbioSet>> pacbios;
-  std::vector<SetRef> handles;  // creation order -> (kind, index)
-  int32_t rank = 0, world = 1;
-  AlignScratch aln_scratch;
-  int64_t aln_windows = 0, aln_candidates = 0;  // GPU aligner statistics
-  double aln_us = 0;
-  double aln_stage_us[5] = {0, 0, 0, 0, 0};  // window strings + upload, spans + candidates, extension, D2H of hits, sort + finalize
-  int64_t aln_batches = 0;
-  int knobs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
-  int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
-  std::string err;
-  // timing
-  bool event_timing = false;
-  int event_every = 1;    // time every k-th scoring launch (attached events cost ~4 us of host time per launch)
-  int64_t event_tick = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // one pair per scoring launch of a call
-  size_t ev_used = 0;
-  double t_host_us = 0, t_dev_wall_us = 0, t_kernel_us = 0;
-  int64_t stat_launches = 0;
-  double stat_device_us = 0, stat_algo_bytes = 0;
-  DevBuf packed;  // 4 doubles per read set
-  PinBuf packed_host;
-  // gaml_hip_shm_exchange_*: the ranks of one node add up their (host-resident) partials through a POSIX shared-memory block
-  char* shm_base = nullptr; size_t shm_bytes = 0; int shm_rank = 0, shm_world = 0, shm_cap = 0; unsigned long long shm_step = 0; std::string shm_name;
-  PinBuf fetch_host;            // gaml_hip_fetch_async / _wait: [sequence word | 63 x pad | doubles]
-  unsigned long long fetch_seq = 0;
-  hipStream_t fetch_stream = nullptr;
-  DevBuf batch_dev;  // gaml_hip_calc_prob_batch: 4 doubles per read set and path set
-  PinBuf batch_host;
-  // evaluation in progress (between eval_begin and eval_finish)
-  bool pending_open = false;
-  std::vector<Walk> pending_paths;
-  int32_t pending_total_len = 0;
-  std::vector<std::unique_ptr<PairedPrep>> pending_prep;  // per paired set
-  double pending_host_us = 0;
-  double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // phase stamps of the last blocking call (us): see gaml_hip_debug_profile
-  bool host_results = false;  // blocking call: kernels write their results into pinned host memory, no D2H copy
-  // sharded evaluation with a coverage penalty: sweeps wait for the other ranks' coverage maps
-  bool defer_cov = false;
-  struct PendingCov { int paired_idx; CovArgs args; double* out4; };
-  std::vector<PendingCov> pending_cov;
-  // same for a PacBio set: the interval events of the other ranks' reads are missing (host lists)
-  struct PendingPacbio {
-    int pacbio_idx;
-    double* out4;
-    std::vector<int32_t> tl;                                            // per path
-    std::vector<std::vector<std::pair<int32_t, int32_t>>> node_events;  // per path: the events every rank has
-    std::vector<int32_t> own;                                           // this rank's record events: (path, position, value) triples
-  };
-  std::vector<PendingPacbio> pending_pb;
-};
+using namespace gaml::detail;
 
 namespace {
 
@@ -1613,11 +1350,45 @@ int combine(gaml_hip_ctx* c, const double* partials, double* prob_out, int32_t* 
 }  // namespace
 
 // =========================================================================================
+// what multi.hip needs from a context (internal.h)
+// =========================================================================================
+namespace gaml {
+int ctx_fail(gaml_hip_ctx* c, int code, const std::string& msg) { return fail(c, code, msg); }
+hipStream_t ctx_stream(const gaml_hip_ctx* c) { return c->stream; }
+int ctx_device(const gaml_hip_ctx* c) { return c->device; }
+int ctx_rank(const gaml_hip_ctx* c) { return c->rank; }
+int ctx_world(const gaml_hip_ctx* c) { return c->world; }
+int ctx_peers(const gaml_hip_ctx* c) { return c->peers; }
+MultiState* ctx_multi(const gaml_hip_ctx* c) { return c->multi; }
+void ctx_set_multi(gaml_hip_ctx* c, MultiState* m) { c->multi = m; }
+CommState* ctx_comm(const gaml_hip_ctx* c) { return c->comm; }
+void ctx_set_comm(gaml_hip_ctx* c, CommState* s) { c->comm = s; }
+gaml_hip_ctx* ctx_new_parent() { return new gaml_hip_ctx(); }
+void ctx_note_reduced(gaml_hip_ctx* c, const double* partials) {
+  auto order = scoring_order(c);
+  for (size_t k = 0; k < order.size(); k++) {
+    if (order[k].kind == 1) c->paireds[order[k].idx]->last_bad_bases = (int64_t)partials[4 * k + 2];
+    else if (order[k].kind == 2) c->pacbios[order[k].idx]->last_bad_bases = (int64_t)partials[4 * k + 2];
+  }
+}
+bool ctx_has_penalty(const gaml_hip_ctx* c) {
+  for (auto& ps : c->paireds) if (ps->cfg.penalty_constant > 0) return true;
+  for (auto& ps : c->pacbios) if (ps->cfg.penalty_constant > 0) return true;
+  return false;
+}
+}  // namespace gaml
+
+// a multi-device context forwards every call to its shards (multi.hip)
+#define MULTI_FWD(c, call) do { if ((c) && (c)->multi) return gaml::call; } while (0)
+// introspection / tuning entry points without a multi-device meaning act on shard 0
+#define MULTI_SHARD0(c) do { if ((c) && (c)->multi) (c) = gaml::multi_shard((c)->multi, 0); } while (0)
+#define MULTI_REFUSE(c, what) do { if ((c) && (c)->multi) return fail(c, GAML_HIP_ESTATE, "multi-device context: " what); } while (0)
+
+// =========================================================================================
 // C ABI
 // =========================================================================================
 extern "C" {
 
-const char* gaml_hip_version(void) { return "gaml_hip 0.1 (gfx950)"; }
 
 int gaml_hip_create(gaml_hip_ctx** out, int device) {
   if (!out) return GAML_HIP_EINVAL;
@@ -1642,20 +1413,24 @@ int gaml_hip_create(gaml_hip_ctx** out, int device) {
 void gaml_hip_destroy(gaml_hip_ctx* c) {
   if (c && c->shm_base) { munmap(c->shm_base, c->shm_bytes); c->shm_base = nullptr; }
   if (!c) return;
+  if (c->multi) { gaml::multi_destroy(c->multi); c->multi = nullptr; }
   if (c->device >= 0) {
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    // everything that may still use this context's memory: the library's streams, a caller's stream the last fetch /
+    // stream-ordered evaluation went to (all streams of the device: the caller's is not ours to name), then the communicator
+    (void)hipDeviceSynchronize();
+    if (c->comm) { gaml::comm_destroy(c->comm); c->comm = nullptr; }
     auto drop_stage = [](Staging& s) { for (int k = 0; k < kRing; k++) { s.host[k].release(); if (s.done[k]) (void)hipEventDestroy(s.done[k]); } };
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
       s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release(); s->len_code.release(); s->len_combo.release();
       s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
-      s->red.release(); drop_stage(s->stage);
+      s->red.release(); drop_stage(s->stage); s->gen_bits.release();
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage);
       s->d_bases.release(); s->dp.release(); }
-    c->packed.release(); c->packed_host.release(); c->batch_dev.release(); c->batch_host.release(); c->aln_scratch.release();
+    c->packed.release(); c->packed_host.release(); c->batch_dev.release(); c->batch_host.release(); c->aln_scratch.release(); c->fetch_host.release();
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -1663,11 +1438,16 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
   delete c;
 }
 
-const char* gaml_hip_last_error(const gaml_hip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* gaml_hip_last_error(const gaml_hip_ctx* c) {
+  if (!c) return "null context";
+  if (c->multi && c->err.empty()) return gaml::multi_last_error(c->multi);  // e.g. why the RCCL exchange is not available
+  return c->err.c_str();
+}
 
 int gaml_hip_set_graph(gaml_hip_ctx* c, int32_t n_nodes, const char* bases, const int64_t* offs) {
   if (!c || n_nodes < 0 || !offs || (n_nodes > 0 && !bases)) return fail(c, GAML_HIP_EINVAL, "bad graph arguments");
   if (n_nodes & 1) return fail(c, GAML_HIP_EINVAL, "node count must be even (twin of i is i^1)");
+  MULTI_FWD(c, multi_set_graph(c->multi, n_nodes, bases, offs));
   c->g.bases.assign(bases + offs[0], bases + offs[n_nodes]);
   c->g.off.resize(n_nodes + 1);
   for (int32_t i = 0; i <= n_nodes; i++) c->g.off[i] = offs[i] - offs[0];
@@ -1678,6 +1458,7 @@ int gaml_hip_set_graph(gaml_hip_ctx* c, int32_t n_nodes, const char* bases, cons
 
 int gaml_hip_load_graph(gaml_hip_ctx* c, const char* file) {
   if (!c || !file) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_FWD(c, multi_load_graph(c->multi, file));
   std::string err;
   if (!c->g.load_lastgraph(file, &err)) return fail(c, GAML_HIP_EINVAL, err);
   c->have_graph = true;
@@ -1686,6 +1467,7 @@ int gaml_hip_load_graph(gaml_hip_ctx* c, const char* file) {
 
 int gaml_hip_set_shard(gaml_hip_ctx* c, int32_t rank, int32_t world) {
   if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, GAML_HIP_EINVAL, "bad shard");
+  MULTI_REFUSE(c, "its shards are the devices given to gaml_hip_create_multi");
   if (!c->handles.empty()) return fail(c, GAML_HIP_ESTATE, "set the shard before adding read sets");
   c->rank = rank; c->world = world; c->peers = world;
   return GAML_HIP_OK;
@@ -1693,6 +1475,7 @@ int gaml_hip_set_shard(gaml_hip_ctx* c, int32_t rank, int32_t world) {
 
 int gaml_hip_set_presharded(gaml_hip_ctx* c, int32_t world) {
   if (!c || world < 1) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_REFUSE(c, "its shards are the devices given to gaml_hip_create_multi");
   if (c->world != 1) return fail(c, GAML_HIP_ESTATE, "gaml_hip_set_shard already partitions this context's reads");
   c->peers = world;
   return GAML_HIP_OK;
@@ -1708,6 +1491,7 @@ static void init_mate(gaml_hip_ctx* c, ShortMate& m, double mismatch, int64_t n,
 
 int gaml_hip_add_single(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, const char* bases, const int64_t* offs) {
   if (!c || !cfg || n < 0 || !offs) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_FWD(c, multi_add_single(c->multi, cfg, n, bases, offs));
   std::unique_ptr<SingleSet> s(new SingleSet());
   s->cfg = *cfg;
   init_mate(c, s->mate, cfg->mismatch_prob, n, bases, offs);
@@ -1719,6 +1503,7 @@ int gaml_hip_add_single(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, 
 int gaml_hip_add_paired(gaml_hip_ctx* c, const gaml_paired_cfg* cfg, int32_t n, const char* b1, const int64_t* o1,
                         const char* b2, const int64_t* o2) {
   if (!c || !cfg || n < 0 || !o1 || !o2) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_FWD(c, multi_add_paired(c->multi, cfg, n, b1, o1, b2, o2));
   std::unique_ptr<PairedSet> s(new PairedSet());
   s->cfg = *cfg;
   {  // the two mates' read indexes are independent: build them side by side
@@ -1735,6 +1520,7 @@ int gaml_hip_add_paired(gaml_hip_ctx* c, const gaml_paired_cfg* cfg, int32_t n, 
 
 int gaml_hip_add_pacbio(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, const int32_t* lens) {
   if (!c || !cfg || n < 0 || (n > 0 && !lens)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_FWD(c, multi_add_pacbio(c->multi, cfg, n, lens));
   std::unique_ptr<PacbioSet> s(new PacbioSet());
   s->cfg = *cfg;
   s->n_global = n;
@@ -1752,6 +1538,7 @@ int gaml_hip_add_pacbio(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, 
 int gaml_hip_add_pacbio_reads(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, const char* bases, const int64_t* offs,
                               const char* names) {
   if (!c || !cfg || n < 0 || !offs || (n > 0 && (!bases || !names))) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_FWD(c, multi_add_pacbio_reads(c->multi, cfg, n, bases, offs, names));
   for (int64_t i = offs[0]; i < offs[n]; i++)
     if (bases[i] == '\n' || bases[i] == '-') return fail(c, GAML_HIP_EINVAL, "a PacBio read holds a separator or gap character");
   std::vector<int32_t> lens(n);
@@ -1810,13 +1597,27 @@ static ShortMate* mate_of(gaml_hip_ctx* c, int readset, int mate) {
 
 int gaml_hip_put_window_records(gaml_hip_ctx* c, int readset, int mate, const int32_t* subpath, int32_t len,
                                 const gaml_aligment* recs, int64_t n) {
+  MULTI_FWD(c, multi_put_window_records(c->multi, readset, mate, subpath, len, recs, n));
   ShortMate* m = mate_of(c, readset, mate);
-  if (!m || !subpath || len <= 0 || n < 0) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (!m || !subpath || len <= 0 || n < 0 || (n > 0 && !recs)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
   Walk w(subpath, subpath + len);
+  int64_t walk_len = 0;
+  for (int32_t x : w) {
+    if (x < 0 || x >= c->g.n()) return fail(c, GAML_HIP_EINVAL, "window refers to a node outside the graph");
+    walk_len += c->g.len(x);
+  }
   if (m->find(w) >= 0) return fail(c, GAML_HIP_ESTATE, "window already cached");
   std::vector<gaml_aligment> v;
   for (int64_t i = 0; i < n; i++) {
+    // Records from outside are indexed with on the device (pow tables by edit count, coverage bitmap by position):
+    // anything the library's own aligner could not have produced is refused, not clamped.
+    if (recs[i].read_id < 0 || recs[i].read_id >= m->n_global) return fail(c, GAML_HIP_EINVAL, "record names a read outside the read set");
+    if (recs[i].orientation != 0 && recs[i].orientation != 1) return fail(c, GAML_HIP_EINVAL, "record orientation must be 0 or 1");
+    if (recs[i].position < 0 || recs[i].position > walk_len) return fail(c, GAML_HIP_EINVAL, "record position outside the window");
+    if (recs[i].edit_dist < 0 || recs[i].edit_dist > 255) return fail(c, GAML_HIP_EINVAL, "record edit distance outside 0..255");
     if (recs[i].read_id < m->lo || recs[i].read_id >= m->hi) continue;  // other shard
+    if (recs[i].edit_dist > m->lens[recs[i].read_id - m->lo]) return fail(c, GAML_HIP_EINVAL, "record edit distance exceeds the read length");
     gaml_aligment r = recs[i];
     r.read_id -= (int32_t)m->lo;
     v.push_back(r);
@@ -1830,9 +1631,12 @@ int gaml_hip_put_window_records(gaml_hip_ctx* c, int readset, int mate, const in
 
 int gaml_hip_put_pacbio_records(gaml_hip_ctx* c, int readset, const int32_t* subpath, int32_t len,
                                 const gaml_pacbio_aligment* recs, int64_t n) {
+  MULTI_FWD(c, multi_put_pacbio_records(c->multi, readset, subpath, len, recs, n));
   if (!c || readset < 0 || readset >= (int)c->handles.size() || c->handles[readset].kind != 2 || !subpath || len <= 0 || n < 0)
     return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PacbioSet& s = *c->pacbios[c->handles[readset].idx];
+  for (int64_t i = 0; i < n; i++)
+    if (recs[i].read_id < 0 || recs[i].read_id >= s.n_global) return fail(c, GAML_HIP_EINVAL, "record names a read outside the read set");
   Walk w(subpath, subpath + len);
   auto it = s.walk_id.find(w);
   int32_t id;
@@ -1914,6 +1718,7 @@ int run_pacbio_dp(gaml_hip_ctx* c, DpDev& d, const std::string& both, const unsi
 }  // namespace
 
 int32_t gaml_hip_pacbio_missing(gaml_hip_ctx* c, int readset, const int32_t* path_in, int32_t n, int32_t* ranges, int32_t cap) {
+  MULTI_FWD(c, multi_pacbio_missing(c->multi, readset, path_in, n, ranges, cap));
   PacbioSet* sp = pacbio_of(c, readset);
   if (!sp || !path_in || n <= 0 || cap < 0 || (cap > 0 && !ranges)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph");
@@ -1948,6 +1753,7 @@ int32_t gaml_hip_pacbio_missing(gaml_hip_ctx* c, int readset, const int32_t* pat
 
 int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path_in, int32_t n, const char* sam, int64_t sam_len,
                                int64_t* filed_out) {
+  MULTI_FWD(c, multi_pacbio_ingest_sam(c->multi, readset, path_in, n, sam, sam_len, filed_out));
   PacbioSet* sp = pacbio_of(c, readset);
   if (!sp || !path_in || n <= 0 || sam_len < 0 || (sam_len > 0 && !sam)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph");
@@ -2166,6 +1972,7 @@ int gaml_hip_debug_sam_shape(const char* sam_line, int64_t len, int32_t total_le
 }
 
 int gaml_hip_pacbio_dp_stats(gaml_hip_ctx* c, int readset, double* out8) {
+  MULTI_SHARD0(c);
   PacbioSet* sp = pacbio_of(c, readset);
   if (!sp || !out8) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   memcpy(out8, sp->dp_stats, sizeof(sp->dp_stats));
@@ -2173,6 +1980,7 @@ int gaml_hip_pacbio_dp_stats(gaml_hip_ctx* c, int readset, double* out8) {
 }
 
 int64_t gaml_hip_pacbio_records(gaml_hip_ctx* c, int readset, const int32_t* subpath, int32_t len, gaml_pacbio_aligment* out, int64_t cap) {
+  MULTI_FWD(c, multi_pacbio_records(c->multi, readset, subpath, len, out, cap));
   PacbioSet* sp = pacbio_of(c, readset);
   if (!sp || !subpath || len <= 0 || cap < 0 || (cap > 0 && !out)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   auto it = sp->walk_id.find(Walk(subpath, subpath + len));
@@ -2185,13 +1993,14 @@ int64_t gaml_hip_pacbio_records(gaml_hip_ctx* c, int readset, const int32_t* sub
 int gaml_hip_eval_begin(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths, int64_t* pending_out,
                         int32_t* total_len_out) {
   if (!c) return GAML_HIP_EINVAL;
+  MULTI_REFUSE(c, "the gaml_hip_eval_* protocol is for one shard per process; gaml_hip_calc_prob runs it over all shards");
   int e = eval_begin(c, paths, offs, n_paths, pending_out);
   if (!e && total_len_out) *total_len_out = c->pending_total_len;
   return e;
 }
 
 int64_t gaml_hip_eval_pending_maxpos(gaml_hip_ctx* c, int32_t* out, int64_t cap) {
-  if (!c) return -1;
+  if (!c || c->multi) return -1;
   int64_t n = 0;
   for (ShortMate* m : filter_mates(c))
     for (int32_t wid : m->unsynced) { if (out && n < cap) out[n] = m->wins[wid].max_pos; n++; }
@@ -2200,6 +2009,7 @@ int64_t gaml_hip_eval_pending_maxpos(gaml_hip_ctx* c, int32_t* out, int64_t cap)
 
 int gaml_hip_eval_apply_maxpos(gaml_hip_ctx* c, const int32_t* reduced, int64_t n) {
   if (!c || (n > 0 && !reduced)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_REFUSE(c, "the gaml_hip_eval_* protocol is for one shard per process");
   int64_t have = 0;
   for (ShortMate* m : filter_mates(c)) have += (int64_t)m->unsynced.size();
   if (have != n) return fail(c, GAML_HIP_EINVAL, "count does not match gaml_hip_eval_pending_maxpos");
@@ -2217,12 +2027,14 @@ int gaml_hip_eval_apply_maxpos(gaml_hip_ctx* c, const int32_t* reduced, int64_t 
 
 int gaml_hip_eval_finish_async(gaml_hip_ctx* c, void* d_partials, void* stream) {
   if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_REFUSE(c, "the gaml_hip_eval_* protocol is for one shard per process");
   if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
   return eval_finish(c, d_partials, stream ? (hipStream_t)stream : c->stream);
 }
 
 int32_t gaml_hip_eval_score_async(gaml_hip_ctx* c, void* d_partials, void* stream) {
   if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_REFUSE(c, "the gaml_hip_eval_* protocol is for one shard per process");
   if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
   c->pending_cov.clear();
   c->pending_pb.clear();
@@ -2305,6 +2117,7 @@ static size_t shm_slot_bytes(int cap) { return 64 + (((size_t)cap * sizeof(doubl
 
 int gaml_hip_shm_exchange_open(gaml_hip_ctx* c, const char* name, int32_t rank, int32_t world, int32_t cap_doubles) {
   if (!c || !name || world < 1 || rank < 0 || rank >= world || cap_doubles < 1) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_REFUSE(c, "its shards are summed in-process");
   if (c->shm_base) return fail(c, GAML_HIP_ESTATE, "exchange already open");
   const size_t bytes = 2 * (size_t)world * shm_slot_bytes(cap_doubles);
   if (rank == 0) shm_unlink(name);  // a block left behind by a crashed run would carry old step numbers: rank 0 starts a fresh one (it opens FIRST)
@@ -2364,6 +2177,7 @@ __global__ void fetch_kernel(const double* src, int n, double* dst, unsigned lon
 
 int gaml_hip_fetch_async(gaml_hip_ctx* c, const void* d_src, int32_t n_doubles, void* stream) {
   if (!c || !d_src || n_doubles <= 0) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_REFUSE(c, "no single device to fetch from");
   if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "no device");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t bytes = 512 + (size_t)n_doubles * sizeof(double);
@@ -2400,6 +2214,7 @@ int gaml_hip_fetch_wait(gaml_hip_ctx* c, double* out, int32_t n_doubles) {
 }
 
 int gaml_hip_sync(gaml_hip_ctx* c) {
+  MULTI_FWD(c, multi_sync(c->multi));
   if (!c || c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "no device");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2410,6 +2225,7 @@ static int fetch_partials(gaml_hip_ctx* c, double* partials_out);
 
 int gaml_hip_eval_finish(gaml_hip_ctx* c, double* partials_out) {
   if (!c || !partials_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_REFUSE(c, "the gaml_hip_eval_* protocol is for one shard per process");
   if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t bytes = std::max<size_t>(1, c->handles.size()) * 4 * sizeof(double);
@@ -2426,6 +2242,7 @@ int gaml_hip_eval_finish(gaml_hip_ctx* c, double* partials_out) {
 int gaml_hip_calc_partials_async(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths,
                                  void* d_partials, void* stream, int32_t* total_len_out) {
   if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_REFUSE(c, "partials of several devices have no single device address; use gaml_hip_calc_partials");
   if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
   return evaluate(c, paths, offs, n_paths, d_partials, stream ? (hipStream_t)stream : c->stream, total_len_out);
 }
@@ -2433,6 +2250,7 @@ int gaml_hip_calc_partials_async(gaml_hip_ctx* c, const int32_t* paths, const in
 int gaml_hip_calc_partials(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths,
                            double* partials_out, int32_t* total_len_out) {
   if (!c || !partials_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_FWD(c, multi_calc_partials(c->multi, paths, offs, n_paths, partials_out, total_len_out));  // reduced over the shards
   if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t bytes = std::max<size_t>(1, c->handles.size()) * 4 * sizeof(double);
@@ -2516,26 +2334,50 @@ static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
 
 int gaml_hip_combine_partials(gaml_hip_ctx* c, const double* partials, int32_t total_len, double* prob_out, int32_t* zeros_out) {
   if (!c || !partials || !prob_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_FWD(c, multi_combine(c->multi, partials, total_len, prob_out, zeros_out));
   return combine(c, partials, prob_out, zeros_out, total_len);
 }
 
 int gaml_hip_calc_prob(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths,
                        double* prob_out, int32_t* zeros_out, int32_t* total_len_out) {
   if (!c || !prob_out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
-  if (c->world != 1) return fail(c, GAML_HIP_ESTATE, "sharded context: use gaml_hip_calc_partials + all-reduce + gaml_hip_combine_partials");
-  std::vector<double> partials(std::max<size_t>(1, c->handles.size()) * 4);
+  const size_t ns = c->multi ? (size_t)gaml::multi_num_readsets(c->multi) : c->handles.size();
+  std::vector<double> partials(std::max<size_t>(1, ns) * 4);
   int32_t tl = 0;
-  int e = gaml_hip_calc_partials(c, paths, offs, n_paths, partials.data(), &tl);
+  int e;
+  if (!c->multi && c->comm) {
+    // one shard per process with a communicator (gaml_hip_comm_init_rank): registration, maxima, kernels and the
+    // one all-reduce(sum) of the partials over RCCL, all in here -- every rank calls with the same paths
+    e = gaml::comm_eval_reduced(c, paths, offs, n_paths, partials.data(), &tl);
+  } else {
+    if (c->peers != 1)
+      return fail(c, GAML_HIP_ESTATE, "sharded context without a communicator: gaml_hip_comm_init_rank first, or use gaml_hip_calc_partials + "
+                                      "your own all-reduce + gaml_hip_combine_partials");
+    e = gaml_hip_calc_partials(c, paths, offs, n_paths, partials.data(), &tl);
+  }
   if (e) return e;
   if (total_len_out) *total_len_out = tl;
-  return combine(c, partials.data(), prob_out, zeros_out, tl);
+  return gaml_hip_combine_partials(c, partials.data(), tl, prob_out, zeros_out);
 }
 
 int gaml_hip_calc_prob_batch(gaml_hip_ctx* c, int32_t n_sets, const int32_t* paths, const int64_t* offs, const int32_t* set_offs,
                              double* probs_out, int32_t* zeros_out, int32_t* total_lens_out) {
   if (!c || n_sets < 0 || !set_offs || !probs_out || (n_sets > 0 && !offs)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  MULTI_FWD(c, multi_calc_prob_batch(c->multi, n_sets, paths, offs, set_offs, probs_out, zeros_out, total_lens_out));
+  if (c->comm && n_sets > 0) {  // one shard per process with a communicator: ONE all-reduce over the whole batch
+    const size_t nsr = std::max<size_t>(1, c->handles.size());
+    std::vector<double> part((size_t)n_sets * 4 * nsr);
+    std::vector<int32_t> tls((size_t)n_sets, 0);
+    if (int e = gaml::comm_eval_reduced_batch(c, n_sets, paths, offs, set_offs, part.data(), tls.data())) return e;
+    for (int32_t i = 0; i < n_sets; i++) {
+      if (int e = combine(c, part.data() + (size_t)i * 4 * nsr, &probs_out[i], zeros_out ? zeros_out + (size_t)i * 2 * nsr : nullptr, tls[i])) return e;
+      if (total_lens_out) total_lens_out[i] = tls[i];
+    }
+    return GAML_HIP_OK;
+  }
   if (c->world != 1 || c->peers != 1)
-    return fail(c, GAML_HIP_ESTATE, "sharded context: run the gaml_hip_eval_* protocol per path set and all-reduce the partials of the batch at once");
+    return fail(c, GAML_HIP_ESTATE, "sharded context without a communicator: gaml_hip_comm_init_rank first, or run the gaml_hip_eval_* protocol per path "
+                                    "set and all-reduce the partials of the batch at once");
   if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
   if (n_sets == 0) return GAML_HIP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -2565,19 +2407,24 @@ int gaml_hip_calc_prob_batch(gaml_hip_ctx* c, int32_t n_sets, const int32_t* pat
   return GAML_HIP_OK;
 }
 
-int gaml_hip_num_readsets(const gaml_hip_ctx* c) { return c ? (int)c->handles.size() : 0; }
-int gaml_hip_readset_kind(const gaml_hip_ctx* c, int rs) { return (c && rs >= 0 && rs < (int)c->handles.size()) ? c->handles[rs].kind : -1; }
+int gaml_hip_num_readsets(const gaml_hip_ctx* c) { MULTI_FWD(c, multi_num_readsets(c->multi)); return c ? (int)c->handles.size() : 0; }
+int gaml_hip_readset_kind(const gaml_hip_ctx* c, int rs) {
+  MULTI_FWD(c, multi_readset_kind(c->multi, rs));
+  return (c && rs >= 0 && rs < (int)c->handles.size()) ? c->handles[rs].kind : -1;
+}
 int64_t gaml_hip_readset_reads(const gaml_hip_ctx* c, int rs) {
+  MULTI_FWD(c, multi_readset_reads(c->multi, rs));
   if (!c || rs < 0 || rs >= (int)c->handles.size()) return -1;
   SetRef h = c->handles[rs];
   if (h.kind == 0) return c->singles[h.idx]->mate.n_global;
   if (h.kind == 1) return c->paireds[h.idx]->mate[0].n_global;
   return c->pacbios[h.idx]->n_global;
 }
-int32_t gaml_hip_num_nodes(const gaml_hip_ctx* c) { return c && c->have_graph ? c->g.n() : 0; }
-int32_t gaml_hip_node_len(const gaml_hip_ctx* c, int32_t node) { return (c && c->have_graph && node >= 0 && node < c->g.n()) ? c->g.len(node) : -1; }
+int32_t gaml_hip_num_nodes(const gaml_hip_ctx* c) { MULTI_FWD(c, multi_num_nodes(c->multi)); return c && c->have_graph ? c->g.n() : 0; }
+int32_t gaml_hip_node_len(const gaml_hip_ctx* c, int32_t node) { MULTI_FWD(c, multi_node_len(c->multi, node)); return (c && c->have_graph && node >= 0 && node < c->g.n()) ? c->g.len(node) : -1; }
 
 int gaml_hip_read_probs(gaml_hip_ctx* c, int rs, double* out, int64_t n) {
+  MULTI_FWD(c, multi_read_probs(c->multi, rs, out, n));
   if (!c || rs < 0 || rs >= (int)c->handles.size() || !out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "host-only context");
   SetRef h = c->handles[rs];
@@ -2599,6 +2446,7 @@ int gaml_hip_read_probs(gaml_hip_ctx* c, int rs, double* out, int64_t n) {
 }
 
 int gaml_hip_bad_bases(gaml_hip_ctx* c, int rs, int64_t* out) {
+  MULTI_FWD(c, multi_bad_bases(c->multi, rs, out));
   if (!c || rs < 0 || rs >= (int)c->handles.size() || !out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   SetRef h = c->handles[rs];
   if (h.kind == 0) *out = 0;  // graph.cc:1701-1733 can never count a base (last_event_type is only -1 or 1)
@@ -2608,11 +2456,13 @@ int gaml_hip_bad_bases(gaml_hip_ctx* c, int rs, int64_t* out) {
 }
 
 int64_t gaml_hip_window_count(const gaml_hip_ctx* c, int rs, int mate) {
+  MULTI_FWD(c, multi_window_count(c->multi, rs, mate));
   ShortMate* m = mate_of(const_cast<gaml_hip_ctx*>(c), rs, mate);
   return m ? (int64_t)m->wins.size() : -1;
 }
 
 int64_t gaml_hip_window_records(gaml_hip_ctx* c, int rs, int mate, const int32_t* subpath, int32_t len, gaml_aligment* out, int64_t cap) {
+  MULTI_FWD(c, multi_window_records(c->multi, rs, mate, subpath, len, out, cap));
   ShortMate* m = mate_of(c, rs, mate);
   if (!m || !subpath || len <= 0) return -2;
   int32_t id = m->find(Walk(subpath, subpath + len));
@@ -2627,6 +2477,7 @@ int64_t gaml_hip_window_records(gaml_hip_ctx* c, int rs, int mate, const int32_t
 }
 
 int64_t gaml_hip_align_window(gaml_hip_ctx* c, int rs, int mate, const int32_t* subpath, int32_t len) {
+  MULTI_FWD(c, multi_align_window(c->multi, rs, mate, subpath, len));
   ShortMate* m = mate_of(c, rs, mate);
   if (!m || !subpath || len <= 0 || !c->have_graph) return -2;
   int32_t id = m->align(c->g, Walk(subpath, subpath + len));
@@ -2640,12 +2491,18 @@ int64_t gaml_hip_align_window(gaml_hip_ctx* c, int rs, int mate, const int32_t* 
 
 int gaml_hip_compact_tables(gaml_hip_ctx* c) {
   if (!c) return GAML_HIP_EINVAL;
+  MULTI_FWD(c, multi_compact_tables(c->multi));
   for (auto& ps : c->paireds) ps->compact_requested = true;
   return GAML_HIP_OK;
 }
 
 int gaml_hip_debug_prepare(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t n_paths) {
   if (!c || n_paths < 0 || (n_paths > 0 && (!flat || !offs))) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->multi) {  // every shard registers / aligns / places on its own reads (host-only shards included)
+    for (int k = 0; k < gaml::multi_num_shards(c->multi); k++)
+      if (int e = gaml_hip_debug_prepare(gaml::multi_shard(c->multi, k), flat, offs, n_paths)) return fail(c, e, gaml_hip_last_error(gaml::multi_shard(c->multi, k)));
+    return GAML_HIP_OK;
+  }
   if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
   std::vector<Walk> paths = unflatten(flat, offs, n_paths);
   for (auto& h : scoring_order(c)) {
@@ -2665,6 +2522,7 @@ int gaml_hip_debug_prepare(gaml_hip_ctx* c, const int32_t* flat, const int64_t* 
 }
 
 int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* c, int rs, int mate, int32_t* out5, int64_t cap) {
+  MULTI_SHARD0(c);
   if (!c || rs < 0 || rs >= (int)c->handles.size()) return -1;
   SetRef h = c->handles[rs];
   const std::vector<Occ>* v = nullptr;
@@ -2679,6 +2537,7 @@ int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* c, int rs, int mate, int32_t* o
 }
 
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wid, int32_t* out, int32_t cap) {
+  MULTI_SHARD0(c);
   ShortMate* m = mate_of(c, rs, mate);
   if (!m || wid < 0 || wid >= (int32_t)m->win_walk.size()) return -1;
   const Walk& w = *m->win_walk[wid];
@@ -2687,6 +2546,7 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wi
 }
 
 int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out3) {
+  MULTI_SHARD0(c);
   if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out3) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
   out3[0] = s.full_rebuilds; out3[1] = s.delta_updates; out3[2] = (int64_t)s.dirty.size();
@@ -2695,6 +2555,7 @@ int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out3) {
 
 int gaml_hip_aligner_stats(gaml_hip_ctx* c, int64_t* windows, int64_t* candidates, double* microseconds) {
   if (!c) return GAML_HIP_EINVAL;
+  MULTI_SHARD0(c);
   if (windows) *windows = c->aln_windows;
   if (candidates) *candidates = c->aln_candidates;
   if (microseconds) *microseconds = c->aln_us;
@@ -2706,11 +2567,13 @@ int gaml_hip_aligner_stats(gaml_hip_ctx* c, int64_t* windows, int64_t* candidate
 
 int gaml_hip_debug_profile(gaml_hip_ctx* c, double* out8) {
   if (!c || !out8) return GAML_HIP_EINVAL;
+  MULTI_SHARD0(c);
   for (int i = 0; i < 8; i++) out8[i] = c->prof[i];
   return GAML_HIP_OK;
 }
 
 int gaml_hip_debug_timeline(gaml_hip_ctx* c, int rs, unsigned long long* out, int64_t cap_waves) {
+  MULTI_SHARD0(c);
   if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
   if (!s.h_timeline.p) return 0;
@@ -2721,11 +2584,13 @@ int gaml_hip_debug_timeline(gaml_hip_ctx* c, int rs, unsigned long long* out, in
 
 int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
   if (!c || knob < 0 || knob >= 12) return GAML_HIP_EINVAL;
+  if (c->multi) { for (int k = 0; k < gaml::multi_num_shards(c->multi); k++) gaml::multi_shard(c->multi, k)->knobs[knob] = value; return GAML_HIP_OK; }
   c->knobs[knob] = value;
   return GAML_HIP_OK;
 }
 
 int gaml_hip_debug_class_counts(gaml_hip_ctx* c, int rs, int64_t* out4) {
+  MULTI_SHARD0(c);
   if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out4) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   for (int k = 0; k < 4; k++) out4[k] = c->paireds[c->handles[rs].idx]->pt.class_count[k];
   return GAML_HIP_OK;
@@ -2733,11 +2598,13 @@ int gaml_hip_debug_class_counts(gaml_hip_ctx* c, int rs, int64_t* out4) {
 
 int gaml_hip_last_timing(const gaml_hip_ctx* c, double* out3) {
   if (!c || !out3) return GAML_HIP_EINVAL;
+  MULTI_FWD(c, multi_last_timing(c->multi, out3));
   out3[0] = c->t_host_us; out3[1] = c->t_dev_wall_us; out3[2] = c->t_kernel_us;
   return GAML_HIP_OK;
 }
 int gaml_hip_set_event_timing(gaml_hip_ctx* c, int on) {
   if (!c) return GAML_HIP_EINVAL;
+  MULTI_FWD(c, multi_set_event_timing(c->multi, on));
   c->event_timing = on != 0;
   c->event_every = on > 1 ? on : 1;
   c->event_tick = 0;
@@ -2756,6 +2623,7 @@ int gaml_hip_set_event_timing(gaml_hip_ctx* c, int on) {
 }
 int gaml_hip_kernel_stats(gaml_hip_ctx* c, int reset, int64_t* launches, double* device_us, double* algo_bytes) {
   if (!c) return GAML_HIP_EINVAL;
+  MULTI_FWD(c, multi_kernel_stats(c->multi, reset, launches, device_us, algo_bytes));
   if (c->device >= 0 && c->ev_used) { if (int e = collect_events(c)) return e; }  // async calls leave pairs pending
   if (launches) *launches = c->stat_launches;
   if (device_us) *device_us = c->stat_device_us;

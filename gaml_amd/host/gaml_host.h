@@ -172,9 +172,12 @@ inline string& BlasrPath() { static string p = "blasr/alignment/bin"; return p; 
 // ---- ProbCalculator (prob_calculator.h:37-124) --------------------------------------------------
 class ProbCalculator {
  public:
+  // device list from the environment (GAML_HIP_DEVICES=all | 0,1,...; unset: device 0): several devices = the reads
+  // sharded over them inside the library, one RCCL all-reduce per CalcProb (gaml_hip_create_from_env)
+  static constexpr int kDevicesFromEnv = -2;
   ProbCalculator(const vector<pair<SingleReadConfig, ReadSet*>>& single_reads,
                  const vector<pair<PairedReadConfig, pair<ReadSet*, ReadSet*>>>& paired_reads,
-                 const vector<pair<SingleReadConfig, PacbioReadSet*>>& pacbio_reads, Graph& gr, int device = 0)
+                 const vector<pair<SingleReadConfig, PacbioReadSet*>>& pacbio_reads, Graph& gr, int device = kDevicesFromEnv)
       : single_reads(single_reads), paired_reads(paired_reads), pacbio_reads(pacbio_reads), gr(gr), device_(device) {}
   ~ProbCalculator() { if (ctx_) gaml_hip_destroy(ctx_); }
 
@@ -209,7 +212,8 @@ class ProbCalculator {
   // built lazily on the first CalcProb: the reference constructs ProbCalculator BEFORE the reads are
   // prepared (gaml.cc:1010 vs 1017)
   bool Build() {
-    if (gaml_hip_create(&ctx_, device_) != GAML_HIP_OK) { err_ = "no HIP device (the likelihood path has no CPU implementation)"; return false; }
+    const int rc = device_ == kDevicesFromEnv ? gaml_hip_create_from_env(&ctx_) : gaml_hip_create(&ctx_, device_);
+    if (rc != GAML_HIP_OK) { ctx_ = nullptr; err_ = "no HIP device (the likelihood path has no CPU implementation)"; return false; }
     string bases;
     vector<int64_t> offs(1, 0);
     for (auto& s : gr.nodes) { bases += s; offs.push_back((int64_t)bases.size()); }

@@ -34,6 +34,8 @@ int main(int argc, char** argv) {
   vector<pair<int, int>> zeros;
   int total_len = 0;
   double prob = pc.CalcProb(paths, zeros, total_len);
+  printf("gaml_hip: %d device shard(s), exchange %s\n", gaml_hip_num_shards(pc.context()),
+         gaml_hip_num_shards(pc.context()) > 1 ? (gaml_hip_get_exchange(pc.context()) == GAML_HIP_EXCHANGE_RCCL ? "rccl" : "host") : "none");
   printf("start prob %.17g len %d low prob reads", prob, total_len);  // gaml.cc:106-110 (more digits)
   for (auto& e : zeros) printf("%d/%d ", e.first, e.second);
   printf("\n");

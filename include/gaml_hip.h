@@ -77,6 +77,39 @@ const char* gaml_hip_version(void);
 #define GAML_HIP_EHIP (-3)
 #define GAML_HIP_ESTATE (-4)
 
+/* ---- several GPUs -------------------------------------------------------------------
+ * The reference's caller is ONE process holding ONE ProbCalculator (gaml.cc:1010, prob_calculator.h:37-124);
+ * nothing in the reference is parallel (the sharding is new design). Two ways to more than one GPU:
+ *
+ * (1) gaml_hip_create_multi: one context that owns n_devices shards, one per listed HIP device (a device may be
+ *     listed more than once, or be -1 for a host-only shard: rehearsals and tests). Reads are split by contiguous
+ *     id range (shard i of n keeps [N*i/n, N*(i+1)/n)), graph / paths / window registration are replicated, each
+ *     shard is driven by its own host thread. Every entry point of this header then works on the whole set:
+ *     gaml_hip_calc_prob returns the value over all reads. Per evaluation the shards exchange ONE sum of 4 f64 per
+ *     read set -- by an RCCL all-reduce over xGMI on the shards' streams (one communicator per shard,
+ *     ncclCommInitAll; the default when every shard has its own GPU) or, as the measured alternative, by adding the
+ *     shards' pinned-host partials in rank order on the calling thread (gaml_hip_set_exchange). The cold-path
+ *     maximum of new windows' record positions and, with penalty_constant > 0, the union of the coverage maps /
+ *     PacBio interval events are merged in the library too. Environment: GAML_HIP_EXCHANGE=host|rccl picks the
+ *     initial exchange ("rccl": creation fails when RCCL cannot be used).
+ * (2) one process per GPU (torch.distributed.run, MPI): every process creates a plain context, calls
+ *     gaml_hip_set_shard(rank, world) (or gaml_hip_set_presharded) and then gaml_hip_comm_init_rank with an id
+ *     that rank 0 made with gaml_hip_comm_unique_id and sent to the others by any means (128 bytes). From then on
+ *     gaml_hip_calc_prob / gaml_hip_calc_prob_batch are collective calls -- same paths on every rank, same value
+ *     back on every rank -- with the same in-library RCCL exchanges as (1). */
+int gaml_hip_create_multi(gaml_hip_ctx** out, const int32_t* devices, int32_t n_devices);
+/* What the ProbCalculator adapters call: environment GAML_HIP_DEVICES unset -> gaml_hip_create(out, 0); "all" -> every
+ * visible HIP device; "0,1,2,3" -> those (one entry: a plain context; several: gaml_hip_create_multi). */
+int gaml_hip_create_from_env(gaml_hip_ctx** out);
+int gaml_hip_num_shards(const gaml_hip_ctx* ctx);  /* 1 for a plain context */
+#define GAML_HIP_EXCHANGE_HOST 0
+#define GAML_HIP_EXCHANGE_RCCL 1
+int gaml_hip_set_exchange(gaml_hip_ctx* ctx, int32_t mode);  /* multi-device contexts only; RCCL needs distinct devices */
+int gaml_hip_get_exchange(const gaml_hip_ctx* ctx);
+#define GAML_HIP_COMM_ID_BYTES 128
+int gaml_hip_comm_unique_id(void* id_out /* GAML_HIP_COMM_ID_BYTES */);
+int gaml_hip_comm_init_rank(gaml_hip_ctx* ctx, const void* id /* GAML_HIP_COMM_ID_BYTES */, int32_t rank, int32_t world);
+
 /* ---- inputs ----------------------------------------------------------------------- */
 /* Graph node sequences, what Graph::nodes[i]->s holds after LoadGraph (graph.cc:52-106):
  * n_nodes = 2 * velvet nodes, twin of i is i^1. bases = concatenation, offs[n_nodes+1]. */
@@ -145,22 +178,6 @@ int64_t gaml_hip_pacbio_records(gaml_hip_ctx* ctx, int readset, const int32_t* s
 /* last ingest: {SAM records, DP jobs, DP rows, DP cells, kernel ms (HIP events), host parse+prepare ms,
  * upload+kernel+download ms, scratch bytes} */
 int gaml_hip_pacbio_dp_stats(gaml_hip_ctx* ctx, int readset, double* out8);
-/* host-only introspection (no device needed): how one SAM line is parsed
- * ({flags,len,posstart,posend,sstart,send,slen,tstart,tend,edit_dist}) and which DP cells it gets
- * (rows row0.., one column interval per row). Returns the number of rows, <0 on a malformed line. */
-/* the banded DP of one SAM line against an explicit target string ("path + '\n' + reverse
- * complement") and read, on the GPU: what AligmentProbability (graph.cc:2175-2297) returns, as a
- * log.  Returns the number of DP rows (<0: error); when band_lo/band_hi hold at least that many
- * entries they receive the column interval per row that the kernel derived from the CIGAR. */
-int gaml_hip_debug_sam_logprob(gaml_hip_ctx* ctx, const char* target, int32_t target_len, const char* read, int32_t read_len,
-                               const char* sam_line, int64_t sam_len, double mismatch_prob, double* logprob_out,
-                               int32_t* band_lo, int32_t* band_hi, int32_t band_cap);
-/* host-only: what the DP kernel is given for one SAM line: {n_ops, row_f, col_f, bl, el, max_width}
- * and the run-length CIGAR ((length << 2) | code, 0 = M, 1 = I, 2 = D). Returns n_ops, <0 on a malformed line. */
-int gaml_hip_debug_sam_shape(const char* sam_line, int64_t len, int32_t total_len, int32_t* out6, uint32_t* ops, int32_t cap);
-int32_t gaml_hip_debug_sam_band(const char* sam_line, int64_t len, int32_t total_len, int32_t* fields10, int32_t* row0,
-                                int32_t* lo, int32_t* hi, int32_t cap);
-
 /* ---- the hot path ------------------------------------------------------------------ */
 /* ProbCalculator::CalcProb(paths, zeros, total_len) (prob_calculator.h:63-109):
  * paths = flattened node ids (>= 0) / gaps (< 0), path_offs[n_paths+1].
@@ -298,38 +315,9 @@ int64_t gaml_hip_window_records(gaml_hip_ctx* ctx, int readset, int mate, const 
                                 gaml_aligment* out, int64_t cap);
 /* force alignment of one window with the library's own aligner (AlignSubpathInternal graph.cc:839-899) */
 int64_t gaml_hip_align_window(gaml_hip_ctx* ctx, int readset, int mate, const int32_t* subpath, int32_t subpath_len);
-/* Host-side half of an evaluation WITHOUT touching the device (works on a host-only context):
- * window registration + alignment of missing windows + window-occurrence lists for `paths`,
- * exactly what gaml_hip_calc_* does before it launches. For tests of the host logic. */
-int gaml_hip_debug_prepare(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths);
-/* occurrence list of the last prepare/evaluation: 5 ints per entry {window id, shift, min_pos,
- * path, rank}; returns the number of entries. */
-int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int32_t* out5, int64_t cap);
-/* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
-int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
-/* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list}.
- * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables). */
-int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out3);
 /* GPU window aligner (cold path): windows aligned on the device so far, seed candidates extended, wall time.
- * Knob 5 = 1 (gaml_hip_debug_set_knob) forces the host aligner. */
+ * Knob 5 = 1 (gaml_hip_debug_set_knob, gaml_hip_debug.h) forces the host aligner. */
 int gaml_hip_aligner_stats(gaml_hip_ctx* ctx, int64_t* windows, int64_t* candidates, double* microseconds);
-/* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner), [1] thresholds +
- * occurrence tables, [2] (unused, 0), [3] packing the staging slot, [4] delta uploads, [5] kernel launches (prep kernel:
- * table copy + memo; scoring kernel), [6] bytes of per-call tables, [7] wait for the device */
-int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
-/* tuning experiments (tools/kbench.py): 0 = compact-path grid cap, 1 = dynamic LDS bytes, 2 = finish mode (1 ticket,
- * 2 finisher kernel), 3 = timing-only ablation, 4 = 1: no floor/log memo, 5 = 1: host window aligner, 6 = 1: no delta list,
- * 7 = 1: always wait with hipStreamSynchronize (no spinning on the pinned partials), 8 = 1: per-call uploads by
- * hipMemcpyAsync instead of the copy kernels, 11 = 1: two-pairs-per-iteration compact body */
-/* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
- * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
- * number of waves copied. Tuning aid (tools/kernel_timeline.py). */
-int gaml_hip_debug_timeline(gaml_hip_ctx* ctx, int rs, unsigned long long* out, int64_t cap_waves);
-
-int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
-/* pairs per record-count class of the device table {<=1, <=2, <=4, more} (paired sets) */
-int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);
-
 /* timing of the last scoring call, microseconds: [0] host preparation (window registration,
  * alignment of new windows, occurrence tables), [1] H2D + kernels + D2H wall, [2] device time
  * of the scoring kernels measured with HIP events on the library's stream (0 if events off). */

@@ -1,0 +1,68 @@
+/* gaml_hip_debug.h -- test, tuning and tracing entry points of libgaml_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/gaml_hip.h): nothing here replaces a reference interface. These entry
+ * points expose intermediate state to the parity tests (tests/), the tuning tools (tools/) and bench.py's reporting;
+ * a caller that only wants ProbCalculator::CalcProb never includes this file.
+ */
+#ifndef GAML_HIP_DEBUG_H_
+#define GAML_HIP_DEBUG_H_
+
+#include "gaml_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- PacBio SAM ingestion, piece by piece ------------------------------------------------------ */
+/* host-only introspection (no device needed): how one SAM line is parsed
+ * ({flags,len,posstart,posend,sstart,send,slen,tstart,tend,edit_dist}) and which DP cells it gets
+ * (rows row0.., one column interval per row). Returns the number of rows, <0 on a malformed line. */
+/* the banded DP of one SAM line against an explicit target string ("path + '\n' + reverse
+ * complement") and read, on the GPU: what AligmentProbability (graph.cc:2175-2297) returns, as a
+ * log.  Returns the number of DP rows (<0: error); when band_lo/band_hi hold at least that many
+ * entries they receive the column interval per row that the kernel derived from the CIGAR. */
+int gaml_hip_debug_sam_logprob(gaml_hip_ctx* ctx, const char* target, int32_t target_len, const char* read, int32_t read_len,
+                               const char* sam_line, int64_t sam_len, double mismatch_prob, double* logprob_out,
+                               int32_t* band_lo, int32_t* band_hi, int32_t band_cap);
+/* host-only: what the DP kernel is given for one SAM line: {n_ops, row_f, col_f, bl, el, max_width}
+ * and the run-length CIGAR ((length << 2) | code, 0 = M, 1 = I, 2 = D). Returns n_ops, <0 on a malformed line. */
+int gaml_hip_debug_sam_shape(const char* sam_line, int64_t len, int32_t total_len, int32_t* out6, uint32_t* ops, int32_t cap);
+int32_t gaml_hip_debug_sam_band(const char* sam_line, int64_t len, int32_t total_len, int32_t* fields10, int32_t* row0,
+                                int32_t* lo, int32_t* hi, int32_t cap);
+
+/* ---- host-side half of an evaluation ----------------------------------------------------------- */
+/* Host-side half of an evaluation WITHOUT touching the device (works on a host-only context):
+ * window registration + alignment of missing windows + window-occurrence lists for `paths`,
+ * exactly what gaml_hip_calc_* does before it launches. For tests of the host logic. */
+int gaml_hip_debug_prepare(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths);
+/* occurrence list of the last prepare/evaluation: 5 ints per entry {window id, shift, min_pos,
+ * path, rank}; returns the number of entries. */
+int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int32_t* out5, int64_t cap);
+/* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
+int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
+/* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list}.
+ * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables). */
+int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out3);
+
+/* ---- tuning ------------------------------------------------------------------------------------- */
+/* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner), [1] thresholds +
+ * occurrence tables, [2] (unused, 0), [3] packing the staging slot, [4] delta uploads, [5] kernel launches (prep kernel:
+ * table copy + memo; scoring kernel), [6] bytes of per-call tables, [7] wait for the device */
+int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
+/* tuning experiments (tools/kbench.py): 0 = compact-path grid cap, 1 = dynamic LDS bytes, 2 = finish mode (1 ticket,
+ * 2 finisher kernel), 3 = timing-only ablation, 4 = 1: no floor/log memo, 5 = 1: host window aligner, 6 = 1: no delta list,
+ * 7 = 1: always wait with hipStreamSynchronize (no spinning on the pinned partials), 8 = 1: per-call uploads by
+ * hipMemcpyAsync instead of the copy kernels, 11 = 1: two-pairs-per-iteration compact body */
+/* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
+ * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
+ * number of waves copied. Tuning aid (tools/kernel_timeline.py). */
+int gaml_hip_debug_timeline(gaml_hip_ctx* ctx, int rs, unsigned long long* out, int64_t cap_waves);
+
+int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
+/* pairs per record-count class of the device table {<=1, <=2, <=4, more} (paired sets) */
+int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAML_HIP_DEBUG_H_ */

@@ -10,15 +10,22 @@
 //       friend class ProbCalculator;
 // to both classes (INTEGRATION.md shows the two-line patch). Nothing else in GAML is touched.
 //
-// NOT compile-tested in the build container: graph.h needs Boost, which the image lacks (see
-// DESIGN.md "Oracle"); gaml_amd/host/gaml_host.h is the same logic over stand-alone mirrors of
-// these classes and IS built and tested.
+// Several GPUs: the device list comes from the environment (GAML_HIP_DEVICES=all | 0,1,2,...; unset: device 0) --
+// gaml_hip_create_from_env. With more than one device the context shards the reads over them inside the library
+// (one host thread per device, one RCCL all-reduce of the per-readset sums per CalcProb); this header does not change.
+//
+// Compile-tested: tests/test_gpu_adapter.py builds tests/mock_ref/adapter_driver.cc, which includes THIS header over a
+// test-only declaration mock of the graph.h members used below (tests/mock_ref/graph.h), and runs all three CalcProb
+// overloads against the ctypes value. The reference's own graph.h needs Boost, which the image lacks (DESIGN.md
+// "Oracle"), so the real gaml.cc is not built here; gaml_amd/host/gaml_host.h is the same logic over stand-alone
+// mirrors of these classes.
 #ifndef PROB_CALCULATOR_H__
 #define PROB_CALCULATOR_H__
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <fstream>
 #include <iterator>
 
@@ -106,7 +113,7 @@ class ProbCalculator {
     exit(1);  // the reference's convention for unrecoverable errors (assert / exit code)
   }
   void Build() {
-    if (gaml_hip_create(&ctx_, 0) != GAML_HIP_OK) { ctx_ = NULL; Die("gaml_hip_create (no HIP device?)"); }
+    if (gaml_hip_create_from_env(&ctx_) != GAML_HIP_OK) { ctx_ = NULL; Die("gaml_hip_create_from_env (no HIP device? GAML_HIP_DEVICES?)"); }
     string bases;
     vector<int64_t> offs(1, 0);
     for (size_t i = 0; i < gr.nodes.size(); i++) { bases += gr.nodes[i]->s; offs.push_back((int64_t)bases.size()); }
@@ -172,11 +179,12 @@ class ProbCalculator {
   }
   string RunBlasr(PacbioReadSet* rs, const vector<int32_t>& sub) {
     extern string gBlasrPath;  // gaml.cc:30
-    char tmpname1[L_tmpnam + 6], tmpname2[L_tmpnam + 6], tmpname3[L_tmpnam];
-    tmpnam(tmpname1); strcat(tmpname1, ".fas");
-    tmpnam(tmpname2); strcat(tmpname2, ".fq");
-    tmpnam(tmpname3);
-    FILE* f = fopen(tmpname1, "w");
+    // (the reference uses tmpnam, graph.cc:2653-2658; a private directory avoids its race and is removed whole)
+    char dir[] = "/tmp/gaml_hip_pbXXXXXX";
+    if (!mkdtemp(dir)) Die("mkdtemp");
+    const string fas = string(dir) + "/path.fas", fq = string(dir) + "/reads.fq", out = string(dir) + "/blasr.sam";
+    FILE* f = fopen(fas.c_str(), "w");
+    if (!f) Die("fopen of the path file");
     fprintf(f, ">tmp\n");
     for (size_t i = 0; i < sub.size(); i++) {
       if (sub[i] < 0) for (int j = 0; j < -sub[i]; j++) fputc('N', f);
@@ -187,16 +195,22 @@ class ProbCalculator {
     string reads_filename = rs->filename_;
     unordered_set<int> read_filter;  // reads anchored on the stretch's nodes (graph.cc:2690-2701)
     for (size_t i = 0; i < sub.size(); i++)
-      if (sub[i] >= 0)
+      if (sub[i] >= 0 && rs->anchors_cache_.count(sub[i]))
         for (auto it = rs->anchors_cache_[sub[i]].begin(); it != rs->anchors_cache_[sub[i]].end(); ++it) read_filter.insert(*it);
-    if (!read_filter.empty()) { rs->FilterReads(tmpname2, read_filter); reads_filename = tmpname2; }
-    string cmd = gBlasrPath + "/blasr " + reads_filename + " " + tmpname1 +
-                 " -sam -sdpTupleSize 8 -guidedAlignBandSize 100 -nCandidates 50 -minMatch 11 -nproc 16 >" + tmpname3;
-    if (system(cmd.c_str()) != 0) Die("blasr");
-    ifstream fi(tmpname3);
-    string sam((std::istreambuf_iterator<char>(fi)), std::istreambuf_iterator<char>());
-    remove(tmpname1);
-    remove(tmpname3);
+    if (!read_filter.empty()) { rs->FilterReads(fq, read_filter); reads_filename = fq; }
+    string cmd = gBlasrPath + "/blasr " + reads_filename + " " + fas +
+                 " -sam -sdpTupleSize 8 -guidedAlignBandSize 100 -nCandidates 50 -minMatch 11 -nproc 16 >" + out;
+    const int rc = system(cmd.c_str());
+    string sam;
+    {
+      ifstream fi(out.c_str());
+      sam.assign((std::istreambuf_iterator<char>(fi)), std::istreambuf_iterator<char>());
+    }
+    remove(fas.c_str());
+    remove(fq.c_str());
+    remove(out.c_str());
+    rmdir(dir);
+    if (rc != 0) Die("blasr");
     return sam;
   }
   vector<int> pacbio_handles_;

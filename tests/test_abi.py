@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "gaml_hip.h")).read()
+def declared_symbols(header="gaml_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(gaml_hip_[a-z_0-9]+)\s*\(", text)))
 
@@ -22,6 +22,25 @@ def test_every_declared_symbol_is_exported(built):
     assert len(names) >= 30
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
+    # the drop-in header carries no debug surface; that lives in gaml_hip_debug.h (tests / tools only) -- also exported
+    assert not [n for n in names if "_debug_" in n]
+    dbg = declared_symbols("gaml_hip_debug.h")
+    assert len(dbg) >= 10 and all("_debug_" in n for n in dbg)
+    assert not [n for n in dbg if not hasattr(lib, n)]
+
+
+def test_library_was_built_from_this_tree(built):
+    """gaml_hip_version() carries the hash of the sources the .so was built from (csrc/Makefile: SRC_HASH): the GPU box
+    receives the prebuilt library, this is how a stale one is noticed."""
+    import hashlib
+    from gaml_amd import api
+    rel = ["gaml_amd/csrc/kernels.hip.h", "gaml_amd/csrc/aligner.hip.h", "gaml_amd/csrc/pacbio_dp.hip.h", "gaml_amd/csrc/ctx.hip.h",
+           "gaml_amd/csrc/internal.h", "gaml_amd/csrc/gaml_hip.hip", "gaml_amd/csrc/multi.hip", "gaml_amd/csrc/host_model.h",
+           "gaml_amd/csrc/host_model.cc", "include/gaml_hip.h", "include/gaml_hip_debug.h"]
+    h = hashlib.sha256()
+    for r in rel:
+        h.update(open(os.path.join(ROOT, r), "rb").read())
+    assert api.version().endswith("src " + h.hexdigest()[:16]), api.version()
 
 
 def test_record_layouts_match_the_reference_structs(built):

@@ -10,36 +10,7 @@ from gaml_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _moves(rng, paths, g):
-    """One random edit of the kind GAML's move generators make."""
-    paths = [list(p) for p in paths]
-    kind = rng.integers(0, 6)
-    i = int(rng.integers(0, len(paths)))
-    p = paths[i]
-    if kind == 0 and len(p) > 3:  # BreakPath
-        c = int(rng.integers(1, len(p) - 1))
-        paths[i:i + 1] = [p[:c], p[c:]]
-    elif kind == 1 and len(paths) > 1:  # join two paths, sometimes over a gap (ExtendPaths / FixGapLength)
-        j = int(rng.integers(0, len(paths)))
-        if j != i:
-            gap = [-int(rng.integers(20, 400))] if rng.random() < 0.5 else []
-            q = paths[j]
-            paths[i] = p + gap + q
-            del paths[j]
-    elif kind == 2:  # reverse a path (the same sequence on the other strand)
-        paths[i] = [x ^ 1 if x >= 0 else x for x in reversed(p)]
-    elif kind == 3 and len(p) > 6:  # LocalChange: drop a short stretch, bridge it by a gap
-        a = int(rng.integers(1, len(p) - 4))
-        b = a + int(rng.integers(1, 3))
-        removed = sum(g.node_len(x) if x >= 0 else -x for x in p[a:b])
-        paths[i] = p[:a] + [-max(1, removed)] + p[b:]
-    elif kind == 4 and len(p) > 4:  # duplicate a node (repeat resolution attempts)
-        a = int(rng.integers(1, len(p) - 1))
-        if p[a] >= 0:
-            paths[i] = p[:a] + [p[a]] + p[a:]
-    elif kind == 5 and len(p) > 2:  # trim an end
-        paths[i] = p[1:] if rng.random() < 0.5 else p[:-1]
-    return [q for q in paths if q]
+_moves = synth.sa_move  # one random edit of the kind GAML's move generators make (shared with bench.py / tools)
 
 
 @pytest.mark.parametrize("penalty", [0.0, 0.0002])

@@ -8,6 +8,9 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.getcwd())
+from bench import source_hash  # the sources the profile was taken on: bench.py prints roofline.traffic only when it matches
+
 tag = sys.argv[1]
 root = f"gpurun_out/prof_{tag}"
 
@@ -38,7 +41,8 @@ if "FETCH_SIZE_KB_mean" in res and "WRITE_SIZE_KB_mean" in res:
     res["hbm_bytes_per_launch"] = (2 * res["FETCH_SIZE_KB_mean"] + res["WRITE_SIZE_KB_mean"]) * 1024
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --no-cpu-baseline "
-               "--steps 24 --warmup 24 (cfg3; last 24 dispatches = timed steps)",
+               "--no-extras --steps 24 --warmup 24 (cfg3; last 24 dispatches = timed steps)",
+    "source_hash": source_hash(),
     "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM); counter unit KiB",
     "round": tag,
     "kernels": {"paired_score_kernel": res},
