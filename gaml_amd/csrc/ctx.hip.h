@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <immintrin.h>
 #include <memory>
 #include <set>
 #include <string>
@@ -77,6 +78,27 @@ struct Staging {
   int next = 0;
 };
 
+// Per-call tables of a paired set: a ring of device slots. On a large-BAR device the host writes a slot directly
+// (fine-grained device memory behind the PCIe BAR); otherwise through the pinned twin + a copy (paired_launch.hip.h).
+struct Arena {
+  void* dev[kRing] = {};
+  size_t cap[kRing] = {};
+  bool direct[kRing] = {};
+  PinBuf host[kRing];
+  hipEvent_t done[kRing] = {};
+  bool armed[kRing] = {};
+  int next = 0;
+  void release() {
+    for (int k = 0; k < kRing; k++) {
+      if (dev[k]) (void)hipFree(dev[k]);
+      dev[k] = nullptr; cap[k] = 0;
+      host[k].release();
+      if (done[k]) (void)hipEventDestroy(done[k]);
+      done[k] = nullptr; armed[k] = false;
+    }
+  }
+};
+
 struct Reducer {  // per read set: partials + ticket + 2-double result
   DevBuf part_sum, part_zero, ticket, out;
   hipError_t init() {
@@ -117,8 +139,7 @@ struct PairedSet {
   PairTables pt;                      // device order + compact / 16-byte record tables (cold path)
   MateDev dev[2];
   DevBuf rec8[2], len_code, len_combo, inl[2], combo_tabs, memo;
-  double lt_two_T = -1;   // 2T the memo table was last built for (-1: stale)
-  int lt_codes = 0;
+  int memo_codes = 0;     // length combinations the memo of pair terms covers (0: no memo); rebuilt with the tables
   // delta since the last full table build: pairs whose record lists gained records of newly
   // activated windows. Their complete lists (device-table order: window id, position) travel with
   // every evaluation; a full rebuild folds them back in when they become too many.
@@ -140,10 +161,13 @@ struct PairedSet {
   int quiet_calls = 0;       // evaluations since the last window activation
   bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
   PinBuf h_timeline; int timeline_waves = 0;  // ablation 8 (tools/kernel_timeline.py)
-  PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls)
-  int last_total_blocks = 0;
+  PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls): [set][block]
+  size_t host_part_stride = 0;        // entries per set
+  int last_total_blocks = 0, last_sets = 1;
   bool last_host_partials = false;
-  DevBuf len12, probs, tabs, occ_arena, cov_bits, bad;
+  DevBuf len12, probs, tabs, cov_bits, bad;
+  Arena arena;                        // per-call tables (occurrence images, thresholds, coverage layout)
+  size_t batch_slack = 0;             // extra bytes per path set region of a batch (grows when a set's tables did not fit)
   DevBuf gen_bits;  // one bit per table-class slot: needs paired_general_kernel (written by the main kernel)
   hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;
   PairedPlanner planner;
@@ -154,7 +178,6 @@ struct PairedSet {
   bool floor_positive = true;  // every floor exp(c + k s) > 0 (else "probability 0 is floored" does not hold: no memo / shortcut paths)
   bool tabs_uploaded = false;
   int64_t last_bad_bases = 0;
-  Staging stage;
 };
 
 struct SingleSet {
@@ -203,7 +226,8 @@ struct PacbioSet {
 struct PairedPrep {
   int64_t assembled_records = 0;  // records the reference would touch in GetPositionsOnlyPath
   std::vector<int32_t> path_base, start_off, starts;
-  int32_t total_bits = 0;
+  int32_t total_bits = 0, n_paths = 0;
+  bool general = false;           // some window occurs several times in this path set: paired_general_kernel runs too
 };
 
 struct SetRef { int kind, idx; };
@@ -233,6 +257,7 @@ struct gaml_hip_ctx {
   double aln_stage_us[5] = {0, 0, 0, 0, 0};  // window strings + upload, spans + candidates, extension, D2H of hits, sort + finalize
   int64_t aln_batches = 0;
   int knobs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
+  bool direct_write = false;  // large-BAR device: the host writes per-call tables straight into device memory (Arena)
   int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;
   // timing

@@ -104,16 +104,20 @@ int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
 
 // layout of one OccTable inside an arena
 struct OccLayout { size_t direct, multi_off, multi, end; };
-OccLayout layout_image(const OccImage& t, size_t at) {  // `direct` holds the 12-byte entries here
+// n_entries > the image's window count: the table is padded with "does not occur" entries (a batch: windows that later
+// path sets of the same batch add must read as absent in the earlier sets' tables)
+OccLayout layout_image(const OccImage& t, size_t at, size_t n_entries = 0) {  // `direct` holds the 12-byte entries here
   OccLayout l;
   l.direct = at;
-  l.multi_off = (l.direct + std::max<size_t>(1, t.occ12.size()) * sizeof(Occ12) + 15) & ~(size_t)15;
+  l.multi_off = (l.direct + std::max<size_t>(1, std::max(n_entries, t.occ12.size())) * sizeof(Occ12) + 15) & ~(size_t)15;
   l.multi = (l.multi_off + t.multi_off.size() * sizeof(int32_t) + 15) & ~(size_t)15;
   l.end = (l.multi + std::max<size_t>(1, t.multi.size()) * sizeof(OccQuad) + 15) & ~(size_t)15;
   return l;
 }
 void pack_image(const OccImage& t, const OccLayout& l, char* base) {
   if (!t.occ12.empty()) memcpy(base + l.direct, t.occ12.data(), t.occ12.size() * sizeof(Occ12));
+  const size_t used = l.direct + t.occ12.size() * sizeof(Occ12);
+  if (l.multi_off > used) memset(base + used, 0xff, l.multi_off - used);  // padding entries: all ones = the window does not occur
   memcpy(base + l.multi_off, t.multi_off.data(), t.multi_off.size() * sizeof(int32_t));
   if (!t.multi.empty()) memcpy(base + l.multi, t.multi.data(), t.multi.size() * sizeof(OccQuad));
 }
@@ -170,592 +174,11 @@ std::vector<Walk> unflatten(const int32_t* flat, const int64_t* offs, int32_t n)
   return r;
 }
 
-// ---------------------------------------------------------------------------------------
-// paired read set: host preparation + launch (CalcScoreForPathsNew graph.cc:1952-1989,
-// evaluated from scratch)
-// ---------------------------------------------------------------------------------------
-int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
-  if (s.tabs_uploaded) return 0;
-  const double c0 = s.cfg.min_prob_start, k0 = s.cfg.min_prob_per_base;
-  // The reference tabulates GetInsertProbability for d < mean + 5 sd (graph.cc:1801-1804) and calls
-  // the same function directly beyond (:1877-1882). Same formula, so one host table serves both;
-  // it is extended until the f64 value is exactly 0.0 (exp underflows at z ~ 38.6; it is
-  // monotone beyond the mean, so everything further is 0.0 too). No exp() on the device.
-  auto ins = [&](int d) {
-    double z = ((double)d - s.cfg.insert_mean) / s.cfg.insert_std;  // graph.cc:1593-1598
-    return std::exp(-z * z / 2.0) / (std::sqrt(2 * M_PI) * s.cfg.insert_std);
-  };
-  const int kInsCap = 1 << 22;
-  s.ins_tab.clear();
-  for (int d = 0; d < kInsCap; d++) {
-    double v = ins(d);
-    if (v == 0.0 && (double)d > s.cfg.insert_mean) break;
-    s.ins_tab.push_back(v);
-  }
-  if ((int)s.ins_tab.size() >= kInsCap)
-    return fail(c, GAML_HIP_EINVAL, "insert_std too large: the insert-size table would exceed 4M entries");
-  int smax = s.mate[0].max_len + s.mate[1].max_len;
-  s.floor_tab.resize(smax + 1);
-  s.logfloor_tab.resize(smax + 1);
-  for (int v = 0; v <= smax; v++) {
-    s.floor_tab[v] = std::exp(c0 + k0 * v);          // graph.cc:1506-1507
-    s.logfloor_tab[v] = std::log(s.floor_tab[v]);    // graph.cc:1510-1512 on a floored read
-    if (!(s.floor_tab[v] > 0.0)) s.floor_positive = false;  // exp underflow: the reference then takes log(0) for a read without alignment
-  }
-  s.covthr_tab.resize(s.mate[1].max_len + 1);
-  for (int v = 0; v <= s.mate[1].max_len; v++) s.covthr_tab[v] = std::exp(c0 + k0 * (v + v));  // graph.cc:1855-1857
-  size_t total = s.ins_tab.size() + s.floor_tab.size() + s.logfloor_tab.size() + s.covthr_tab.size();
-  HIP_TRY(c, s.tabs.reserve(std::max<size_t>(1, total) * sizeof(double)));
-  double* d = s.tabs.as<double>();
-  size_t at = 0;
-  auto up = [&](const std::vector<double>& v) -> hipError_t {
-    hipError_t e = v.empty() ? hipSuccess : hipMemcpy(d + at, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
-    at += v.size();
-    return e;
-  };
-  HIP_TRY(c, up(s.ins_tab));
-  HIP_TRY(c, up(s.floor_tab));
-  HIP_TRY(c, up(s.logfloor_tab));
-  HIP_TRY(c, up(s.covthr_tab));
-  const int64_t n = s.mate[0].n_local();
-  HIP_TRY(c, s.len12.reserve(std::max<size_t>(1, n) * sizeof(uint32_t)));
-  HIP_TRY(c, s.probs.reserve(std::max<size_t>(1, n) * sizeof(double)));
-  HIP_TRY(c, s.red.init());
-  HIP_TRY(c, s.bad.reserve(sizeof(unsigned long long)));
-  s.tabs_uploaded = true;
-  return 0;
-}
+}  // namespace
 
+#include "paired_launch.hip.h"
 
-// pass 1: window registration / alignment of missing windows and the placement of cached windows
-// (memoised per distinct path: PairedPlanner)
-void prepare_paired_structure(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p) {
-  (void)p;
-  s.planner.begin(c->g, s.mate, paths);
-}
-
-// pass 2: position-filter thresholds (need the windows' global largest positions) + device tables
-void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
-  (void)c;
-  static const bool trace = getenv("GAML_HIP_TRACE_HOST") != nullptr;
-  const double q0 = now_us();
-  s.planner.finish(s.mate);
-  const double q1 = now_us();
-  const PlanView& v = s.planner.view();
-  const bool cov = s.cfg.penalty_constant > 0;
-  // coverage bitmap layout + contig starts (events of type 1, graph.cc:1826,1833-1835)
-  p.path_base.assign(1, 0);
-  p.start_off.assign(1, 0);
-  p.starts.clear();
-  if (cov) {  // only the coverage sweep reads these
-    p.path_base.reserve(v.paths.size() + 1);
-    p.start_off.reserve(v.paths.size() + 1);
-    for (const PathMemo* pm : v.paths) {
-      p.starts.insert(p.starts.end(), pm->starts.begin(), pm->starts.end());
-      p.start_off.push_back((int32_t)p.starts.size());
-      int32_t bits = ((pm->length + 64 + 31) / 32) * 32;  // one bit per path position, padded to words (+ slack)
-      p.path_base.push_back(p.path_base.back() + bits);
-    }
-  }
-  p.total_bits = p.path_base.back();
-  const double q2 = now_us();
-  p.assembled_records = 0;
-  for (int mt = 0; mt < 2; mt++) {
-    s.image[mt].build(s.mate[mt].wins.size(), v, mt);  // sized to the final window count
-    for (const PathMemo* pm : v.paths) p.assembled_records += pm->assembled[mt];
-  }
-  if (trace) fprintf(stderr, "pass2: finish %.1f us, starts %.1f us, images %.1f us\n", q1 - q0, q2 - q1, now_us() - q2);
-}
-
-void prepare_paired_host(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p) {
-  prepare_paired_structure(c, s, paths, p);
-  prepare_paired_tables_host(c, s, p);
-}
-
-int launch_paired(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths, PairedPrep& p, int32_t total_len, hipStream_t st, double* out4) {
-  if (int e = prepare_paired_tables(c, s)) return e;
-  const double tp0 = now_us();
-  prepare_paired_tables_host(c, s, p);  // pass 2 (pass 1 ran in eval_begin)
-  const double t_after_host = now_us();
-  c->prof[1] = t_after_host - tp0;  // thresholds + occurrence tables
-  bool need_full = s.dev[0].pow_n == 0;
-  const bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
-  s.quiet_calls = activated_now ? 0 : s.quiet_calls + 1;
-  // the cache has settled (no activation for a while) but pairs still sit on the slower delta path: fold them in
-  // A rebuild costs ~30 ms at 833 k pairs, a pair on the delta path ~0.4 ns per evaluation (one lane per pair). In an
-  // annealing run new junction windows appear every few calls, so folding after a short quiet spell
-  // (as an earlier version did after 16 calls) rebuilt 8 times per 1000 iterations for nothing;
-  // 64 quiet calls mean the path set has stopped producing new windows (steady re-scoring).
-  if (!need_full && !activated_now && !s.dirty.empty() && (s.quiet_calls >= 64 || s.compact_requested) && c->knobs[6] != 2) need_full = true;
-  s.compact_requested = false;
-  if (!need_full && (s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation)) {
-    // Windows were activated since the tables were built. Few new records: keep the tables, put the
-    // affected pairs on the delta list. Many: rebuild.
-    const int64_t np = s.mate[0].n_local();
-    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / 8);
-    size_t new_records = 0;
-    for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
-    if (s.dirty.size() + new_records > limit) need_full = true;
-    else {
-      auto base_records = [&](int32_t slot, int mt, std::vector<RecQuad>& out) {
-        // the pair's records as the device tables hold them (activated before the last full build)
-        const int64_t n0s = s.pt.class_count[0];
-        if (slot < n0s) {
-          const uint64_t r = s.pt.rec8[mt][slot];
-          if (r != kNoRec8) out.push_back(RecQuad{(int32_t)(r & 0xffffff), (int32_t)((r >> 24) & 0xfffffff), (int32_t)((r >> 52) & 63) | ((int32_t)((r >> 58) & 1) << 8), 0});
-        } else {
-          const RecQuad& f = s.pt.rm[mt].first[slot - n0s];
-          if (f.wid >= 0) {
-            const int cnt1 = 1 + (int)((uint32_t)f.flags >> 9);
-            for (int q = 0; q < cnt1; q++) { RecQuad r = q == 0 ? f : s.pt.rm[mt].extra[f.link + q - 1]; r.flags &= 0x1ff; r.link = 0; out.push_back(r); }
-          }
-        }
-      };
-      for (int mt = 0; mt < 2; mt++) {
-        const ShortMate& m = s.mate[mt];
-        for (int32_t w : m.activated_log) {
-          const Window& win = m.wins[w];
-          for (int64_t k = win.first; k < win.first + win.count; k++) {
-            const gaml_aligment& r = m.pool[k];
-            const int32_t slot = s.pt.slot_of_read[r.read_id];
-            auto it = s.dirty_index.find(slot);
-            if (it == s.dirty_index.end()) {
-              it = s.dirty_index.emplace(slot, (int32_t)s.dirty.size()).first;
-              s.dirty.emplace_back();
-              s.dirty.back().slot = slot;
-              base_records(slot, 0, s.dirty.back().recs[0]);
-              base_records(slot, 1, s.dirty.back().recs[1]);
-            }
-            s.dirty_touched.push_back(it->second);
-            auto& lst = s.dirty[it->second].recs[mt];
-            RecQuad q{w, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
-            // keep the device-table order: (window id, position)
-            auto pos = std::upper_bound(lst.begin(), lst.end(), q, [](const RecQuad& x, const RecQuad& y) { return x.wid != y.wid ? x.wid < y.wid : x.pos < y.pos; });
-            lst.insert(pos, q);
-          }
-        }
-      }
-      for (int mt = 0; mt < 2; mt++) { s.mate[mt].activated_log.clear(); s.dev[mt].uploaded_generation = s.mate[mt].active_generation; }
-      s.delta_updates++;
-    }
-  }
-  if (need_full) {
-    s.dirty.clear();
-    s.dirty_index.clear();
-    s.dirty_marked = 0;
-    s.dirty_touched.clear(); s.spill_of.clear(); s.spill_pairs.clear(); s.spill_changed = false;
-    s.full_rebuilds++;
-    for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
-    // cold path: the set of activated windows of either mate changed -> new device order of the
-    // pairs, record tables rebuilt on the host and uploaded
-    const double tb0 = now_us();
-    build_pair_tables(s.mate[0], s.mate[1], s.pt);
-    const double tb1 = now_us();
-    HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old tables
-    auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
-      hipError_t e = d.reserve(std::max<size_t>(16, bytes));
-      if (e != hipSuccess || bytes == 0) return e;
-      return hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice);
-    };
-    for (int mt = 0; mt < 2; mt++) {
-      MateDev& d = s.dev[mt];
-      const ShortMate& m = s.mate[mt];
-      if (d.pow_n == 0) {
-        d.pow_n = m.match_pow.size();
-        HIP_TRY(c, d.pows.reserve(2 * d.pow_n * sizeof(double)));
-        HIP_TRY(c, hipMemcpy(d.pows.p, m.mismatch_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(d.pows.as<double>() + d.pow_n, m.match_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
-      }
-      HIP_TRY(c, up(s.rec8[mt], s.pt.rec8[mt].data(), s.pt.rec8[mt].size() * sizeof(uint64_t)));
-      HIP_TRY(c, up(d.first, s.pt.rm[mt].first.data(), s.pt.rm[mt].first.size() * sizeof(RecQuad)));
-      HIP_TRY(c, up(d.extra, s.pt.rm[mt].extra.data(), s.pt.rm[mt].extra.size() * sizeof(RecQuad)));
-      HIP_TRY(c, up(s.inl[mt], s.pt.inl[mt].data(), s.pt.inl[mt].size() * sizeof(RecQuad)));
-      d.uploaded_generation = m.active_generation;
-    }
-    HIP_TRY(c, up(s.len_code, s.pt.len_code.data(), s.pt.len_code.size()));
-    HIP_TRY(c, up(s.len_combo, s.pt.len_combo.data(), s.pt.len_combo.size() * sizeof(uint32_t)));
-    HIP_TRY(c, up(s.len12, s.pt.len12.data(), s.pt.len12.size() * sizeof(uint32_t)));
-    // per length-combination tables of the compact path: [pe mate 0 | pe mate 1 | floor | logfloor | covthr]
-    {
-      const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
-      std::vector<double> t(nc * 64 * 2 + nc * 3, 0.0);
-      for (size_t ci = 0; ci < s.pt.len_combo.size(); ci++) {
-        const int L[2] = {(int)(s.pt.len_combo[ci] & 0xffff), (int)(s.pt.len_combo[ci] >> 16)};
-        for (int mt = 0; mt < 2; mt++)
-          for (int e = 0; e < 64 && e <= L[mt]; e++)
-            t[(size_t)mt * nc * 64 + ci * 64 + e] = s.mate[mt].mismatch_pow[e] * s.mate[mt].match_pow[L[mt] - e];  // graph.cc:1859-1863
-        t[2 * nc * 64 + ci] = s.floor_tab[L[0] + L[1]];
-        t[2 * nc * 64 + nc + ci] = s.logfloor_tab[L[0] + L[1]];
-        t[2 * nc * 64 + 2 * nc + ci] = s.covthr_tab[L[1]];
-      }
-      HIP_TRY(c, up(s.combo_tabs, t.data(), t.size() * sizeof(double)));
-      s.lt_two_T = -1;
-    }
-    if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "rebuild: tables on the host %.1f ms, uploads %.1f ms\n", (tb1 - tb0) * 1e-3, (now_us() - tb1) * 1e-3);
-  }
-
-  const bool cov = s.cfg.penalty_constant > 0;
-  OccLayout l0 = layout_image(s.image[0], 0);
-  OccLayout l1 = layout_image(s.image[1], l0.end);
-  size_t meta = l1.end;
-  size_t pb_off = meta, so_off = 0, st_off = 0, total = meta;
-  if (cov) {
-    so_off = align16(pb_off + p.path_base.size() * sizeof(int32_t));
-    st_off = align16(so_off + p.start_off.size() * sizeof(int32_t));
-    total = align16(st_off + p.starts.size() * sizeof(int32_t));
-  }
-  // (Pairs with a record in a window that occurs several times: the main kernel notes them in a bitmap and
-  // paired_general_kernel scores them, see below. An earlier version listed them here on the host,
-  // O(records of such windows) per call -- 2.6 ms per call once an annealing run had produced many repeated nodes.)
-  const size_t nd = s.dirty.size();
-  const double tp1 = now_us();
-  c->prof[2] = tp1 - t_after_host;  // layout only (the host-built overflow list is gone)
-  void* host = nullptr;
-  int slot = stage_acquire(c, s.stage, total, &host);
-  if (slot < 0) return slot;
-  pack_image(s.image[0], l0, (char*)host);
-  pack_image(s.image[1], l1, (char*)host);
-  if (cov) {
-    memcpy((char*)host + pb_off, p.path_base.data(), p.path_base.size() * sizeof(int32_t));
-    memcpy((char*)host + so_off, p.start_off.data(), p.start_off.size() * sizeof(int32_t));
-    memcpy((char*)host + st_off, p.starts.data(), p.starts.size() * sizeof(int32_t));
-  }
-  // the arena is overwritten in stream order: earlier launches that read it have been enqueued
-  // before this copy on the same stream
-  if (total > s.occ_arena.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.occ_arena.reserve(total)); }
-  const double tp2 = now_us();
-  c->prof[3] = tp2 - tp1;  // staging memcpy
-  c->prof[6] = (double)total;
-  // (the arena upload itself goes out further down, in one launch with the memo: prep_kernel)
-  // delta pairs: a patch for the pairs whose lists changed in this evaluation (new windows were activated)
-  if (!s.dirty_touched.empty()) {
-    const int64_t np_all = s.mate[0].n_local();
-    if (s.delta_cap == 0) {  // sized once for the largest delta the rebuild policy allows: the store is never reallocated
-      s.delta_cap = (size_t)std::max<int64_t>(4096, np_all / 8) + 4096;
-      HIP_TRY(c, s.dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
-      HIP_TRY(c, s.dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
-      for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
-    }
-    if (nd > s.delta_cap) return fail(c, GAML_HIP_ESTATE, "delta store overflow (rebuild policy violated)");
-    std::sort(s.dirty_touched.begin(), s.dirty_touched.end());
-    s.dirty_touched.erase(std::unique(s.dirty_touched.begin(), s.dirty_touched.end()), s.dirty_touched.end());
-    s.spill_of.resize(nd, -1);
-    const size_t np_patch = s.dirty_touched.size();
-    void* ph = nullptr;
-    int pslot = stage_acquire(c, s.stage_delta, np_patch * sizeof(DeltaPatch), &ph);
-    if (pslot < 0) return pslot;
-    DeltaPatch* patch = (DeltaPatch*)ph;
-    for (size_t t = 0; t < np_patch; t++) {
-      const int32_t dj = s.dirty_touched[t];
-      const auto& d = s.dirty[dj];
-      DeltaPatch& pe = patch[t];
-      pe.dj = dj; pe.slot = d.slot; pe.pad = 0;
-      const bool lng = d.recs[0].size() > 4 || d.recs[1].size() > 4;
-      if (lng) {
-        if (s.spill_of[dj] < 0) { s.spill_of[dj] = (int32_t)s.spill_pairs.size(); s.spill_pairs.push_back(dj); }
-        s.spill_changed = true;
-      }
-      pe.spill = s.spill_of[dj];
-      for (int mt = 0; mt < 2; mt++)
-        for (int k = 0; k < 4; k++) {
-          const RecQuad none{-1, 0, 0, 0};
-          const RecQuad& r = (!lng && k < (int)d.recs[mt].size()) ? d.recs[mt][k] : none;
-          pe.rec[mt][k] = make_int4(r.wid, r.pos, r.flags, r.link);
-        }
-    }
-    HIP_TRY(c, s.dl_patch.reserve(np_patch * sizeof(DeltaPatch) + 1));
-    if (int e = stage_upload(c, s.stage_delta, pslot, s.dl_patch.p, np_patch * sizeof(DeltaPatch), st)) return e;
-    if (int e = stage_release(c, s.stage_delta, pslot, st)) return e;
-    hipLaunchKernelGGL(apply_delta_patch_kernel, dim3((unsigned)std::min<size_t>((np_patch + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
-                       (const DeltaPatch*)s.dl_patch.p, (int)np_patch, s.dl_slot.as<int>(), s.dl_spill.as<int>(), s.dl_rec[0].as<int4>(), s.dl_rec[1].as<int4>());
-    HIP_TRY(c, hipGetLastError());
-    s.dirty_touched.clear();
-    if (s.spill_changed) {  // the few long lists: CSR rebuilt as a whole
-      const size_t ns = s.spill_pairs.size();
-      size_t dn[2] = {0, 0};
-      for (int32_t dj : s.spill_pairs) { dn[0] += s.dirty[dj].recs[0].size(); dn[1] += s.dirty[dj].recs[1].size(); }
-      size_t dt = 0;
-      for (int mt = 0; mt < 2; mt++) {
-        s.delta_off[2 * mt] = dt; dt = align16(dt + (ns + 1) * sizeof(int32_t));
-        s.delta_off[2 * mt + 1] = dt; dt = align16(dt + std::max<size_t>(1, dn[mt]) * sizeof(RecQuad));
-      }
-      void* dh = nullptr;
-      int dslot = stage_acquire(c, s.stage_delta, dt, &dh);
-      if (dslot < 0) return dslot;
-      for (int mt = 0; mt < 2; mt++) {
-        int32_t* of = (int32_t*)((char*)dh + s.delta_off[2 * mt]);
-        RecQuad* rc = (RecQuad*)((char*)dh + s.delta_off[2 * mt + 1]);
-        int32_t at = 0;
-        for (size_t k = 0; k < ns; k++) {
-          of[k] = at;
-          const auto& l = s.dirty[s.spill_pairs[k]].recs[mt];
-          if (!l.empty()) memcpy(rc + at, l.data(), l.size() * sizeof(RecQuad));
-          at += (int32_t)l.size();
-        }
-        of[ns] = at;
-      }
-      if (dt > s.delta_dev.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.delta_dev.reserve(dt + dt / 2)); }
-      if (int e = stage_upload(c, s.stage_delta, dslot, s.delta_dev.p, dt, st)) return e;  // stream order: after the kernels that read the old lists
-      if (int e = stage_release(c, s.stage_delta, dslot, st)) return e;
-      s.spill_changed = false;
-    }
-  }
-  c->prof[4] = now_us() - tp2;  // H2D enqueue
-
-  const int64_t n = s.mate[0].n_local();
-  const char* arena = (const char*)s.occ_arena.p;
-  PairedArgs a;
-  a.m[0] = view_of(s.dev[0], arena, l0);
-  a.m[1] = view_of(s.dev[1], arena, l1);
-  a.len12 = s.len12.as<uint32_t>();
-  const double* tabs = s.tabs.as<double>();
-  a.ins_tab = tabs; a.ins_n = (int)s.ins_tab.size();
-  a.floor_tab = tabs + s.ins_tab.size();
-  a.logfloor_tab = a.floor_tab + s.floor_tab.size();
-  a.covthr_tab = a.logfloor_tab + s.logfloor_tab.size();
-  int tl = total_len == 0 ? 1 : total_len;  // graph.cc:1500-1502
-  a.two_T = (double)(2 * tl);
-  a.n = (int)n;
-  a.probs = s.probs.as<double>();
-  a.cov_bits = nullptr; a.path_base = nullptr;
-  if (cov) {
-    size_t words = (size_t)p.total_bits / 32;
-    if (words * 4 > s.cov_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.cov_bits.reserve(std::max<size_t>(4, words * 4))); }
-    HIP_TRY(c, hipMemsetAsync(s.cov_bits.p, 0, std::max<size_t>(4, words * 4), st));
-    HIP_TRY(c, hipMemsetAsync(s.bad.p, 0, sizeof(unsigned long long), st));
-    a.cov_bits = s.cov_bits.as<uint32_t>();
-    a.path_base = (const int*)(arena + pb_off);
-  }
-  a.part_sum = s.red.part_sum.as<double>();
-  a.part_zero = s.red.part_zero.as<int>();
-  if (c->host_results) {
-    // blocking call: every block stores its partial straight into pinned host memory; the host adds
-    // them up in the finisher kernel's order after the stream sync (no finisher launch, no D2H copy)
-    HIP_TRY(c, s.h_part_sum.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(double)));
-    HIP_TRY(c, s.h_part_zero.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(int)));
-    void *dp = nullptr, *dz = nullptr;
-    HIP_TRY(c, hipHostGetDevicePointer(&dp, s.h_part_sum.p, 0));
-    HIP_TRY(c, hipHostGetDevicePointer(&dz, s.h_part_zero.p, 0));
-    a.part_sum = (double*)dp;
-    a.part_zero = (int*)dz;
-  }
-  s.last_host_partials = c->host_results;
-  a.ticket = s.red.ticket.as<unsigned>();
-  a.out = out4;
-  a.n_reads = (double)n;
-  // main kernel: pairs with <= 2 records per mate; overflow kernel: the rest + pairs touching a
-  // window that occurs several times (list built below, same rule as the main kernel's skip)
-  const int64_t n0 = s.pt.class_count[0], n01 = n0 + s.pt.class_count[1], n_main = n01 + s.pt.class_count[2];
-  a.n0 = (int)n0;
-  a.n01 = (int)n01;
-  a.n_main = (int)n_main;
-  for (int mt = 0; mt < 2; mt++) {
-    a.rec8[mt] = s.rec8[mt].as<unsigned long long>();
-    a.inl[mt] = s.inl[mt].as<int4>();
-    a.m[mt].occ12 = (const Occ12*)a.m[mt].occ;  // paired sets: 12-byte entries instead of the 16-byte image
-    a.m[mt].occ = nullptr;
-    a.occ12[mt] = a.m[mt].occ12;
-  }
-  {
-    const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
-    const double* ct = s.combo_tabs.as<double>();
-    a.pe[0] = ct; a.pe[1] = ct + nc * 64; a.floor_c = ct + 2 * nc * 64; a.logfloor_c = a.floor_c + nc; a.covthr_c = a.logfloor_c + nc;
-  }
-  a.len_code = s.len_code.as<unsigned char>();
-  a.len_combo = s.len_combo.as<uint32_t>();
-  a.n_codes = (int)std::min<size_t>(256, s.pt.len_combo.size());
-  // memo of floor + log over the values a single-term pair can take; rebuilt only when 2T (or the
-  // tables) changed. Floor must be positive for the "no alignment -> floored" shortcut.
-  a.memo = nullptr; a.lt_codes = 0;
-  int memo_codes = 0;  // > 0: the memo has to be (re)built for this evaluation
-  if (c->knobs[4] == 0 && s.floor_positive && !s.pt.len_combo.empty() && s.ins_tab.size() > 0) {
-    const int codes = (int)std::min<size_t>(s.pt.len_combo.size(), 4);
-    const size_t entries = (size_t)codes * 49 * s.ins_tab.size();
-    if (entries <= ((size_t)1 << 24)) {
-      if (s.lt_two_T != a.two_T || s.lt_codes != codes) {
-        if (entries * sizeof(double2) > s.memo.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.memo.reserve(entries * sizeof(double2))); }
-        memo_codes = codes;
-        s.lt_two_T = a.two_T; s.lt_codes = codes;
-      }
-      a.memo = s.memo.as<double2>(); a.lt_codes = codes;
-    }
-  }
-  // per-call tables -> arena and the memo, ONE launch (prep_kernel); odd sizes / knob 8 = 1: hipMemcpyAsync + logterm_kernel
-  {
-    const bool fused = c->knobs[8] != 1 && (total & 15) == 0 && total <= ((size_t)1 << 30);
-    const size_t entries = (size_t)memo_codes * 49 * s.ins_tab.size();
-    if (fused) {
-      const int n16 = (int)(total / 16);
-      const int copy_blocks = std::max(1, std::min(64, (n16 + kBlock - 1) / kBlock));
-      const int memo_blocks = memo_codes ? (int)std::min<size_t>((entries + kBlock - 1) / kBlock, 128) : 0;
-      hipLaunchKernelGGL(prep_kernel, dim3(copy_blocks + memo_blocks), dim3(kBlock), 0, st, (const int4*)s.stage.host[slot].dev,
-                         (int4*)s.occ_arena.p, n16, copy_blocks, a.pe[0], a.pe[1], a.ins_tab, a.ins_n, a.floor_c, a.logfloor_c, memo_codes,
-                         a.two_T, s.memo.as<double2>());
-      HIP_TRY(c, hipGetLastError());
-    } else {
-      if (int e = stage_upload(c, s.stage, slot, s.occ_arena.p, total, st)) return e;
-      if (memo_codes) {
-        hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
-                           a.pe[0], a.pe[1], a.ins_tab, a.ins_n, a.floor_c, a.logfloor_c, memo_codes, a.two_T, s.memo.as<double2>());
-        HIP_TRY(c, hipGetLastError());
-      }
-    }
-    if (int e = stage_release(c, s.stage, slot, st)) return e;
-  }
-  a.n_dirty = (int)nd;
-  const char* delta = (const char*)s.delta_dev.p;
-  a.dirty_slots = s.dl_slot.as<int>();
-  a.dirty_spill = s.dl_spill.as<int>();
-  for (int mt = 0; mt < 2; mt++) {
-    a.dirty_recs[mt] = s.dl_rec[mt].as<int4>();
-    a.spill_off[mt] = (const int*)(delta + s.delta_off[2 * mt]);
-    a.spill_recs[mt] = (const int4*)(delta + s.delta_off[2 * mt + 1]);
-  }
-  const int64_t ovf_total = n - n_main;  // wave-per-pair items (delta pairs: lane per pair in the main range)
-  // 3 blocks per CU and ~2-3 pipelined iterations per lane at cfg3 (tools/kbench.py sweep); larger sets get more blocks, up to 8 per CU
-  const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : (int)std::min<int64_t>(kMaxBlocks, std::max<int64_t>(768, n0 / 2900));
-  // the compact path handles 2 pairs per lane and iteration
-  const int blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
-  // the 2-record class: a quarter of the compact class's blocks (3/4 block per CU at cfg3), lanes take 1-2 pairs;
-  // more blocks only crowd the compact class out (tools/kbench.py sweep: 312 blocks 16.4 us, 192 blocks 15.0 us)
-  const int cap1 = c->knobs[10] > 0 ? c->knobs[10] : cap0 / 4;
-  const int blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, cap1));
-  const int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>((n_main - n01 + kBlock - 1) / kBlock, kMaxBlocks / 4));
-  // delta pairs: one lane per pair behind the table classes (they used to go through the wave-per-pair path)
-  const int blocks_d = nd ? (int)std::min<int64_t>(((int64_t)nd + kBlock - 1) / kBlock, 1024) : 0;
-  const int main_blocks = blocks0 + blocks1 + blocks2 + blocks_d;
-  a.blocks0 = blocks0;
-  a.blocks01 = blocks0 + blocks1;
-  a.blocks012 = blocks0 + blocks1 + blocks2;
-  const int ovf_blocks = ovf_total > 0 ? (int)std::min<int64_t>((ovf_total + 3) / 4, kOvfMaxBlocks) : 0;
-  a.main_blocks = main_blocks;
-  a.total_blocks = main_blocks + ovf_blocks;
-  // some window occurs several times in this path set (or needs the long occurrence form): second launch over
-  // the pairs the main kernel notes
-  const bool gen_pass = n_main > 0 && c->knobs[3] == 0 && (!s.image[0].general_wids.empty() || !s.image[1].general_wids.empty());
-  a.gen_bits = nullptr; a.gen_w1 = a.gen_w2 = 0;
-  a.wide4 = c->knobs[11];
-  a.timeline = nullptr;
-  if (c->knobs[3] == 8) {  // in-kernel timeline (tools/kernel_timeline.py): stamps land in mapped host memory
-    HIP_TRY(c, s.h_timeline.reserve((size_t)(4 * kMaxBlocks + kOvfMaxBlocks + 256) * (kBlock / 64) * 8 * sizeof(unsigned long long)));
-    memset(s.h_timeline.p, 0, s.h_timeline.cap);
-    void* dp = nullptr;
-    HIP_TRY(c, hipHostGetDevicePointer(&dp, s.h_timeline.p, 0));
-    a.timeline = (unsigned long long*)dp;
-    s.timeline_waves = a.total_blocks * (kBlock / 64);
-  }
-
-  int gen_blocks = 0;
-  if (gen_pass) {
-    const int64_t w0 = (n0 + 63) / 64, w1 = (n01 - n0 + 63) / 64, w2 = (n_main - n01 + 63) / 64;
-    const size_t bytes = (size_t)(w0 + w1 + w2) * sizeof(unsigned long long);
-    if (bytes > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(bytes + bytes / 4)); }
-    a.gen_bits = s.gen_bits.as<unsigned long long>();
-    a.gen_w1 = (int)w0; a.gen_w2 = (int)(w0 + w1);
-    gen_blocks = (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, kMaxBlocks);
-  }
-
-  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  if (n > 0) {
-    // HIP events bracket the dominant kernel only (bench.py's roofline; rocprofv3 must agree)
-    if (c->event_timing && (c->event_tick++ % c->event_every) == 0) { if (int e = take_events(c, &ev)) return e; }
-    int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
-    if (fin_mode == 0 && gen_pass) fin_mode = 1;
-    const int n_partials = a.total_blocks + gen_blocks;
-    s.last_total_blocks = n_partials;
-    if (c->host_results) {
-      // sentinels: the host can tell when every block's partial has landed without waiting for the
-      // runtime's completion signal (fetch_partials)
-      double* hs = (double*)s.h_part_sum.p;
-      int* hz = (int*)s.h_part_zero.p;
-      for (int b2 = 0; b2 < n_partials; b2++) { hs[b2] = std::numeric_limits<double>::quiet_NaN(); hz[b2] = INT_MIN; }
-    }
-    const int dyn_lds = c->knobs[1];  // experiment: occupancy limiter
-    if (nd > s.dirty_marked) {  // marks stay on the device until the next full build: only new delta pairs need one
-      const size_t fresh = nd - s.dirty_marked;
-      hipLaunchKernelGGL(mark_dirty_kernel, dim3((unsigned)std::min<size_t>((fresh + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
-                         a.dirty_slots + s.dirty_marked, (int)fresh, s.rec8[0].as<unsigned long long>(), a.n0, s.inl[0].as<int4>(), a.n01,
-                         a.n_main, s.dev[0].first.as<int4>());
-      HIP_TRY(c, hipGetLastError());
-      s.dirty_marked = nd;
-    }
-    const dim3 grid(a.total_blocks), block(kBlock);
-    // Timed launches attach the two events to the dispatch itself (hipExtLaunchKernelGGL: the events carry
-    // the kernel's own begin / end stamps, what rocprofv3's kernel trace reports). Separate hipEventRecord
-    // markers around the launch would add the marker packets' processing to the interval: an EMPTY kernel
-    // of this grid reads 6 us that way (tools/stream_floor.hip).
-    hipEvent_t e0 = ev ? ev->first : nullptr, e1 = ev ? ev->second : nullptr;
-#define GAML_LAUNCH_SCORE(...) hipExtLaunchKernelGGL((paired_score_kernel<__VA_ARGS__>), grid, block, dyn_lds, st, e0, e1, 0, a)
-    switch (c->knobs[3]) {  // 1-5: timing-only ablations (tools/kbench.py)
-      case 1: GAML_LAUNCH_SCORE(false, 1); break;
-      case 2: GAML_LAUNCH_SCORE(false, 2); break;
-      case 3: GAML_LAUNCH_SCORE(false, 3); break;
-      case 4: GAML_LAUNCH_SCORE(false, 4); break;
-      case 5: GAML_LAUNCH_SCORE(false, 5); break;
-      case 6: GAML_LAUNCH_SCORE(false, 6); break;
-      case 7: GAML_LAUNCH_SCORE(false, 7); break;
-      case 8: GAML_LAUNCH_SCORE(false, 8); break;
-      default:
-        if (gen_pass) GAML_LAUNCH_SCORE(false, 0, true);
-        else if (fin_mode) GAML_LAUNCH_SCORE(false, 0);
-        else GAML_LAUNCH_SCORE(true, 0);
-    }
-#undef GAML_LAUNCH_SCORE
-    HIP_TRY(c, hipGetLastError());
-    if (gen_pass) {
-      hipLaunchKernelGGL(paired_general_kernel, dim3(gen_blocks), dim3(kBlock), 0, st, a, a.total_blocks);
-      HIP_TRY(c, hipGetLastError());
-    }
-    if (fin_mode == 1) {
-      hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, n_partials, out4, cov ? -1.0 : 0.0, (double)n);
-      HIP_TRY(c, hipGetLastError());
-    }
-  } else {
-    s.last_total_blocks = 0;
-    if (!c->host_results) HIP_TRY(c, hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
-  }
-  if (cov && c->defer_cov) {
-    // the sweep needs the union of all ranks' coverage marks: gaml_hip_eval_coverage_finish_async runs it
-    CovArgs ca;
-    ca.bits = s.cov_bits.as<uint32_t>();
-    ca.path_base = (const int*)(arena + pb_off);
-    ca.start_off = (const int*)(arena + so_off);
-    ca.starts = (const int*)(arena + st_off);
-    ca.n_paths = (int)paths.size();
-    ca.total_words = p.total_bits / 32;
-    ca.cov_move = s.cfg.step;
-    ca.far = s.cfg.insert_mean + 5 * s.cfg.insert_std;
-    ca.bad = s.bad.as<unsigned long long>();
-    int idx = 0;
-    for (size_t i = 0; i < c->paireds.size(); i++) if (c->paireds[i].get() == &s) idx = (int)i;
-    c->pending_cov.push_back(gaml_hip_ctx::PendingCov{idx, ca, out4});
-  } else if (cov && n > 0 && p.total_bits > 0) {
-    CovArgs ca;
-    ca.bits = s.cov_bits.as<uint32_t>();
-    ca.path_base = (const int*)(arena + pb_off);
-    ca.start_off = (const int*)(arena + so_off);
-    ca.starts = (const int*)(arena + st_off);
-    ca.n_paths = (int)paths.size();
-    ca.total_words = p.total_bits / 32;
-    ca.cov_move = s.cfg.step;
-    ca.far = s.cfg.insert_mean + 5 * s.cfg.insert_std;
-    ca.bad = s.bad.as<unsigned long long>();
-    hipLaunchKernelGGL(coverage_sweep_kernel, dim3(grid_for(ca.total_words)), dim3(kBlock), 0, st, ca);
-    HIP_TRY(c, hipGetLastError());
-  }
-  if (cov && n > 0 && !c->defer_cov) {
-    hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), out4, 1.0);
-    HIP_TRY(c, hipGetLastError());
-  }
-  c->prof[5] = now_us() - tp2 - c->prof[4];  // kernel launches
-  // SURVEY.md 8d accounting: 16 B per record, 8 B read lengths, 8 B probability written, per pair
-  if (!c->event_timing || ev) {  // with timing on, the statistics describe the timed launches
-    c->stat_algo_bytes += 16.0 * (double)p.assembled_records + 16.0 * (double)n;
-    c->stat_launches++;
-  }
-  c->t_host_us += t_after_host;  // caller subtracts the start stamp
-  return 0;
-}
+namespace {
 
 // ---------------------------------------------------------------------------------------
 // single-end read set (CalcScoreForPaths graph.cc:1650-1743)
@@ -1247,7 +670,7 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
   c->pending_prep.resize(c->paireds.size());
   for (size_t i = 0; i < c->paireds.size(); i++) {
     c->pending_prep[i].reset(new PairedPrep());
-    prepare_paired_structure(c, *c->paireds[i], c->pending_paths, *c->pending_prep[i]);
+    prepare_paired_structure(c, *c->paireds[i], c->pending_paths);
     // windows registered by pass 1 get their records now, all at once (GPU aligner when there is a device)
     for (int mt = 0; mt < 2; mt++)
       if (int e = gpu_align_pending(c, c->paireds[i]->mate[mt], c->paireds[i]->dev[mt].aln)) return e;
@@ -1298,7 +721,7 @@ int eval_finish(gaml_hip_ctx* c, void* d_partials, hipStream_t st) {
     double* out4 = (double*)d_partials + 4 * k;  // every scorer's last block writes its 4 partials here
     int e = 0;
     if (h.kind == 0) e = launch_single(c, *c->singles[h.idx], paths, total_len, st, out4);
-    else if (h.kind == 1) e = launch_paired(c, *c->paireds[h.idx], paths, *c->pending_prep[h.idx], total_len, st, out4);
+    else if (h.kind == 1) e = launch_paired(c, *c->paireds[h.idx], *c->pending_prep[h.idx], total_len, st, out4);
     else e = launch_pacbio(c, *c->pacbios[h.idx], paths, st, out4);
     if (e) return e;
     c->t_host_us -= tk;  // launch_* added its "host part finished" stamp
@@ -1405,6 +828,12 @@ int gaml_hip_create(gaml_hip_ctx** out, int device) {
     if (hipSetDevice(device) != hipSuccess) return GAML_HIP_EHIP;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return GAML_HIP_EHIP;
     if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) return GAML_HIP_EHIP;
+    // large BAR (every MI300-class part): per-call tables are written by the host straight into device memory
+    // (paired_launch.hip.h: Arena). GAML_HIP_DIRECT_WRITE=0 forces the staged path.
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess) large_bar = 0;
+    const char* dw = getenv("GAML_HIP_DIRECT_WRITE");
+    c->direct_write = large_bar != 0 && !(dw && dw[0] == '0');
   }
   *out = c.release();
   return GAML_HIP_OK;
@@ -1425,8 +854,8 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
       s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release(); s->len_code.release(); s->len_combo.release();
-      s->len12.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
-      s->red.release(); drop_stage(s->stage); s->gen_bits.release();
+      s->len12.release(); s->probs.release(); s->tabs.release(); s->arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
+      s->red.release(); s->gen_bits.release();
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage);
       s->d_bases.release(); s->dp.release(); }
@@ -2281,25 +1710,27 @@ static void finisher_order_sum(const double* ps, const int* pz, int n, double* s
   *zeros_out = (double)z;
 }
 
-static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
-  // the kernels wrote into pinned host memory: nothing to copy, only to wait for
+// Blocking calls: the scoring kernels wrote their per-block partials into pinned host memory. When paired scorers
+// without coverage penalty are all there is, those partials ARE the result: spin on their sentinels instead of
+// waiting for the stream's completion signal (saves the runtime's ~6 us wake-up, tools/latency_probe.hip). Bounded;
+// any doubt -> a real stream sync. Returns whether the spin sufficed.
+static int wait_host_partials(gaml_hip_ctx* c, bool* spun) {
   const double t0 = now_us();
-  // When paired scorers without coverage penalty are all there is, the per-block partials ARE the
-  // result: spin on their sentinels instead of waiting for the stream's completion signal (saves the
-  // runtime's ~6 us wake-up, tools/latency_probe.hip). Bounded; any doubt -> a real stream sync.
   bool spin = c->knobs[7] == 0 && !c->handles.empty();
   for (auto& h : c->handles) if (h.kind != 1) spin = false;
   for (auto& ps : c->paireds) if (ps->cfg.penalty_constant > 0 || !ps->last_host_partials || ps->last_total_blocks == 0) spin = false;
   if (spin) {
     const double deadline = t0 + 2e6;
     for (auto& ps : c->paireds) {
-      const volatile double* hs = (const volatile double*)ps->h_part_sum.p;
-      const volatile int* hz = (const volatile int*)ps->h_part_zero.p;
-      int done = 0;
-      while (done < ps->last_total_blocks) {
-        if (hs[done] == hs[done] && hz[done] != INT_MIN) { done++; continue; }  // NaN != NaN
-        __builtin_ia32_pause();
-        if ((done & 63) == 0 && now_us() > deadline) { spin = false; break; }
+      for (int k = 0; k < ps->last_sets && spin; k++) {
+        const volatile double* hs = (const volatile double*)ps->h_part_sum.p + (size_t)k * ps->host_part_stride;
+        const volatile int* hz = (const volatile int*)ps->h_part_zero.p + (size_t)k * ps->host_part_stride;
+        int done = 0;
+        while (done < ps->last_total_blocks) {
+          if (hs[done] == hs[done] && hz[done] != INT_MIN) { done++; continue; }  // NaN != NaN
+          __builtin_ia32_pause();
+          if ((done & 63) == 0 && now_us() > deadline) { spin = false; break; }
+        }
       }
       if (!spin) break;
     }
@@ -2308,6 +1739,13 @@ static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
   if (!spin) HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->t_dev_wall_us += now_us() - t0;
   c->prof[7] = now_us() - t0;  // wait for the device
+  *spun = spin;
+  return 0;
+}
+
+static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
+  bool spun = false;
+  if (int e = wait_host_partials(c, &spun)) return e;
   {
     double* res = (double*)c->packed_host.p;
     auto ord = scoring_order(c);
@@ -2324,12 +1762,87 @@ static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
   }
   memcpy(partials_out, c->packed_host.p, c->handles.size() * 4 * sizeof(double));
   c->t_kernel_us = 0;
-  if (!spin) { if (int e2 = collect_events(c)) return e2; }  // after a spin the events are collected lazily (gaml_hip_kernel_stats)
+  if (!spun) { if (int e2 = collect_events(c)) return e2; }  // after a spin the events are collected lazily (gaml_hip_kernel_stats)
   // bookkeeping for gaml_hip_bad_bases
   auto order = scoring_order(c);
   for (size_t k = 0; k < order.size(); k++)
     if (order[k].kind == 1) c->paireds[order[k].idx]->last_bad_bases = (int64_t)partials_out[4 * k + 2];
   return GAML_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gaml_hip_calc_prob_batch, fast path: up to kMaxSets path sets in ONE pass over the records of every paired set
+// (paired_score_multi_kernel). The host plans the sets one after the other straight into consecutive regions of one
+// arena slot; then one launch per read set, one wait. Contexts with other kinds of read sets, a coverage penalty or
+// without a memo take the sequential path below (same results).
+// ---------------------------------------------------------------------------------------------------------
+static bool batch_fast_capable(const gaml_hip_ctx* c) {
+  if (c->handles.empty() || c->knobs[11] == 1) return false;  // knob 11 = 1: force the sequential path (A/B, tools/)
+  for (auto& h : c->handles) if (h.kind != 1) return false;
+  for (auto& ps : c->paireds) if (!paired_multi_capable(c, *ps)) return false;
+  return true;
+}
+
+// returns 1 when a set's tables did not fit the region reserved for it (the caller falls back for this chunk)
+static int batch_chunk_fast(gaml_hip_ctx* c, int n, const int32_t* paths, const int64_t* offs, const int32_t* set_offs,
+                            double* partials_out, int32_t* tls) {
+  hipStream_t st = c->stream;
+  const size_t nps = c->paireds.size();
+  struct PerSet { int slot = 0; char* wp = nullptr; size_t stride = 0, cap_w[2] = {0, 0}; std::vector<PairedLayout> L; std::vector<PairedPrep> prep; };
+  std::vector<PerSet> per(nps);
+  c->host_results = true;
+  struct Reset { gaml_hip_ctx* c; ~Reset() { c->host_results = false; c->pending_open = false; } } reset{c};
+  for (size_t i = 0; i < nps; i++) {
+    PairedSet& ps = *c->paireds[i];
+    if (int e = prepare_paired_tables(c, ps)) return e;
+    // a region per path set: the occurrence images of the current window count plus room for windows and lists that
+    // this very batch adds
+    // windows the batch itself may add: every set's tables are padded to this many entries per mate
+    per[i].cap_w[0] = ps.mate[0].wins.size() + 2048 + ps.batch_slack / 24;
+    per[i].cap_w[1] = ps.mate[1].wins.size() + 2048 + ps.batch_slack / 24;
+    const size_t est = 4096 + 12 * (per[i].cap_w[0] + per[i].cap_w[1]) + 65536 + ps.batch_slack;
+    per[i].stride = align16(est);
+    if (int e = arena_acquire(c, ps.arena, per[i].stride * (size_t)n, st, &per[i].slot, &per[i].wp)) return e;
+    per[i].L.resize((size_t)n);
+    per[i].prep.resize((size_t)n);
+  }
+  for (int k = 0; k < n; k++) {
+    int64_t pending = 0;
+    if (int e = eval_begin(c, paths, offs + set_offs[k], set_offs[k + 1] - set_offs[k], &pending)) return e;
+    tls[k] = c->pending_total_len;
+    for (size_t i = 0; i < nps; i++) {
+      PairedSet& ps = *c->paireds[i];
+      PairedPrep& p = per[i].prep[(size_t)k];
+      prepare_paired_tables_host(c, ps, p);
+      if (ps.mate[0].wins.size() > per[i].cap_w[0] || ps.mate[1].wins.size() > per[i].cap_w[1]) { ps.batch_slack += 24 * 16384; return 1; }
+      per[i].L[(size_t)k] = paired_layout(ps, p, per[i].cap_w);
+      if (per[i].L[(size_t)k].total > per[i].stride) { ps.batch_slack += 2 * per[i].L[(size_t)k].total; return 1; }
+      paired_pack(ps, p, per[i].L[(size_t)k], per[i].wp + (size_t)k * per[i].stride);
+    }
+    c->pending_open = false;
+  }
+  for (size_t i = 0; i < nps; i++) {
+    PairedSet& ps = *c->paireds[i];
+    if (int e = paired_sync_tables(c, ps, st)) return e;
+    for (int k = 0; k < n; k++) paired_pack_thresholds(ps, per[i].L[(size_t)k], (double)(2 * (tls[k] == 0 ? 1 : tls[k])), per[i].wp + (size_t)k * per[i].stride);
+    if (int e = arena_commit(c, ps.arena, per[i].slot, per[i].stride * (size_t)n, st)) return e;
+    if (int e = launch_paired_multi(c, ps, n, per[i].L.data(), per[i].prep.data(), tls, (const char*)ps.arena.dev[per[i].slot], per[i].stride, st)) return e;
+  }
+  bool spun = false;
+  if (int e = wait_host_partials(c, &spun)) return e;
+  if (!spun) { if (int e2 = collect_events(c)) return e2; }
+  for (int k = 0; k < n; k++)
+    for (size_t i = 0; i < nps; i++) {
+      PairedSet& ps = *c->paireds[i];
+      double* out = partials_out + ((size_t)k * nps + i) * 4;
+      out[0] = out[1] = out[2] = 0;
+      if (ps.last_total_blocks > 0)
+        finisher_order_sum((const double*)ps.h_part_sum.p + (size_t)k * ps.host_part_stride, (const int*)ps.h_part_zero.p + (size_t)k * ps.host_part_stride,
+                           ps.last_total_blocks, &out[0], &out[1]);
+      out[3] = (double)ps.mate[0].n_local();
+      ps.last_bad_bases = 0;
+    }
+  return 0;
 }
 
 int gaml_hip_combine_partials(gaml_hip_ctx* c, const double* partials, int32_t total_len, double* prob_out, int32_t* zeros_out) {
@@ -2382,6 +1895,30 @@ int gaml_hip_calc_prob_batch(gaml_hip_ctx* c, int32_t n_sets, const int32_t* pat
   if (n_sets == 0) return GAML_HIP_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t ns = std::max<size_t>(1, c->handles.size());
+  for (int32_t i = 0; i < n_sets; i++) if (set_offs[i + 1] < set_offs[i]) return fail(c, GAML_HIP_EINVAL, "set offsets must not decrease");
+  int32_t done_sets = 0;
+  if (batch_fast_capable(c)) {
+    std::vector<double> part((size_t)kMaxSets * 4 * ns);
+    int32_t tls[kMaxSets];
+    while (done_sets < n_sets) {
+      const int n = std::min<int32_t>(kMaxSets, n_sets - done_sets);
+      const int rc = n > 1 ? batch_chunk_fast(c, n, paths, offs, set_offs + done_sets, part.data(), tls) : 1;
+      if (rc < 0) return rc;
+      if (rc > 0) break;  // a single leftover set, or tables that outgrew their region: the sequential path takes the rest
+      for (int k = 0; k < n; k++) {
+        const int32_t i = done_sets + k;
+        if (int e = combine(c, part.data() + (size_t)k * 4 * ns, &probs_out[i], zeros_out ? zeros_out + (size_t)i * 2 * ns : nullptr, tls[k])) return e;
+        if (total_lens_out) total_lens_out[i] = tls[k];
+      }
+      done_sets += n;
+    }
+    if (done_sets == n_sets) return GAML_HIP_OK;
+    // (the sequential path below handles sets [done_sets, n_sets))
+    paths = paths; offs = offs; set_offs += done_sets; probs_out += done_sets;
+    if (zeros_out) zeros_out += (size_t)done_sets * 2 * ns;
+    if (total_lens_out) total_lens_out += done_sets;
+    n_sets -= done_sets;
+  }
   const size_t doubles = (size_t)n_sets * 4 * ns;
   if (doubles * sizeof(double) > c->batch_dev.cap) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, c->batch_dev.reserve(doubles * sizeof(double))); }
   HIP_TRY(c, c->batch_host.reserve(doubles * sizeof(double)));
@@ -2510,7 +2047,7 @@ int gaml_hip_debug_prepare(gaml_hip_ctx* c, const int32_t* flat, const int64_t* 
     else if (h.kind == 1) {
       PairedPrep p;
       PairedSet& ps = *c->paireds[h.idx];
-      prepare_paired_structure(c, ps, paths, p);
+      prepare_paired_structure(c, ps, paths);
       for (int mt = 0; mt < 2; mt++) if (int e = gpu_align_pending(c, ps.mate[mt], ps.dev[mt].aln)) return e;
       prepare_paired_tables_host(c, ps, p);
     }

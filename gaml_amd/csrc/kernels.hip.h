@@ -55,14 +55,18 @@ struct PairedArgs {
   const double* floor_c;     // [code] exp(c + k (L1+L2)); logfloor_c = log of it; covthr_c = exp(c + k 2 L2)
   const double* logfloor_c;
   const double* covthr_c;
-  // memoised floor/log of single-term pairs: the value of a pair with one alignment per mate depends
-  // only on (length code, edit 1, edit 2, insert distance) -- a few 10^4 combinations per evaluation.
-  // logterm_kernel evaluates the reference's floor + log once per combination (same device log on
-  // the same f64 value as the per-pair path), the compact path then looks the result up.
-  // memo[((code*7 + e1)*7 + e2)*ins_n + dist] = {pair term (sign bit set when the read is floored),
-  // floored ? log(floor) : log(term / 2T)}; null: off
+  // memoised term + log of single-term pairs: the value of a pair with one alignment per mate depends only on
+  // (length code, edit 1, edit 2, insert distance) -- a few 10^4 combinations. logterm_kernel tabulates
+  // memo[((code*7 + e1)*7 + e2)*ins_n + dist] = {pair term t, log(t)} once per table build: nothing in it depends on
+  // the path set. GetTotalProb's per-read step (graph.cc:1504-1513: p = t / 2T; p < floor ? floored : log(p)) then is
+  //   floored  <=>  t < tfloor_c[code]   (tfloor = the smallest double whose quotient by 2T reaches the floor, found on the
+  //                                       host with the same division: the SAME decision as the reference, exactly)
+  //   log(p)    =   log(t) - log(2T)     (within an ulp or two of log(fl(t / 2T)): ~1e-16 relative on the mean)
+  // so a change of total_len costs two doubles per length code per call instead of a table rebuild. null: off
   const double2* memo;
   int lt_codes;              // codes covered (< lt_codes), edits < 7
+  const double* tfloor_c;    // [code] per call: see above
+  double log_two_T;          // log(2T), host libm, per call
   const int4* inl[2];        // inline records of the register classes: [2t + k] (class 1), [2 n1 + 4 t2 + k] (class 2)
   int n0;                    // first[] / extra[] / len12[] hold slots >= n0, indexed slot - n0
   int blocks0;               // blocks [0, blocks0): compact path; [blocks0, blocks01): <= 2 records; [blocks01, blocks012): <= 4;
@@ -75,8 +79,7 @@ struct PairedArgs {
   // one wave, so nothing has to be zeroed); paired_general_kernel scores them in a second launch. Null when the
   // host saw no such window in this path set -- then neither the notes nor the second launch exist.
   unsigned long long* gen_bits;
-  int wide4;                 // knob 11 = 1: the two-pairs-per-iteration compact body instead of the four-wide one (tools/kbench.py)
-  unsigned long long* timeline;  // ablation 8: 8 wall-clock stamps (10 ns units) per wave of the grid
+  unsigned long long* timeline;  // TL instantiation only: 8 wall-clock stamps (10 ns units) per wave of the grid
   int gen_w1, gen_w2;        // first word of class 1 / class 2 (class 0 starts at word 0)
   int main_blocks, total_blocks;  // grid sizes: partial slots [0, main_blocks) main, then overflow
   // Delta: pairs whose record lists changed since the device tables were built (newly activated
@@ -366,9 +369,6 @@ __device__ __forceinline__ int4 rec8_to_quad(unsigned long long r) {  // 8-byte 
   return make_int4((int)(r & 0xffffff), (int)((r >> 24) & 0xfffffff), (int)((r >> 52) & 63) | ((int)((r >> 58) & 1) << 8), 0);
 }
 
-// ABL > 0: timing-only ablations for tools/kbench.py (results are wrong on purpose):
-//   1 = stream the records and lengths, write probs, nothing else; 2 = + occurrence lookups;
-//   3 = + pair terms (tables), but no floor / log
 // Class 0: at most one record per mate, packed to 8 bytes; pairs are ordered by window id, so the
 // occurrence entries of a wave's lanes are mostly the same address (broadcast).
 struct Compact1 {  // one class-0 pair in flight
@@ -376,12 +376,10 @@ struct Compact1 {  // one class-0 pair in flight
   int L1, L2, lc;
 };
 
-// one thread per (length code, edit 1, edit 2, distance): the pair term (graph.cc:1858-1882) and
-// GetTotalProb's per-read step (graph.cc:1504-1513) for every value a single-term pair can take in
-// this evaluation. Same operations in the same order as the per-pair path, so the looked-up values
-// are the per-pair values.
-__global__ __launch_bounds__(kBlock) void logterm_kernel(const double* pe0, const double* pe1, const double* ins_tab, int ins_n,
-                                                        const double* floor_c, const double* logfloor_c, int codes, double two_T,
+// one thread per (length code, edit 1, edit 2, distance): the pair term (graph.cc:1858-1882) for every value a
+// single-term pair can take, and its log. Same products in the same order as the per-pair path, so the looked-up
+// terms are the per-pair terms, bit for bit.
+__global__ __launch_bounds__(kBlock) void logterm_kernel(const double* pe0, const double* pe1, const double* ins_tab, int ins_n, int codes,
                                                         double2* memo) {
   const int total = codes * 49 * ins_n;
   for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
@@ -389,31 +387,7 @@ __global__ __launch_bounds__(kBlock) void logterm_kernel(const double* pe0, cons
     const int q = idx / ins_n;
     const int e2 = q % 7, e1 = (q / 7) % 7, code = q / 49;
     const double t = pe0[code * 64 + e1] * pe1[code * 64 + e2] * ins_tab[dist];  // as compact_term_tables
-    const double p = t / two_T;
-    const bool floored = p < floor_c[code];
-    memo[idx] = make_double2(floored ? -t : t, floored ? logfloor_c[code] : log(p));
-  }
-}
-
-// One launch for the two small jobs in front of a scoring launch: blocks [0, copy_blocks) move the per-call tables
-// from the pinned staging slot (mapped host memory) into the arena, the remaining blocks build the memo (when 2T
-// changed). They touch disjoint data and run side by side; one launch less per evaluation is ~3.5 us of host time.
-__global__ __launch_bounds__(kBlock) void prep_kernel(const int4* __restrict__ src, int4* __restrict__ dst, int n16, int copy_blocks,
-                                                      const double* pe0, const double* pe1, const double* ins_tab, int ins_n,
-                                                      const double* floor_c, const double* logfloor_c, int codes, double two_T, double2* memo) {
-  if ((int)blockIdx.x < copy_blocks) {
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n16; i += copy_blocks * kBlock) dst[i] = src[i];
-    return;
-  }
-  const int total = codes * 49 * ins_n, mb = (int)blockIdx.x - copy_blocks, n_mb = (int)gridDim.x - copy_blocks;
-  for (int idx = mb * kBlock + threadIdx.x; idx < total; idx += n_mb * kBlock) {  // as logterm_kernel
-    const int dist = idx % ins_n;
-    const int q = idx / ins_n;
-    const int e2 = q % 7, e1 = (q / 7) % 7, code = q / 49;
-    const double t = pe0[code * 64 + e1] * pe1[code * 64 + e2] * ins_tab[dist];
-    const double p = t / two_T;
-    const bool floored = p < floor_c[code];
-    memo[idx] = make_double2(floored ? -t : t, floored ? logfloor_c[code] : log(p));
+    memo[idx] = make_double2(t, log(t));  // t = 0 (distance beyond the Gaussian's f64 range): -inf, never used (0 < tfloor: floored)
   }
 }
 
@@ -488,11 +462,12 @@ __device__ __forceinline__ void compact_general(const PairedArgs& a, int i, doub
 __device__ __forceinline__ void compact_finish(const PairedArgs& a, int i, const Compact1& c, const CompactPrep& q, double2 m,
                                                double& lsum, int& zeros) {
   if (q.memo_idx >= 0) {
-    const double t = fabs(m.x);
+    const double t = m.x;
     compact_cover(a, c, q, t);
     __builtin_nontemporal_store(t, &a.probs[i]);  // written once, read by nobody on the hot path: keep it out of the caches
-    lsum += m.y;
-    zeros += (int)(__double2hiint(m.x) < 0);  // sign bit: floored (also for a term of exactly zero)
+    const bool floored = t < a.tfloor_c[c.lc];    // <=> t / 2T < floor (PairedArgs::memo)
+    lsum += floored ? a.logfloor_c[c.lc] : m.y - a.log_two_T;
+    zeros += (int)floored;
     return;
   }
   double t = 0.0;
@@ -506,11 +481,10 @@ __device__ __forceinline__ void compact_load(const PairedArgs& a, int i, bool ok
   c.lc = ok ? a.len_code[i] : 0;
 }
 
-template <int ABL, bool GEN>
+template <bool GEN>
 __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb, double& lsum, int& zeros) {
-  // Two pairs per lane and iteration, software pipelined: the record loads of iteration k+1 are
-  // issued before iteration k's occurrence lookups and arithmetic, so a lane always has one round of
-  // streaming loads in flight while it computes.
+  // Class 0 in the general form (coverage marks to set, or no memo): two pairs per lane and iteration, software
+  // pipelined -- the record loads of iteration k+1 are issued before iteration k's occurrence lookups and arithmetic.
   const int stride = a.blocks0 * kBlock;
   int i0 = lb * kBlock + threadIdx.x;
   if (i0 >= a.n0) return;
@@ -527,40 +501,25 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
     compact_load(a, j0 + stride, j0 + stride < a.n0, n1v);
     const uint32_t l0 = a.len_combo[c0.lc], l1 = a.len_combo[c1.lc];
     c0.L1 = l0 & 0xffff; c0.L2 = l0 >> 16; c1.L1 = l1 & 0xffff; c1.L2 = l1 >> 16;
-    if (ABL == 1 || ABL == 4) {
-      a.probs[i0] = (double)(int)(c0.r1 + c0.r2 + c0.L1); lsum += (double)(int)c0.r1;
-      if (two) { a.probs[i1] = (double)(int)(c1.r1 + c1.r2 + c1.L1); lsum += (double)(int)c1.r1; }
-    } else {
-      const bool d0 = c0.r1 == kDirty8, d1 = c1.r1 == kDirty8;  // scored by the overflow path from the delta lists
-      if (d0) { c0.r1 = kNone8; c0.r2 = kNone8; }
-      if (d1) { c1.r1 = kNone8; c1.r2 = kNone8; }
-      const unsigned long long wmask = ABL == 6 ? 0x0 : 0xffffff;  // ablation 6: every lookup at entry 0
-      c0.o1 = c0.r1 != kNone8 ? occ8_of(a.occ12[0], (unsigned)(c0.r1 & wmask)) : kNone8;
-      c0.o2 = c0.r2 != kNone8 ? occ8_of(a.occ12[1], (unsigned)(c0.r2 & wmask)) : kNone8;
-      c1.o1 = c1.r1 != kNone8 ? occ8_of(a.occ12[0], (unsigned)(c1.r1 & wmask)) : kNone8;
-      c1.o2 = c1.r2 != kNone8 ? occ8_of(a.occ12[1], (unsigned)(c1.r2 & wmask)) : kNone8;
-      if (ABL == 2) {
-        a.probs[i0] = (double)(int)(c0.o1 + c0.o2); lsum += (double)(int)(c0.o1 + c0.o2);
-        if (two) { a.probs[i1] = (double)(int)(c1.o1 + c1.o2); lsum += (double)(int)(c1.o1 + c1.o2); }
-      } else {
-        CompactPrep q0, q1;
-        compact_prep(a, c0, q0);
-        compact_prep(a, c1, q1);
-        // both memo entries are requested before anything is stored
-        if (ABL == 7) { if (q0.memo_idx >= 0) q0.memo_idx = threadIdx.x; if (q1.memo_idx >= 0) q1.memo_idx = 256 + threadIdx.x; }  // ablation 7: coalesced memo reads
-        const double2 m0 = q0.memo_idx >= 0 ? a.memo[q0.memo_idx] : make_double2(0.0, 0.0);
-        const double2 m1 = q1.memo_idx >= 0 ? a.memo[q1.memo_idx] : make_double2(0.0, 0.0);
-        if (ABL == 3) { a.probs[i0] = fabs(m0.x); lsum += m0.x; if (two) { a.probs[i1] = fabs(m1.x); lsum += m1.x; } }
-        else {
-          if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
-            const unsigned long long k0 = __ballot(q0.skip), k1 = __ballot(q1.skip);
-            if ((threadIdx.x & 63) == 0) { a.gen_bits[i0 >> 6] = k0; if (two) a.gen_bits[i1 >> 6] = k1; }
-          }
-          if (!d0 && !q0.skip) compact_finish(a, i0, c0, q0, m0, lsum, zeros);
-          if (two && !d1 && !q1.skip) compact_finish(a, i1, c1, q1, m1, lsum, zeros);
-        }
-      }
+    const bool d0 = c0.r1 == kDirty8, d1 = c1.r1 == kDirty8;  // scored from the delta lists (paired_delta_body)
+    if (d0) { c0.r1 = kNone8; c0.r2 = kNone8; }
+    if (d1) { c1.r1 = kNone8; c1.r2 = kNone8; }
+    c0.o1 = c0.r1 != kNone8 ? occ8_of(a.occ12[0], (unsigned)(c0.r1 & 0xffffff)) : kNone8;
+    c0.o2 = c0.r2 != kNone8 ? occ8_of(a.occ12[1], (unsigned)(c0.r2 & 0xffffff)) : kNone8;
+    c1.o1 = c1.r1 != kNone8 ? occ8_of(a.occ12[0], (unsigned)(c1.r1 & 0xffffff)) : kNone8;
+    c1.o2 = c1.r2 != kNone8 ? occ8_of(a.occ12[1], (unsigned)(c1.r2 & 0xffffff)) : kNone8;
+    CompactPrep q0, q1;
+    compact_prep(a, c0, q0);
+    compact_prep(a, c1, q1);
+    // both memo entries are requested before anything is stored
+    const double2 m0 = q0.memo_idx >= 0 ? a.memo[q0.memo_idx] : make_double2(0.0, 0.0);
+    const double2 m1 = q1.memo_idx >= 0 ? a.memo[q1.memo_idx] : make_double2(0.0, 0.0);
+    if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
+      const unsigned long long k0 = __ballot(q0.skip), k1 = __ballot(q1.skip);
+      if ((threadIdx.x & 63) == 0) { a.gen_bits[i0 >> 6] = k0; if (two) a.gen_bits[i1 >> 6] = k1; }
     }
+    if (!d0 && !q0.skip) compact_finish(a, i0, c0, q0, m0, lsum, zeros);
+    if (two && !d1 && !q1.skip) compact_finish(a, i1, c1, q1, m1, lsum, zeros);
     if (!more) break;
     c0 = n0v; c1 = n1v;
     i0 = j0;
@@ -616,7 +575,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
   const char* const memo = (const char*)a.memo;
   char* const probs = (char*)a.probs;
   const uint32_t l12_one = ONE ? a.len_combo[0] : 0u;
-  const double logfloor_one = ONE ? a.logfloor_c[0] : 0.0;
+  const double logfloor_one = ONE ? a.logfloor_c[0] : 0.0, tfloor_one = ONE ? a.tfloor_c[0] : 0.0, log2T = a.log_two_T;
   for (unsigned base = (unsigned)lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
     uint2 r1[4], r2[4], o1[4], o2[4];
     unsigned lc[4];
@@ -657,9 +616,10 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
     for (int k = 0; k < 4; k++) {
       double* const out = (double*)(probs + (base + k * stride) * 8u);
       if (state[k] >= 0) {  // as compact_finish
-        __builtin_nontemporal_store(fabs(m[k].x), out);
-        lsum += m[k].y;
-        zeros += (int)(__double2hiint(m[k].x) < 0);
+        __builtin_nontemporal_store(m[k].x, out);
+        const bool floored = m[k].x < (ONE ? tfloor_one : a.tfloor_c[lc[k]]);  // a memo index was built from this pair's length code
+        lsum += floored ? (ONE ? logfloor_one : a.logfloor_c[lc[k]]) : m[k].y - log2T;
+        zeros += (int)floored;
       } else if (state[k] > kPairOther) {  // as finish_read_compact(acc = 0)
         __builtin_nontemporal_store(0.0, out);
         zeros++;
@@ -727,10 +687,9 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
 
 // Classes 1 and 2: at most K = 2 / 4 records per mate, 16-byte records, overwrite rule in registers.
 // Slots [slot_lo, slot_hi), blocks [block_lo, block_hi).
-template <int K, int ABL, bool GEN>
+template <int K, bool GEN>
 __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
                                                  double& lsum, int& zeros) {
-  if (ABL >= 1 && ABL != 4 && ABL != 8) return;  // ablations 1,2,3,5: compact classes alone; 4: compact stream-only + these classes in full; 8: timeline
   unsigned long long* bits = GEN ? a.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2) : nullptr;
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
     const int t = i - a.n0;
@@ -798,35 +757,35 @@ __global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const DeltaPa
   }
 }
 
-template <bool TICKET, int ABL, bool GEN>
+// TL: the in-kernel timeline of tools/kernel_timeline.py (a separate instantiation: the product kernels carry none of it)
+template <bool TICKET, bool GEN, bool TL>
 __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z) {
   double lsum = 0.0;
   int zeros = 0;
-  unsigned long long* tl = ABL == 8 ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
-  if (ABL == 8 && (threadIdx.x & 63) == 0) { tl[0] = wall_clock64(); tl[7] = lb < a.blocks0 ? 0 : (lb < a.blocks01 ? 1 : 2); }
+  unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
+  if (TL && (threadIdx.x & 63) == 0) { tl[0] = wall_clock64(); tl[7] = lb < a.blocks0 ? 0 : (lb < a.blocks01 ? 1 : 2); }
   if (lb < a.blocks0) {
-    const bool wide = a.memo && !a.cov_bits && a.wide4 == 0;  // block-uniform: memo present, no coverage marks to set
-    if ((ABL == 0 || ABL == 5) && wide && a.n_codes == 1) {
+    const bool wide = a.memo && !a.cov_bits;  // block-uniform: memo present, no coverage marks to set
+    if (!TL && wide && a.n_codes == 1) {
       paired_compact4_body<GEN, false, true>(a, lb, lsum, zeros);  // one length combination: no tables, no barrier
     } else {
       // the per-length-combination tables of the compact class (<= 256 entries each) are looked up once or twice
       // per pair, each time behind another load: from LDS they cost an LDS access instead of an L2 round trip
       __shared__ uint32_t sh_combo[256];
-      __shared__ double sh_floor[256], sh_logfloor[256];
-      for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_floor[k] = a.floor_c[k]; sh_logfloor[k] = a.logfloor_c[k]; }
+      __shared__ double sh_floor[256], sh_logfloor[256], sh_tfloor[256];
+      for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_floor[k] = a.floor_c[k]; sh_logfloor[k] = a.logfloor_c[k]; sh_tfloor[k] = a.tfloor_c ? a.tfloor_c[k] : 0.0; }
       __syncthreads();
       PairedArgs b = a;
-      b.len_combo = sh_combo; b.floor_c = sh_floor; b.logfloor_c = sh_logfloor;
-      if (ABL == 8 && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
-      if (ABL == 8) paired_compact4_body<GEN, true>(b, lb, lsum, zeros);
-      else if ((ABL == 0 || ABL == 5) && wide) paired_compact4_body<GEN>(b, lb, lsum, zeros);
-      else paired_compact_body<ABL, GEN>(b, lb, lsum, zeros);
+      b.len_combo = sh_combo; b.floor_c = sh_floor; b.logfloor_c = sh_logfloor; b.tfloor_c = sh_tfloor;
+      if (TL && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
+      if (wide) paired_compact4_body<GEN, TL>(b, lb, lsum, zeros);
+      else paired_compact_body<GEN>(b, lb, lsum, zeros);
     }
-  } else if (lb < a.blocks01) paired_regs_body<2, ABL, GEN>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
-  else if (lb < a.blocks012) paired_regs_body<4, ABL, GEN>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
+  } else if (lb < a.blocks01) paired_regs_body<2, GEN>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
+  else if (lb < a.blocks012) paired_regs_body<4, GEN>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
   else paired_delta_body(a, lb - a.blocks012, a.main_blocks - a.blocks012, lsum, zeros);
   block_reduce(lsum, zeros, sh_s, sh_z);
-  if (ABL == 8 && (threadIdx.x & 63) == 0) tl[6] = wall_clock64();
+  if (TL && (threadIdx.x & 63) == 0) tl[6] = wall_clock64();
   if (TICKET) {
     grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out,
                 a.cov_bits ? -1.0 : 0.0, a.n_reads, sh_s, sh_z);
@@ -961,7 +920,7 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
 // but read-only tables, so no ordering between them is needed.
 // GEN: the path set has windows that occur several times -- note their pairs for paired_general_kernel. Without
 // such windows the notes are compiled out (they cost 0.3 us of 12 at cfg3 even when nothing is noted).
-template <bool TICKET, int ABL = 0, bool GEN = false>
+template <bool TICKET, bool GEN = false, bool TL = false>
 __global__ __launch_bounds__(kBlock, 5) void paired_score_kernel(PairedArgs a) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
@@ -970,8 +929,171 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_kernel(PairedArgs a) {
   // REVERSE dispatch order so that the few long-latency blocks (overflow, multi-record classes)
   // start first and hide under the compact stream instead of forming a tail.
   const int lb = a.total_blocks - 1 - (int)blockIdx.x;
-  if (lb < a.main_blocks) paired_main_body<TICKET, ABL, GEN>(a, lb, sh_s, sh_z);
+  if (lb < a.main_blocks) paired_main_body<TICKET, GEN, TL>(a, lb, sh_s, sh_z);
   else paired_overflow_body<TICKET>(a, lb - a.main_blocks, a.total_blocks - a.main_blocks, sh_s, sh_z, cand);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Several path sets in ONE pass over the records (gaml_hip_calc_prob_batch; the move generators compare a handful of
+// near-identical candidate assemblies: moves.cc:107-113 LocalChange2, 694-800 FixGapLength, 1156-1305 FixRepForNode2).
+// A path set only changes WHERE windows sit (its occurrence tables, 12 B per window) and 2T; the records, the
+// memo of pair terms and the grid are the same for all of them. So: the compact class (90 % of the pairs) loads
+// its 8-byte records once and resolves them against every set's tables (S x 95 KB at cfg3: L2 resident) in an inner
+// loop; the other classes (10 % of the pairs, a few records each, L2 hits after the first set) simply run their body
+// once per set. Every (block, set) writes its own partial: same lane -> pair mapping and reduction order as the
+// single-set kernel, so a batch gives bit for bit what the sets give one by one.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxSets = 8;
+struct SetDev {  // what differs between the path sets of one batch
+  const Occ12* occ12[2];
+  const int* multi_off[2];
+  const int4* multi[2];
+  const double* tfloor_c;          // [code] for this set's 2T
+  double two_T, log_two_T;
+  unsigned long long* gen_bits;    // this set's notes for paired_general_kernel (GEN instantiation)
+  double* part_sum;                // this set's per-block partials
+  int* part_zero;
+};
+struct MultiSets { int n; int pad_; SetDev set[kMaxSets]; };
+
+__device__ __forceinline__ PairedArgs with_set(const PairedArgs& a, const SetDev& sd) {
+  PairedArgs b = a;
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) { b.m[mt].occ12 = sd.occ12[mt]; b.occ12[mt] = sd.occ12[mt]; b.m[mt].multi_off = sd.multi_off[mt]; b.m[mt].multi = sd.multi[mt]; }
+  b.tfloor_c = sd.tfloor_c; b.two_T = sd.two_T; b.log_two_T = sd.log_two_T; b.gen_bits = sd.gen_bits;
+  b.part_sum = sd.part_sum; b.part_zero = sd.part_zero;
+  return b;
+}
+
+// paired_compact4_body with the path sets in the inner loop. acc_s / acc_z: one running sum per (set, thread) in LDS
+// (a lane may take several rounds of four pairs; registers cannot be indexed by the set number).
+template <bool GEN, bool ONE>
+__device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, const MultiSets& ms, int lb, double* acc_s, int* acc_z) {
+  const unsigned stride = (unsigned)a.blocks0 * kBlock, n0 = (unsigned)a.n0;
+  const char* const rec0 = (const char*)a.rec8[0];
+  const char* const rec1 = (const char*)a.rec8[1];
+  const char* const memo = (const char*)a.memo;
+  char* const probs = (char*)a.probs;
+  const uint32_t l12_one = ONE ? a.len_combo[0] : 0u;
+  const double logfloor_one = ONE ? a.logfloor_c[0] : 0.0;
+  for (int s = 0; s < ms.n; s++) { acc_s[s * kBlock + threadIdx.x] = 0.0; acc_z[s * kBlock + threadIdx.x] = 0; }
+  for (unsigned base = (unsigned)lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
+    uint2 r1[4], r2[4];
+    unsigned lc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // the records: ONCE for all sets
+      const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
+      r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); lc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
+    }
+#pragma unroll 1
+    for (int s = 0; s < ms.n; s++) {
+      const SetDev& sd = ms.set[s];
+      const char* const occ0 = (const char*)sd.occ12[0];
+      const char* const occ1 = (const char*)sd.occ12[1];
+      const double log2T = sd.log_two_T, tfloor_one = ONE ? sd.tfloor_c[0] : 0.0;
+      const bool last_set = s == ms.n - 1;  // per-read probabilities: those of the last set, as after a sequence of calls
+      uint2 o1[4], o2[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const Occ12* e1 = (const Occ12*)(occ0 + (r1[k].y != ~0u ? (r1[k].x & 0xffffffu) : 0u) * 12u);
+        const Occ12* e2 = (const Occ12*)(occ1 + (r2[k].y != ~0u ? (r2[k].x & 0xffffffu) : 0u) * 12u);
+        o1[k] = make_uint2(e1->lo, e1->hi); o2[k] = make_uint2(e2->lo, e2->hi);
+      }
+      int state[4];
+      unsigned skip_bits = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        bool skip;
+        state[k] = compact_state(a, r1[k], r2[k], o1[k], o2[k], lc[k], ONE ? l12_one : a.len_combo[lc[k]], base + k * stride < n0, skip);
+        skip_bits |= (unsigned)skip << k;
+      }
+      double2 m[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
+      if (GEN) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned long long w = __ballot((skip_bits >> k) & 1u);
+          if ((threadIdx.x & 63) == 0 && base + k * stride < n0) sd.gen_bits[(base + k * stride) >> 6] = w;
+        }
+      }
+      double lsum = 0.0;
+      int zeros = 0;
+      bool other = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        double* const out = (double*)(probs + (base + k * stride) * 8u);
+        if (state[k] >= 0) {
+          if (last_set) __builtin_nontemporal_store(m[k].x, out);
+          const bool floored = m[k].x < (ONE ? tfloor_one : sd.tfloor_c[lc[k]]);
+          lsum += floored ? (ONE ? logfloor_one : a.logfloor_c[lc[k]]) : m[k].y - log2T;
+          zeros += (int)floored;
+        } else if (state[k] > kPairOther) {
+          if (last_set) __builtin_nontemporal_store(0.0, out);
+          zeros++;
+          lsum += ONE ? logfloor_one : a.logfloor_c[kPairZero - state[k]];
+        } else other |= state[k] == kPairOther && !((skip_bits >> k) & 1u);
+      }
+      if (__any(other)) {  // scores, but outside the memo: from the tables (rare)
+        const PairedArgs b = with_set(a, sd);
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+          if (state[k] != kPairOther || ((skip_bits >> k) & 1u)) continue;
+          const int i = (int)(base + k * stride);
+          Compact1 d;
+          compact_load(b, i, true, d);
+          d.o1 = d.r1 != kNone8 ? occ8_of(b.occ12[0], (unsigned)(d.r1 & 0xffffff)) : kNone8;
+          d.o2 = d.r2 != kNone8 ? occ8_of(b.occ12[1], (unsigned)(d.r2 & 0xffffff)) : kNone8;
+          const uint32_t l = b.len_combo[d.lc];
+          d.L1 = l & 0xffff; d.L2 = l >> 16;
+          CompactPrep q;
+          compact_prep(b, d, q);
+          compact_finish(b, i, d, q, make_double2(0.0, 0.0), lsum, zeros);
+        }
+      }
+      acc_s[s * kBlock + threadIdx.x] += lsum;
+      acc_z[s * kBlock + threadIdx.x] += zeros;
+    }
+  }
+}
+
+template <bool GEN>
+__global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArgs a, MultiSets ms) {
+  __shared__ double sh_s[kBlock / 64];
+  __shared__ int sh_z[kBlock / 64];
+  // the wave-per-pair blocks stage candidates here (16 KB), the compact blocks keep their per-set running sums here
+  // (8 sets x 256 threads x (8 + 4) B = 24 KB): block-uniform roles, one buffer
+  __shared__ __align__(16) unsigned char sh_raw[kMaxSets * kBlock * 12];
+  static_assert(sizeof(int4) * (kBlock / 64) * 2 * kOvfCap <= sizeof(sh_raw), "candidate staging must fit");
+  const int lb = a.total_blocks - 1 - (int)blockIdx.x;
+  if (lb < a.blocks0 && a.memo && !a.cov_bits) {
+    double* acc_s = (double*)sh_raw;
+    int* acc_z = (int*)(sh_raw + kMaxSets * kBlock * 8);
+    if (a.n_codes == 1) paired_compact4_multi_body<GEN, true>(a, ms, lb, acc_s, acc_z);
+    else {
+      __shared__ uint32_t sh_combo[256];
+      __shared__ double sh_logfloor[256];
+      for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_logfloor[k] = a.logfloor_c[k]; }
+      __syncthreads();
+      PairedArgs b = a;
+      b.len_combo = sh_combo; b.logfloor_c = sh_logfloor;
+      paired_compact4_multi_body<GEN, false>(b, ms, lb, acc_s, acc_z);
+    }
+    for (int s = 0; s < ms.n; s++) {
+      double lsum = acc_s[s * kBlock + threadIdx.x];
+      int zeros = acc_z[s * kBlock + threadIdx.x];
+      block_reduce(lsum, zeros, sh_s, sh_z);
+      if (threadIdx.x == 0) { ms.set[s].part_sum[lb] = lsum; ms.set[s].part_zero[lb] = zeros; }
+      __syncthreads();  // sh_s / sh_z are reused by the next set
+    }
+    return;
+  }
+  for (int s = 0; s < ms.n; s++) {  // the other classes: the single-set body, once per set
+    const PairedArgs b = with_set(a, ms.set[s]);
+    if (lb < a.main_blocks) paired_main_body<false, GEN, false>(b, lb, sh_s, sh_z);
+    else paired_overflow_body<false>(b, lb - a.main_blocks, a.total_blocks - a.main_blocks, sh_s, sh_z, (int4(*)[2][kOvfCap])sh_raw);
+    __syncthreads();
+  }
 }
 
 // Second launch, only for path sets in which some window occurs several times: one lane per table-class slot,

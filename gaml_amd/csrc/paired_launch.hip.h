@@ -1,0 +1,743 @@
+// paired_launch.hip.h -- a paired read set on the device: tables, per-call arena, kernel arguments, launches.
+// (CalcScoreForPathsNew graph.cc:1952-1989 evaluated from scratch; included by gaml_hip.hip only.)
+//
+//   prepare_paired_tables      once per set: insert-size / floor tables (host libm) on the device
+//   paired_sync_tables         cold path: the record tables follow the window cache (delta lists or a full rebuild)
+//   paired_layout / _pack      per path set: where its tables sit in an arena slot, and the bytes
+//   arena_acquire / _commit    the slot itself: device memory the HOST writes directly (PCIe BAR), or pinned staging
+//                              + copy when the device has no large BAR
+//   paired_base_args / paired_set_view   kernel arguments: what is common to all path sets / what one set changes
+//   launch_paired              one path set: ONE dispatch (paired_score_kernel) on the warm path
+//   launch_paired_multi        up to 8 path sets in one pass over the records (paired_score_multi_kernel)
+#pragma once
+
+namespace {
+
+int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
+  if (s.tabs_uploaded) return 0;
+  const double c0 = s.cfg.min_prob_start, k0 = s.cfg.min_prob_per_base;
+  // The reference tabulates GetInsertProbability for d < mean + 5 sd (graph.cc:1801-1804) and calls
+  // the same function directly beyond (:1877-1882). Same formula, so one host table serves both;
+  // it is extended until the f64 value is exactly 0.0 (exp underflows at z ~ 38.6; it is
+  // monotone beyond the mean, so everything further is 0.0 too). No exp() on the device.
+  auto ins = [&](int d) {
+    double z = ((double)d - s.cfg.insert_mean) / s.cfg.insert_std;  // graph.cc:1593-1598
+    return std::exp(-z * z / 2.0) / (std::sqrt(2 * M_PI) * s.cfg.insert_std);
+  };
+  const int kInsCap = 1 << 22;
+  s.ins_tab.clear();
+  for (int d = 0; d < kInsCap; d++) {
+    double v = ins(d);
+    if (v == 0.0 && (double)d > s.cfg.insert_mean) break;
+    s.ins_tab.push_back(v);
+  }
+  if ((int)s.ins_tab.size() >= kInsCap)
+    return fail(c, GAML_HIP_EINVAL, "insert_std too large: the insert-size table would exceed 4M entries");
+  int smax = s.mate[0].max_len + s.mate[1].max_len;
+  s.floor_tab.resize(smax + 1);
+  s.logfloor_tab.resize(smax + 1);
+  for (int v = 0; v <= smax; v++) {
+    s.floor_tab[v] = std::exp(c0 + k0 * v);          // graph.cc:1506-1507
+    s.logfloor_tab[v] = std::log(s.floor_tab[v]);    // graph.cc:1510-1512 on a floored read
+    if (!(s.floor_tab[v] > 0.0)) s.floor_positive = false;  // exp underflow: the reference then takes log(0) for a read without alignment
+  }
+  s.covthr_tab.resize(s.mate[1].max_len + 1);
+  for (int v = 0; v <= s.mate[1].max_len; v++) s.covthr_tab[v] = std::exp(c0 + k0 * (v + v));  // graph.cc:1855-1857
+  size_t total = s.ins_tab.size() + s.floor_tab.size() + s.logfloor_tab.size() + s.covthr_tab.size();
+  HIP_TRY(c, s.tabs.reserve(std::max<size_t>(1, total) * sizeof(double)));
+  double* d = s.tabs.as<double>();
+  size_t at = 0;
+  auto up = [&](const std::vector<double>& v) -> hipError_t {
+    hipError_t e = v.empty() ? hipSuccess : hipMemcpy(d + at, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+    at += v.size();
+    return e;
+  };
+  HIP_TRY(c, up(s.ins_tab));
+  HIP_TRY(c, up(s.floor_tab));
+  HIP_TRY(c, up(s.logfloor_tab));
+  HIP_TRY(c, up(s.covthr_tab));
+  const int64_t n = s.mate[0].n_local();
+  HIP_TRY(c, s.len12.reserve(std::max<size_t>(1, n) * sizeof(uint32_t)));
+  HIP_TRY(c, s.probs.reserve(std::max<size_t>(1, n) * sizeof(double)));
+  HIP_TRY(c, s.red.init());
+  HIP_TRY(c, s.bad.reserve(sizeof(unsigned long long)));
+  s.tabs_uploaded = true;
+  return 0;
+}
+
+// pass 1: window registration / alignment of missing windows and the placement of cached windows
+// (memoised per distinct path: PairedPlanner)
+void prepare_paired_structure(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths) {
+  s.planner.begin(c->g, s.mate, paths);
+}
+
+// pass 2: position-filter thresholds (need the windows' global largest positions) + occurrence images
+void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
+  (void)c;
+  static const bool trace = getenv("GAML_HIP_TRACE_HOST") != nullptr;
+  const double q0 = now_us();
+  s.planner.finish(s.mate);
+  const double q1 = now_us();
+  const PlanView& v = s.planner.view();
+  const bool cov = s.cfg.penalty_constant > 0;
+  // coverage bitmap layout + contig starts (events of type 1, graph.cc:1826,1833-1835)
+  p.path_base.assign(1, 0);
+  p.start_off.assign(1, 0);
+  p.starts.clear();
+  if (cov) {  // only the coverage sweep reads these
+    p.path_base.reserve(v.paths.size() + 1);
+    p.start_off.reserve(v.paths.size() + 1);
+    for (const PathMemo* pm : v.paths) {
+      p.starts.insert(p.starts.end(), pm->starts.begin(), pm->starts.end());
+      p.start_off.push_back((int32_t)p.starts.size());
+      int32_t bits = ((pm->length + 64 + 31) / 32) * 32;  // one bit per path position, padded to words (+ slack)
+      p.path_base.push_back(p.path_base.back() + bits);
+    }
+  }
+  p.total_bits = p.path_base.back();
+  p.n_paths = (int32_t)v.paths.size();
+  const double q2 = now_us();
+  p.assembled_records = 0;
+  for (int mt = 0; mt < 2; mt++) {
+    s.image[mt].build(s.mate[mt].wins.size(), v, mt);  // sized to the final window count
+    for (const PathMemo* pm : v.paths) p.assembled_records += pm->assembled[mt];
+  }
+  p.general = !s.image[0].general_wids.empty() || !s.image[1].general_wids.empty();
+  if (trace) fprintf(stderr, "pass2: finish %.1f us, starts %.1f us, images %.1f us\n", q1 - q0, q2 - q1, now_us() - q2);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cold path: the device record tables follow the alignment-window cache
+// ---------------------------------------------------------------------------------------------------------
+// the pair's records as the device tables hold them (activated before the last full build)
+void paired_base_records(const PairedSet& s, int32_t slot, int mt, std::vector<RecQuad>& out) {
+  const int64_t n0s = s.pt.class_count[0];
+  if (slot < n0s) {
+    const uint64_t r = s.pt.rec8[mt][slot];
+    if (r != kNoRec8) out.push_back(RecQuad{(int32_t)(r & 0xffffff), (int32_t)((r >> 24) & 0xfffffff), (int32_t)((r >> 52) & 63) | ((int32_t)((r >> 58) & 1) << 8), 0});
+  } else {
+    const RecQuad& f = s.pt.rm[mt].first[slot - n0s];
+    if (f.wid >= 0) {
+      const int cnt1 = 1 + (int)((uint32_t)f.flags >> 9);
+      for (int q = 0; q < cnt1; q++) { RecQuad r = q == 0 ? f : s.pt.rm[mt].extra[f.link + q - 1]; r.flags &= 0x1ff; r.link = 0; out.push_back(r); }
+    }
+  }
+}
+
+// windows activated since the tables were built: their pairs move to the delta list (host side)
+void paired_extend_delta(PairedSet& s) {
+  for (int mt = 0; mt < 2; mt++) {
+    const ShortMate& m = s.mate[mt];
+    for (int32_t w : m.activated_log) {
+      const Window& win = m.wins[w];
+      for (int64_t k = win.first; k < win.first + win.count; k++) {
+        const gaml_aligment& r = m.pool[k];
+        const int32_t slot = s.pt.slot_of_read[r.read_id];
+        auto it = s.dirty_index.find(slot);
+        if (it == s.dirty_index.end()) {
+          it = s.dirty_index.emplace(slot, (int32_t)s.dirty.size()).first;
+          s.dirty.emplace_back();
+          s.dirty.back().slot = slot;
+          paired_base_records(s, slot, 0, s.dirty.back().recs[0]);
+          paired_base_records(s, slot, 1, s.dirty.back().recs[1]);
+        }
+        s.dirty_touched.push_back(it->second);
+        auto& lst = s.dirty[it->second].recs[mt];
+        RecQuad q{w, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
+        // keep the device-table order: (window id, position)
+        auto pos = std::upper_bound(lst.begin(), lst.end(), q, [](const RecQuad& x, const RecQuad& y) { return x.wid != y.wid ? x.wid < y.wid : x.pos < y.pos; });
+        lst.insert(pos, q);
+      }
+    }
+  }
+  for (int mt = 0; mt < 2; mt++) { s.mate[mt].activated_log.clear(); s.dev[mt].uploaded_generation = s.mate[mt].active_generation; }
+  s.delta_updates++;
+}
+
+// full rebuild: new device order of the pairs, record tables built on the host and uploaded; the memo of pair terms
+// (nothing in it depends on a path set: PairedArgs::memo) is tabulated here too
+int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
+  s.dirty.clear();
+  s.dirty_index.clear();
+  s.dirty_marked = 0;
+  s.dirty_touched.clear(); s.spill_of.clear(); s.spill_pairs.clear(); s.spill_changed = false;
+  s.full_rebuilds++;
+  for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
+  const double tb0 = now_us();
+  build_pair_tables(s.mate[0], s.mate[1], s.pt);
+  const double tb1 = now_us();
+  HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old tables
+  auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = d.reserve(std::max<size_t>(16, bytes));
+    if (e != hipSuccess || bytes == 0) return e;
+    return hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice);
+  };
+  for (int mt = 0; mt < 2; mt++) {
+    MateDev& d = s.dev[mt];
+    const ShortMate& m = s.mate[mt];
+    if (d.pow_n == 0) {
+      d.pow_n = m.match_pow.size();
+      HIP_TRY(c, d.pows.reserve(2 * d.pow_n * sizeof(double)));
+      HIP_TRY(c, hipMemcpy(d.pows.p, m.mismatch_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(d.pows.as<double>() + d.pow_n, m.match_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(c, up(s.rec8[mt], s.pt.rec8[mt].data(), s.pt.rec8[mt].size() * sizeof(uint64_t)));
+    HIP_TRY(c, up(d.first, s.pt.rm[mt].first.data(), s.pt.rm[mt].first.size() * sizeof(RecQuad)));
+    HIP_TRY(c, up(d.extra, s.pt.rm[mt].extra.data(), s.pt.rm[mt].extra.size() * sizeof(RecQuad)));
+    HIP_TRY(c, up(s.inl[mt], s.pt.inl[mt].data(), s.pt.inl[mt].size() * sizeof(RecQuad)));
+    d.uploaded_generation = m.active_generation;
+  }
+  HIP_TRY(c, up(s.len_code, s.pt.len_code.data(), s.pt.len_code.size()));
+  HIP_TRY(c, up(s.len_combo, s.pt.len_combo.data(), s.pt.len_combo.size() * sizeof(uint32_t)));
+  HIP_TRY(c, up(s.len12, s.pt.len12.data(), s.pt.len12.size() * sizeof(uint32_t)));
+  // per length-combination tables of the compact path: [pe mate 0 | pe mate 1 | floor | logfloor | covthr]
+  const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
+  std::vector<double> t(nc * 64 * 2 + nc * 3, 0.0);
+  for (size_t ci = 0; ci < s.pt.len_combo.size(); ci++) {
+    const int L[2] = {(int)(s.pt.len_combo[ci] & 0xffff), (int)(s.pt.len_combo[ci] >> 16)};
+    for (int mt = 0; mt < 2; mt++)
+      for (int e = 0; e < 64 && e <= L[mt]; e++)
+        t[(size_t)mt * nc * 64 + ci * 64 + e] = s.mate[mt].mismatch_pow[e] * s.mate[mt].match_pow[L[mt] - e];  // graph.cc:1859-1863
+    t[2 * nc * 64 + ci] = s.floor_tab[L[0] + L[1]];
+    t[2 * nc * 64 + nc + ci] = s.logfloor_tab[L[0] + L[1]];
+    t[2 * nc * 64 + 2 * nc + ci] = s.covthr_tab[L[1]];
+  }
+  HIP_TRY(c, up(s.combo_tabs, t.data(), t.size() * sizeof(double)));
+  // memo of the pair terms a single-term pair can take (first 4 length combinations, edits < 7, every tabulated distance)
+  s.memo_codes = 0;
+  if (c->knobs[4] == 0 && s.floor_positive && !s.pt.len_combo.empty() && !s.ins_tab.empty()) {
+    const int codes = (int)std::min<size_t>(s.pt.len_combo.size(), 4);
+    const size_t entries = (size_t)codes * 49 * s.ins_tab.size();
+    if (entries <= ((size_t)1 << 24)) {
+      HIP_TRY(c, s.memo.reserve(entries * sizeof(double2)));
+      const double* ct = s.combo_tabs.as<double>();
+      hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
+                         ct, ct + nc * 64, s.tabs.as<double>(), (int)s.ins_tab.size(), codes, s.memo.as<double2>());
+      HIP_TRY(c, hipGetLastError());
+      s.memo_codes = codes;
+    }
+  }
+  if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "rebuild: tables on the host %.1f ms, uploads %.1f ms\n", (tb1 - tb0) * 1e-3, (now_us() - tb1) * 1e-3);
+  return 0;
+}
+
+// delta pairs: a patch for the pairs whose lists changed since the last upload (new windows were activated)
+int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
+  if (s.dirty_touched.empty()) return 0;
+  const size_t nd = s.dirty.size();
+  const int64_t np_all = s.mate[0].n_local();
+  if (s.delta_cap == 0) {  // sized once for the largest delta the rebuild policy allows: the store is never reallocated
+    s.delta_cap = (size_t)std::max<int64_t>(4096, np_all / 8) + 4096;
+    HIP_TRY(c, s.dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
+    HIP_TRY(c, s.dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
+    for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
+  }
+  if (nd > s.delta_cap) return fail(c, GAML_HIP_ESTATE, "delta store overflow (rebuild policy violated)");
+  std::sort(s.dirty_touched.begin(), s.dirty_touched.end());
+  s.dirty_touched.erase(std::unique(s.dirty_touched.begin(), s.dirty_touched.end()), s.dirty_touched.end());
+  s.spill_of.resize(nd, -1);
+  const size_t np_patch = s.dirty_touched.size();
+  void* ph = nullptr;
+  int pslot = stage_acquire(c, s.stage_delta, np_patch * sizeof(DeltaPatch), &ph);
+  if (pslot < 0) return pslot;
+  DeltaPatch* patch = (DeltaPatch*)ph;
+  for (size_t t = 0; t < np_patch; t++) {
+    const int32_t dj = s.dirty_touched[t];
+    const auto& d = s.dirty[dj];
+    DeltaPatch& pe = patch[t];
+    pe.dj = dj; pe.slot = d.slot; pe.pad = 0;
+    const bool lng = d.recs[0].size() > 4 || d.recs[1].size() > 4;
+    if (lng) {
+      if (s.spill_of[dj] < 0) { s.spill_of[dj] = (int32_t)s.spill_pairs.size(); s.spill_pairs.push_back(dj); }
+      s.spill_changed = true;
+    }
+    pe.spill = s.spill_of[dj];
+    for (int mt = 0; mt < 2; mt++)
+      for (int k = 0; k < 4; k++) {
+        const RecQuad none{-1, 0, 0, 0};
+        const RecQuad& r = (!lng && k < (int)d.recs[mt].size()) ? d.recs[mt][k] : none;
+        pe.rec[mt][k] = make_int4(r.wid, r.pos, r.flags, r.link);
+      }
+  }
+  HIP_TRY(c, s.dl_patch.reserve(np_patch * sizeof(DeltaPatch) + 1));
+  if (int e = stage_upload(c, s.stage_delta, pslot, s.dl_patch.p, np_patch * sizeof(DeltaPatch), st)) return e;
+  if (int e = stage_release(c, s.stage_delta, pslot, st)) return e;
+  hipLaunchKernelGGL(apply_delta_patch_kernel, dim3((unsigned)std::min<size_t>((np_patch + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
+                     (const DeltaPatch*)s.dl_patch.p, (int)np_patch, s.dl_slot.as<int>(), s.dl_spill.as<int>(), s.dl_rec[0].as<int4>(), s.dl_rec[1].as<int4>());
+  HIP_TRY(c, hipGetLastError());
+  s.dirty_touched.clear();
+  if (s.spill_changed) {  // the few long lists: CSR rebuilt as a whole
+    const size_t ns = s.spill_pairs.size();
+    size_t dn[2] = {0, 0};
+    for (int32_t dj : s.spill_pairs) { dn[0] += s.dirty[dj].recs[0].size(); dn[1] += s.dirty[dj].recs[1].size(); }
+    size_t dt = 0;
+    for (int mt = 0; mt < 2; mt++) {
+      s.delta_off[2 * mt] = dt; dt = align16(dt + (ns + 1) * sizeof(int32_t));
+      s.delta_off[2 * mt + 1] = dt; dt = align16(dt + std::max<size_t>(1, dn[mt]) * sizeof(RecQuad));
+    }
+    void* dh = nullptr;
+    int dslot = stage_acquire(c, s.stage_delta, dt, &dh);
+    if (dslot < 0) return dslot;
+    for (int mt = 0; mt < 2; mt++) {
+      int32_t* of = (int32_t*)((char*)dh + s.delta_off[2 * mt]);
+      RecQuad* rc = (RecQuad*)((char*)dh + s.delta_off[2 * mt + 1]);
+      int32_t at = 0;
+      for (size_t k = 0; k < ns; k++) {
+        of[k] = at;
+        const auto& l = s.dirty[s.spill_pairs[k]].recs[mt];
+        if (!l.empty()) memcpy(rc + at, l.data(), l.size() * sizeof(RecQuad));
+        at += (int32_t)l.size();
+      }
+      of[ns] = at;
+    }
+    if (dt > s.delta_dev.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.delta_dev.reserve(dt + dt / 2)); }
+    if (int e = stage_upload(c, s.stage_delta, dslot, s.delta_dev.p, dt, st)) return e;  // stream order: after the kernels that read the old lists
+    if (int e = stage_release(c, s.stage_delta, dslot, st)) return e;
+    s.spill_changed = false;
+  }
+  return 0;
+}
+
+// Everything the record tables need before a scoring launch; enqueued on `st`. One call per evaluation (or batch).
+int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
+  bool need_full = s.dev[0].pow_n == 0;
+  const bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
+  s.quiet_calls = activated_now ? 0 : s.quiet_calls + 1;
+  // the cache has settled (no activation for a while) but pairs still sit on the slower delta path: fold them in
+  // A rebuild costs ~30 ms at 833 k pairs, a pair on the delta path ~0.4 ns per evaluation (one lane per pair). In an
+  // annealing run new junction windows appear every few calls, so folding after a short quiet spell
+  // (as an earlier version did after 16 calls) rebuilt 8 times per 1000 iterations for nothing;
+  // 64 quiet calls mean the path set has stopped producing new windows (steady re-scoring).
+  if (!need_full && !activated_now && !s.dirty.empty() && (s.quiet_calls >= 64 || s.compact_requested) && c->knobs[6] != 2) need_full = true;
+  s.compact_requested = false;
+  if (!need_full && activated_now) {
+    // Windows were activated since the tables were built. Few new records: keep the tables, put the
+    // affected pairs on the delta list. Many: rebuild.
+    const int64_t np = s.mate[0].n_local();
+    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / 8);
+    size_t new_records = 0;
+    for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
+    if (s.dirty.size() + new_records > limit) need_full = true;
+    else paired_extend_delta(s);
+  }
+  if (need_full) { if (int e = paired_rebuild_tables(c, s, st)) return e; }
+  if (int e = paired_upload_delta(c, s, st)) return e;
+  const size_t nd = s.dirty.size();
+  if (nd > s.dirty_marked) {  // marks stay on the device until the next full build: only new delta pairs need one
+    const size_t fresh = nd - s.dirty_marked;
+    const int n0 = (int)s.pt.class_count[0], n01 = n0 + (int)s.pt.class_count[1], n_main = n01 + (int)s.pt.class_count[2];
+    hipLaunchKernelGGL(mark_dirty_kernel, dim3((unsigned)std::min<size_t>((fresh + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
+                       s.dl_slot.as<int>() + s.dirty_marked, (int)fresh, s.rec8[0].as<unsigned long long>(), n0, s.inl[0].as<int4>(), n01,
+                       n_main, s.dev[0].first.as<int4>());
+    HIP_TRY(c, hipGetLastError());
+    s.dirty_marked = nd;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per path set: its tables inside an arena slot
+// ---------------------------------------------------------------------------------------------------------
+// GetTotalProb's "p = t / 2T; p < floor" as a threshold on t: the smallest double whose quotient by 2T reaches the
+// floor, found with the same IEEE division (monotone in t), so `t < tfloor` IS the reference's decision
+double tfloor_for(double floor, double two_T) {
+  if (!(floor > 0.0)) return 0.0;
+  double x = floor * two_T;
+  for (int k = 0; k < 64 && x > 0.0 && (std::nextafter(x, 0.0) / two_T) >= floor; k++) x = std::nextafter(x, 0.0);
+  for (int k = 0; k < 64 && (x / two_T) < floor; k++) x = std::nextafter(x, std::numeric_limits<double>::infinity());
+  return x;
+}
+
+struct PairedLayout { size_t tfloor_off; OccLayout l0, l1; size_t pb_off, so_off, st_off, total; };
+
+// pad_to: table entries per mate (a batch pads every set's tables to the window count the batch may reach)
+PairedLayout paired_layout(const PairedSet& s, const PairedPrep& p, const size_t* pad_to = nullptr) {
+  PairedLayout L;
+  L.tfloor_off = 0;
+  const size_t hdr = align16(256 * sizeof(double));  // thresholds per length code (the table of codes may grow with a rebuild)
+  L.l0 = layout_image(s.image[0], hdr, pad_to ? pad_to[0] : 0);
+  L.l1 = layout_image(s.image[1], L.l0.end, pad_to ? pad_to[1] : 0);
+  L.pb_off = L.l1.end; L.so_off = L.st_off = 0; L.total = L.l1.end;
+  if (s.cfg.penalty_constant > 0) {
+    L.so_off = align16(L.pb_off + p.path_base.size() * sizeof(int32_t));
+    L.st_off = align16(L.so_off + p.start_off.size() * sizeof(int32_t));
+    L.total = align16(L.st_off + p.starts.size() * sizeof(int32_t));
+  }
+  return L;
+}
+
+// the thresholds on t per length code for this set's 2T -- AFTER paired_sync_tables (a rebuild renumbers the codes)
+void paired_pack_thresholds(const PairedSet& s, const PairedLayout& L, double two_T, char* dst) {
+  double tf[256];
+  const size_t nc = std::min<size_t>(256, s.pt.len_combo.size());
+  for (size_t ci = 0; ci < nc; ci++) {
+    const int L0 = (int)(s.pt.len_combo[ci] & 0xffff), L1 = (int)(s.pt.len_combo[ci] >> 16);
+    tf[ci] = tfloor_for(s.floor_tab[L0 + L1], two_T);
+  }
+  if (nc) memcpy(dst + L.tfloor_off, tf, nc * sizeof(double));
+}
+
+// write-only (dst may be device memory behind the PCIe BAR: never read it back)
+void paired_pack(const PairedSet& s, const PairedPrep& p, const PairedLayout& L, char* dst) {
+  pack_image(s.image[0], L.l0, dst);
+  pack_image(s.image[1], L.l1, dst);
+  if (s.cfg.penalty_constant > 0) {
+    memcpy(dst + L.pb_off, p.path_base.data(), p.path_base.size() * sizeof(int32_t));
+    memcpy(dst + L.so_off, p.start_off.data(), p.start_off.size() * sizeof(int32_t));
+    memcpy(dst + L.st_off, p.starts.data(), p.starts.size() * sizeof(int32_t));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the arena: a ring of slots holding per-call tables. On a large-BAR device (MI355X) a slot is fine-grained device
+// memory that the host fills with plain stores through the PCIe BAR (write-combined: 96 KB in ~2 us,
+// tools/bar_write_probe.hip) -- no staging buffer, no copy command, no copy kernel in front of the scoring launch.
+// Otherwise (or knob 8 != 0): pinned staging slot + hipMemcpyAsync (knob 8 = 1) / copy kernel (knob 8 = 2).
+// ---------------------------------------------------------------------------------------------------------
+int arena_acquire(gaml_hip_ctx* c, Arena& A, size_t bytes, hipStream_t st, int* slot_out, char** write_ptr) {
+  const int k = A.next;
+  A.next = (A.next + 1) % kRing;
+  if (A.armed[k]) { HIP_TRY(c, hipEventSynchronize(A.done[k])); A.armed[k] = false; }
+  if (!A.done[k]) HIP_TRY(c, hipEventCreateWithFlags(&A.done[k], hipEventDisableTiming));
+  const bool direct = c->direct_write && c->knobs[8] == 0;
+  if (bytes > A.cap[k] || A.direct[k] != direct) {
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (A.dev[k]) { HIP_TRY(c, hipFree(A.dev[k])); A.dev[k] = nullptr; A.cap[k] = 0; }
+    const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+    if (direct) HIP_TRY(c, hipExtMallocWithFlags(&A.dev[k], want, hipDeviceMallocFinegrained));
+    else HIP_TRY(c, hipMalloc(&A.dev[k], want));
+    A.cap[k] = want; A.direct[k] = direct;
+  }
+  if (direct) *write_ptr = (char*)A.dev[k];
+  else { HIP_TRY(c, A.host[k].reserve(bytes)); *write_ptr = (char*)A.host[k].p; }
+  *slot_out = k;
+  return 0;
+}
+
+// after packing: make the bytes visible to the kernels launched next on `st`
+int arena_commit(gaml_hip_ctx* c, Arena& A, int k, size_t bytes, hipStream_t st) {
+  if (A.direct[k]) { _mm_sfence(); return 0; }  // drain the write-combining buffers; the doorbell write of the launch orders behind them
+  if (bytes == 0) return 0;
+  if (c->knobs[8] == 1 || (bytes & 15)) { HIP_TRY(c, hipMemcpyAsync(A.dev[k], A.host[k].p, bytes, hipMemcpyHostToDevice, st)); return 0; }
+  const int n16 = (int)(bytes / 16);
+  hipLaunchKernelGGL(stage_copy_kernel, dim3((unsigned)std::min(64, (n16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                     (const int4*)A.host[k].dev, (int4*)A.dev[k], n16);
+  HIP_TRY(c, hipGetLastError());
+  return 0;
+}
+
+int arena_release(gaml_hip_ctx* c, Arena& A, int k, hipStream_t st) {
+  if (c->host_results) return 0;  // a blocking call returns after the device is done with the slot: no event
+  HIP_TRY(c, hipEventRecord(A.done[k], st));
+  A.armed[k] = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel arguments
+// ---------------------------------------------------------------------------------------------------------
+struct GridPlan { int blocks0, blocks1, blocks2, blocks_d, main_blocks, ovf_blocks, total_blocks, gen_blocks; int64_t gen_words[3]; };
+
+// what every path set of a launch shares: record tables, length tables, memo, classes, grid
+void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp) {
+  const int64_t n = s.mate[0].n_local();
+  memset(&a, 0, sizeof(a));
+  for (int mt = 0; mt < 2; mt++) {
+    a.m[mt].first = s.dev[mt].first.as<int4>();
+    a.m[mt].extra = s.dev[mt].extra.as<int4>();
+    a.m[mt].mism_pow = s.dev[mt].pows.as<double>();
+    a.m[mt].match_pow = s.dev[mt].pows.as<double>() + s.dev[mt].pow_n;
+    a.rec8[mt] = s.rec8[mt].as<unsigned long long>();
+    a.inl[mt] = s.inl[mt].as<int4>();
+    a.dirty_recs[mt] = s.dl_rec[mt].as<int4>();
+    a.spill_off[mt] = (const int*)((const char*)s.delta_dev.p + s.delta_off[2 * mt]);
+    a.spill_recs[mt] = (const int4*)((const char*)s.delta_dev.p + s.delta_off[2 * mt + 1]);
+  }
+  a.len12 = s.len12.as<uint32_t>();
+  const double* tabs = s.tabs.as<double>();
+  a.ins_tab = tabs; a.ins_n = (int)s.ins_tab.size();
+  a.floor_tab = tabs + s.ins_tab.size();
+  a.logfloor_tab = a.floor_tab + s.floor_tab.size();
+  a.covthr_tab = a.logfloor_tab + s.logfloor_tab.size();
+  a.n = (int)n;
+  a.probs = s.probs.as<double>();
+  a.n_reads = (double)n;
+  a.ticket = s.red.ticket.as<unsigned>();
+  const int64_t n0 = s.pt.class_count[0], n01 = n0 + s.pt.class_count[1], n_main = n01 + s.pt.class_count[2];
+  a.n0 = (int)n0; a.n01 = (int)n01; a.n_main = (int)n_main;
+  const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
+  const double* ct = s.combo_tabs.as<double>();
+  a.pe[0] = ct; a.pe[1] = ct + nc * 64; a.floor_c = ct + 2 * nc * 64; a.logfloor_c = a.floor_c + nc; a.covthr_c = a.logfloor_c + nc;
+  a.len_code = s.len_code.as<unsigned char>();
+  a.len_combo = s.len_combo.as<uint32_t>();
+  a.n_codes = (int)std::min<size_t>(256, s.pt.len_combo.size());
+  a.memo = s.memo_codes > 0 ? s.memo.as<double2>() : nullptr;
+  a.lt_codes = s.memo_codes;
+  const size_t nd = s.dirty.size();
+  a.n_dirty = (int)nd;
+  a.dirty_slots = s.dl_slot.as<int>();
+  a.dirty_spill = s.dl_spill.as<int>();
+  const int64_t ovf_total = n - n_main;  // wave-per-pair items (delta pairs: lane per pair in the main range)
+  // 3 blocks per CU and one round of four pairs per lane at cfg3 (tools/kbench.py sweep); larger sets get more blocks, up to 8 per CU
+  const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : (int)std::min<int64_t>(kMaxBlocks, std::max<int64_t>(768, n0 / 2900));
+  gp.blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
+  // the 2-record class: a quarter of the compact class's blocks (3/4 block per CU at cfg3), lanes take 1-2 pairs;
+  // more blocks only crowd the compact class out (tools/kbench.py sweep: 312 blocks 16.4 us, 192 blocks 15.0 us)
+  const int cap1 = c->knobs[10] > 0 ? c->knobs[10] : cap0 / 4;
+  gp.blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, cap1));
+  gp.blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>((n_main - n01 + kBlock - 1) / kBlock, kMaxBlocks / 4));
+  // delta pairs: one lane per pair behind the table classes
+  gp.blocks_d = nd ? (int)std::min<int64_t>(((int64_t)nd + kBlock - 1) / kBlock, 1024) : 0;
+  gp.main_blocks = gp.blocks0 + gp.blocks1 + gp.blocks2 + gp.blocks_d;
+  gp.ovf_blocks = ovf_total > 0 ? (int)std::min<int64_t>((ovf_total + 3) / 4, kOvfMaxBlocks) : 0;
+  gp.total_blocks = gp.main_blocks + gp.ovf_blocks;
+  gp.gen_words[0] = (n0 + 63) / 64; gp.gen_words[1] = (n01 - n0 + 63) / 64; gp.gen_words[2] = (n_main - n01 + 63) / 64;
+  gp.gen_blocks = n_main > 0 ? (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, kMaxBlocks) : 0;
+  a.blocks0 = gp.blocks0;
+  a.blocks01 = gp.blocks0 + gp.blocks1;
+  a.blocks012 = gp.blocks0 + gp.blocks1 + gp.blocks2;
+  a.main_blocks = gp.main_blocks;
+  a.total_blocks = gp.total_blocks;
+  a.gen_w1 = (int)gp.gen_words[0]; a.gen_w2 = (int)(gp.gen_words[0] + gp.gen_words[1]);
+}
+
+// what one path set changes: its occurrence tables inside `arena`, 2T and the thresholds that follow from it
+void paired_set_view(const PairedLayout& L, const char* arena, int32_t total_len, SetDev& sd) {
+  const OccLayout* l[2] = {&L.l0, &L.l1};
+  for (int mt = 0; mt < 2; mt++) {
+    sd.occ12[mt] = (const Occ12*)(arena + l[mt]->direct);
+    sd.multi_off[mt] = (const int*)(arena + l[mt]->multi_off);
+    sd.multi[mt] = (const int4*)(arena + l[mt]->multi);
+  }
+  sd.tfloor_c = (const double*)(arena + L.tfloor_off);
+  const int tl = total_len == 0 ? 1 : total_len;  // graph.cc:1500-1502
+  sd.two_T = (double)(2 * tl);
+  sd.log_two_T = std::log(sd.two_T);
+  sd.gen_bits = nullptr; sd.part_sum = nullptr; sd.part_zero = nullptr;
+}
+
+void paired_apply_set(PairedArgs& a, const SetDev& sd) {
+  for (int mt = 0; mt < 2; mt++) { a.m[mt].occ12 = sd.occ12[mt]; a.m[mt].occ = nullptr; a.occ12[mt] = sd.occ12[mt]; a.m[mt].multi_off = sd.multi_off[mt]; a.m[mt].multi = sd.multi[mt]; }
+  a.tfloor_c = sd.tfloor_c; a.two_T = sd.two_T; a.log_two_T = sd.log_two_T;
+  a.gen_bits = sd.gen_bits; a.part_sum = sd.part_sum; a.part_zero = sd.part_zero;
+}
+
+CovArgs paired_cov_args(const PairedSet& s, const PairedPrep& p, const PairedLayout& L, const char* arena) {
+  CovArgs ca;
+  ca.bits = s.cov_bits.as<uint32_t>();
+  ca.path_base = (const int*)(arena + L.pb_off);
+  ca.start_off = (const int*)(arena + L.so_off);
+  ca.starts = (const int*)(arena + L.st_off);
+  ca.n_paths = p.n_paths;
+  ca.total_words = p.total_bits / 32;
+  ca.cov_move = s.cfg.step;
+  ca.far = s.cfg.insert_mean + 5 * s.cfg.insert_std;
+  ca.bad = s.bad.as<unsigned long long>();
+  return ca;
+}
+
+// per-block partials in pinned host memory (blocking calls): every block stores its partial straight there, the
+// host adds them up in the finisher kernel's order (no finisher launch, no D2H copy). Sentinels let the host see
+// when every partial has landed without waiting for the runtime's completion signal (fetch_partials).
+int paired_host_partials(gaml_hip_ctx* c, PairedSet& s, int n_sets, int n_partials, double** d_sum, int** d_zero) {
+  const size_t per = (size_t)(4 * kMaxBlocks + kOvfMaxBlocks);
+  HIP_TRY(c, s.h_part_sum.reserve(per * sizeof(double) * kMaxSets));
+  HIP_TRY(c, s.h_part_zero.reserve(per * sizeof(int) * kMaxSets));
+  *d_sum = (double*)s.h_part_sum.dev;
+  *d_zero = (int*)s.h_part_zero.dev;
+  double* hs = (double*)s.h_part_sum.p;
+  int* hz = (int*)s.h_part_zero.p;
+  for (int k = 0; k < n_sets; k++)
+    for (int b2 = 0; b2 < n_partials; b2++) { hs[(size_t)k * per + b2] = std::numeric_limits<double>::quiet_NaN(); hz[(size_t)k * per + b2] = INT_MIN; }
+  s.host_part_stride = per;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ONE path set
+// ---------------------------------------------------------------------------------------------------------
+int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_len, hipStream_t st, double* out4) {
+  if (int e = prepare_paired_tables(c, s)) return e;
+  const double tp0 = now_us();
+  prepare_paired_tables_host(c, s, p);  // pass 2 (pass 1 ran in eval_begin)
+  const double t_after_host = now_us();
+  c->prof[1] = t_after_host - tp0;  // thresholds + occurrence tables
+  if (int e = paired_sync_tables(c, s, st)) return e;  // cold path: nothing to do on a warm cache
+  const double tp1 = now_us();
+  c->prof[4] = tp1 - t_after_host;
+
+  const bool cov = s.cfg.penalty_constant > 0;
+  const PairedLayout L = paired_layout(s, p);
+  const int tl = total_len == 0 ? 1 : total_len;
+  int slot = 0;
+  char* wp = nullptr;
+  if (int e = arena_acquire(c, s.arena, L.total, st, &slot, &wp)) return e;
+  paired_pack(s, p, L, wp);
+  paired_pack_thresholds(s, L, (double)(2 * tl), wp);
+  if (int e = arena_commit(c, s.arena, slot, L.total, st)) return e;
+  const char* arena = (const char*)s.arena.dev[slot];
+  const double tp2 = now_us();
+  c->prof[2] = 0;
+  c->prof[3] = tp2 - tp1;  // per-call tables written (directly into device memory, or staged)
+  c->prof[6] = (double)L.total;
+
+  PairedArgs a;
+  GridPlan gp;
+  paired_base_args(c, s, a, gp);
+  SetDev sd;
+  paired_set_view(L, arena, total_len, sd);
+  const int64_t n = s.mate[0].n_local();
+  if (cov) {
+    size_t words = (size_t)p.total_bits / 32;
+    if (words * 4 > s.cov_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.cov_bits.reserve(std::max<size_t>(4, words * 4))); }
+    HIP_TRY(c, hipMemsetAsync(s.cov_bits.p, 0, std::max<size_t>(4, words * 4), st));
+    HIP_TRY(c, hipMemsetAsync(s.bad.p, 0, sizeof(unsigned long long), st));
+    a.cov_bits = s.cov_bits.as<uint32_t>();
+    a.path_base = (const int*)(arena + L.pb_off);
+  }
+  // some window occurs several times in this path set (or needs the long occurrence form): second launch over
+  // the pairs the main kernel notes
+  const bool gen_pass = a.n_main > 0 && p.general;
+  int gen_blocks = 0;
+  if (gen_pass) {
+    const size_t bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2]) * sizeof(unsigned long long);
+    if (bytes > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(bytes + bytes / 4)); }
+    sd.gen_bits = s.gen_bits.as<unsigned long long>();
+    gen_blocks = gp.gen_blocks;
+  }
+  const int n_partials = gp.total_blocks + gen_blocks;
+  sd.part_sum = s.red.part_sum.as<double>();
+  sd.part_zero = s.red.part_zero.as<int>();
+  if (c->host_results && n > 0) { if (int e = paired_host_partials(c, s, 1, n_partials, &sd.part_sum, &sd.part_zero)) return e; }
+  s.last_host_partials = c->host_results;
+  s.last_sets = 1;
+  paired_apply_set(a, sd);
+  a.out = out4;
+  a.timeline = nullptr;
+  const bool timeline = c->knobs[3] == 8;
+  if (timeline) {  // in-kernel timeline (tools/kernel_timeline.py): stamps land in mapped host memory
+    HIP_TRY(c, s.h_timeline.reserve((size_t)(4 * kMaxBlocks + kOvfMaxBlocks + 256) * (kBlock / 64) * 8 * sizeof(unsigned long long)));
+    memset(s.h_timeline.p, 0, s.h_timeline.cap);
+    a.timeline = (unsigned long long*)s.h_timeline.dev;
+    s.timeline_waves = a.total_blocks * (kBlock / 64);
+  }
+
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (n > 0) {
+    // HIP events bracket the dominant kernel only (bench.py's roofline; rocprofv3 must agree)
+    if (c->event_timing && (c->event_tick++ % c->event_every) == 0) { if (int e = take_events(c, &ev)) return e; }
+    int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
+    if (fin_mode == 0 && gen_pass) fin_mode = 1;
+    s.last_total_blocks = n_partials;
+    const dim3 grid(a.total_blocks), block(kBlock);
+    // Timed launches attach the two events to the dispatch itself (hipExtLaunchKernelGGL: the events carry
+    // the kernel's own begin / end stamps, what rocprofv3's kernel trace reports). Separate hipEventRecord
+    // markers around the launch would add the marker packets' processing to the interval: an EMPTY kernel
+    // of this grid reads 6 us that way (tools/stream_floor.hip).
+    hipEvent_t e0 = ev ? ev->first : nullptr, e1 = ev ? ev->second : nullptr;
+#define GAML_LAUNCH_SCORE(...) hipExtLaunchKernelGGL((paired_score_kernel<__VA_ARGS__>), grid, block, c->knobs[1], st, e0, e1, 0, a)
+    if (timeline) GAML_LAUNCH_SCORE(false, false, true);
+    else if (gen_pass) GAML_LAUNCH_SCORE(false, true);
+    else if (fin_mode) GAML_LAUNCH_SCORE(false, false);
+    else GAML_LAUNCH_SCORE(true, false);
+#undef GAML_LAUNCH_SCORE
+    HIP_TRY(c, hipGetLastError());
+    if (gen_pass) {
+      hipLaunchKernelGGL(paired_general_kernel, dim3(gen_blocks), dim3(kBlock), 0, st, a, a.total_blocks);
+      HIP_TRY(c, hipGetLastError());
+    }
+    if (fin_mode == 1) {
+      hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, n_partials, out4, cov ? -1.0 : 0.0, (double)n);
+      HIP_TRY(c, hipGetLastError());
+    }
+  } else {
+    s.last_total_blocks = 0;
+    if (!c->host_results) HIP_TRY(c, hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
+  }
+  if (cov && c->defer_cov) {
+    // the sweep needs the union of all ranks' coverage marks: gaml_hip_eval_coverage_finish_async runs it
+    int idx = 0;
+    for (size_t i = 0; i < c->paireds.size(); i++) if (c->paireds[i].get() == &s) idx = (int)i;
+    c->pending_cov.push_back(gaml_hip_ctx::PendingCov{idx, paired_cov_args(s, p, L, arena), out4});
+  } else if (cov && n > 0 && p.total_bits > 0) {
+    const CovArgs ca = paired_cov_args(s, p, L, arena);
+    hipLaunchKernelGGL(coverage_sweep_kernel, dim3(grid_for(ca.total_words)), dim3(kBlock), 0, st, ca);
+    HIP_TRY(c, hipGetLastError());
+  }
+  if (cov && n > 0 && !c->defer_cov) {
+    hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), out4, 1.0);
+    HIP_TRY(c, hipGetLastError());
+  }
+  if (int e = arena_release(c, s.arena, slot, st)) return e;
+  c->prof[5] = now_us() - tp2;  // kernel launches
+  // SURVEY.md 8d accounting: 16 B per record, 8 B read lengths, 8 B probability written, per pair
+  if (!c->event_timing || ev) {  // with timing on, the statistics describe the timed launches
+    c->stat_algo_bytes += 16.0 * (double)p.assembled_records + 16.0 * (double)n;
+    c->stat_launches++;
+  }
+  c->t_host_us += t_after_host;  // caller subtracts the start stamp
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// several path sets, one pass over the records. The caller has planned every set (pass 1 + pass 2 + pack) into
+// consecutive regions of ONE arena slot: `arena` + k * stride, layouts L[k]. Blocking only (partials in pinned memory).
+// ---------------------------------------------------------------------------------------------------------
+bool paired_multi_capable(const gaml_hip_ctx* c, const PairedSet& s) {
+  return !(s.cfg.penalty_constant > 0) && c->knobs[3] == 0 && c->knobs[4] == 0 && s.floor_positive;
+}
+
+int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int n_sets, const PairedLayout* L, const PairedPrep* preps, const int32_t* total_lens,
+                        const char* arena, size_t stride, hipStream_t st) {
+  PairedArgs a;
+  GridPlan gp;
+  paired_base_args(c, s, a, gp);
+  if (!a.memo) return fail(c, GAML_HIP_ESTATE, "multi-set launch without a memo (caller must check paired_multi_capable)");
+  const int64_t n = s.mate[0].n_local();
+  bool any_general = false;
+  for (int k = 0; k < n_sets; k++) any_general = any_general || (a.n_main > 0 && preps[k].general);
+  const size_t gen_bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2]) * sizeof(unsigned long long);
+  if (any_general && gen_bytes * n_sets > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(gen_bytes * kMaxSets + 64)); }
+  const int n_partials = gp.total_blocks + (any_general ? gp.gen_blocks : 0);
+  double* d_sum = nullptr;
+  int* d_zero = nullptr;
+  s.last_total_blocks = n > 0 ? n_partials : 0;
+  s.last_host_partials = true;
+  s.last_sets = n_sets;
+  if (n == 0) return 0;
+  if (int e = paired_host_partials(c, s, n_sets, n_partials, &d_sum, &d_zero)) return e;
+  MultiSets ms;
+  memset(&ms, 0, sizeof(ms));
+  ms.n = n_sets;
+  for (int k = 0; k < n_sets; k++) {
+    paired_set_view(L[k], arena + (size_t)k * stride, total_lens[k], ms.set[k]);
+    ms.set[k].part_sum = d_sum + (size_t)k * s.host_part_stride;
+    ms.set[k].part_zero = d_zero + (size_t)k * s.host_part_stride;
+    if (any_general) ms.set[k].gen_bits = (unsigned long long*)((char*)s.gen_bits.p + (size_t)k * gen_bytes);
+  }
+  paired_apply_set(a, ms.set[0]);  // (fields every set overrides; harmless defaults)
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (c->event_timing && (c->event_tick++ % c->event_every) == 0) { if (int e = take_events(c, &ev)) return e; }
+  hipEvent_t e0 = ev ? ev->first : nullptr, e1 = ev ? ev->second : nullptr;
+  const dim3 grid(a.total_blocks), block(kBlock);
+  if (any_general) hipExtLaunchKernelGGL((paired_score_multi_kernel<true>), grid, block, 0, st, e0, e1, 0, a, ms);
+  else hipExtLaunchKernelGGL((paired_score_multi_kernel<false>), grid, block, 0, st, e0, e1, 0, a, ms);
+  HIP_TRY(c, hipGetLastError());
+  if (any_general) {
+    for (int k = 0; k < n_sets; k++) {  // the notes of every set were written; only sets with such windows have any bit set
+      PairedArgs b = a;
+      paired_apply_set(b, ms.set[k]);
+      hipLaunchKernelGGL(paired_general_kernel, dim3(gp.gen_blocks), dim3(kBlock), 0, st, b, a.total_blocks);
+      HIP_TRY(c, hipGetLastError());
+    }
+  }
+  if (!c->event_timing || ev) {
+    double rec = 0;
+    for (int k = 0; k < n_sets; k++) rec += (double)preps[k].assembled_records;
+    c->stat_algo_bytes += 16.0 * rec + 16.0 * (double)n * n_sets;
+    c->stat_launches++;
+  }
+  return 0;
+}
+
+}  // namespace

@@ -35,7 +35,7 @@ def test_library_was_built_from_this_tree(built):
     import hashlib
     from gaml_amd import api
     rel = ["gaml_amd/csrc/kernels.hip.h", "gaml_amd/csrc/aligner.hip.h", "gaml_amd/csrc/pacbio_dp.hip.h", "gaml_amd/csrc/ctx.hip.h",
-           "gaml_amd/csrc/internal.h", "gaml_amd/csrc/gaml_hip.hip", "gaml_amd/csrc/multi.hip", "gaml_amd/csrc/host_model.h",
+           "gaml_amd/csrc/internal.h", "gaml_amd/csrc/paired_launch.hip.h", "gaml_amd/csrc/gaml_hip.hip", "gaml_amd/csrc/multi.hip", "gaml_amd/csrc/host_model.h",
            "gaml_amd/csrc/host_model.cc", "include/gaml_hip.h", "include/gaml_hip_debug.h"]
     h = hashlib.sha256()
     for r in rel:

@@ -66,6 +66,91 @@ def test_batch_against_the_oracle():
         assert abs(b[0] - w[0]) <= 1e-9 * abs(w[0])  # LL tolerance of the north star: 1e-6 relative
 
 
+def _pack(reads):
+    offs = np.zeros(len(reads) + 1, np.int64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    return np.concatenate([np.asarray(r, np.uint8) for r in reads]), offs
+
+
+def _paired_only(mixed_lengths=False, n=9000, seed=83):
+    from gaml_amd import api
+    genome = synth.plant_repeats(synth.make_genome(120_000, seed), 2, 700, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(120_000, seed, long_rng=(900, 4000)))
+    pr = synth.make_paired_reads(genome, n, 150, 300.0, 30.0, 0.01, seed)
+    m1, m2 = list(pr.mate1), list(pr.mate2)
+    if mixed_lengths:  # trimmed reads: several (L1, L2) combinations -> the length-code tables of the compact class
+        rng = np.random.default_rng(3)
+        for i in range(0, n, 3):
+            m1[i] = m1[i][: int(rng.integers(110, 150))]
+        for i in range(1, n, 5):
+            m2[i] = m2[i][: int(rng.integers(120, 150))]
+    walk = synth.genome_walk(g)
+    rng = np.random.default_rng(9)
+    sets = []
+    for k in range(19):  # more than one chunk of 8
+        cut = int(rng.integers(2, len(walk) - 2))
+        kind = k % 5
+        if kind == 0:
+            sets.append([walk[:cut], walk[cut:]])
+        elif kind == 1:
+            sets.append([walk[:cut] + walk[cut + 1:]])
+        elif kind == 2:
+            sets.append([walk[:cut], [x ^ 1 for x in reversed(walk[cut:])]])
+        elif kind == 3:  # a duplicated stretch: its windows occur several times (paired_general_kernel)
+            sets.append([walk[:cut] + walk[max(0, cut - 3):cut] + walk[cut:]])
+        else:
+            sets.append([walk[:cut] + [-int(rng.integers(10, 300))] + walk[cut + 2:], walk[2:9]])
+    sets.insert(7, [])
+
+    def make():
+        c = api.Context(device=0)
+        c.set_graph(*g.packed())
+        c.add_paired(api.paired_cfg(300.0, 30.0), *_pack(m1), *_pack(m2))
+        return c
+    return g, (m1, m2), sets, make
+
+
+@pytest.mark.parametrize("mixed_lengths", [False, True])
+def test_one_pass_batch_equals_single_calls(mixed_lengths):
+    """Contexts of paired sets only take the one-pass kernel (paired_score_multi_kernel): every set's tables resolved
+    against records that are loaded once. Cold (windows aligned along the way, delta lists), warm, after a table
+    rebuild; chunks of 8; sets with repeated windows; an empty set. Values, floored counts and the per-read
+    probabilities left behind are those of the single calls."""
+    g, reads, sets, make = _paired_only(mixed_lengths)
+    one, many = make(), make()
+    want = [one.calc_prob(s) for s in sets]
+    got = many.calc_prob_batch(sets)
+    assert len(got) == len(sets)
+    for w, b in zip(want, got):
+        assert b[2] == w[2] and b[1].tolist() == w[1].tolist()
+        assert abs(b[0] - w[0]) <= 1e-13 * abs(w[0]), (b[0], w[0])
+    assert np.array_equal(many.read_probs(0), one.read_probs(0))  # those of the last set
+    one.compact_tables(); many.compact_tables()
+    for rnd in range(2):
+        want = [one.calc_prob(s) for s in sets]
+        got = many.calc_prob_batch(sets)
+        for w, b in zip(want, got):
+            assert b[2] == w[2] and b[1].tolist() == w[1].tolist() and abs(b[0] - w[0]) <= 1e-13 * abs(w[0])
+    # same device state on both sides now: bit for bit
+    assert [b[0] for b in many.calc_prob_batch(sets[:8])] == [many.calc_prob(s)[0] for s in sets[:8]]
+    many.debug_set_knob(11, 1)  # the sequential path (one launch per set)
+    assert [b[0] for b in many.calc_prob_batch(sets[:8])] == [many.calc_prob(s)[0] for s in sets[:8]]
+
+
+def test_one_pass_batch_against_the_oracle():
+    import oracle_py as op
+    g, (m1, m2), sets, make = _paired_only(True, n=5000, seed=21)
+    o = op.Oracle()
+    o.set_graph(*g.packed())
+    o.add_paired(*_pack(m1), *_pack(m2), 0.01, op.paired_cfg(300.0, 30.0))
+    pick = [sets[0], sets[3], sets[4], sets[2], sets[7]]
+    got = make().calc_prob_batch(pick)
+    for s, b in zip(pick, got):
+        w = o.calc_prob(s, fresh=True)
+        assert b[1].tolist() == w[1].tolist() and b[2] == w[2]
+        assert (b[0] == w[0]) or abs(b[0] - w[0]) <= 1e-9 * abs(w[0])
+
+
 def test_batch_refused_on_sharded_context():
     from gaml_amd import api
     c = api.Context(device=0, rank=0, world=2)

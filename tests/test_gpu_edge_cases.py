@@ -209,8 +209,9 @@ def test_floor_that_underflows_to_zero():
 
 
 def test_upload_paths_agree():
-    """The per-call tables reach the device through a copy kernel reading the pinned staging slot; knob 8 = 1 selects
-    the hipMemcpyAsync route (also what odd sizes fall back to). Same values bit for bit."""
+    """The per-call tables are written by the host straight into device memory (large BAR: fine-grained allocation behind
+    the PCIe BAR); knob 8 = 1 selects the pinned staging slot + hipMemcpyAsync route, knob 8 = 2 staging + copy kernel
+    (what a device without a large BAR gets). Same values bit for bit -- also for a batch."""
     from gaml_amd import api
     genome = synth.make_genome(90_000, 141)
     g = synth.make_graph(genome, synth.cut_lengths(90_000, 141, long_rng=(600, 4000)))
@@ -222,6 +223,9 @@ def test_upload_paths_agree():
     sets = [[walk], [walk[:9], walk[9:]], [walk[:20] + [-40] + walk[22:]]]
     [ctx.calc_prob(s) for s in sets]
     a = [ctx.calc_prob(s)[0] for s in sets]
-    ctx.debug_set_knob(8, 1)
-    b = [ctx.calc_prob(s)[0] for s in sets]
-    assert a == b
+    ab = [b[0] for b in ctx.calc_prob_batch(sets)]
+    for knob in (1, 2, 0):
+        ctx.debug_set_knob(8, knob)
+        assert [ctx.calc_prob(s)[0] for s in sets] == a, knob
+        assert [b[0] for b in ctx.calc_prob_batch(sets)] == ab, knob
+    assert ab == a  # one pass over the records for all sets: the same lanes, the same sums
