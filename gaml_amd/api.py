@@ -180,6 +180,8 @@ def _load():
     L.gaml_hip_debug_prepare.argtypes = [vp, _i32p, _i64p, C.c_int32]
     L.gaml_hip_debug_occurrences.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int64]
     L.gaml_hip_debug_occurrences.restype = C.c_int64
+    L.gaml_hip_debug_table_occurrences.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int64, _i64p]
+    L.gaml_hip_debug_table_occurrences.restype = C.c_int64
     L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
@@ -637,6 +639,14 @@ class Context:
         out = np.zeros(5 * max(1, n), np.int32)
         _lib.gaml_hip_debug_occurrences(self._h, rs, mate, out, n)
         return out.reshape(-1, 5)[:n]
+
+    def debug_table_occurrences(self, rs, mate=0):
+        """(entries [n, 5] = window, shift, min_pos, path position, path-local rank; info = {incremental, incremental_calls, full_calls})"""
+        info = np.zeros(3, np.int64)
+        n = _lib.gaml_hip_debug_table_occurrences(self._h, rs, mate, np.zeros(5, np.int32), 0, info)
+        out = np.zeros(5 * max(1, n), np.int32)
+        _lib.gaml_hip_debug_table_occurrences(self._h, rs, mate, out, n, info)
+        return out.reshape(-1, 5)[:n], {"incremental": bool(info[0]), "incremental_calls": int(info[1]), "full_calls": int(info[2])}
 
     def debug_window_walk(self, rs, mate, wid) -> list:
         buf = np.zeros(64, np.int32)

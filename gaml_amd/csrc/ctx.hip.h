@@ -166,7 +166,17 @@ struct PairedSet {
   int last_total_blocks = 0, last_sets = 1;
   bool last_host_partials = false;
   DevBuf len12, probs, tabs, cov_bits, bad;
-  Arena arena;                        // per-call tables (occurrence images, thresholds, coverage layout)
+  Arena arena;                        // per-call tables (occurrence images, thresholds, coverage layout): ring, whole tables per call
+  // Blocking calls on a large-BAR device keep ONE resident copy of the tables and patch it in place (the kernel
+  // of the previous call is done when the call returns): a call that shares most paths with the previous one writes
+  // a few dozen 12-byte entries through the BAR instead of the whole image. Capacities leave room to grow.
+  struct Persist {
+    void* dev = nullptr; size_t bytes = 0;
+    size_t cap_w[2] = {0, 0}, cap_lo[2] = {0, 0}, cap_m[2] = {0, 0};  // table entries / list bounds / list entries per mate
+    size_t off_tfloor = 0, off_occ[2] = {0, 0}, off_lo[2] = {0, 0}, off_m[2] = {0, 0};
+    bool valid = false;                // the copy mirrors the host images as of their last take_changed()
+    void release() { if (dev) (void)hipFree(dev); dev = nullptr; bytes = 0; valid = false; }
+  } persist;
   size_t batch_slack = 0;             // extra bytes per path set region of a batch (grows when a set's tables did not fit)
   DevBuf gen_bits;  // one bit per table-class slot: needs paired_general_kernel (written by the main kernel)
   hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;
@@ -256,7 +266,7 @@ struct gaml_hip_ctx {
   double aln_us = 0;
   double aln_stage_us[5] = {0, 0, 0, 0, 0};  // window strings + upload, spans + candidates, extension, D2H of hits, sort + finalize
   int64_t aln_batches = 0;
-  int knobs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
+  int knobs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
   bool direct_write = false;  // large-BAR device: the host writes per-call tables straight into device memory (Arena)
   int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;
@@ -281,6 +291,7 @@ struct gaml_hip_ctx {
   // evaluation in progress (between eval_begin and eval_finish)
   bool pending_open = false;
   std::vector<Walk> pending_paths;
+  bool pending_paths_valid = false;  // contexts of paired sets only never materialise the vectors
   int32_t pending_total_len = 0;
   std::vector<std::unique_ptr<PairedPrep>> pending_prep;  // per paired set
   double pending_host_us = 0;

@@ -657,20 +657,27 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
   if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
   if (n_paths < 0 || (n_paths > 0 && (!flat || !offs))) return fail(c, GAML_HIP_EINVAL, "bad path arguments");
   const double t0 = now_us();
-  // (the vectors of the previous evaluation are reused: a path set of ~900 short paths would otherwise cost
-  // ~900 allocations per call)
-  c->pending_paths.resize((size_t)n_paths);
-  for (int32_t i = 0; i < n_paths; i++) c->pending_paths[i].assign(flat + offs[i], flat + offs[i + 1]);
-  for (auto& p : c->pending_paths)
-    for (int32_t x : p)
-      if (x >= c->g.n()) return fail(c, GAML_HIP_EINVAL, "path refers to a node outside the graph");
-  c->pending_total_len = 0;
-  for (auto& p : c->pending_paths) c->pending_total_len += walk_length(c->g, p);  // GetTotalLen graph.cc:1775-1781
+  for (int32_t i = 0; i < n_paths; i++) if (offs[i + 1] < offs[i]) return fail(c, GAML_HIP_EINVAL, "path offsets must not decrease");
+  // Paired sets take the paths in the ABI's flat form (their planner diffs them against the previous call's); the
+  // other kinds, or a context without a paired set, get them as vectors (reused: a set of ~900 short paths would
+  // otherwise cost ~900 allocations per call).
+  const bool want_vectors = c->paireds.empty() || !c->singles.empty() || !c->pacbios.empty();
+  c->pending_paths_valid = want_vectors;
+  if (want_vectors) {
+    c->pending_paths.resize((size_t)n_paths);
+    for (int32_t i = 0; i < n_paths; i++) c->pending_paths[i].assign(flat + offs[i], flat + offs[i + 1]);
+    for (auto& p : c->pending_paths)
+      for (int32_t x : p)
+        if (x >= c->g.n()) return fail(c, GAML_HIP_EINVAL, "path refers to a node outside the graph");
+    c->pending_total_len = 0;
+    for (auto& p : c->pending_paths) c->pending_total_len += walk_length(c->g, p);  // GetTotalLen graph.cc:1775-1781
+  }
   c->pending_prep.clear();
   c->pending_prep.resize(c->paireds.size());
   for (size_t i = 0; i < c->paireds.size(); i++) {
     c->pending_prep[i].reset(new PairedPrep());
-    prepare_paired_structure(c, *c->paireds[i], c->pending_paths);
+    if (int e = prepare_paired_structure(c, *c->paireds[i], flat, offs, n_paths)) return e;
+    if (!want_vectors) c->pending_total_len = c->paireds[i]->planner.total_len();
     // windows registered by pass 1 get their records now, all at once (GPU aligner when there is a device)
     for (int mt = 0; mt < 2; mt++)
       if (int e = gpu_align_pending(c, c->paireds[i]->mate[mt], c->paireds[i]->dev[mt].aln)) return e;
@@ -854,7 +861,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->paireds) {
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
       s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release(); s->len_code.release(); s->len_combo.release();
-      s->len12.release(); s->probs.release(); s->tabs.release(); s->arena.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
+      s->len12.release(); s->probs.release(); s->tabs.release(); s->arena.release(); s->persist.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); s->gen_bits.release();
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage);
@@ -2047,7 +2054,7 @@ int gaml_hip_debug_prepare(gaml_hip_ctx* c, const int32_t* flat, const int64_t* 
     else if (h.kind == 1) {
       PairedPrep p;
       PairedSet& ps = *c->paireds[h.idx];
-      prepare_paired_structure(c, ps, paths);
+      if (int e = prepare_paired_structure(c, ps, flat, offs, n_paths)) return e;
       for (int mt = 0; mt < 2; mt++) if (int e = gpu_align_pending(c, ps.mate[mt], ps.dev[mt].aln)) return e;
       prepare_paired_tables_host(c, ps, p);
     }
@@ -2071,6 +2078,25 @@ int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* c, int rs, int mate, int32_t* o
     out5[5 * i] = o.wid; out5[5 * i + 1] = o.shift; out5[5 * i + 2] = o.min_pos; out5[5 * i + 3] = o.path; out5[5 * i + 4] = o.rank;
   }
   return (int64_t)v->size();
+}
+
+int64_t gaml_hip_debug_table_occurrences(gaml_hip_ctx* c, int rs, int mate, int32_t* out5, int64_t cap, int64_t* info3) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || (mate != 0 && mate != 1)) return -1;
+  PairedSet& ps = *c->paireds[c->handles[rs].idx];
+  if (info3) { info3[0] = ps.planner.last_was_incremental(); info3[1] = (int64_t)ps.planner.incremental_calls; info3[2] = (int64_t)ps.planner.full_calls; }
+  std::vector<Occ> v;
+  ps.image[mate].dump(v);
+  const std::vector<int32_t>& slots = ps.planner.slots();
+  std::unordered_map<int32_t, int32_t> pos;
+  for (size_t k = 0; k < slots.size(); k++) pos[slots[k]] = (int32_t)k;
+  for (Occ& o : v) { auto it = pos.find(o.path); o.path = it == pos.end() ? -1 : it->second; }
+  std::sort(v.begin(), v.end(), [](const Occ& a, const Occ& b) { return a.path != b.path ? a.path < b.path : (a.rank != b.rank ? a.rank < b.rank : a.wid < b.wid); });
+  for (int64_t i = 0; i < (int64_t)v.size() && i < cap; i++) {
+    const Occ& o = v[(size_t)i];
+    out5[5 * i] = o.wid; out5[5 * i + 1] = o.shift; out5[5 * i + 2] = o.min_pos; out5[5 * i + 3] = o.path; out5[5 * i + 4] = o.rank;
+  }
+  return (int64_t)v.size();
 }
 
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wid, int32_t* out, int32_t cap) {
@@ -2120,7 +2146,7 @@ int gaml_hip_debug_timeline(gaml_hip_ctx* c, int rs, unsigned long long* out, in
 }
 
 int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
-  if (!c || knob < 0 || knob >= 12) return GAML_HIP_EINVAL;
+  if (!c || knob < 0 || knob >= 16) return GAML_HIP_EINVAL;
   if (c->multi) { for (int k = 0; k < gaml::multi_num_shards(c->multi); k++) gaml::multi_shard(c->multi, k)->knobs[knob] = value; return GAML_HIP_OK; }
   c->knobs[knob] = value;
   return GAML_HIP_OK;

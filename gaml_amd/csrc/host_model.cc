@@ -617,20 +617,22 @@ void occurrences_single_contig(const GraphStore& g, ShortMate& m, const int32_t*
 // ---------------------------------------------------------------------------------------
 // PairedPlanner
 // ---------------------------------------------------------------------------------------
-int32_t PairedPlanner::lookup_or_create(const GraphStore& g, const Walk& p) {
+int32_t PairedPlanner::lookup_or_create(const GraphStore& g, const int32_t* pp, int32_t len, std::string* err) {
+  Walk p(pp, pp + len);
   auto it = by_path_.find(p);
   if (it != by_path_.end()) { hits++; return it->second; }
+  for (int32_t x : p) if (x >= g.n()) { if (err) *err = "path refers to a node outside the graph"; return -1; }
   misses++;
   int32_t id;
   if (memos_.size() < kMaxMemos) {
     id = (int32_t)memos_.size();
     memos_.emplace_back(new PathMemo());
   } else {
-    // evict the least recently used memo that is not part of the current evaluation
+    // evict the least recently used memo that is not part of the current path set
     id = -1;
     uint64_t best = ~0ull;
     for (int32_t k = 0; k < (int32_t)memos_.size(); k++)
-      if (memos_[k]->last_used < clock_ && memos_[k]->last_used < best) { best = memos_[k]->last_used; id = k; }
+      if (memos_[k]->use_count == 0 && memos_[k]->last_used < best) { best = memos_[k]->last_used; id = k; }
     if (id < 0) { id = (int32_t)memos_.size(); memos_.emplace_back(new PathMemo()); }
     else { by_path_.erase(memos_[id]->path); uint32_t ser = memos_[id]->serial + 1; memos_[id].reset(new PathMemo()); memos_[id]->serial = ser; }
   }
@@ -647,7 +649,7 @@ int32_t PairedPlanner::lookup_or_create(const GraphStore& g, const Walk& p) {
     if (ci > 0) { cur += gaps[ci - 1]; pm.starts.push_back(cur); }
     for (int32_t k = ranges[ci].first; k < ranges[ci].second; k++) cur += g.len(p[k]);
   }
-  pm.length = cur;
+  pm.length = walk_length(g, p);  // GetTotalLen counts every gap, also a leading / trailing one (graph.cc:1775-1781)
   Walk w;
   for (int32_t i = 0; i < (int32_t)p.size(); i++) {
     if (p[i] < 0) continue;
@@ -667,7 +669,11 @@ void PairedPlanner::drain(ShortMate mate[2]) {
         auto it = missed_[mt].find(*m.win_walk[wid]);
         if (it == missed_[mt].end()) continue;
         for (auto& ref : it->second)
-          if (ref.first < (int32_t)memos_.size() && memos_[ref.first]->serial == ref.second) memos_[ref.first]->valid[mt] = false;
+          if (ref.first < (int32_t)memos_.size() && memos_[ref.first]->serial == ref.second) {
+            PathMemo& pm = *memos_[ref.first];
+            if (pm.valid[mt] && pm.use_count > 0) stale_.push_back(ref.first);  // in the current set: its table entries need a refresh
+            pm.valid[mt] = false;
+          }
         missed_[mt].erase(it);
       }
     }
@@ -688,9 +694,7 @@ void PairedPlanner::build_placements(const GraphStore& g, ShortMate& m, int mt, 
     const int32_t* ctg = pm.path.data() + ranges[ci].first;
     const int32_t n = ranges[ci].second - ranges[ci].first;
     register_for_contig(g, m, ctg, n);
-    const size_t before = pm.pl[mt].size();
     placements_paired_contig(g, m, ctg, n, cur_len, 0, (int32_t)ci, pm.pl[mt]);
-    (void)before;
     // remember the keys this contig looked up and missed
     for (int32_t i = 0; i < n; i++) {
       junction(g, ctg, n, i, false, w);
@@ -706,19 +710,16 @@ void PairedPlanner::build_placements(const GraphStore& g, ShortMate& m, int mt, 
   pm.occ_valid[mt] = false;
 }
 
-void PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const std::vector<Walk>& paths) {
-  clock_++;
-  cur_ids_.clear();
-  for (const Walk& p : paths) {
-    int32_t id = lookup_or_create(g, p);
-    memos_[id]->last_used = clock_;
-    cur_ids_.push_back(id);
-  }
-  // phase 1: PrecomputeAlignmentForPaths over the whole set, per mate (graph.cc:1967-1968)
+// phase 1 (PrecomputeAlignmentForPaths graph.cc:447-493, per mate) for the paths [from, to) of the current set. The
+// rule of a path's first node depends on the last_end its predecessor leaves (:449, 471-472): taken from the nearest
+// earlier path that has a node.
+void PairedPlanner::registration_chain(const GraphStore& g, ShortMate mate[2], int32_t from, int32_t to) {
   for (int mt = 0; mt < 2; mt++) {
     int32_t last_end = -1;
-    for (int32_t id : cur_ids_) {
-      PathMemo& pm = *memos_[id];
+    for (int32_t k = from - 1; k >= 0; k--)
+      if (memos_[cur_ids_[k]]->final_last_end != -2) { last_end = memos_[cur_ids_[k]]->final_last_end; break; }
+    for (int32_t k = from; k < to; k++) {
+      PathMemo& pm = *memos_[cur_ids_[k]];
       if (!pm.registered[mt]) {
         bool skipped = false;
         register_one_path(g, mate[mt], pm.path, last_end, &skipped);
@@ -733,44 +734,211 @@ void PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const std::vec
       if (pm.final_last_end != -2) last_end = pm.final_last_end;
     }
   }
-  // phase 2: per path in order: (re)build placements where the memo is stale
-  for (int32_t id : cur_ids_) {
-    drain(mate);
-    PathMemo& pm = *memos_[id];
-    for (int mt = 0; mt < 2; mt++)
-      if (!pm.valid[mt]) build_placements(g, mate[mt], mt, pm, id);
+}
+
+bool PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const int32_t* flat, const int64_t* offs, int32_t n_paths,
+                          bool allow_incremental, std::string* err) {
+  clock_++;
+  view_valid_ = false;
+  removed_.clear();
+  work_.clear();
+  drain(mate);  // windows aligned since the last call invalidate the memos that had looked them up in vain
+  const int64_t base = n_paths > 0 ? offs[0] : 0;
+  auto path_ptr = [&](int32_t k) { return flat + offs[k]; };
+  auto path_len = [&](int32_t k) { return (int32_t)(offs[k + 1] - offs[k]); };
+  // ---- what changed against the previous call: common prefix / suffix of whole paths
+  int32_t n_prev = have_prev_ ? (int32_t)prev_offs_.size() - 1 : 0;
+  int32_t P = 0, S = 0;
+  incremental_ = allow_incremental && have_prev_ && n_prev > 0 && n_paths > 0;
+  if (incremental_) {
+    auto same = [&](int32_t a, int32_t b) {  // path a of the previous set == path b of this one
+      const int64_t la = prev_offs_[a + 1] - prev_offs_[a];
+      return la == path_len(b) && (la == 0 || memcmp(prev_flat_.data() + prev_offs_[a], path_ptr(b), (size_t)la * sizeof(int32_t)) == 0);
+    };
+    const int32_t lim = std::min(n_prev, n_paths);
+    while (P < lim && same(P, P)) P++;
+    while (S < lim - P && same(n_prev - 1 - S, n_paths - 1 - S)) S++;
+    // more than half of the set changed: the whole-set rebuild is cheaper than path-by-path bookkeeping
+    if ((int64_t)(n_prev - P - S) + (n_paths - P - S) > (int64_t)(n_prev + n_paths) / 2) incremental_ = false;
   }
-  drain(mate);
-  view_.paths.clear();
-  for (int32_t id : cur_ids_) view_.paths.push_back(memos_[id].get());
+  if (!incremental_) {
+    // ---- from scratch: every path looked up, slots = positions
+    full_calls++;
+    for (int32_t id : cur_ids_) memos_[id]->use_count--;
+    cur_ids_.clear(); cur_slots_.clear(); free_slots_.clear(); stale_.clear();
+    total_len_ = 0;
+    for (int32_t k = 0; k < n_paths; k++) {
+      const int32_t id = lookup_or_create(g, path_ptr(k), path_len(k), err);
+      if (id < 0) { for (auto& pm : memos_) pm->use_count = 0; cur_ids_.clear(); cur_slots_.clear(); have_prev_ = false; return false; }
+      memos_[id]->last_used = clock_;
+      memos_[id]->use_count++;
+      cur_ids_.push_back(id);
+      cur_slots_.push_back(k);
+      total_len_ += memos_[id]->length;
+    }
+    next_slot_ = n_paths;
+    registration_chain(g, mate, 0, n_paths);
+    // phase 2: per path in order: (re)build placements where the memo is stale
+    for (int32_t id : cur_ids_) {
+      drain(mate);
+      PathMemo& pm = *memos_[id];
+      for (int mt = 0; mt < 2; mt++)
+        if (!pm.valid[mt]) build_placements(g, mate[mt], mt, pm, id);
+    }
+    drain(mate);
+    stale_.clear();  // (every memo of the set is looked at again by the next from-scratch call; an incremental one re-collects)
+    for (int32_t id : cur_ids_) { const PathMemo& pm = *memos_[id]; if (!pm.valid[0] || !pm.valid[1]) stale_.push_back(id); }
+  } else {
+    // ---- incremental: paths [P, n_prev - S) of the previous set leave, paths [P, n_paths - S) of this one enter
+    incremental_calls++;
+    const int32_t out_end = n_prev - S, in_end = n_paths - S;
+    std::vector<int32_t> freed_now;  // handed out again from the next call on
+    for (int32_t k = P; k < out_end; k++) {
+      PathMemo& pm = *memos_[cur_ids_[k]];
+      removed_.push_back(Removed{cur_slots_[k], {pm.assembled[0], pm.assembled[1]}, {pm.occ[0], pm.occ[1]}});  // lists as they stand: the memo may be evicted or rebuilt before apply()
+      pm.use_count--;
+      total_len_ -= pm.length;
+      freed_now.push_back(cur_slots_[k]);
+    }
+    std::vector<int32_t> in_ids, in_slots;
+    for (int32_t k = P; k < in_end; k++) {
+      const int32_t id = lookup_or_create(g, path_ptr(k), path_len(k), err);
+      if (id < 0) {  // leave a consistent "nothing known" state: the next call starts from scratch
+        for (auto& pm : memos_) pm->use_count = 0;
+        cur_ids_.clear(); cur_slots_.clear(); stale_.clear(); removed_.clear(); work_.clear(); have_prev_ = false; incremental_ = false;
+        return false;
+      }
+      memos_[id]->last_used = clock_;
+      memos_[id]->use_count++;
+      total_len_ += memos_[id]->length;
+      in_ids.push_back(id);
+      int32_t slot;
+      if (!free_slots_.empty()) { slot = free_slots_.back(); free_slots_.pop_back(); }
+      else slot = next_slot_++;
+      in_slots.push_back(slot);
+    }
+    free_slots_.insert(free_slots_.end(), freed_now.begin(), freed_now.end());
+    cur_ids_.erase(cur_ids_.begin() + P, cur_ids_.begin() + out_end);
+    cur_ids_.insert(cur_ids_.begin() + P, in_ids.begin(), in_ids.end());
+    cur_slots_.erase(cur_slots_.begin() + P, cur_slots_.begin() + out_end);
+    cur_slots_.insert(cur_slots_.begin() + P, in_slots.begin(), in_slots.end());
+    // registration: the new paths, and behind them everything up to the first path that has a node (its predecessor,
+    // i.e. the last_end it sees, changed; paths without a node pass the value through)
+    int32_t chain_end = in_end;
+    while (chain_end < n_paths) { const bool has_node = memos_[cur_ids_[chain_end]]->final_last_end != -2; chain_end++; if (has_node) break; }
+    registration_chain(g, mate, P, chain_end);
+    // memos to (re)place: the new paths, and memos of the set that were invalidated since they were placed. A memo
+    // is rebuilt once for all its instances; every instance's table entries are taken out first (with the lists as
+    // they stand) and put back after pass 2.
+    std::vector<char> redo(memos_.size(), 0);
+    for (int32_t id : in_ids) redo[id] = 1;
+    for (int32_t id : stale_) if (id < (int32_t)memos_.size() && memos_[id]->use_count > 0 && (!memos_[id]->valid[0] || !memos_[id]->valid[1] || !memos_[id]->occ_valid[0] || !memos_[id]->occ_valid[1])) redo[id] = 2;
+    stale_.clear();
+    // phase 2 in path order, as the whole-set pass does it: a placement built at position k may register windows
+    // (per-contig rule) that invalidate other memos of the set -- one with an instance BEHIND k is redone in this call
+    // too (the whole-set pass would reach it with valid = false), the others keep their tables until the next call
+    drain(mate);
+    size_t seen = stale_.size();
+    for (int32_t k = 0; k < n_paths; k++) {
+      const int32_t id = cur_ids_[k];
+      if (!redo[id]) continue;
+      PathMemo& pm = *memos_[id];
+      bool built = false;
+      for (int mt = 0; mt < 2; mt++)
+        if (!pm.valid[mt]) { build_placements(g, mate[mt], mt, pm, id); built = true; }
+      if (!built) continue;
+      drain(mate);
+      for (; seen < stale_.size(); seen++) {
+        const int32_t sid = stale_[seen];
+        if (sid >= (int32_t)redo.size() || redo[sid]) continue;
+        for (int32_t q = k + 1; q < n_paths; q++) if (cur_ids_[q] == sid) { redo[sid] = 2; break; }
+      }
+    }
+    // every instance of a memo that is being redone: instances that were in the tables before this call lose their
+    // entries (lists as they stand: pass 2 has not touched them yet), all instances get (back) in after pass 2
+    for (int32_t k = 0; k < n_paths; k++) {
+      const int32_t id = cur_ids_[k];
+      if (!redo[id]) continue;
+      if (k < P || k >= in_end) {
+        const PathMemo& pm = *memos_[id];
+        removed_.push_back(Removed{cur_slots_[k], {pm.assembled[0], pm.assembled[1]}, {pm.occ[0], pm.occ[1]}});
+      }
+      work_.push_back(k);
+    }
+    // keep for the next call what this one could not settle: memos invalidated behind their last instance
+    std::vector<int32_t> keep;
+    for (int32_t sid : stale_) if (sid < (int32_t)memos_.size() && memos_[sid]->use_count > 0 && (!memos_[sid]->valid[0] || !memos_[sid]->valid[1])) keep.push_back(sid);
+    stale_.swap(keep);
+  }
+  // remember this call's paths for the next diff
+  const int64_t total = n_paths > 0 ? offs[n_paths] - base : 0;
+  prev_flat_.assign(flat + base, flat + base + total);
+  prev_offs_.resize((size_t)n_paths + 1);
+  for (int32_t k = 0; k <= n_paths; k++) prev_offs_[k] = (n_paths > 0 ? offs[k] : 0) - base;
+  have_prev_ = true;
+  return true;
 }
 
 void PairedPlanner::invalidate_thresholds() {
   for (auto& pm : memos_) pm->occ_valid[0] = pm->occ_valid[1] = false;
+  have_prev_ = false;  // every occurrence list changes: the next call rebuilds the tables from scratch
 }
 
 void PairedPlanner::finish(ShortMate mate[2]) {
-  for (int32_t id : cur_ids_) {
-    PathMemo& pm = *memos_[id];
+  auto redo_occ = [&](PathMemo& pm) {
     for (int mt = 0; mt < 2; mt++) {
-      if (pm.occ_valid[mt]) {
-        // windows stay activated once used; nothing to redo
-        continue;
-      }
+      if (pm.occ_valid[mt]) continue;  // windows stay activated once used; nothing to redo
       pm.occ[mt].clear();
       occurrences_from_placements(mate[mt], pm.pl[mt], pm.occ[mt]);
       pm.assembled[mt] = 0;
       for (const Occ& o : pm.occ[mt]) pm.assembled[mt] += mate[mt].wins[o.wid].count;
       pm.occ_valid[mt] = true;
     }
+  };
+  if (!incremental_) {
+    for (int32_t id : cur_ids_) redo_occ(*memos_[id]);
+    assembled_[0] = assembled_[1] = 0;
+    for (int32_t id : cur_ids_) { assembled_[0] += memos_[id]->assembled[0]; assembled_[1] += memos_[id]->assembled[1]; }
+  } else {
+    for (int32_t k : work_) redo_occ(*memos_[cur_ids_[k]]);
   }
 }
 
-void PairedPlanner::flat_occurrences(int mate, std::vector<Occ>& out) const {
+const PlanView& PairedPlanner::view() {
+  if (!view_valid_) {
+    view_.paths.clear();
+    for (int32_t id : cur_ids_) view_.paths.push_back(memos_[id].get());
+    view_valid_ = true;
+  }
+  return view_;
+}
+
+void PairedPlanner::apply(ShortMate mate[2], OccImage image[2]) {
+  if (!incremental_) {
+    const PlanView& v = view();
+    for (int mt = 0; mt < 2; mt++) image[mt].build(mate[mt].wins.size(), v, mt);
+    return;
+  }
+  if ((int32_t)pos_of_slot_.size() < next_slot_) pos_of_slot_.resize((size_t)next_slot_ + 64, 0);
+  for (int32_t k = 0; k < (int32_t)cur_slots_.size(); k++) pos_of_slot_[cur_slots_[k]] = k;
+  for (int mt = 0; mt < 2; mt++) {
+    OccImage& im = image[mt];
+    for (const Removed& r : removed_) { im.remove_path(r.occ[mt], r.slot); assembled_[mt] -= r.assembled[mt]; }
+    for (int32_t k : work_) {
+      const PathMemo& pm = *memos_[cur_ids_[k]];
+      im.add_path(mate[mt].wins.size(), pm.occ[mt], cur_slots_[k]);
+      assembled_[mt] += pm.assembled[mt];
+    }
+    im.finalize(pos_of_slot_);
+  }
+}
+
+void PairedPlanner::flat_occurrences(int mate, std::vector<Occ>& out) {
   out.clear();
   int32_t rank0 = 0;
-  for (size_t slot = 0; slot < view_.paths.size(); slot++) {
-    const PathMemo& pm = *view_.paths[slot];
+  const PlanView& v = view();
+  for (size_t slot = 0; slot < v.paths.size(); slot++) {
+    const PathMemo& pm = *v.paths[slot];
     for (const Occ& o : pm.occ[mate]) out.push_back(Occ{o.wid, o.shift, o.min_pos, (int32_t)slot, rank0 + o.rank});
     rank0 += (int32_t)pm.occ[mate].size();
   }
@@ -976,63 +1144,140 @@ static inline uint64_t occ8_pack(const OccQuad& q, bool general) {
          ((uint64_t)(general ? 1 : 0) << 63);
 }
 
-void OccImage::build(size_t n_windows, const PlanView& view, int mate) {
-  if (occ12.size() < n_windows) {
-    occ12.resize(n_windows, Occ12{~0u, ~0u, 0});
-    cnt_.resize(n_windows, 0);
-    list_of_.resize(n_windows, -1);
-    stamp_.resize(n_windows, 0);
+// ---- OccImage: entries -------------------------------------------------------------------------------------
+// cnt_[w] = occurrences of window w in the current path set. One occurrence that the 8-byte form can hold lives in
+// the table entry itself; everything else (several occurrences, slot or threshold out of range) lives in gen_[w]
+// and the entry only carries the "general" flag + the list number.
+static inline bool occ_fits_direct(const OccQuad& q) { return q.path < 32767 && q.min_pos <= 32767; }
+static inline OccQuad occ_from_direct(const Occ12& f) {
+  return OccQuad{(int32_t)f.lo, (int32_t)(int16_t)(f.hi & 0xffff), (int32_t)((f.hi >> 16) & 0x7fff), f.rank};
+}
+
+void OccImage::grow(size_t n_windows) {
+  if (occ12.size() >= n_windows) return;
+  occ12.resize(n_windows, Occ12{~0u, ~0u, 0});
+  cnt_.resize(n_windows, 0);
+  list_of_.resize(n_windows, -1);
+  stamp_.resize(n_windows, 0);
+  mark_.resize(n_windows, 0);
+}
+
+void OccImage::set_direct(int32_t w, const OccQuad& q) {
+  const uint64_t e = occ8_pack(q, false);
+  occ12[w] = Occ12{(uint32_t)e, (uint32_t)(e >> 32), q.rank};
+  mark(w);
+}
+
+void OccImage::add_path(size_t n_windows, const std::vector<Occ>& occ, int32_t slot) {
+  grow(n_windows);
+  for (const Occ& o : occ) {
+    const OccQuad q{o.shift, o.min_pos, slot, o.rank};
+    const int32_t w = o.wid;
+    if (cnt_[w] == 0) {
+      cnt_[w] = 1;
+      if (stamp_[w] != serial_) { stamp_[w] = serial_; touched_.push_back(w); }
+      if (occ_fits_direct(q)) { set_direct(w, q); continue; }
+      gen_[w].push_back(q);
+    } else {
+      auto it = gen_.find(w);
+      if (it == gen_.end()) it = gen_.emplace(w, std::vector<OccQuad>(1, occ_from_direct(occ12[w]))).first;  // the direct occupant moves to the list
+      it->second.push_back(q);
+      cnt_[w]++;
+    }
+    lists_dirty_ = true;
   }
-  for (int32_t w : touched_) occ12[w] = Occ12{~0u, ~0u, 0};
-  touched_.clear();
-  if (++serial_ == 0) { std::fill(stamp_.begin(), stamp_.end(), 0); serial_ = 1; }
+}
+
+void OccImage::remove_path(const std::vector<Occ>& occ, int32_t slot) {
+  for (const Occ& o : occ) {
+    const int32_t w = o.wid;
+    if (w >= (int32_t)cnt_.size() || cnt_[w] == 0) continue;  // (cannot happen: every removal mirrors an add)
+    auto it = gen_.find(w);
+    if (it == gen_.end()) {  // the one direct occupant
+      cnt_[w] = 0;
+      occ12[w] = Occ12{~0u, ~0u, 0};
+      mark(w);
+      continue;
+    }
+    auto& lst = it->second;
+    for (size_t k = 0; k < lst.size(); k++)
+      if (lst[k].path == slot && lst[k].rank == o.rank && lst[k].shift == o.shift) { lst.erase(lst.begin() + k); break; }
+    cnt_[w] = (int32_t)lst.size();
+    lists_dirty_ = true;
+    if (lst.empty()) { gen_.erase(it); occ12[w] = Occ12{~0u, ~0u, 0}; mark(w); }
+    else if (lst.size() == 1 && occ_fits_direct(lst[0])) { const OccQuad q = lst[0]; gen_.erase(it); set_direct(w, q); }
+  }
+}
+
+void OccImage::finalize(const std::vector<int32_t>& pos_of_slot) {
+  if (!lists_dirty_) return;
+  lists_dirty_ = false;
+  lists_changed = true;
   multi_off.assign(1, 0);
   multi.clear();
   general_wids.clear();
-  pending_.clear();
-  // ONE pass over the occurrences (it used to be a counting pass + a filling pass): a window's first occurrence is
-  // written as a direct entry straight away; a second occurrence moves the first one to the pending list (the entry
-  // holds everything a list entry needs: a filter threshold clamped at -32768 filters like the exact one, positions
-  // are >= 0). list_of_: -1 = direct entry so far, -2 = on the pending list.
-  int32_t rank0 = 0;
+  if (gen_.empty()) return;
+  for (auto& e : gen_) general_wids.push_back(e.first);
+  std::sort(general_wids.begin(), general_wids.end());  // list numbering: by window id (any fixed order does)
+  for (int32_t w : general_wids) {
+    auto& lst = gen_[w];
+    // entries in visiting order: position of the path in the set, then the path-local rank
+    std::sort(lst.begin(), lst.end(), [&](const OccQuad& x, const OccQuad& y) {
+      const int32_t px = pos_of_slot[x.path], py = pos_of_slot[y.path];
+      return px != py ? px < py : x.rank < y.rank;
+    });
+    const int32_t list = (int32_t)multi_off.size() - 1;
+    multi.insert(multi.end(), lst.begin(), lst.end());
+    multi_off.push_back((int32_t)multi.size());
+    const uint64_t e = occ8_pack(OccQuad{0, 0, 0, 0}, true);  // only the flag is read (the occurrences are in the list); never all ones
+    const Occ12 ent{(uint32_t)e, (uint32_t)(e >> 32), -(list + 1)};
+    if (occ12[w].lo != ent.lo || occ12[w].hi != ent.hi || occ12[w].rank != ent.rank) { occ12[w] = ent; mark(w); }
+  }
+}
+
+void OccImage::dump(std::vector<Occ>& out) const {
+  out.clear();
+  for (size_t w = 0; w < cnt_.size(); w++) {
+    if (cnt_[w] == 0) continue;
+    auto it = gen_.find((int32_t)w);
+    if (it == gen_.end()) { const OccQuad q = occ_from_direct(occ12[w]); out.push_back(Occ{(int32_t)w, q.shift, q.min_pos, q.path, q.rank}); }
+    else for (const OccQuad& q : it->second) out.push_back(Occ{(int32_t)w, q.shift, q.min_pos, q.path, q.rank});
+  }
+}
+
+void OccImage::build(size_t n_windows, const PlanView& view, int mate) {
+  grow(n_windows);
+  for (int32_t w : touched_) { if (cnt_[w]) { occ12[w] = Occ12{~0u, ~0u, 0}; cnt_[w] = 0; } }
+  touched_.clear();
+  gen_.clear();
+  if (++serial_ == 0) { std::fill(stamp_.begin(), stamp_.end(), 0); serial_ = 1; }
+  // ONE pass over the occurrences: a window's first occurrence is written as a direct entry straight away; a second
+  // occurrence moves the first one to the window's list (the entry holds everything a list entry needs: a filter
+  // threshold clamped at -32768 filters like the exact one, positions are >= 0).
   for (size_t slot = 0; slot < view.paths.size(); slot++) {
     const PathMemo& pm = *view.paths[slot];
     for (const Occ& o : pm.occ[mate]) {
-      const OccQuad q{o.shift, o.min_pos, (int32_t)slot, rank0 + o.rank};
+      const OccQuad q{o.shift, o.min_pos, (int32_t)slot, o.rank};
       const int32_t w = o.wid;
       if (stamp_[w] != serial_) {  // first occurrence of this window in this path set
         stamp_[w] = serial_; cnt_[w] = 1; touched_.push_back(w);
-        if (q.path < 32767 && q.min_pos <= 32767) {  // the 8-byte form can hold it
+        if (occ_fits_direct(q)) {
           const uint64_t e = occ8_pack(q, false);
           occ12[w] = Occ12{(uint32_t)e, (uint32_t)(e >> 32), q.rank};
-          list_of_[w] = -1;
-        } else { pending_.push_back(Pending{w, q}); list_of_[w] = -2; }
+        } else gen_[w].push_back(q);
         continue;
       }
-      if (list_of_[w] == -1) {  // second occurrence: the first one leaves its direct entry
-        const Occ12& f = occ12[w];
-        pending_.push_back(Pending{w, OccQuad{(int32_t)f.lo, (int32_t)(int16_t)(f.hi & 0xffff), (int32_t)((f.hi >> 16) & 0x7fff), f.rank}});
-        list_of_[w] = -2;
-      }
-      pending_.push_back(Pending{w, q});
+      auto it = gen_.find(w);
+      if (it == gen_.end()) it = gen_.emplace(w, std::vector<OccQuad>(1, occ_from_direct(occ12[w]))).first;
+      it->second.push_back(q);
       cnt_[w]++;
     }
-    rank0 += (int32_t)pm.occ[mate].size();
   }
-  if (!pending_.empty()) {
-    // lists in order of first appearance, entries in visiting (rank) order
-    for (const Pending& pe : pending_)
-      if (list_of_[pe.wid] == -2) {
-        list_of_[pe.wid] = (int32_t)multi_off.size() - 1;
-        multi_off.push_back(multi_off.back() + cnt_[pe.wid]);
-        general_wids.push_back(pe.wid);
-        const uint64_t e = occ8_pack(OccQuad{0, 0, 0, 0}, true);  // only the flag is read (the occurrences are in the list); never all ones
-        occ12[pe.wid] = Occ12{(uint32_t)e, (uint32_t)(e >> 32), -(list_of_[pe.wid] + 1)};  //
-      }
-    multi.resize(multi_off.back());
-    std::vector<int32_t> fill(multi_off.size(), 0);
-    for (const Pending& pe : pending_) { int32_t l = list_of_[pe.wid]; multi[multi_off[l] + fill[l]++] = pe.q; }
-  }
+  changed_all = true;
+  lists_dirty_ = true;
+  std::vector<int32_t> ident(view.paths.size());
+  for (size_t k = 0; k < ident.size(); k++) ident[k] = (int32_t)k;  // slots are positions here
+  finalize(ident);
 }
 
 void build_occ_table(size_t n_windows, const std::vector<Occ>& occs, OccTable& out) {

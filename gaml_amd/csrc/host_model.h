@@ -212,13 +212,34 @@ struct OccImage {
   std::vector<int32_t> multi_off;
   std::vector<OccQuad> multi;
   std::vector<int32_t> general_wids;  // windows whose entry sends their reads to the general path
+  // whole path set at once (every path changed, first call, coverage penalty): O(occurrences)
   void build(size_t n_windows, const PlanView& view, int mate);
+  // one path's occurrences in or out (a call that shares most paths with the previous one): O(its occurrences).
+  // `slot` is what the entries carry as their path (stable while the path stays in the set; only equality of the
+  // two mates' paths matters to the scorers), the rank is path-local (it only ever orders occurrences of one path).
+  void add_path(size_t n_windows, const std::vector<Occ>& occ, int32_t slot);
+  void remove_path(const std::vector<Occ>& occ, int32_t slot);
+  // after the adds / removes of a call: the lists of windows that occur several times, entries in visiting order
+  // (position of the path in the set, then path-local rank) -- the order build() gives
+  void finalize(const std::vector<int32_t>& pos_of_slot);
+  // table entries that changed since the last take_changed() (window ids, each once); `all` = everything may have
+  std::vector<int32_t> changed;
+  bool changed_all = true, lists_changed = true;
+  // every occurrence the tables describe, as {window, shift, min_pos (as stored: clamped at -32768 in the 8-byte form), slot, rank}
+  void dump(std::vector<Occ>& out) const;
+  void take_changed() { changed.clear(); changed_all = false; lists_changed = false; if (++mark_serial_ == 0) { std::fill(mark_.begin(), mark_.end(), 0); mark_serial_ = 1; } }
  private:
+  void grow(size_t n_windows);
+  void mark(int32_t w) { if (mark_[w] != mark_serial_) { mark_[w] = mark_serial_; changed.push_back(w); } }
+  void set_direct(int32_t w, const OccQuad& q);
   std::vector<int32_t> touched_, cnt_, list_of_;
-  std::vector<uint32_t> stamp_;
-  uint32_t serial_ = 0;
+  std::vector<uint32_t> stamp_, mark_;
+  uint32_t serial_ = 0, mark_serial_ = 1;
   struct Pending { int32_t wid; OccQuad q; };
   std::vector<Pending> pending_;
+  // windows that need lists (several occurrences, or one that the 8-byte form cannot hold): all their occurrences
+  std::unordered_map<int32_t, std::vector<OccQuad>> gen_;
+  bool lists_dirty_ = false;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -244,6 +265,7 @@ struct PathMemo {
   int32_t length = 0;                    // incl. gaps
   int32_t first_idx = -1, first_end = -1;// first non-gap position and the end index of its junction window
   int32_t final_last_end = -2;           // last_end after the path (-2: path has no node, passes through)
+  int32_t use_count = 0;                 // instances in the current path set (a memo in use is never evicted)
   uint64_t last_used = 0;
   uint32_t serial = 0;                   // bumps when the slot is reused (stale ids in the miss index)
 };
@@ -254,24 +276,55 @@ struct PlanView {  // what one evaluation needs from the planner
 
 class PairedPlanner {
  public:
-  void begin(const GraphStore& g, ShortMate mate[2], const std::vector<Walk>& paths);  // pass 1
-  void finish(ShortMate mate[2]);                                                       // pass 2 (needs global maxima)
+  // pass 1: registration + placements for the path set given in the ABI's flat form. When the set shares a prefix
+  // and / or suffix of paths with the previous call's (what an annealing move leaves: it edits one or two paths), only
+  // the paths in between are looked at: hashing, registration replay, placements, occurrence lists and the table
+  // entries that follow from them are O(changed paths). Returns false (and sets *err) on a node id outside the graph.
+  // allow_incremental = false: everything from scratch (first call, coverage penalty, after the window maxima changed).
+  bool begin(const GraphStore& g, ShortMate mate[2], const int32_t* flat, const int64_t* offs, int32_t n_paths,
+             bool allow_incremental, std::string* err);
+  void finish(ShortMate mate[2]);          // pass 2 (needs the windows' records / global maxima): occurrence lists
+  // the occurrence tables of this call: whole-set rebuild or per-path adds / removes (what begin() decided)
+  void apply(ShortMate mate[2], OccImage image[2]);
   void invalidate_thresholds();          // window maxima changed (sharded cold path)
-  const PlanView& view() const { return view_; }
-  // flat occurrence list of the current path set (path = slot in the set, rank global, visiting order)
-  void flat_occurrences(int mate, std::vector<Occ>& out) const;
+  void forget_previous() { have_prev_ = false; }  // the next begin() starts from scratch
+  const PlanView& view();                // memos of the current set, in path order (built on demand)
+  // flat occurrence list of the current path set (path = index in the set, rank global, visiting order)
+  void flat_occurrences(int mate, std::vector<Occ>& out);
   size_t memo_count() const { return memos_.size(); }
-  uint64_t hits = 0, misses = 0;
+  int32_t total_len() const { return total_len_; }          // incl. gaps (GetTotalLen graph.cc:1775-1781)
+  int64_t assembled(int mate) const { return assembled_[mate]; }
+  int32_t n_paths() const { return (int32_t)cur_ids_.size(); }
+  bool last_was_incremental() const { return incremental_; }
+  const std::vector<int32_t>& slots() const { return cur_slots_; }  // slot of every path of the current set
+  uint64_t hits = 0, misses = 0, incremental_calls = 0, full_calls = 0;
  private:
-  int32_t lookup_or_create(const GraphStore& g, const Walk& p);
+  int32_t lookup_or_create(const GraphStore& g, const int32_t* p, int32_t len, std::string* err);
   void drain(ShortMate mate[2]);
   void build_placements(const GraphStore& g, ShortMate& m, int mt, PathMemo& pm, int32_t id);
+  void registration_chain(const GraphStore& g, ShortMate mate[2], int32_t from, int32_t to);
   std::vector<std::unique_ptr<PathMemo>> memos_;
   std::unordered_map<Walk, int32_t, WalkHasher> by_path_;
   // window key looked up and missed -> memos to invalidate when it gets aligned
   std::unordered_map<Walk, std::vector<std::pair<int32_t, uint32_t>>, WalkHasher> missed_[2];
   PlanView view_;
-  std::vector<int32_t> cur_ids_;
+  bool view_valid_ = false;
+  std::vector<int32_t> cur_ids_;         // memo of every path of the current set
+  std::vector<int32_t> cur_slots_;       // ... and its slot (the `path` its table entries carry)
+  std::vector<int32_t> free_slots_, pos_of_slot_;
+  int32_t next_slot_ = 0;
+  // previous call, for the diff
+  std::vector<int32_t> prev_flat_;
+  std::vector<int64_t> prev_offs_;
+  bool have_prev_ = false;
+  // what this call changes
+  bool incremental_ = false;
+  struct Removed { int32_t slot; int64_t assembled[2]; std::vector<Occ> occ[2]; };
+  std::vector<Removed> removed_;         // instances whose table entries go: their occurrence lists as they were when they went in
+  std::vector<int32_t> work_;            // path indices whose occurrences go (back) in after pass 2, ascending
+  std::vector<int32_t> stale_;           // memos invalidated while in use: refreshed at the next begin()
+  int32_t total_len_ = 0;
+  int64_t assembled_[2] = {0, 0};
   uint64_t clock_ = 0;
   static constexpr size_t kMaxMemos = 2048;
 };

@@ -67,8 +67,13 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
 
 // pass 1: window registration / alignment of missing windows and the placement of cached windows
 // (memoised per distinct path: PairedPlanner)
-void prepare_paired_structure(gaml_hip_ctx* c, PairedSet& s, const std::vector<Walk>& paths) {
-  s.planner.begin(c->g, s.mate, paths);
+int prepare_paired_structure(gaml_hip_ctx* c, PairedSet& s, const int32_t* flat, const int64_t* offs, int32_t n_paths) {
+  // a coverage penalty needs per-path bitmap layout by position (and the sweep's contig starts): whole-set planning;
+  // knob 12 = 1 forces it for A/B runs and tests
+  const bool incremental = !(s.cfg.penalty_constant > 0) && c->knobs[12] == 0;
+  std::string err;
+  if (!s.planner.begin(c->g, s.mate, flat, offs, n_paths, incremental, &err)) return fail(c, GAML_HIP_EINVAL, err);
+  return 0;
 }
 
 // pass 2: position-filter thresholds (need the windows' global largest positions) + occurrence images
@@ -78,13 +83,13 @@ void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
   const double q0 = now_us();
   s.planner.finish(s.mate);
   const double q1 = now_us();
-  const PlanView& v = s.planner.view();
   const bool cov = s.cfg.penalty_constant > 0;
   // coverage bitmap layout + contig starts (events of type 1, graph.cc:1826,1833-1835)
   p.path_base.assign(1, 0);
   p.start_off.assign(1, 0);
   p.starts.clear();
-  if (cov) {  // only the coverage sweep reads these
+  if (cov) {  // only the coverage sweep reads these (whole-set planning: slots are positions)
+    const PlanView& v = s.planner.view();
     p.path_base.reserve(v.paths.size() + 1);
     p.start_off.reserve(v.paths.size() + 1);
     for (const PathMemo* pm : v.paths) {
@@ -95,13 +100,10 @@ void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
     }
   }
   p.total_bits = p.path_base.back();
-  p.n_paths = (int32_t)v.paths.size();
+  p.n_paths = s.planner.n_paths();
   const double q2 = now_us();
-  p.assembled_records = 0;
-  for (int mt = 0; mt < 2; mt++) {
-    s.image[mt].build(s.mate[mt].wins.size(), v, mt);  // sized to the final window count
-    for (const PathMemo* pm : v.paths) p.assembled_records += pm->assembled[mt];
-  }
+  s.planner.apply(s.mate, s.image);  // the occurrence tables: whole-set rebuild, or the changed paths' entries in / out
+  p.assembled_records = s.planner.assembled(0) + s.planner.assembled(1);
   p.general = !s.image[0].general_wids.empty() || !s.image[1].general_wids.empty();
   if (trace) fprintf(stderr, "pass2: finish %.1f us, starts %.1f us, images %.1f us\n", q1 - q0, q2 - q1, now_us() - q2);
 }
@@ -434,6 +436,79 @@ int arena_release(gaml_hip_ctx* c, Arena& A, int k, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// the resident copy of the tables (blocking calls on a large-BAR device): patched in place through the BAR
+// ---------------------------------------------------------------------------------------------------------
+int paired_persist_update(gaml_hip_ctx* c, PairedSet& s, double two_T, hipStream_t st) {
+  PairedSet::Persist& P = s.persist;
+  OccImage* im = s.image;
+  size_t need_w[2], need_lo[2], need_m[2];
+  bool relayout = P.dev == nullptr;
+  for (int mt = 0; mt < 2; mt++) {
+    need_w[mt] = std::max<size_t>(1, im[mt].occ12.size());
+    need_lo[mt] = im[mt].multi_off.size();
+    need_m[mt] = std::max<size_t>(1, im[mt].multi.size());
+    if (need_w[mt] > P.cap_w[mt] || need_lo[mt] > P.cap_lo[mt] || need_m[mt] > P.cap_m[mt]) relayout = true;
+  }
+  bool full = !P.valid || im[0].changed_all || im[1].changed_all;
+  if (relayout) {
+    size_t at = align16(256 * sizeof(double));  // thresholds per length code
+    P.off_tfloor = 0;
+    for (int mt = 0; mt < 2; mt++) {
+      P.cap_w[mt] = need_w[mt] + need_w[mt] / 4 + 2048;
+      P.cap_lo[mt] = 2 * need_lo[mt] + 256;
+      P.cap_m[mt] = 2 * need_m[mt] + 1024;
+      P.off_occ[mt] = at; at = align16(at + P.cap_w[mt] * sizeof(Occ12));
+      P.off_lo[mt] = at; at = align16(at + P.cap_lo[mt] * sizeof(int32_t));
+      P.off_m[mt] = at; at = align16(at + P.cap_m[mt] * sizeof(OccQuad));
+    }
+    if (at > P.bytes) {
+      HIP_TRY(c, hipStreamSynchronize(st));
+      if (P.dev) { HIP_TRY(c, hipFree(P.dev)); P.dev = nullptr; }
+      HIP_TRY(c, hipExtMallocWithFlags(&P.dev, at, hipDeviceMallocFinegrained));
+      P.bytes = at;
+    }
+    full = true;
+  }
+  char* wp = (char*)P.dev;  // write-only: device memory behind the PCIe BAR
+  for (int mt = 0; mt < 2; mt++) {
+    OccImage& t = im[mt];
+    char* occ = wp + P.off_occ[mt];
+    if (full) {
+      if (!t.occ12.empty()) memcpy(occ, t.occ12.data(), t.occ12.size() * sizeof(Occ12));
+      memset(occ + t.occ12.size() * sizeof(Occ12), 0xff, (P.cap_w[mt] - t.occ12.size()) * sizeof(Occ12));  // windows to come: absent
+    } else {
+      for (int32_t w : t.changed) memcpy(occ + (size_t)w * sizeof(Occ12), &t.occ12[w], sizeof(Occ12));
+    }
+    if (full || t.lists_changed) {
+      memcpy(wp + P.off_lo[mt], t.multi_off.data(), t.multi_off.size() * sizeof(int32_t));
+      if (!t.multi.empty()) memcpy(wp + P.off_m[mt], t.multi.data(), t.multi.size() * sizeof(OccQuad));
+    }
+    t.take_changed();
+  }
+  PairedLayout L;  // only the threshold offset is used here
+  L.tfloor_off = P.off_tfloor;
+  paired_pack_thresholds(s, L, two_T, wp);
+  P.valid = true;
+  _mm_sfence();  // drain the write-combining buffers; the launch's doorbell write orders behind them
+  return 0;
+}
+
+void paired_persist_view(const PairedSet& s, int32_t total_len, SetDev& sd) {
+  const PairedSet::Persist& P = s.persist;
+  const char* base = (const char*)P.dev;
+  for (int mt = 0; mt < 2; mt++) {
+    sd.occ12[mt] = (const Occ12*)(base + P.off_occ[mt]);
+    sd.multi_off[mt] = (const int*)(base + P.off_lo[mt]);
+    sd.multi[mt] = (const int4*)(base + P.off_m[mt]);
+  }
+  sd.tfloor_c = (const double*)(base + P.off_tfloor);
+  const int tl = total_len == 0 ? 1 : total_len;
+  sd.two_T = (double)(2 * tl);
+  sd.log_two_T = std::log(sd.two_T);
+  sd.gen_bits = nullptr; sd.part_sum = nullptr; sd.part_zero = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------------------------------------
 struct GridPlan { int blocks0, blocks1, blocks2, blocks_d, main_blocks, ovf_blocks, total_blocks, gen_blocks; int64_t gen_words[3]; };
@@ -567,25 +642,38 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   c->prof[4] = tp1 - t_after_host;
 
   const bool cov = s.cfg.penalty_constant > 0;
-  const PairedLayout L = paired_layout(s, p);
   const int tl = total_len == 0 ? 1 : total_len;
-  int slot = 0;
-  char* wp = nullptr;
-  if (int e = arena_acquire(c, s.arena, L.total, st, &slot, &wp)) return e;
-  paired_pack(s, p, L, wp);
-  paired_pack_thresholds(s, L, (double)(2 * tl), wp);
-  if (int e = arena_commit(c, s.arena, slot, L.total, st)) return e;
-  const char* arena = (const char*)s.arena.dev[slot];
+  // blocking call on a large-BAR device: the resident copy of the tables is patched in place (a few entries when the
+  // path set shares most paths with the previous call's); otherwise a ring slot receives the whole tables
+  const bool resident = c->host_results && c->direct_write && c->knobs[8] == 0 && c->knobs[13] == 0 && !cov;
+  PairedLayout L;
+  memset(&L, 0, sizeof(L));
+  int slot = -1;
+  const char* arena = nullptr;
+  SetDev sd;
+  if (resident) {
+    c->prof[6] = (double)((s.image[0].changed_all || s.image[1].changed_all || !s.persist.valid) ? (s.image[0].occ12.size() + s.image[1].occ12.size()) * sizeof(Occ12)
+                                                                                            : (s.image[0].changed.size() + s.image[1].changed.size()) * sizeof(Occ12));
+    if (int e = paired_persist_update(c, s, (double)(2 * tl), st)) return e;
+    paired_persist_view(s, total_len, sd);
+  } else {
+    L = paired_layout(s, p);
+    char* wp = nullptr;
+    if (int e = arena_acquire(c, s.arena, L.total, st, &slot, &wp)) return e;
+    paired_pack(s, p, L, wp);
+    paired_pack_thresholds(s, L, (double)(2 * tl), wp);
+    if (int e = arena_commit(c, s.arena, slot, L.total, st)) return e;
+    arena = (const char*)s.arena.dev[slot];
+    paired_set_view(L, arena, total_len, sd);
+    c->prof[6] = (double)L.total;
+  }
   const double tp2 = now_us();
   c->prof[2] = 0;
   c->prof[3] = tp2 - tp1;  // per-call tables written (directly into device memory, or staged)
-  c->prof[6] = (double)L.total;
 
   PairedArgs a;
   GridPlan gp;
   paired_base_args(c, s, a, gp);
-  SetDev sd;
-  paired_set_view(L, arena, total_len, sd);
   const int64_t n = s.mate[0].n_local();
   if (cov) {
     size_t words = (size_t)p.total_bits / 32;
@@ -668,7 +756,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
     hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, s.bad.as<unsigned long long>(), out4, 1.0);
     HIP_TRY(c, hipGetLastError());
   }
-  if (int e = arena_release(c, s.arena, slot, st)) return e;
+  if (slot >= 0) { if (int e = arena_release(c, s.arena, slot, st)) return e; }
   c->prof[5] = now_us() - tp2;  // kernel launches
   // SURVEY.md 8d accounting: 16 B per record, 8 B read lengths, 8 B probability written, per pair
   if (!c->event_timing || ev) {  // with timing on, the statistics describe the timed launches

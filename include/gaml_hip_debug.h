@@ -38,6 +38,12 @@ int gaml_hip_debug_prepare(gaml_hip_ctx* ctx, const int32_t* paths, const int64_
 /* occurrence list of the last prepare/evaluation: 5 ints per entry {window id, shift, min_pos,
  * path, rank}; returns the number of entries. */
 int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int32_t* out5, int64_t cap);
+/* what the occurrence TABLES of the last prepare/evaluation hold (the host image that the device copy mirrors), as the
+ * same 5 ints per entry, path = position of the path in the set, rank = path-local; min_pos as stored (clamped at
+ * -32768 in the 8-byte entries). Sorted by (path, rank). For tests of the incremental table maintenance: must describe
+ * the same occurrences as gaml_hip_debug_occurrences. info3 (may be NULL): {1 if the last planning was incremental,
+ * incremental calls so far, whole-set calls so far}. */
+int64_t gaml_hip_debug_table_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int32_t* out5, int64_t cap, int64_t* info3);
 /* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
 /* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list}.
