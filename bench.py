@@ -116,6 +116,32 @@ def sa_pattern(ctx, rs, g, iters, api, synth):
             "recipe": "gaml_amd.synth.sa_sequence(seed 7): BreakPath / join / reverse / LocalChange / duplicate / trim edits, 60 % accepted"}
 
 
+def batched_candidates(ctx, g, api, synth, n_batches=40, per_batch=8):
+    """What the move generators do (moves.cc:107-113, 694-800, 1156-1305): several single-edit candidates of ONE current
+    assembly, scored together, the best kept. Base = a state of the annealing walk (~900 paths); every batch holds
+    `per_batch` different edits of the current base; 60 % of the batches move the base on."""
+    start, seq = synth.sa_sequence(g, 200, seed=11)
+    base = seq[-1]
+    rng = np.random.default_rng(23)
+    batches = []
+    for _ in range(n_batches):
+        cands = [synth.sa_move(rng, base, g) for _ in range(per_batch)]
+        batches.append(api.BatchPaths(cands))
+        if rng.random() < 0.6:
+            base = cands[int(rng.integers(0, per_batch))]
+    ctx.calc_prob(base)
+    for b in batches:  # cold pass: windows the candidates need get aligned
+        ctx.calc_prob_batch(b)
+    gc.disable()
+    t0 = time.perf_counter()
+    for b in batches:
+        ctx.calc_prob_batch(b)
+    dt = time.perf_counter() - t0
+    gc.enable()
+    return {"api": "gaml_hip_calc_prob_batch", "sets_per_call": per_batch, "calls": n_batches, "paths_per_set": len(base),
+            "ms_per_set": 1e3 * dt / (n_batches * per_batch), "pattern": "8 single-edit candidates of one ~900-path assembly per call"}
+
+
 def inproc_child(args):
     """`--inproc-devices 0,1,..`: ONE process, one context over those devices (gaml_hip_create_multi) -- what a gaml.cc
     linked against the adapter header runs. Same read set and steps as the headline; prints its own JSON line."""
@@ -405,6 +431,7 @@ def main():
                               "reads_per_sec": total_reads * calls * len(variants_py) / tb}
             if not args.no_sa:
                 out["sa_pattern"] = sa_pattern(ctx, rs, g, args.sa_iters, api, synth)
+                out["batched_candidates"] = batched_candidates(ctx, g, api, synth)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is taken on rank 0 at N = 1 only
             pairs = min(args.cpu_sample_pairs or wl.n_pairs, wl.n_pairs)
             cb, cpu_vals = cpu_baseline(gb, go, b1, o1, b2, o2, pairs, wl.read_len, variants_py, cfg)

@@ -204,15 +204,9 @@ struct AlnWaveSearch {
   }
 };
 
-__global__ __launch_bounds__(64 * kAlnWaves) void extend_kernel(const AlnCand* cands, const unsigned* n_cands, unsigned cap_cands,
-                                                                const char* wstr, const AlnWindow* wins, const char* reads,
-                                                                const int64_t* read_off, AlnHit* hits) {
-  __shared__ AlnWaveLds lds_all[kAlnWaves];
-  const unsigned n = *n_cands < cap_cands ? *n_cands : cap_cands;
-  const int lane = (int)(threadIdx.x & 63);
-  const unsigned t = blockIdx.x * kAlnWaves + (threadIdx.x >> 6);  // candidate of this wave
-  if (t >= n) return;                                              // whole waves leave together
-  AlnWaveLds& L = lds_all[threadIdx.x >> 6];
+// one candidate, one wave (every `return` leaves the candidate, not the kernel)
+__device__ __forceinline__ void extend_candidate(AlnWaveLds& L, const int lane, const unsigned t, const AlnCand* cands, const char* wstr,
+                                                 const AlnWindow* wins, const char* reads, const int64_t* read_off, AlnHit* hits) {
   const AlnCand c = cands[t];
   AlnHit out{c.win, 0, -1, c.read, c.strand, c.order};
   const AlnWindow win = wins[c.win];
@@ -348,6 +342,32 @@ __global__ __launch_bounds__(64 * kAlnWaves) void extend_kernel(const AlnCand* c
   out.pos = begin_pos + 1 + win.offset;  // graph.cc:890
   out.edit = fwd + bwd;
   if (lane == 0) hits[t] = out;
+}
+
+// grid-stride over the candidates: the grid does not depend on their number, so the launch needs no count on the host
+__global__ __launch_bounds__(64 * kAlnWaves) void extend_kernel(const AlnCand* cands, const unsigned* n_cands, unsigned cap_cands,
+                                                                const char* wstr, const AlnWindow* wins, const char* reads,
+                                                                const int64_t* read_off, AlnHit* hits) {
+  __shared__ AlnWaveLds lds_all[kAlnWaves];
+  const unsigned n = *n_cands < cap_cands ? *n_cands : cap_cands;
+  const int lane = (int)(threadIdx.x & 63);
+  AlnWaveLds& L = lds_all[threadIdx.x >> 6];
+  for (unsigned t = blockIdx.x * kAlnWaves + (threadIdx.x >> 6); t < n; t += gridDim.x * kAlnWaves) {  // whole waves move together
+    extend_candidate(L, lane, t, cands, wstr, wins, reads, read_off, hits);
+    aln_lds_sync();  // the wave's LDS slice is reused by its next candidate
+  }
+}
+
+// Small batches (an annealing move's handful of new junction windows): the counters and the hits go to mapped pinned
+// host memory and a sequence word tells the host they are there -- ONE wait per batch, no copy commands.
+__global__ __launch_bounds__(256) void publish_hits_kernel(const unsigned* counters, const AlnHit* hits, unsigned cap_cands, unsigned* h_counts,
+                                                           AlnHit* h_hits, unsigned cap_host, volatile unsigned long long* h_seq, unsigned long long seq) {
+  const unsigned n_spans = counters[0], n_cands = counters[1];
+  const unsigned n = n_cands < cap_cands ? (n_cands < cap_host ? n_cands : 0u) : 0u;  // overflow: counts only, the host takes the slow route
+  for (unsigned t = threadIdx.x; t < n; t += 256) h_hits[t] = hits[t];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) { h_counts[0] = n_spans; h_counts[1] = n_cands; __threadfence_system(); *h_seq = seq; }
 }
 
 

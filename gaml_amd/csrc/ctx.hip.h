@@ -126,6 +126,31 @@ struct AlignScratch {  // per context, grown on demand
                    sort_keys.release(); sort_idx.release(); sort_tmp.release(); hits_sorted.release(); }
 };
 
+// small batches (aln_small_*): one set of buffers per mate, so that the two mates' pipelines run side by side. Input
+// block written by the host (device memory behind the BAR, or its pinned twin), counters + hits published in mapped
+// pinned memory behind a sequence word.
+struct AlignSmall {
+  DevBuf hbuf, spans, cands, hits, counters;
+  void* in_dev = nullptr; size_t in_cap = 0; bool in_direct = false;
+  PinBuf in_host, out_host;
+  unsigned long long out_seq = 0;
+  void release() {
+    hbuf.release(); spans.release(); cands.release(); hits.release(); counters.release();
+    if (in_dev) (void)hipFree(in_dev);
+    in_dev = nullptr; in_cap = 0; in_host.release(); out_host.release();
+  }
+};
+// one batch of pending windows of one mate: strings built once, possibly already in flight on the device
+struct AlnJob {
+  bool prepared = false, enqueued = false;
+  std::string wstr;
+  std::vector<AlnWindow> wins;
+  std::vector<int64_t> hoff;
+  int64_t hbuf_total = 0;
+  unsigned long long seq = 0;
+  void* stream = nullptr;  // where the small-batch pipeline was enqueued
+};
+
 struct MateDev {
   DevBuf first, extra, pows;  // pows = mismatch_pow | match_pow
   AlignDev aln;
@@ -133,13 +158,40 @@ struct MateDev {
   size_t pow_n = 0;
 };
 
+// the device side of one build of the record tables (PairTables): everything a rebuild replaces as a whole
+struct TableDev {
+  DevBuf rec8[2], first[2], extra[2], inl[2], len_code, len_combo, len12, combo_tabs, memo;
+  int memo_codes = 0;     // length combinations the memo of pair terms covers (0: no memo)
+  void release() {
+    for (int m = 0; m < 2; m++) { rec8[m].release(); first[m].release(); extra[m].release(); inl[m].release(); }
+    len_code.release(); len_combo.release(); len12.release(); combo_tabs.release(); memo.release();
+  }
+};
+
+// A rebuild of the record tables off the caller's thread: the calling thread takes a private copy of what the build
+// reads (active windows' records, ~4 ms at 833 k pairs), a worker builds the tables (~30 ms) and uploads them into a
+// second set of device buffers; evaluations go on meanwhile over the old tables + delta lists, and a later call swaps.
+struct TableRebuild {
+  std::thread th;
+  std::atomic<int> state{0};   // 0 idle, 1 running, 2 ready, 3 failed
+  ShortMate snap[2];
+  PairTables pt;
+  TableDev tab;
+  std::string err;
+  std::vector<int32_t> activated_after[2];  // windows activated since the snapshot
+  uint64_t gen_snap[2] = {0, 0};
+  hipStream_t stream = nullptr;
+  double snapshot_us = 0, build_ms = 0;
+};
+
 struct PairedSet {
   gaml_paired_cfg cfg;
   ShortMate mate[2];
   PairTables pt;                      // device order + compact / 16-byte record tables (cold path)
-  MateDev dev[2];
-  DevBuf rec8[2], len_code, len_combo, inl[2], combo_tabs, memo;
-  int memo_codes = 0;     // length combinations the memo of pair terms covers (0: no memo); rebuilt with the tables
+  MateDev dev[2];                     // (pows, aligner index, generation; the record tables themselves are in `tab`)
+  TableDev tab;
+  TableRebuild rebuild;
+  int64_t async_rebuilds = 0;
   // delta since the last full table build: pairs whose record lists gained records of newly
   // activated windows. Their complete lists (device-table order: window id, position) travel with
   // every evaluation; a full rebuild folds them back in when they become too many.
@@ -164,8 +216,9 @@ struct PairedSet {
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls): [set][block]
   size_t host_part_stride = 0;        // entries per set
   int last_total_blocks = 0, last_sets = 1;
+  int last_blocks[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // partials written per path set of the last launch(es)
   bool last_host_partials = false;
-  DevBuf len12, probs, tabs, cov_bits, bad;
+  DevBuf probs, tabs, cov_bits, bad;
   Arena arena;                        // per-call tables (occurrence images, thresholds, coverage layout): ring, whole tables per call
   // Blocking calls on a large-BAR device keep ONE resident copy of the tables and patch it in place (the kernel
   // of the previous call is done when the call returns): a call that shares most paths with the previous one writes
@@ -262,6 +315,7 @@ struct gaml_hip_ctx {
   std::vector<SetRef> handles;  // creation order -> (kind, index)
   int32_t rank = 0, world = 1;
   AlignScratch aln_scratch;
+  AlignSmall aln_small[2];
   int64_t aln_windows = 0, aln_candidates = 0;  // GPU aligner statistics
   double aln_us = 0;
   double aln_stage_us[5] = {0, 0, 0, 0, 0};  // window strings + upload, spans + candidates, extension, D2H of hits, sort + finalize

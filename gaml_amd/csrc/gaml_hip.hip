@@ -418,42 +418,155 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
 // aligner for inputs the kernels do not cover (reads shorter than 16 or longer than 254 bases,
 // mixed read lengths are fine). Records are identical to the host aligner's.
 // ---------------------------------------------------------------------------------------
-int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
+// Small batches -- what an annealing move brings: a handful of new junction windows, a few thousand seed candidates.
+// Everything on the library's stream, ONE wait: the window strings and descriptors are written by the host straight
+// into device memory (large BAR) or copied asynchronously from pinned memory; the three kernels run back to back (the
+// extension kernel strides over a candidate count it reads on the device); a last small kernel leaves counters and
+// hits in mapped pinned memory and publishes a sequence word the host polls. Returns 1 when the batch does not fit
+// the fixed capacities (the caller takes the general route), 0 with `hits` filled, < 0 on error.
+constexpr unsigned kFastSpans = 1u << 16, kFastCands = 1u << 17;
+
+// device copies the aligner kernels need: the reads (1 byte per base) and the max-hash index, once per mate
+int aln_upload_index(gaml_hip_ctx* c, const ShortMate& m, AlignDev& d) {
+  if (d.uploaded) return 0;
+  auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = b.reserve(std::max<size_t>(16, bytes));
+    return (e != hipSuccess || bytes == 0) ? e : hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+  };
+  HIP_TRY(c, up(d.reads, m.bases.data(), m.bases.size()));
+  HIP_TRY(c, up(d.read_off, m.roff.data(), m.roff.size() * sizeof(int64_t)));
+  HIP_TRY(c, up(d.bucket_hash, m.bucket_hash.data(), m.bucket_hash.size() * sizeof(uint64_t)));
+  HIP_TRY(c, up(d.bucket_off, m.bucket_off.data(), m.bucket_off.size() * sizeof(int32_t)));
+  HIP_TRY(c, up(d.bucket_reads, m.bucket_reads.data(), m.bucket_reads.size() * sizeof(int32_t)));
+  d.uploaded = true;
+  return 0;
+}
+
+bool aln_gpu_capable(const gaml_hip_ctx* c, const ShortMate& m) {
+  return !(c->device < 0 || c->knobs[5] == 1 || m.index_read_len < 16 || m.max_len > kAlnMaxRead || m.n_local() == 0 || m.bucket_hash.empty());
+}
+
+// window strings (graph.cc:846-857) of the pending windows, concatenated
+void aln_prepare(const gaml_hip_ctx* c, const ShortMate& m, AlnJob& job) {
+  const int nw = (int)m.pending.size();
+  job.wstr.clear();
+  job.wins.resize((size_t)nw);
+  job.hoff.resize((size_t)nw);
+  job.hbuf_total = 0;
+  for (int k = 0; k < nw; k++) {
+    int32_t off = 0;
+    std::string ws = m.window_string(c->g, *m.win_walk[m.pending[k]], &off);
+    job.wins[k] = AlnWindow{(int32_t)job.wstr.size(), (int32_t)ws.size(), off};
+    job.hoff[k] = job.hbuf_total;
+    job.hbuf_total += 2 * (int64_t)ws.size();
+    job.wstr += ws;
+  }
+  job.prepared = true;
+  job.enqueued = false;
+}
+
+// enqueue the whole small-batch pipeline on the library's stream; 1: the batch does not fit the fixed capacities
+int aln_small_enqueue(gaml_hip_ctx* c, const ShortMate& m, AlignDev& d, AlignSmall& S, AlnJob& job, hipStream_t st) {
+  job.stream = st;
+  const int nw = (int)job.wins.size();
+  const size_t in_bytes = align16(nw * sizeof(AlnWindow)) + align16(nw * sizeof(int64_t)) + align16(job.wstr.size() + 16);
+  if (nw == 0 || nw > 4096 || in_bytes > ((size_t)1 << 20) || job.hbuf_total > (1 << 22)) return 1;
+  // input block: [windows][code-buffer offsets][window strings]
+  const bool direct = c->direct_write && c->knobs[8] == 0;
+  if (in_bytes > S.in_cap || S.in_direct != direct) {
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (S.in_dev) { HIP_TRY(c, hipFree(S.in_dev)); S.in_dev = nullptr; }
+    const size_t want = std::max<size_t>(in_bytes * 2, (size_t)1 << 16);
+    if (direct) HIP_TRY(c, hipExtMallocWithFlags(&S.in_dev, want, hipDeviceMallocFinegrained));
+    else HIP_TRY(c, hipMalloc(&S.in_dev, want));
+    S.in_cap = want; S.in_direct = direct;
+  }
+  char* wp = (char*)S.in_dev;
+  if (!direct) { HIP_TRY(c, S.in_host.reserve(in_bytes)); wp = (char*)S.in_host.p; }
+  const size_t off_hoff = align16(nw * sizeof(AlnWindow)), off_str = off_hoff + align16(nw * sizeof(int64_t));
+  memcpy(wp, job.wins.data(), nw * sizeof(AlnWindow));
+  memcpy(wp + off_hoff, job.hoff.data(), nw * sizeof(int64_t));
+  memcpy(wp + off_str, job.wstr.data(), job.wstr.size());
+  if (direct) _mm_sfence();
+  else HIP_TRY(c, hipMemcpyAsync(S.in_dev, S.in_host.p, in_bytes, hipMemcpyHostToDevice, st));
+  const char* dbase = (const char*)S.in_dev;
+  HIP_TRY(c, S.hbuf.reserve(std::max<int64_t>(16, job.hbuf_total * 4)));
+  HIP_TRY(c, S.counters.reserve(256));
+  HIP_TRY(c, S.spans.reserve((size_t)kFastSpans * sizeof(AlnSpan)));
+  HIP_TRY(c, S.cands.reserve((size_t)kFastCands * sizeof(AlnCand)));
+  HIP_TRY(c, S.hits.reserve((size_t)kFastCands * sizeof(AlnHit)));
+  const size_t out_bytes = 64 + 64 + (size_t)kFastCands * sizeof(AlnHit);
+  if (!S.out_host.p) { HIP_TRY(c, S.out_host.reserve(out_bytes)); memset(S.out_host.p, 0, 128); }
+  HIP_TRY(c, hipMemsetAsync(S.counters.p, 0, 16, st));
+  const AlnWindow* d_wins = (const AlnWindow*)dbase;
+  const int64_t* d_hoff = (const int64_t*)(dbase + off_hoff);
+  const char* d_wstr = dbase + off_str;
+  hipLaunchKernelGGL(span_maxima_kernel, dim3(2 * nw), dim3(kAlnBlock), 0, st, d_wstr, d_wins, nw, m.index_read_len, S.hbuf.as<uint32_t>(), d_hoff,
+                     S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans);
+  hipLaunchKernelGGL(candidates_kernel, dim3(64), dim3(kAlnBlock), 0, st, S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans,
+                     d.bucket_hash.as<uint64_t>(), d.bucket_off.as<int32_t>(), d.bucket_reads.as<int32_t>(), (int)m.bucket_hash.size(), S.cands.as<AlnCand>(),
+                     S.counters.as<unsigned>() + 1, kFastCands);
+  hipLaunchKernelGGL(extend_kernel, dim3(1024), dim3(64 * kAlnWaves), 0, st, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1, kFastCands, d_wstr,
+                     d_wins, d.reads.as<char>(), d.read_off.as<int64_t>(), S.hits.as<AlnHit>());
+  job.seq = ++S.out_seq;
+  char* oh = (char*)S.out_host.dev;
+  hipLaunchKernelGGL(publish_hits_kernel, dim3(1), dim3(256), 0, st, S.counters.as<unsigned>(), S.hits.as<AlnHit>(), kFastCands, (unsigned*)(oh + 64),
+                     (AlnHit*)(oh + 128), kFastCands, (volatile unsigned long long*)oh, job.seq);
+  HIP_TRY(c, hipGetLastError());
+  job.enqueued = true;
+  return 0;
+}
+
+// the one wait of a small batch: poll the sequence word (bounded), then the runtime's wait. 1: capacities exceeded
+int aln_small_collect(gaml_hip_ctx* c, AlignSmall& S, AlnJob& job, std::vector<AlnHit>& hits, unsigned* n_cands_out) {
+  volatile unsigned long long* word = (volatile unsigned long long*)S.out_host.p;
+  const double t0 = now_us();
+  bool seen = false;
+  while (!seen && now_us() - t0 < 5000.0) { for (int k = 0; k < 256 && !seen; k++) { seen = *word == job.seq; __builtin_ia32_pause(); } }
+  if (!seen) { HIP_TRY(c, hipStreamSynchronize((hipStream_t)job.stream)); if (*word != job.seq) return fail(c, GAML_HIP_ESTATE, "aligner: the publish kernel finished without its sequence word"); }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  job.enqueued = false;
+  const unsigned* counts = (const unsigned*)((const char*)S.out_host.p + 64);
+  if (counts[0] > kFastSpans || counts[1] > kFastCands) return 1;  // did not fit: the general route redoes the batch
+  const unsigned nc = counts[1];
+  hits.resize(nc);
+  if (nc) memcpy(hits.data(), (const char*)S.out_host.p + 128, (size_t)nc * sizeof(AlnHit));
+  *n_cands_out = nc;
+  return 0;
+}
+
+// `small`: this mate's small-batch buffers (null: general route only); `job`: strings already built and possibly the
+// small-batch pipeline already in flight (eval_begin starts both mates' pipelines before it waits for either)
+int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* small = nullptr, AlnJob* job_in = nullptr) {
   if (m.pending.empty()) return 0;
-  if (c->device < 0 || c->knobs[5] == 1 || m.index_read_len < 16 || m.max_len > kAlnMaxRead || m.n_local() == 0 ||
-      m.bucket_hash.empty()) {
+  if (!aln_gpu_capable(c, m)) {
     m.flush_pending_cpu(c->g);
     return 0;
   }
   const double t0 = now_us();
   HIP_TRY(c, hipSetDevice(c->device));
-  if (!d.uploaded) {
-    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
-      hipError_t e = b.reserve(std::max<size_t>(16, bytes));
-      return (e != hipSuccess || bytes == 0) ? e : hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
-    };
-    HIP_TRY(c, up(d.reads, m.bases.data(), m.bases.size()));
-    HIP_TRY(c, up(d.read_off, m.roff.data(), m.roff.size() * sizeof(int64_t)));
-    HIP_TRY(c, up(d.bucket_hash, m.bucket_hash.data(), m.bucket_hash.size() * sizeof(uint64_t)));
-    HIP_TRY(c, up(d.bucket_off, m.bucket_off.data(), m.bucket_off.size() * sizeof(int32_t)));
-    HIP_TRY(c, up(d.bucket_reads, m.bucket_reads.data(), m.bucket_reads.size() * sizeof(int32_t)));
-    d.uploaded = true;
-  }
+  if (int e = aln_upload_index(c, m, d)) return e;
   AlignScratch& S = c->aln_scratch;
+  AlnJob local;
+  AlnJob& job = job_in ? *job_in : local;
+  if (!job.prepared) aln_prepare(c, m, job);
   const int nw = (int)m.pending.size();
-  // window strings (graph.cc:846-857), concatenated
-  std::string wstr;
-  std::vector<AlnWindow> wins(nw);
-  std::vector<int64_t> hoff(nw);
-  int64_t hbuf_total = 0;
-  for (int k = 0; k < nw; k++) {
-    int32_t off = 0;
-    std::string ws = m.window_string(c->g, *m.win_walk[m.pending[k]], &off);
-    wins[k] = AlnWindow{(int32_t)wstr.size(), (int32_t)ws.size(), off};
-    hoff[k] = hbuf_total;
-    hbuf_total += 2 * (int64_t)ws.size();
-    wstr += ws;
+  const std::string& wstr = job.wstr;
+  const std::vector<AlnWindow>& wins = job.wins;
+  const std::vector<int64_t>& hoff = job.hoff;
+  const int64_t hbuf_total = job.hbuf_total;
+  bool small_done = false, device_sorted = false;
+  unsigned nc = 0;
+  std::vector<AlnHit> hits;
+  double t1 = now_us(), t2 = t1, t3 = t1;
+  if (small && c->knobs[5] != 3) {  // knob 5 = 3: always the general route (tests compare the two)
+    int rc = job.enqueued ? 0 : aln_small_enqueue(c, m, d, *small, job, c->stream);
+    if (rc == 0) rc = aln_small_collect(c, *small, job, hits, &nc);
+    if (rc < 0) return rc;
+    small_done = rc == 0;
+    t2 = t3 = now_us();
   }
+  if (!small_done) {
   HIP_TRY(c, S.wstr.reserve(std::max<size_t>(16, wstr.size())));
   HIP_TRY(c, S.wins.reserve(nw * sizeof(AlnWindow)));
   HIP_TRY(c, S.hbuf_off.reserve(nw * sizeof(int64_t)));
@@ -462,7 +575,7 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
   if (!wstr.empty()) HIP_TRY(c, hipMemcpy(S.wstr.p, wstr.data(), wstr.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(S.wins.p, wins.data(), nw * sizeof(AlnWindow), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(S.hbuf_off.p, hoff.data(), nw * sizeof(int64_t), hipMemcpyHostToDevice));
-  const double t1 = now_us();
+  t1 = now_us();
   size_t cap_spans = std::max<size_t>(1 << 16, wstr.size());        // a span per window base and strand at most ~2x
   size_t cap_cands = std::max<size_t>(1 << 18, 8 * wstr.size());
   unsigned counts[2] = {0, 0};
@@ -484,11 +597,10 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
     cap_cands = std::max<size_t>(cap_cands, (size_t)counts[1] + 16);
     if (attempt == 5) { m.flush_pending_cpu(c->g); return 0; }
   }
-  const double t2 = now_us();
-  double t3 = t2;
-  const unsigned nc = counts[1];
-  std::vector<AlnHit> hits(nc);
-  bool device_sorted = false;
+  t2 = now_us();
+  t3 = t2;
+  nc = counts[1];
+  hits.assign(nc, AlnHit{0, 0, -1, 0, 0, 0});
   if (nc) {
     HIP_TRY(c, S.hits.reserve((size_t)nc * sizeof(AlnHit)));
     hipLaunchKernelGGL(extend_kernel, dim3((nc + kAlnWaves - 1) / kAlnWaves), dim3(64 * kAlnWaves), 0, 0, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1,
@@ -539,6 +651,7 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
       HIP_TRY(c, hipMemcpy(hits.data(), S.hits.p, (size_t)nc * sizeof(AlnHit), hipMemcpyDeviceToHost));
     }
   }
+  }  // general route
   const double t4 = now_us();
   if (!c->knobs[9]) t3 = t4;
   // per window: sort by (position, read), the first alignment found for a key survives
@@ -644,6 +757,25 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d) {
   return 0;
 }
 
+int align_pending_pair(gaml_hip_ctx* c, PairedSet& ps) {
+  if (ps.mate[0].pending.empty() && ps.mate[1].pending.empty()) return 0;
+  AlnJob job[2];
+  if (c->device >= 0 && c->knobs[5] != 3) {
+    for (int mt = 0; mt < 2; mt++) {
+      ShortMate& m = ps.mate[mt];
+      if (m.pending.empty() || !aln_gpu_capable(c, m)) continue;
+      HIP_TRY(c, hipSetDevice(c->device));
+      if (int e = aln_upload_index(c, m, ps.dev[mt].aln)) return e;
+      aln_prepare(c, m, job[mt]);
+      const int rc = aln_small_enqueue(c, m, ps.dev[mt].aln, c->aln_small[mt], job[mt], mt == 0 ? c->stream : c->aux_stream);  // side by side
+      if (rc < 0) return rc;
+    }
+  }
+  for (int mt = 0; mt < 2; mt++)
+    if (int e = gpu_align_pending(c, ps.mate[mt], ps.dev[mt].aln, c->device >= 0 ? &c->aln_small[mt] : nullptr, &job[mt])) return e;
+  return 0;
+}
+
 std::vector<ShortMate*> filter_mates(gaml_hip_ctx* c) {  // mates whose windows feed a position filter, in handle order
   std::vector<ShortMate*> v;
   for (auto& h : c->handles)
@@ -672,15 +804,14 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
     c->pending_total_len = 0;
     for (auto& p : c->pending_paths) c->pending_total_len += walk_length(c->g, p);  // GetTotalLen graph.cc:1775-1781
   }
-  c->pending_prep.clear();
-  c->pending_prep.resize(c->paireds.size());
+  if (c->pending_prep.size() != c->paireds.size()) { c->pending_prep.clear(); c->pending_prep.resize(c->paireds.size()); }
   for (size_t i = 0; i < c->paireds.size(); i++) {
-    c->pending_prep[i].reset(new PairedPrep());
+    if (!c->pending_prep[i]) c->pending_prep[i].reset(new PairedPrep());  // (reused from call to call: its vectors keep their capacity)
     if (int e = prepare_paired_structure(c, *c->paireds[i], flat, offs, n_paths)) return e;
     if (!want_vectors) c->pending_total_len = c->paireds[i]->planner.total_len();
-    // windows registered by pass 1 get their records now, all at once (GPU aligner when there is a device)
-    for (int mt = 0; mt < 2; mt++)
-      if (int e = gpu_align_pending(c, c->paireds[i]->mate[mt], c->paireds[i]->dev[mt].aln)) return e;
+    // windows registered by pass 1 get their records now, all at once (GPU aligner when there is a device): small
+    // batches of the two mates go out together on the stream before either is waited for
+    if (int e = align_pending_pair(c, *c->paireds[i])) return e;
   }
   int64_t n = 0;
   for (ShortMate* m : filter_mates(c)) {
@@ -859,14 +990,18 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     auto drop_stage = [](Staging& s) { for (int k = 0; k < kRing; k++) { s.host[k].release(); if (s.done[k]) (void)hipEventDestroy(s.done[k]); } };
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
+      if (s->rebuild.th.joinable()) s->rebuild.th.join();
+      if (s->rebuild.stream) (void)hipStreamDestroy(s->rebuild.stream);
+      s->tab.release(); s->rebuild.tab.release();
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
-      s->rec8[0].release(); s->rec8[1].release(); s->inl[0].release(); s->inl[1].release(); s->combo_tabs.release(); s->memo.release(); s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release(); s->len_code.release(); s->len_combo.release();
-      s->len12.release(); s->probs.release(); s->tabs.release(); s->arena.release(); s->persist.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
+      s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release();
+      s->probs.release(); s->tabs.release(); s->arena.release(); s->persist.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); s->gen_bits.release();
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage);
       s->d_bases.release(); s->dp.release(); }
-    c->packed.release(); c->packed_host.release(); c->batch_dev.release(); c->batch_host.release(); c->aln_scratch.release(); c->fetch_host.release();
+    c->packed.release(); c->packed_host.release(); c->batch_dev.release(); c->batch_host.release(); c->aln_scratch.release();
+    c->aln_small[0].release(); c->aln_small[1].release(); c->fetch_host.release();
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -1733,7 +1868,7 @@ static int wait_host_partials(gaml_hip_ctx* c, bool* spun) {
         const volatile double* hs = (const volatile double*)ps->h_part_sum.p + (size_t)k * ps->host_part_stride;
         const volatile int* hz = (const volatile int*)ps->h_part_zero.p + (size_t)k * ps->host_part_stride;
         int done = 0;
-        while (done < ps->last_total_blocks) {
+        while (done < ps->last_blocks[k]) {
           if (hs[done] == hs[done] && hz[done] != INT_MIN) { done++; continue; }  // NaN != NaN
           __builtin_ia32_pause();
           if ((done & 63) == 0 && now_us() > deadline) { spin = false; break; }
@@ -1760,8 +1895,8 @@ static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
       if (ord[k].kind != 1) continue;
       PairedSet& s = *c->paireds[ord[k].idx];
       if (!s.last_host_partials) continue;
-      if (s.last_total_blocks > 0)
-        finisher_order_sum((const double*)s.h_part_sum.p, (const int*)s.h_part_zero.p, s.last_total_blocks, &res[4 * k], &res[4 * k + 1]);
+      if (s.last_blocks[0] > 0)
+        finisher_order_sum((const double*)s.h_part_sum.p, (const int*)s.h_part_zero.p, s.last_blocks[0], &res[4 * k], &res[4 * k + 1]);
       else res[4 * k] = res[4 * k + 1] = 0;
       if (!(s.cfg.penalty_constant > 0) || s.last_total_blocks == 0) res[4 * k + 2] = 0;  // else store_bad_bases_kernel wrote it
       res[4 * k + 3] = (double)s.mate[0].n_local();
@@ -1805,14 +1940,30 @@ static int batch_chunk_fast(gaml_hip_ctx* c, int n, const int32_t* paths, const 
     // a region per path set: the occurrence images of the current window count plus room for windows and lists that
     // this very batch adds
     // windows the batch itself may add: every set's tables are padded to this many entries per mate
-    per[i].cap_w[0] = ps.mate[0].wins.size() + 2048 + ps.batch_slack / 24;
-    per[i].cap_w[1] = ps.mate[1].wins.size() + 2048 + ps.batch_slack / 24;
-    const size_t est = 4096 + 12 * (per[i].cap_w[0] + per[i].cap_w[1]) + 65536 + ps.batch_slack;
+    per[i].cap_w[0] = ps.mate[0].wins.size() + 256 + ps.batch_slack / 24;
+    per[i].cap_w[1] = ps.mate[1].wins.size() + 256 + ps.batch_slack / 24;
+    const size_t lists = 2 * (sizeof(int32_t) * (ps.image[0].multi_off.size() + ps.image[1].multi_off.size()) + sizeof(OccQuad) * (ps.image[0].multi.size() + ps.image[1].multi.size()));
+    const size_t est = 4096 + 12 * (per[i].cap_w[0] + per[i].cap_w[1]) + 16384 + lists + ps.batch_slack;
     per[i].stride = align16(est);
     if (int e = arena_acquire(c, ps.arena, per[i].stride * (size_t)n, st, &per[i].slot, &per[i].wp)) return e;
     per[i].L.resize((size_t)n);
     per[i].prep.resize((size_t)n);
   }
+  // the batch goes out in two launches: the host plans the second half while the device scores the first
+  const int half = n > 4 ? (n + 1) / 2 : n;
+  int launched = 0;
+  auto launch_upto = [&](int upto) -> int {
+    for (size_t i = 0; i < nps; i++) {
+      PairedSet& ps = *c->paireds[i];
+      if (int e = paired_sync_tables(c, ps, st)) return e;
+      for (int k = launched; k < upto; k++) paired_pack_thresholds(ps, per[i].L[(size_t)k], (double)(2 * (tls[k] == 0 ? 1 : tls[k])), per[i].wp + (size_t)k * per[i].stride);
+      // (the staged route copies the regions written so far; the direct route only drains the write-combining buffers)
+      if (int e = arena_commit(c, ps.arena, per[i].slot, per[i].stride * (size_t)upto, st)) return e;
+      if (int e = launch_paired_multi(c, ps, launched, upto - launched, per[i].L.data(), per[i].prep.data(), tls, (const char*)ps.arena.dev[per[i].slot], per[i].stride, st)) return e;
+    }
+    launched = upto;
+    return 0;
+  };
   for (int k = 0; k < n; k++) {
     int64_t pending = 0;
     if (int e = eval_begin(c, paths, offs + set_offs[k], set_offs[k + 1] - set_offs[k], &pending)) return e;
@@ -1821,20 +1972,19 @@ static int batch_chunk_fast(gaml_hip_ctx* c, int n, const int32_t* paths, const 
       PairedSet& ps = *c->paireds[i];
       PairedPrep& p = per[i].prep[(size_t)k];
       prepare_paired_tables_host(c, ps, p);
-      if (ps.mate[0].wins.size() > per[i].cap_w[0] || ps.mate[1].wins.size() > per[i].cap_w[1]) { ps.batch_slack += 24 * 16384; return 1; }
-      per[i].L[(size_t)k] = paired_layout(ps, p, per[i].cap_w);
-      if (per[i].L[(size_t)k].total > per[i].stride) { ps.batch_slack += 2 * per[i].L[(size_t)k].total; return 1; }
+      bool fits = ps.mate[0].wins.size() <= per[i].cap_w[0] && ps.mate[1].wins.size() <= per[i].cap_w[1];
+      if (fits) { per[i].L[(size_t)k] = paired_layout(ps, p, per[i].cap_w); fits = per[i].L[(size_t)k].total <= per[i].stride; }
+      if (!fits) {  // the tables outgrew the region reserved per set: the sequential path takes this chunk (after what is in flight)
+        ps.batch_slack += 24 * 16384 + 2 * per[i].stride;
+        if (launched > 0) { bool spun = false; (void)wait_host_partials(c, &spun); if (!spun) (void)collect_events(c); }
+        return 1;
+      }
       paired_pack(ps, p, per[i].L[(size_t)k], per[i].wp + (size_t)k * per[i].stride);
     }
     c->pending_open = false;
+    if (k + 1 == half && half < n) { if (int e = launch_upto(half)) return e; }
   }
-  for (size_t i = 0; i < nps; i++) {
-    PairedSet& ps = *c->paireds[i];
-    if (int e = paired_sync_tables(c, ps, st)) return e;
-    for (int k = 0; k < n; k++) paired_pack_thresholds(ps, per[i].L[(size_t)k], (double)(2 * (tls[k] == 0 ? 1 : tls[k])), per[i].wp + (size_t)k * per[i].stride);
-    if (int e = arena_commit(c, ps.arena, per[i].slot, per[i].stride * (size_t)n, st)) return e;
-    if (int e = launch_paired_multi(c, ps, n, per[i].L.data(), per[i].prep.data(), tls, (const char*)ps.arena.dev[per[i].slot], per[i].stride, st)) return e;
-  }
+  if (int e = launch_upto(n)) return e;
   bool spun = false;
   if (int e = wait_host_partials(c, &spun)) return e;
   if (!spun) { if (int e2 = collect_events(c)) return e2; }
@@ -1843,9 +1993,9 @@ static int batch_chunk_fast(gaml_hip_ctx* c, int n, const int32_t* paths, const 
       PairedSet& ps = *c->paireds[i];
       double* out = partials_out + ((size_t)k * nps + i) * 4;
       out[0] = out[1] = out[2] = 0;
-      if (ps.last_total_blocks > 0)
+      if (ps.last_blocks[k] > 0)
         finisher_order_sum((const double*)ps.h_part_sum.p + (size_t)k * ps.host_part_stride, (const int*)ps.h_part_zero.p + (size_t)k * ps.host_part_stride,
-                           ps.last_total_blocks, &out[0], &out[1]);
+                           ps.last_blocks[k], &out[0], &out[1]);
       out[3] = (double)ps.mate[0].n_local();
       ps.last_bad_bases = 0;
     }
@@ -2055,7 +2205,7 @@ int gaml_hip_debug_prepare(gaml_hip_ctx* c, const int32_t* flat, const int64_t* 
       PairedPrep p;
       PairedSet& ps = *c->paireds[h.idx];
       if (int e = prepare_paired_structure(c, ps, flat, offs, n_paths)) return e;
-      for (int mt = 0; mt < 2; mt++) if (int e = gpu_align_pending(c, ps.mate[mt], ps.dev[mt].aln)) return e;
+      if (int e = align_pending_pair(c, ps)) return e;
       prepare_paired_tables_host(c, ps, p);
     }
   }

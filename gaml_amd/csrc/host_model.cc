@@ -756,7 +756,17 @@ bool PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const int32_t*
       return la == path_len(b) && (la == 0 || memcmp(prev_flat_.data() + prev_offs_[a], path_ptr(b), (size_t)la * sizeof(int32_t)) == 0);
     };
     const int32_t lim = std::min(n_prev, n_paths);
-    while (P < lim && same(P, P)) P++;
+    {
+      // common prefix: the first differing int of the two flat arrays bounds it (one pass, no call per path)
+      const int64_t max_ints = std::min<int64_t>(prev_offs_[n_prev], offs[n_paths] - base);
+      const int32_t* a = prev_flat_.data();
+      const int32_t* b = flat + base;
+      int64_t d = 0;
+      while (d + 8 <= max_ints && memcmp(a + d, b + d, 8 * sizeof(int32_t)) == 0) d += 8;
+      while (d < max_ints && a[d] == b[d]) d++;
+      // paths that end at or before d with equal boundaries are equal
+      while (P < lim && prev_offs_[P + 1] == offs[P + 1] - base && prev_offs_[P + 1] <= d) P++;
+    }
     while (S < lim - P && same(n_prev - 1 - S, n_paths - 1 - S)) S++;
     // more than half of the set changed: the whole-set rebuild is cheaper than path-by-path bookkeeping
     if ((int64_t)(n_prev - P - S) + (n_paths - P - S) > (int64_t)(n_prev + n_paths) / 2) incremental_ = false;
@@ -830,7 +840,8 @@ bool PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const int32_t*
     // memos to (re)place: the new paths, and memos of the set that were invalidated since they were placed. A memo
     // is rebuilt once for all its instances; every instance's table entries are taken out first (with the lists as
     // they stand) and put back after pass 2.
-    std::vector<char> redo(memos_.size(), 0);
+    std::vector<char>& redo = redo_;
+    redo.assign(memos_.size(), 0);
     for (int32_t id : in_ids) redo[id] = 1;
     for (int32_t id : stale_) if (id < (int32_t)memos_.size() && memos_[id]->use_count > 0 && (!memos_[id]->valid[0] || !memos_[id]->valid[1] || !memos_[id]->occ_valid[0] || !memos_[id]->occ_valid[1])) redo[id] = 2;
     stale_.clear();

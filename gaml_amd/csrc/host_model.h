@@ -323,6 +323,7 @@ class PairedPlanner {
   std::vector<Removed> removed_;         // instances whose table entries go: their occurrence lists as they were when they went in
   std::vector<int32_t> work_;            // path indices whose occurrences go (back) in after pass 2, ascending
   std::vector<int32_t> stale_;           // memos invalidated while in use: refreshed at the next begin()
+  std::vector<char> redo_;
   int32_t total_len_ = 0;
   int64_t assembled_[2] = {0, 0};
   uint64_t clock_ = 0;

@@ -57,7 +57,6 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
   HIP_TRY(c, up(s.logfloor_tab));
   HIP_TRY(c, up(s.covthr_tab));
   const int64_t n = s.mate[0].n_local();
-  HIP_TRY(c, s.len12.reserve(std::max<size_t>(1, n) * sizeof(uint32_t)));
   HIP_TRY(c, s.probs.reserve(std::max<size_t>(1, n) * sizeof(double)));
   HIP_TRY(c, s.red.init());
   HIP_TRY(c, s.bad.reserve(sizeof(unsigned long long)));
@@ -156,47 +155,32 @@ void paired_extend_delta(PairedSet& s) {
   s.delta_updates++;
 }
 
-// full rebuild: new device order of the pairs, record tables built on the host and uploaded; the memo of pair terms
-// (nothing in it depends on a path set: PairedArgs::memo) is tabulated here too
-int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
-  s.dirty.clear();
-  s.dirty_index.clear();
-  s.dirty_marked = 0;
-  s.dirty_touched.clear(); s.spill_of.clear(); s.spill_pairs.clear(); s.spill_changed = false;
-  s.full_rebuilds++;
-  for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
-  const double tb0 = now_us();
-  build_pair_tables(s.mate[0], s.mate[1], s.pt);
-  const double tb1 = now_us();
-  HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old tables
+// One build of the record tables onto the device: uploads `pt` into `T`, derives the per-length-combination tables
+// and tabulates the memo of pair terms (nothing in it depends on a path set: PairedArgs::memo) on `st`. Runs on the
+// caller's thread -- the evaluation's, or the rebuild worker's (then `err` receives the text: the context's error
+// string belongs to the evaluating thread).
+int paired_upload_tables(gaml_hip_ctx* c, PairedSet& s, const PairTables& pt, TableDev& T, hipStream_t st, std::string* err) {
+  auto bad = [&](const char* what, hipError_t e) { const std::string m = std::string(what) + ": " + hipGetErrorString(e); if (err) { *err = m; return GAML_HIP_EHIP; } return fail(c, GAML_HIP_EHIP, m); };
   auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = d.reserve(std::max<size_t>(16, bytes));
     if (e != hipSuccess || bytes == 0) return e;
     return hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice);
   };
+#define UP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bad(#expr, e__); } while (0)
   for (int mt = 0; mt < 2; mt++) {
-    MateDev& d = s.dev[mt];
-    const ShortMate& m = s.mate[mt];
-    if (d.pow_n == 0) {
-      d.pow_n = m.match_pow.size();
-      HIP_TRY(c, d.pows.reserve(2 * d.pow_n * sizeof(double)));
-      HIP_TRY(c, hipMemcpy(d.pows.p, m.mismatch_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
-      HIP_TRY(c, hipMemcpy(d.pows.as<double>() + d.pow_n, m.match_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
-    }
-    HIP_TRY(c, up(s.rec8[mt], s.pt.rec8[mt].data(), s.pt.rec8[mt].size() * sizeof(uint64_t)));
-    HIP_TRY(c, up(d.first, s.pt.rm[mt].first.data(), s.pt.rm[mt].first.size() * sizeof(RecQuad)));
-    HIP_TRY(c, up(d.extra, s.pt.rm[mt].extra.data(), s.pt.rm[mt].extra.size() * sizeof(RecQuad)));
-    HIP_TRY(c, up(s.inl[mt], s.pt.inl[mt].data(), s.pt.inl[mt].size() * sizeof(RecQuad)));
-    d.uploaded_generation = m.active_generation;
+    UP_TRY(up(T.rec8[mt], pt.rec8[mt].data(), pt.rec8[mt].size() * sizeof(uint64_t)));
+    UP_TRY(up(T.first[mt], pt.rm[mt].first.data(), pt.rm[mt].first.size() * sizeof(RecQuad)));
+    UP_TRY(up(T.extra[mt], pt.rm[mt].extra.data(), pt.rm[mt].extra.size() * sizeof(RecQuad)));
+    UP_TRY(up(T.inl[mt], pt.inl[mt].data(), pt.inl[mt].size() * sizeof(RecQuad)));
   }
-  HIP_TRY(c, up(s.len_code, s.pt.len_code.data(), s.pt.len_code.size()));
-  HIP_TRY(c, up(s.len_combo, s.pt.len_combo.data(), s.pt.len_combo.size() * sizeof(uint32_t)));
-  HIP_TRY(c, up(s.len12, s.pt.len12.data(), s.pt.len12.size() * sizeof(uint32_t)));
+  UP_TRY(up(T.len_code, pt.len_code.data(), pt.len_code.size()));
+  UP_TRY(up(T.len_combo, pt.len_combo.data(), pt.len_combo.size() * sizeof(uint32_t)));
+  UP_TRY(up(T.len12, pt.len12.data(), pt.len12.size() * sizeof(uint32_t)));
   // per length-combination tables of the compact path: [pe mate 0 | pe mate 1 | floor | logfloor | covthr]
-  const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
+  const size_t nc = std::max<size_t>(1, pt.len_combo.size());
   std::vector<double> t(nc * 64 * 2 + nc * 3, 0.0);
-  for (size_t ci = 0; ci < s.pt.len_combo.size(); ci++) {
-    const int L[2] = {(int)(s.pt.len_combo[ci] & 0xffff), (int)(s.pt.len_combo[ci] >> 16)};
+  for (size_t ci = 0; ci < pt.len_combo.size(); ci++) {
+    const int L[2] = {(int)(pt.len_combo[ci] & 0xffff), (int)(pt.len_combo[ci] >> 16)};
     for (int mt = 0; mt < 2; mt++)
       for (int e = 0; e < 64 && e <= L[mt]; e++)
         t[(size_t)mt * nc * 64 + ci * 64 + e] = s.mate[mt].mismatch_pow[e] * s.mate[mt].match_pow[L[mt] - e];  // graph.cc:1859-1863
@@ -204,22 +188,143 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     t[2 * nc * 64 + nc + ci] = s.logfloor_tab[L[0] + L[1]];
     t[2 * nc * 64 + 2 * nc + ci] = s.covthr_tab[L[1]];
   }
-  HIP_TRY(c, up(s.combo_tabs, t.data(), t.size() * sizeof(double)));
+  UP_TRY(up(T.combo_tabs, t.data(), t.size() * sizeof(double)));
   // memo of the pair terms a single-term pair can take (first 4 length combinations, edits < 7, every tabulated distance)
-  s.memo_codes = 0;
-  if (c->knobs[4] == 0 && s.floor_positive && !s.pt.len_combo.empty() && !s.ins_tab.empty()) {
-    const int codes = (int)std::min<size_t>(s.pt.len_combo.size(), 4);
+  T.memo_codes = 0;
+  if (c->knobs[4] == 0 && s.floor_positive && !pt.len_combo.empty() && !s.ins_tab.empty()) {
+    const int codes = (int)std::min<size_t>(pt.len_combo.size(), 4);
     const size_t entries = (size_t)codes * 49 * s.ins_tab.size();
     if (entries <= ((size_t)1 << 24)) {
-      HIP_TRY(c, s.memo.reserve(entries * sizeof(double2)));
-      const double* ct = s.combo_tabs.as<double>();
+      UP_TRY(T.memo.reserve(entries * sizeof(double2)));
+      const double* ct = T.combo_tabs.as<double>();
       hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
-                         ct, ct + nc * 64, s.tabs.as<double>(), (int)s.ins_tab.size(), codes, s.memo.as<double2>());
-      HIP_TRY(c, hipGetLastError());
-      s.memo_codes = codes;
+                         ct, ct + nc * 64, s.tabs.as<double>(), (int)s.ins_tab.size(), codes, T.memo.as<double2>());
+      UP_TRY(hipGetLastError());
+      T.memo_codes = codes;
+    }
+  }
+#undef UP_TRY
+  return 0;
+}
+
+void paired_reset_delta(PairedSet& s) {
+  s.dirty.clear();
+  s.dirty_index.clear();
+  s.dirty_marked = 0;
+  s.dirty_touched.clear(); s.spill_of.clear(); s.spill_pairs.clear(); s.spill_changed = false;
+}
+
+int paired_upload_pows(gaml_hip_ctx* c, PairedSet& s) {
+  for (int mt = 0; mt < 2; mt++) {
+    MateDev& d = s.dev[mt];
+    const ShortMate& m = s.mate[mt];
+    if (d.pow_n) continue;
+    d.pow_n = m.match_pow.size();
+    HIP_TRY(c, d.pows.reserve(2 * d.pow_n * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(d.pows.p, m.mismatch_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d.pows.as<double>() + d.pow_n, m.match_pow.data(), d.pow_n * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// full rebuild on the calling thread: new device order of the pairs, record tables built on the host and uploaded
+int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
+  paired_reset_delta(s);
+  s.full_rebuilds++;
+  for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
+  const double tb0 = now_us();
+  build_pair_tables(s.mate[0], s.mate[1], s.pt);
+  const double tb1 = now_us();
+  HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old tables
+  if (int e = paired_upload_pows(c, s)) return e;
+  if (int e = paired_upload_tables(c, s, s.pt, s.tab, st, nullptr)) return e;
+  for (int mt = 0; mt < 2; mt++) s.dev[mt].uploaded_generation = s.mate[mt].active_generation;
+  // room for the private copy a later rebuild off this thread takes (paired_snapshot_mate): allocated and touched here,
+  // inside a call that takes tens of milliseconds anyway, so that the snapshot itself is a plain copy
+  if (c->knobs[14] == 0 && s.rebuild.state.load(std::memory_order_acquire) == 0 && !s.rebuild.th.joinable()) {
+    for (int mt = 0; mt < 2; mt++) {
+      ShortMate& sn = s.rebuild.snap[mt];
+      if (sn.lens.size() != s.mate[mt].lens.size()) sn.lens = s.mate[mt].lens;
+      const size_t want = (size_t)s.mate[mt].active_records + (size_t)s.mate[mt].active_records / 2 + 65536;
+      if (sn.pool.capacity() < want) { sn.pool.clear(); sn.pool.resize(want); sn.pool.clear(); }  // resize touches the pages, clear keeps them
     }
   }
   if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "rebuild: tables on the host %.1f ms, uploads %.1f ms\n", (tb1 - tb0) * 1e-3, (now_us() - tb1) * 1e-3);
+  return 0;
+}
+
+// ---- the same off the caller's thread -----------------------------------------------------------------
+// what build_pair_tables reads of a mate, copied: lengths, the window headers, and the records of the ACTIVE windows
+// (compacted: `first` re-pointed into the copy). The live mate keeps growing meanwhile.
+void paired_snapshot_mate(const ShortMate& m, ShortMate& out) {
+  out.n_global = m.n_global; out.lo = m.lo; out.hi = m.hi;
+  if (out.lens.size() != m.lens.size()) out.lens = m.lens;  // read lengths never change
+  out.wins = m.wins;
+  out.pool.clear();
+  if (out.pool.capacity() < (size_t)m.active_records) out.pool.reserve((size_t)m.active_records + (size_t)m.active_records / 4);
+  for (Window& w : out.wins) {
+    if (!w.active) continue;
+    const int64_t first = (int64_t)out.pool.size();
+    out.pool.insert(out.pool.end(), m.pool.begin() + w.first, m.pool.begin() + w.first + w.count);
+    w.first = first;
+  }
+  out.active_records = m.active_records;
+  out.active_generation = m.active_generation;
+}
+
+int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s) {
+  TableRebuild& rb = s.rebuild;
+  const double t0 = now_us();
+  if (rb.th.joinable()) rb.th.join();
+  for (int mt = 0; mt < 2; mt++) {
+    paired_snapshot_mate(s.mate[mt], rb.snap[mt]);
+    rb.gen_snap[mt] = s.mate[mt].active_generation;
+    rb.activated_after[mt].clear();
+  }
+  if (!rb.stream) HIP_TRY(c, hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
+  rb.err.clear();
+  rb.state.store(1, std::memory_order_release);
+  rb.snapshot_us = now_us() - t0;
+  const int device = c->device;
+  rb.th = std::thread([c, &s, &rb, device] {
+    const double b0 = now_us();
+    int rc = hipSetDevice(device) == hipSuccess ? 0 : GAML_HIP_EHIP;
+    if (rc) rb.err = "hipSetDevice failed in the rebuild worker";
+    if (!rc) {
+      build_pair_tables(rb.snap[0], rb.snap[1], rb.pt);
+      rc = paired_upload_tables(c, s, rb.pt, rb.tab, rb.stream, &rb.err);
+      if (!rc && hipStreamSynchronize(rb.stream) != hipSuccess) { rc = GAML_HIP_EHIP; rb.err = "stream synchronise failed in the rebuild worker"; }
+    }
+    rb.build_ms = (now_us() - b0) * 1e-3;
+    rb.state.store(rc ? 3 : 2, std::memory_order_release);
+  });
+  return 0;
+}
+
+// the worker is done (or: wait for it): the new tables take over; pairs touched by windows activated since the
+// snapshot go (back) onto the delta lists, now relative to the new tables
+int paired_finish_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
+  TableRebuild& rb = s.rebuild;
+  if (rb.th.joinable()) rb.th.join();
+  const int state = rb.state.load(std::memory_order_acquire);
+  rb.state.store(0, std::memory_order_release);
+  if (state == 3) return fail(c, GAML_HIP_EHIP, "table rebuild worker: " + rb.err);
+  if (state != 2) return 0;
+  HIP_TRY(c, hipStreamSynchronize(st));  // launches in flight may still read the old tables
+  std::swap(s.tab, rb.tab);
+  std::swap(s.pt, rb.pt);
+  paired_reset_delta(s);
+  s.full_rebuilds++;
+  s.async_rebuilds++;
+  for (int mt = 0; mt < 2; mt++) {
+    // everything activated since the snapshot: what earlier calls logged, then what this call's planning just activated
+    std::vector<int32_t> log = std::move(rb.activated_after[mt]);
+    log.insert(log.end(), s.mate[mt].activated_log.begin(), s.mate[mt].activated_log.end());
+    s.mate[mt].activated_log.swap(log);
+    rb.activated_after[mt].clear();
+    s.dev[mt].uploaded_generation = rb.gen_snap[mt];
+  }
+  if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "rebuild (worker): snapshot %.1f ms on the calling thread, build + upload %.1f ms beside it\n", rb.snapshot_us * 1e-3, rb.build_ms);
   return 0;
 }
 
@@ -229,7 +334,7 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   const size_t nd = s.dirty.size();
   const int64_t np_all = s.mate[0].n_local();
   if (s.delta_cap == 0) {  // sized once for the largest delta the rebuild policy allows: the store is never reallocated
-    s.delta_cap = (size_t)std::max<int64_t>(4096, np_all / 8) + 4096;
+    s.delta_cap = (size_t)std::max<int64_t>(4096, np_all / 4) + 8192;  // twice the rebuild threshold: room for what arrives while a worker rebuilds
     HIP_TRY(c, s.dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
     HIP_TRY(c, s.dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
     for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
@@ -302,35 +407,55 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
 
 // Everything the record tables need before a scoring launch; enqueued on `st`. One call per evaluation (or batch).
 int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
-  bool need_full = s.dev[0].pow_n == 0;
-  const bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
+  TableRebuild& rb = s.rebuild;
+  const int64_t np = s.mate[0].n_local();
+  int rstate = rb.state.load(std::memory_order_acquire);
+  if (rstate == 2 || rstate == 3) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; rstate = 0; }
+  const bool first_build = s.dev[0].pow_n == 0;
+  bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
   s.quiet_calls = activated_now ? 0 : s.quiet_calls + 1;
-  // the cache has settled (no activation for a while) but pairs still sit on the slower delta path: fold them in
-  // A rebuild costs ~30 ms at 833 k pairs, a pair on the delta path ~0.4 ns per evaluation (one lane per pair). In an
-  // annealing run new junction windows appear every few calls, so folding after a short quiet spell
-  // (as an earlier version did after 16 calls) rebuilt 8 times per 1000 iterations for nothing;
-  // 64 quiet calls mean the path set has stopped producing new windows (steady re-scoring).
-  if (!need_full && !activated_now && !s.dirty.empty() && (s.quiet_calls >= 64 || s.compact_requested) && c->knobs[6] != 2) need_full = true;
-  s.compact_requested = false;
-  if (!need_full && activated_now) {
-    // Windows were activated since the tables were built. Few new records: keep the tables, put the
-    // affected pairs on the delta list. Many: rebuild.
-    const int64_t np = s.mate[0].n_local();
+  if (first_build) {
+    if (int e = paired_rebuild_tables(c, s, st)) return e;
+    activated_now = false;
+  } else {
+    // Windows activated since the tables were built put their pairs on the delta lists (one lane per pair, a few ns each per
+    // evaluation). The tables are rebuilt -- ~30 ms of host work at 833 k pairs -- when the delta passes pairs / 8, when the
+    // cache has been quiet for 64 evaluations with pairs still on the delta path (steady re-scoring: an annealing run adds
+    // windows every few calls), or on request. On request the calling thread does it (gaml_hip_compact_tables: "at the next
+    // evaluation"); otherwise a worker does, and the evaluations go on over the old tables + delta lists meanwhile.
     const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / 8);
     size_t new_records = 0;
-    for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
-    if (s.dirty.size() + new_records > limit) need_full = true;
-    else paired_extend_delta(s);
+    if (activated_now) for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
+    const bool over = activated_now && s.dirty.size() + new_records > limit;
+    const bool quiet = !activated_now && !s.dirty.empty() && s.quiet_calls >= 64 && c->knobs[6] != 2;
+    const bool asked = s.compact_requested && (!s.dirty.empty() || activated_now);
+    s.compact_requested = false;
+    const bool use_worker = c->knobs[14] == 0 && c->knobs[6] != 1;
+    // the delta store must hold what accumulates while a worker builds; when it cannot, wait for the worker
+    const size_t hard = s.delta_cap ? s.delta_cap - 2048 : (size_t)std::max<int64_t>(4096, np / 4);
+    const bool overflow = s.dirty.size() + new_records > hard;
+    if (asked || ((over || quiet) && !use_worker) || overflow) {
+      if (rstate == 1) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; rstate = 0; activated_now = !s.mate[0].activated_log.empty() || !s.mate[1].activated_log.empty(); }
+      const bool still = asked || overflow || !use_worker;
+      if (still && (!s.dirty.empty() || activated_now)) { if (int e = paired_rebuild_tables(c, s, st)) return e; activated_now = false; }
+    } else if ((over || quiet) && rstate == 0) {
+      if (int e = paired_start_async_rebuild(c, s)) return e;
+      rstate = 1;
+      s.quiet_calls = 0;
+    }
+    if (activated_now) {
+      if (rstate == 1) for (int mt = 0; mt < 2; mt++) rb.activated_after[mt].insert(rb.activated_after[mt].end(), s.mate[mt].activated_log.begin(), s.mate[mt].activated_log.end());
+      paired_extend_delta(s);
+    }
   }
-  if (need_full) { if (int e = paired_rebuild_tables(c, s, st)) return e; }
   if (int e = paired_upload_delta(c, s, st)) return e;
   const size_t nd = s.dirty.size();
   if (nd > s.dirty_marked) {  // marks stay on the device until the next full build: only new delta pairs need one
     const size_t fresh = nd - s.dirty_marked;
     const int n0 = (int)s.pt.class_count[0], n01 = n0 + (int)s.pt.class_count[1], n_main = n01 + (int)s.pt.class_count[2];
     hipLaunchKernelGGL(mark_dirty_kernel, dim3((unsigned)std::min<size_t>((fresh + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
-                       s.dl_slot.as<int>() + s.dirty_marked, (int)fresh, s.rec8[0].as<unsigned long long>(), n0, s.inl[0].as<int4>(), n01,
-                       n_main, s.dev[0].first.as<int4>());
+                       s.dl_slot.as<int>() + s.dirty_marked, (int)fresh, s.tab.rec8[0].as<unsigned long long>(), n0, s.tab.inl[0].as<int4>(), n01,
+                       n_main, s.tab.first[0].as<int4>());
     HIP_TRY(c, hipGetLastError());
     s.dirty_marked = nd;
   }
@@ -467,6 +592,8 @@ int paired_persist_update(gaml_hip_ctx* c, PairedSet& s, double two_T, hipStream
       HIP_TRY(c, hipExtMallocWithFlags(&P.dev, at, hipDeviceMallocFinegrained));
       P.bytes = at;
     }
+    // windows to come read as absent: every table entry all ones, once per layout (the image only ever grows)
+    for (int mt = 0; mt < 2; mt++) memset((char*)P.dev + P.off_occ[mt], 0xff, P.cap_w[mt] * sizeof(Occ12));
     full = true;
   }
   char* wp = (char*)P.dev;  // write-only: device memory behind the PCIe BAR
@@ -475,7 +602,6 @@ int paired_persist_update(gaml_hip_ctx* c, PairedSet& s, double two_T, hipStream
     char* occ = wp + P.off_occ[mt];
     if (full) {
       if (!t.occ12.empty()) memcpy(occ, t.occ12.data(), t.occ12.size() * sizeof(Occ12));
-      memset(occ + t.occ12.size() * sizeof(Occ12), 0xff, (P.cap_w[mt] - t.occ12.size()) * sizeof(Occ12));  // windows to come: absent
     } else {
       for (int32_t w : t.changed) memcpy(occ + (size_t)w * sizeof(Occ12), &t.occ12[w], sizeof(Occ12));
     }
@@ -518,17 +644,17 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   const int64_t n = s.mate[0].n_local();
   memset(&a, 0, sizeof(a));
   for (int mt = 0; mt < 2; mt++) {
-    a.m[mt].first = s.dev[mt].first.as<int4>();
-    a.m[mt].extra = s.dev[mt].extra.as<int4>();
+    a.m[mt].first = s.tab.first[mt].as<int4>();
+    a.m[mt].extra = s.tab.extra[mt].as<int4>();
     a.m[mt].mism_pow = s.dev[mt].pows.as<double>();
     a.m[mt].match_pow = s.dev[mt].pows.as<double>() + s.dev[mt].pow_n;
-    a.rec8[mt] = s.rec8[mt].as<unsigned long long>();
-    a.inl[mt] = s.inl[mt].as<int4>();
+    a.rec8[mt] = s.tab.rec8[mt].as<unsigned long long>();
+    a.inl[mt] = s.tab.inl[mt].as<int4>();
     a.dirty_recs[mt] = s.dl_rec[mt].as<int4>();
     a.spill_off[mt] = (const int*)((const char*)s.delta_dev.p + s.delta_off[2 * mt]);
     a.spill_recs[mt] = (const int4*)((const char*)s.delta_dev.p + s.delta_off[2 * mt + 1]);
   }
-  a.len12 = s.len12.as<uint32_t>();
+  a.len12 = s.tab.len12.as<uint32_t>();
   const double* tabs = s.tabs.as<double>();
   a.ins_tab = tabs; a.ins_n = (int)s.ins_tab.size();
   a.floor_tab = tabs + s.ins_tab.size();
@@ -541,13 +667,13 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   const int64_t n0 = s.pt.class_count[0], n01 = n0 + s.pt.class_count[1], n_main = n01 + s.pt.class_count[2];
   a.n0 = (int)n0; a.n01 = (int)n01; a.n_main = (int)n_main;
   const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
-  const double* ct = s.combo_tabs.as<double>();
+  const double* ct = s.tab.combo_tabs.as<double>();
   a.pe[0] = ct; a.pe[1] = ct + nc * 64; a.floor_c = ct + 2 * nc * 64; a.logfloor_c = a.floor_c + nc; a.covthr_c = a.logfloor_c + nc;
-  a.len_code = s.len_code.as<unsigned char>();
-  a.len_combo = s.len_combo.as<uint32_t>();
+  a.len_code = s.tab.len_code.as<unsigned char>();
+  a.len_combo = s.tab.len_combo.as<uint32_t>();
   a.n_codes = (int)std::min<size_t>(256, s.pt.len_combo.size());
-  a.memo = s.memo_codes > 0 ? s.memo.as<double2>() : nullptr;
-  a.lt_codes = s.memo_codes;
+  a.memo = s.tab.memo_codes > 0 ? s.tab.memo.as<double2>() : nullptr;
+  a.lt_codes = s.tab.memo_codes;
   const size_t nd = s.dirty.size();
   a.n_dirty = (int)nd;
   a.dirty_slots = s.dl_slot.as<int>();
@@ -614,7 +740,7 @@ CovArgs paired_cov_args(const PairedSet& s, const PairedPrep& p, const PairedLay
 // per-block partials in pinned host memory (blocking calls): every block stores its partial straight there, the
 // host adds them up in the finisher kernel's order (no finisher launch, no D2H copy). Sentinels let the host see
 // when every partial has landed without waiting for the runtime's completion signal (fetch_partials).
-int paired_host_partials(gaml_hip_ctx* c, PairedSet& s, int n_sets, int n_partials, double** d_sum, int** d_zero) {
+int paired_host_partials(gaml_hip_ctx* c, PairedSet& s, int first_set, int n_sets, int n_partials, double** d_sum, int** d_zero) {
   const size_t per = (size_t)(4 * kMaxBlocks + kOvfMaxBlocks);
   HIP_TRY(c, s.h_part_sum.reserve(per * sizeof(double) * kMaxSets));
   HIP_TRY(c, s.h_part_zero.reserve(per * sizeof(int) * kMaxSets));
@@ -622,8 +748,10 @@ int paired_host_partials(gaml_hip_ctx* c, PairedSet& s, int n_sets, int n_partia
   *d_zero = (int*)s.h_part_zero.dev;
   double* hs = (double*)s.h_part_sum.p;
   int* hz = (int*)s.h_part_zero.p;
-  for (int k = 0; k < n_sets; k++)
+  for (int k = first_set; k < first_set + n_sets; k++) {
     for (int b2 = 0; b2 < n_partials; b2++) { hs[(size_t)k * per + b2] = std::numeric_limits<double>::quiet_NaN(); hz[(size_t)k * per + b2] = INT_MIN; }
+    s.last_blocks[k] = n_partials;
+  }
   s.host_part_stride = per;
   return 0;
 }
@@ -696,7 +824,8 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   const int n_partials = gp.total_blocks + gen_blocks;
   sd.part_sum = s.red.part_sum.as<double>();
   sd.part_zero = s.red.part_zero.as<int>();
-  if (c->host_results && n > 0) { if (int e = paired_host_partials(c, s, 1, n_partials, &sd.part_sum, &sd.part_zero)) return e; }
+  if (c->host_results && n > 0) { if (int e = paired_host_partials(c, s, 0, 1, n_partials, &sd.part_sum, &sd.part_zero)) return e; }
+  s.last_blocks[0] = n > 0 ? n_partials : 0;
   s.last_host_partials = c->host_results;
   s.last_sets = 1;
   paired_apply_set(a, sd);
@@ -775,7 +904,10 @@ bool paired_multi_capable(const gaml_hip_ctx* c, const PairedSet& s) {
   return !(s.cfg.penalty_constant > 0) && c->knobs[3] == 0 && c->knobs[4] == 0 && s.floor_positive;
 }
 
-int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int n_sets, const PairedLayout* L, const PairedPrep* preps, const int32_t* total_lens,
+// Sets [first, first + n_sets) of a batch (L / preps / total_lens / arena regions / partial regions are indexed by the
+// set's number in the batch): a batch may go out in two launches so that the host plans the second half while the
+// device scores the first.
+int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, const PairedLayout* L, const PairedPrep* preps, const int32_t* total_lens,
                         const char* arena, size_t stride, hipStream_t st) {
   PairedArgs a;
   GridPlan gp;
@@ -783,25 +915,26 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int n_sets, const PairedL
   if (!a.memo) return fail(c, GAML_HIP_ESTATE, "multi-set launch without a memo (caller must check paired_multi_capable)");
   const int64_t n = s.mate[0].n_local();
   bool any_general = false;
-  for (int k = 0; k < n_sets; k++) any_general = any_general || (a.n_main > 0 && preps[k].general);
+  for (int k = first; k < first + n_sets; k++) any_general = any_general || (a.n_main > 0 && preps[k].general);
   const size_t gen_bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2]) * sizeof(unsigned long long);
-  if (any_general && gen_bytes * n_sets > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(gen_bytes * kMaxSets + 64)); }
+  if (any_general && gen_bytes * kMaxSets > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(gen_bytes * kMaxSets + 64)); }
   const int n_partials = gp.total_blocks + (any_general ? gp.gen_blocks : 0);
   double* d_sum = nullptr;
   int* d_zero = nullptr;
   s.last_total_blocks = n > 0 ? n_partials : 0;
   s.last_host_partials = true;
-  s.last_sets = n_sets;
-  if (n == 0) return 0;
-  if (int e = paired_host_partials(c, s, n_sets, n_partials, &d_sum, &d_zero)) return e;
+  s.last_sets = first + n_sets;
+  if (n == 0) { for (int k = first; k < first + n_sets; k++) s.last_blocks[k] = 0; return 0; }
+  if (int e = paired_host_partials(c, s, first, n_sets, n_partials, &d_sum, &d_zero)) return e;
   MultiSets ms;
   memset(&ms, 0, sizeof(ms));
   ms.n = n_sets;
   for (int k = 0; k < n_sets; k++) {
-    paired_set_view(L[k], arena + (size_t)k * stride, total_lens[k], ms.set[k]);
-    ms.set[k].part_sum = d_sum + (size_t)k * s.host_part_stride;
-    ms.set[k].part_zero = d_zero + (size_t)k * s.host_part_stride;
-    if (any_general) ms.set[k].gen_bits = (unsigned long long*)((char*)s.gen_bits.p + (size_t)k * gen_bytes);
+    const int g = first + k;  // the set's number in the batch
+    paired_set_view(L[g], arena + (size_t)g * stride, total_lens[g], ms.set[k]);
+    ms.set[k].part_sum = d_sum + (size_t)g * s.host_part_stride;
+    ms.set[k].part_zero = d_zero + (size_t)g * s.host_part_stride;
+    if (any_general) ms.set[k].gen_bits = (unsigned long long*)((char*)s.gen_bits.p + (size_t)g * gen_bytes);
   }
   paired_apply_set(a, ms.set[0]);  // (fields every set overrides; harmless defaults)
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -821,7 +954,7 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int n_sets, const PairedL
   }
   if (!c->event_timing || ev) {
     double rec = 0;
-    for (int k = 0; k < n_sets; k++) rec += (double)preps[k].assembled_records;
+    for (int k = first; k < first + n_sets; k++) rec += (double)preps[k].assembled_records;
     c->stat_algo_bytes += 16.0 * rec + 16.0 * (double)n * n_sets;
     c->stat_launches++;
   }

@@ -82,3 +82,41 @@ def test_delta_list_equals_full_rebuild():
     st0, st1 = ctxs[0].debug_table_stats(0), ctxs[1].debug_table_stats(0)
     assert st0["delta_updates"] > 5 and st0["full_rebuilds"] < st1["full_rebuilds"]
     assert st1["delta_updates"] == 0 and st1["dirty_pairs"] == 0
+
+
+def test_incremental_planning_and_resident_tables_change_no_bit():
+    """Three contexts walk the same annealing-style sequence: (a) the default -- paths diffed against the previous call,
+    the resident device copy of the occurrence tables patched in place; (b) every set planned from scratch (knob 12);
+    (c) whole tables through the ring for every call (knob 13). Values, floored counts and per-read probabilities are
+    equal bit for bit at every step (the tables describe the same occurrences; slots and ranks only ever enter through
+    equality / order within one path)."""
+    from gaml_amd import api
+    G, n, seed = 150_000, 8000, 17
+    genome = synth.plant_repeats(synth.make_genome(G, seed), 3, 800, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(600, 4000), short_rng=(25, 330)))
+    pr = synth.make_paired_reads(genome, n, 100, 240.0, 24.0, 0.01, seed)
+    ctxs = []
+    for knob in (None, 12, 13):
+        c = api.Context(device=0)
+        c.set_graph(*g.packed())
+        c.add_paired(api.paired_cfg(240.0, 24.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+        if knob:
+            c.debug_set_knob(knob, 1)
+        ctxs.append(c)
+    start, seq = synth.sa_sequence(g, 300, seed=5, threshold=400)
+    rng = np.random.default_rng(1)
+    sets = [start]
+    for s in seq:
+        sets.append(s)
+        if rng.random() < 0.1:
+            sets.append(sets[int(rng.integers(0, len(sets)))])
+    n_inc = 0
+    for k, ps in enumerate(sets):
+        vals = [c.calc_prob(ps) for c in ctxs]
+        for v in vals[1:]:
+            assert v[0] == vals[0][0] and v[1].tolist() == vals[0][1].tolist() and v[2] == vals[0][2], (k, vals)
+        if k % 25 == 0:
+            p0 = ctxs[0].read_probs(0)
+            assert np.array_equal(p0, ctxs[1].read_probs(0)) and np.array_equal(p0, ctxs[2].read_probs(0))
+        n_inc += ctxs[0].debug_table_occurrences(0, 0)[1]["incremental"]
+    assert n_inc > len(sets) // 2
