@@ -2258,11 +2258,11 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wi
   return (int32_t)w.size();
 }
 
-int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out3) {
+int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out3 /* 4 values */) {
   MULTI_SHARD0(c);
   if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out3) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
-  out3[0] = s.full_rebuilds; out3[1] = s.delta_updates; out3[2] = (int64_t)s.dirty.size();
+  out3[0] = s.full_rebuilds; out3[1] = s.delta_updates; out3[2] = (int64_t)s.dirty.size(); out3[3] = s.async_rebuilds;
   return GAML_HIP_OK;
 }
 

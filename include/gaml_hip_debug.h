@@ -46,9 +46,11 @@ int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int
 int64_t gaml_hip_debug_table_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int32_t* out5, int64_t cap, int64_t* info3);
 /* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
-/* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list}.
- * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables). */
-int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out3);
+/* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list, rebuilds
+ * done by the worker thread (of the full rebuilds)}.
+ * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables); knob 14 = 1 keeps every
+ * rebuild on the calling thread. */
+int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out4);
 
 /* ---- tuning ------------------------------------------------------------------------------------- */
 /* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner), [1] thresholds +
