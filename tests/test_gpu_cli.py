@@ -58,6 +58,44 @@ def test_gaml_score_matches_oracle_from_the_same_config(tmp_path):
         assert abs(got - want) <= 1e-9 * abs(want)
 
 
+@pytest.mark.gpu
+def test_cfg1_at_its_stated_size_through_files(tmp_path):
+    """BASELINE config 1 as stated: a 50 kbp synthetic Velvet LastGraph and 10,000 x 100 bp single reads, through the
+    files a GAML user has -- LastGraph (graph.cc:52-106), FASTQ, GAML config (gaml.cc:748-872) -- into the C++ host
+    mirror's ProbCalculator, against the oracle reading the same config. (BASELINE runs this configuration on the CPU
+    only; here it is the plumbing check of the file readers at full size.)"""
+    import oracle_py as op
+    d = str(tmp_path)
+    G, n, seed = 50_000, 10_000, 101
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed))
+    synth.write_lastgraph(os.path.join(d, "LastGraph"), g)
+    sr = synth.make_single_reads(genome, n, 100, 0.01, seed)
+    synth.write_fastq(os.path.join(d, "reads.fastq"), sr, "s", None)
+    synth.write_config(os.path.join(d, "run.cfg"), os.path.join(d, "LastGraph"),
+                       [dict(name="single1", type="single", filename=os.path.join(d, "reads.fastq"))], extra={"long_contig_threshold": 500})
+    walk = synth.genome_walk(g)
+    with open(os.path.join(d, "genome.walks"), "w") as f:
+        pos, parts = 0, []
+        for x in walk:
+            parts.append(f"{x}({pos})")
+            pos += g.node_len(x)
+        f.write(">tmp0-" + "-".join(parts) + "\n")
+    orc = op.Oracle()
+    assert orc.load_config(os.path.join(d, "run.cfg")) == 1
+    start = [[i] for i in range(0, g.n_nodes, 2) if g.node_len(i) > 500]  # gaml.cc:1002-1005
+    for args, ps in (([os.path.join(d, "genome.walks")], [walk]), ([], start)):
+        out = subprocess.run([CLI, os.path.join(d, "run.cfg")] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert f"Loaded {g.n_nodes // 2} nodes" in out.stdout
+        m = re.search(r"start prob (\S+) len (\d+) low prob reads(.*)", out.stdout)
+        got, tl = float(m.group(1)), int(m.group(2))
+        zeros = [[int(a), int(b)] for a, b in re.findall(r"(\d+)/(\d+)", m.group(3))]
+        want, wz, wtl = orc.calc_prob(ps, fresh=True)
+        assert tl == wtl and zeros == wz.tolist() and zeros[0][1] == n
+        assert abs(got - want) <= 1e-9 * abs(want)
+
+
 def test_gaml_score_fails_loudly_without_a_gpu(tmp_path, built):
     try:
         import torch

@@ -128,11 +128,11 @@ def test_cfg4_two_read_sets_full_size():
 
 
 def test_cfg5_annealing_pattern_at_full_size_is_history_independent():
-    """BASELINE config 5's call pattern at cfg3 size: 150 edited path sets in a row (new junction windows
-    aligned on the fly, delta lists growing, tables rebuilt when due). CalcProb must stay a pure function
-    of the path set: at checkpoints the long-lived context agrees with a context that has never seen
-    anything else (same windows get aligned there from scratch), and the batch entry point agrees with
-    single calls."""
+    """BASELINE config 5's call pattern at its stated size: the reference's start state on the 5 Mbp graph with
+    833,333 pairs, then 1000 edited path sets in a row (new junction windows aligned on the fly, paths diffed against
+    the previous call, delta lists growing, tables rebuilt -- by the worker thread -- when due). CalcProb must stay a
+    pure function of the path set: at checkpoints the long-lived context agrees with a context that has never seen
+    anything else (same windows get aligned there from scratch), and the batch entry point agrees with single calls."""
     from gaml_amd import api
     from test_gpu_sa_pattern import _moves
     wl = synth.WORKLOADS["cfg3"]
@@ -142,7 +142,7 @@ def test_cfg5_annealing_pattern_at_full_size_is_history_independent():
     rng = np.random.default_rng(11)
     ctx.calc_prob(cur)
     seq = []
-    for it in range(150):
+    for it in range(1000):
         new = _moves(rng, cur, g)
         seq.append(new)
         if rng.random() < 0.6:
@@ -153,10 +153,11 @@ def test_cfg5_annealing_pattern_at_full_size_is_history_independent():
     fresh = api.Context(device=0)
     fresh.set_graph(*g.packed())
     fresh.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
-    for k in (149, 60, 5):
+    assert ctx.debug_table_occurrences(rs, 0)[1]["incremental_calls"] > 800
+    for k in (999, 700, 149, 60, 5):
         want = fresh.calc_prob(seq[k])
         assert vals[k][2] == want[2] and vals[k][1].tolist() == want[1].tolist()
         assert abs(vals[k][0] - want[0]) <= 1e-12 * abs(want[0]), (k, vals[k][0], want[0])
-    again = ctx.calc_prob_batch([seq[149], seq[60], seq[5]])
-    for b, k in zip(again, (149, 60, 5)):
+    again = ctx.calc_prob_batch([seq[999], seq[149], seq[60], seq[5]])
+    for b, k in zip(again, (999, 149, 60, 5)):
         assert abs(b[0] - vals[k][0]) <= 1e-12 * abs(vals[k][0])
