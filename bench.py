@@ -108,11 +108,20 @@ def sa_pattern(ctx, rs, g, iters, api, synth):
     a1 = ctx.aligner_stats()
     t_stats1 = ctx.debug_table_stats(rs)
     per *= 1e6
+    # where a warm call of this pattern goes (replay of the last 200 sets: everything cached), library-side phases
+    prof = []
+    for f in flat[-200:]:
+        ctx.score(f)
+        prof.append(ctx.debug_profile())
+    ph = np.median(np.array(prof), axis=0)
     return {"iterations": iters, "paths_at_start": len(start), "total_s": total, "first_call_cold_s": first_s,
             "us_median": float(np.median(per)), "us_p90": float(np.percentile(per, 90)), "us_p99": float(np.percentile(per, 99)),
             "us_max": float(per.max()), "table_rebuilds": t_stats1["full_rebuilds"] - t_stats0["full_rebuilds"],
             "delta_updates": t_stats1["delta_updates"] - t_stats0["delta_updates"],
+            "worker_rebuilds": t_stats1["worker_rebuilds"] - t_stats0["worker_rebuilds"],
             "windows_aligned": a1["windows"] - a0["windows"], "aligner_ms": (a1["us"] - a0["us"]) * 1e-3,
+            "warm_call_phases_us": {"planning": float(ph[0]), "tables": float(ph[1]), "write": float(ph[3]), "launch": float(ph[5]),
+                                    "wait": float(ph[7]), "bytes_written": float(ph[6])},
             "recipe": "gaml_amd.synth.sa_sequence(seed 7): BreakPath / join / reverse / LocalChange / duplicate / trim edits, 60 % accepted"}
 
 

@@ -182,6 +182,7 @@ struct TableRebuild {
   uint64_t gen_snap[2] = {0, 0};
   hipStream_t stream = nullptr;
   double snapshot_us = 0, build_ms = 0;
+  int64_t start_eval = 0;      // the set's evaluation count when the worker was started
 };
 
 struct PairedSet {
@@ -191,7 +192,7 @@ struct PairedSet {
   MateDev dev[2];                     // (pows, aligner index, generation; the record tables themselves are in `tab`)
   TableDev tab;
   TableRebuild rebuild;
-  int64_t async_rebuilds = 0;
+  int64_t async_rebuilds = 0, retired_windows = 0, eval_count = 0;
   // delta since the last full table build: pairs whose record lists gained records of newly
   // activated windows. Their complete lists (device-table order: window id, position) travel with
   // every evaluation; a full rebuild folds them back in when they become too many.

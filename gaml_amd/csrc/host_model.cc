@@ -460,6 +460,22 @@ int32_t ShortMate::align(const GraphStore& g, const Walk& w) {
   return id;
 }
 
+int64_t ShortMate::retire_unused() {
+  int64_t n = 0;
+  used.resize(wins.size(), 0);
+  for (size_t w = 0; w < wins.size(); w++) {
+    Window& win = wins[w];
+    if (win.active && !used[w] && !win.pending) {
+      win.active = false;
+      active_records -= win.count;
+      n++;
+    }
+    used[w] = 0;
+  }
+  if (n) active_generation++;
+  return n;
+}
+
 void ShortMate::flush_pending_cpu(const GraphStore& g) {
   std::vector<gaml_aligment> recs;
   for (int32_t id : pending) {
@@ -638,6 +654,7 @@ int32_t PairedPlanner::lookup_or_create(const GraphStore& g, const int32_t* pp, 
   }
   PathMemo& pm = *memos_[id];
   pm.path = p;
+  pm.touched_serial = retire_serial_;  // its lists are yet to be computed (and activate what they name)
   by_path_.emplace(p, id);
   // path-only facts: contig starts, length, first node position and its window end, final last_end
   std::vector<std::pair<int32_t, int32_t>> ranges;
@@ -807,6 +824,7 @@ bool PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const int32_t*
       PathMemo& pm = *memos_[cur_ids_[k]];
       removed_.push_back(Removed{cur_slots_[k], {pm.assembled[0], pm.assembled[1]}, {pm.occ[0], pm.occ[1]}});  // lists as they stand: the memo may be evicted or rebuilt before apply()
       pm.use_count--;
+      pm.last_used = clock_;  // in use up to the previous call (window retirement asks which paths were scored since the last rebuild)
       total_len_ -= pm.length;
       freed_now.push_back(cur_slots_[k]);
     }
@@ -927,8 +945,20 @@ const PlanView& PairedPlanner::view() {
 void PairedPlanner::apply(ShortMate mate[2], OccImage image[2]) {
   if (!incremental_) {
     const PlanView& v = view();
+    for (int32_t id : cur_ids_) {
+      PathMemo& pm = *memos_[id];
+      if (pm.touched_serial == retire_serial_) continue;
+      for (int mt = 0; mt < 2; mt++) for (const Occ& o : pm.occ[mt]) mate[mt].touch(o.wid);  // a memoised list may name windows a rebuild retired
+      pm.touched_serial = retire_serial_;
+    }
     for (int mt = 0; mt < 2; mt++) image[mt].build(mate[mt].wins.size(), v, mt);
     return;
+  }
+  for (int32_t k : work_) {
+    PathMemo& pm = *memos_[cur_ids_[k]];
+    if (pm.touched_serial == retire_serial_) continue;
+    for (int mt = 0; mt < 2; mt++) for (const Occ& o : pm.occ[mt]) mate[mt].touch(o.wid);
+    pm.touched_serial = retire_serial_;
   }
   if ((int32_t)pos_of_slot_.size() < next_slot_) pos_of_slot_.resize((size_t)next_slot_ + 64, 0);
   for (int32_t k = 0; k < (int32_t)cur_slots_.size(); k++) pos_of_slot_[cur_slots_[k]] = k;
@@ -942,6 +972,13 @@ void PairedPlanner::apply(ShortMate mate[2], OccImage image[2]) {
     }
     im.finalize(pos_of_slot_);
   }
+}
+
+void PairedPlanner::mark_used(ShortMate mate[2], const OccImage image[2]) {
+  for (int mt = 0; mt < 2; mt++) image[mt].for_each_present([&](int32_t w) { mate[mt].touch(w); });
+  for (auto& pm : memos_)
+    if (pm->last_used > rebuild_clock_ || pm->use_count > 0)
+      for (int mt = 0; mt < 2; mt++) for (const Occ& o : pm->occ[mt]) if (o.wid < (int32_t)mate[mt].wins.size()) mate[mt].touch(o.wid);
 }
 
 void PairedPlanner::flat_occurrences(int mate, std::vector<Occ>& out) {

@@ -100,6 +100,17 @@ struct ShortMate {
     if (!w.active) { w.active = true; active_records += w.count; if (w.count) { active_generation++; activated_log.push_back(wid); } }
   }
 
+  // A window that occurs in a scored path set: on the device (activated if it was not) and marked as used. At a
+  // table rebuild the windows no path set has used since the previous rebuild leave the device tables again
+  // (retire_unused): a long run does not drag the records of every junction it ever tried through every evaluation.
+  std::vector<uint8_t> used;             // per window: occurred in a path set since the last rebuild
+  void touch(int32_t wid) {
+    if (!wins[wid].active) activate(wid);
+    if (used.size() <= (size_t)wid) used.resize(wins.size(), 0);
+    used[wid] = 1;
+  }
+  int64_t retire_unused();               // returns the number of windows retired; clears the marks
+
   int64_t n_local() const { return hi - lo; }
   const char* read(int64_t local) const { return bases.data() + roff[local]; }
   void set_reads(int64_t n_global_, int64_t lo_, int64_t hi_, const char* b, const int64_t* offs_global);
@@ -227,6 +238,7 @@ struct OccImage {
   bool changed_all = true, lists_changed = true;
   // every occurrence the tables describe, as {window, shift, min_pos (as stored: clamped at -32768 in the 8-byte form), slot, rank}
   void dump(std::vector<Occ>& out) const;
+  template <class F> void for_each_present(F f) const { for (int32_t w : touched_) if (cnt_[w] > 0) f(w); }
   void take_changed() { changed.clear(); changed_all = false; lists_changed = false; if (++mark_serial_ == 0) { std::fill(mark_.begin(), mark_.end(), 0); mark_serial_ = 1; } }
  private:
   void grow(size_t n_windows);
@@ -266,6 +278,7 @@ struct PathMemo {
   int32_t first_idx = -1, first_end = -1;// first non-gap position and the end index of its junction window
   int32_t final_last_end = -2;           // last_end after the path (-2: path has no node, passes through)
   int32_t use_count = 0;                 // instances in the current path set (a memo in use is never evicted)
+  uint32_t touched_serial = 0;           // windows retired after this: the lists' windows must be (re)activated when the path enters a set
   uint64_t last_used = 0;
   uint32_t serial = 0;                   // bumps when the slot is reused (stale ids in the miss index)
 };
@@ -286,6 +299,10 @@ class PairedPlanner {
   void finish(ShortMate mate[2]);          // pass 2 (needs the windows' records / global maxima): occurrence lists
   // the occurrence tables of this call: whole-set rebuild or per-path adds / removes (what begin() decided)
   void apply(ShortMate mate[2], OccImage image[2]);
+  // table rebuilds retire windows no path set has used since the previous rebuild: mark_used() marks the windows of
+  // the current set and of every path that entered a set since the last call of note_rebuild()
+  void mark_used(ShortMate mate[2], const OccImage image[2]);
+  void note_rebuild(bool retired_some) { rebuild_clock_ = clock_; if (retired_some) retire_serial_++; }
   void invalidate_thresholds();          // window maxima changed (sharded cold path)
   void forget_previous() { have_prev_ = false; }  // the next begin() starts from scratch
   const PlanView& view();                // memos of the current set, in path order (built on demand)
@@ -326,7 +343,8 @@ class PairedPlanner {
   std::vector<char> redo_;
   int32_t total_len_ = 0;
   int64_t assembled_[2] = {0, 0};
-  uint64_t clock_ = 0;
+  uint64_t clock_ = 0, rebuild_clock_ = 0;
+  uint32_t retire_serial_ = 0;
   static constexpr size_t kMaxMemos = 2048;
 };
 int32_t walk_length(const GraphStore& g, const Walk& w);

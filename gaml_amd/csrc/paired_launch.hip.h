@@ -228,9 +228,21 @@ int paired_upload_pows(gaml_hip_ctx* c, PairedSet& s) {
 }
 
 // full rebuild on the calling thread: new device order of the pairs, record tables built on the host and uploaded
+// a rebuild is also when windows that no scored path set has used since the previous rebuild leave the device tables
+// (knob 15 = 1: never). The current path set's windows stay, whatever their marks.
+void paired_retire_windows(gaml_hip_ctx* c, PairedSet& s) {
+  if (c->knobs[15] == 1) return;
+  s.planner.mark_used(s.mate, s.image);
+  int64_t n = 0;
+  for (int mt = 0; mt < 2; mt++) n += s.mate[mt].retire_unused();
+  s.retired_windows += n;
+  s.planner.note_rebuild(n > 0);
+}
+
 int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   paired_reset_delta(s);
   s.full_rebuilds++;
+  paired_retire_windows(c, s);
   for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
   const double tb0 = now_us();
   build_pair_tables(s.mate[0], s.mate[1], s.pt);
@@ -241,7 +253,7 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   for (int mt = 0; mt < 2; mt++) s.dev[mt].uploaded_generation = s.mate[mt].active_generation;
   // room for the private copy a later rebuild off this thread takes (paired_snapshot_mate): allocated and touched here,
   // inside a call that takes tens of milliseconds anyway, so that the snapshot itself is a plain copy
-  if (c->knobs[14] == 0 && s.rebuild.state.load(std::memory_order_acquire) == 0 && !s.rebuild.th.joinable()) {
+  if (c->knobs[14] != 1 && s.rebuild.state.load(std::memory_order_acquire) == 0 && !s.rebuild.th.joinable()) {
     for (int mt = 0; mt < 2; mt++) {
       ShortMate& sn = s.rebuild.snap[mt];
       if (sn.lens.size() != s.mate[mt].lens.size()) sn.lens = s.mate[mt].lens;
@@ -276,6 +288,7 @@ int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s) {
   TableRebuild& rb = s.rebuild;
   const double t0 = now_us();
   if (rb.th.joinable()) rb.th.join();
+  paired_retire_windows(c, s);
   for (int mt = 0; mt < 2; mt++) {
     paired_snapshot_mate(s.mate[mt], rb.snap[mt]);
     rb.gen_snap[mt] = s.mate[mt].active_generation;
@@ -283,6 +296,7 @@ int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s) {
   }
   if (!rb.stream) HIP_TRY(c, hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
   rb.err.clear();
+  rb.start_eval = s.eval_count;
   rb.state.store(1, std::memory_order_release);
   rb.snapshot_us = now_us() - t0;
   const int device = c->device;
@@ -410,7 +424,14 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   TableRebuild& rb = s.rebuild;
   const int64_t np = s.mate[0].n_local();
   int rstate = rb.state.load(std::memory_order_acquire);
-  if (rstate == 2 || rstate == 3) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; rstate = 0; }
+  s.eval_count++;
+  // The new tables take over a FIXED number of evaluations after the worker was started -- not whenever the worker
+  // happens to be done: a rebuild changes the order of the final sum (last bits), and equal inputs must give equal
+  // outputs run to run (the annealing loop compares likelihoods with strict >). The worker needs ~30 ms at
+  // 833 k pairs, 768 evaluations take at least that long; if it is not done by then, this call waits for it.
+  const int64_t swap_after = c->knobs[14] > 1 ? c->knobs[14] : 768;
+  if (rstate != 0 && s.eval_count - rb.start_eval >= swap_after) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; rstate = 0; }
+  else if (rstate != 0) rstate = 1;  // (ready or not: not yet)
   const bool first_build = s.dev[0].pow_n == 0;
   bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
   s.quiet_calls = activated_now ? 0 : s.quiet_calls + 1;
@@ -430,7 +451,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     const bool quiet = !activated_now && !s.dirty.empty() && s.quiet_calls >= 64 && c->knobs[6] != 2;
     const bool asked = s.compact_requested && (!s.dirty.empty() || activated_now);
     s.compact_requested = false;
-    const bool use_worker = c->knobs[14] == 0 && c->knobs[6] != 1;
+    const bool use_worker = c->knobs[14] != 1 && c->knobs[6] != 1;
     // the delta store must hold what accumulates while a worker builds; when it cannot, wait for the worker
     const size_t hard = s.delta_cap ? s.delta_cap - 2048 : (size_t)std::max<int64_t>(4096, np / 4);
     const bool overflow = s.dirty.size() + new_records > hard;

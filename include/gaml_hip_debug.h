@@ -49,7 +49,8 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int
 /* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list, rebuilds
  * done by the worker thread (of the full rebuilds)}.
  * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables); knob 14 = 1 keeps every
- * rebuild on the calling thread. */
+ * rebuild on the calling thread, knob 14 = k > 1 lets a worker's tables take over k evaluations after its start
+ * (default 768); knob 15 = 1: rebuilds never retire unused windows. */
 int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out4);
 
 /* ---- tuning ------------------------------------------------------------------------------------- */
