@@ -210,7 +210,7 @@ struct PairedSet {
   size_t delta_cap = 0;                 // pairs the device store holds
   DevBuf dl_slot, dl_spill, dl_rec[2], dl_patch, delta_dev /* spill CSR */;
   Staging stage_delta;
-  size_t delta_off[4] = {0, 0, 0, 0};   // spill CSR: offsets mate 0, records mate 0, offsets mate 1, records mate 1
+  size_t delta_off[5] = {0, 0, 0, 0, 0};   // spill CSR: offsets mate 0, records mate 0, offsets mate 1, records mate 1, slots
   int quiet_calls = 0;       // evaluations since the last window activation
   bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
   PinBuf h_timeline; int timeline_waves = 0;  // ablation 8 (tools/kernel_timeline.py)

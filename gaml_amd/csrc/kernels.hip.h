@@ -91,6 +91,8 @@ struct PairedArgs {
   const int* dirty_spill;     // [n_dirty] -1, or the pair's index in the spill lists (more than 4 records on a mate)
   const int* spill_off[2];    // CSR of the spill lists
   const int4* spill_recs[2];
+  const int* spill_slot;      // [n_spill] slot of the pair (scored one WAVE per pair, behind the table pairs with long lists)
+  int n_spill;
   double* part_sum;          // per-block partials: main kernel blocks, then overflow kernel blocks
   int* part_zero;
   unsigned* ticket;          // zero before first launch; the last block resets it
@@ -721,13 +723,7 @@ __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, i
     const int sp = a.dirty_spill[dj];
     const uint32_t l12 = i < a.n0 ? a.len_combo[a.len_code[i]] : a.len12[i - a.n0];
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-    if (sp >= 0) {  // a long list: fully general per-lane loop
-      const int b0 = a.spill_off[0][sp], b1 = a.spill_off[1][sp];
-      const double acc = paired_general_src(a, ListSrc{a.spill_recs[0] + b0, a.spill_off[0][sp + 1] - b0},
-                                            ListSrc{a.spill_recs[1] + b1, a.spill_off[1][sp + 1] - b1}, L1, L2);
-      finish_read(a, i, acc, L1, L2, lsum, zeros);
-      continue;
-    }
+    if (sp >= 0) continue;  // a long list: one WAVE scores it (paired_overflow_body) -- a lane looping over it alone was the launch's tail
     int4 r0[4], r1[4];
     int c0 = 0, c1 = 0;
 #pragma unroll
@@ -815,16 +811,17 @@ __global__ __launch_bounds__(kBlock) void finish_partials_kernel(const double* p
 constexpr int kOvfCap = 128;     // candidates per mate held in LDS per wave
 constexpr int kOvfMaxBlocks = 1024;
 
-__device__ __forceinline__ int wave_gather(const MateView& v, const int4& r0, int4* lds, int lane) {
+template <class Src>
+__device__ __forceinline__ int wave_gather(const MateView& v, const Src& src, int4* lds, int lane) {
   // returns the number of candidates, or -1 if they do not fit
-  const int cnt = r0.x < 0 ? 0 : 1 + (int)((unsigned)r0.z >> 9);
+  const int cnt = src.count();
   int total = 0;
   for (int base = 0; base < cnt; base += 64) {
     const int k = base + lane;
     int mine = 0;
     int4 r = make_int4(-1, 0, 0, 0), o = make_int4(0, 0, -1, 0);
     if (k < cnt) {
-      r = k == 0 ? r0 : v.extra[r0.w + k - 1];
+      r = src.get(k);
       if (r.x >= 0) { const Occ12 e = v.occ12[r.x]; o = occ_from_compact((unsigned long long)e.lo | ((unsigned long long)e.hi << 32), e.rank); }  // (paired sets only)
       if (o.z >= 0) mine = o.w >= 0 ? 1 : v.multi_off[-o.w] - v.multi_off[-o.w - 1];
     }
@@ -848,62 +845,81 @@ __device__ __forceinline__ int wave_gather(const MateView& v, const int4& r0, in
   return total;
 }
 
+// one pair, one wave: candidates of both mates staged in LDS, overwrite rule and pair terms spread over the lanes
+template <class Src>
+__device__ __forceinline__ double wave_score_pair(const PairedArgs& a, const Src& s1, const Src& s2, int L1, int L2, int4* c1, int4* c2, int lane) {
+  const int n1 = wave_gather(a.m[0], s1, c1, lane);
+  const int n2 = wave_gather(a.m[1], s2, c2, lane);
+  double acc = 0.0;
+  if (n1 < 0 || n2 < 0) {
+    // more candidates than the LDS staging holds: fully general per-lane loop
+    if (lane == 0) acc = paired_general_src(a, s1, s2, L1, L2);
+    return acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // overwrite rule: candidate is live iff valid and no later-ranked valid twin (same path, pos)
+  for (int m = 0; m < 2; m++) {
+    int4* c = m == 0 ? c1 : c2;
+    const int n = m == 0 ? n1 : n2;
+    for (int x = lane; x < n; x += 64) {
+      int4 me = c[x];
+      bool live = (me.z & 0x200) != 0;
+      for (int y = 0; y < n && live; y++) {
+        const int4 ot = c[y];
+        if (y != x && (ot.z & 0x200) && ot.x == me.x && ot.y == me.y && (ot.w > me.w || (ot.w == me.w && y > x))) live = false;
+      }
+      if (live) me.z |= 0x400;
+      c[x].z = me.z;  // readers only test the valid bit 0x200; the live bit 0x400 is written once per slot
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int pairs = n1 * n2;
+  for (int idx = lane; idx < pairs; idx += 64) {
+    const int4 xr = c1[idx / n2];
+    const int4 yr = c2[idx % n2];
+    if ((xr.z & 0x400) && (yr.z & 0x400) && xr.x == yr.x) {
+      Cand x, y;
+      x.path = xr.x; x.pos = xr.y; x.edit = xr.z & 0xff; x.orient = (xr.z >> 8) & 1;
+      y.path = yr.x; y.pos = yr.y; y.edit = yr.z & 0xff; y.orient = (yr.z >> 8) & 1;
+      acc += pair_term(a, x, y, L1, L2);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  __builtin_amdgcn_wave_barrier();
+  return acc;
+}
+
 template <bool TICKET>
 __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ovf_block, int ovf_blocks, double* sh_s, int* sh_z,
                                                      int4 (*cand)[2][kOvfCap]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = ovf_block * (kBlock / 64) + wave;
   const int n_waves = ovf_blocks * (kBlock / 64);
-  const int n_items = a.n - a.n_main;  // delta pairs: paired_delta_body; table-class pairs of repeated windows: paired_general_kernel
+  const int n_table = a.n - a.n_main;  // table pairs with more than 4 records on a mate
+  const int n_items = n_table + a.n_spill;  // ... then the delta pairs with long lists
   double lsum = 0.0;
   int zeros = 0;
+  int4* c1 = cand[wave][0];
+  int4* c2 = cand[wave][1];
   for (int item = wave_global; item < n_items; item += n_waves) {  // fixed item -> wave assignment
-    const int i = a.n_main + item;
-    const int4 r1 = a.m[0].first[i - a.n0], r2 = a.m[1].first[i - a.n0];
-    const uint32_t l12 = a.len12[i - a.n0];
-    if (r1.x == kDirtyWid) continue;  // a class-3 pair that is on the delta list: scored there
-    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-    int4* c1 = cand[wave][0];
-    int4* c2 = cand[wave][1];
-    const int n1 = wave_gather(a.m[0], r1, c1, lane);
-    const int n2 = wave_gather(a.m[1], r2, c2, lane);
-    double acc = 0.0;
-    if (n1 < 0 || n2 < 0) {
-      // more candidates than the LDS staging holds: fully general per-lane loop
-      if (lane == 0) acc = paired_general(a, r1, r2, L1, L2);
+    if (item < n_table) {
+      const int i = a.n_main + item;
+      const int4 r1 = a.m[0].first[i - a.n0], r2 = a.m[1].first[i - a.n0];
+      const uint32_t l12 = a.len12[i - a.n0];
+      if (r1.x == kDirtyWid) continue;  // a class-3 pair that is on the delta list: scored there
+      const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+      const double acc = wave_score_pair(a, TableSrc{&a.m[0], r1}, TableSrc{&a.m[1], r2}, L1, L2, c1, c2, lane);
+      if (lane == 0) finish_read(a, i, acc, L1, L2, lsum, zeros);
     } else {
-      __builtin_amdgcn_wave_barrier();
-      // overwrite rule: candidate is live iff valid and no later-ranked valid twin (same path, pos)
-      for (int m = 0; m < 2; m++) {
-        int4* c = m == 0 ? c1 : c2;
-        const int n = m == 0 ? n1 : n2;
-        for (int x = lane; x < n; x += 64) {
-          int4 me = c[x];
-          bool live = (me.z & 0x200) != 0;
-          for (int y = 0; y < n && live; y++) {
-            const int4 ot = c[y];
-            if (y != x && (ot.z & 0x200) && ot.x == me.x && ot.y == me.y && (ot.w > me.w || (ot.w == me.w && y > x))) live = false;
-          }
-          if (live) me.z |= 0x400;
-          c[x].z = me.z;  // readers only test the valid bit 0x200; the live bit 0x400 is written once per slot
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      const int pairs = n1 * n2;
-      for (int idx = lane; idx < pairs; idx += 64) {
-        const int4 xr = c1[idx / n2];
-        const int4 yr = c2[idx % n2];
-        if ((xr.z & 0x400) && (yr.z & 0x400) && xr.x == yr.x) {
-          Cand x, y;
-          x.path = xr.x; x.pos = xr.y; x.edit = xr.z & 0xff; x.orient = (xr.z >> 8) & 1;
-          y.path = yr.x; y.pos = yr.y; y.edit = yr.z & 0xff; y.orient = (yr.z >> 8) & 1;
-          acc += pair_term(a, x, y, L1, L2);
-        }
-      }
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      __builtin_amdgcn_wave_barrier();
+      const int sp = item - n_table;
+      const int i = a.spill_slot[sp];
+      const uint32_t l12 = i < a.n0 ? a.len_combo[a.len_code[i]] : a.len12[i - a.n0];
+      const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+      const int b0 = a.spill_off[0][sp], b1 = a.spill_off[1][sp];
+      const double acc = wave_score_pair(a, ListSrc{a.spill_recs[0] + b0, a.spill_off[0][sp + 1] - b0},
+                                         ListSrc{a.spill_recs[1] + b1, a.spill_off[1][sp + 1] - b1}, L1, L2, c1, c2, lane);
+      if (lane == 0) finish_read(a, i, acc, L1, L2, lsum, zeros);
     }
-    if (lane == 0) finish_read(a, i, acc, L1, L2, lsum, zeros);
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
   if (TICKET) {

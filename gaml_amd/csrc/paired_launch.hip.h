@@ -396,6 +396,7 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
       s.delta_off[2 * mt] = dt; dt = align16(dt + (ns + 1) * sizeof(int32_t));
       s.delta_off[2 * mt + 1] = dt; dt = align16(dt + std::max<size_t>(1, dn[mt]) * sizeof(RecQuad));
     }
+    s.delta_off[4] = dt; dt = align16(dt + std::max<size_t>(1, ns) * sizeof(int32_t));  // the pairs' slots
     void* dh = nullptr;
     int dslot = stage_acquire(c, s.stage_delta, dt, &dh);
     if (dslot < 0) return dslot;
@@ -410,6 +411,10 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
         at += (int32_t)l.size();
       }
       of[ns] = at;
+    }
+    {
+      int32_t* sl = (int32_t*)((char*)dh + s.delta_off[4]);
+      for (size_t k = 0; k < ns; k++) sl[k] = s.dirty[s.spill_pairs[k]].slot;
     }
     if (dt > s.delta_dev.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.delta_dev.reserve(dt + dt / 2)); }
     if (int e = stage_upload(c, s.stage_delta, dslot, s.delta_dev.p, dt, st)) return e;  // stream order: after the kernels that read the old lists
@@ -696,10 +701,12 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   a.memo = s.tab.memo_codes > 0 ? s.tab.memo.as<double2>() : nullptr;
   a.lt_codes = s.tab.memo_codes;
   const size_t nd = s.dirty.size();
+  a.spill_slot = (const int*)((const char*)s.delta_dev.p + s.delta_off[4]);
+  a.n_spill = (int)s.spill_pairs.size();
   a.n_dirty = (int)nd;
   a.dirty_slots = s.dl_slot.as<int>();
   a.dirty_spill = s.dl_spill.as<int>();
-  const int64_t ovf_total = n - n_main;  // wave-per-pair items (delta pairs: lane per pair in the main range)
+  const int64_t ovf_total = n - n_main + (int64_t)s.spill_pairs.size();  // wave-per-pair items: table pairs with long lists, then delta pairs with long lists
   // 3 blocks per CU and one round of four pairs per lane at cfg3 (tools/kbench.py sweep); larger sets get more blocks, up to 8 per CU
   const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : (int)std::min<int64_t>(kMaxBlocks, std::max<int64_t>(768, n0 / 2900));
   gp.blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
