@@ -61,7 +61,9 @@ struct PinBuf {
     if (bytes <= cap) return hipSuccess;
     if (p) { (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
     size_t want = std::max(bytes + bytes / 4, (size_t)4096);
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);  // device-visible: kernels read / write it directly
+    // device-visible (kernels read / write it directly) and coherent: the host polls words the device writes (per-block
+    // partials, sequence words) without any runtime call in between
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, p, 0);
     if (e == hipSuccess) cap = want;
     return e;
@@ -173,7 +175,7 @@ struct TableDev {
 // second set of device buffers; evaluations go on meanwhile over the old tables + delta lists, and a later call swaps.
 struct TableRebuild {
   std::thread th;
-  std::atomic<int> state{0};   // 0 idle, 1 running, 2 ready, 3 failed
+  std::atomic<int> state{0};   // 0 idle, 4 taking the private copy (a slice per evaluation), 1 worker running, 2 ready, 3 failed
   ShortMate snap[2];
   PairTables pt;
   TableDev tab;
@@ -182,7 +184,8 @@ struct TableRebuild {
   uint64_t gen_snap[2] = {0, 0};
   hipStream_t stream = nullptr;
   double snapshot_us = 0, build_ms = 0;
-  int64_t start_eval = 0;      // the set's evaluation count when the worker was started
+  int64_t start_eval = 0;      // the set's evaluation count when the rebuild was decided
+  size_t next_w[2] = {0, 0};   // state 4: progress of the private copy (first window not copied yet)
 };
 
 struct PairedSet {
@@ -196,9 +199,25 @@ struct PairedSet {
   // delta since the last full table build: pairs whose record lists gained records of newly
   // activated windows. Their complete lists (device-table order: window id, position) travel with
   // every evaluation; a full rebuild folds them back in when they become too many.
-  struct DirtyPair { int32_t slot; std::vector<RecQuad> recs[2]; };
+  // (a pair's list: up to 4 records inline -- the usual case, no allocation per pair -- or all of them in `more`)
+  struct RecList {
+    uint32_t n = 0;
+    RecQuad in[4];
+    std::vector<RecQuad> more;
+    size_t size() const { return n; }
+    const RecQuad* data() const { return n <= 4 ? in : more.data(); }
+    const RecQuad& operator[](size_t k) const { return data()[k]; }
+    void insert(size_t at, const RecQuad& q) {
+      if (n < 4) { for (size_t k = n; k > at; k--) in[k] = in[k - 1]; in[at] = q; n++; return; }
+      if (n == 4) more.assign(in, in + 4);
+      more.insert(more.begin() + at, q);
+      n++;
+    }
+    void push_back(const RecQuad& q) { insert(n, q); }
+  };
+  struct DirtyPair { int32_t slot; RecList recs[2]; };
   std::vector<DirtyPair> dirty;
-  std::unordered_map<int32_t, int32_t> dirty_index;  // slot -> index in `dirty`
+  std::vector<int32_t> dirty_of_slot;                // slot -> index in `dirty`, -1: not on the delta list
   int64_t full_rebuilds = 0, delta_updates = 0;
   size_t dirty_marked = 0;   // delta pairs whose slots already carry the mark on the device
   // The delta lists live on the device at a fixed stride (4 records per mate and pair, longer lists in

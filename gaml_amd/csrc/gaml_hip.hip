@@ -442,6 +442,25 @@ int aln_upload_index(gaml_hip_ctx* c, const ShortMate& m, AlignDev& d) {
   return 0;
 }
 
+// the small-batch pipeline's fixed-capacity buffers, allocated together with the index upload (the cold first
+// evaluation), not in the annealing call that first brings a small batch
+int aln_small_reserve(gaml_hip_ctx* c, AlignSmall& S) {
+  HIP_TRY(c, S.counters.reserve(256));
+  HIP_TRY(c, S.spans.reserve((size_t)kFastSpans * sizeof(AlnSpan)));
+  HIP_TRY(c, S.cands.reserve((size_t)kFastCands * sizeof(AlnCand)));
+  HIP_TRY(c, S.hits.reserve((size_t)kFastCands * sizeof(AlnHit)));
+  HIP_TRY(c, S.hbuf.reserve((size_t)1 << 20));
+  if (!S.out_host.p) { HIP_TRY(c, S.out_host.reserve(64 + 64 + (size_t)kFastCands * sizeof(AlnHit))); memset(S.out_host.p, 0, 128); }
+  if (!S.in_dev) {
+    const bool direct = c->direct_write && c->knobs[8] == 0;
+    const size_t want = (size_t)1 << 18;
+    if (direct) HIP_TRY(c, hipExtMallocWithFlags(&S.in_dev, want, hipDeviceMallocFinegrained));
+    else { HIP_TRY(c, hipMalloc(&S.in_dev, want)); HIP_TRY(c, S.in_host.reserve(want)); }
+    S.in_cap = want; S.in_direct = direct;
+  }
+  return 0;
+}
+
 bool aln_gpu_capable(const gaml_hip_ctx* c, const ShortMate& m) {
   return !(c->device < 0 || c->knobs[5] == 1 || m.index_read_len < 16 || m.max_len > kAlnMaxRead || m.n_local() == 0 || m.bucket_hash.empty());
 }
@@ -545,6 +564,7 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
   }
   const double t0 = now_us();
   HIP_TRY(c, hipSetDevice(c->device));
+  if (!d.uploaded && small) { if (int e = aln_small_reserve(c, *small)) return e; }
   if (int e = aln_upload_index(c, m, d)) return e;
   AlignScratch& S = c->aln_scratch;
   AlnJob local;
@@ -697,8 +717,10 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
       sort_range(0, nw);
     }
   }
-  if (m.pool.capacity() < m.pool.size() + ok.size())  // one growth step for the whole batch -- geometric: an exact reserve per
-    m.pool.reserve(std::max(m.pool.size() + ok.size(), m.pool.capacity() + m.pool.capacity() / 2));  // small batch copied the 45 MB pool every time
+  // One growth step for the whole batch. Growing copies the pool (45 MB at cfg3: ~5 ms per mate), so the cold batch
+  // leaves room for twice its size -- untouched pages cost nothing -- and later growth is geometric.
+  if (m.pool.capacity() < m.pool.size() + ok.size())
+    m.pool.reserve(std::max(2 * (m.pool.size() + ok.size()), m.pool.capacity() + m.pool.capacity() / 2));
   if (ok.size() >= (size_t)200000) {
     // large batch (the cold first evaluation files ~2.8 M records): count the surviving records per window, then fill the
     // pool segment and the window headers on a few threads (windows are independent; same result as the loop below)
@@ -765,6 +787,7 @@ int align_pending_pair(gaml_hip_ctx* c, PairedSet& ps) {
       ShortMate& m = ps.mate[mt];
       if (m.pending.empty() || !aln_gpu_capable(c, m)) continue;
       HIP_TRY(c, hipSetDevice(c->device));
+      if (!ps.dev[mt].aln.uploaded) { if (int e = aln_small_reserve(c, c->aln_small[mt])) return e; }
       if (int e = aln_upload_index(c, m, ps.dev[mt].aln)) return e;
       aln_prepare(c, m, job[mt]);
       const int rc = aln_small_enqueue(c, m, ps.dev[mt].aln, c->aln_small[mt], job[mt], mt == 0 ? c->stream : c->aux_stream);  // side by side

@@ -111,7 +111,7 @@ void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
 // cold path: the device record tables follow the alignment-window cache
 // ---------------------------------------------------------------------------------------------------------
 // the pair's records as the device tables hold them (activated before the last full build)
-void paired_base_records(const PairedSet& s, int32_t slot, int mt, std::vector<RecQuad>& out) {
+void paired_base_records(const PairedSet& s, int32_t slot, int mt, PairedSet::RecList& out) {
   const int64_t n0s = s.pt.class_count[0];
   if (slot < n0s) {
     const uint64_t r = s.pt.rec8[mt][slot];
@@ -127,6 +127,7 @@ void paired_base_records(const PairedSet& s, int32_t slot, int mt, std::vector<R
 
 // windows activated since the tables were built: their pairs move to the delta list (host side)
 void paired_extend_delta(PairedSet& s) {
+  if (s.dirty_of_slot.size() != (size_t)s.mate[0].n_local()) s.dirty_of_slot.assign((size_t)s.mate[0].n_local(), -1);
   for (int mt = 0; mt < 2; mt++) {
     const ShortMate& m = s.mate[mt];
     for (int32_t w : m.activated_log) {
@@ -134,20 +135,21 @@ void paired_extend_delta(PairedSet& s) {
       for (int64_t k = win.first; k < win.first + win.count; k++) {
         const gaml_aligment& r = m.pool[k];
         const int32_t slot = s.pt.slot_of_read[r.read_id];
-        auto it = s.dirty_index.find(slot);
-        if (it == s.dirty_index.end()) {
-          it = s.dirty_index.emplace(slot, (int32_t)s.dirty.size()).first;
+        int32_t dj = s.dirty_of_slot[slot];
+        if (dj < 0) {
+          dj = s.dirty_of_slot[slot] = (int32_t)s.dirty.size();
           s.dirty.emplace_back();
           s.dirty.back().slot = slot;
           paired_base_records(s, slot, 0, s.dirty.back().recs[0]);
           paired_base_records(s, slot, 1, s.dirty.back().recs[1]);
         }
-        s.dirty_touched.push_back(it->second);
-        auto& lst = s.dirty[it->second].recs[mt];
+        s.dirty_touched.push_back(dj);
+        auto& lst = s.dirty[dj].recs[mt];
         RecQuad q{w, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
         // keep the device-table order: (window id, position)
-        auto pos = std::upper_bound(lst.begin(), lst.end(), q, [](const RecQuad& x, const RecQuad& y) { return x.wid != y.wid ? x.wid < y.wid : x.pos < y.pos; });
-        lst.insert(pos, q);
+        const RecQuad* b = lst.data();
+        const RecQuad* pos = std::upper_bound(b, b + lst.size(), q, [](const RecQuad& x, const RecQuad& y) { return x.wid != y.wid ? x.wid < y.wid : x.pos < y.pos; });
+        lst.insert((size_t)(pos - b), q);
       }
     }
   }
@@ -208,8 +210,8 @@ int paired_upload_tables(gaml_hip_ctx* c, PairedSet& s, const PairTables& pt, Ta
 }
 
 void paired_reset_delta(PairedSet& s) {
+  for (const auto& d : s.dirty) if ((size_t)d.slot < s.dirty_of_slot.size()) s.dirty_of_slot[d.slot] = -1;
   s.dirty.clear();
-  s.dirty_index.clear();
   s.dirty_marked = 0;
   s.dirty_touched.clear(); s.spill_of.clear(); s.spill_pairs.clear(); s.spill_changed = false;
 }
@@ -226,6 +228,8 @@ int paired_upload_pows(gaml_hip_ctx* c, PairedSet& s) {
   }
   return 0;
 }
+
+int paired_reserve_delta(gaml_hip_ctx* c, PairedSet& s);
 
 // full rebuild on the calling thread: new device order of the pairs, record tables built on the host and uploaded
 // a rebuild is also when windows that no scored path set has used since the previous rebuild leave the device tables
@@ -251,9 +255,11 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   if (int e = paired_upload_pows(c, s)) return e;
   if (int e = paired_upload_tables(c, s, s.pt, s.tab, st, nullptr)) return e;
   for (int mt = 0; mt < 2; mt++) s.dev[mt].uploaded_generation = s.mate[mt].active_generation;
+  if (int e = paired_reserve_delta(c, s)) return e;
   // room for the private copy a later rebuild off this thread takes (paired_snapshot_mate): allocated and touched here,
   // inside a call that takes tens of milliseconds anyway, so that the snapshot itself is a plain copy
   if (c->knobs[14] != 1 && s.rebuild.state.load(std::memory_order_acquire) == 0 && !s.rebuild.th.joinable()) {
+    if (!s.rebuild.stream) HIP_TRY(c, hipStreamCreateWithFlags(&s.rebuild.stream, hipStreamNonBlocking));  // (a new queue: ~ms)
     for (int mt = 0; mt < 2; mt++) {
       ShortMate& sn = s.rebuild.snap[mt];
       if (sn.lens.size() != s.mate[mt].lens.size()) sn.lens = s.mate[mt].lens;
@@ -267,38 +273,36 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
 
 // ---- the same off the caller's thread -----------------------------------------------------------------
 // what build_pair_tables reads of a mate, copied: lengths, the window headers, and the records of the ACTIVE windows
-// (compacted: `first` re-pointed into the copy). The live mate keeps growing meanwhile.
-void paired_snapshot_mate(const ShortMate& m, ShortMate& out) {
+// (compacted: `first` re-pointed into the copy). The live mate keeps growing meanwhile. The headers (with the active
+// flags) are copied when the rebuild is decided; the records -- immutable once a window is aligned -- follow in
+// slices of at most `budget` records per evaluation, so that no single call pays for the whole copy (24 MB at cfg3).
+void paired_snapshot_begin(const ShortMate& m, ShortMate& out) {
   out.n_global = m.n_global; out.lo = m.lo; out.hi = m.hi;
   if (out.lens.size() != m.lens.size()) out.lens = m.lens;  // read lengths never change
   out.wins = m.wins;
   out.pool.clear();
   if (out.pool.capacity() < (size_t)m.active_records) out.pool.reserve((size_t)m.active_records + (size_t)m.active_records / 4);
-  for (Window& w : out.wins) {
-    if (!w.active) continue;
-    const int64_t first = (int64_t)out.pool.size();
-    out.pool.insert(out.pool.end(), m.pool.begin() + w.first, m.pool.begin() + w.first + w.count);
-    w.first = first;
-  }
   out.active_records = m.active_records;
   out.active_generation = m.active_generation;
 }
-
-int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s) {
-  TableRebuild& rb = s.rebuild;
-  const double t0 = now_us();
-  if (rb.th.joinable()) rb.th.join();
-  paired_retire_windows(c, s);
-  for (int mt = 0; mt < 2; mt++) {
-    paired_snapshot_mate(s.mate[mt], rb.snap[mt]);
-    rb.gen_snap[mt] = s.mate[mt].active_generation;
-    rb.activated_after[mt].clear();
+// returns true when the copy is complete; *next_w = first window not copied yet
+bool paired_snapshot_slice(const ShortMate& m, ShortMate& out, size_t* next_w, int64_t budget) {
+  size_t w = *next_w;
+  for (; w < out.wins.size() && budget > 0; w++) {
+    Window& win = out.wins[w];
+    if (!win.active) continue;
+    const int64_t first = (int64_t)out.pool.size();
+    out.pool.insert(out.pool.end(), m.pool.begin() + win.first, m.pool.begin() + win.first + win.count);
+    win.first = first;
+    budget -= win.count;
   }
-  if (!rb.stream) HIP_TRY(c, hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
-  rb.err.clear();
-  rb.start_eval = s.eval_count;
+  *next_w = w;
+  return w >= out.wins.size();
+}
+
+void paired_launch_worker(gaml_hip_ctx* c, PairedSet& s) {
+  TableRebuild& rb = s.rebuild;
   rb.state.store(1, std::memory_order_release);
-  rb.snapshot_us = now_us() - t0;
   const int device = c->device;
   rb.th = std::thread([c, &s, &rb, device] {
     const double b0 = now_us();
@@ -312,13 +316,49 @@ int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s) {
     rb.build_ms = (now_us() - b0) * 1e-3;
     rb.state.store(rc ? 3 : 2, std::memory_order_release);
   });
+}
+
+// state 4: the private copy is being taken, a slice per evaluation; then the worker starts (state 1)
+int paired_continue_snapshot(gaml_hip_ctx* c, PairedSet& s, bool all_at_once) {
+  TableRebuild& rb = s.rebuild;
+  const double t0 = now_us();
+  const int64_t budget = all_at_once ? INT64_MAX / 4 : 96 * 1024;  // ~1.5 MB of records per evaluation
+  bool done = true;
+  for (int mt = 0; mt < 2; mt++) done = paired_snapshot_slice(s.mate[mt], rb.snap[mt], &rb.next_w[mt], budget) && done;
+  rb.snapshot_us += now_us() - t0;
+  if (done) paired_launch_worker(c, s);
   return 0;
+}
+
+int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s) {
+  TableRebuild& rb = s.rebuild;
+  const double t0 = now_us();
+  if (rb.th.joinable()) rb.th.join();
+  paired_retire_windows(c, s);
+  const double t1 = now_us();
+  for (int mt = 0; mt < 2; mt++) {
+    paired_snapshot_begin(s.mate[mt], rb.snap[mt]);
+    rb.gen_snap[mt] = s.mate[mt].active_generation;
+    rb.activated_after[mt].clear();
+    rb.next_w[mt] = 0;
+  }
+  const double t2 = now_us();
+  if (!rb.stream) HIP_TRY(c, hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
+  rb.err.clear();
+  rb.start_eval = s.eval_count;
+  rb.state.store(4, std::memory_order_release);
+  rb.snapshot_us = now_us() - t0;
+  const int rc = paired_continue_snapshot(c, s, false);
+  if (getenv("GAML_HIP_TRACE_HOST"))
+    fprintf(stderr, "rebuild start: retire %.0f us, headers %.0f, first slice of the records %.0f\n", t1 - t0, t2 - t1, now_us() - t2);
+  return rc;
 }
 
 // the worker is done (or: wait for it): the new tables take over; pairs touched by windows activated since the
 // snapshot go (back) onto the delta lists, now relative to the new tables
 int paired_finish_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   TableRebuild& rb = s.rebuild;
+  if (rb.state.load(std::memory_order_acquire) == 4) { if (int e = paired_continue_snapshot(c, s, true)) return e; }  // (the copy had not finished: take the rest now)
   if (rb.th.joinable()) rb.th.join();
   const int state = rb.state.load(std::memory_order_acquire);
   rb.state.store(0, std::memory_order_release);
@@ -342,17 +382,35 @@ int paired_finish_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   return 0;
 }
 
+// The delta store and its staging, allocated ONCE (with the first table build, inside a call that takes tens of
+// milliseconds anyway): device / pinned allocations cost 0.1-3 ms each, and an annealing run must not meet them in the
+// call that happens to activate a large window.
+int paired_reserve_delta(gaml_hip_ctx* c, PairedSet& s) {
+  if (s.delta_cap) return 0;
+  const int64_t np_all = s.mate[0].n_local();
+  s.delta_cap = (size_t)std::max<int64_t>(4096, np_all / 4) + 8192;  // twice the rebuild threshold: room for what arrives while a worker rebuilds
+  HIP_TRY(c, s.dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
+  HIP_TRY(c, s.dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
+  for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
+  // patches: a call rarely touches more than a few thousand pairs; the largest activations (a long node's twin) ~30 k
+  const size_t patch = std::min<size_t>(s.delta_cap, 32768) * sizeof(DeltaPatch);
+  HIP_TRY(c, s.dl_patch.reserve(patch));
+  for (int k = 0; k < kRing; k++) HIP_TRY(c, s.stage_delta.host[k].reserve(patch));
+  HIP_TRY(c, s.delta_dev.reserve((size_t)1 << 20));
+  // host lists: never moved while they fill (a DirtyPair is ~200 bytes; growing a vector of 60 k of them costs milliseconds)
+  s.dirty.reserve(s.delta_cap);
+  s.spill_of.reserve(s.delta_cap);
+  s.dirty_touched.reserve(65536);
+  return 0;
+}
+
 // delta pairs: a patch for the pairs whose lists changed since the last upload (new windows were activated)
 int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   if (s.dirty_touched.empty()) return 0;
   const size_t nd = s.dirty.size();
   const int64_t np_all = s.mate[0].n_local();
-  if (s.delta_cap == 0) {  // sized once for the largest delta the rebuild policy allows: the store is never reallocated
-    s.delta_cap = (size_t)std::max<int64_t>(4096, np_all / 4) + 8192;  // twice the rebuild threshold: room for what arrives while a worker rebuilds
-    HIP_TRY(c, s.dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
-    HIP_TRY(c, s.dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
-    for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
-  }
+  if (int e = paired_reserve_delta(c, s)) return e;
+  (void)np_all;
   if (nd > s.delta_cap) return fail(c, GAML_HIP_ESTATE, "delta store overflow (rebuild policy violated)");
   std::sort(s.dirty_touched.begin(), s.dirty_touched.end());
   s.dirty_touched.erase(std::unique(s.dirty_touched.begin(), s.dirty_touched.end()), s.dirty_touched.end());
@@ -407,7 +465,7 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
       for (size_t k = 0; k < ns; k++) {
         of[k] = at;
         const auto& l = s.dirty[s.spill_pairs[k]].recs[mt];
-        if (!l.empty()) memcpy(rc + at, l.data(), l.size() * sizeof(RecQuad));
+        if (l.size()) memcpy(rc + at, l.data(), l.size() * sizeof(RecQuad));
         at += (int32_t)l.size();
       }
       of[ns] = at;
@@ -426,6 +484,10 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
 
 // Everything the record tables need before a scoring launch; enqueued on `st`. One call per evaluation (or batch).
 int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
+  static const bool trace = getenv("GAML_HIP_TRACE_HOST") != nullptr;
+  const double ts0 = now_us();
+  double ts1 = ts0, ts2 = ts0;
+  size_t tr_new = 0, tr_touched = 0;
   TableRebuild& rb = s.rebuild;
   const int64_t np = s.mate[0].n_local();
   int rstate = rb.state.load(std::memory_order_acquire);
@@ -436,6 +498,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   // 833 k pairs, 768 evaluations take at least that long; if it is not done by then, this call waits for it.
   const int64_t swap_after = c->knobs[14] > 1 ? c->knobs[14] : 768;
   if (rstate != 0 && s.eval_count - rb.start_eval >= swap_after) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; rstate = 0; }
+  else if (rstate == 4) { if (int e = paired_continue_snapshot(c, s, false)) return e; rstate = 1; }  // the next slice of the private copy
   else if (rstate != 0) rstate = 1;  // (ready or not: not yet)
   const bool first_build = s.dev[0].pow_n == 0;
   bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
@@ -469,12 +532,18 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
       rstate = 1;
       s.quiet_calls = 0;
     }
+    ts1 = now_us();
     if (activated_now) {
       if (rstate == 1) for (int mt = 0; mt < 2; mt++) rb.activated_after[mt].insert(rb.activated_after[mt].end(), s.mate[mt].activated_log.begin(), s.mate[mt].activated_log.end());
       paired_extend_delta(s);
     }
+    tr_new = new_records; tr_touched = s.dirty_touched.size();
+    ts2 = now_us();
   }
   if (int e = paired_upload_delta(c, s, st)) return e;
+  if (trace && now_us() - ts0 > 300.0)
+    fprintf(stderr, "table sync %.0f us: policy %.0f, delta lists %.0f (%zu new records, %zu list entries touched, %zu delta pairs, %zu spill), upload %.0f; worker state %d\n",
+            now_us() - ts0, ts1 - ts0, ts2 - ts1, tr_new, tr_touched, s.dirty.size(), s.spill_pairs.size(), now_us() - ts2, rstate);
   const size_t nd = s.dirty.size();
   if (nd > s.dirty_marked) {  // marks stay on the device until the next full build: only new delta pairs need one
     const size_t fresh = nd - s.dirty_marked;

@@ -31,6 +31,8 @@ for knob6 in (0,):
           f"calls that aligned windows: {al.sum()} (median {np.median(per[al]):.0f} us, p90 {np.percentile(per[al], 90):.0f}); others median {np.median(per[~al]):.1f} p99 {np.percentile(per[~al], 99):.1f}")
     print("   aligning calls, median phases [pass1, tables_host, -, write, sync(delta), launch, bytes, wait]:", np.round(np.median(prof[al], axis=0), 1))
     print("   other calls,    median phases:", np.round(np.median(prof[~al], axis=0), 1))
+    order = np.argsort(-per)[:8]
+    for k in order: print(f"   slow call {k}: {per[k]:.0f} us, windows aligned {kinds[k]}, phases", np.round(prof[k], 1))
     print("   last 200 calls median", np.median(per[-200:]), ctx.debug_table_stats(rs))
     os.environ["GAML_HIP_TRACE_ALIGNER"] = "1"; print("   at the end:", end=" ", flush=True); ctx.aligner_stats(); del os.environ["GAML_HIP_TRACE_ALIGNER"]
     ctx.close()
