@@ -338,9 +338,10 @@ class Context:
         self._check(_lib.gaml_hip_pacbio_missing(self._h, rs, path, len(path), out, n))
         return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
 
-    def pacbio_ingest_sam(self, rs, path, sam_text: str) -> int:
+    def pacbio_ingest_sam(self, rs, path, sam_text) -> int:
+        """sam_text: the SAM file's text (str, or bytes as read from the file -- no copy then)"""
         path = np.ascontiguousarray(path, np.int32)
-        raw = sam_text.encode()
+        raw = sam_text.encode() if isinstance(sam_text, str) else bytes(sam_text) if not isinstance(sam_text, bytes) else sam_text
         filed = C.c_int64(0)
         self._check(_lib.gaml_hip_pacbio_ingest_sam(self._h, rs, path, len(path), raw, len(raw), C.byref(filed)))
         return filed.value

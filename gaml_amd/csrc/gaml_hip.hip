@@ -1264,18 +1264,26 @@ void pacbio_path_string(const gaml_hip_ctx* c, const Walk& path, std::string* se
 }
 // upload one batch of DP jobs, run the banded DP kernel, fetch the log probabilities
 int run_pacbio_dp(gaml_hip_ctx* c, DpDev& d, const std::string& both, const unsigned char* d_reads, const std::vector<DpJob>& jobs,
-                  const std::vector<uint32_t>& ops, int64_t scratch, double log_match, double log_mismatch, double* logp,
+                  const std::vector<std::pair<const uint32_t*, size_t>>& ops, int64_t scratch, double log_match, double log_mismatch, double* logp,
                   float* kernel_ms, int64_t* cells_out, int32_t* dbg_lo = nullptr, int32_t* dbg_hi = nullptr, int32_t dbg_rows = 0) {
   hipStream_t st = c->stream;
   const size_t nj = jobs.size();
   HIP_TRY(c, d.path.reserve(both.size()));
   HIP_TRY(c, d.jobs.reserve(nj * sizeof(DpJob)));
-  HIP_TRY(c, d.ops.reserve(std::max<size_t>(1, ops.size()) * sizeof(uint32_t)));
+  size_t n_ops = 0;
+  for (const auto& part : ops) n_ops += part.second;
+  HIP_TRY(c, d.ops.reserve(std::max<size_t>(1, n_ops) * sizeof(uint32_t)));
   HIP_TRY(c, d.scratch.reserve(std::max<size_t>(1, (size_t)scratch) * sizeof(double)));
   HIP_TRY(c, d.out.reserve(nj * (sizeof(double) + sizeof(long long))));
   HIP_TRY(c, hipMemcpy(d.path.p, both.data(), both.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(d.jobs.p, jobs.data(), nj * sizeof(DpJob), hipMemcpyHostToDevice));
-  if (!ops.empty()) HIP_TRY(c, hipMemcpy(d.ops.p, ops.data(), ops.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  {
+    size_t at = 0;
+    for (const auto& part : ops) {
+      if (part.second) HIP_TRY(c, hipMemcpy(d.ops.as<uint32_t>() + at, part.first, part.second * sizeof(uint32_t), hipMemcpyHostToDevice));
+      at += part.second;
+    }
+  }
   if (dbg_rows > 0) HIP_TRY(c, d.dbg.reserve(2 * (size_t)dbg_rows * sizeof(int32_t)));
   DpArgs a;
   a.path = d.path.as<unsigned char>(); a.path_len = (int32_t)both.size();
@@ -1290,7 +1298,7 @@ int run_pacbio_dp(gaml_hip_ctx* c, DpDev& d, const std::string& both, const unsi
   HIP_TRY(c, hipEventCreate(&ev0));
   HIP_TRY(c, hipEventCreate(&ev1));
   HIP_TRY(c, hipEventRecord(ev0, st));
-  constexpr int kLanes = 16;  // lanes per alignment: 14 columns per chunk cover a typical row in one step
+  constexpr int kLanes = 16;  // lanes per alignment (one DPP row): 15 columns per chunk cover a typical row in one step
   const unsigned grid = (unsigned)(((int64_t)nj * kLanes + 255) / 256);
   hipLaunchKernelGGL(pacbio_dp_kernel<kLanes>, dim3(grid), dim3(256), 0, st, a);
   HIP_TRY(c, hipGetLastError());
@@ -1366,29 +1374,35 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path
   pacbio_path_string(c, path, &seq, begins, ends);
   if (2 * (int64_t)seq.size() + 1 > INT32_MAX) return fail(c, GAML_HIP_EINVAL, "path too long");
   const int32_t seq_len = (int32_t)seq.size();
-  std::string both = seq;  // path + separator + reverse complement (graph.cc:2687-2688)
-  both += '\n';
-  for (int32_t i = seq_len - 1; i >= 0; i--) {
-    char ch = seq[i];
-    both += ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;  // ReverseBase graph.h:58-64
+  std::string both;  // path + separator + reverse complement (graph.cc:2687-2688)
+  both.resize(2 * (size_t)seq_len + 1);
+  {
+    char comp[256];  // ReverseBase graph.h:58-64
+    for (int k = 0; k < 256; k++) comp[k] = (char)k;
+    comp[(unsigned char)'A'] = 'T'; comp[(unsigned char)'C'] = 'G'; comp[(unsigned char)'G'] = 'C'; comp[(unsigned char)'T'] = 'A';
+    char* out = &both[0];
+    memcpy(out, seq.data(), (size_t)seq_len);
+    out[seq_len] = '\n';
+    char* rc = out + seq_len + 1;
+    for (int32_t i = 0; i < seq_len; i++) rc[i] = comp[(unsigned char)seq[seq_len - 1 - i]];
   }
   // sub-walks this call may file under (graph.cc:2724-2743): new ones get an (empty) cache entry,
   // ones cached before are left alone
-  std::unordered_map<Walk, int32_t, WalkHasher> starts;
-  std::unordered_map<Walk, int32_t, WalkHasher> fresh;  // -> cache id
+  struct SubWalk { int32_t start; int32_t fresh_id; };  // last index it starts at in this path; cache id when this call created the entry, else -1
+  std::unordered_map<Walk, SubWalk, WalkHasher> subs;
   {
     Walk sub;
     for (int32_t i = 0; i < n; i++) {
       sub.clear();
       for (int32_t j = i; j < n; j++) {
         sub.push_back(path[j]);
-        if (!s.walk_id.count(sub)) {
-          const int32_t id = (int32_t)s.recs.size();
-          s.walk_id.emplace(sub, id);
-          s.recs.emplace_back();
-          fresh.emplace(sub, id);
+        auto mine = subs.try_emplace(sub, SubWalk{i, -1});
+        if (mine.second) {  // first time in this call: new to the cache?
+          auto ins = s.walk_id.try_emplace(sub, (int32_t)s.recs.size());
+          if (ins.second) { s.recs.emplace_back(); mine.first->second.fresh_id = ins.first->second; }
+        } else {
+          mine.first->second.start = i;
         }
-        starts[sub] = i;
         if ((ends[j] - begins[i]) - (ends[i] - begins[i]) > s.max_len) break;
       }
     }
@@ -1405,32 +1419,39 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path
     int64_t records = 0, rows = 0;
     int err = 0;
     std::string msg;
+    double us[4] = {0, 0, 0, 0};  // trace: record fields + CIGAR, name lookup + filing rule, DP operations, whole chunk
   };
   const int32_t both_len = (int32_t)both.size();
+  static const bool trace_host = getenv("GAML_HIP_TRACE_HOST") != nullptr;
   auto parse_chunk = [&](const char* cb, const char* ce, Chunk& out) {
     SamRecord rec;
+    const double c_begin = now_us();
     for (const char* p = cb; p < ce;) {
       const char* e = (const char*)memchr(p, '\n', (size_t)(ce - p));
       const char* le = e ? e : ce;
       if (le > p && *p != '@') {
+        const double q0 = trace_host ? now_us() : 0;
         if (!parse_sam_record(p, le, both_len, rec)) { out.err = GAML_HIP_EINVAL; out.msg = "SAM line with fewer than 10 columns"; return; }
+        if (trace_host) out.us[0] += now_us() - q0;
         out.records++;
         auto id = s.name_id.find(rec.name);
         if (id == s.name_id.end()) { out.err = GAML_HIP_EINVAL; out.msg = "SAM record names a read that is not in the read set: " + rec.name; return; }  // assert graph.cc:2751
         const int32_t ib = (int32_t)(std::lower_bound(ends.begin(), ends.end(), std::max(0, rec.tstart - 5)) - ends.begin());
         const int32_t ie = (int32_t)(std::lower_bound(ends.begin(), ends.end(), std::min(rec.tstart + rec.len + 5, seq_len)) - ends.begin());
         if (ib < n && ie < n && ie >= ib && id->second >= s.lo && id->second < s.hi) {
-          Walk sub(path.begin() + ib, path.begin() + ie + 1);
-          auto st = starts.find(sub);
-          auto fr = fresh.find(sub);
-          if (st != starts.end() && st->second == ib && fr != fresh.end()) {
+          thread_local Walk sub;
+          sub.assign(path.begin() + ib, path.begin() + ie + 1);
+          auto sw = subs.find(sub);
+          if (sw != subs.end() && sw->second.start == ib && sw->second.fresh_id >= 0) {
             const int32_t local = (int32_t)(id->second - s.lo);
             const int32_t pos_begin = ib > 0 ? ends[ib - 1] : 0;
-            out.filed.push_back(Filed{fr->second, rec.tstart - pos_begin, rec.tend - pos_begin, local});
+            out.filed.push_back(Filed{sw->second.fresh_id, rec.tstart - pos_begin, rec.tend - pos_begin, local});
             DpShape shape;
             DpJob j;
             j.ops_off = (int64_t)out.ops.size();  // chunk-relative until the chunks are joined
+            const double q1 = trace_host ? now_us() : 0;
             pacbio_dp_ops(rec.cigar, out.ops, shape);
+            if (trace_host) out.us[2] += now_us() - q1;
             j.read_off = s.base_off[local];
             j.read_len = (int32_t)(s.base_off[local + 1] - s.base_off[local]);
             j.scratch_off = 0;
@@ -1445,8 +1466,10 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path
       if (!e) break;
       p = e + 1;
     }
+    out.us[3] = now_us() - c_begin;
   };
-  const int n_chunks = sam_len < (1 << 20) ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+  const double t_parse0 = now_us();
+  const int n_chunks = sam_len < (1 << 20) ? 1 : (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
   std::vector<Chunk> chunks(n_chunks);
   {
     std::vector<const char*> cut(n_chunks + 1, sam + sam_len);
@@ -1462,24 +1485,32 @@ int gaml_hip_pacbio_ingest_sam(gaml_hip_ctx* c, int readset, const int32_t* path
     parse_chunk(cut[0], cut[1], chunks[0]);
     for (auto& th : pool) th.join();
   }
+  const double t_join0 = now_us();
   std::vector<Filed> filed;
   std::vector<DpJob> jobs;
-  std::vector<uint32_t> ops;
-  int64_t scratch = 0, records = 0, cells = 0, rows = 0;
+  std::vector<std::pair<const uint32_t*, size_t>> ops;  // the chunks' operation lists go to the device one after the other, unjoined
+  int64_t scratch = 0, records = 0, cells = 0, rows = 0, ops_total = 0;
   for (Chunk& ch : chunks) {
     if (ch.err) return fail(c, ch.err, ch.msg);
     records += ch.records; rows += ch.rows;
-    const int64_t ops_base = (int64_t)ops.size();
-    ops.insert(ops.end(), ch.ops.begin(), ch.ops.end());
+    const int64_t ops_base = ops_total;
+    ops.emplace_back(ch.ops.data(), ch.ops.size());
+    ops_total += (int64_t)ch.ops.size();
     filed.insert(filed.end(), ch.filed.begin(), ch.filed.end());
     for (DpJob j : ch.jobs) {
       j.ops_off += ops_base;
       j.scratch_off = scratch;
-      scratch += 2 * (int64_t)j.max_width;
+      scratch += 2 * dp_row_stride(j.max_width);
       jobs.push_back(j);
     }
   }
   const double t1 = now_us();
+  if (trace_host) {
+    double f = 0, o = 0, w = 0;
+    for (Chunk& ch : chunks) { f += ch.us[0]; o += ch.us[2]; w = std::max(w, ch.us[3]); }
+    fprintf(stderr, "pacbio ingest: %d chunks; path string + sub-walks %.1f ms, parse (slowest chunk) %.1f ms [all chunks: record fields + CIGAR %.1f, DP operations %.1f], join %.1f ms\n",
+            n_chunks, (t_parse0 - t0) * 1e-3, w * 1e-3, f * 1e-3, o * 1e-3, (t1 - t_join0) * 1e-3);
+  }
   float kernel_ms = 0;
   std::vector<double> logp(jobs.size());
   if (!jobs.empty()) {
@@ -1544,8 +1575,9 @@ int gaml_hip_debug_sam_logprob(gaml_hip_ctx* c, const char* target, int32_t targ
   HIP_TRY(c, d_read.reserve(std::max(1, read_len)));
   HIP_TRY(c, hipMemcpy(d_read.p, read, read_len, hipMemcpyHostToDevice));
   float ms = 0;
-  int e = run_pacbio_dp(c, dev, std::string(target, target + target_len), d_read.as<unsigned char>(), std::vector<DpJob>(1, j), ops,
-                        2 * (int64_t)shape.max_width, std::log(1.0 - 4 * mismatch_prob), std::log(mismatch_prob), logprob_out, &ms, nullptr,
+  int e = run_pacbio_dp(c, dev, std::string(target, target + target_len), d_read.as<unsigned char>(), std::vector<DpJob>(1, j),
+                        std::vector<std::pair<const uint32_t*, size_t>>(1, std::make_pair((const uint32_t*)ops.data(), ops.size())),
+                        2 * dp_row_stride(shape.max_width), std::log(1.0 - 4 * mismatch_prob), std::log(mismatch_prob), logprob_out, &ms, nullptr,
                         band_lo, band_hi, want_band ? n_rows : 0);
   dev.release();
   d_read.release();

@@ -22,6 +22,7 @@ bases, offs = g.packed()
 rb = np.frombuffer("".join(ps.reads).encode(), np.uint8)
 ro = np.zeros(len(ps.reads) + 1, np.int64)
 ro[1:] = np.cumsum([len(r) for r in ps.reads])
+sam_bytes = ps.sam.encode()  # what reading BLASR's output file gives
 ctx = api.Context()
 ctx.set_graph(bases, offs)
 rs = ctx.add_pacbio_reads(api.single_cfg(min_prob_per_base=-1.0, mismatch_prob=0.15), rb, ro, ps.names)
@@ -29,7 +30,7 @@ for rep in range(2):  # second round: fresh context state is not needed, re-inge
     if rep:
         rs = ctx.add_pacbio_reads(api.single_cfg(min_prob_per_base=-1.0, mismatch_prob=0.15), rb, ro, ps.names)
     t = time.time()
-    filed = ctx.pacbio_ingest_sam(rs, walk, ps.sam)
+    filed = ctx.pacbio_ingest_sam(rs, walk, sam_bytes)
     dt = time.time() - t
     st = ctx.pacbio_dp_stats(rs)
     print(f"gpu ingest #{rep}: {dt * 1e3:.1f} ms wall, filed {filed}; kernel {st['kernel_ms']:.2f} ms, host prepare {st['host_prepare_ms']:.1f} ms, "
