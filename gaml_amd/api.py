@@ -160,9 +160,10 @@ def _load():
     L.gaml_hip_eval_coverage_finish_async.argtypes = [vp, C.c_int32, vp, C.c_int32, C.c_int32, vp]
     L.gaml_hip_eval_pacbio_pending.argtypes = [vp]
     L.gaml_hip_eval_pacbio_pending.restype = C.c_int32
-    L.gaml_hip_eval_pacbio_events.argtypes = [vp, C.c_int32, vp, C.c_int64]
-    L.gaml_hip_eval_pacbio_events.restype = C.c_int64
-    L.gaml_hip_eval_pacbio_finish_async.argtypes = [vp, C.c_int32, _i32p, C.c_int64, C.c_int32, vp]
+    L.gaml_hip_eval_pacbio_intervals.argtypes = [vp, C.c_int32]
+    L.gaml_hip_eval_pacbio_intervals.restype = C.c_int64
+    L.gaml_hip_eval_pacbio_export_async.argtypes = [vp, C.c_int32, vp, C.c_int64, vp]
+    L.gaml_hip_eval_pacbio_finish_async.argtypes = [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp]
     L.gaml_hip_num_readsets.argtypes = [vp]
     L.gaml_hip_readset_kind.argtypes = [vp, C.c_int]
     L.gaml_hip_readset_reads.argtypes = [vp, C.c_int]
@@ -561,20 +562,16 @@ class Context:
     def eval_pacbio_pending(self) -> int:
         return self._check(_lib.gaml_hip_eval_pacbio_pending(self._h))
 
-    def eval_pacbio_events(self, i: int) -> np.ndarray:
-        n = self._check(int(_lib.gaml_hip_eval_pacbio_events(self._h, i, None, 0)))
-        out = np.zeros(max(1, n), np.int32)
-        self._check(int(_lib.gaml_hip_eval_pacbio_events(self._h, i, out.ctypes.data, n)))
-        return out[:n]
+    def eval_pacbio_intervals(self, i: int) -> int:
+        """How many alignment intervals (16 bytes each, device memory) this rank's reads contribute to the sweep."""
+        return self._check(int(_lib.gaml_hip_eval_pacbio_intervals(self._h, i)))
 
-    def eval_pacbio_finish_async(self, i: int, events: np.ndarray, contribute: bool, stream_ptr: int = 0):
-        ev = np.ascontiguousarray(events, np.int32)
-        if ev.size == 0:
-            ev = np.zeros(3, np.int32)
-            n = 0
-        else:
-            n = ev.size
-        self._check(_lib.gaml_hip_eval_pacbio_finish_async(self._h, i, ev, n, 1 if contribute else 0, C.c_void_p(stream_ptr)))
+    def eval_pacbio_export_async(self, i: int, dst_ptr: int, cap: int, stream_ptr: int = 0):
+        self._check(_lib.gaml_hip_eval_pacbio_export_async(self._h, i, C.c_void_p(dst_ptr), cap, C.c_void_p(stream_ptr)))
+
+    def eval_pacbio_finish_async(self, i: int, intervals_ptr: int, n_intervals: int, contribute: bool, stream_ptr: int = 0):
+        """intervals_ptr: all ranks' gathered intervals in DEVICE memory (int32 {contig, begin, end, 0} each)."""
+        self._check(_lib.gaml_hip_eval_pacbio_finish_async(self._h, i, C.c_void_p(intervals_ptr), n_intervals, 1 if contribute else 0, C.c_void_p(stream_ptr)))
 
     def eval_coverage_finish_async(self, i: int, maps_ptr: int, n_maps: int, contribute: bool, stream_ptr: int = 0):
         self._check(_lib.gaml_hip_eval_coverage_finish_async(self._h, i, C.c_void_p(maps_ptr), n_maps, 1 if contribute else 0,

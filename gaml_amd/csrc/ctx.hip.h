@@ -28,6 +28,7 @@
 #include "host_model.h"
 #include "kernels.hip.h"
 #include "pacbio_dp.hip.h"
+#include "pacbio_sweep.hip.h"
 #include "internal.h"
 
 
@@ -281,6 +282,24 @@ struct DpDev {  // device buffers of the PacBio banded DP
   void release() { path.release(); jobs.release(); ops.release(); scratch.release(); out.release(); dbg.release(); }
 };
 
+// coverage sweep of a PacBio set with a penalty (pacbio_sweep.hip.h)
+struct PbSweepDev {
+  // follows the record cache: per sub-walk the intervals {position, position_end} of its records that clear GetMinReadProb
+  DevBuf iv_off, iv;
+  std::vector<int32_t> iv_off_host;
+  uint64_t generation = ~0ull;
+  // per evaluation: contig lengths | node intervals | occurrences, staged as one block; then the evaluation's interval
+  // list: node intervals first, the records' after them (this rank's; all ranks' after the exchange)
+  DevBuf in, all;
+  DevBuf key_begin, key_end, pos, key_begin_s, key_end_s, pos_s, end_max, tmp, bad;
+  Staging stage;
+  void release() {
+    iv_off.release(); iv.release(); in.release(); all.release(); key_begin.release(); key_end.release(); pos.release();
+    key_begin_s.release(); key_end_s.release(); pos_s.release(); end_max.release(); tmp.release(); bad.release();
+    for (int k = 0; k < kRing; k++) { stage.host[k].release(); if (stage.done[k]) (void)hipEventDestroy(stage.done[k]); stage.done[k] = nullptr; stage.armed[k] = false; }
+  }
+};
+
 struct PacbioSet {
   gaml_single_cfg cfg;
   int64_t n_global = 0, lo = 0, hi = 0;
@@ -295,6 +314,7 @@ struct PacbioSet {
   Reducer red;
   int64_t last_bad_bases = 0;
   Staging stage;
+  PbSweepDev sweep;
   // cache-miss side (SAM ingestion): bases of this shard's reads and the name -> global id map
   bool have_reads = false;
   std::string bases;
@@ -375,13 +395,12 @@ struct gaml_hip_ctx {
   bool defer_cov = false;
   struct PendingCov { int paired_idx; CovArgs args; double* out4; };
   std::vector<PendingCov> pending_cov;
-  // same for a PacBio set: the interval events of the other ranks' reads are missing (host lists)
+  // same for a PacBio set: the alignment intervals of the other ranks' reads are missing (device lists: PbSweepDev::all)
   struct PendingPacbio {
     int pacbio_idx;
     double* out4;
-    std::vector<int32_t> tl;                                            // per path
-    std::vector<std::vector<std::pair<int32_t, int32_t>>> node_events;  // per path: the events every rank has
-    std::vector<int32_t> own;                                           // this rank's record events: (path, position, value) triples
+    int32_t n_paths;
+    int64_t n_node, n_own;  // node intervals (every rank has them); this rank's record intervals behind them
   };
   std::vector<PendingPacbio> pending_pb;
 };

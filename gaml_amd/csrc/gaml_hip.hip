@@ -263,22 +263,110 @@ int launch_single(gaml_hip_ctx* c, SingleSet& s, const std::vector<Walk>& paths,
 }
 
 // ---------------------------------------------------------------------------------------
-// integer event sweep of one path (graph.cc:3226-3250): sorted events, multiset of open intervals
-int64_t pacbio_sweep(std::vector<std::pair<int32_t, int32_t>>& events, int32_t tl, double step) {
-  int64_t bad = 0;
-  std::sort(events.begin(), events.end());
-  std::multiset<int32_t> open;
-  for (size_t j = 0; j < events.size(); j++) {
-    if (events[j].second == 1) open.insert(events[j].first);
-    else { auto it = open.find(events[j].first + events[j].second); if (it != open.end()) open.erase(it); }
-    int32_t good = tl - 250;
-    if (!open.empty()) good = (int32_t)(*open.begin() + step);
-    if (j + 1 < events.size()) good = std::min(events[j + 1].first, good);
-    good = std::min(good, tl - 250);
-    int32_t from = std::max(2500, events[j].first);
-    if (good > from) bad += good - from;
+// coverage sweep of a PacBio set on the device (graph.cc:3198-3250; pacbio_sweep.hip.h)
+// ---------------------------------------------------------------------------------------
+// the walk-major interval arrays follow the record cache
+int pacbio_sweep_sync(gaml_hip_ctx* c, PacbioSet& s, hipStream_t st) {
+  PbSweepDev& d = s.sweep;
+  if (d.generation == s.generation) return 0;
+  std::vector<int32_t>& off = d.iv_off_host;
+  off.assign(s.recs.size() + 1, 0);
+  std::vector<int32_t> iv;
+  for (size_t w = 0; w < s.recs.size(); w++) {
+    for (const auto& r : s.recs[w]) {
+      // only records that clear GetMinReadProb (graph.h:478-481) count (graph.cc:3216)
+      const double min_lp = s.log_mismatch * (s.lens[r.read_id] * 0.25) + s.log_match * (s.lens[r.read_id] * 0.75);
+      if (r.logprob < min_lp) continue;
+      iv.push_back(r.position); iv.push_back(r.position_end);
+    }
+    off[w + 1] = (int32_t)(iv.size() / 2);
   }
-  return bad;
+  HIP_TRY(c, hipStreamSynchronize(st));  // an earlier evaluation may still read the old arrays
+  HIP_TRY(c, d.iv_off.reserve(off.size() * sizeof(int32_t)));
+  HIP_TRY(c, d.iv.reserve(std::max<size_t>(1, iv.size()) * sizeof(int32_t)));
+  HIP_TRY(c, hipMemcpy(d.iv_off.p, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!iv.empty()) HIP_TRY(c, hipMemcpy(d.iv.p, iv.data(), iv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  d.generation = s.generation;
+  return 0;
+}
+
+// this evaluation's intervals into PbSweepDev::all: the node intervals (`node`, computed on the host: every rank has
+// them), then the alignment intervals of this rank's records, expanded on the device from the occurrence list
+int pacbio_sweep_prepare(gaml_hip_ctx* c, PacbioSet& s, const std::vector<int32_t>& tl, const std::vector<int32_t>& node /* 4 per interval */,
+                         std::vector<PbOcc>& occ, hipStream_t st, int64_t* n_own_out) {
+  PbSweepDev& d = s.sweep;
+  if (int e = pacbio_sweep_sync(c, s, st)) return e;
+  int64_t n_own = 0;
+  for (PbOcc& o : occ) { o.out = (int32_t)n_own; n_own += d.iv_off_host[o.walk + 1] - d.iv_off_host[o.walk]; }
+  const int64_t n_node = (int64_t)node.size() / 4;
+  if (n_node + n_own > (int64_t)1 << 28) return fail(c, GAML_HIP_EINVAL, "too many alignment intervals in one evaluation");
+  for (PbOcc& o : occ) o.out += (int32_t)n_node;
+  const size_t tl_bytes = align16(tl.size() * sizeof(int32_t)), node_bytes = node.size() * sizeof(int32_t), occ_bytes = occ.size() * sizeof(PbOcc);
+  const size_t bytes = std::max<size_t>(16, tl_bytes + node_bytes + occ_bytes);
+  void* host = nullptr;
+  int slot = stage_acquire(c, d.stage, bytes, &host);
+  if (slot < 0) return slot;
+  memcpy(host, tl.data(), tl.size() * sizeof(int32_t));
+  if (node_bytes) memcpy((char*)host + tl_bytes, node.data(), node_bytes);
+  if (occ_bytes) memcpy((char*)host + tl_bytes + node_bytes, occ.data(), occ_bytes);
+  const size_t all_bytes = (size_t)std::max<int64_t>(1, n_node + n_own) * sizeof(int4);
+  if (bytes > d.in.cap || all_bytes > d.all.cap) {
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, d.in.reserve(bytes));
+    HIP_TRY(c, d.all.reserve(all_bytes));
+  }
+  if (int e = stage_upload(c, d.stage, slot, d.in.p, bytes, st)) return e;
+  if (int e = stage_release(c, d.stage, slot, st)) return e;
+  if (node_bytes) HIP_TRY(c, hipMemcpyAsync(d.all.p, (const char*)d.in.p + tl_bytes, node_bytes, hipMemcpyDeviceToDevice, st));
+  if (!occ.empty() && n_own > 0) {
+    const unsigned grid = (unsigned)std::min<size_t>((occ.size() + 3) / 4, 1024);
+    hipLaunchKernelGGL(pacbio_intervals_kernel, dim3(grid), dim3(256), 0, st, (const PbOcc*)((const char*)d.in.p + tl_bytes + node_bytes), (int)occ.size(),
+                       d.iv_off.as<int>(), d.iv.as<int2>(), d.all.as<int4>());
+    HIP_TRY(c, hipGetLastError());
+  }
+  *n_own_out = n_own;
+  return 0;
+}
+
+// sort + running maximum + sweep over the n intervals in PbSweepDev::all; bad_bases (times `scale`) into out4[2]
+int pacbio_sweep_run(gaml_hip_ctx* c, PacbioSet& s, int64_t n, int32_t n_paths, hipStream_t st, double* out4, double scale) {
+  PbSweepDev& d = s.sweep;
+  typedef unsigned long long u64;
+  const size_t n1 = (size_t)std::max<int64_t>(1, n);
+  int path_bits = 1;
+  while ((1 << path_bits) < n_paths && path_bits < 30) path_bits++;
+  const int end_bit = 32 + path_bits;
+  size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
+  HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, (const u64*)nullptr, (u64*)nullptr, (const u64*)nullptr, (u64*)nullptr, (int)n1, 0, end_bit, st));
+  HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp2, (const u64*)nullptr, (u64*)nullptr, (int)(2 * n1), 0, end_bit, st));
+  HIP_TRY(c, hipcub::DeviceScan::InclusiveScan(nullptr, tmp3, (const u64*)nullptr, (u64*)nullptr, hipcub::Max(), (int)n1, st));
+  const size_t tmp_bytes = std::max(std::max(tmp1, tmp2), std::max<size_t>(tmp3, 16));
+  if (n1 * sizeof(u64) > d.key_begin.cap || tmp_bytes > d.tmp.cap || !d.bad.p) {
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (DevBuf* b : {&d.key_begin, &d.key_end, &d.key_begin_s, &d.key_end_s, &d.end_max}) HIP_TRY(c, b->reserve(n1 * sizeof(u64)));
+    for (DevBuf* b : {&d.pos, &d.pos_s}) HIP_TRY(c, b->reserve(2 * n1 * sizeof(u64)));
+    HIP_TRY(c, d.tmp.reserve(tmp_bytes));
+    HIP_TRY(c, d.bad.reserve(sizeof(u64)));
+  }
+  HIP_TRY(c, hipMemsetAsync(d.bad.p, 0, sizeof(u64), st));
+  if (n > 0) {
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(pacbio_sweep_keys_kernel, dim3(grid), dim3(256), 0, st, d.all.as<int4>(), (int)n, d.key_begin.as<u64>(), d.key_end.as<u64>(), d.pos.as<u64>());
+    HIP_TRY(c, hipGetLastError());
+    size_t t = d.tmp.cap;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(d.tmp.p, t, d.key_begin.as<u64>(), d.key_begin_s.as<u64>(), d.key_end.as<u64>(), d.key_end_s.as<u64>(), (int)n, 0, end_bit, st));
+    t = d.tmp.cap;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(d.tmp.p, t, d.pos.as<u64>(), d.pos_s.as<u64>(), (int)(2 * n), 0, end_bit, st));
+    t = d.tmp.cap;
+    HIP_TRY(c, hipcub::DeviceScan::InclusiveScan(d.tmp.p, t, d.key_end_s.as<u64>(), d.end_max.as<u64>(), hipcub::Max(), (int)n, st));
+    const unsigned grid2 = (unsigned)std::min<int64_t>((2 * n + 255) / 256, 1024);
+    hipLaunchKernelGGL(pacbio_sweep_kernel, dim3(grid2), dim3(256), 0, st, d.pos_s.as<u64>(), (int)(2 * n), d.key_begin_s.as<u64>(), d.end_max.as<u64>(), (int)n,
+                       d.in.as<int>(), s.cfg.step, d.bad.as<u64>());
+    HIP_TRY(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(store_bad_bases_kernel, dim3(1), dim3(64), 0, st, d.bad.as<u64>(), out4, scale);
+  HIP_TRY(c, hipGetLastError());
+  return 0;
 }
 
 // PacBio read set (CalcScoreForPacbio graph.cc:3171-3261)
@@ -293,10 +381,10 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
   }
   // sub-walk occurrence counts + coverage events, per path (graph.cc:3183-3251)
   std::vector<int32_t> count(s.recs.size(), 0);
-  int64_t bad_bases = 0;
   const bool cov = s.cfg.penalty_constant > 0;
-  const bool defer = cov && c->defer_cov;  // sharded: the sweep waits for the other ranks' events
-  gaml_hip_ctx::PendingPacbio pend;
+  const bool defer = cov && c->defer_cov;  // sharded: the sweep waits for the other ranks' intervals
+  std::vector<int32_t> sweep_tl, sweep_node;  // contig lengths; node intervals {contig, begin, end, 0}
+  std::vector<PbOcc> sweep_occ;
   int32_t path_no = -1;
   for (Walk path : paths_in) {
     path_no++;
@@ -309,17 +397,15 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
       len += path[i] < 0 ? -path[i] : c->g.len(path[i]);
       ends[i] = len;
     }
-    const int32_t tl = len;
-    std::vector<std::pair<int32_t, int32_t>> events;
-    size_t n_node_events = 0;
     if (cov) {
-      events.emplace_back(-1000, 1); events.emplace_back(2000, -3000);  // graph.cc:3198-3199
+      sweep_tl.push_back(len);
+      auto interval = [&](int32_t b, int32_t e) { sweep_node.push_back(path_no); sweep_node.push_back(b); sweep_node.push_back(e); sweep_node.push_back(0); };
+      interval(-1000, 2000);  // the events (-1000, 1), (2000, -3000) of graph.cc:3198-3199
       int32_t pp = 0;
       for (int32_t e : path) {
-        if (e >= 0) { int32_t cl = c->g.len(e); events.emplace_back(pp, 1); events.emplace_back(pp + cl, -cl); pp += cl; }
+        if (e >= 0) { const int32_t cl = c->g.len(e); if (cl > 0) interval(pp, pp + cl); pp += cl; }  // graph.cc:3202-3210
         else pp += -e;
       }
-      n_node_events = events.size();
     }
     Walk sub;
     for (int32_t i = 0; i < m; i++) {  // graph.cc:2438-2454
@@ -330,30 +416,12 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
         if (it == s.walk_id.end()) s.misses++;  // the reference would run BLASR here (out of scope)
         else {
           count[it->second]++;
-          if (cov) {
-            // host-side interval events of this occurrence (graph.cc:3214-3222); only records that
-            // clear GetMinReadProb (graph.h:478-481) count
-            for (const auto& r : s.recs[it->second]) {
-              double min_lp = s.log_mismatch * (s.lens[r.read_id] * 0.25) + s.log_match * (s.lens[r.read_id] * 0.75);
-              if (r.logprob < min_lp) continue;
-              events.emplace_back(begins[i] + r.position, 1);
-              events.emplace_back(begins[i] + r.position_end, r.position - r.position_end);
-            }
-          }
+          if (cov) sweep_occ.push_back(PbOcc{it->second, begins[i], path_no, 0});  // its records' intervals (graph.cc:3214-3222)
         }
         if ((ends[j] - begins[i]) - (ends[i] - begins[i]) > s.max_len) break;
       }
     }
-    if (defer) {
-      pend.tl.push_back(tl);
-      for (size_t j = n_node_events; j < events.size(); j++) { pend.own.push_back(path_no); pend.own.push_back(events[j].first); pend.own.push_back(events[j].second); }
-      events.resize(n_node_events);
-      pend.node_events.push_back(std::move(events));
-    } else if (cov) {
-      bad_bases += pacbio_sweep(events, tl, s.cfg.step);
-    }
   }
-  s.last_bad_bases = bad_bases;
   const double t_after_host = now_us();
   // read-major CSR of the cached records (rebuilt when the cache changed)
   if (s.uploaded_generation != s.generation) {
@@ -392,18 +460,26 @@ int launch_pacbio(gaml_hip_ctx* c, PacbioSet& s, const std::vector<Walk>& paths_
   a.logprobs = s.logprobs.as<double>();
   a.part_sum = s.red.part_sum.as<double>(); a.part_zero = s.red.part_zero.as<int>();
   a.ticket = s.red.ticket.as<unsigned>(); a.out = out4;
-  a.n_reads = (double)n; a.bad_bases = (double)bad_bases;
-  if (defer) {
-    pend.out4 = out4;
-    for (size_t i = 0; i < c->pacbios.size(); i++) if (c->pacbios[i].get() == &s) pend.pacbio_idx = (int)i;
-    c->pending_pb.push_back(std::move(pend));
-  }
+  a.n_reads = (double)n; a.bad_bases = 0.0;  // (with a penalty: the sweep below stores it)
   if (n > 0) {
     int64_t threads = n * 64;  // one wave per read
     hipLaunchKernelGGL(pacbio_score_kernel, dim3(grid_for(threads)), dim3(kBlock), 0, st, a);
     HIP_TRY(c, hipGetLastError());
   } else {
     HIP_TRY(c, hipMemsetAsync(out4, 0, 4 * sizeof(double), st));
+  }
+  if (cov) {
+    int64_t n_own = 0;
+    if (int e = pacbio_sweep_prepare(c, s, sweep_tl, sweep_node, sweep_occ, st, &n_own)) return e;
+    const int64_t n_node = (int64_t)sweep_node.size() / 4;
+    if (defer) {
+      gaml_hip_ctx::PendingPacbio pend;
+      pend.out4 = out4; pend.n_paths = (int32_t)sweep_tl.size(); pend.n_node = n_node; pend.n_own = n_own; pend.pacbio_idx = -1;
+      for (size_t i = 0; i < c->pacbios.size(); i++) if (c->pacbios[i].get() == &s) pend.pacbio_idx = (int)i;
+      c->pending_pb.push_back(pend);
+    } else {
+      if (int e = pacbio_sweep_run(c, s, n_node + n_own, (int32_t)sweep_tl.size(), st, out4, 1.0)) return e;
+    }
   }
   int64_t nrec = 0;
   for (auto& v : s.recs) nrec += (int64_t)v.size();
@@ -1022,7 +1098,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
       s->red.release(); s->gen_bits.release();
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage);
-      s->d_bases.release(); s->dp.release(); }
+      s->d_bases.release(); s->dp.release(); s->sweep.release(); }
     c->packed.release(); c->packed_host.release(); c->batch_dev.release(); c->batch_host.release(); c->aln_scratch.release();
     c->aln_small[0].release(); c->aln_small[1].release(); c->fetch_host.release();
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1673,30 +1749,43 @@ int32_t gaml_hip_eval_score_async(gaml_hip_ctx* c, void* d_partials, void* strea
 
 int32_t gaml_hip_eval_pacbio_pending(gaml_hip_ctx* c) { return c ? (int32_t)c->pending_pb.size() : GAML_HIP_EINVAL; }
 
-int64_t gaml_hip_eval_pacbio_events(gaml_hip_ctx* c, int32_t i, int32_t* out, int64_t cap) {
-  if (!c || i < 0 || i >= (int32_t)c->pending_pb.size() || cap < 0 || (cap > 0 && !out)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
-  const auto& own = c->pending_pb[i].own;
-  if ((int64_t)own.size() <= cap && !own.empty()) memcpy(out, own.data(), own.size() * sizeof(int32_t));
-  return (int64_t)own.size();
+int64_t gaml_hip_eval_pacbio_intervals(gaml_hip_ctx* c, int32_t i) {
+  if (!c || i < 0 || i >= (int32_t)c->pending_pb.size()) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  return c->pending_pb[i].n_own;
 }
 
-int gaml_hip_eval_pacbio_finish_async(gaml_hip_ctx* c, int32_t i, const int32_t* events, int64_t n_values, int32_t contribute, void* stream) {
-  if (!c || i < 0 || i >= (int32_t)c->pending_pb.size() || n_values < 0 || n_values % 3 != 0 || (n_values > 0 && !events))
+int gaml_hip_eval_pacbio_export_async(gaml_hip_ctx* c, int32_t i, void* dst, int64_t cap, void* stream) {
+  if (!c || i < 0 || i >= (int32_t)c->pending_pb.size() || cap < 0 || (cap > 0 && !dst)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  const gaml_hip_ctx::PendingPacbio& pb = c->pending_pb[i];
+  if (cap < pb.n_own) return fail(c, GAML_HIP_EINVAL, "the intervals do not fit the destination");
+  HIP_TRY(c, hipSetDevice(c->device));
+  PacbioSet& s = *c->pacbios[pb.pacbio_idx];
+  if (pb.n_own > 0)
+    HIP_TRY(c, hipMemcpyAsync(dst, s.sweep.all.as<int4>() + pb.n_node, (size_t)pb.n_own * sizeof(int4), hipMemcpyDeviceToDevice, stream ? (hipStream_t)stream : c->stream));
+  return GAML_HIP_OK;
+}
+
+int gaml_hip_eval_pacbio_finish_async(gaml_hip_ctx* c, int32_t i, const void* intervals, int64_t n_intervals, int32_t contribute, void* stream) {
+  if (!c || i < 0 || i >= (int32_t)c->pending_pb.size() || n_intervals < 0 || (n_intervals > 0 && !intervals) || n_intervals > ((int64_t)1 << 28))
     return fail(c, GAML_HIP_EINVAL, "bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
-  gaml_hip_ctx::PendingPacbio& pb = c->pending_pb[i];
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const gaml_hip_ctx::PendingPacbio& pb = c->pending_pb[i];
   PacbioSet& s = *c->pacbios[pb.pacbio_idx];
-  const int32_t n_paths = (int32_t)pb.tl.size();
-  for (int64_t k = 0; k < n_values; k += 3) {
-    if (events[k] < 0 || events[k] >= n_paths) return fail(c, GAML_HIP_EINVAL, "event names a path that is not in this evaluation");
-    pb.node_events[events[k]].emplace_back(events[k + 1], events[k + 2]);
+  PbSweepDev& d = s.sweep;
+  const size_t want = (size_t)std::max<int64_t>(1, pb.n_node + n_intervals) * sizeof(int4);
+  if (want > d.all.cap) {  // the node intervals move along
+    DevBuf bigger;
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, bigger.reserve(want));
+    if (pb.n_node) HIP_TRY(c, hipMemcpy(bigger.p, d.all.p, (size_t)pb.n_node * sizeof(int4), hipMemcpyDeviceToDevice));
+    d.all.release();
+    d.all = bigger;
   }
-  int64_t bad = 0;
-  for (int32_t p = 0; p < n_paths; p++) bad += pacbio_sweep(pb.node_events[p], pb.tl[p], s.cfg.step);
-  s.last_bad_bases = bad;
-  hipLaunchKernelGGL(store_double_kernel, dim3(1), dim3(64), 0, stream ? (hipStream_t)stream : c->stream, pb.out4 + 2, contribute ? (double)bad : 0.0);
-  HIP_TRY(c, hipGetLastError());
-  return GAML_HIP_OK;
+  // all ranks' alignment intervals behind the node intervals (this rank's own are among them)
+  if (n_intervals > 0) HIP_TRY(c, hipMemcpyAsync(d.all.as<int4>() + pb.n_node, intervals, (size_t)n_intervals * sizeof(int4), hipMemcpyDeviceToDevice, st));
+  // every rank computes the same bad_bases; one of them contributes it to the all-reduce(sum) of the partials
+  return pacbio_sweep_run(c, s, pb.n_node + n_intervals, pb.n_paths, st, pb.out4, contribute ? 1.0 : 0.0);
 }
 
 int gaml_hip_eval_coverage_export_async(gaml_hip_ctx* c, int32_t i, void* dst, int64_t cap, int64_t* bytes_out, void* stream) {
@@ -1962,8 +2051,10 @@ static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
   if (!spun) { if (int e2 = collect_events(c)) return e2; }  // after a spin the events are collected lazily (gaml_hip_kernel_stats)
   // bookkeeping for gaml_hip_bad_bases
   auto order = scoring_order(c);
-  for (size_t k = 0; k < order.size(); k++)
+  for (size_t k = 0; k < order.size(); k++) {
     if (order[k].kind == 1) c->paireds[order[k].idx]->last_bad_bases = (int64_t)partials_out[4 * k + 2];
+    else if (order[k].kind == 2) c->pacbios[order[k].idx]->last_bad_bases = (int64_t)partials_out[4 * k + 2];
+  }
   return GAML_HIP_OK;
 }
 

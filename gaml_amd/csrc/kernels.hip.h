@@ -1315,10 +1315,6 @@ __global__ void store_bad_bases_kernel(const unsigned long long* bad, double* ou
   if (threadIdx.x == 0 && blockIdx.x == 0) out4[2] = scale * (double)*bad;
 }
 
-__global__ void store_double_kernel(double* dst, double v) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
-}
-
 // union of the coverage maps of all ranks: own |= maps[0] | maps[1] | ...
 __global__ __launch_bounds__(kBlock) void or_maps_kernel(uint32_t* own, const uint32_t* maps, int n_maps, int words) {
   for (int w = blockIdx.x * kBlock + threadIdx.x; w < words; w += gridDim.x * kBlock) {

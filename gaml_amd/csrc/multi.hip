@@ -93,7 +93,7 @@ struct DevMem {  // grow-only device buffer (the caller synchronises the stream 
 struct CommState {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
-  DevMem part, small, own, all;  // partials (f64) | maxima, sizes | this rank's map / events | the gathered ones
+  DevMem part, small, own, all, pack;  // partials (f64) | maxima, sizes | this rank's map / intervals | the gathered ones | the gathered intervals, contiguous
 };
 
 #define COMM_HIP(c, expr)                                                                            \
@@ -110,7 +110,7 @@ struct CommState {
 void comm_destroy(CommState* s) {
   if (!s) return;
   if (s->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(s->comm);
-  s->part.release(); s->small.release(); s->own.release(); s->all.release();
+  s->part.release(); s->small.release(); s->own.release(); s->all.release(); s->pack.release();
   delete s;
 }
 
@@ -151,11 +151,9 @@ int comm_score(gaml_hip_ctx* c, CommState* s, double* d_part) {
     if (int e = gaml_hip_eval_coverage_finish_async(c, i, s->all.p, bytes > 0 ? s->world : 0, s->rank == 0, st)) return e;
   }
   const int32_t n_pb = gaml_hip_eval_pacbio_pending(c);
-  for (int32_t i = 0; i < n_pb; i++) {  // PacBio sets with a penalty: interval events of all ranks' reads (host lists)
-    const int64_t n_own = gaml_hip_eval_pacbio_events(c, i, nullptr, 0);
+  for (int32_t i = 0; i < n_pb; i++) {  // PacBio sets with a penalty: the alignment intervals of all ranks' reads (device lists)
+    const int64_t n_own = gaml_hip_eval_pacbio_intervals(c, i);
     if (n_own < 0) return (int)n_own;
-    std::vector<int32_t> own((size_t)n_own);
-    if (n_own) gaml_hip_eval_pacbio_events(c, i, own.data(), n_own);
     std::vector<long long> sizes((size_t)s->world, 0);
     long long mine = n_own;
     COMM_HIP(c, s->small.reserve(sizeof(long long) * (size_t)(s->world + 1), st));
@@ -164,17 +162,20 @@ int comm_score(gaml_hip_ctx* c, CommState* s, double* d_part) {
     COMM_NCCL(c, rccl()->AllGather(d_sz, d_sz + 1, 1, ncclInt64, s->comm, st));
     COMM_HIP(c, hipMemcpyAsync(sizes.data(), d_sz + 1, sizeof(long long) * (size_t)s->world, hipMemcpyDeviceToHost, st));
     COMM_HIP(c, hipStreamSynchronize(st));
-    const long long width = std::max<long long>(1, *std::max_element(sizes.begin(), sizes.end()));
-    own.resize((size_t)width, 0);
-    COMM_HIP(c, s->own.reserve((size_t)width * sizeof(int32_t), st));
-    COMM_HIP(c, s->all.reserve((size_t)width * sizeof(int32_t) * (size_t)s->world, st));
-    COMM_HIP(c, hipMemcpyAsync(s->own.p, own.data(), (size_t)width * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    COMM_NCCL(c, rccl()->AllGather(s->own.p, s->all.p, (size_t)width, ncclInt32, s->comm, st));
-    std::vector<int32_t> all((size_t)width * (size_t)s->world), merged;
-    COMM_HIP(c, hipMemcpyAsync(all.data(), s->all.p, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    COMM_HIP(c, hipStreamSynchronize(st));
-    for (int r = 0; r < s->world; r++) merged.insert(merged.end(), all.begin() + (size_t)r * width, all.begin() + (size_t)r * width + sizes[r]);
-    if (int e = gaml_hip_eval_pacbio_finish_async(c, i, merged.data(), (int64_t)merged.size(), s->rank == 0, st)) return e;
+    long long total = 0;
+    for (long long v : sizes) total += v;
+    const long long width = std::max<long long>(1, *std::max_element(sizes.begin(), sizes.end()));  // intervals per rank in the gather (16 bytes each)
+    COMM_HIP(c, s->own.reserve((size_t)width * 16, st));
+    COMM_HIP(c, s->all.reserve((size_t)width * 16 * (size_t)s->world, st));
+    COMM_HIP(c, s->pack.reserve((size_t)std::max<long long>(1, total) * 16, st));
+    if (int e = gaml_hip_eval_pacbio_export_async(c, i, s->own.p, width, st)) return e;
+    COMM_NCCL(c, rccl()->AllGather(s->own.p, s->all.p, (size_t)width * 16, ncclChar, s->comm, st));
+    long long at = 0;
+    for (int r = 0; r < s->world; r++) {  // rank order, the padding dropped
+      if (sizes[r]) COMM_HIP(c, hipMemcpyAsync((char*)s->pack.p + at * 16, (const char*)s->all.p + (size_t)r * (size_t)width * 16, (size_t)sizes[r] * 16, hipMemcpyDeviceToDevice, st));
+      at += sizes[r];
+    }
+    if (int e = gaml_hip_eval_pacbio_finish_async(c, i, s->pack.p, total, s->rank == 0, st)) return e;
   }
   return 0;
 }
@@ -447,16 +448,38 @@ int multi_finish_with_penalty(MultiState* m, std::vector<std::vector<double>>& p
   }
   const int32_t n_pb = gaml_hip_eval_pacbio_pending(m->kids[0]);
   for (int32_t i = 0; i < n_pb; i++) {
-    std::vector<int32_t> merged;
-    for (gaml_hip_ctx* kid : m->kids) {  // host lists, rank order
-      const int64_t cnt = gaml_hip_eval_pacbio_events(kid, i, nullptr, 0);
-      if (cnt < 0) return ctx_fail(m->parent, (int)cnt, gaml_hip_last_error(kid));
-      const size_t at = merged.size();
-      merged.resize(at + (size_t)cnt);
-      if (cnt) gaml_hip_eval_pacbio_events(kid, i, merged.data() + at, cnt);
+    // every shard's alignment intervals to every shard, device to device (rank order)
+    std::vector<int64_t> cnt((size_t)n, 0);
+    int64_t total = 0;
+    for (int k = 0; k < n; k++) {
+      cnt[k] = gaml_hip_eval_pacbio_intervals(m->kids[k], i);
+      if (cnt[k] < 0) return ctx_fail(m->parent, (int)cnt[k], gaml_hip_last_error(m->kids[k]));
+      total += cnt[k];
     }
     rc = m->run_all([&](int k, gaml_hip_ctx* kid) {
-      return gaml_hip_eval_pacbio_finish_async(kid, i, merged.data(), (int64_t)merged.size(), k == 0, ctx_stream(kid));
+      hipStream_t st = ctx_stream(kid);
+      auto& kb = m->bufs[k];
+      if (hipSuccess != kb.own.reserve((size_t)std::max<int64_t>(1, cnt[k]) * 16, st) || hipSuccess != kb.all.reserve((size_t)std::max<int64_t>(1, total) * 16, st))
+        return ctx_fail(kid, GAML_HIP_EHIP, "hipMalloc of the interval lists failed");
+      if (int e = gaml_hip_eval_pacbio_export_async(kid, i, kb.own.p, cnt[k], st)) return e;
+      return hipSuccess == hipStreamSynchronize(st) ? 0 : ctx_fail(kid, GAML_HIP_EHIP, "stream synchronise failed");
+    });
+    if (rc) return rc;
+    rc = m->run_all([&](int k, gaml_hip_ctx* kid) {
+      hipStream_t st = ctx_stream(kid);
+      int64_t at = 0;
+      for (int r = 0; r < n; r++) {
+        if (cnt[r]) {
+          const int dev_k = ctx_device(kid), dev_r = ctx_device(m->kids[r]);
+          char* dst = (char*)m->bufs[k].all.p + at * 16;
+          const hipError_t e = dev_k == dev_r ? hipMemcpyAsync(dst, m->bufs[r].own.p, (size_t)cnt[r] * 16, hipMemcpyDeviceToDevice, st)
+                                              : hipMemcpyPeerAsync(dst, dev_k, m->bufs[r].own.p, dev_r, (size_t)cnt[r] * 16, st);
+          if (e != hipSuccess) return ctx_fail(kid, GAML_HIP_EHIP, std::string("copy of a shard's interval list failed: ") + hipGetErrorString(e));
+        }
+        at += cnt[r];
+      }
+      if (int e = gaml_hip_eval_pacbio_finish_async(kid, i, m->bufs[k].all.p, total, k == 0, st)) return e;
+      return hipSuccess == hipStreamSynchronize(st) ? 0 : ctx_fail(kid, GAML_HIP_EHIP, "stream synchronise failed");  // (the peers' `own` lists are read by the copies)
     });
     if (rc) return rc;
   }

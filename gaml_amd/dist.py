@@ -116,26 +116,21 @@ class ShardedScorer:
             ctx.eval_coverage_export_async(i, own.data_ptr(), nbytes, sp)
             self._all_gather(gathered, own)
             ctx.eval_coverage_finish_async(i, gathered.data_ptr(), self.world, self.rank == 0, sp)
-        for i in range(ctx.eval_pacbio_pending() if self._has_pacbio else 0):  # PacBio sets with a penalty: interval events of all ranks (host lists)
-            own = torch.from_numpy(ctx.eval_pacbio_events(i).copy())
-            sizes = torch.zeros(self.world, dtype=torch.int64)
-            sizes[self.rank] = own.numel()
-            if not self._host_collectives:
-                sizes = sizes.cuda()
-            dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=self.group)
-            sizes = sizes.cpu()
-            width = int(sizes.max())
-            pad = torch.zeros(max(1, width), dtype=torch.int32)
-            pad[: own.numel()] = own
-            if self._host_collectives:
-                parts = [torch.empty_like(pad) for _ in range(self.world)]
-                dist.all_gather(parts, pad, group=self.group)
-            else:
-                dev = torch.empty(self.world * pad.numel(), dtype=torch.int32, device="cuda")
-                dist.all_gather_into_tensor(dev, pad.cuda(), group=self.group)
-                parts = list(dev.cpu().view(self.world, -1))
-            merged = np.concatenate([parts[r][: int(sizes[r])].numpy() for r in range(self.world)]) if width else np.zeros(0, np.int32)
-            ctx.eval_pacbio_finish_async(i, merged, self.rank == 0, sp)
+        for i in range(ctx.eval_pacbio_pending() if self._has_pacbio else 0):  # PacBio sets with a penalty: alignment intervals of all ranks (device lists)
+            n_own = ctx.eval_pacbio_intervals(i)
+            sizes = torch.zeros(self.world, dtype=torch.int64, device="cuda")
+            sizes[self.rank] = n_own
+            self._all_reduce(sizes, dist.ReduceOp.SUM)
+            sizes = sizes.cpu().tolist()
+            width = max(1, max(sizes))  # intervals per rank in the gather; 4 int32 each
+            own = torch.zeros(4 * width, dtype=torch.int32, device="cuda")
+            ctx.eval_pacbio_export_async(i, own.data_ptr(), width, sp)
+            gathered = torch.empty(self.world * 4 * width, dtype=torch.int32, device="cuda")
+            self._all_gather(gathered, own)
+            rows = gathered.view(self.world, 4 * width)
+            merged = torch.cat([rows[r, : 4 * sizes[r]] for r in range(self.world)]).contiguous()  # rank order, the padding dropped
+            ctx.eval_pacbio_finish_async(i, merged.data_ptr(), sum(sizes), self.rank == 0, sp)
+            self._keep = (own, gathered, merged)  # (alive until the stream has run the sweep)
         return total_len
 
     def calc_prob(self, paths):

@@ -260,17 +260,23 @@ int gaml_hip_compact_tables(gaml_hip_ctx* ctx);
  * Single-end sets need no exchange (their bad_bases is identically 0 in the reference, graph.cc:1701-1733).
  * PacBio sets with a penalty (graph.cc:3198-3250: sweep over the alignment intervals of ALL reads): after
  * gaml_hip_eval_score_async, for i < gaml_hip_eval_pacbio_pending(ctx):
- *     n = gaml_hip_eval_pacbio_events(ctx, i, out, cap)   this rank's interval events, int32 triples
- *         (path, position, value) in host memory; returns the number of int32 values (call with cap 0 for the size);
- *     all-gather them; gaml_hip_eval_pacbio_finish_async(ctx, i, all_events, n_values, contribute, stream)
- *         sweeps the union on the host and stores bad_bases into the partials like the paired form. */
+ *     n = gaml_hip_eval_pacbio_intervals(ctx, i)   how many alignment intervals this rank's reads contribute
+ *         (known on the host, no synchronisation);
+ *     gaml_hip_eval_pacbio_export_async(ctx, i, dst, cap, stream)   copy them -- 16 bytes each: int32 {contig,
+ *         begin, end, 0} in path coordinates -- into caller DEVICE memory with room for `cap` intervals;
+ *     all-gather them (counts differ per rank: gather the counts first); then
+ *     gaml_hip_eval_pacbio_finish_async(ctx, i, intervals, n_intervals, contribute, stream)   `intervals`: the
+ *         n_intervals gathered intervals of all ranks (this rank's among them) in device memory; sorts them
+ *         together with the contigs' node intervals, runs the sweep on the device and stores bad_bases into the
+ *         partials like the paired form. No interval ever visits the host. */
 int32_t gaml_hip_eval_score_async(gaml_hip_ctx* ctx, void* d_partials, void* stream);
 int gaml_hip_eval_coverage_export_async(gaml_hip_ctx* ctx, int32_t i, void* dst, int64_t cap, int64_t* bytes_out, void* stream);
 int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* ctx, int32_t i, const void* maps, int32_t n_maps, int32_t contribute,
                                         void* stream);
 int32_t gaml_hip_eval_pacbio_pending(gaml_hip_ctx* ctx);
-int64_t gaml_hip_eval_pacbio_events(gaml_hip_ctx* ctx, int32_t i, int32_t* out, int64_t cap);
-int gaml_hip_eval_pacbio_finish_async(gaml_hip_ctx* ctx, int32_t i, const int32_t* events, int64_t n_values, int32_t contribute,
+int64_t gaml_hip_eval_pacbio_intervals(gaml_hip_ctx* ctx, int32_t i);
+int gaml_hip_eval_pacbio_export_async(gaml_hip_ctx* ctx, int32_t i, void* dst, int64_t cap, void* stream);
+int gaml_hip_eval_pacbio_finish_async(gaml_hip_ctx* ctx, int32_t i, const void* intervals, int64_t n_intervals, int32_t contribute,
                                       void* stream);
 
 /* Device-resident form for callers that already own a HIP stream (e.g. torch): enqueue the

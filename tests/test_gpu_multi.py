@@ -77,8 +77,11 @@ def test_shards_with_coverage_penalties_and_long_reads():
         rec3 = [(int(p), int(min(span, p + lens[i])), int(i)) for i, p in zip(ids, rng.integers(0, max(1, span - 900), 120))]
         cached.append((sub, rec3, -rng.uniform(200, 900, 120)))
     ctxs = []
-    for kw in (dict(device=0), dict(devices=[0, 0])):
+    for kw in (dict(device=0), dict(devices=[0, 0]), dict(device=0, comm=True)):
+        comm = kw.pop("comm", False)
         c = api.Context(**kw)
+        if comm:  # one process per GPU, world = 1: the RCCL form of the exchanges (all-gather of maps / interval lists)
+            c.comm_init_rank(api.comm_unique_id(), 0, 1)
         c.set_graph(gb, go)
         c.add_paired(api.paired_cfg(300.0, 30.0, penalty_constant=0.001, penalty_step=20.0), *reads)
         c.add_single(api.single_cfg(weight=0.5), *synth.pack_reads(sr))
@@ -86,14 +89,16 @@ def test_shards_with_coverage_penalties_and_long_reads():
         for sub, rec3, logp in cached:
             c.put_pacbio_records(pb, sub, rec3, logp)
         ctxs.append(c)
-    whole, multi = ctxs
+    whole, multi, solo = ctxs
     for ps in ([walk], [walk[:8], walk[8:]]):
         want, wz, wtl = whole.calc_prob(ps)
-        got, gz, gtl = multi.calc_prob(ps)
-        assert gtl == wtl and np.array_equal(gz, wz)
-        assert whole.bad_bases(0) > 0 and multi.bad_bases(0) == whole.bad_bases(0)
-        assert multi.bad_bases(2) == whole.bad_bases(2)
-        assert _rel(got, want) <= 1e-12, (got, want)
+        assert whole.bad_bases(0) > 0 and whole.bad_bases(2) > 0
+        for c in (multi, solo):
+            got, gz, gtl = c.calc_prob(ps)
+            assert gtl == wtl and np.array_equal(gz, wz)
+            assert c.bad_bases(0) == whole.bad_bases(0)
+            assert c.bad_bases(2) == whole.bad_bases(2)
+            assert _rel(got, want) <= 1e-12, (got, want)
     multi.close()
 
 

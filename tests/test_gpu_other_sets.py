@@ -87,6 +87,56 @@ def test_pacbio_parity_and_golden():
         assert abs(got - want) <= 1e-12 * abs(want)
 
 
+@pytest.mark.parametrize("step", [30.0, 0.5, 777.25])
+def test_pacbio_coverage_sweep_on_crafted_intervals(step):
+    """The device sweep (sort + running maximum + binary search, pacbio_sweep.hip.h) against the oracle's restatement of
+    the reference's event / multiset loop (graph.cc:3198-3250) on intervals chosen to hit its corners: nested and
+    identical intervals, intervals that touch (one ends where the next begins), begins equal to node boundaries, long
+    uncovered stretches, records below GetMinReadProb (not counted), several contigs, a gap in a contig."""
+    from gaml_amd import api
+    import oracle_py as op
+    genome, g = _graph(120_000, 97, long_rng=(2500, 6000))
+    walk = synth.genome_walk(g)
+    gb, go = g.packed()
+    rng = np.random.default_rng(5)
+    n_reads = 400
+    lens = np.full(n_reads, 1500, np.int32)
+    cfg = dict(penalty_constant=0.002, min_prob_per_base=-1.2)
+    ctx = api.Context(device=0)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_pacbio(api.single_cfg(mismatch_prob=0.15, penalty_step=step, **cfg), lens)
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    ors = orc.add_pacbio(lens, 0.15, op.single_cfg(step=step, **cfg))
+    node_len = lambda x: int(go[x + 1] - go[x])
+    good_lp, bad_lp = -900.0, -5000.0  # GetMinReadProb(1500 bases at 15 %) is about -1130: the second kind is not counted
+    rid = 0
+    for sub in synth.all_subwalks_for_pacbio(g, walk, 1500):
+        span = sum(node_len(x) for x in sub)
+        recs, lps = [], []
+        k = int(rng.integers(0, 5))
+        anchors = rng.integers(0, max(1, span - 10), size=k)
+        for a in anchors:
+            a = int(a)
+            e = int(min(span + 40, a + rng.integers(1, 1800)))
+            for rep in range(int(rng.integers(1, 3))):  # identical copies
+                recs.append((a, e, rid % n_reads)); lps.append(good_lp if rng.random() < 0.8 else bad_lp); rid += 1
+            if rng.random() < 0.5:  # one that starts exactly where this one ends, one nested inside
+                recs.append((e, e + int(rng.integers(1, 900)), rid % n_reads)); lps.append(good_lp); rid += 1
+                if e - a > 4:
+                    recs.append((a + 1, e - 1, rid % n_reads)); lps.append(good_lp); rid += 1
+        rec = np.array(recs, np.int32).reshape(-1, 3)
+        lp = np.array(lps, np.float64)
+        ctx.put_pacbio_records(rs, sub, rec, lp)
+        orc.pacbio_put(ors, sub, rec, lp)
+    for paths in ([walk], [walk[:6], walk[6:]], [walk[:4] + [-700] + walk[5:11], walk[11:], walk[2:3]]):
+        got, zeros, tl = ctx.calc_prob(paths)
+        want, wlp, o3 = orc.pacbio_detail(ors, paths)
+        assert int(o3[2]) > 0 or step < 1  # (int(begin + 0.5) never passes the position: nothing is bad)
+        assert ctx.bad_bases(rs) == int(o3[2]), (step, paths)
+        assert abs(got - want) <= 1e-12 * abs(want)
+
+
 def test_pacbio_many_alignments_per_read_wave_lse():
     """A read with hundreds of candidate positions exercises the strided wave-level log-sum-exp."""
     from gaml_amd import api
@@ -317,7 +367,7 @@ def test_sharded_coverage_penalty_merges_the_ranks_maps():
 
 def test_sharded_pacbio_penalty_merges_the_ranks_intervals():
     """A PacBio set with penalty_constant > 0 on sharded contexts: bad_bases (graph.cc:3198-3250) sweeps the
-    alignment intervals of ALL reads, so the ranks exchange their interval events. Three shards on one GPU
+    alignment intervals of ALL reads, so the ranks exchange their interval lists (device memory). Three shards on one GPU
     play the ranks; sparse long reads leave uncovered stretches that only the union closes."""
     import torch
     from gaml_amd import api
@@ -343,15 +393,21 @@ def test_sharded_pacbio_penalty_merges_the_ranks_intervals():
     shards = [make(r, 3)[0] for r in range(3)]
     stream = torch.cuda.current_stream().cuda_stream
     parts = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in shards]
-    own = []
+    own, counts = [], []
     for c, p in zip(shards, parts):
         c.eval_begin(paths)
         assert c.eval_score_async(p.data_ptr(), stream) == 0 and c.eval_pacbio_pending() == 1
-        own.append(c.eval_pacbio_events(0))
-    assert all(len(e) % 3 == 0 for e in own) and sum(len(e) for e in own) > 0
-    merged = np.concatenate(own)  # what the all-gather leaves on every rank
+        n = c.eval_pacbio_intervals(0)  # known on the host; the intervals themselves stay on the device
+        t = torch.zeros(4 * max(1, n), dtype=torch.int32, device="cuda")
+        c.eval_pacbio_export_async(0, t.data_ptr(), max(1, n), stream)
+        own.append(t[: 4 * n])
+        counts.append(n)
+    assert sum(counts) > 0
+    merged = torch.cat(own).contiguous()  # what the all-gather leaves on every rank (device memory)
+    iv = merged.view(-1, 4).cpu().numpy()
+    assert set(iv[:, 0].tolist()) <= {0, 1} and (iv[:, 2] > iv[:, 1]).all() and (iv[:, 3] == 0).all()
     for r, c in enumerate(shards):
-        c.eval_pacbio_finish_async(0, merged, r == 1, stream)  # any one rank may contribute
+        c.eval_pacbio_finish_async(0, merged.data_ptr(), sum(counts), r == 1, stream)  # any one rank may contribute
     torch.cuda.synchronize()
     assert [float(p[2]) for p in parts] == [0.0, float(bad_whole), 0.0]
     acc = torch.stack(parts).sum(0).cpu().numpy()
