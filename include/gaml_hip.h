@@ -90,7 +90,7 @@ const char* gaml_hip_version(void);
  *     ncclCommInitAll; the default when every shard has its own GPU) or, as the measured alternative, by adding the
  *     shards' pinned-host partials in rank order on the calling thread (gaml_hip_set_exchange). The cold-path
  *     maximum of new windows' record positions and, with penalty_constant > 0, the union of the coverage maps /
- *     PacBio interval events are merged in the library too. Environment: GAML_HIP_EXCHANGE=host|rccl picks the
+ *     PacBio alignment intervals are merged in the library too (device lists). Environment: GAML_HIP_EXCHANGE=host|rccl picks the
  *     initial exchange ("rccl": creation fails when RCCL cannot be used).
  * (2) one process per GPU (torch.distributed.run, MPI): every process creates a plain context, calls
  *     gaml_hip_set_shard(rank, world) (or gaml_hip_set_presharded) and then gaml_hip_comm_init_rank with an id
