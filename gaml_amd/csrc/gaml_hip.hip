@@ -910,7 +910,9 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
     if (!want_vectors) c->pending_total_len = c->paireds[i]->planner.total_len();
     // windows registered by pass 1 get their records now, all at once (GPU aligner when there is a device): small
     // batches of the two mates go out together on the stream before either is waited for
+    const double ta = now_us();
     if (int e = align_pending_pair(c, *c->paireds[i])) return e;
+    c->prof[2] = (i ? c->prof[2] : 0.0) + now_us() - ta;  // alignment of newly registered windows (inside pass 1)
   }
   int64_t n = 0;
   for (ShortMate* m : filter_mates(c)) {
@@ -944,8 +946,8 @@ int eval_finish(gaml_hip_ctx* c, void* d_partials, hipStream_t st) {
     // (single-end sets: bad_bases is identically 0 in the reference, graph.cc:1701-1733 -- nothing to exchange)
     for (auto& ps : c->pacbios)
       if (ps->cfg.penalty_constant > 0 && !c->defer_cov)
-        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded PacBio set: the interval events of all ranks must be merged "
-                                        "(gaml_hip_eval_score_async -> gaml_hip_eval_pacbio_events -> all-gather -> gaml_hip_eval_pacbio_finish_async)");
+        return fail(c, GAML_HIP_ESTATE, "penalty_constant > 0 on a sharded PacBio set: the alignment intervals of all ranks must be merged "
+                                        "(gaml_hip_eval_score_async -> gaml_hip_eval_pacbio_export_async -> all-gather -> gaml_hip_eval_pacbio_finish_async)");
   }
   const std::vector<Walk>& paths = c->pending_paths;
   const int32_t total_len = c->pending_total_len;
@@ -2071,6 +2073,142 @@ static bool batch_fast_capable(const gaml_hip_ctx* c) {
   return true;
 }
 
+// The same with the sets' tables built on the device (batch_tables_kernel): on a large-BAR device the resident copy
+// of the tables mirrors the previous call's path set, and candidates differ from it -- and from each other -- in a
+// few dozen entries. Returns 1 when this chunk cannot go that way (tables rebuilt as a whole, list changes, growth
+// past the resident capacities): the caller takes the full-tables route, which plans the chunk again.
+static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, const int64_t* offs, const int32_t* set_offs,
+                               double* partials_out, int32_t* tls) {
+  hipStream_t st = c->stream;
+  const size_t nps = c->paireds.size();
+  if (!c->direct_write || c->knobs[8] != 0 || c->knobs[13] != 0 || c->knobs[11] == 2) return 1;  // knob 11 = 2: full tables per set (A/B)
+  constexpr size_t kPatchCap = 8192;  // entries per read set and batch
+  struct PerSet {
+    int slot = 0; char* wp = nullptr; size_t stride = 0;
+    PairedLayout L; std::vector<PairedLayout> Ls; std::vector<PairedPrep> prep;
+    std::vector<int> patch_off; size_t n_patches = 0;
+    std::vector<int32_t> touched[2];  // union of the changed entries: the resident copy follows after the batch
+  };
+  std::vector<PerSet> per(nps);
+  c->host_results = true;
+  struct Reset { gaml_hip_ctx* c; ~Reset() { c->host_results = false; c->pending_open = false; } } reset{c};
+  for (size_t i = 0; i < nps; i++) {
+    PairedSet& ps = *c->paireds[i];
+    if (int e = prepare_paired_tables(c, ps)) return e;
+    PairedSet::Persist& P = ps.persist;
+    // bring the copy up to the images (made here if no blocking call has yet; entries changed by a call that did not go through it)
+    if (!P.valid || ps.image[0].changed_all || ps.image[1].changed_all || !ps.image[0].changed.empty() || !ps.image[1].changed.empty() ||
+        ps.image[0].lists_changed || ps.image[1].lists_changed) {
+      if (int e = paired_persist_update(c, ps, 2.0, st)) return e;
+    }
+    PerSet& r = per[i];
+    r.stride = align16(P.bytes);
+    r.L.tfloor_off = P.off_tfloor;
+    r.L.l0 = OccLayout{P.off_occ[0], P.off_lo[0], P.off_m[0], P.off_lo[1] /* unused */};
+    r.L.l1 = OccLayout{P.off_occ[1], P.off_lo[1], P.off_m[1], P.bytes};
+    r.L.pb_off = r.L.so_off = r.L.st_off = 0; r.L.total = P.bytes;
+    r.Ls.assign((size_t)n, r.L);
+    r.prep.resize((size_t)n);
+    r.patch_off.assign(2 * (size_t)n + 1, 0);
+    const size_t bytes = r.stride * (size_t)n + align16(kPatchCap * sizeof(BatchPatch)) + align16((2 * (size_t)kMaxSets + 1) * sizeof(int));
+    if (int e = arena_acquire(c, ps.arena, bytes, st, &r.slot, &r.wp)) return e;
+  }
+  auto give_up = [&](bool in_flight) -> int {  // the resident copies no longer mirror the images: rewritten as a whole next time
+    for (size_t i = 0; i < nps; i++) c->paireds[i]->persist.valid = false;
+    if (in_flight) { bool spun = false; (void)wait_host_partials(c, &spun); if (!spun) (void)collect_events(c); }
+    return 1;
+  };
+  const int half = n > 4 ? (n + 1) / 2 : n;
+  int launched = 0;
+  auto launch_upto = [&](int upto) -> int {
+    for (size_t i = 0; i < nps; i++) {
+      PairedSet& ps = *c->paireds[i];
+      PerSet& r = per[i];
+      const PairedSet::Persist& P = ps.persist;
+      if (int e = paired_sync_tables(c, ps, st)) return e;
+      for (int k = launched; k < upto; k++) paired_pack_thresholds(ps, r.L, (double)(2 * (tls[k] == 0 ? 1 : tls[k])), r.wp + (size_t)k * r.stride);
+      char* tail = r.wp + r.stride * (size_t)n;
+      int* d_off = (int*)(tail + align16(kPatchCap * sizeof(BatchPatch)));
+      memcpy(d_off, r.patch_off.data(), (2 * (size_t)upto + 1) * sizeof(int));
+      if (int e = arena_commit(c, ps.arena, r.slot, 0, st)) return e;  // (direct route: drains the write-combining buffers)
+      BatchTabArgs ta;
+      ta.base = (const char*)P.dev;
+      ta.regions = (char*)ps.arena.dev[r.slot];
+      ta.stride = r.stride;
+      for (int mt = 0; mt < 2; mt++) {
+        ta.off_occ[mt] = P.off_occ[mt]; ta.bytes_occ[mt] = P.cap_w[mt] * sizeof(Occ12);
+        ta.off_lo[mt] = P.off_lo[mt]; ta.bytes_lo[mt] = ps.image[mt].multi_off.size() * sizeof(int32_t);
+        ta.off_m[mt] = P.off_m[mt]; ta.bytes_m[mt] = ps.image[mt].multi.size() * sizeof(OccQuad);
+      }
+      ta.patches = (const BatchPatch*)((const char*)ps.arena.dev[r.slot] + r.stride * (size_t)n);
+      ta.patch_off = (const int*)((const char*)ta.patches + align16(kPatchCap * sizeof(BatchPatch)));
+      ta.first = launched;
+      hipLaunchKernelGGL(batch_tables_kernel, dim3((unsigned)(upto - launched), 2), dim3(1024), 0, st, ta);
+      HIP_TRY(c, hipGetLastError());
+      if (int e = launch_paired_multi(c, ps, launched, upto - launched, r.Ls.data(), r.prep.data(), tls, (const char*)ps.arena.dev[r.slot], r.stride, st)) return e;
+    }
+    launched = upto;
+    return 0;
+  };
+  for (int k = 0; k < n; k++) {
+    int64_t pending = 0;
+    if (int e = eval_begin(c, paths, offs + set_offs[k], set_offs[k + 1] - set_offs[k], &pending)) return e;
+    tls[k] = c->pending_total_len;
+    for (size_t i = 0; i < nps; i++) {
+      PairedSet& ps = *c->paireds[i];
+      PerSet& r = per[i];
+      const PairedSet::Persist& P = ps.persist;
+      prepare_paired_tables_host(c, ps, r.prep[(size_t)k]);
+      OccImage* im = ps.image;
+      bool ok = !im[0].changed_all && !im[1].changed_all && !im[0].lists_changed && !im[1].lists_changed;
+      for (int mt = 0; mt < 2 && ok; mt++) ok = im[mt].occ12.size() <= P.cap_w[mt] && r.n_patches + im[mt].changed.size() <= kPatchCap;
+      if (!ok) {
+        if (getenv("GAML_HIP_TRACE_HOST"))
+          fprintf(stderr, "batch set %d: not a patch (all %d %d, lists %d %d, windows %zu/%zu %zu/%zu, patches %zu + %zu + %zu)\n", k, (int)im[0].changed_all, (int)im[1].changed_all,
+                  (int)im[0].lists_changed, (int)im[1].lists_changed, im[0].occ12.size(), P.cap_w[0], im[1].occ12.size(), P.cap_w[1], r.n_patches, im[0].changed.size(), im[1].changed.size());
+        c->pending_open = false;
+        return give_up(launched > 0);
+      }
+      BatchPatch* dp = (BatchPatch*)(r.wp + r.stride * (size_t)n);
+      for (int mt = 0; mt < 2; mt++) {
+        for (int32_t w : im[mt].changed) {
+          const Occ12& o = im[mt].occ12[w];
+          dp[r.n_patches++] = BatchPatch{w, o.lo, o.hi, o.rank};
+          r.touched[mt].push_back(w);
+        }
+        r.patch_off[2 * (size_t)k + mt + 1] = (int)r.n_patches;
+        im[mt].take_changed();
+      }
+    }
+    c->pending_open = false;
+    if (k + 1 == half && half < n) { if (int e = launch_upto(half)) return e; }
+  }
+  if (int e = launch_upto(n)) return e;
+  bool spun = false;
+  if (int e = wait_host_partials(c, &spun)) return e;
+  if (!spun) { if (int e2 = collect_events(c)) return e2; }
+  // the device is done with the resident copies: they follow the images (now the last set's)
+  for (size_t i = 0; i < nps; i++) {
+    PairedSet& ps = *c->paireds[i];
+    char* occ[2] = {(char*)ps.persist.dev + ps.persist.off_occ[0], (char*)ps.persist.dev + ps.persist.off_occ[1]};
+    for (int mt = 0; mt < 2; mt++)
+      for (int32_t w : per[i].touched[mt]) memcpy(occ[mt] + (size_t)w * sizeof(Occ12), &ps.image[mt].occ12[w], sizeof(Occ12));
+  }
+  _mm_sfence();
+  for (int k = 0; k < n; k++)
+    for (size_t i = 0; i < nps; i++) {
+      PairedSet& ps = *c->paireds[i];
+      double* out = partials_out + ((size_t)k * nps + i) * 4;
+      out[0] = out[1] = out[2] = 0;
+      if (ps.last_blocks[k] > 0)
+        finisher_order_sum((const double*)ps.h_part_sum.p + (size_t)k * ps.host_part_stride, (const int*)ps.h_part_zero.p + (size_t)k * ps.host_part_stride,
+                           ps.last_blocks[k], &out[0], &out[1]);
+      out[3] = (double)ps.mate[0].n_local();
+      ps.last_bad_bases = 0;
+    }
+  return 0;
+}
+
 // returns 1 when a set's tables did not fit the region reserved for it (the caller falls back for this chunk)
 static int batch_chunk_fast(gaml_hip_ctx* c, int n, const int32_t* paths, const int64_t* offs, const int32_t* set_offs,
                             double* partials_out, int32_t* tls) {
@@ -2205,7 +2343,8 @@ int gaml_hip_calc_prob_batch(gaml_hip_ctx* c, int32_t n_sets, const int32_t* pat
     int32_t tls[kMaxSets];
     while (done_sets < n_sets) {
       const int n = std::min<int32_t>(kMaxSets, n_sets - done_sets);
-      const int rc = n > 1 ? batch_chunk_fast(c, n, paths, offs, set_offs + done_sets, part.data(), tls) : 1;
+      int rc = n > 1 ? batch_chunk_patched(c, n, paths, offs, set_offs + done_sets, part.data(), tls) : 1;
+      if (rc > 0 && n > 1) rc = batch_chunk_fast(c, n, paths, offs, set_offs + done_sets, part.data(), tls);
       if (rc < 0) return rc;
       if (rc > 0) break;  // a single leftover set, or tables that outgrew their region: the sequential path takes the rest
       for (int k = 0; k < n; k++) {

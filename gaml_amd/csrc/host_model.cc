@@ -785,8 +785,38 @@ bool PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const int32_t*
       while (P < lim && prev_offs_[P + 1] == offs[P + 1] - base && prev_offs_[P + 1] <= d) P++;
     }
     while (S < lim - P && same(n_prev - 1 - S, n_paths - 1 - S)) S++;
+    // Between the common prefix and suffix: an edit script of (previous range -> new range) pairs with the common
+    // runs between them left alone. Two candidates of one assembly differ from each other in BOTH their edits, and
+    // what lies between the two is most of the set: greedy -- at a mismatch take the closest pair of equal paths
+    // within a few positions as the next point where the two lists run together again.
+    edits_.clear();
+    int32_t i = P, j = P;
+    const int32_t pe = n_prev - S, ce = n_paths - S;
+    int64_t changed = 0;
+    while (i < pe || j < ce) {
+      constexpr int32_t kReach = 4;
+      int32_t best_a = -1, best_b = -1;
+      for (int32_t sum = 1; sum <= 2 * kReach && best_a < 0; sum++)
+        for (int32_t a = std::max(0, sum - kReach); a <= std::min(sum, kReach); a++) {
+          const int32_t b = sum - a;
+          if (i + a < pe && j + b < ce && same(i + a, j + b)) { best_a = a; best_b = b; break; }
+        }
+      if (best_a < 0) { edits_.push_back(Edit{i, pe, j, ce}); changed += (pe - i) + (ce - j); break; }
+      edits_.push_back(Edit{i, i + best_a, j, j + best_b});
+      changed += best_a + best_b;
+      i += best_a; j += best_b;
+      // the common run: first differing int of the two flat arrays from here, then whole paths inside it
+      const int64_t a0 = prev_offs_[i], b0 = offs[j] - base;
+      const int64_t max_ints = std::min<int64_t>(prev_offs_[pe] - a0, (offs[ce] - base) - b0);
+      const int32_t* pa = prev_flat_.data() + a0;
+      const int32_t* pb = flat + base + b0;
+      int64_t d = 0;
+      while (d + 8 <= max_ints && memcmp(pa + d, pb + d, 8 * sizeof(int32_t)) == 0) d += 8;
+      while (d < max_ints && pa[d] == pb[d]) d++;
+      while (i < pe && j < ce && prev_offs_[i + 1] - a0 == (offs[j + 1] - base) - b0 && prev_offs_[i + 1] - a0 <= d) { i++; j++; }
+    }
     // more than half of the set changed: the whole-set rebuild is cheaper than path-by-path bookkeeping
-    if ((int64_t)(n_prev - P - S) + (n_paths - P - S) > (int64_t)(n_prev + n_paths) / 2) incremental_ = false;
+    if (changed > (int64_t)(n_prev + n_paths) / 2) incremental_ = false;
   }
   if (!incremental_) {
     // ---- from scratch: every path looked up, slots = positions
@@ -816,45 +846,58 @@ bool PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const int32_t*
     stale_.clear();  // (every memo of the set is looked at again by the next from-scratch call; an incremental one re-collects)
     for (int32_t id : cur_ids_) { const PathMemo& pm = *memos_[id]; if (!pm.valid[0] || !pm.valid[1]) stale_.push_back(id); }
   } else {
-    // ---- incremental: paths [P, n_prev - S) of the previous set leave, paths [P, n_paths - S) of this one enter
+    // ---- incremental: per edit, paths [p0, p1) of the previous set leave, paths [c0, c1) of this one enter
     incremental_calls++;
-    const int32_t out_end = n_prev - S, in_end = n_paths - S;
     std::vector<int32_t> freed_now;  // handed out again from the next call on
-    for (int32_t k = P; k < out_end; k++) {
-      PathMemo& pm = *memos_[cur_ids_[k]];
-      removed_.push_back(Removed{cur_slots_[k], {pm.assembled[0], pm.assembled[1]}, {pm.occ[0], pm.occ[1]}});  // lists as they stand: the memo may be evicted or rebuilt before apply()
-      pm.use_count--;
-      pm.last_used = clock_;  // in use up to the previous call (window retirement asks which paths were scored since the last rebuild)
-      total_len_ -= pm.length;
-      freed_now.push_back(cur_slots_[k]);
-    }
-    std::vector<int32_t> in_ids, in_slots;
-    for (int32_t k = P; k < in_end; k++) {
-      const int32_t id = lookup_or_create(g, path_ptr(k), path_len(k), err);
-      if (id < 0) {  // leave a consistent "nothing known" state: the next call starts from scratch
-        for (auto& pm : memos_) pm->use_count = 0;
-        cur_ids_.clear(); cur_slots_.clear(); stale_.clear(); removed_.clear(); work_.clear(); have_prev_ = false; incremental_ = false;
-        return false;
+    for (const Edit& e : edits_)
+      for (int32_t k = e.p0; k < e.p1; k++) {
+        PathMemo& pm = *memos_[cur_ids_[k]];
+        removed_.push_back(Removed{cur_slots_[k], {pm.assembled[0], pm.assembled[1]}, {pm.occ[0], pm.occ[1]}});  // lists as they stand: the memo may be evicted or rebuilt before apply()
+        pm.use_count--;
+        pm.last_used = clock_;  // in use up to the previous call (window retirement asks which paths were scored since the last rebuild)
+        total_len_ -= pm.length;
+        freed_now.push_back(cur_slots_[k]);
       }
-      memos_[id]->last_used = clock_;
-      memos_[id]->use_count++;
-      total_len_ += memos_[id]->length;
-      in_ids.push_back(id);
-      int32_t slot;
-      if (!free_slots_.empty()) { slot = free_slots_.back(); free_slots_.pop_back(); }
-      else slot = next_slot_++;
-      in_slots.push_back(slot);
-    }
+    std::vector<int32_t> in_ids, in_slots;  // of all edits, in path order
+    for (const Edit& e : edits_)
+      for (int32_t k = e.c0; k < e.c1; k++) {
+        const int32_t id = lookup_or_create(g, path_ptr(k), path_len(k), err);
+        if (id < 0) {  // leave a consistent "nothing known" state: the next call starts from scratch
+          for (auto& pm : memos_) pm->use_count = 0;
+          cur_ids_.clear(); cur_slots_.clear(); stale_.clear(); removed_.clear(); work_.clear(); have_prev_ = false; incremental_ = false;
+          return false;
+        }
+        memos_[id]->last_used = clock_;
+        memos_[id]->use_count++;
+        total_len_ += memos_[id]->length;
+        in_ids.push_back(id);
+        int32_t slot;
+        if (!free_slots_.empty()) { slot = free_slots_.back(); free_slots_.pop_back(); }
+        else slot = next_slot_++;
+        in_slots.push_back(slot);
+      }
     free_slots_.insert(free_slots_.end(), freed_now.begin(), freed_now.end());
-    cur_ids_.erase(cur_ids_.begin() + P, cur_ids_.begin() + out_end);
-    cur_ids_.insert(cur_ids_.begin() + P, in_ids.begin(), in_ids.end());
-    cur_slots_.erase(cur_slots_.begin() + P, cur_slots_.begin() + out_end);
-    cur_slots_.insert(cur_slots_.begin() + P, in_slots.begin(), in_slots.end());
+    {  // splice back to front: positions of earlier edits stay valid
+      size_t taken = in_ids.size();
+      for (size_t q = edits_.size(); q-- > 0;) {
+        const Edit& e = edits_[q];
+        const size_t cnt = (size_t)(e.c1 - e.c0);
+        taken -= cnt;
+        cur_ids_.erase(cur_ids_.begin() + e.p0, cur_ids_.begin() + e.p1);
+        cur_ids_.insert(cur_ids_.begin() + e.p0, in_ids.begin() + taken, in_ids.begin() + taken + cnt);
+        cur_slots_.erase(cur_slots_.begin() + e.p0, cur_slots_.begin() + e.p1);
+        cur_slots_.insert(cur_slots_.begin() + e.p0, in_slots.begin() + taken, in_slots.begin() + taken + cnt);
+      }
+    }
+    is_new_.assign((size_t)n_paths, 0);
+    for (const Edit& e : edits_) for (int32_t k = e.c0; k < e.c1; k++) is_new_[k] = 1;
     // registration: the new paths, and behind them everything up to the first path that has a node (its predecessor,
     // i.e. the last_end it sees, changed; paths without a node pass the value through)
-    int32_t chain_end = in_end;
-    while (chain_end < n_paths) { const bool has_node = memos_[cur_ids_[chain_end]]->final_last_end != -2; chain_end++; if (has_node) break; }
-    registration_chain(g, mate, P, chain_end);
+    for (const Edit& e : edits_) {
+      int32_t chain_end = e.c1;
+      while (chain_end < n_paths) { const bool has_node = memos_[cur_ids_[chain_end]]->final_last_end != -2; chain_end++; if (has_node) break; }
+      registration_chain(g, mate, e.c0, chain_end);
+    }
     // memos to (re)place: the new paths, and memos of the set that were invalidated since they were placed. A memo
     // is rebuilt once for all its instances; every instance's table entries are taken out first (with the lists as
     // they stand) and put back after pass 2.
@@ -888,7 +931,7 @@ bool PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const int32_t*
     for (int32_t k = 0; k < n_paths; k++) {
       const int32_t id = cur_ids_[k];
       if (!redo[id]) continue;
-      if (k < P || k >= in_end) {
+      if (!is_new_[k]) {
         const PathMemo& pm = *memos_[id];
         removed_.push_back(Removed{cur_slots_[k], {pm.assembled[0], pm.assembled[1]}, {pm.occ[0], pm.occ[1]}});
       }

@@ -341,6 +341,9 @@ class PairedPlanner {
   std::vector<int32_t> work_;            // path indices whose occurrences go (back) in after pass 2, ascending
   std::vector<int32_t> stale_;           // memos invalidated while in use: refreshed at the next begin()
   std::vector<char> redo_;
+  struct Edit { int32_t p0, p1, c0, c1; };  // paths [p0, p1) of the previous set are replaced by paths [c0, c1) of this one
+  std::vector<Edit> edits_;              // this call's edit script, ascending
+  std::vector<char> is_new_;             // per path of this call: entered with this call
   int32_t total_len_ = 0;
   int64_t assembled_[2] = {0, 0};
   uint64_t clock_ = 0, rebuild_clock_ = 0;

@@ -1308,6 +1308,46 @@ __global__ __launch_bounds__(kBlock) void mark_dirty_kernel(const int* slots, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// A batch's per-set occurrence tables, built on the device: set g = the resident tables (the path set of the
+// previous call) + the entries that changed from set to set, patches of sets 0..g applied in order. The host
+// writes only the patches (a few dozen 16-byte entries per candidate) instead of every set's whole tables.
+// ---------------------------------------------------------------------------------------------------------
+struct BatchPatch { int32_t w; uint32_t lo, hi; int32_t rank; };  // table entry w := {lo, hi, rank}
+struct BatchTabArgs {
+  const char* base;      // the resident tables
+  char* regions;         // set g at regions + g * stride, laid out like the resident tables
+  size_t stride;
+  size_t off_occ[2], bytes_occ[2], off_lo[2], bytes_lo[2], off_m[2], bytes_m[2];  // per mate; byte counts are multiples of 4
+  const BatchPatch* patches;
+  const int* patch_off;  // patches of (set g, mate mt): [patch_off[2 g + mt], patch_off[2 g + mt + 1])
+  int first;             // first set of this launch
+};
+
+__device__ __forceinline__ void block_copy_words(char* dst, const char* src, size_t bytes) {  // both 16-byte aligned
+  const size_t n16 = bytes / 16;
+  for (size_t i = threadIdx.x; i < n16; i += blockDim.x) ((int4*)dst)[i] = ((const int4*)src)[i];
+  const size_t done = n16 * 16;
+  for (size_t i = done / 4 + threadIdx.x; i < bytes / 4; i += blockDim.x) ((int*)dst)[i] = ((const int*)src)[i];
+}
+
+__global__ __launch_bounds__(1024) void batch_tables_kernel(BatchTabArgs a) {  // grid (sets of this launch, 2 mates)
+  const int g = a.first + (int)blockIdx.x, mt = (int)blockIdx.y;
+  char* region = a.regions + (size_t)g * a.stride;
+  block_copy_words(region + a.off_occ[mt], a.base + a.off_occ[mt], a.bytes_occ[mt]);
+  block_copy_words(region + a.off_lo[mt], a.base + a.off_lo[mt], a.bytes_lo[mt]);
+  block_copy_words(region + a.off_m[mt], a.base + a.off_m[mt], a.bytes_m[mt]);
+  int* occ = (int*)(region + a.off_occ[mt]);
+  for (int j = 0; j <= g; j++) {  // later sets override earlier ones
+    __syncthreads();
+    for (int t = a.patch_off[2 * j + mt] + (int)threadIdx.x; t < a.patch_off[2 * j + mt + 1]; t += blockDim.x) {
+      const BatchPatch pt = a.patches[t];
+      int* e = occ + 3 * (size_t)pt.w;
+      e[0] = (int)pt.lo; e[1] = (int)pt.hi; e[2] = pt.rank;
+    }
+  }
+}
+
 // bad_bases of a paired set with coverage penalty: u64 counter of the sweep -> its partial slot
 // (scale 0: a rank other than 0 of a sharded evaluation -- the all-reduce(sum) of the partials must
 // count the value once)

@@ -893,7 +893,6 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
     c->prof[6] = (double)L.total;
   }
   const double tp2 = now_us();
-  c->prof[2] = 0;
   c->prof[3] = tp2 - tp1;  // per-call tables written (directly into device memory, or staged)
 
   PairedArgs a;

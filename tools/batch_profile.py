@@ -38,3 +38,4 @@ for fs in flat_sets:
     for f in fs: ctx.score(f); prof.append(ctx.debug_profile())
 print("median phases [pass1, tables_host, -, write, sync, launch, bytes, wait]:", np.round(np.median(np.array(prof), axis=0), 1))
 print(ctx.debug_table_occurrences(rs, 0)[1], ctx.debug_table_stats(rs))
+ctx.close()

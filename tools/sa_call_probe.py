@@ -27,3 +27,4 @@ for k, p in enumerate(seq):
         nodes = sorted(set(abs(x) for q in p for x in q) - set(abs(x) for q in (seq[k - 1] if k else start) for x in q))
         print("   nodes new to the path set:", [(n, int(g.lens[n]) if hasattr(g, "lens") else None) for n in nodes][:10])
 ctx.close()
+ctx.close()

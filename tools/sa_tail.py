@@ -29,7 +29,7 @@ for knob6 in (0,):
     al = kinds > 0
     print(f"knob6={knob6}: total {per.sum() / 1e3:.1f} ms, median {np.median(per):.1f}, p90 {np.percentile(per, 90):.1f}, p99 {np.percentile(per, 99):.1f}, max {per.max():.0f} us; "
           f"calls that aligned windows: {al.sum()} (median {np.median(per[al]):.0f} us, p90 {np.percentile(per[al], 90):.0f}); others median {np.median(per[~al]):.1f} p99 {np.percentile(per[~al], 99):.1f}")
-    print("   aligning calls, median phases [pass1, tables_host, -, write, sync(delta), launch, bytes, wait]:", np.round(np.median(prof[al], axis=0), 1))
+    print("   aligning calls, median phases [pass1, tables_host, align (in pass1), write, sync(delta), launch, bytes, wait]:", np.round(np.median(prof[al], axis=0), 1))
     print("   other calls,    median phases:", np.round(np.median(prof[~al], axis=0), 1))
     order = np.argsort(-per)[:8]
     for k in order: print(f"   slow call {k}: {per[k]:.0f} us, windows aligned {kinds[k]}, phases", np.round(prof[k], 1))
