@@ -2087,6 +2087,8 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
     int slot = 0; char* wp = nullptr; size_t stride = 0;
     PairedLayout L; std::vector<PairedLayout> Ls; std::vector<PairedPrep> prep;
     std::vector<int> patch_off; size_t n_patches = 0;
+    size_t tail_fixed = 0, chg_bytes[2] = {0, 0};
+    int launches = 0;
     std::vector<int32_t> touched[2];  // union of the changed entries: the resident copy follows after the batch
   };
   std::vector<PerSet> per(nps);
@@ -2110,7 +2112,10 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
     r.Ls.assign((size_t)n, r.L);
     r.prep.resize((size_t)n);
     r.patch_off.assign(2 * (size_t)n + 1, 0);
-    const size_t bytes = r.stride * (size_t)n + align16(kPatchCap * sizeof(BatchPatch)) + align16((2 * (size_t)kMaxSets + 1) * sizeof(int));
+    // behind the regions: the patches, their offsets, and per launch and mate one byte per table entry (MultiSets::chg)
+    r.chg_bytes[0] = align16(P.cap_w[0]); r.chg_bytes[1] = align16(P.cap_w[1]);
+    r.tail_fixed = align16(kPatchCap * sizeof(BatchPatch)) + align16((2 * (size_t)kMaxSets + 1) * sizeof(int));
+    const size_t bytes = r.stride * (size_t)n + r.tail_fixed + 2 * (r.chg_bytes[0] + r.chg_bytes[1]);
     if (int e = arena_acquire(c, ps.arena, bytes, st, &r.slot, &r.wp)) return e;
   }
   auto give_up = [&](bool in_flight) -> int {  // the resident copies no longer mirror the images: rewritten as a whole next time
@@ -2143,9 +2148,16 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
       ta.patches = (const BatchPatch*)((const char*)ps.arena.dev[r.slot] + r.stride * (size_t)n);
       ta.patch_off = (const int*)((const char*)ta.patches + align16(kPatchCap * sizeof(BatchPatch)));
       ta.first = launched;
-      hipLaunchKernelGGL(batch_tables_kernel, dim3((unsigned)(upto - launched), 2), dim3(1024), 0, st, ta);
+      ta.n_sets = upto - launched;
+      char* chg0 = (char*)ps.arena.dev[r.slot] + r.stride * (size_t)n + r.tail_fixed + (size_t)(r.launches & 1) * (r.chg_bytes[0] + r.chg_bytes[1]);
+      ta.chg[0] = (unsigned char*)chg0; ta.chg[1] = (unsigned char*)chg0 + r.chg_bytes[0];
+      ta.chg_bytes[0] = r.chg_bytes[0]; ta.chg_bytes[1] = r.chg_bytes[1];
+      r.launches++;
+      hipLaunchKernelGGL(batch_tables_kernel, dim3((unsigned)(upto - launched) + 1, 2), dim3(1024), 0, st, ta);
       HIP_TRY(c, hipGetLastError());
-      if (int e = launch_paired_multi(c, ps, launched, upto - launched, r.Ls.data(), r.prep.data(), tls, (const char*)ps.arena.dev[r.slot], r.stride, st)) return e;
+      const unsigned char* chg[2] = {ta.chg[0], ta.chg[1]};
+      if (int e = launch_paired_multi(c, ps, launched, upto - launched, r.Ls.data(), r.prep.data(), tls, (const char*)ps.arena.dev[r.slot], r.stride, st,
+                                      c->knobs[11] == 3 ? nullptr : chg)) return e;  // knob 11 = 3: every set resolves every pair (A/B)
     }
     launched = upto;
     return 0;
@@ -2184,6 +2196,11 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
     if (k + 1 == half && half < n) { if (int e = launch_upto(half)) return e; }
   }
   if (int e = launch_upto(n)) return e;
+  if (getenv("GAML_HIP_TRACE_HOST")) {
+    fprintf(stderr, "batch of %d sets, patch entries per set (mate 1 + mate 2):", n);
+    for (int k = 0; k < n; k++) fprintf(stderr, " %d+%d", per[0].patch_off[2 * k + 1] - per[0].patch_off[2 * k], per[0].patch_off[2 * k + 2] - per[0].patch_off[2 * k + 1]);
+    fprintf(stderr, "\n");
+  }
   bool spun = false;
   if (int e = wait_host_partials(c, &spun)) return e;
   if (!spun) { if (int e2 = collect_events(c)) return e2; }

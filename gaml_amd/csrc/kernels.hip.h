@@ -275,8 +275,15 @@ __device__ __forceinline__ void grid_finish(double s, int z, int my_slot, int n_
   }
 }
 
+// What a pair contributes before the path set's 2T and floor threshold enter: a batch of path sets resolves a pair
+// once and finishes it per set (finish_val) wherever the sets' tables agree on the pair's windows.
+// kind 0: nothing here (scored elsewhere, or not at all); 1: a memo entry {t, log t}, key = length code;
+// 2: class 0 outside the memo, key = length code; 3: table classes, key = L1 + L2
+struct PairVal { double t, logt; int key, kind; };
+
 // per-read floor + log (GetTotalProb graph.cc:1504-1513)
-__device__ __forceinline__ void finish_read(const PairedArgs& a, int i, double acc, int L1, int L2, double& lsum, int& zeros) {
+__device__ __forceinline__ void finish_read(const PairedArgs& a, int i, double acc, int L1, int L2, double& lsum, int& zeros, PairVal* cap = nullptr) {
+  if (cap) *cap = PairVal{acc, 0.0, L1 + L2, 3};
   a.probs[i] = acc;
   const double p = acc / a.two_T;
   const int s = L1 + L2;
@@ -393,7 +400,8 @@ __global__ __launch_bounds__(kBlock) void logterm_kernel(const double* pe0, cons
   }
 }
 
-__device__ __forceinline__ void finish_read_compact(const PairedArgs& a, int i, double acc, int lc, double& lsum, int& zeros) {
+__device__ __forceinline__ void finish_read_compact(const PairedArgs& a, int i, double acc, int lc, double& lsum, int& zeros, PairVal* cap = nullptr) {
+  if (cap) *cap = PairVal{acc, 0.0, lc, 2};
   a.probs[i] = acc;
   if (acc == 0.0 && a.floor_c[lc] > 0.0) { zeros++; lsum += a.logfloor_c[lc]; return; }  // 0 / 2T < floor
   const double p = acc / a.two_T;
@@ -462,9 +470,10 @@ __device__ __forceinline__ void compact_general(const PairedArgs& a, int i, doub
 
 // one scored class-0 pair: per-read probability out, floor / log into the running sums
 __device__ __forceinline__ void compact_finish(const PairedArgs& a, int i, const Compact1& c, const CompactPrep& q, double2 m,
-                                               double& lsum, int& zeros) {
+                                               double& lsum, int& zeros, PairVal* cap = nullptr) {
   if (q.memo_idx >= 0) {
     const double t = m.x;
+    if (cap) *cap = PairVal{t, m.y, c.lc, 1};
     compact_cover(a, c, q, t);
     __builtin_nontemporal_store(t, &a.probs[i]);  // written once, read by nobody on the hot path: keep it out of the caches
     const bool floored = t < a.tfloor_c[c.lc];    // <=> t / 2T < floor (PairedArgs::memo)
@@ -474,7 +483,27 @@ __device__ __forceinline__ void compact_finish(const PairedArgs& a, int i, const
   }
   double t = 0.0;
   if (q.scores) { t = compact_term_tables(a, c, q); compact_cover(a, c, q, t); }
-  finish_read_compact(a, i, t, c.lc, lsum, zeros);
+  finish_read_compact(a, i, t, c.lc, lsum, zeros, cap);
+}
+
+// a captured pair under another path set's 2T / thresholds (`a`: that set's view): exactly what the finishers above do
+__device__ __forceinline__ void finish_val(const PairedArgs& a, int i, const PairVal& v, bool store, double& lsum, int& zeros) {
+  if (v.kind == 0) return;
+  if (store) __builtin_nontemporal_store(v.t, &a.probs[i]);
+  if (v.kind == 1) {
+    const bool floored = v.t < a.tfloor_c[v.key];
+    lsum += floored ? a.logfloor_c[v.key] : v.logt - a.log_two_T;
+    zeros += (int)floored;
+  } else if (v.kind == 2) {
+    if (v.t == 0.0 && a.floor_c[v.key] > 0.0) { zeros++; lsum += a.logfloor_c[v.key]; return; }
+    const double p = v.t / a.two_T;
+    if (p < a.floor_c[v.key]) { zeros++; lsum += a.logfloor_c[v.key]; }
+    else lsum += log(p);
+  } else {
+    const double p = v.t / a.two_T;
+    if (p < a.floor_tab[v.key]) { zeros++; lsum += a.logfloor_tab[v.key]; }
+    else lsum += log(p);
+  }
 }
 
 __device__ __forceinline__ void compact_load(const PairedArgs& a, int i, bool ok, Compact1& c) {
@@ -653,7 +682,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
 // up to K live candidates per mate in registers -> per-read probability, floor / log, running sums
 template <int K>
 __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int i, uint32_t l12, const RegCands<K>& x, const RegCands<K>& y,
-                                                       double& lsum, int& zeros) {
+                                                       double& lsum, int& zeros, PairVal* cap = nullptr) {
   const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     // Junction duplicates: the overwrite rule usually leaves one alignment per mate, i.e. one pair
     // term -- the value the compact path looks up in the memo (same table, same index).
@@ -678,13 +707,13 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
           c.lc = code; c.L1 = L1; c.L2 = L2;
           q.dist = dist; q.scores = true; q.skip = false;
           q.memo_idx = ((code * 7 + q.x.edit) * 7 + q.y.edit) * a.ins_n + dist;
-          compact_finish(a, i, c, q, a.memo[q.memo_idx], lsum, zeros);
+          compact_finish(a, i, c, q, a.memo[q.memo_idx], lsum, zeros, cap);
           return;
         }
       }
     }
     const double acc = score_regs<K>(a, x, y, L1, L2);
-    finish_read(a, i, acc, L1, L2, lsum, zeros);
+    finish_read(a, i, acc, L1, L2, lsum, zeros, cap);
 }
 
 // Classes 1 and 2: at most K = 2 / 4 records per mate, 16-byte records, overwrite rule in registers.
@@ -970,13 +999,19 @@ struct SetDev {  // what differs between the path sets of one batch
   double* part_sum;                // this set's per-block partials
   int* part_zero;
 };
-struct MultiSets { int n; int pad_; SetDev set[kMaxSets]; };
+// chg[mt][w]: bit s set = window w's table entry in set s of this launch may differ from set 0's (s >= 1; a batch whose
+// sets' tables were built from patches knows, batch_tables_kernel). A pair none of whose records touch such a window
+// resolves to the same candidates in set s as in set 0: its set-0 result is finished again under set s's 2T and
+// thresholds, no table is read. The bits are cumulative (bit s implies bit s + 1: a set's tables are its
+// predecessor's plus a patch). Null: unknown, every set resolves every pair.
+struct MultiSets { int n; int pad_; const unsigned char* chg[2]; SetDev set[kMaxSets]; };
 
-__device__ __forceinline__ PairedArgs with_set(const PairedArgs& a, const SetDev& sd) {
+constexpr int kTfCodes = 16;  // length codes whose per-set thresholds a multi-set block keeps in LDS
+__device__ __forceinline__ PairedArgs with_set(const PairedArgs& a, const SetDev& sd, const double* tfloor_lds = nullptr) {
   PairedArgs b = a;
 #pragma unroll
   for (int mt = 0; mt < 2; mt++) { b.m[mt].occ12 = sd.occ12[mt]; b.occ12[mt] = sd.occ12[mt]; b.m[mt].multi_off = sd.multi_off[mt]; b.m[mt].multi = sd.multi[mt]; }
-  b.tfloor_c = sd.tfloor_c; b.two_T = sd.two_T; b.log_two_T = sd.log_two_T; b.gen_bits = sd.gen_bits;
+  b.tfloor_c = tfloor_lds ? tfloor_lds : sd.tfloor_c; b.two_T = sd.two_T; b.log_two_T = sd.log_two_T; b.gen_bits = sd.gen_bits;
   b.part_sum = sd.part_sum; b.part_zero = sd.part_zero;
   return b;
 }
@@ -984,7 +1019,7 @@ __device__ __forceinline__ PairedArgs with_set(const PairedArgs& a, const SetDev
 // paired_compact4_body with the path sets in the inner loop. acc_s / acc_z: one running sum per (set, thread) in LDS
 // (a lane may take several rounds of four pairs; registers cannot be indexed by the set number).
 template <bool GEN, bool ONE>
-__device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, const MultiSets& ms, int lb, double* acc_s, int* acc_z) {
+__device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, const MultiSets& ms, int lb, double* acc_s, int* acc_z, const double* tf) {
   const unsigned stride = (unsigned)a.blocks0 * kBlock, n0 = (unsigned)a.n0;
   const char* const rec0 = (const char*)a.rec8[0];
   const char* const rec1 = (const char*)a.rec8[1];
@@ -992,40 +1027,55 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
   char* const probs = (char*)a.probs;
   const uint32_t l12_one = ONE ? a.len_combo[0] : 0u;
   const double logfloor_one = ONE ? a.logfloor_c[0] : 0.0;
-  for (int s = 0; s < ms.n; s++) { acc_s[s * kBlock + threadIdx.x] = 0.0; acc_z[s * kBlock + threadIdx.x] = 0; }
   for (unsigned base = (unsigned)lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
     uint2 r1[4], r2[4];
     unsigned lc[4];
+    unsigned chg = ms.chg[0] ? 0u : ~0u;  // per pair k: byte k = the sets (bits) whose tables may differ from set 0's on its windows
 #pragma unroll
     for (int k = 0; k < 4; k++) {  // the records: ONCE for all sets
       const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
       r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); lc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
     }
+    if (ms.chg[0]) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned c1 = r1[k].y != ~0u ? ms.chg[0][r1[k].x & 0xffffffu] : 0u, c2 = r2[k].y != ~0u ? ms.chg[1][r2[k].x & 0xffffffu] : 0u;
+        chg |= (c1 | c2) << (8 * k);
+      }
+    }
+    int state[4];       // of the last set that resolved this pair: set 0, or a later one that had to (and then every set after it has to: the bits of `chg` are cumulative)
+    double2 m[4];
+    unsigned skip_bits = 0;
 #pragma unroll 1
     for (int s = 0; s < ms.n; s++) {
       const SetDev& sd = ms.set[s];
       const char* const occ0 = (const char*)sd.occ12[0];
       const char* const occ1 = (const char*)sd.occ12[1];
-      const double log2T = sd.log_two_T, tfloor_one = ONE ? sd.tfloor_c[0] : 0.0;
+      const double* const tfs = tf ? tf + s * kTfCodes : sd.tfloor_c;  // this set's thresholds per length code (LDS copy when it fits)
+      const double log2T = sd.log_two_T, tfloor_one = ONE ? tfs[0] : 0.0;
       const bool last_set = s == ms.n - 1;  // per-read probabilities: those of the last set, as after a sequence of calls
-      uint2 o1[4], o2[4];
+      // resolve against this set's tables: set 0 always; a later set only the (wave's) pairs on changed windows --
+      // pairs are ordered by window, so those sit in a few wavefronts and the others skip both round trips
+      const unsigned need = s == 0 ? 0x01010101u : (chg >> s) & 0x01010101u;
+      if (s == 0 || __any(need != 0)) {
+        uint2 o1[4], o2[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const Occ12* e1 = (const Occ12*)(occ0 + (r1[k].y != ~0u ? (r1[k].x & 0xffffffu) : 0u) * 12u);
-        const Occ12* e2 = (const Occ12*)(occ1 + (r2[k].y != ~0u ? (r2[k].x & 0xffffffu) : 0u) * 12u);
-        o1[k] = make_uint2(e1->lo, e1->hi); o2[k] = make_uint2(e2->lo, e2->hi);
+        for (int k = 0; k < 4; k++) {
+          const bool go = (need >> (8 * k)) & 1u;
+          const Occ12* e1 = (const Occ12*)(occ0 + (go && r1[k].y != ~0u ? (r1[k].x & 0xffffffu) : 0u) * 12u);
+          const Occ12* e2 = (const Occ12*)(occ1 + (go && r2[k].y != ~0u ? (r2[k].x & 0xffffffu) : 0u) * 12u);
+          o1[k] = make_uint2(e1->lo, e1->hi); o2[k] = make_uint2(e2->lo, e2->hi);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (!((need >> (8 * k)) & 1u)) continue;
+          bool skip;
+          state[k] = compact_state(a, r1[k], r2[k], o1[k], o2[k], lc[k], ONE ? l12_one : a.len_combo[lc[k]], base + k * stride < n0, skip);
+          skip_bits = (skip_bits & ~(1u << k)) | ((unsigned)skip << k);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) if ((need >> (8 * k)) & 1u) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
       }
-      int state[4];
-      unsigned skip_bits = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        bool skip;
-        state[k] = compact_state(a, r1[k], r2[k], o1[k], o2[k], lc[k], ONE ? l12_one : a.len_combo[lc[k]], base + k * stride < n0, skip);
-        skip_bits |= (unsigned)skip << k;
-      }
-      double2 m[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
       if (GEN) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1041,7 +1091,7 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
         double* const out = (double*)(probs + (base + k * stride) * 8u);
         if (state[k] >= 0) {
           if (last_set) __builtin_nontemporal_store(m[k].x, out);
-          const bool floored = m[k].x < (ONE ? tfloor_one : sd.tfloor_c[lc[k]]);
+          const bool floored = m[k].x < (ONE ? tfloor_one : tfs[lc[k]]);
           lsum += floored ? (ONE ? logfloor_one : a.logfloor_c[lc[k]]) : m[k].y - log2T;
           zeros += (int)floored;
         } else if (state[k] > kPairOther) {
@@ -1051,7 +1101,7 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
         } else other |= state[k] == kPairOther && !((skip_bits >> k) & 1u);
       }
       if (__any(other)) {  // scores, but outside the memo: from the tables (rare)
-        const PairedArgs b = with_set(a, sd);
+        const PairedArgs b = with_set(a, sd, tf ? tfs : nullptr);
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
           if (state[k] != kPairOther || ((skip_bits >> k) & 1u)) continue;
@@ -1073,28 +1123,194 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
   }
 }
 
+// Classes 1 and 2 with the path sets in the inner loop (paired_regs_body's pairs, lane -> pair mapping and order of
+// additions): records once, set 0 resolved and captured, later sets finished from the capture unless one of the
+// pair's windows changed.
+template <int K, bool GEN>
+__device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, const MultiSets& ms, int lb, int slot_lo, int slot_hi, int block_lo,
+                                                       int block_hi, double* acc_s, int* acc_z, const double* tf) {
+  for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
+    const uint32_t l12 = a.len12[i - a.n0];
+    const size_t at = K == 2 ? (size_t)2 * (i - a.n0) : (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01);
+    int4 r1[K], r2[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { r1[k] = a.inl[0][at + k]; r2[k] = a.inl[1][at + k]; }
+    const bool dirty = r1[0].x == kDirtyWid;  // scored from the delta lists
+    unsigned chg = ms.chg[0] ? 0u : 0xffu;
+    if (ms.chg[0] && !dirty) {
+#pragma unroll
+      for (int k = 0; k < K; k++) chg |= (r1[k].x >= 0 ? ms.chg[0][r1[k].x] : 0u) | (r2[k].x >= 0 ? ms.chg[1][r2[k].x] : 0u);
+    }
+    PairVal val{0.0, 0.0, 0, 0};
+    bool general = false;
+#pragma unroll 1
+    for (int s = 0; s < ms.n; s++) {
+      const PairedArgs b = with_set(a, ms.set[s], tf ? tf + s * kTfCodes : nullptr);
+      double lsum = acc_s[s * kBlock + threadIdx.x];
+      int zeros = acc_z[s * kBlock + threadIdx.x];
+      if (s == 0 || ((chg >> s) & 1u)) {
+        RegCands<K> x, y;
+        const bool m1 = cands_from_records<K>(b.m[0], r1, x), m2 = cands_from_records<K>(b.m[1], r2, y);
+        general = !dirty && (m1 || m2);  // a window that occurs several times: paired_general_kernel
+        val.kind = 0;
+        if (!dirty && !general) score_cands_and_finish<K>(b, i, l12, x, y, lsum, zeros, &val);
+      } else {
+        finish_val(b, i, val, s == ms.n - 1, lsum, zeros);
+      }
+      if (GEN) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
+        unsigned long long* bits = b.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2);
+        const unsigned long long k = __ballot(general);
+        if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
+      }
+      acc_s[s * kBlock + threadIdx.x] = lsum;
+      acc_z[s * kBlock + threadIdx.x] = zeros;
+    }
+  }
+}
+
+// paired_delta_body with the path sets in the inner loop
+__device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, const MultiSets& ms, int db, int delta_blocks, double* acc_s, int* acc_z, const double* tf) {
+  for (int dj = db * kBlock + threadIdx.x; dj < a.n_dirty; dj += delta_blocks * kBlock) {
+    const int i = a.dirty_slots[dj];
+    const int sp = a.dirty_spill[dj];
+    const uint32_t l12 = i < a.n0 ? a.len_combo[a.len_code[i]] : a.len12[i - a.n0];
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    if (sp >= 0) continue;  // a long list: one WAVE scores it
+    int4 r0[4], r1[4];
+    int c0 = 0, c1 = 0;
+    unsigned chg = ms.chg[0] ? 0u : 0xffu;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      r0[k] = a.dirty_recs[0][4 * (size_t)dj + k];
+      r1[k] = a.dirty_recs[1][4 * (size_t)dj + k];
+      c0 += r0[k].x >= 0; c1 += r1[k].x >= 0;
+      if (ms.chg[0]) chg |= (r0[k].x >= 0 ? ms.chg[0][r0[k].x] : 0u) | (r1[k].x >= 0 ? ms.chg[1][r1[k].x] : 0u);
+    }
+    PairVal val{0.0, 0.0, 0, 0};
+#pragma unroll 1
+    for (int s = 0; s < ms.n; s++) {
+      const PairedArgs b = with_set(a, ms.set[s], tf ? tf + s * kTfCodes : nullptr);
+      double lsum = acc_s[s * kBlock + threadIdx.x];
+      int zeros = acc_z[s * kBlock + threadIdx.x];
+      if (s == 0 || ((chg >> s) & 1u)) {
+        RegCands<4> x, y;
+        const bool m0 = cands_from_records<4>(b.m[0], r0, x), m1 = cands_from_records<4>(b.m[1], r1, y);
+        if (!(m0 || m1)) score_cands_and_finish<4>(b, i, l12, x, y, lsum, zeros, &val);
+        else {  // a window that occurs several times in this path set: general loop over the same records
+          const double acc = paired_general_src(b, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
+          finish_read(b, i, acc, L1, L2, lsum, zeros, &val);
+        }
+      } else {
+        finish_val(b, i, val, s == ms.n - 1, lsum, zeros);
+      }
+      acc_s[s * kBlock + threadIdx.x] = lsum;
+      acc_z[s * kBlock + threadIdx.x] = zeros;
+    }
+  }
+}
+
+// the sets (bits) in which one of a pair's windows changed, over all its records of one mate: lanes stride, wave OR
+template <class Src>
+__device__ __forceinline__ unsigned wave_changed(const Src& src, const unsigned char* chg, int lane) {
+  unsigned m = 0;
+  const int cnt = src.count();
+  for (int k = lane; k < cnt; k += 64) { const int4 r = src.get(k); if (r.x >= 0) m |= chg[r.x]; }
+  for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off, 64);
+  return m;
+}
+
+// paired_overflow_body with the path sets in the inner loop: wave w keeps its running sums per set in acc (lane 0's)
+__device__ __forceinline__ void paired_overflow_multi_body(const PairedArgs& a, const MultiSets& ms, int ovf_block, int ovf_blocks,
+                                                           int4 (*cand)[2][kOvfCap], double* acc_s, int* acc_z, const double* tf) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = ovf_block * (kBlock / 64) + wave;
+  const int n_waves = ovf_blocks * (kBlock / 64);
+  const int n_table = a.n - a.n_main;
+  const int n_items = n_table + a.n_spill;
+  int4* c1 = cand[wave][0];
+  int4* c2 = cand[wave][1];
+  for (int item = wave_global; item < n_items; item += n_waves) {  // fixed item -> wave assignment
+    int i, L1, L2;
+    TableSrc t1{&a.m[0], make_int4(-1, 0, 0, 0)}, t2{&a.m[1], make_int4(-1, 0, 0, 0)};
+    ListSrc l1{nullptr, 0}, l2{nullptr, 0};
+    const bool table = item < n_table;
+    if (table) {
+      i = a.n_main + item;
+      t1.r0 = a.m[0].first[i - a.n0]; t2.r0 = a.m[1].first[i - a.n0];
+      const uint32_t l12 = a.len12[i - a.n0];
+      if (t1.r0.x == kDirtyWid) continue;  // a class-3 pair that is on the delta list: scored there
+      L1 = l12 & 0xffff; L2 = l12 >> 16;
+    } else {
+      const int sp = item - n_table;
+      i = a.spill_slot[sp];
+      const uint32_t l12 = i < a.n0 ? a.len_combo[a.len_code[i]] : a.len12[i - a.n0];
+      L1 = l12 & 0xffff; L2 = l12 >> 16;
+      const int b0 = a.spill_off[0][sp], b1 = a.spill_off[1][sp];
+      l1 = ListSrc{a.spill_recs[0] + b0, a.spill_off[0][sp + 1] - b0};
+      l2 = ListSrc{a.spill_recs[1] + b1, a.spill_off[1][sp + 1] - b1};
+    }
+    unsigned chg = 0xffu;
+    if (ms.chg[0]) chg = table ? (wave_changed(t1, ms.chg[0], lane) | wave_changed(t2, ms.chg[1], lane)) : (wave_changed(l1, ms.chg[0], lane) | wave_changed(l2, ms.chg[1], lane));
+    PairVal val{0.0, 0.0, 0, 0};
+    for (int s = 0; s < ms.n; s++) {
+      const PairedArgs b = with_set(a, ms.set[s], tf ? tf + s * kTfCodes : nullptr);
+      double lsum = 0.0;
+      int zeros = 0;
+      if (s == 0 || ((chg >> s) & 1u)) {  // wave-uniform
+        TableSrc u1{&b.m[0], t1.r0}, u2{&b.m[1], t2.r0};
+        const double acc = table ? wave_score_pair(b, u1, u2, L1, L2, c1, c2, lane) : wave_score_pair(b, l1, l2, L1, L2, c1, c2, lane);
+        if (lane == 0) finish_read(b, i, acc, L1, L2, lsum, zeros, &val);
+      } else if (lane == 0) {
+        finish_val(b, i, val, s == ms.n - 1, lsum, zeros);
+      }
+      if (lane == 0) { acc_s[s * (kBlock / 64) + wave] += lsum; acc_z[s * (kBlock / 64) + wave] += zeros; }
+    }
+  }
+}
+
 template <bool GEN>
 __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArgs a, MultiSets ms) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
-  // the wave-per-pair blocks stage candidates here (16 KB), the compact blocks keep their per-set running sums here
-  // (8 sets x 256 threads x (8 + 4) B = 24 KB): block-uniform roles, one buffer
+  // the lane-per-pair blocks keep one running sum per (set, thread) here (8 sets x 256 threads x (8 + 4) B = 24 KB);
+  // the wave-per-pair blocks stage candidates here (16 KB) and keep one running sum per (set, wave) behind them:
+  // block-uniform roles, one buffer
   __shared__ __align__(16) unsigned char sh_raw[kMaxSets * kBlock * 12];
-  static_assert(sizeof(int4) * (kBlock / 64) * 2 * kOvfCap <= sizeof(sh_raw), "candidate staging must fit");
+  constexpr size_t kCandBytes = sizeof(int4) * (kBlock / 64) * 2 * kOvfCap;
+  static_assert(kCandBytes + kMaxSets * (kBlock / 64) * 12 <= sizeof(sh_raw), "candidate staging + per-wave sums must fit");
   const int lb = a.total_blocks - 1 - (int)blockIdx.x;
-  if (lb < a.blocks0 && a.memo && !a.cov_bits) {
+  // every set's thresholds per length code: read once per block (they sit in host-written device memory, a round trip
+  // each), not once per set and pair
+  __shared__ double sh_tf[kMaxSets * kTfCodes];
+  const double* tf = a.n_codes <= kTfCodes ? sh_tf : nullptr;
+  if (tf && threadIdx.x < kMaxSets * kTfCodes) {
+    const int s = threadIdx.x / kTfCodes, k = threadIdx.x % kTfCodes;
+    sh_tf[threadIdx.x] = s < ms.n && k < a.n_codes ? ms.set[s].tfloor_c[k] : 0.0;
+  }
+  if (lb < a.main_blocks) {
     double* acc_s = (double*)sh_raw;
     int* acc_z = (int*)(sh_raw + kMaxSets * kBlock * 8);
-    if (a.n_codes == 1) paired_compact4_multi_body<GEN, true>(a, ms, lb, acc_s, acc_z);
-    else {
-      __shared__ uint32_t sh_combo[256];
-      __shared__ double sh_logfloor[256];
-      for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_logfloor[k] = a.logfloor_c[k]; }
-      __syncthreads();
-      PairedArgs b = a;
-      b.len_combo = sh_combo; b.logfloor_c = sh_logfloor;
-      paired_compact4_multi_body<GEN, false>(b, ms, lb, acc_s, acc_z);
+    for (int s = 0; s < ms.n; s++) { acc_s[s * kBlock + threadIdx.x] = 0.0; acc_z[s * kBlock + threadIdx.x] = 0; }
+    __syncthreads();
+    const int cls = lb < a.blocks0 ? 0 : lb < a.blocks01 ? 1 : lb < a.blocks012 ? 2 : 3;
+    if ((ms.pad_ >> cls) & 1) {  // timing experiments (tools/): a class of blocks left out, results wrong
+      if (threadIdx.x == 0) for (int s = 0; s < ms.n; s++) { ms.set[s].part_sum[lb] = 0.0; ms.set[s].part_zero[lb] = 0; }
+      return;
     }
+    if (lb < a.blocks0) {
+      if (a.n_codes == 1) paired_compact4_multi_body<GEN, true>(a, ms, lb, acc_s, acc_z, tf);
+      else {
+        __shared__ uint32_t sh_combo[256];
+        __shared__ double sh_logfloor[256];
+        for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_logfloor[k] = a.logfloor_c[k]; }
+        __syncthreads();
+        PairedArgs b = a;
+        b.len_combo = sh_combo; b.logfloor_c = sh_logfloor;
+        paired_compact4_multi_body<GEN, false>(b, ms, lb, acc_s, acc_z, tf);
+      }
+    } else if (lb < a.blocks01) paired_regs_multi_body<2, GEN>(a, ms, lb, a.n0, a.n01, a.blocks0, a.blocks01, acc_s, acc_z, tf);
+    else if (lb < a.blocks012) paired_regs_multi_body<4, GEN>(a, ms, lb, a.n01, a.n_main, a.blocks01, a.blocks012, acc_s, acc_z, tf);
+    else paired_delta_multi_body(a, ms, lb - a.blocks012, a.main_blocks - a.blocks012, acc_s, acc_z, tf);
     for (int s = 0; s < ms.n; s++) {
       double lsum = acc_s[s * kBlock + threadIdx.x];
       int zeros = acc_z[s * kBlock + threadIdx.x];
@@ -1104,10 +1320,22 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArg
     }
     return;
   }
-  for (int s = 0; s < ms.n; s++) {  // the other classes: the single-set body, once per set
-    const PairedArgs b = with_set(a, ms.set[s]);
-    if (lb < a.main_blocks) paired_main_body<false, GEN, false>(b, lb, sh_s, sh_z);
-    else paired_overflow_body<false>(b, lb - a.main_blocks, a.total_blocks - a.main_blocks, sh_s, sh_z, (int4(*)[2][kOvfCap])sh_raw);
+  if ((ms.pad_ >> 4) & 1) {
+    if (threadIdx.x == 0) for (int s = 0; s < ms.n; s++) { ms.set[s].part_sum[lb] = 0.0; ms.set[s].part_zero[lb] = 0; }
+    return;
+  }
+  double* acc_s = (double*)(sh_raw + kCandBytes);
+  int* acc_z = (int*)(sh_raw + kCandBytes + kMaxSets * (kBlock / 64) * 8);
+  if (threadIdx.x < kMaxSets * (kBlock / 64)) { acc_s[threadIdx.x] = 0.0; acc_z[threadIdx.x] = 0; }
+  __syncthreads();
+  paired_overflow_multi_body(a, ms, lb - a.main_blocks, a.total_blocks - a.main_blocks, (int4(*)[2][kOvfCap])sh_raw, acc_s, acc_z, tf);
+  __syncthreads();
+  for (int s = 0; s < ms.n; s++) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double lsum = lane == 0 ? acc_s[s * (kBlock / 64) + wave] : 0.0;
+    int zeros = lane == 0 ? acc_z[s * (kBlock / 64) + wave] : 0;
+    block_reduce(lsum, zeros, sh_s, sh_z);
+    if (threadIdx.x == 0) { ms.set[s].part_sum[lb] = lsum; ms.set[s].part_zero[lb] = zeros; }
     __syncthreads();
   }
 }
@@ -1322,6 +1550,9 @@ struct BatchTabArgs {
   const BatchPatch* patches;
   const int* patch_off;  // patches of (set g, mate mt): [patch_off[2 g + mt], patch_off[2 g + mt + 1])
   int first;             // first set of this launch
+  int n_sets;            // sets of this launch
+  unsigned char* chg[2]; // per mate: MultiSets::chg of this launch (one byte per table entry), written by the last blocks
+  size_t chg_bytes[2];   // multiples of 16
 };
 
 __device__ __forceinline__ void block_copy_words(char* dst, const char* src, size_t bytes) {  // both 16-byte aligned
@@ -1331,8 +1562,24 @@ __device__ __forceinline__ void block_copy_words(char* dst, const char* src, siz
   for (size_t i = done / 4 + threadIdx.x; i < bytes / 4; i += blockDim.x) ((int*)dst)[i] = ((const int*)src)[i];
 }
 
-__global__ __launch_bounds__(1024) void batch_tables_kernel(BatchTabArgs a) {  // grid (sets of this launch, 2 mates)
-  const int g = a.first + (int)blockIdx.x, mt = (int)blockIdx.y;
+__global__ __launch_bounds__(1024) void batch_tables_kernel(BatchTabArgs a) {  // grid (sets of this launch + 1, 2 mates)
+  const int mt = (int)blockIdx.y;
+  if ((int)blockIdx.x == a.n_sets) {
+    // which of this launch's sets may differ from its first one, per table entry: set s differs in the entries its own
+    // patch and the patches of the sets between them name -- bits s .. n-1 for every entry of patch first + s
+    int4* z = (int4*)a.chg[mt];
+    for (size_t i = threadIdx.x; i < a.chg_bytes[mt] / 16; i += blockDim.x) z[i] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    for (int sidx = 1; sidx < a.n_sets; sidx++) {
+      const unsigned bits = (0xffu << sidx) & 0xffu;
+      for (int t = a.patch_off[2 * (a.first + sidx) + mt] + (int)threadIdx.x; t < a.patch_off[2 * (a.first + sidx) + mt + 1]; t += blockDim.x) {
+        const int w = a.patches[t].w;
+        atomicOr((unsigned*)(a.chg[mt] + (w & ~3)), bits << (8 * (w & 3)));
+      }
+    }
+    return;
+  }
+  const int g = a.first + (int)blockIdx.x;
   char* region = a.regions + (size_t)g * a.stride;
   block_copy_words(region + a.off_occ[mt], a.base + a.off_occ[mt], a.bytes_occ[mt]);
   block_copy_words(region + a.off_lo[mt], a.base + a.off_lo[mt], a.bytes_lo[mt]);

@@ -777,7 +777,11 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   a.dirty_spill = s.dl_spill.as<int>();
   const int64_t ovf_total = n - n_main + (int64_t)s.spill_pairs.size();  // wave-per-pair items: table pairs with long lists, then delta pairs with long lists
   // 3 blocks per CU and one round of four pairs per lane at cfg3 (tools/kbench.py sweep); larger sets get more blocks, up to 8 per CU
-  const int cap0 = c->knobs[0] > 0 ? c->knobs[0] : (int)std::min<int64_t>(kMaxBlocks, std::max<int64_t>(768, n0 / 2900));
+  // A second round for a few lanes doubles the launch (every block is resident: the launch lasts as long as its longest
+  // lane): up to 5 blocks per CU the compact class gets exactly the blocks one round needs.
+  const int64_t one_round = (n0 + 4 * kBlock - 1) / (4 * kBlock);
+  const int cap0 = c->knobs[0] > 0 ? c->knobs[0]
+                                   : (int)std::min<int64_t>(kMaxBlocks, one_round > 768 && one_round <= 1280 ? one_round : std::max<int64_t>(768, n0 / 2900));
   gp.blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
   // the 2-record class: a quarter of the compact class's blocks (3/4 block per CU at cfg3), lanes take 1-2 pairs;
   // more blocks only crowd the compact class out (tools/kbench.py sweep: 312 blocks 16.4 us, 192 blocks 15.0 us)
@@ -1004,7 +1008,7 @@ bool paired_multi_capable(const gaml_hip_ctx* c, const PairedSet& s) {
 // set's number in the batch): a batch may go out in two launches so that the host plans the second half while the
 // device scores the first.
 int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, const PairedLayout* L, const PairedPrep* preps, const int32_t* total_lens,
-                        const char* arena, size_t stride, hipStream_t st) {
+                        const char* arena, size_t stride, hipStream_t st, const unsigned char* const* chg = nullptr) {
   PairedArgs a;
   GridPlan gp;
   paired_base_args(c, s, a, gp);
@@ -1025,6 +1029,8 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, co
   MultiSets ms;
   memset(&ms, 0, sizeof(ms));
   ms.n = n_sets;
+  if (c->knobs[11] >= 32) ms.pad_ = (c->knobs[11] - 32) & 31;  // timing experiments: leave out classes of blocks (bits: compact, <=2, <=4, delta, wave-per-pair)
+  if (chg && c->knobs[11] < 64) { ms.chg[0] = chg[0]; ms.chg[1] = chg[1]; }  // (>= 64: and every set resolves every pair)  // (which table entries differ between the sets: only a batch built from patches knows)
   for (int k = 0; k < n_sets; k++) {
     const int g = first + k;  // the set's number in the batch
     paired_set_view(L[g], arena + (size_t)g * stride, total_lens[g], ms.set[k]);
