@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <climits>
 
 namespace gaml {
 
@@ -39,84 +40,109 @@ __device__ __forceinline__ char aln_wbase(const char* s, int W, int strand, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1. sliding maximum (graph.cc:1289-1323). hbuf = scratch for the codes, one uint32 per window base
-//    and strand. Emission rule: at i == R-1 and wherever the span maximum differs from the previous
-//    span's; the position is the EARLIEST seed attaining the maximum.
+// 1. sliding maximum (graph.cc:1289-1323). Emission rule: at i == R-1 and wherever the span maximum differs from
+//    the previous span's; the position is the EARLIEST seed attaining the maximum. `order` of a span = the index of
+//    its last base: increasing in emission order, which is all the later stages use it for.
+//    One block per (window, strand, chunk of 256 span ends): the chunk's slice of the window string and the scrambled
+//    15-mer codes of its spans live in LDS; a span's maximum is one scan of its R - 14 codes, its predecessor's
+//    maximum is the neighbouring lane's. Chunks are independent, so a 30 kbp window is 2 x 117 blocks, not 2.
+//    blk[w] = first block of window w (blk[n_win] = grid size): 2 x chunks(window length) blocks per window.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kAlnBlock) void span_maxima_kernel(const char* wstr, const AlnWindow* wins, int n_win, int R,
-                                                               uint32_t* hbuf, const int64_t* hbuf_off, AlnSpan* spans,
-                                                               unsigned* n_spans, unsigned cap_spans) {
-  const int w = blockIdx.x >> 1, strand = blockIdx.x & 1;
-  if (w >= n_win) return;
+__host__ __device__ inline int aln_span_first(int R) { return R - 1 > kAlnSeed ? R - 1 : kAlnSeed; }  // the reference's loop starts at i = kIndexKmer
+__host__ __device__ inline int aln_span_chunks(int W, int R) { const int f = aln_span_first(R); return W > f ? (W - f + kAlnBlock - 1) / kAlnBlock : 0; }
+
+// (windows [split, n_win) belong to a second read set -- the other mate -- whose index was built for read length R2)
+__global__ __launch_bounds__(kAlnBlock) void span_maxima_kernel(const char* wstr, const AlnWindow* wins, int n_win, int R, const int* blk,
+                                                               AlnSpan* spans, unsigned* n_spans, unsigned cap_spans, int split = INT_MAX, int R2 = 0) {
+  __shared__ char sh_str[kAlnBlock + kAlnMaxRead + 2];
+  __shared__ uint32_t sh_code[kAlnBlock + kAlnMaxRead + 2];
+  __shared__ uint32_t sh_max[kAlnBlock];
+  __shared__ int sh_wave[kAlnBlock / 64];
+  __shared__ unsigned sh_base;
+  int lo = 0, hi = n_win;  // the window this block belongs to: last w with blk[w] <= blockIdx.x
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (blk[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const int w = lo;
+  if (w >= split) R = R2;
   const AlnWindow win = wins[w];
   const char* s = wstr + win.str_off;
   const int W = win.len;
-  uint32_t* h = hbuf + hbuf_off[w] + (int64_t)strand * W;
-  // scrambled code of the 15-mer ENDING at j
-  for (int j = threadIdx.x; j < W; j += kAlnBlock) {
+  const int chunks = aln_span_chunks(W, R);
+  const int rel = (int)blockIdx.x - blk[w];
+  if (chunks == 0 || rel >= 2 * chunks) return;
+  const int strand = rel / chunks, chunk = rel % chunks;
+  const int base = aln_span_first(R) + chunk * kAlnBlock;     // span ends [base, base + 256)
+  // codes of the seeds ending at j in [c_lo, c_hi]: those of span base - 1 (the first lane's predecessor) up to the last span's
+  const int c_lo = max(base - 1 - R + kAlnSeed, kAlnSeed - 1), c_hi = min(base + kAlnBlock - 1, W - 1);
+  const int s_lo = c_lo - (kAlnSeed - 1);                        // string bases [s_lo, c_hi]
+  for (int k = threadIdx.x; k <= c_hi - s_lo; k += kAlnBlock) sh_str[k] = aln_wbase(s, W, strand, s_lo + k);
+  __syncthreads();
+  for (int k = threadIdx.x; k <= c_hi - c_lo; k += kAlnBlock) {  // scrambled code of the 15-mer ENDING at c_lo + k
     uint32_t code = 0;
-    if (j >= kAlnSeed - 1) {
-      for (int k = j - kAlnSeed + 1; k <= j; k++) code = (code << 2) | aln_code(aln_wbase(s, W, strand, k));
-      code ^= 0x2204abcdu;
-    }
-    h[j] = code;
+    for (int q = 0; q < kAlnSeed; q++) code = (code << 2) | aln_code(sh_str[k + q]);
+    sh_code[k] = code ^ 0x2204abcdu;
   }
   __syncthreads();
-  __shared__ int sh_cnt[kAlnBlock];
-  __shared__ unsigned sh_base;
-  const int first_i = R - 1 > kAlnSeed ? R - 1 : kAlnSeed;  // the reference's loop starts at i = kIndexKmer
-  int emitted_before = 0;                                  // spans this (window, strand) emitted in earlier chunks
-  for (int base = first_i; base < W; base += kAlnBlock) {
-    const int i = base + threadIdx.x;
-    uint32_t m = 0, mprev = 0;
-    int p = -1;
-    bool emit = false;
-    if (i < W) {
-      const int lo = i - R + kAlnSeed > kAlnSeed - 1 ? i - R + kAlnSeed : kAlnSeed - 1;
-      for (int j = lo; j <= i; j++) { const uint32_t v = h[j]; if (p < 0 || v > m) { m = v; p = j; } }  // strictly greater: earliest maximum
-      if (i == R - 1) emit = true;
-      else {
-        const int lo2 = (i - 1) - R + kAlnSeed > kAlnSeed - 1 ? (i - 1) - R + kAlnSeed : kAlnSeed - 1;
-        for (int j = lo2; j <= i - 1; j++) { uint32_t v = h[j]; if (v > mprev) mprev = v; }
-        // previous span's maximum == what the reference last emitted, except before the first emission
-        // (i-1 < R-1 can only happen when R-1 < kAlnSeed; the host path handles such short reads)
-        emit = m != mprev;
-      }
+  auto span_max = [&](int i, int& p) -> uint32_t {  // maximum over the seeds of the span ending at i; p = the earliest seed attaining it
+    const int lo_j = max(i - R + kAlnSeed, kAlnSeed - 1);
+    uint32_t m = 0;
+    p = -1;
+    for (int j = lo_j; j <= i; j++) { const uint32_t v = sh_code[j - c_lo]; if (p < 0 || v > m) { m = v; p = j; } }  // strictly greater: earliest maximum
+    return m;
+  };
+  const int i = base + (int)threadIdx.x;
+  uint32_t m = 0;
+  int p = -1;
+  if (i < W) m = span_max(i, p);
+  sh_max[threadIdx.x] = m;
+  __syncthreads();
+  bool emit = false;
+  if (i < W) {
+    if (i == R - 1) emit = true;
+    else {
+      // previous span's maximum == what the reference last emitted, except before the first emission
+      // (i-1 < R-1 can only happen when R-1 < kAlnSeed; the host path handles such short reads)
+      uint32_t mprev;
+      if (threadIdx.x > 0) mprev = sh_max[threadIdx.x - 1];
+      else { int pp; mprev = span_max(i - 1, pp); }
+      emit = m != mprev;
     }
-    // ordered compaction inside the block
-    sh_cnt[threadIdx.x] = emit ? 1 : 0;
-    __syncthreads();
-    for (int d = 1; d < kAlnBlock; d <<= 1) {
-      int t = threadIdx.x >= d ? sh_cnt[threadIdx.x - d] : 0;
-      __syncthreads();
-      sh_cnt[threadIdx.x] += t;
-      __syncthreads();
-    }
-    const int total = sh_cnt[kAlnBlock - 1];
-    if (threadIdx.x == 0) sh_base = total ? atomicAdd(n_spans, (unsigned)total) : 0;
-    __syncthreads();
-    if (emit) {
-      const unsigned at = sh_base + sh_cnt[threadIdx.x] - 1;
-      if (at < cap_spans) spans[at] = AlnSpan{m, p, w, strand, emitted_before + sh_cnt[threadIdx.x] - 1};
-    }
-    emitted_before += total;
-    __syncthreads();
+  }
+  // ordered compaction inside the block: ballots per wave, wave totals through LDS
+  const unsigned long long bal = __ballot(emit);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) sh_wave[wave] = __popcll(bal);
+  __syncthreads();
+  int wave_before = 0, total = 0;
+  for (int q = 0; q < kAlnBlock / 64; q++) { if (q < wave) wave_before += sh_wave[q]; total += sh_wave[q]; }
+  if (threadIdx.x == 0) sh_base = total ? atomicAdd(n_spans, (unsigned)total) : 0;
+  __syncthreads();
+  if (emit) {
+    const unsigned at = sh_base + (unsigned)(wave_before + before);
+    if (at < cap_spans) spans[at] = AlnSpan{m, p, w, strand, i};
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // 2. candidates: every read of the bucket whose key is the span's hash (graph.cc:1329-1347)
 // ---------------------------------------------------------------------------------------------
+// the bucket whose key is `hash`, or -1: top[h] = first bucket with key >= h << 16 (65537 entries), so the lower
+// bound runs over the few dozen keys that share the hash's upper half -- 5 dependent loads instead of 21
+__device__ __forceinline__ int aln_find_bucket(const uint64_t* bucket_hash, const int32_t* top, int n_buckets, uint32_t hash) {
+  int lo = top[hash >> 16], hi = top[(hash >> 16) + 1];
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (bucket_hash[mid] < (uint64_t)hash) lo = mid + 1; else hi = mid; }
+  return lo < n_buckets && bucket_hash[lo] == (uint64_t)hash ? lo : -1;
+}
+
 __global__ __launch_bounds__(kAlnBlock) void candidates_kernel(const AlnSpan* spans, const unsigned* n_spans, unsigned cap_spans,
-                                                              const uint64_t* bucket_hash, const int32_t* bucket_off,
+                                                              const uint64_t* bucket_hash, const int32_t* bucket_top, const int32_t* bucket_off,
                                                               const int32_t* bucket_reads, int n_buckets, AlnCand* cands,
                                                               unsigned* n_cands, unsigned cap_cands) {
   const unsigned n = *n_spans < cap_spans ? *n_spans : cap_spans;
   for (unsigned t = blockIdx.x * kAlnBlock + threadIdx.x; t < n; t += gridDim.x * kAlnBlock) {
     const AlnSpan sp = spans[t];
-    int lo = 0, hi = n_buckets;  // lower_bound
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (bucket_hash[mid] < (uint64_t)sp.hash) lo = mid + 1; else hi = mid; }
-    if (lo >= n_buckets || bucket_hash[lo] != (uint64_t)sp.hash) continue;
+    const int lo = aln_find_bucket(bucket_hash, bucket_top, n_buckets, sp.hash);
+    if (lo < 0) continue;
     const int b0 = bucket_off[lo], b1 = bucket_off[lo + 1];
     const unsigned at = atomicAdd(n_cands, (unsigned)(b1 - b0));
     for (int k = b0; k < b1; k++) {
@@ -358,16 +384,65 @@ __global__ __launch_bounds__(64 * kAlnWaves) void extend_kernel(const AlnCand* c
   }
 }
 
+// Both mates of a paired read set in ONE small batch: windows [0, split) are mate 1's, [split, n) mate 2's (the same
+// junction strings, looked up in the other mate's index and extended against the other mate's reads).
+struct AlnMates {
+  const uint64_t* bucket_hash[2];
+  const int32_t* bucket_top[2];
+  const int32_t* bucket_off[2];
+  const int32_t* bucket_reads[2];
+  int n_buckets[2];
+  const char* reads[2];
+  const int64_t* read_off[2];
+  int split;
+};
+
+__global__ __launch_bounds__(kAlnBlock) void candidates_pair_kernel(const AlnSpan* spans, const unsigned* n_spans, unsigned cap_spans, AlnMates ix,
+                                                                   AlnCand* cands, unsigned* n_cands, unsigned cap_cands) {
+  const unsigned n = *n_spans < cap_spans ? *n_spans : cap_spans;
+  for (unsigned t = blockIdx.x * kAlnBlock + threadIdx.x; t < n; t += gridDim.x * kAlnBlock) {
+    const AlnSpan sp = spans[t];
+    const int mt = sp.win >= ix.split ? 1 : 0;
+    const int lo = aln_find_bucket(ix.bucket_hash[mt], ix.bucket_top[mt], ix.n_buckets[mt], sp.hash);
+    if (lo < 0) continue;
+    const int b0 = ix.bucket_off[mt][lo], b1 = ix.bucket_off[mt][lo + 1];
+    const unsigned at = atomicAdd(n_cands, (unsigned)(b1 - b0));
+    for (int k = b0; k < b1; k++) {
+      const unsigned o = at + (unsigned)(k - b0);
+      if (o < cap_cands) cands[o] = AlnCand{sp.win, sp.strand, sp.order, sp.pos, ix.bucket_reads[mt][k]};
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * kAlnWaves) void extend_pair_kernel(const AlnCand* cands, const unsigned* n_cands, unsigned cap_cands,
+                                                                     const char* wstr, const AlnWindow* wins, AlnMates ix, AlnHit* hits) {
+  __shared__ AlnWaveLds lds_all[kAlnWaves];
+  const unsigned n = *n_cands < cap_cands ? *n_cands : cap_cands;
+  const int lane = (int)(threadIdx.x & 63);
+  AlnWaveLds& L = lds_all[threadIdx.x >> 6];
+  for (unsigned t = blockIdx.x * kAlnWaves + (threadIdx.x >> 6); t < n; t += gridDim.x * kAlnWaves) {  // whole waves move together
+    const int mt = cands[t].win >= ix.split ? 1 : 0;  // wave-uniform
+    extend_candidate(L, lane, t, cands, wstr, wins, ix.reads[mt], ix.read_off[mt], hits);
+    aln_lds_sync();  // the wave's LDS slice is reused by its next candidate
+  }
+}
+
 // Small batches (an annealing move's handful of new junction windows): the counters and the hits go to mapped pinned
-// host memory and a sequence word tells the host they are there -- ONE wait per batch, no copy commands.
-__global__ __launch_bounds__(256) void publish_hits_kernel(const unsigned* counters, const AlnHit* hits, unsigned cap_cands, unsigned* h_counts,
+// host memory and a sequence word tells the host they are there -- ONE wait per batch, no copy commands. The counters
+// are left at zero for the next batch.
+__global__ __launch_bounds__(256) void publish_hits_kernel(unsigned* counters, const AlnHit* hits, unsigned cap_cands, unsigned* h_counts,
                                                            AlnHit* h_hits, unsigned cap_host, volatile unsigned long long* h_seq, unsigned long long seq) {
   const unsigned n_spans = counters[0], n_cands = counters[1];
   const unsigned n = n_cands < cap_cands ? (n_cands < cap_host ? n_cands : 0u) : 0u;  // overflow: counts only, the host takes the slow route
   for (unsigned t = threadIdx.x; t < n; t += 256) h_hits[t] = hits[t];
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0) { h_counts[0] = n_spans; h_counts[1] = n_cands; __threadfence_system(); *h_seq = seq; }
+  if (threadIdx.x == 0) {
+    h_counts[0] = n_spans; h_counts[1] = n_cands;
+    counters[0] = 0; counters[1] = 0;
+    __threadfence_system();
+    *h_seq = seq;
+  }
 }
 
 

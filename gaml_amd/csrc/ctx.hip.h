@@ -118,14 +118,14 @@ struct Reducer {  // per read set: partials + ticket + 2-double result
 };
 
 struct AlignDev {  // device copies the GPU aligner needs: reads (1 byte per base) + the max-hash index
-  DevBuf reads, read_off, bucket_hash, bucket_off, bucket_reads;
+  DevBuf reads, read_off, bucket_hash, bucket_top, bucket_off, bucket_reads;  // bucket_top: first bucket per upper half of the key (aln_find_bucket)
   bool uploaded = false;
-  void release() { reads.release(); read_off.release(); bucket_hash.release(); bucket_off.release(); bucket_reads.release(); }
+  void release() { reads.release(); read_off.release(); bucket_hash.release(); bucket_top.release(); bucket_off.release(); bucket_reads.release(); }
 };
 struct AlignScratch {  // per context, grown on demand
-  DevBuf wstr, wins, hbuf, hbuf_off, spans, cands, hits, counters;
+  DevBuf wstr, wins, blk, spans, cands, hits, counters;
   DevBuf sort_keys, sort_idx, sort_tmp, hits_sorted;  // large batches: hits ordered on the device
-  void release() { wstr.release(); wins.release(); hbuf.release(); hbuf_off.release(); spans.release(); cands.release(); hits.release(); counters.release();
+  void release() { wstr.release(); wins.release(); blk.release(); spans.release(); cands.release(); hits.release(); counters.release();
                    sort_keys.release(); sort_idx.release(); sort_tmp.release(); hits_sorted.release(); }
 };
 
@@ -133,12 +133,12 @@ struct AlignScratch {  // per context, grown on demand
 // block written by the host (device memory behind the BAR, or its pinned twin), counters + hits published in mapped
 // pinned memory behind a sequence word.
 struct AlignSmall {
-  DevBuf hbuf, spans, cands, hits, counters;
+  DevBuf spans, cands, hits, counters;
   void* in_dev = nullptr; size_t in_cap = 0; bool in_direct = false;
   PinBuf in_host, out_host;
   unsigned long long out_seq = 0;
   void release() {
-    hbuf.release(); spans.release(); cands.release(); hits.release(); counters.release();
+    spans.release(); cands.release(); hits.release(); counters.release();
     if (in_dev) (void)hipFree(in_dev);
     in_dev = nullptr; in_cap = 0; in_host.release(); out_host.release();
   }
@@ -148,8 +148,7 @@ struct AlnJob {
   bool prepared = false, enqueued = false;
   std::string wstr;
   std::vector<AlnWindow> wins;
-  std::vector<int64_t> hoff;
-  int64_t hbuf_total = 0;
+  std::vector<int32_t> blk;  // blk[w] = first block of window w in span_maxima_kernel's grid; blk[n] = the grid size
   unsigned long long seq = 0;
   void* stream = nullptr;  // where the small-batch pipeline was enqueued
 };
