@@ -1003,7 +1003,8 @@ struct SetDev {  // what differs between the path sets of one batch
 // sets' tables were built from patches knows, batch_tables_kernel). A pair none of whose records touch such a window
 // resolves to the same candidates in set s as in set 0: its set-0 result is finished again under set s's 2T and
 // thresholds, no table is read. The bits are cumulative (bit s implies bit s + 1: a set's tables are its
-// predecessor's plus a patch). Null: unknown, every set resolves every pair.
+// predecessor's plus a patch). Null: unknown, every set resolves every pair. Used by the classes with several records
+// per pair and the delta / wave-per-pair blocks; the compact class resolves every set (see its body).
 struct MultiSets { int n; int pad_; const unsigned char* chg[2]; SetDev set[kMaxSets]; };
 
 constexpr int kTfCodes = 16;  // length codes whose per-set thresholds a multi-set block keeps in LDS
@@ -1030,22 +1031,15 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
   for (unsigned base = (unsigned)lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
     uint2 r1[4], r2[4];
     unsigned lc[4];
-    unsigned chg = ms.chg[0] ? 0u : ~0u;  // per pair k: byte k = the sets (bits) whose tables may differ from set 0's on its windows
 #pragma unroll
     for (int k = 0; k < 4; k++) {  // the records: ONCE for all sets
       const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
       r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); lc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
     }
-    if (ms.chg[0]) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned c1 = r1[k].y != ~0u ? ms.chg[0][r1[k].x & 0xffffffu] : 0u, c2 = r2[k].y != ~0u ? ms.chg[1][r2[k].x & 0xffffffu] : 0u;
-        chg |= (c1 | c2) << (8 * k);
-      }
-    }
-    int state[4];       // of the last set that resolved this pair: set 0, or a later one that had to (and then every set after it has to: the bits of `chg` are cumulative)
-    double2 m[4];
-    unsigned skip_bits = 0;
+    // (Every set resolves every pair here. Finishing a pair from its set-0 result where no window of it changed -- as the
+    // other classes do -- does not pay in this class: the launch lasts as long as its slowest wavefront, and some
+    // wavefront always holds a pair on a changed window; the bookkeeping only costs registers. Measured: 26.1 us for
+    // four sets this way, 28.7 us with the capture, tools/batch_ablate.py.)
 #pragma unroll 1
     for (int s = 0; s < ms.n; s++) {
       const SetDev& sd = ms.set[s];
@@ -1054,28 +1048,24 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
       const double* const tfs = tf ? tf + s * kTfCodes : sd.tfloor_c;  // this set's thresholds per length code (LDS copy when it fits)
       const double log2T = sd.log_two_T, tfloor_one = ONE ? tfs[0] : 0.0;
       const bool last_set = s == ms.n - 1;  // per-read probabilities: those of the last set, as after a sequence of calls
-      // resolve against this set's tables: set 0 always; a later set only the (wave's) pairs on changed windows --
-      // pairs are ordered by window, so those sit in a few wavefronts and the others skip both round trips
-      const unsigned need = s == 0 ? 0x01010101u : (chg >> s) & 0x01010101u;
-      if (s == 0 || __any(need != 0)) {
-        uint2 o1[4], o2[4];
+      uint2 o1[4], o2[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const bool go = (need >> (8 * k)) & 1u;
-          const Occ12* e1 = (const Occ12*)(occ0 + (go && r1[k].y != ~0u ? (r1[k].x & 0xffffffu) : 0u) * 12u);
-          const Occ12* e2 = (const Occ12*)(occ1 + (go && r2[k].y != ~0u ? (r2[k].x & 0xffffffu) : 0u) * 12u);
-          o1[k] = make_uint2(e1->lo, e1->hi); o2[k] = make_uint2(e2->lo, e2->hi);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (!((need >> (8 * k)) & 1u)) continue;
-          bool skip;
-          state[k] = compact_state(a, r1[k], r2[k], o1[k], o2[k], lc[k], ONE ? l12_one : a.len_combo[lc[k]], base + k * stride < n0, skip);
-          skip_bits = (skip_bits & ~(1u << k)) | ((unsigned)skip << k);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) if ((need >> (8 * k)) & 1u) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
+      for (int k = 0; k < 4; k++) {
+        const Occ12* e1 = (const Occ12*)(occ0 + (r1[k].y != ~0u ? (r1[k].x & 0xffffffu) : 0u) * 12u);
+        const Occ12* e2 = (const Occ12*)(occ1 + (r2[k].y != ~0u ? (r2[k].x & 0xffffffu) : 0u) * 12u);
+        o1[k] = make_uint2(e1->lo, e1->hi); o2[k] = make_uint2(e2->lo, e2->hi);
       }
+      int state[4];
+      unsigned skip_bits = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        bool skip;
+        state[k] = compact_state(a, r1[k], r2[k], o1[k], o2[k], lc[k], ONE ? l12_one : a.len_combo[lc[k]], base + k * stride < n0, skip);
+        skip_bits |= (unsigned)skip << k;
+      }
+      double2 m[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
       if (GEN) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
