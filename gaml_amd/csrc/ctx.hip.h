@@ -250,6 +250,7 @@ struct PairedSet {
     bool valid = false;                // the copy mirrors the host images as of their last take_changed()
     void release() { if (dev) (void)hipFree(dev); dev = nullptr; bytes = 0; valid = false; }
   } persist;
+  int64_t batches_patched = 0, batches_full = 0;  // gaml_hip_calc_prob_batch chunks whose per-set tables were built on the device from patches / written whole
   size_t batch_slack = 0;             // extra bytes per path set region of a batch (grows when a set's tables did not fit)
   DevBuf gen_bits;  // one bit per table-class slot: needs paired_general_kernel (written by the main kernel)
   hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;

@@ -2322,6 +2322,7 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
       for (int32_t w : per[i].touched[mt]) memcpy(occ[mt] + (size_t)w * sizeof(Occ12), &ps.image[mt].occ12[w], sizeof(Occ12));
   }
   _mm_sfence();
+  for (size_t i = 0; i < nps; i++) c->paireds[i]->batches_patched++;
   for (int k = 0; k < n; k++)
     for (size_t i = 0; i < nps; i++) {
       PairedSet& ps = *c->paireds[i];
@@ -2399,6 +2400,7 @@ static int batch_chunk_fast(gaml_hip_ctx* c, int n, const int32_t* paths, const 
   bool spun = false;
   if (int e = wait_host_partials(c, &spun)) return e;
   if (!spun) { if (int e2 = collect_events(c)) return e2; }
+  for (size_t i = 0; i < nps; i++) c->paireds[i]->batches_full++;
   for (int k = 0; k < n; k++)
     for (size_t i = 0; i < nps; i++) {
       PairedSet& ps = *c->paireds[i];
@@ -2670,11 +2672,12 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wi
   return (int32_t)w.size();
 }
 
-int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out3 /* 4 values */) {
+int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out6) {
   MULTI_SHARD0(c);
-  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out3) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out6) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
-  out3[0] = s.full_rebuilds; out3[1] = s.delta_updates; out3[2] = (int64_t)s.dirty.size(); out3[3] = s.async_rebuilds;
+  out6[0] = s.full_rebuilds; out6[1] = s.delta_updates; out6[2] = (int64_t)s.dirty.size(); out6[3] = s.async_rebuilds;
+  out6[4] = s.batches_patched; out6[5] = s.batches_full;
   return GAML_HIP_OK;
 }
 

@@ -47,11 +47,12 @@ int64_t gaml_hip_debug_table_occurrences(gaml_hip_ctx* ctx, int readset, int mat
 /* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
 /* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list, rebuilds
- * done by the worker thread (of the full rebuilds)}.
+ * done by the worker thread (of the full rebuilds), gaml_hip_calc_prob_batch chunks whose per-set tables were built on
+ * the device from patches, chunks whose tables were written whole}.
  * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables); knob 14 = 1 keeps every
  * rebuild on the calling thread, knob 14 = k > 1 lets a worker's tables take over k evaluations after its start
  * (default 768); knob 15 = 1: rebuilds never retire unused windows. */
-int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out4);
+int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out6);
 
 /* ---- tuning ------------------------------------------------------------------------------------- */
 /* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner), [1] thresholds +

@@ -137,6 +137,60 @@ def test_one_pass_batch_equals_single_calls(mixed_lengths):
     assert [b[0] for b in many.calc_prob_batch(sets[:8])] == [many.calc_prob(s)[0] for s in sets[:8]]
 
 
+def test_candidate_batches_build_their_tables_on_the_device():
+    """Candidates of one assembly (each a single edit away from the current one): the per-set occurrence tables are
+    built on the device from the resident copy + a few patched entries, and pairs whose windows no later set changed
+    are finished from their first set's result. Every route must give the same bits: the device-built tables, whole
+    tables per set (knob 11 = 2), no capture (knob 11 = 3), one launch per set (knob 11 = 1), and single calls."""
+    from gaml_amd import api
+    G, seed = 400_000, 31
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(600, 2500), short_rng=(25, 250)))
+    pr = synth.make_paired_reads(genome, 40_000, 100, 250.0, 25.0, 0.01, seed)
+    args = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    start, seq = synth.sa_sequence(g, 60, seed=seed, threshold=400)
+    base = seq[-1]
+    rng = np.random.default_rng(seed)
+    batches = []
+    for _ in range(12):
+        cands = [synth.sa_move(rng, base, g) for _ in range(8)]
+        batches.append(cands)
+        if rng.random() < 0.6:
+            base = cands[int(rng.integers(0, 8))]
+    ctxs = []
+    for knob in (0, 2, 3, 1, None):  # None: single calls
+        c = api.Context(device=0)
+        c.set_graph(*g.packed())
+        c.add_paired(api.paired_cfg(250.0, 25.0), *args)
+        if knob:
+            c.debug_set_knob(11, knob)
+        c.calc_prob(seq[-1])
+        ctxs.append((knob, c))
+    for rnd in range(2):  # cold (windows aligned along the way), then warm
+        for cands in batches:
+            vals = []
+            for knob, c in ctxs:
+                if knob is None:
+                    vals.append([(c.calc_prob(s)[0], c.calc_prob(s)[1].tolist()) for s in cands])
+                else:
+                    vals.append([(b[0], b[1].tolist()) for b in c.calc_prob_batch(cands)])
+            for v in vals[1:]:
+                if rnd == 0:  # the contexts' delta lists fill in different orders while windows get aligned: last bits of the sum
+                    assert all(a[1] == b[1] and abs(a[0] - b[0]) <= 1e-13 * abs(b[0]) for a, b in zip(v, vals[0]))
+                else:
+                    assert v == vals[0]
+        if rnd == 0:  # the same device state everywhere: everything folded into the record tables
+            for knob, c in ctxs:
+                c.compact_tables()
+                c.calc_prob(base)
+    st = ctxs[0][1].debug_table_stats(0)
+    assert st["batches_patched"] >= 20 and st["batches_patched"] > 5 * st["batches_full"], st
+    assert ctxs[1][1].debug_table_stats(0)["batches_patched"] == 0
+    # a blocking call after a batch finds the resident tables in step with the planner
+    last = batches[-1][-1]
+    assert ctxs[0][1].calc_prob(last)[0] == ctxs[4][1].calc_prob(last)[0]
+
+
 def test_one_pass_batch_against_the_oracle():
     import oracle_py as op
     g, (m1, m2), sets, make = _paired_only(True, n=5000, seed=21)

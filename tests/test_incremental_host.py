@@ -74,6 +74,39 @@ def test_incremental_tables_equal_planning_from_scratch(built, seed):
             assert np.array_equal(inc.window_records(rs, mate, w), ref.window_records(rs, mate, w))
 
 
+def test_candidates_of_one_assembly_stay_incremental(built):
+    """Two candidates of one assembly differ from each other in BOTH their edits, with most of the set between the two
+    (what a move generator's batch looks like, and every step of an annealing walk whose previous move was rejected):
+    the diff is an edit script with several edits, not one prefix / suffix pair -- the planner must not fall back to
+    planning the whole set, and the tables must equal planning from scratch."""
+    from gaml_amd import api
+    G, n, seed = 120_000, 2500, 19
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(500, 1500), short_rng=(25, 200)))
+    pr = synth.make_paired_reads(genome, n, 100, 240.0, 24.0, 0.01, seed)
+    reads = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    inc, ref = api.Context(device=-1), api.Context(device=-1)
+    ref.debug_set_knob(12, 1)
+    for c in (inc, ref):
+        c.set_graph(*g.packed())
+        c.add_paired(api.paired_cfg(240.0, 24.0), *reads)
+    start, seq = synth.sa_sequence(g, 40, seed=seed, threshold=400)
+    base = seq[-1]
+    assert len(base) >= 40
+    rng = np.random.default_rng(seed)
+    def edit(at):  # break path `at` in two (one path out, two in), or drop it when it cannot be broken
+        p = base[at]
+        return base[:at] + ([p[: len(p) // 2], p[len(p) // 2:]] if len(p) >= 2 else []) + base[at + 1:]
+    cands = [edit(2), edit(len(base) - 3), edit(len(base) // 2), edit(5), base, edit(len(base) - 2), edit(1)]
+    inc.debug_prepare(base); ref.debug_prepare(base)
+    for k, ps in enumerate(cands):
+        inc.debug_prepare(ps); ref.debug_prepare(ps)
+        info = _same_tables(inc, 0)
+        assert info["incremental"], k
+        for mate in (0, 1):
+            assert np.array_equal(_canon_flat(inc.debug_occurrences(0, mate)), _canon_flat(ref.debug_occurrences(0, mate))), (k, mate)
+
+
 def test_a_bad_path_leaves_the_planner_usable(built):
     from gaml_amd import api
     genome = synth.make_genome(30_000, 5)
