@@ -14,11 +14,11 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// mode 0: plain loads after the gate; 1: the gate is polled with an acquire load at system scope
+// mode 0: plain loads after the gate; 1: the gate is polled with an acquire load at system scope; 2: one wave polls the host word
 template <int MODE>
 __global__ __launch_bounds__(256) void gated_kernel(const unsigned* table, int n, const unsigned long long* gate, unsigned long long seq,
                                                     unsigned want_old, unsigned want_new, unsigned* bad_old, unsigned* bad_new,
-                                                    volatile unsigned long long* done, unsigned long long* spins, unsigned* ticket) {
+                                                    volatile unsigned long long* done, unsigned long long* spins, unsigned* ticket, unsigned long long* go) {
   // 1. read the tables as they are now (what an earlier launch would have left in the caches)
   unsigned stale = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) stale += table[i] != want_old + (unsigned)i;
@@ -26,7 +26,19 @@ __global__ __launch_bounds__(256) void gated_kernel(const unsigned* table, int n
   // 2. wait for the host
   unsigned long long polls = 0;
   const long long t0 = wall_clock64();
-  if ((threadIdx.x & 63) == 0) {
+  if (MODE == 2) {
+    // ONE wave of the grid polls the host's word; everybody else waits for a word in ordinary device memory that this
+    // wave sets (thousands of waves polling one fine-grained address serialise on it)
+    if ((threadIdx.x & 63) == 0) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        while (__hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) { polls++; if (wall_clock64() - t0 > 100000000ll) break; }
+        __hip_atomic_store(go, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        while (__hip_atomic_load(go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) { polls++; if (wall_clock64() - t0 > 100000000ll) break; __builtin_amdgcn_s_sleep(8); }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  } else if ((threadIdx.x & 63) == 0) {
     while (true) {
       const unsigned long long v = MODE == 1 ? __hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)
                                              : *(volatile const unsigned long long*)gate;
@@ -71,11 +83,12 @@ int main() {
   unsigned *d_bad_old, *d_bad_new; CK(hipMalloc(&d_bad_old, 4)); CK(hipMalloc(&d_bad_new, 4));
   unsigned long long* d_spins; CK(hipMalloc(&d_spins, 8));
   unsigned* d_ticket; CK(hipMalloc(&d_ticket, 4)); CK(hipMemset(d_ticket, 0, 4));
+  unsigned long long* d_go; CK(hipMalloc(&d_go, 8)); CK(hipMemset(d_go, 0, 8));
   unsigned long long* h_done; CK(hipHostMalloc(&h_done, 64, hipHostMallocMapped | hipHostMallocCoherent));
   unsigned long long* d_done; CK(hipHostGetDevicePointer((void**)&d_done, h_done, 0));
   std::vector<unsigned> src(n);
   auto write_tables = [&](unsigned want, int words) { for (int i = 0; i < words; i++) src[i] = want + i; memcpy(table, src.data(), (size_t)words * 4); _mm_sfence(); };
-  for (int mode = 0; mode < 2; mode++) {
+  for (int mode = 0; mode < 3; mode++) {
     for (int words : {n, 24}) {  // the whole tables / a handful of entries (an annealing move)
       CK(hipMemset(d_bad_old, 0, 4)); CK(hipMemset(d_bad_new, 0, 4)); CK(hipMemset(d_spins, 0, 8));
       write_tables(7, n); *gate = 0; _mm_sfence(); CK(hipDeviceSynchronize());
@@ -86,8 +99,9 @@ int main() {
         const unsigned long long seq = rep + 1;
         *h_done = 0;
         const double t0 = now_us();
-        if (mode == 0) hipLaunchKernelGGL(gated_kernel<0>, dim3(grid), dim3(256), 0, st, table, n, gate, seq, want_old, want_new, d_bad_old, d_bad_new, d_done, d_spins, d_ticket);
-        else hipLaunchKernelGGL(gated_kernel<1>, dim3(grid), dim3(256), 0, st, table, n, gate, seq, want_old, want_new, d_bad_old, d_bad_new, d_done, d_spins, d_ticket);
+        if (mode == 0) hipLaunchKernelGGL(gated_kernel<0>, dim3(grid), dim3(256), 0, st, table, n, gate, seq, want_old, want_new, d_bad_old, d_bad_new, d_done, d_spins, d_ticket, d_go);
+        else if (mode == 1) hipLaunchKernelGGL(gated_kernel<1>, dim3(grid), dim3(256), 0, st, table, n, gate, seq, want_old, want_new, d_bad_old, d_bad_new, d_done, d_spins, d_ticket, d_go);
+        else hipLaunchKernelGGL(gated_kernel<2>, dim3(grid), dim3(256), 0, st, table, n, gate, seq, want_old, want_new, d_bad_old, d_bad_new, d_done, d_spins, d_ticket, d_go);
         // the host's turn: "planning" for ~6 us, then the tables, then the gate
         const double tw = now_us();
         while (now_us() - tw < 6.0) _mm_pause();
@@ -103,7 +117,7 @@ int main() {
       unsigned bo = 0, bn = 0; unsigned long long sp = 0;
       CK(hipMemcpy(&bo, d_bad_old, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&bn, d_bad_new, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&sp, d_spins, 8, hipMemcpyDeviceToHost));
       printf("mode %d (%s): %d launches; words wrong before the gate %u, STALE words after the gate %u; gate -> all blocks done %.1f us, launch -> done %.1f us; %.1f polls per wave\n",
-             mode, mode ? "acquire, system scope" : "volatile poll", reps, bo, bn, t_gate / reps, t_total / reps, (double)sp / reps / (grid * 4));
+             mode, mode == 0 ? "volatile poll" : mode == 1 ? "acquire, system scope" : "one poller, agent-scope hand-over", reps, bo, bn, t_gate / reps, t_total / reps, (double)sp / reps / (grid * 4));
     }
   }
   {  // the plain order: tables, then launch, then wait
