@@ -1417,8 +1417,12 @@ int gaml_hip_put_pacbio_records(gaml_hip_ctx* c, int readset, const int32_t* sub
   if (!c || readset < 0 || readset >= (int)c->handles.size() || c->handles[readset].kind != 2 || !subpath || len <= 0 || n < 0)
     return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PacbioSet& s = *c->pacbios[c->handles[readset].idx];
-  for (int64_t i = 0; i < n; i++)
+  for (int64_t i = 0; i < n; i++) {
     if (recs[i].read_id < 0 || recs[i].read_id >= s.n_global) return fail(c, GAML_HIP_EINVAL, "record names a read outside the read set");
+    // an alignment interval ends behind its begin: the reference's coverage sweep closes an interval that is not open
+    // otherwise (inters.erase(end()), graph.cc:3229-3231)
+    if (recs[i].position_end < recs[i].position) return fail(c, GAML_HIP_EINVAL, "record with position_end < position");
+  }
   Walk w(subpath, subpath + len);
   auto it = s.walk_id.find(w);
   int32_t id;

@@ -86,23 +86,26 @@ def test_gpu_aligner_speed_and_parity_at_cfg2():
 
 
 def test_small_batch_pipeline_equals_the_general_route():
-    """Small batches of new windows (what an annealing move brings) take a one-wait pipeline on the library's stream
-    (gpu_align_small); knob 5 = 3 forces the general route. Same records, same values, along an annealing-style walk."""
+    """Small batches of new windows (what an annealing move brings) take a one-wait pipeline on the library's stream:
+    both mates in one (aln_pair_small), or one per mate side by side (knob 5 = 4); knob 5 = 3 forces the general route.
+    Same records, same values, along an annealing-style walk."""
     from gaml_amd import api
     G, n, seed = 120_000, 6000, 77
     genome = synth.plant_repeats(synth.make_genome(G, seed), 2, 700, seed)
     g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(600, 4000), short_rng=(25, 330)))
     pr = synth.make_paired_reads(genome, n, 150, 300.0, 30.0, 0.01, seed)
     gb, go = g.packed()
-    fast, general = _ctx(api, gb, go, pr, False), _ctx(api, gb, go, pr, False)
+    fast, per_mate, general = _ctx(api, gb, go, pr, False), _ctx(api, gb, go, pr, False), _ctx(api, gb, go, pr, False)
+    per_mate.debug_set_knob(5, 4)
     general.debug_set_knob(5, 3)
     start, seq = synth.sa_sequence(g, 120, seed=3, threshold=400)
     for ps in [start] + seq:
-        a, b = fast.calc_prob(ps), general.calc_prob(ps)
-        assert a[0] == b[0] and a[1].tolist() == b[1].tolist()
-    assert fast.aligner_stats()["windows"] == general.aligner_stats()["windows"] > 0
+        a, b, c = fast.calc_prob(ps), general.calc_prob(ps), per_mate.calc_prob(ps)
+        assert a[0] == b[0] == c[0] and a[1].tolist() == b[1].tolist() == c[1].tolist()
+    assert fast.aligner_stats()["windows"] == general.aligner_stats()["windows"] == per_mate.aligner_stats()["windows"] > 0
     for mate in (0, 1):
         wa = _all_windows(fast, mate)
-        assert wa == _all_windows(general, mate)
+        assert wa == _all_windows(general, mate) == _all_windows(per_mate, mate)
         for key in wa[::3]:
-            assert fast.window_records(0, mate, list(key)).tobytes() == general.window_records(0, mate, list(key)).tobytes()
+            rec = fast.window_records(0, mate, list(key)).tobytes()
+            assert rec == general.window_records(0, mate, list(key)).tobytes() == per_mate.window_records(0, mate, list(key)).tobytes()

@@ -149,6 +149,24 @@ def test_put_window_records_is_an_alternative_to_the_internal_aligner(built):
         ctx.put_window_records(rs, 0, key, recs)
 
 
+def test_put_pacbio_records_rejects_what_the_sweep_cannot_take(built):
+    """PacBio records from outside: a read id outside the set, or an alignment that ends before it begins (the
+    reference's coverage sweep would close an interval that is not open, graph.cc:3229-3231)."""
+    from gaml_amd import api
+    genome = synth.make_genome(20_000, 3)
+    g = synth.make_graph(genome, synth.cut_lengths(20_000, 3, long_rng=(700, 2500)))
+    ctx = api.Context(device=-1)
+    ctx.set_graph(*g.packed())
+    rs = ctx.add_pacbio(api.single_cfg(mismatch_prob=0.15), np.full(10, 800, np.int32))
+    walk = synth.genome_walk(g)[:2]
+    ctx.put_pacbio_records(rs, walk, [(5, 700, 3), (40, 40, 4)], [-300.0, -280.0])  # (an empty interval is allowed)
+    assert len(ctx.pacbio_records(rs, walk)) == 2
+    for bad in ([(5, 700, 10)], [(5, 700, -1)], [(700, 5, 3)]):
+        with pytest.raises(api.GamlHipError):
+            ctx.put_pacbio_records(rs, walk, bad, [-300.0])
+    assert len(ctx.pacbio_records(rs, walk)) == 2
+
+
 def test_sharded_contexts_partition_the_records(built):
     from gaml_amd import api
     G, n, seed = 40_000, 2000, 25
