@@ -51,9 +51,34 @@ __device__ __forceinline__ char aln_wbase(const char* s, int W, int strand, int 
 __host__ __device__ inline int aln_span_first(int R) { return R - 1 > kAlnSeed ? R - 1 : kAlnSeed; }  // the reference's loop starts at i = kIndexKmer
 __host__ __device__ inline int aln_span_chunks(int W, int R) { const int f = aln_span_first(R); return W > f ? (W - f + kAlnBlock - 1) / kAlnBlock : 0; }
 
+// the bucket whose key is `hash`, or -1: top[h] = first bucket with key >= h << 16 (65537 entries), so the lower
+// bound runs over the few dozen keys that share the hash's upper half -- 5 dependent loads instead of 21
+__device__ __forceinline__ int aln_find_bucket(const uint64_t* bucket_hash, const int32_t* top, int n_buckets, uint32_t hash) {
+  int lo = top[hash >> 16], hi = top[(hash >> 16) + 1];
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (bucket_hash[mid] < (uint64_t)hash) lo = mid + 1; else hi = mid; }
+  return lo < n_buckets && bucket_hash[lo] == (uint64_t)hash ? lo : -1;
+}
+
+// Both mates of a paired read set in ONE small batch: windows [0, split) are mate 1's, [split, n) mate 2's (the same
+// junction strings, looked up in the other mate's index and extended against the other mate's reads).
+struct AlnMates {
+  const uint64_t* bucket_hash[2];
+  const int32_t* bucket_top[2];
+  const int32_t* bucket_off[2];
+  const int32_t* bucket_reads[2];
+  int n_buckets[2];
+  const char* reads[2];
+  const int64_t* read_off[2];
+  int split;
+};
+
+// FUSED (small batches of both mates): an emitted span looks its bucket up right here and appends its candidates -- no
+// span list, no second launch.
 // (windows [split, n_win) belong to a second read set -- the other mate -- whose index was built for read length R2)
+template <bool FUSED>
 __global__ __launch_bounds__(kAlnBlock) void span_maxima_kernel(const char* wstr, const AlnWindow* wins, int n_win, int R, const int* blk,
-                                                               AlnSpan* spans, unsigned* n_spans, unsigned cap_spans, int split = INT_MAX, int R2 = 0) {
+                                                               AlnSpan* spans, unsigned* n_spans, unsigned cap_spans, int split, int R2,
+                                                               AlnMates ix, AlnCand* cands, unsigned* n_cands, unsigned cap_cands) {
   __shared__ char sh_str[kAlnBlock + kAlnMaxRead + 2];
   __shared__ uint32_t sh_code[kAlnBlock + kAlnMaxRead + 2];
   __shared__ uint32_t sh_max[kAlnBlock];
@@ -118,22 +143,27 @@ __global__ __launch_bounds__(kAlnBlock) void span_maxima_kernel(const char* wstr
   if (threadIdx.x == 0) sh_base = total ? atomicAdd(n_spans, (unsigned)total) : 0;
   __syncthreads();
   if (emit) {
-    const unsigned at = sh_base + (unsigned)(wave_before + before);
-    if (at < cap_spans) spans[at] = AlnSpan{m, p, w, strand, i};
+    if (FUSED) {
+      const int mt = w >= ix.split ? 1 : 0;
+      const int b = aln_find_bucket(ix.bucket_hash[mt], ix.bucket_top[mt], ix.n_buckets[mt], m);
+      if (b >= 0) {
+        const int b0 = ix.bucket_off[mt][b], b1 = ix.bucket_off[mt][b + 1];
+        const unsigned at = atomicAdd(n_cands, (unsigned)(b1 - b0));
+        for (int k = b0; k < b1; k++) {
+          const unsigned o = at + (unsigned)(k - b0);
+          if (o < cap_cands) cands[o] = AlnCand{w, strand, i, p, ix.bucket_reads[mt][k]};
+        }
+      }
+    } else {
+      const unsigned at = sh_base + (unsigned)(wave_before + before);
+      if (at < cap_spans) spans[at] = AlnSpan{m, p, w, strand, i};
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // 2. candidates: every read of the bucket whose key is the span's hash (graph.cc:1329-1347)
 // ---------------------------------------------------------------------------------------------
-// the bucket whose key is `hash`, or -1: top[h] = first bucket with key >= h << 16 (65537 entries), so the lower
-// bound runs over the few dozen keys that share the hash's upper half -- 5 dependent loads instead of 21
-__device__ __forceinline__ int aln_find_bucket(const uint64_t* bucket_hash, const int32_t* top, int n_buckets, uint32_t hash) {
-  int lo = top[hash >> 16], hi = top[(hash >> 16) + 1];
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (bucket_hash[mid] < (uint64_t)hash) lo = mid + 1; else hi = mid; }
-  return lo < n_buckets && bucket_hash[lo] == (uint64_t)hash ? lo : -1;
-}
-
 __global__ __launch_bounds__(kAlnBlock) void candidates_kernel(const AlnSpan* spans, const unsigned* n_spans, unsigned cap_spans,
                                                               const uint64_t* bucket_hash, const int32_t* bucket_top, const int32_t* bucket_off,
                                                               const int32_t* bucket_reads, int n_buckets, AlnCand* cands,
@@ -381,36 +411,6 @@ __global__ __launch_bounds__(64 * kAlnWaves) void extend_kernel(const AlnCand* c
   for (unsigned t = blockIdx.x * kAlnWaves + (threadIdx.x >> 6); t < n; t += gridDim.x * kAlnWaves) {  // whole waves move together
     extend_candidate(L, lane, t, cands, wstr, wins, reads, read_off, hits);
     aln_lds_sync();  // the wave's LDS slice is reused by its next candidate
-  }
-}
-
-// Both mates of a paired read set in ONE small batch: windows [0, split) are mate 1's, [split, n) mate 2's (the same
-// junction strings, looked up in the other mate's index and extended against the other mate's reads).
-struct AlnMates {
-  const uint64_t* bucket_hash[2];
-  const int32_t* bucket_top[2];
-  const int32_t* bucket_off[2];
-  const int32_t* bucket_reads[2];
-  int n_buckets[2];
-  const char* reads[2];
-  const int64_t* read_off[2];
-  int split;
-};
-
-__global__ __launch_bounds__(kAlnBlock) void candidates_pair_kernel(const AlnSpan* spans, const unsigned* n_spans, unsigned cap_spans, AlnMates ix,
-                                                                   AlnCand* cands, unsigned* n_cands, unsigned cap_cands) {
-  const unsigned n = *n_spans < cap_spans ? *n_spans : cap_spans;
-  for (unsigned t = blockIdx.x * kAlnBlock + threadIdx.x; t < n; t += gridDim.x * kAlnBlock) {
-    const AlnSpan sp = spans[t];
-    const int mt = sp.win >= ix.split ? 1 : 0;
-    const int lo = aln_find_bucket(ix.bucket_hash[mt], ix.bucket_top[mt], ix.n_buckets[mt], sp.hash);
-    if (lo < 0) continue;
-    const int b0 = ix.bucket_off[mt][lo], b1 = ix.bucket_off[mt][lo + 1];
-    const unsigned at = atomicAdd(n_cands, (unsigned)(b1 - b0));
-    for (int k = b0; k < b1; k++) {
-      const unsigned o = at + (unsigned)(k - b0);
-      if (o < cap_cands) cands[o] = AlnCand{sp.win, sp.strand, sp.order, sp.pos, ix.bucket_reads[mt][k]};
-    }
   }
 }
 

@@ -595,8 +595,8 @@ int aln_small_enqueue(gaml_hip_ctx* c, const ShortMate& m, AlignDev& d, AlignSma
   const AlnWindow* d_wins = (const AlnWindow*)dbase;
   const int* d_blk = (const int*)(dbase + off_blk);
   const char* d_wstr = dbase + off_str;
-  hipLaunchKernelGGL(span_maxima_kernel, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, d_wstr, d_wins, nw, m.index_read_len, d_blk,
-                     S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans);
+  hipLaunchKernelGGL(span_maxima_kernel<false>, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, d_wstr, d_wins, nw, m.index_read_len, d_blk,
+                     S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans, INT_MAX, 0, AlnMates{}, (AlnCand*)nullptr, (unsigned*)nullptr, 0u);
   hipLaunchKernelGGL(candidates_kernel, dim3(64), dim3(kAlnBlock), 0, st, S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans,
                      d.bucket_hash.as<uint64_t>(), d.bucket_top.as<int32_t>(), d.bucket_off.as<int32_t>(), d.bucket_reads.as<int32_t>(), (int)m.bucket_hash.size(), S.cands.as<AlnCand>(),
                      S.counters.as<unsigned>() + 1, kFastCands);
@@ -790,10 +790,9 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
     ix.reads[mt] = d.reads.as<char>(); ix.read_off[mt] = d.read_off.as<int64_t>();
   }
   ix.split = n0;
-  hipLaunchKernelGGL(span_maxima_kernel, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, d_wstr, d_wins, nw, mm[0]->index_read_len, d_blk,
-                     S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans, n0, mm[1]->index_read_len);
-  hipLaunchKernelGGL(candidates_pair_kernel, dim3(64), dim3(kAlnBlock), 0, st, S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans, ix,
-                     S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1, kFastCands);
+  hipLaunchKernelGGL(span_maxima_kernel<true>, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, d_wstr, d_wins, nw, mm[0]->index_read_len, d_blk,
+                     S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans, n0, mm[1]->index_read_len, ix, S.cands.as<AlnCand>(),
+                     S.counters.as<unsigned>() + 1, kFastCands);
   hipLaunchKernelGGL(extend_pair_kernel, dim3(1024), dim3(64 * kAlnWaves), 0, st, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1, kFastCands, d_wstr,
                      d_wins, ix, S.hits.as<AlnHit>());
   job.seq = ++S.out_seq;
@@ -877,8 +876,9 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
     HIP_TRY(c, S.cands.reserve(cap_cands * sizeof(AlnCand)));
     HIP_TRY(c, hipMemset(S.counters.p, 0, 16));
     if (blk[(size_t)nw] > 0) {
-      hipLaunchKernelGGL(span_maxima_kernel, dim3((unsigned)blk[(size_t)nw]), dim3(kAlnBlock), 0, 0, S.wstr.as<char>(), S.wins.as<AlnWindow>(), nw,
-                         m.index_read_len, S.blk.as<int>(), S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), (unsigned)cap_spans);
+      hipLaunchKernelGGL(span_maxima_kernel<false>, dim3((unsigned)blk[(size_t)nw]), dim3(kAlnBlock), 0, 0, S.wstr.as<char>(), S.wins.as<AlnWindow>(), nw,
+                         m.index_read_len, S.blk.as<int>(), S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), (unsigned)cap_spans, INT_MAX, 0, AlnMates{},
+                         (AlnCand*)nullptr, (unsigned*)nullptr, 0u);
       HIP_TRY(c, hipGetLastError());
     }
     hipLaunchKernelGGL(candidates_kernel, dim3(256), dim3(kAlnBlock), 0, 0, S.spans.as<AlnSpan>(), S.counters.as<unsigned>(),
