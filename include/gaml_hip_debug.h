@@ -55,14 +55,20 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int
 int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out6);
 
 /* ---- tuning ------------------------------------------------------------------------------------- */
-/* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner), [1] thresholds +
- * occurrence tables, [2] (unused, 0), [3] packing the staging slot, [4] delta uploads, [5] kernel launches (prep kernel:
- * table copy + memo; scoring kernel), [6] bytes of per-call tables, [7] wait for the device */
+/* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner; includes [2]),
+ * [1] thresholds + occurrence tables, [2] alignment of newly registered windows (inside pass 1), [3] per-call tables
+ * written, [4] record tables / delta lists brought up to date, [5] kernel launches, [6] bytes of per-call tables
+ * written, [7] wait for the device */
 int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
-/* tuning experiments (tools/kbench.py): 0 = compact-path grid cap, 1 = dynamic LDS bytes, 2 = finish mode (1 ticket,
- * 2 finisher kernel), 3 = timing-only ablation, 4 = 1: no floor/log memo, 5 = 1: host window aligner, 6 = 1: no delta list,
- * 7 = 1: always wait with hipStreamSynchronize (no spinning on the pinned partials), 8 = 1: per-call uploads by
- * hipMemcpyAsync instead of the copy kernels, 11 = 1: two-pairs-per-iteration compact body */
+/* tuning experiments and A/B switches (tools/, tests): 0 = compact-class blocks, 1 = dynamic LDS bytes, 2 = finish mode
+ * (1 ticket, 2 finisher kernel), 3 = 8: in-kernel timeline, 4 = 1: no floor/log memo, 5 = 1: host window aligner,
+ * 2: hits sorted on the host, 3: always the general aligner route, 4: one small-batch pipeline per mate, 6 = 1: no delta
+ * list, 2: no quiet-spell rebuild, 7 = 1: always wait with hipStreamSynchronize (no spinning on the pinned partials),
+ * 8 = 1: no direct writes through the BAR (staging slots + copies), 9 = 1: aligner stage times with device syncs,
+ * 10 = blocks of the <=2-record class, 11 = batches: 1 one launch per path set, 2 whole tables per set, 3 no capture of
+ * unchanged pairs, 32 + mask: classes of blocks left out (TIMING ONLY, results wrong; tools/batch_ablate.py),
+ * 12 = 1: every path set planned from scratch, 13 = 1: whole per-call tables through the ring (no resident copy),
+ * 14 / 15: table rebuilds (above) */
 /* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
  * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
  * number of waves copied. Tuning aid (tools/kernel_timeline.py). */
