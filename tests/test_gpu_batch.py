@@ -137,7 +137,8 @@ def test_one_pass_batch_equals_single_calls(mixed_lengths):
     assert [b[0] for b in many.calc_prob_batch(sets[:8])] == [many.calc_prob(s)[0] for s in sets[:8]]
 
 
-def test_candidate_batches_build_their_tables_on_the_device():
+@pytest.mark.parametrize("two_sets", [False, True])
+def test_candidate_batches_build_their_tables_on_the_device(two_sets):
     """Candidates of one assembly (each a single edit away from the current one): the per-set occurrence tables are
     built on the device from the resident copy + a few patched entries, and pairs whose windows no later set changed
     are finished from their first set's result. Every route must give the same bits: the device-built tables, whole
@@ -148,6 +149,8 @@ def test_candidate_batches_build_their_tables_on_the_device():
     g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(600, 2500), short_rng=(25, 250)))
     pr = synth.make_paired_reads(genome, 40_000, 100, 250.0, 25.0, 0.01, seed)
     args = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    pr2 = synth.make_paired_reads(genome, 15_000, 100, 400.0, 40.0, 0.01, seed + 1)
+    args2 = (*synth.pack_reads(pr2.mate1), *synth.pack_reads(pr2.mate2))
     start, seq = synth.sa_sequence(g, 60, seed=seed, threshold=400)
     base = seq[-1]
     rng = np.random.default_rng(seed)
@@ -162,6 +165,8 @@ def test_candidate_batches_build_their_tables_on_the_device():
         c = api.Context(device=0)
         c.set_graph(*g.packed())
         c.add_paired(api.paired_cfg(250.0, 25.0), *args)
+        if two_sets:  # a second library over the same assembly: its own tables, patches and launches
+            c.add_paired(api.paired_cfg(400.0, 40.0, weight=0.5), *args2)
         if knob:
             c.debug_set_knob(11, knob)
         c.calc_prob(seq[-1])
