@@ -2489,7 +2489,7 @@ int gaml_hip_calc_prob_batch(gaml_hip_ctx* c, int32_t n_sets, const int32_t* pat
     }
     if (done_sets == n_sets) return GAML_HIP_OK;
     // (the sequential path below handles sets [done_sets, n_sets))
-    paths = paths; offs = offs; set_offs += done_sets; probs_out += done_sets;
+    set_offs += done_sets; probs_out += done_sets;  // (paths / offs stay: set_offs indexes into them)
     if (zeros_out) zeros_out += (size_t)done_sets * 2 * ns;
     if (total_lens_out) total_lens_out += done_sets;
     n_sets -= done_sets;
