@@ -796,9 +796,10 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   const int cap0 = c->knobs[0] > 0 ? c->knobs[0]
                                    : (int)std::min<int64_t>(kMaxBlocks, one_round > 768 && one_round <= 1280 ? one_round : std::max<int64_t>(768, n0 / 2900));
   gp.blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
-  // the 2-record class: a quarter of the compact class's blocks (3/4 block per CU at cfg3), lanes take 1-2 pairs;
-  // more blocks only crowd the compact class out (tools/kbench.py sweep: 312 blocks 16.4 us, 192 blocks 15.0 us)
-  const int cap1 = c->knobs[10] > 0 ? c->knobs[10] : cap0 / 4;
+  // the 2-record class: a third of the compact class's blocks (one block per CU at cfg3), lanes take 1-2 pairs; more
+  // blocks only crowd the compact class out (tools/blocks_sweep.py at cfg3, pairs ordered by window in every class:
+  // 128 blocks 11.4 us, 192: 10.1, 224-256: 9.8-9.9, 320: 10.2)
+  const int cap1 = c->knobs[10] > 0 ? c->knobs[10] : cap0 / 3;
   gp.blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, cap1));
   gp.blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>((n_main - n01 + kBlock - 1) / kBlock, kMaxBlocks / 4));
   // delta pairs: one lane per pair behind the table classes
