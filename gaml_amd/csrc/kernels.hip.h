@@ -718,10 +718,13 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
 
 // Classes 1 and 2: at most K = 2 / 4 records per mate, 16-byte records, overwrite rule in registers.
 // Slots [slot_lo, slot_hi), blocks [block_lo, block_hi).
+// (tl: the in-kernel timeline's slot of this wave, stamps [2] records in, [3] candidates (occurrence entries) in, [5]
+// first pair finished -- tools/kernel_timeline.py)
 template <int K, bool GEN>
 __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
-                                                 double& lsum, int& zeros) {
+                                                 double& lsum, int& zeros, unsigned long long* tl = nullptr) {
   unsigned long long* bits = GEN ? a.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2) : nullptr;
+  bool first_pair = true;
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
     const int t = i - a.n0;
     const uint32_t l12 = a.len12[t];
@@ -731,11 +734,15 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
     int4 r1[K], r2[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { r1[k] = a.inl[0][at + k]; r2[k] = a.inl[1][at + k]; }
+    if (tl && first_pair) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[2] = (unsigned long long)wall_clock64() + (r1[0].x == 0x12345 ? 1 : 0); }
     RegCands<K> x, y;
     const bool m1 = cands_from_records<K>(a.m[0], r1, x), m2 = cands_from_records<K>(a.m[1], r2, y);
+    if (tl && first_pair) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[3] = (unsigned long long)wall_clock64() + (x.pos[0] == 0x12345 ? 1 : 0); }
     const bool dirty = r1[0].x == kDirtyWid;  // scored from the delta lists (paired_delta_body)
     const bool general = !dirty && (m1 || m2);  // a window that occurs several times: paired_general_kernel
     if (!dirty && !general) score_cands_and_finish<K>(a, i, l12, x, y, lsum, zeros);
+    if (tl && first_pair) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[5] = (unsigned long long)wall_clock64() + (lsum == 0.12345 ? 1 : 0); }
+    first_pair = false;
     if (GEN) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
       const unsigned long long k = __ballot(general);
       if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
@@ -806,7 +813,7 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
       if (wide) paired_compact4_body<GEN, TL>(b, lb, lsum, zeros);
       else paired_compact_body<GEN>(b, lb, lsum, zeros);
     }
-  } else if (lb < a.blocks01) paired_regs_body<2, GEN>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros);
+  } else if (lb < a.blocks01) paired_regs_body<2, GEN>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros, tl);
   else if (lb < a.blocks012) paired_regs_body<4, GEN>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
   else paired_delta_body(a, lb - a.blocks012, a.main_blocks - a.blocks012, lsum, zeros);
   block_reduce(lsum, zeros, sh_s, sh_z);

@@ -34,7 +34,7 @@ for rep in range(3):
         if not len(w):
             continue
         print(f"  class {label}: {len(w)} waves")
-        cols = range(7) if cls == 0 else (0, 6)
+        cols = range(7) if cls == 0 else ((0, 2, 3, 5, 6) if cls == 1 else (0, 6))  # the two-record class stamps: records in, candidates in, first pair finished
         prev = None
         for c in cols:
             abs_us = (w[:, c] - t0) / 100
