@@ -185,6 +185,7 @@ struct TableRebuild {
   hipStream_t stream = nullptr;
   double snapshot_us = 0, build_ms = 0;
   int64_t start_eval = 0;      // the set's evaluation count when the rebuild was decided
+  bool keep_dominated = false; // knob 16 as the worker read it
   size_t next_w[2] = {0, 0};   // state 4: progress of the private copy (first window not copied yet)
 };
 
@@ -231,6 +232,7 @@ struct PairedSet {
   Staging stage_delta;
   size_t delta_off[5] = {0, 0, 0, 0, 0};   // spill CSR: offsets mate 0, records mate 0, offsets mate 1, records mate 1, slots
   int quiet_calls = 0;       // evaluations since the last window activation
+  bool built_keep_dominated = false;  // knob 16 at the last table build on the calling thread
   bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
   PinBuf h_timeline; int timeline_waves = 0;  // ablation 8 (tools/kernel_timeline.py)
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls): [set][block]
@@ -360,7 +362,7 @@ struct gaml_hip_ctx {
   double aln_us = 0;
   double aln_stage_us[5] = {0, 0, 0, 0, 0};  // window strings + upload, spans + candidates, extension, D2H of hits, sort + finalize
   int64_t aln_batches = 0;
-  int knobs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
+  int knobs[24] = {0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
   bool direct_write = false;  // large-BAR device: the host writes per-call tables straight into device memory (Arena)
   int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;

@@ -1407,7 +1407,7 @@ int gaml_hip_put_window_records(gaml_hip_ctx* c, int readset, int mate, const in
   std::stable_sort(v.begin(), v.end(), [](const gaml_aligment& a, const gaml_aligment& b) {  // graph.cc:1024-1026
     return a.position == b.position ? a.read_id < b.read_id : a.position < b.position;
   });
-  m->add_window(w, v);
+  m->add_window(c->g, w, v);
   return GAML_HIP_OK;
 }
 
@@ -2676,12 +2676,13 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wi
   return (int32_t)w.size();
 }
 
-int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out6) {
+int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out8) {
   MULTI_SHARD0(c);
-  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out6) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out8) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
-  out6[0] = s.full_rebuilds; out6[1] = s.delta_updates; out6[2] = (int64_t)s.dirty.size(); out6[3] = s.async_rebuilds;
-  out6[4] = s.batches_patched; out6[5] = s.batches_full;
+  out8[0] = s.full_rebuilds; out8[1] = s.delta_updates; out8[2] = (int64_t)s.dirty.size(); out8[3] = s.async_rebuilds;
+  out8[4] = s.batches_patched; out8[5] = s.batches_full;
+  out8[6] = s.pt.dropped_records[0]; out8[7] = s.pt.dropped_records[1];
   return GAML_HIP_OK;
 }
 
@@ -2715,7 +2716,7 @@ int gaml_hip_debug_timeline(gaml_hip_ctx* c, int rs, unsigned long long* out, in
 }
 
 int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
-  if (!c || knob < 0 || knob >= 16) return GAML_HIP_EINVAL;
+  if (!c || knob < 0 || knob >= 24) return GAML_HIP_EINVAL;
   if (c->multi) { for (int k = 0; k < gaml::multi_num_shards(c->multi); k++) gaml::multi_shard(c->multi, k)->knobs[knob] = value; return GAML_HIP_OK; }
   c->knobs[knob] = value;
   return GAML_HIP_OK;

@@ -363,11 +363,18 @@ static void revcomp_into(const char* s, int32_t n, std::string& out) {
   for (int32_t i = 0; i < n; i++) out[i] = comp(s[n - 1 - i]);
 }
 
-int32_t ShortMate::add_window(const Walk& w, std::vector<gaml_aligment>& recs) {
+void ShortMate::tag_window(const GraphStore& g, int32_t wid, const Walk& w) {
+  Window& win = wins[wid];
+  if (w.size() == 1) win.solo = w[0];
+  else if (w.size() > 1 && w[0] >= 0 && g.len(w[0]) > kTail) win.head = w[0];  // the condition of placements_paired_contig
+}
+
+int32_t ShortMate::add_window(const GraphStore& g, const Walk& w, std::vector<gaml_aligment>& recs) {
   auto it = win_id.find(w);
   if (it != win_id.end()) return it->second;  // re-alignment would give the same records
   int32_t id = (int32_t)wins.size();
   wins.push_back(Window());
+  tag_window(g, id, w);
   auto ins = win_id.emplace(w, id);
   win_walk.push_back(&ins.first->first);
   unsynced.push_back(id);
@@ -448,6 +455,7 @@ int32_t ShortMate::align(const GraphStore& g, const Walk& w) {
   int32_t id = (int32_t)wins.size();
   wins.push_back(Window());
   wins[id].pending = true;
+  tag_window(g, id, w);
   auto ins = win_id.emplace(w, id);
   win_walk.push_back(&ins.first->first);
   unsynced.push_back(id);
@@ -1071,7 +1079,45 @@ void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_re
   out.built_generation = m.active_generation;
 }
 
-void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) {
+// Records that can never survive the overwrite rule (graph.cc:583-592), whatever the path set. A window J of several
+// nodes whose first node i is longer than kTail is looked up together with the node's own window {i}, J first, both at
+// the node's path position and under the same position filter (GetPositionsOnlyPath graph.cc:563-577;
+// placements_paired_contig above). A record of J that {i} also holds for the same read at the same position -- a read
+// in the last kTail bases of a long node, seen through the node and through the junction that follows it -- is
+// therefore overwritten by {i}'s record wherever J occurs, and absent wherever J does not. Leaving it out of the
+// device tables changes no value; it turns most two-record pairs (a tenth of the pairs at BASELINE config 3) into
+// one-record pairs of the compact class. {i} must be on the device itself (active) for its record to stand in; a
+// rebuild, which is also where windows retire, decides anew.
+// Both windows' records are ordered by (position, read) (graph.h:229-232): one merge per junction window.
+static void dominated_records(const ShortMate& m, std::vector<uint8_t>& drop) {
+  drop.assign(m.pool.size(), 0);
+  std::unordered_map<int32_t, int32_t> solo;  // node -> its active single-node window
+  bool any_head = false;
+  for (size_t wid = 0; wid < m.wins.size(); wid++) {
+    const Window& w = m.wins[wid];
+    if (!w.active || w.count == 0) continue;
+    if (w.solo >= 0) solo.emplace(w.solo, (int32_t)wid);
+    any_head |= w.head >= 0;
+  }
+  if (!any_head || solo.empty()) return;
+  auto before = [](const gaml_aligment& x, const gaml_aligment& y) { return x.position != y.position ? x.position < y.position : x.read_id < y.read_id; };
+  for (const Window& j : m.wins) {
+    if (!j.active || j.count == 0 || j.head < 0) continue;
+    auto it = solo.find(j.head);
+    if (it == solo.end()) continue;
+    const Window& sw = m.wins[it->second];
+    const gaml_aligment* a = m.pool.data() + j.first, * const ae = a + j.count;
+    const gaml_aligment* const sb = m.pool.data() + sw.first, * const se = sb + sw.count;
+    const gaml_aligment* b = std::lower_bound(sb, se, *a, before);
+    while (a < ae && b < se) {
+      if (before(*a, *b)) a++;
+      else if (before(*b, *a)) b++;
+      else { drop[(size_t)(a - m.pool.data())] = 1; a++; }
+    }
+  }
+}
+
+void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold) {
   static const bool trace_bpt = getenv("GAML_HIP_TRACE_HOST") != nullptr;
   auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_stage[8]; int n_stage = 0;
@@ -1081,15 +1127,20 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
   // per read: record count over ACTIVE windows, and the single record when there is exactly one
   std::vector<int32_t> k[2];
   std::vector<uint64_t> one[2];
+  std::vector<uint8_t> drop[2];  // records left out: dominated_records
   const bool big = n >= (1 << 16);
   parallel_mates(big, [&](int mt) {
     k[mt].assign(n, 0);
     one[mt].assign(n, kNoRec8);
     const ShortMate& m = *mates[mt];
+    if (fold) dominated_records(m, drop[mt]); else drop[mt].assign(m.pool.size(), 0);
+    out.dropped_records[mt] = 0;
+    for (uint8_t d : drop[mt]) out.dropped_records[mt] += d;
     for (size_t wid = 0; wid < m.wins.size(); wid++) {
       const Window& w = m.wins[wid];
       if (!w.active) continue;
       for (int64_t q = w.first; q < w.first + w.count; q++) {
+        if (drop[mt][q]) continue;
         const gaml_aligment& r = m.pool[q];
         if (k[mt][r.read_id]++ == 0)
           one[mt][r.read_id] = rec8_fits((int32_t)wid, r.position, r.edit_dist) ? rec8_pack((int32_t)wid, r.position, r.edit_dist, r.orientation)
@@ -1184,7 +1235,7 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
     ReadMajor& rm = out.rm[mt];
     const int64_t n16 = n - n0;
     std::vector<int32_t> cnt(n16 + 1, 0);
-    for (const Window& w : m.wins) if (w.active) for (int64_t q = w.first; q < w.first + w.count; q++) { int32_t t = slot16[m.pool[q].read_id]; if (t >= 0) cnt[t + 1]++; }
+    for (const Window& w : m.wins) if (w.active) for (int64_t q = w.first; q < w.first + w.count; q++) { if (drop[mt][q]) continue; int32_t t = slot16[m.pool[q].read_id]; if (t >= 0) cnt[t + 1]++; }
     std::vector<int64_t> start(n16 + 1, 0);
     int64_t extras = 0;
     for (int64_t i = 0; i < n16; i++) { start[i] = extras; extras += cnt[i + 1] > 1 ? cnt[i + 1] - 1 : 0; }
@@ -1197,7 +1248,7 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out) 
       for (int64_t q = win.first; q < win.first + win.count; q++) {
         const gaml_aligment& r = m.pool[q];
         const int32_t at = slot16[r.read_id];
-        if (at < 0) continue;
+        if (at < 0 || drop[mt][q]) continue;
         RecQuad rq{(int32_t)wid, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
         int32_t sn = seen[at]++;
         if (sn == 0) { rq.flags |= (cnt[at + 1] - 1) << 9; rq.link = (int32_t)start[at]; rm.first[at] = rq; }

@@ -54,6 +54,10 @@ struct Window {
   int32_t global_max_pos = INT_MIN;  // ... among all shards' reads (== max_pos until exchanged)
   bool active = false;        // has occurred in a scored path set: its records are on the device
   bool pending = false;       // registered, records not computed yet (batched alignment)
+  // what build_pair_tables needs of the walk (set at registration, ShortMate::tag_window):
+  int32_t solo = -1;          // single-node window: the node
+  int32_t head = -1;          // window of several nodes whose first node is longer than kTail: that node. Wherever this
+                              // window is looked up, the node's own window is looked up right after it (graph.cc:563-566)
 };
 
 // One occurrence of a window in the path set being scored.
@@ -116,7 +120,8 @@ struct ShortMate {
   void set_reads(int64_t n_global_, int64_t lo_, int64_t hi_, const char* b, const int64_t* offs_global);
   void build_index();
   int32_t find(const Walk& w) const { auto it = win_id.find(w); return it == win_id.end() ? -1 : it->second; }
-  int32_t add_window(const Walk& w, std::vector<gaml_aligment>& recs_sorted_local);
+  int32_t add_window(const GraphStore& g, const Walk& w, std::vector<gaml_aligment>& recs_sorted_local);
+  void tag_window(const GraphStore& g, int32_t wid, const Walk& w);
   // the library's own aligner (AlignSubpathInternal graph.cc:839-899). With defer_alignment the
   // window is only registered (cache membership is what the registration rules look at); its
   // records are computed later for the whole batch: flush_pending_cpu, or the GPU aligner.
@@ -190,8 +195,10 @@ struct PairTables {
   // the same records once more, inline per pair, for the register paths: class 1 holds 2 slots per
   // pair and mate at [2t + k], class 2 holds 4 at [2 n1 + 4 t2 + k] (wid = -1: no record)
   std::vector<RecQuad> inl[2];
+  int64_t dropped_records[2] = {0, 0};    // records of active windows left out of the tables (dominated_records)
 };
-void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out);
+// fold = false keeps the records that can never survive the overwrite rule (A/B and tests; same values either way)
+void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold = true);
 
 
 // direct-mapped occurrence table for the device: one 16-B entry per window.

@@ -261,7 +261,8 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   paired_retire_windows(c, s);
   for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
   const double tb0 = now_us();
-  build_pair_tables(s.mate[0], s.mate[1], s.pt);
+  build_pair_tables(s.mate[0], s.mate[1], s.pt, c->knobs[16] != 1);
+  s.built_keep_dominated = c->knobs[16] == 1;
   const double tb1 = now_us();
   HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old tables
   if (int e = paired_upload_pows(c, s)) return e;
@@ -321,7 +322,8 @@ void paired_launch_worker(gaml_hip_ctx* c, PairedSet& s) {
     int rc = hipSetDevice(device) == hipSuccess ? 0 : GAML_HIP_EHIP;
     if (rc) rb.err = "hipSetDevice failed in the rebuild worker";
     if (!rc) {
-      build_pair_tables(rb.snap[0], rb.snap[1], rb.pt);
+      rb.keep_dominated = c->knobs[16] == 1;
+      build_pair_tables(rb.snap[0], rb.snap[1], rb.pt, !rb.keep_dominated);
       rc = paired_upload_tables(c, s, rb.pt, rb.tab, rb.stream, &rb.err);
       if (!rc && hipStreamSynchronize(rb.stream) != hipSuccess) { rc = GAML_HIP_EHIP; rb.err = "stream synchronise failed in the rebuild worker"; }
     }
@@ -379,6 +381,7 @@ int paired_finish_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   HIP_TRY(c, hipStreamSynchronize(st));  // launches in flight may still read the old tables
   std::swap(s.tab, rb.tab);
   std::swap(s.pt, rb.pt);
+  s.built_keep_dominated = rb.keep_dominated;
   paired_reset_delta(s);
   s.full_rebuilds++;
   s.async_rebuilds++;
@@ -530,7 +533,8 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     if (activated_now) for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
     const bool over = activated_now && s.dirty.size() + new_records > limit;
     const bool quiet = !activated_now && !s.dirty.empty() && s.quiet_calls >= 64 && c->knobs[6] != 2;
-    const bool asked = s.compact_requested && (!s.dirty.empty() || activated_now);
+    const bool refold = (c->knobs[16] == 1) != s.built_keep_dominated;  // A/B of the table contents: a request rebuilds even without delta pairs
+    const bool asked = s.compact_requested && (!s.dirty.empty() || activated_now || refold);
     s.compact_requested = false;
     const bool use_worker = c->knobs[14] != 1 && c->knobs[6] != 1;
     // the delta store must hold what accumulates while a worker builds; when it cannot, wait for the worker
@@ -539,7 +543,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     if (asked || ((over || quiet) && !use_worker) || overflow) {
       if (rstate == 1) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; rstate = 0; activated_now = !s.mate[0].activated_log.empty() || !s.mate[1].activated_log.empty(); }
       const bool still = asked || overflow || !use_worker;
-      if (still && (!s.dirty.empty() || activated_now)) { if (int e = paired_rebuild_tables(c, s, st)) return e; activated_now = false; }
+      if (still && (!s.dirty.empty() || activated_now || refold)) { if (int e = paired_rebuild_tables(c, s, st)) return e; activated_now = false; }
     } else if ((over || quiet) && rstate == 0) {
       if (int e = paired_start_async_rebuild(c, s)) return e;
       rstate = 1;

@@ -48,11 +48,12 @@ int64_t gaml_hip_debug_table_occurrences(gaml_hip_ctx* ctx, int readset, int mat
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
 /* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list, rebuilds
  * done by the worker thread (of the full rebuilds), gaml_hip_calc_prob_batch chunks whose per-set tables were built on
- * the device from patches, chunks whose tables were written whole}.
+ * the device from patches, chunks whose tables were written whole, records of mate 1 / mate 2 that the current tables
+ * leave out because another record of the same read always overwrites them (knob 16)}.
  * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables); knob 14 = 1 keeps every
  * rebuild on the calling thread, knob 14 = k > 1 lets a worker's tables take over k evaluations after its start
  * (default 768); knob 15 = 1: rebuilds never retire unused windows. */
-int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out6);
+int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out8);
 
 /* ---- tuning ------------------------------------------------------------------------------------- */
 /* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner; includes [2]),
@@ -68,7 +69,8 @@ int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
  * 10 = blocks of the <=2-record class, 11 = batches: 1 one launch per path set, 2 whole tables per set, 3 no capture of
  * unchanged pairs, 32 + mask: classes of blocks left out (TIMING ONLY, results wrong; tools/batch_ablate.py),
  * 12 = 1: every path set planned from scratch, 13 = 1: whole per-call tables through the ring (no resident copy),
- * 14 / 15: table rebuilds (above) */
+ * 14 / 15: table rebuilds (above), 16 = 1: record tables keep the records that can never survive the overwrite rule
+ * (host_model.cc dominated_records; takes effect at the next table build; same values either way) */
 /* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
  * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
  * number of waves copied. Tuning aid (tools/kernel_timeline.py). */

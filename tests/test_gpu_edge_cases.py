@@ -229,3 +229,35 @@ def test_upload_paths_agree():
         assert [ctx.calc_prob(s)[0] for s in sets] == a, knob
         assert [b[0] for b in ctx.calc_prob_batch(sets)] == ab, knob
     assert ab == a  # one pass over the records for all sets: the same lanes, the same sums
+
+
+def test_records_that_are_always_overwritten_stay_out_of_the_tables():
+    """A read in the last 300 bases of a long node is aligned through the node's window and through the junction window
+    that follows it; wherever both occur the node's record overwrites the junction's (graph.cc:583-592, 563-566). The
+    table build leaves such junction records out (host_model.cc dominated_records): every per-pair value must be the
+    one computed with them (knob 16 = 1) and the oracle's, for path sets that use the junctions, cut them and drop them."""
+    G, n, seed = 120_000, 30_000, 4242
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(500, 3000)))
+    pr = synth.make_paired_reads(genome, n, 100, 260.0, 26.0, 0.01, seed)
+    r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 3
+    sets = [[walk], [walk[:k], walk[k:]], [walk[:k] + walk[k + 2:]], [walk[k:2 * k], walk[:k]], [walk]]
+    ctx, rs, orc, ors = _both(*g.packed(), r1, r2, {}, 260.0, 26.0)
+    keep, rs_k, _, _ = _both(*g.packed(), r1, r2, {}, 260.0, 26.0)
+    keep.debug_set_knob(16, 1)
+    for rnd in range(2):  # second round: tables rebuilt with every window of the sets on the device
+        for paths in sets:
+            got, kept = ctx.calc_prob(paths), keep.calc_prob(paths)
+            assert np.array_equal(ctx.read_probs(rs), keep.read_probs(rs_k))
+            assert got[1].tolist() == kept[1].tolist() and abs(got[0] - kept[0]) <= 1e-13 * abs(kept[0])
+            _agree(ctx, rs, orc, ors, paths)
+        ctx.compact_tables()
+        keep.compact_tables()
+    ctx.calc_prob(sets[0])
+    keep.calc_prob(sets[0])
+    st, st_k = ctx.debug_table_stats(rs), keep.debug_table_stats(rs_k)
+    assert min(st["records_left_out"]) > 0 and st_k["records_left_out"] == [0, 0]
+    c0, c1 = ctx.debug_class_counts(rs), keep.debug_class_counts(rs_k)
+    assert c0[0] > c1[0] and sum(c0) == sum(c1) == n

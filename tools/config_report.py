@@ -151,7 +151,7 @@ for f in seq[:100]:
 t_cpu = (time.perf_counter() - t) / 100
 emit({"config": 5, "what": "1000 annealing-pattern evaluations (edited path sets, ~900 paths, new junction windows aligned on the fly) on config 3's reads, ONE GPU",
       "gpu_total_s": tot, "gpu_us_per_eval_median": float(np.median(per)), "gpu_us_per_eval_p90": float(np.percentile(per, 90)),
-      "gpu_us_per_eval_max": float(per.max()), "table_stats": {k: int(v) for k, v in ctx.debug_table_stats(0).items()},
+      "gpu_us_per_eval_max": float(per.max()), "table_stats": ctx.debug_table_stats(0),
       "cpu_oracle_incremental_ms_per_eval_on_50000_pairs": t_cpu * 1e3,
       "cpu_oracle_incremental_ms_per_eval_scaled_to_all_pairs": t_cpu * 1e3 * wl.n_pairs / ns})
 if out_path:
