@@ -20,7 +20,7 @@ paths = variants[0]
 ctx.score(paths)
 print("class counts", ctx.debug_class_counts(rs))
 ctx.set_event_timing(True)
-for k0, k10 in ((0, 0), (0, 128), (0, 160), (0, 224), (0, 256), (0, 320), (0, 384), (0, 512), (0, 640), (0, 0)):
+for k0, k10 in ((0, 0), (0, 64), (0, 80), (0, 112), (0, 128), (0, 160), (0, 256), (700, 0), (776, 0), (850, 0), (1024, 0), (0, 0)):
     ctx.debug_set_knob(0, k0); ctx.debug_set_knob(10, k10)
     for _ in range(50): ctx.score(paths)
     ctx.kernel_stats(reset=True)
