@@ -20,8 +20,8 @@ paths = variants[0]
 ctx.score(paths)
 print("class counts", ctx.debug_class_counts(rs))
 ctx.set_event_timing(True)
-for k0, k10 in ((0, 0), (0, 64), (0, 80), (0, 112), (0, 128), (0, 160), (0, 256), (700, 0), (776, 0), (850, 0), (1024, 0), (0, 0)):
-    ctx.debug_set_knob(0, k0); ctx.debug_set_knob(10, k10)
+for k0, k10 in eval(os.environ.get('SWEEP', '((0, 0), (0, 128), (0, 160), (0, 256), (776, 0), (850, 0), (0, 0))')):
+    ctx.debug_set_knob(0, k0 % 10000); ctx.debug_set_knob(10, k10); ctx.debug_set_knob(17, k0 // 10000)  # k0 = order * 10000 + blocks
     for _ in range(50): ctx.score(paths)
     ctx.kernel_stats(reset=True)
     t = time.perf_counter()

@@ -44,6 +44,14 @@ for rep in range(3):
                 line += f"   stage {np.median(d):5.2f} us (p90 {np.percentile(d, 90):5.2f})"
             print(line)
             prev = c
+    if True:  # which blocks are late, evaluation after evaluation? (lb = blocks - 1 - blockIdx: position in the pair order)
+        fw = ctx.debug_timeline(rs).astype(np.int64)
+        okc = (fw[:, 0] > 0) & (fw[:, 7] == 0)
+        dn = (fw[:, 6] - t0) / 100
+        nblk = len(fw) // 4
+        late = sorted(set((np.arange(len(fw))[okc & (dn > np.percentile(dn[okc], 97))] // 4).tolist()))
+        rec = {b: float(((fw[b * 4:(b + 1) * 4, 2] - fw[b * 4:(b + 1) * 4, 1]) / 100).max()) for b in late}
+        print("  late blocks (done beyond p97), blockIdx:records stage us:", ", ".join(f"{b}:{rec[b]:.1f}" for b in late))
     if rep == 2:  # dispatch order: when does block b enter?
         full = ctx.debug_timeline(rs).astype(np.int64)
         nb = len(full) // 4
@@ -51,3 +59,17 @@ for rep in range(3):
         print("  entry time by blockIdx:", ", ".join(f"{b}: {ent[b]:.2f}" for b in (0, 1, 2, 3, 8, 16, 64, 128, 256, 512, 768, nb - 2, nb - 1) if b < nb))
         order = np.argsort(ent)
         print("  first blocks to enter:", order[:16].tolist(), " last:", order[-8:].tolist())
+        # the stragglers: which compact-class waves finish last, and in which stage do they lose their time?
+        wave_id = np.arange(len(full))
+        ok = (full[:, 0] > 0) & (full[:, 7] == 0)
+        wv, ids = full[ok], wave_id[ok]
+        done = (wv[:, 6] - t0) / 100
+        med = [np.median((wv[:, c] - wv[:, c - 1]) / 100) for c in range(1, 7)]
+        print("  median stage durations (tables, records, occurrences, memo, stores, reduce):", " ".join(f"{x:.2f}" for x in med))
+        print("  slowest compact-class waves: block.wave, entry, then stage durations, done")
+        for k in np.argsort(done)[-16:][::-1]:
+            st = [(wv[k, c] - wv[k, c - 1]) / 100 for c in range(1, 7)]
+            print(f"    {ids[k] // 4:4d}.{ids[k] % 4}  entry {(wv[k, 0] - t0) / 100:5.2f}  " + " ".join(f"{x:5.2f}" for x in st) + f"  done {done[k]:5.2f}")
+        blk_done = np.array([done[ids // 4 == b].max() for b in np.unique(ids // 4)])
+        print("  blocks done after 9 us:", int((blk_done > 9).sum()), "of", len(blk_done), "; after 8.5:", int((blk_done > 8.5).sum()), "; after 8:", int((blk_done > 8).sum()))
+ctx.close()
