@@ -959,6 +959,16 @@ bool PairedPlanner::begin(const GraphStore& g, ShortMate mate[2], const int32_t*
   return true;
 }
 
+// the entries of a path's occurrences as OccImage::build writes them, minus the path slot (packed as occ8_pack packs them)
+static void occ_prepack(const std::vector<Occ>& occ, std::vector<OccPre>& pre) {
+  pre.resize(occ.size());
+  for (size_t k = 0; k < occ.size(); k++) {
+    const Occ& o = occ[k];
+    const int32_t mp = o.min_pos < -32768 ? -32768 : o.min_pos;
+    pre[k] = OccPre{o.min_pos <= 32767 ? o.wid : ~o.wid, (uint32_t)o.shift, (uint32_t)(uint16_t)(int16_t)mp, o.rank};
+  }
+}
+
 void PairedPlanner::invalidate_thresholds() {
   for (auto& pm : memos_) pm->occ_valid[0] = pm->occ_valid[1] = false;
   have_prev_ = false;  // every occurrence list changes: the next call rebuilds the tables from scratch
@@ -972,6 +982,7 @@ void PairedPlanner::finish(ShortMate mate[2]) {
       occurrences_from_placements(mate[mt], pm.pl[mt], pm.occ[mt]);
       pm.assembled[mt] = 0;
       for (const Occ& o : pm.occ[mt]) pm.assembled[mt] += mate[mt].wins[o.wid].count;
+      occ_prepack(pm.occ[mt], pm.pre[mt]);
       pm.occ_valid[mt] = true;
     }
   };
@@ -1387,32 +1398,39 @@ void OccImage::dump(std::vector<Occ>& out) const {
 
 void OccImage::build(size_t n_windows, const PlanView& view, int mate) {
   grow(n_windows);
-  for (int32_t w : touched_) { if (cnt_[w]) { occ12[w] = Occ12{~0u, ~0u, 0}; cnt_[w] = 0; } }
+  // The previous set's entries are cleared AFTER the new ones are written, and only where the new set has none: path
+  // sets of one assembly mostly name the same windows, whose entries would otherwise be written twice.
+  stale_.swap(touched_);
   touched_.clear();
   gen_.clear();
   if (++serial_ == 0) { std::fill(stamp_.begin(), stamp_.end(), 0); serial_ = 1; }
-  // ONE pass over the occurrences: a window's first occurrence is written as a direct entry straight away; a second
-  // occurrence moves the first one to the window's list (the entry holds everything a list entry needs: a filter
-  // threshold clamped at -32768 filters like the exact one, positions are >= 0).
+  // ONE pass over the occurrences: a window's first occurrence is written as a direct entry straight away (prepacked
+  // with the path's occurrence list: only the path slot is added here); a second occurrence moves the first one to
+  // the window's list (the entry holds everything a list entry needs: a filter threshold clamped at -32768 filters like
+  // the exact one, positions are >= 0).
   for (size_t slot = 0; slot < view.paths.size(); slot++) {
     const PathMemo& pm = *view.paths[slot];
-    for (const Occ& o : pm.occ[mate]) {
-      const OccQuad q{o.shift, o.min_pos, (int32_t)slot, o.rank};
-      const int32_t w = o.wid;
+    const std::vector<OccPre>& pre = pm.pre[mate];
+    const bool slot_fits = slot < 32767;
+    const uint32_t slot_bits = (uint32_t)(slot & 0x7fff) << 16;
+    for (size_t k = 0; k < pre.size(); k++) {
+      const OccPre& e = pre[k];
+      const bool direct = slot_fits && e.wid >= 0;
+      const int32_t w = e.wid >= 0 ? e.wid : ~e.wid;
       if (stamp_[w] != serial_) {  // first occurrence of this window in this path set
         stamp_[w] = serial_; cnt_[w] = 1; touched_.push_back(w);
-        if (occ_fits_direct(q)) {
-          const uint64_t e = occ8_pack(q, false);
-          occ12[w] = Occ12{(uint32_t)e, (uint32_t)(e >> 32), q.rank};
-        } else gen_[w].push_back(q);
+        if (direct) occ12[w] = Occ12{e.lo, e.hi | slot_bits, e.rank};
+        else { const Occ& o = pm.occ[mate][k]; gen_[w].push_back(OccQuad{o.shift, o.min_pos, (int32_t)slot, o.rank}); }
         continue;
       }
+      const Occ& o = pm.occ[mate][k];
       auto it = gen_.find(w);
       if (it == gen_.end()) it = gen_.emplace(w, std::vector<OccQuad>(1, occ_from_direct(occ12[w]))).first;
-      it->second.push_back(q);
+      it->second.push_back(OccQuad{o.shift, o.min_pos, (int32_t)slot, o.rank});
       cnt_[w]++;
     }
   }
+  for (int32_t w : stale_) if (stamp_[w] != serial_ && cnt_[w]) { occ12[w] = Occ12{~0u, ~0u, 0}; cnt_[w] = 0; }
   changed_all = true;
   lists_dirty_ = true;
   std::vector<int32_t> ident(view.paths.size());

@@ -251,7 +251,7 @@ struct OccImage {
   void grow(size_t n_windows);
   void mark(int32_t w) { if (mark_[w] != mark_serial_) { mark_[w] = mark_serial_; changed.push_back(w); } }
   void set_direct(int32_t w, const OccQuad& q);
-  std::vector<int32_t> touched_, cnt_, list_of_;
+  std::vector<int32_t> touched_, stale_, cnt_, list_of_;
   std::vector<uint32_t> stamp_, mark_;
   uint32_t serial_ = 0, mark_serial_ = 1;
   struct Pending { int32_t wid; OccQuad q; };
@@ -271,6 +271,10 @@ struct OccImage {
 //   * registration is idempotent, so a memoised path only has to redo the one rule position whose
 //     outcome depends on the previous path in the list (`last_end`, graph.cc:449,471-472).
 // ---------------------------------------------------------------------------------------------
+// An occurrence as its 12-byte table entry without the path slot: what a whole-set build writes per occurrence
+// (hi gets `slot << 16`). wid < 0 (~wid): the 8-byte form cannot hold the threshold -- the build takes the Occ instead.
+struct OccPre { int32_t wid; uint32_t lo, hi; int32_t rank; };
+
 struct PathMemo {
   Walk path;
   bool registered[2] = {false, false};   // PrecomputeAlignmentForPaths rule has run for this path
@@ -279,6 +283,7 @@ struct PathMemo {
   bool occ_valid[2] = {false, false};    // occurrence list reflects placements + window maxima
   std::vector<Placement> pl[2];          // shifts relative to the path start, path = 0
   std::vector<Occ> occ[2];               // rank path-local, path = 0
+  std::vector<OccPre> pre[2];            // the same occurrences as table entries minus the path slot (OccImage::build)
   int64_t assembled[2] = {0, 0};         // records of the occurring windows
   std::vector<int32_t> starts;           // contig start coordinates (events of type 1, graph.cc:1826,1835)
   int32_t length = 0;                    // incl. gaps
