@@ -655,10 +655,10 @@ class Context:
         return [int(x) for x in buf[:n]]
 
     def debug_table_stats(self, rs):
-        out = np.zeros(8, np.int64)
+        out = np.zeros(10, np.int64)
         self._check(_lib.gaml_hip_debug_table_stats(self._h, rs, out))
         return {"full_rebuilds": int(out[0]), "delta_updates": int(out[1]), "dirty_pairs": int(out[2]), "worker_rebuilds": int(out[3]),
-                "batches_patched": int(out[4]), "batches_full": int(out[5]), "records_left_out": [int(out[6]), int(out[7])]}
+                "batches_patched": int(out[4]), "batches_full": int(out[5]), "records_left_out": [int(out[6]), int(out[7])], "delta_records_left_out": int(out[8])}
 
     def aligner_stats(self):
         w, k, us = C.c_int64(), C.c_int64(), C.c_double()

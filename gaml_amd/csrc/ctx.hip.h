@@ -232,6 +232,7 @@ struct PairedSet {
   Staging stage_delta;
   size_t delta_off[5] = {0, 0, 0, 0, 0};   // spill CSR: offsets mate 0, records mate 0, offsets mate 1, records mate 1, slots
   int quiet_calls = 0;       // evaluations since the last window activation
+  int64_t delta_left_out = 0;         // records of later windows that never reached the delta lists (always overwritten)
   bool built_keep_dominated = false;  // knob 16 at the last table build on the calling thread
   bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
   PinBuf h_timeline; int timeline_waves = 0;  // ablation 8 (tools/kernel_timeline.py)

@@ -2676,13 +2676,15 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wi
   return (int32_t)w.size();
 }
 
-int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out8) {
+int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out10) {
+  int64_t* out8 = out10;
   MULTI_SHARD0(c);
-  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out8) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out10) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
   out8[0] = s.full_rebuilds; out8[1] = s.delta_updates; out8[2] = (int64_t)s.dirty.size(); out8[3] = s.async_rebuilds;
   out8[4] = s.batches_patched; out8[5] = s.batches_full;
   out8[6] = s.pt.dropped_records[0]; out8[7] = s.pt.dropped_records[1];
+  out10[8] = s.delta_left_out; out10[9] = 0;
   return GAML_HIP_OK;
 }
 

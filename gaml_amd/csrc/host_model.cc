@@ -365,7 +365,7 @@ static void revcomp_into(const char* s, int32_t n, std::string& out) {
 
 void ShortMate::tag_window(const GraphStore& g, int32_t wid, const Walk& w) {
   Window& win = wins[wid];
-  if (w.size() == 1) win.solo = w[0];
+  if (w.size() == 1) { win.solo = w[0]; solo_of_node[w[0]] = wid; }
   else if (w.size() > 1 && w[0] >= 0 && g.len(w[0]) > kTail) win.head = w[0];  // the condition of placements_paired_contig
 }
 
@@ -1126,6 +1126,28 @@ static void dominated_records(const ShortMate& m, std::vector<uint8_t>& drop) {
       else { drop[(size_t)(a - m.pool.data())] = 1; a++; }
     }
   }
+}
+
+static inline bool rec_before(const gaml_aligment& x, const gaml_aligment& y) { return x.position != y.position ? x.position < y.position : x.read_id < y.read_id; }
+
+int64_t undominated_records(const ShortMate& m, int32_t wid, std::vector<uint8_t>& keep) {
+  const Window& j = m.wins[wid];
+  keep.assign((size_t)j.count, 1);
+  if (j.head < 0 || j.count == 0) return j.count;
+  auto it = m.solo_of_node.find(j.head);
+  if (it == m.solo_of_node.end()) return j.count;
+  const Window& sw = m.wins[it->second];
+  if (!sw.active || sw.count == 0) return j.count;
+  const gaml_aligment* const a0 = m.pool.data() + j.first, * a = a0, * const ae = a0 + j.count;
+  const gaml_aligment* const sb = m.pool.data() + sw.first, * const se = sb + sw.count;
+  const gaml_aligment* b = std::lower_bound(sb, se, *a, rec_before);
+  int64_t kept = j.count;
+  while (a < ae && b < se) {
+    if (rec_before(*a, *b)) a++;
+    else if (rec_before(*b, *a)) b++;
+    else { keep[(size_t)(a - a0)] = 0; kept--; a++; }
+  }
+  return kept;
 }
 
 void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold) {

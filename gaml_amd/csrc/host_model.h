@@ -88,6 +88,7 @@ struct ShortMate {
   std::unordered_map<Walk, int32_t, WalkHasher> win_id;
   std::vector<Window> wins;
   std::vector<const Walk*> win_walk;     // window id -> its node ids (keys of win_id are stable)
+  std::unordered_map<int32_t, int32_t> solo_of_node;  // node -> id of its single-node window (tag_window)
   std::vector<gaml_aligment> pool;       // read_id = LOCAL id inside the shard
   std::vector<int32_t> unsynced;         // windows added since the last max-position exchange (sharded runs)
   std::vector<int32_t> added_log;        // windows added since the planner last looked (memo invalidation)
@@ -199,6 +200,9 @@ struct PairTables {
 };
 // fold = false keeps the records that can never survive the overwrite rule (A/B and tests; same values either way)
 void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold = true);
+// The same rule for ONE window that joins the device tables later (delta lists): keep[k] = 0 for the records of window
+// `wid` that its first node's own window -- active -- always overwrites. Returns the number of records to keep.
+int64_t undominated_records(const ShortMate& m, int32_t wid, std::vector<uint8_t>& keep);
 
 
 // direct-mapped occurrence table for the device: one 16-B entry per window.

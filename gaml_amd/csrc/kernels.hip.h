@@ -755,19 +755,29 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
 // pairs touching a window that occurs several times take the fully general per-lane loop (rare).
 __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, int delta_blocks, double& lsum, int& zeros) {
   for (int dj = db * kBlock + threadIdx.x; dj < a.n_dirty; dj += delta_blocks * kBlock) {
+    // Everything a delta pair needs sits at index dj (no chain through the pair's slot): the first record of mate 1
+    // carries the two read lengths in its spare word, the first record of mate 2 the two list lengths (paired_upload_delta)
     const int i = a.dirty_slots[dj];
     const int sp = a.dirty_spill[dj];
-    const uint32_t l12 = i < a.n0 ? a.len_combo[a.len_code[i]] : a.len12[i - a.n0];
-    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-    if (sp >= 0) continue;  // a long list: one WAVE scores it (paired_overflow_body) -- a lane looping over it alone was the launch's tail
     int4 r0[4], r1[4];
-    int c0 = 0, c1 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      r0[k] = a.dirty_recs[0][4 * (size_t)dj + k];
-      r1[k] = a.dirty_recs[1][4 * (size_t)dj + k];
-      c0 += r0[k].x >= 0; c1 += r1[k].x >= 0;
+    for (int k = 0; k < 2; k++) { r0[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r1[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
+    const uint32_t l12 = (uint32_t)r0[0].w;
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    const int c0 = r1[0].w & 0xff, c1 = (r1[0].w >> 8) & 0xff;
+    if (__all(sp >= 0 || (c0 <= 2 && c1 <= 2))) {  // the usual delta pair: a second window per mate (a node and its twin, a junction)
+      if (sp >= 0) continue;
+      RegCands<2> x, y;
+      const int4 q0[2] = {r0[0], r0[1]}, q1[2] = {r1[0], r1[1]};
+      const bool m0 = cands_from_records<2>(a.m[0], q0, x), m1 = cands_from_records<2>(a.m[1], q1, y);
+      if (!(m0 || m1)) { score_cands_and_finish<2>(a, i, l12, x, y, lsum, zeros); continue; }
+      const double acc = paired_general_src(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
+      finish_read(a, i, acc, L1, L2, lsum, zeros);
+      continue;
     }
+    if (sp >= 0) continue;  // a long list: one WAVE scores it (paired_overflow_body) -- a lane looping over it alone was the launch's tail
+#pragma unroll
+    for (int k = 2; k < 4; k++) { r0[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r1[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
     RegCands<4> x, y;
     const bool m0 = cands_from_records<4>(a.m[0], r0, x), m1 = cands_from_records<4>(a.m[1], r1, y);
     if (!(m0 || m1)) { score_cands_and_finish<4>(a, i, l12, x, y, lsum, zeros); continue; }
@@ -1170,8 +1180,6 @@ __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, con
   for (int dj = db * kBlock + threadIdx.x; dj < a.n_dirty; dj += delta_blocks * kBlock) {
     const int i = a.dirty_slots[dj];
     const int sp = a.dirty_spill[dj];
-    const uint32_t l12 = i < a.n0 ? a.len_combo[a.len_code[i]] : a.len12[i - a.n0];
-    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     if (sp >= 0) continue;  // a long list: one WAVE scores it
     int4 r0[4], r1[4];
     int c0 = 0, c1 = 0;
@@ -1183,6 +1191,8 @@ __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, con
       c0 += r0[k].x >= 0; c1 += r1[k].x >= 0;
       if (ms.chg[0]) chg |= (r0[k].x >= 0 ? ms.chg[0][r0[k].x] : 0u) | (r1[k].x >= 0 ? ms.chg[1][r1[k].x] : 0u);
     }
+    const uint32_t l12 = (uint32_t)r0[0].w;  // the pair's read lengths travel with its first record (paired_upload_delta)
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     PairVal val{0.0, 0.0, 0, 0};
 #pragma unroll 1
     for (int s = 0; s < ms.n; s++) {

@@ -126,13 +126,17 @@ void paired_base_records(const PairedSet& s, int32_t slot, int mt, PairedSet::Re
 }
 
 // windows activated since the tables were built: their pairs move to the delta list (host side)
-void paired_extend_delta(PairedSet& s) {
+void paired_extend_delta(PairedSet& s, bool fold) {
   if (s.dirty_of_slot.size() != (size_t)s.mate[0].n_local()) s.dirty_of_slot.assign((size_t)s.mate[0].n_local(), -1);
   const int64_t n0s = s.pt.class_count[0];
   for (int mt = 0; mt < 2; mt++) {
     const ShortMate& m = s.mate[mt];
+    std::vector<uint8_t> keep;
     for (int32_t w : m.activated_log) {
       const Window& win = m.wins[w];
+      // a junction window's records that its first node's window always overwrites change nothing (host_model.cc
+      // dominated_records): their pairs stay where they are
+      const bool some_left_out = fold && undominated_records(m, w, keep) < win.count;
       // A record touches four places chosen by its read id (its pair's slot, the slot's delta index, the pair's records
       // in the tables of both mates): ~100 ns of cache misses each when taken one after the other. Ask for them ahead.
       constexpr int64_t kAhead = 24, kAhead2 = 12;
@@ -145,6 +149,7 @@ void paired_extend_delta(PairedSet& s) {
           if (sl < n0s) { __builtin_prefetch(&s.pt.rec8[0][sl]); __builtin_prefetch(&s.pt.rec8[1][sl]); }
           else { __builtin_prefetch(&s.pt.rm[0].first[sl - n0s]); __builtin_prefetch(&s.pt.rm[1].first[sl - n0s]); }
         }
+        if (some_left_out && !keep[(size_t)(k - win.first)]) { s.delta_left_out++; continue; }
         const gaml_aligment& r = m.pool[k];
         const int32_t slot = s.pt.slot_of_read[r.read_id];
         int32_t dj = s.dirty_of_slot[slot];
@@ -453,6 +458,10 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
         const RecQuad& r = (!lng && k < (int)d.recs[mt].size()) ? d.recs[mt][k] : none;
         pe.rec[mt][k] = make_int4(r.wid, r.pos, r.flags, r.link);
       }
+    // the spare words of the two first records: the pair's read lengths and the lengths of its lists (paired_delta_body)
+    const int32_t read = s.pt.read_of_slot[d.slot];
+    pe.rec[0][0].w = (int)((uint32_t)s.mate[0].lens[read] | ((uint32_t)s.mate[1].lens[read] << 16));
+    pe.rec[1][0].w = lng ? 0 : (int)(d.recs[0].size() | (d.recs[1].size() << 8));
   }
   HIP_TRY(c, s.dl_patch.reserve(np_patch * sizeof(DeltaPatch) + 1));
   if (int e = stage_upload(c, s.stage_delta, pslot, s.dl_patch.p, np_patch * sizeof(DeltaPatch), st)) return e;
@@ -552,7 +561,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     ts1 = now_us();
     if (activated_now) {
       if (rstate == 1) for (int mt = 0; mt < 2; mt++) rb.activated_after[mt].insert(rb.activated_after[mt].end(), s.mate[mt].activated_log.begin(), s.mate[mt].activated_log.end());
-      paired_extend_delta(s);
+      paired_extend_delta(s, c->knobs[16] != 1);
     }
     tr_new = new_records; tr_touched = s.dirty_touched.size();
     ts2 = now_us();

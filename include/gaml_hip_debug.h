@@ -49,11 +49,12 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int
 /* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list, rebuilds
  * done by the worker thread (of the full rebuilds), gaml_hip_calc_prob_batch chunks whose per-set tables were built on
  * the device from patches, chunks whose tables were written whole, records of mate 1 / mate 2 that the current tables
- * leave out because another record of the same read always overwrites them (knob 16)}.
+ * leave out because another record of the same read always overwrites them (knob 16), such records of windows that
+ * joined later and therefore never reached the delta lists (since creation), 0}.
  * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables); knob 14 = 1 keeps every
  * rebuild on the calling thread, knob 14 = k > 1 lets a worker's tables take over k evaluations after its start
  * (default 768); knob 15 = 1: rebuilds never retire unused windows. */
-int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out8);
+int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out10);
 
 /* ---- tuning ------------------------------------------------------------------------------------- */
 /* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner; includes [2]),

@@ -261,3 +261,15 @@ def test_records_that_are_always_overwritten_stay_out_of_the_tables():
     assert min(st["records_left_out"]) > 0 and st_k["records_left_out"] == [0, 0]
     c0, c1 = ctx.debug_class_counts(rs), keep.debug_class_counts(rs_k)
     assert c0[0] > c1[0] and sum(c0) == sum(c1) == n
+    # the same rule for junction windows that join the device tables LATER (delta lists): tables built for one path per
+    # node, then the nodes joined
+    ctx2, rs2, orc2, ors2 = _both(*g.packed(), r1, r2, {}, 260.0, 26.0)
+    keep2, rs_k2, _, _ = _both(*g.packed(), r1, r2, {}, 260.0, 26.0)
+    keep2.debug_set_knob(16, 1)
+    for paths in ([[x] for x in walk], [walk[:k]] + [[x] for x in walk[k:]], [walk], [walk[:k], walk[k:]], [[x] for x in walk]):
+        got, kept = ctx2.calc_prob(paths), keep2.calc_prob(paths)
+        assert np.array_equal(ctx2.read_probs(rs2), keep2.read_probs(rs_k2))
+        assert got[1].tolist() == kept[1].tolist() and abs(got[0] - kept[0]) <= 1e-13 * abs(kept[0])
+        _agree(ctx2, rs2, orc2, ors2, paths)
+    st2, st_k2 = ctx2.debug_table_stats(rs2), keep2.debug_table_stats(rs_k2)
+    assert st2["delta_records_left_out"] > 0 and st_k2["delta_records_left_out"] == 0
