@@ -9,7 +9,7 @@ genome = synth.make_genome(wl.genome_len, wl.seed)
 g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
 pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
 reads = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
-start, seq = synth.sa_sequence(g, 1000)
+start, seq = synth.sa_sequence(g, int(os.environ.get("SA_ITERS", "1000")))
 flat = [api.FlatPaths(p) for p in seq]
 for knob6 in (0,):
     ctx = api.Context(device=0)
