@@ -173,6 +173,24 @@ struct TableDev {
 // A rebuild of the record tables off the caller's thread: the calling thread takes a private copy of what the build
 // reads (active windows' records, ~4 ms at 833 k pairs), a worker builds the tables (~30 ms) and uploads them into a
 // second set of device buffers; evaluations go on meanwhile over the old tables + delta lists, and a later call swaps.
+// a delta pair's record list: up to 4 records inline -- the usual case, no allocation per pair -- or all of them in `more`
+struct DeltaRecList {
+  uint32_t n = 0;
+  RecQuad in[4];
+  std::vector<RecQuad> more;
+  size_t size() const { return n; }
+  const RecQuad* data() const { return n <= 4 ? in : more.data(); }
+  const RecQuad& operator[](size_t k) const { return data()[k]; }
+  void insert(size_t at, const RecQuad& q) {
+    if (n < 4) { for (size_t k = n; k > at; k--) in[k] = in[k - 1]; in[at] = q; n++; return; }
+    if (n == 4) more.assign(in, in + 4);
+    more.insert(more.begin() + at, q);
+    n++;
+  }
+  void push_back(const RecQuad& q) { insert(n, q); }
+};
+struct DeltaPair { int32_t slot; DeltaRecList recs[2]; };
+
 struct TableRebuild {
   std::thread th;
   std::atomic<int> state{0};   // 0 idle, 4 taking the private copy (a slice per evaluation), 1 worker running, 2 ready, 3 failed
@@ -180,7 +198,20 @@ struct TableRebuild {
   PairTables pt;
   TableDev tab;
   std::string err;
-  std::vector<int32_t> activated_after[2];  // windows activated since the snapshot
+  // windows activated since the snapshot, call by call (mate 0's, then mate 1's): what the new tables do not hold
+  struct After { int32_t mate, wid; int64_t keep_at; };  // keep_at: -1, or where the window's keep mask starts in after_keep
+  std::vector<After> after;
+  std::vector<uint8_t> after_keep;  // per record of such a window: 0 = always overwritten, left out (as the live lists left it out)
+  // Their pairs' lists relative to the NEW tables ("shadow" lists), filled on the calling thread a slice per evaluation
+  // once the worker is done, so that the call at which the tables take over has only the last few windows left.
+  std::vector<DeltaPair> sh_dirty;
+  std::vector<int32_t> sh_of_slot;
+  // ... and their device copy: a second delta store, patched slice by slice like the live one (swapped in at the take-over)
+  std::vector<int32_t> sh_touched, sh_spill_of, sh_spill_pairs;
+  DevBuf sh_dl_slot, sh_dl_spill, sh_dl_rec[2];
+  size_t sh_next = 0;          // first entry of `after` not yet in the shadow lists
+  bool sh_open = false;
+  int64_t sh_records = 0;      // records of after[sh_next..) still to go (budget of a slice)
   uint64_t gen_snap[2] = {0, 0};
   hipStream_t stream = nullptr;
   double snapshot_us = 0, build_ms = 0;
@@ -201,22 +232,8 @@ struct PairedSet {
   // activated windows. Their complete lists (device-table order: window id, position) travel with
   // every evaluation; a full rebuild folds them back in when they become too many.
   // (a pair's list: up to 4 records inline -- the usual case, no allocation per pair -- or all of them in `more`)
-  struct RecList {
-    uint32_t n = 0;
-    RecQuad in[4];
-    std::vector<RecQuad> more;
-    size_t size() const { return n; }
-    const RecQuad* data() const { return n <= 4 ? in : more.data(); }
-    const RecQuad& operator[](size_t k) const { return data()[k]; }
-    void insert(size_t at, const RecQuad& q) {
-      if (n < 4) { for (size_t k = n; k > at; k--) in[k] = in[k - 1]; in[at] = q; n++; return; }
-      if (n == 4) more.assign(in, in + 4);
-      more.insert(more.begin() + at, q);
-      n++;
-    }
-    void push_back(const RecQuad& q) { insert(n, q); }
-  };
-  struct DirtyPair { int32_t slot; RecList recs[2]; };
+  using RecList = DeltaRecList;
+  using DirtyPair = DeltaPair;
   std::vector<DirtyPair> dirty;
   std::vector<int32_t> dirty_of_slot;                // slot -> index in `dirty`, -1: not on the delta list
   int64_t full_rebuilds = 0, delta_updates = 0;

@@ -37,6 +37,36 @@ int grid_for(int64_t n) {
 }
 
 // take the next staging slot; waits only if the device is kRing evaluations behind
+// GAML_HIP_BACKTRACE=1: a backtrace on stderr when the process aborts or faults inside the library (debugging aid)
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+#include <exception>
+namespace {
+void gaml_hip_crash_handler(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "libgaml_hip: fatal signal, backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct CrashHook {
+  CrashHook() {
+    if (!getenv("GAML_HIP_BACKTRACE")) return;
+    signal(SIGABRT, gaml_hip_crash_handler);
+    signal(SIGSEGV, gaml_hip_crash_handler);
+    std::set_terminate([] {
+      if (auto e = std::current_exception()) {
+        try { std::rethrow_exception(e); } catch (const std::exception& x) { fprintf(stderr, "libgaml_hip: uncaught exception: %s\n", x.what()); } catch (...) { fprintf(stderr, "libgaml_hip: uncaught exception\n"); }
+      } else fprintf(stderr, "libgaml_hip: std::terminate without an exception (a joinable std::thread destroyed or assigned?)\n");
+      abort();
+    });
+  }
+} crash_hook;
+}  // namespace
+
 int stage_acquire(gaml_hip_ctx* c, Staging& s, size_t bytes, void** host) {
   int k = s.next;
   s.next = (s.next + 1) % kRing;
@@ -1205,7 +1235,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
       if (s->rebuild.stream) (void)hipStreamDestroy(s->rebuild.stream);
       s->tab.release(); s->rebuild.tab.release();
       for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
-      s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release();
+      s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); s->rebuild.sh_dl_slot.release(); s->rebuild.sh_dl_spill.release(); s->rebuild.sh_dl_rec[0].release(); s->rebuild.sh_dl_rec[1].release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release();
       s->probs.release(); s->tabs.release(); s->arena.release(); s->persist.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); s->gen_bits.release();
     }

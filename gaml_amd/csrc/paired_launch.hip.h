@@ -111,67 +111,107 @@ void prepare_paired_tables_host(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p) {
 // cold path: the device record tables follow the alignment-window cache
 // ---------------------------------------------------------------------------------------------------------
 // the pair's records as the device tables hold them (activated before the last full build)
-void paired_base_records(const PairedSet& s, int32_t slot, int mt, PairedSet::RecList& out) {
-  const int64_t n0s = s.pt.class_count[0];
+void paired_base_records(const PairTables& pt, int32_t slot, int mt, PairedSet::RecList& out) {
+  const int64_t n0s = pt.class_count[0];
   if (slot < n0s) {
-    const uint64_t r = s.pt.rec8[mt][slot];
+    const uint64_t r = pt.rec8[mt][slot];
     if (r != kNoRec8) out.push_back(RecQuad{(int32_t)(r & 0xffffff), (int32_t)((r >> 24) & 0xfffffff), (int32_t)((r >> 52) & 63) | ((int32_t)((r >> 58) & 1) << 8), 0});
   } else {
-    const RecQuad& f = s.pt.rm[mt].first[slot - n0s];
+    const RecQuad& f = pt.rm[mt].first[slot - n0s];
     if (f.wid >= 0) {
       const int cnt1 = 1 + (int)((uint32_t)f.flags >> 9);
-      for (int q = 0; q < cnt1; q++) { RecQuad r = q == 0 ? f : s.pt.rm[mt].extra[f.link + q - 1]; r.flags &= 0x1ff; r.link = 0; out.push_back(r); }
+      for (int q = 0; q < cnt1; q++) { RecQuad r = q == 0 ? f : pt.rm[mt].extra[f.link + q - 1]; r.flags &= 0x1ff; r.link = 0; out.push_back(r); }
     }
   }
 }
 
 // windows activated since the tables were built: their pairs move to the delta list (host side)
-void paired_extend_delta(PairedSet& s, bool fold) {
+// the records of window `w` of mate `mt` onto delta lists that are relative to the tables `pt` (the live lists and
+// tables, or the lists being prepared for tables a worker has built). keep: null, or per record 0 = left out.
+// touched: the lists' indices that changed (null: not tracked).
+static void delta_add_window(const PairedSet& s, const PairTables& pt, std::vector<PairedSet::DirtyPair>& dirty, std::vector<int32_t>& of_slot,
+                             std::vector<int32_t>* touched, int mt, int32_t w, const uint8_t* keep) {
+  const ShortMate& m = s.mate[mt];
+  const Window& win = m.wins[w];
+  const int64_t n0s = pt.class_count[0];
+  // A record touches four places chosen by its read id (its pair's slot, the slot's delta index, the pair's records
+  // in the tables of both mates): ~100 ns of cache misses each when taken one after the other. Ask for them ahead.
+  constexpr int64_t kAhead = 24, kAhead2 = 12;
+  const int64_t end = win.first + win.count;
+  for (int64_t k = win.first; k < end; k++) {
+    if (k + kAhead < end) __builtin_prefetch(&pt.slot_of_read[m.pool[k + kAhead].read_id]);
+    if (k + kAhead2 < end) {
+      const int32_t sl = pt.slot_of_read[m.pool[k + kAhead2].read_id];
+      __builtin_prefetch(&of_slot[sl]);
+      if (sl < n0s) { __builtin_prefetch(&pt.rec8[0][sl]); __builtin_prefetch(&pt.rec8[1][sl]); }
+      else { __builtin_prefetch(&pt.rm[0].first[sl - n0s]); __builtin_prefetch(&pt.rm[1].first[sl - n0s]); }
+    }
+    if (keep && !keep[(size_t)(k - win.first)]) continue;
+    const gaml_aligment& r = m.pool[k];
+    const int32_t slot = pt.slot_of_read[r.read_id];
+    int32_t dj = of_slot[slot];
+    if (dj < 0) {
+      dj = of_slot[slot] = (int32_t)dirty.size();
+      dirty.emplace_back();
+      dirty.back().slot = slot;
+      paired_base_records(pt, slot, 0, dirty.back().recs[0]);
+      paired_base_records(pt, slot, 1, dirty.back().recs[1]);
+    }
+    if (touched) touched->push_back(dj);
+    auto& lst = dirty[dj].recs[mt];
+    RecQuad q{w, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
+    // keep the device-table order: (window id, position)
+    const RecQuad* b = lst.data();
+    const RecQuad* pos = std::upper_bound(b, b + lst.size(), q, [](const RecQuad& x, const RecQuad& y) { return x.wid != y.wid ? x.wid < y.wid : x.pos < y.pos; });
+    lst.insert((size_t)(pos - b), q);
+  }
+}
+
+// windows activated since the tables were built: their pairs move to the delta lists (host side). While a worker
+// builds new tables (log_after) the windows are also noted for the lists that will go with those tables.
+void paired_extend_delta(PairedSet& s, bool fold, bool log_after) {
   if (s.dirty_of_slot.size() != (size_t)s.mate[0].n_local()) s.dirty_of_slot.assign((size_t)s.mate[0].n_local(), -1);
-  const int64_t n0s = s.pt.class_count[0];
+  TableRebuild& rb = s.rebuild;
+  std::vector<uint8_t> keep;
   for (int mt = 0; mt < 2; mt++) {
     const ShortMate& m = s.mate[mt];
-    std::vector<uint8_t> keep;
     for (int32_t w : m.activated_log) {
       const Window& win = m.wins[w];
       // a junction window's records that its first node's window always overwrites change nothing (host_model.cc
       // dominated_records): their pairs stay where they are
       const bool some_left_out = fold && undominated_records(m, w, keep) < win.count;
-      // A record touches four places chosen by its read id (its pair's slot, the slot's delta index, the pair's records
-      // in the tables of both mates): ~100 ns of cache misses each when taken one after the other. Ask for them ahead.
-      constexpr int64_t kAhead = 24, kAhead2 = 12;
-      const int64_t end = win.first + win.count;
-      for (int64_t k = win.first; k < end; k++) {
-        if (k + kAhead < end) __builtin_prefetch(&s.pt.slot_of_read[m.pool[k + kAhead].read_id]);
-        if (k + kAhead2 < end) {
-          const int32_t sl = s.pt.slot_of_read[m.pool[k + kAhead2].read_id];
-          __builtin_prefetch(&s.dirty_of_slot[sl]);
-          if (sl < n0s) { __builtin_prefetch(&s.pt.rec8[0][sl]); __builtin_prefetch(&s.pt.rec8[1][sl]); }
-          else { __builtin_prefetch(&s.pt.rm[0].first[sl - n0s]); __builtin_prefetch(&s.pt.rm[1].first[sl - n0s]); }
-        }
-        if (some_left_out && !keep[(size_t)(k - win.first)]) { s.delta_left_out++; continue; }
-        const gaml_aligment& r = m.pool[k];
-        const int32_t slot = s.pt.slot_of_read[r.read_id];
-        int32_t dj = s.dirty_of_slot[slot];
-        if (dj < 0) {
-          dj = s.dirty_of_slot[slot] = (int32_t)s.dirty.size();
-          s.dirty.emplace_back();
-          s.dirty.back().slot = slot;
-          paired_base_records(s, slot, 0, s.dirty.back().recs[0]);
-          paired_base_records(s, slot, 1, s.dirty.back().recs[1]);
-        }
-        s.dirty_touched.push_back(dj);
-        auto& lst = s.dirty[dj].recs[mt];
-        RecQuad q{w, r.position, (r.edit_dist & 0xff) | ((r.orientation & 1) << 8), 0};
-        // keep the device-table order: (window id, position)
-        const RecQuad* b = lst.data();
-        const RecQuad* pos = std::upper_bound(b, b + lst.size(), q, [](const RecQuad& x, const RecQuad& y) { return x.wid != y.wid ? x.wid < y.wid : x.pos < y.pos; });
-        lst.insert((size_t)(pos - b), q);
+      if (some_left_out) for (uint8_t kp : keep) s.delta_left_out += !kp;
+      if (log_after) {
+        rb.after.push_back(TableRebuild::After{mt, w, some_left_out ? (int64_t)rb.after_keep.size() : -1});
+        if (some_left_out) rb.after_keep.insert(rb.after_keep.end(), keep.begin(), keep.end());
+        rb.sh_records += win.count;
       }
+      delta_add_window(s, s.pt, s.dirty, s.dirty_of_slot, &s.dirty_touched, mt, w, some_left_out ? keep.data() : nullptr);
     }
   }
   for (int mt = 0; mt < 2; mt++) { s.mate[mt].activated_log.clear(); s.dev[mt].uploaded_generation = s.mate[mt].active_generation; }
   s.delta_updates++;
+}
+
+// The lists that go with the tables a worker has built: up to `budget` records' worth of the windows noted since the
+// snapshot (whole windows, in the order they were activated -- the lists do not depend on how the work was sliced).
+void paired_shadow_advance(PairedSet& s, int64_t budget) {
+  TableRebuild& rb = s.rebuild;
+  if (!rb.sh_open) {
+    rb.sh_dirty.clear();  // (normally emptied by the worker already)
+    rb.sh_dirty.reserve(s.dirty.capacity());
+    rb.sh_of_slot.assign((size_t)s.mate[0].n_local(), -1);
+    rb.sh_touched.clear(); rb.sh_spill_of.clear(); rb.sh_spill_pairs.clear();
+    rb.sh_next = 0;
+    rb.sh_open = true;
+  }
+  while (rb.sh_next < rb.after.size() && budget > 0) {
+    const TableRebuild::After& a = rb.after[rb.sh_next++];
+    const int64_t cnt = s.mate[a.mate].wins[a.wid].count;
+    delta_add_window(s, rb.pt, rb.sh_dirty, rb.sh_of_slot, &rb.sh_touched, a.mate, a.wid, a.keep_at >= 0 ? rb.after_keep.data() + a.keep_at : nullptr);
+    budget -= cnt;
+    rb.sh_records -= cnt;
+  }
 }
 
 // One build of the record tables onto the device: uploads `pt` into `T`, derives the per-length-combination tables
@@ -247,6 +287,7 @@ int paired_upload_pows(gaml_hip_ctx* c, PairedSet& s) {
 }
 
 int paired_reserve_delta(gaml_hip_ctx* c, PairedSet& s);
+int paired_shadow_upload(gaml_hip_ctx* c, PairedSet& s, hipStream_t st);
 
 // full rebuild on the calling thread: new device order of the pairs, record tables built on the host and uploaded
 // a rebuild is also when windows that no scored path set has used since the previous rebuild leave the device tables
@@ -326,6 +367,7 @@ void paired_launch_worker(gaml_hip_ctx* c, PairedSet& s) {
     const double b0 = now_us();
     int rc = hipSetDevice(device) == hipSuccess ? 0 : GAML_HIP_EHIP;
     if (rc) rb.err = "hipSetDevice failed in the rebuild worker";
+    rb.sh_dirty.clear();  // the lists of the tables before last (swapped out at the previous take-over): emptied here, off the caller's thread
     if (!rc) {
       rb.keep_dominated = c->knobs[16] == 1;
       build_pair_tables(rb.snap[0], rb.snap[1], rb.pt, !rb.keep_dominated);
@@ -358,9 +400,9 @@ int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s) {
   for (int mt = 0; mt < 2; mt++) {
     paired_snapshot_begin(s.mate[mt], rb.snap[mt]);
     rb.gen_snap[mt] = s.mate[mt].active_generation;
-    rb.activated_after[mt].clear();
     rb.next_w[mt] = 0;
   }
+  rb.after.clear(); rb.after_keep.clear(); rb.sh_next = 0; rb.sh_open = false; rb.sh_records = 0;
   const double t2 = now_us();
   if (!rb.stream) HIP_TRY(c, hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
   rb.err.clear();
@@ -383,21 +425,33 @@ int paired_finish_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   rb.state.store(0, std::memory_order_release);
   if (state == 3) return fail(c, GAML_HIP_EHIP, "table rebuild worker: " + rb.err);
   if (state != 2) return 0;
+  // what this call's planning just activated joins the windows noted since the snapshot (on the old lists as well: the
+  // bookkeeping is the same as in any other call), then the lists for the new tables are completed -- usually all
+  // but the last few windows are in them already (paired_shadow_advance, a slice per evaluation)
+  if (!s.mate[0].activated_log.empty() || !s.mate[1].activated_log.empty()) paired_extend_delta(s, c->knobs[16] != 1, true);
+  paired_shadow_advance(s, INT64_MAX / 4);
   HIP_TRY(c, hipStreamSynchronize(st));  // launches in flight may still read the old tables
   std::swap(s.tab, rb.tab);
   std::swap(s.pt, rb.pt);
   s.built_keep_dominated = rb.keep_dominated;
-  paired_reset_delta(s);
+  s.dirty.swap(rb.sh_dirty);            // the old lists are emptied off this thread (the next worker does it)
+  s.dirty_of_slot.swap(rb.sh_of_slot);
+  s.spill_of.swap(rb.sh_spill_of); s.spill_pairs.swap(rb.sh_spill_pairs);
+  s.dirty_touched.swap(rb.sh_touched);  // what the slices have not sent to the second store yet: this call's upload
+  rb.sh_touched.clear();
+  if (rb.sh_dl_slot.p) {
+    std::swap(s.dl_slot, rb.sh_dl_slot); std::swap(s.dl_spill, rb.sh_dl_spill);
+    for (int mt = 0; mt < 2; mt++) std::swap(s.dl_rec[mt], rb.sh_dl_rec[mt]);
+  } else {  // no second store (it is reserved with the first table build unless rebuilds never leave the calling thread): everything from here
+    s.dirty_touched.resize(s.dirty.size());
+    for (size_t k = 0; k < s.dirty_touched.size(); k++) s.dirty_touched[k] = (int32_t)k;
+    s.spill_of.clear(); s.spill_pairs.clear();
+  }
+  rb.sh_open = false; rb.after.clear(); rb.after_keep.clear(); rb.sh_next = 0; rb.sh_records = 0;
+  s.dirty_marked = 0;
+  s.spill_changed = true;  // the long lists' CSR goes with the lists
   s.full_rebuilds++;
   s.async_rebuilds++;
-  for (int mt = 0; mt < 2; mt++) {
-    // everything activated since the snapshot: what earlier calls logged, then what this call's planning just activated
-    std::vector<int32_t> log = std::move(rb.activated_after[mt]);
-    log.insert(log.end(), s.mate[mt].activated_log.begin(), s.mate[mt].activated_log.end());
-    s.mate[mt].activated_log.swap(log);
-    rb.activated_after[mt].clear();
-    s.dev[mt].uploaded_generation = rb.gen_snap[mt];
-  }
   if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "rebuild (worker): snapshot %.1f ms on the calling thread, build + upload %.1f ms beside it\n", rb.snapshot_us * 1e-3, rb.build_ms);
   return 0;
 }
@@ -408,10 +462,20 @@ int paired_finish_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
 int paired_reserve_delta(gaml_hip_ctx* c, PairedSet& s) {
   if (s.delta_cap) return 0;
   const int64_t np_all = s.mate[0].n_local();
-  s.delta_cap = (size_t)std::max<int64_t>(4096, np_all / 4) + 8192;  // twice the rebuild threshold: room for what arrives while a worker rebuilds
+  // four times the rebuild threshold. Right after a take-over the lists hold what was activated while the worker built
+  // (often more than the threshold already: the next rebuild starts at once), and as much again arrives before that one
+  // takes over -- an annealing run that keeps activating windows at cfg3's rate peaks near 2 x 130 k pairs
+  s.delta_cap = (size_t)std::max<int64_t>(4096, np_all / 2) + 8192;
+  s.rebuild.sh_dirty.reserve(s.delta_cap);
   HIP_TRY(c, s.dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
   HIP_TRY(c, s.dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
   for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
+  if (c->knobs[14] != 1) {  // the second store, for the lists that go with a worker's tables
+    HIP_TRY(c, s.rebuild.sh_dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
+    HIP_TRY(c, s.rebuild.sh_dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
+    for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.rebuild.sh_dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
+    s.rebuild.sh_spill_of.reserve(s.delta_cap);
+  }
   // patches: a call rarely touches more than a few thousand pairs; the largest activations (a long node's twin) ~30 k
   const size_t patch = std::min<size_t>(s.delta_cap, 32768) * sizeof(DeltaPatch);
   HIP_TRY(c, s.dl_patch.reserve(patch));
@@ -425,33 +489,32 @@ int paired_reserve_delta(gaml_hip_ctx* c, PairedSet& s) {
   return 0;
 }
 
-// delta pairs: a patch for the pairs whose lists changed since the last upload (new windows were activated)
-int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
-  if (s.dirty_touched.empty()) return 0;
-  const size_t nd = s.dirty.size();
-  const int64_t np_all = s.mate[0].n_local();
-  if (int e = paired_reserve_delta(c, s)) return e;
-  (void)np_all;
-  if (nd > s.delta_cap) return fail(c, GAML_HIP_ESTATE, "delta store overflow (rebuild policy violated)");
-  std::sort(s.dirty_touched.begin(), s.dirty_touched.end());
-  s.dirty_touched.erase(std::unique(s.dirty_touched.begin(), s.dirty_touched.end()), s.dirty_touched.end());
-  s.spill_of.resize(nd, -1);
-  const size_t np_patch = s.dirty_touched.size();
+// a patch for the lists `touched` names: their fixed-stride device copy (slot, spill index, 4 records per mate). The
+// lists are the live ones or those being prepared for a worker's tables (`pt` = the tables the slots refer to).
+struct DeltaStore { DevBuf* slot; DevBuf* spill; DevBuf* rec0; DevBuf* rec1; };
+static int delta_upload_patch(gaml_hip_ctx* c, PairedSet& s, hipStream_t st, const PairTables& pt, const std::vector<PairedSet::DirtyPair>& dirty,
+                              std::vector<int32_t>& touched, std::vector<int32_t>& spill_of, std::vector<int32_t>& spill_pairs, bool* spill_changed,
+                              const DeltaStore& dev) {
+  const size_t nd = dirty.size();
+  std::sort(touched.begin(), touched.end());
+  touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+  spill_of.resize(nd, -1);
+  const size_t np_patch = touched.size();
   void* ph = nullptr;
   int pslot = stage_acquire(c, s.stage_delta, np_patch * sizeof(DeltaPatch), &ph);
   if (pslot < 0) return pslot;
   DeltaPatch* patch = (DeltaPatch*)ph;
   for (size_t t = 0; t < np_patch; t++) {
-    const int32_t dj = s.dirty_touched[t];
-    const auto& d = s.dirty[dj];
+    const int32_t dj = touched[t];
+    const auto& d = dirty[dj];
     DeltaPatch& pe = patch[t];
     pe.dj = dj; pe.slot = d.slot; pe.pad = 0;
     const bool lng = d.recs[0].size() > 4 || d.recs[1].size() > 4;
     if (lng) {
-      if (s.spill_of[dj] < 0) { s.spill_of[dj] = (int32_t)s.spill_pairs.size(); s.spill_pairs.push_back(dj); }
-      s.spill_changed = true;
+      if (spill_of[dj] < 0) { spill_of[dj] = (int32_t)spill_pairs.size(); spill_pairs.push_back(dj); }
+      *spill_changed = true;
     }
-    pe.spill = s.spill_of[dj];
+    pe.spill = spill_of[dj];
     for (int mt = 0; mt < 2; mt++)
       for (int k = 0; k < 4; k++) {
         const RecQuad none{-1, 0, 0, 0};
@@ -459,7 +522,7 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
         pe.rec[mt][k] = make_int4(r.wid, r.pos, r.flags, r.link);
       }
     // the spare words of the two first records: the pair's read lengths and the lengths of its lists (paired_delta_body)
-    const int32_t read = s.pt.read_of_slot[d.slot];
+    const int32_t read = pt.read_of_slot[d.slot];
     pe.rec[0][0].w = (int)((uint32_t)s.mate[0].lens[read] | ((uint32_t)s.mate[1].lens[read] << 16));
     pe.rec[1][0].w = lng ? 0 : (int)(d.recs[0].size() | (d.recs[1].size() << 8));
   }
@@ -467,9 +530,20 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   if (int e = stage_upload(c, s.stage_delta, pslot, s.dl_patch.p, np_patch * sizeof(DeltaPatch), st)) return e;
   if (int e = stage_release(c, s.stage_delta, pslot, st)) return e;
   hipLaunchKernelGGL(apply_delta_patch_kernel, dim3((unsigned)std::min<size_t>((np_patch + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
-                     (const DeltaPatch*)s.dl_patch.p, (int)np_patch, s.dl_slot.as<int>(), s.dl_spill.as<int>(), s.dl_rec[0].as<int4>(), s.dl_rec[1].as<int4>());
+                     (const DeltaPatch*)s.dl_patch.p, (int)np_patch, dev.slot->as<int>(), dev.spill->as<int>(), dev.rec0->as<int4>(), dev.rec1->as<int4>());
   HIP_TRY(c, hipGetLastError());
-  s.dirty_touched.clear();
+  touched.clear();
+  return 0;
+}
+
+// delta pairs: a patch for the pairs whose lists changed since the last upload (new windows were activated)
+int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
+  if (s.dirty_touched.empty() && !s.spill_changed) return 0;
+  if (int e = paired_reserve_delta(c, s)) return e;
+  if (s.dirty.size() > s.delta_cap) return fail(c, GAML_HIP_ESTATE, "delta store overflow (rebuild policy violated)");
+  if (!s.dirty_touched.empty())
+    if (int e = delta_upload_patch(c, s, st, s.pt, s.dirty, s.dirty_touched, s.spill_of, s.spill_pairs, &s.spill_changed,
+                                   DeltaStore{&s.dl_slot, &s.dl_spill, &s.dl_rec[0], &s.dl_rec[1]})) return e;
   if (s.spill_changed) {  // the few long lists: CSR rebuilt as a whole
     const size_t ns = s.spill_pairs.size();
     size_t dn[2] = {0, 0};
@@ -507,6 +581,15 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   return 0;
 }
 
+// the lists prepared for a worker's tables: what a slice changed goes to the second device store
+int paired_shadow_upload(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
+  TableRebuild& rb = s.rebuild;
+  if (rb.sh_touched.empty() || !rb.sh_dl_slot.p || rb.sh_dirty.size() > s.delta_cap) return 0;  // (too many: the take-over reports it)
+  bool long_lists = false;  // their CSR is built at the take-over
+  return delta_upload_patch(c, s, st, rb.pt, rb.sh_dirty, rb.sh_touched, rb.sh_spill_of, rb.sh_spill_pairs, &long_lists,
+                            DeltaStore{&rb.sh_dl_slot, &rb.sh_dl_spill, &rb.sh_dl_rec[0], &rb.sh_dl_rec[1]});
+}
+
 // Everything the record tables need before a scoring launch; enqueued on `st`. One call per evaluation (or batch).
 int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   static const bool trace = getenv("GAML_HIP_TRACE_HOST") != nullptr;
@@ -521,10 +604,22 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   // happens to be done: a rebuild changes the order of the final sum (last bits), and equal inputs must give equal
   // outputs run to run (the annealing loop compares likelihoods with strict >). The worker needs ~30 ms at
   // 833 k pairs, 768 evaluations take at least that long; if it is not done by then, this call waits for it.
-  const int64_t swap_after = c->knobs[14] > 1 ? c->knobs[14] : 768;
+  const int64_t swap_after = c->knobs[14] > 1 ? c->knobs[14] : 1152;
   if (rstate != 0 && s.eval_count - rb.start_eval >= swap_after) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; rstate = 0; }
   else if (rstate == 4) { if (int e = paired_continue_snapshot(c, s, false)) return e; rstate = 1; }  // the next slice of the private copy
-  else if (rstate != 0) rstate = 1;  // (ready or not: not yet)
+  else if (rstate != 0) {  // (ready or not: not yet)
+    if (rstate == 2) {
+      // the worker is done: until the new tables take over, every evaluation re-bases a slice of what was activated since
+      // the snapshot onto them, sized to be through a few calls before the take-over
+      const int64_t calls_left = swap_after - (s.eval_count - rb.start_eval);
+      const int64_t budget = std::max<int64_t>(384, rb.sh_records / std::max<int64_t>(1, calls_left - 8) * 3 / 2);
+      if (rb.sh_records > 0 || !rb.sh_open) {
+        paired_shadow_advance(s, std::min<int64_t>(budget, 8192));
+        if (int e = paired_shadow_upload(c, s, st)) return e;
+      }
+    }
+    rstate = 1;
+  }
   const bool first_build = s.dev[0].pow_n == 0;
   bool activated_now = s.dev[0].uploaded_generation != s.mate[0].active_generation || s.dev[1].uploaded_generation != s.mate[1].active_generation;
   s.quiet_calls = activated_now ? 0 : s.quiet_calls + 1;
@@ -547,7 +642,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     s.compact_requested = false;
     const bool use_worker = c->knobs[14] != 1 && c->knobs[6] != 1;
     // the delta store must hold what accumulates while a worker builds; when it cannot, wait for the worker
-    const size_t hard = s.delta_cap ? s.delta_cap - 2048 : (size_t)std::max<int64_t>(4096, np / 4);
+    const size_t hard = s.delta_cap ? s.delta_cap - 2048 : (size_t)std::max<int64_t>(4096, np / 2);
     const bool overflow = s.dirty.size() + new_records > hard;
     if (asked || ((over || quiet) && !use_worker) || overflow) {
       if (rstate == 1) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; rstate = 0; activated_now = !s.mate[0].activated_log.empty() || !s.mate[1].activated_log.empty(); }
@@ -560,8 +655,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     }
     ts1 = now_us();
     if (activated_now) {
-      if (rstate == 1) for (int mt = 0; mt < 2; mt++) rb.activated_after[mt].insert(rb.activated_after[mt].end(), s.mate[mt].activated_log.begin(), s.mate[mt].activated_log.end());
-      paired_extend_delta(s, c->knobs[16] != 1);
+      paired_extend_delta(s, c->knobs[16] != 1, rstate == 1);
     }
     tr_new = new_records; tr_touched = s.dirty_touched.size();
     ts2 = now_us();

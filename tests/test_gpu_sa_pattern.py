@@ -133,7 +133,11 @@ def test_rebuild_on_the_worker_thread_takes_over_mid_walk():
     g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(600, 4000), short_rng=(25, 330)))
     pr = synth.make_paired_reads(genome, n, 100, 240.0, 24.0, 0.01, seed)
     ctxs = []
-    for knobs in ({14: 40}, {14: 1}, {6: 1}):  # the new tables take over 40 evaluations after the worker started (default 768)
+    # the new tables take over 40 evaluations after the worker started (default 1152). The last context is the first one
+    # again, but slowed down: its worker is done long before the take-over, so the lists that go with the new tables are
+    # prepared in other slices than the first context's -- and every value must still be equal bit for bit (the point
+    # of a take-over at a fixed evaluation count)
+    for knobs in ({14: 40}, {14: 1}, {6: 1}, {14: 40}):
         c = api.Context(device=0)
         c.set_graph(*g.packed())
         c.add_paired(api.paired_cfg(240.0, 24.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
@@ -141,8 +145,12 @@ def test_rebuild_on_the_worker_thread_takes_over_mid_walk():
             c.debug_set_knob(k, v)
         ctxs.append(c)
     start, seq = synth.sa_sequence(g, 500, seed=9, threshold=400)
+    import time
+    slow_ctx = ctxs.pop()
+    first = []
     for k, ps in enumerate([start] + seq):
         vals = [c.calc_prob(ps) for c in ctxs]
+        first.append(vals[0][0])
         for v in vals[1:]:
             assert v[1].tolist() == vals[0][1].tolist() and v[2] == vals[0][2]
             assert v[0] == vals[0][0] or abs(v[0] - vals[0][0]) <= 1e-12 * abs(vals[0][0]), (k, v[0], vals[0][0])
@@ -151,6 +159,10 @@ def test_rebuild_on_the_worker_thread_takes_over_mid_walk():
             # (a pair with several terms adds them in table order: list vs rebuilt table may differ in the last bit)
             np.testing.assert_allclose(p0, ctxs[1].read_probs(0), rtol=4e-16, atol=0)
             np.testing.assert_allclose(p0, ctxs[2].read_probs(0), rtol=4e-16, atol=0)
+    for k, ps in enumerate([start] + seq):
+        assert slow_ctx.calc_prob(ps)[0] == first[k], k
+        time.sleep(0.001)
+    assert slow_ctx.debug_table_stats(0)["worker_rebuilds"] == ctxs[0].debug_table_stats(0)["worker_rebuilds"]
     st = ctxs[0].debug_table_stats(0)
     assert st["worker_rebuilds"] >= 1, st
     assert ctxs[1].debug_table_stats(0)["worker_rebuilds"] == 0 and ctxs[1].debug_table_stats(0)["full_rebuilds"] >= 2

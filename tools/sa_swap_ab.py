@@ -1,0 +1,32 @@
+"""Annealing pattern over several table take-overs: total time, tail and the take-over calls for different take-over
+delays (knob 14).  python tools/sa_swap_ab.py [iterations] [delays...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gaml_amd import synth, api
+n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+delays = [int(a) for a in sys.argv[2:]] or [0, 768]
+wl = synth.WORKLOADS["cfg3"]
+genome = synth.make_genome(wl.genome_len, wl.seed)
+g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
+pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
+reads = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+start, seq = synth.sa_sequence(g, n_it)
+flat = [api.FlatPaths(p) for p in seq]
+for d in delays:
+    ctx = api.Context(device=0)
+    ctx.set_graph(*g.packed())
+    rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *reads)
+    if d: ctx.debug_set_knob(14, d)
+    ctx.calc_prob(start)
+    per, wr, at = [], 0, []
+    for k, f in enumerate(flat):
+        t = time.perf_counter(); ctx.score(f); per.append((time.perf_counter() - t) * 1e6)
+        if k % 16 == 0:
+            w = ctx.debug_table_stats(rs)["worker_rebuilds"]
+            if w != wr: at.append(k); wr = w
+    per = np.array(per)
+    slow = np.argsort(-per)[:5]
+    print(f"delay {d or 'default'}: total {per.sum() / 1e3:.1f} ms, median {np.median(per):.1f}, p90 {np.percentile(per, 90):.1f}, p99 {np.percentile(per, 99):.1f}, max {per.max():.0f} us; "
+          f"take-overs seen by call {at}; slowest calls {[(int(k), int(per[k])) for k in slow]}; {ctx.debug_table_stats(rs)}", flush=True)
+    ctx.close()
