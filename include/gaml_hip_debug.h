@@ -53,7 +53,7 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int
  * joined later and therefore never reached the delta lists (since creation), 0}.
  * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables); knob 14 = 1 keeps every
  * rebuild on the calling thread, knob 14 = k > 1 lets a worker's tables take over k evaluations after its start
- * (default 768); knob 15 = 1: rebuilds never retire unused windows. */
+ * (default 1152); knob 15 = 1: rebuilds never retire unused windows. */
 int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out10);
 
 /* ---- tuning ------------------------------------------------------------------------------------- */
@@ -78,6 +78,9 @@ int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
 int gaml_hip_debug_timeline(gaml_hip_ctx* ctx, int rs, unsigned long long* out, int64_t cap_waves);
 
 int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
+/* Environment (read once): GAML_HIP_TRACE_HOST=1 -- host-side phase times of slow calls, table builds and rebuilds on
+ * stderr; GAML_HIP_TRACE_ALIGNER=1 -- aligner stage times with gaml_hip_aligner_stats; GAML_HIP_BACKTRACE=1 -- a
+ * backtrace on stderr when the process aborts or faults (also after the HIP runtime reports a GPU memory fault). */
 /* pairs per record-count class of the device table {<=1, <=2, <=4, more} (paired sets) */
 int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);
 
