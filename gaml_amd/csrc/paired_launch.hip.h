@@ -632,7 +632,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     // cache has been quiet for 64 evaluations with pairs still on the delta path (steady re-scoring: an annealing run adds
     // windows every few calls), or on request. On request the calling thread does it (gaml_hip_compact_tables: "at the next
     // evaluation"); otherwise a worker does, and the evaluations go on over the old tables + delta lists meanwhile.
-    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / 8);
+    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / (c->knobs[18] > 0 ? c->knobs[18] : 8));
     size_t new_records = 0;
     if (activated_now) for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
     const bool over = activated_now && s.dirty.size() + new_records > limit;

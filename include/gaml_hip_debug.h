@@ -71,7 +71,8 @@ int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
  * unchanged pairs, 32 + mask: classes of blocks left out (TIMING ONLY, results wrong; tools/batch_ablate.py),
  * 12 = 1: every path set planned from scratch, 13 = 1: whole per-call tables through the ring (no resident copy),
  * 14 / 15: table rebuilds (above), 16 = 1: record tables keep the records that can never survive the overwrite rule
- * (host_model.cc dominated_records; takes effect at the next table build; same values either way) */
+ * (host_model.cc dominated_records; takes effect at the next table build; same values either way), 18 = d: tables are
+ * rebuilt when the delta lists pass pairs / d (default 8) */
 /* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
  * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
  * number of waves copied. Tuning aid (tools/kernel_timeline.py). */

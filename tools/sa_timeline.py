@@ -15,7 +15,7 @@ rs = ctx.add_paired(api.paired_cfg(300.0, 30.0), *synth.pack_reads(pr.mate1), *s
 variants = [api.FlatPaths(v) for v in bench.path_variants(synth.genome_walk(g))]
 if len(sys.argv) < 2 or sys.argv[1] != "fresh":
     [ctx.score(v) for v in variants]
-start, seq = synth.sa_sequence(g, 300)
+start, seq = synth.sa_sequence(g, int(os.environ.get("SA_STEPS", "300")))
 ctx.calc_prob(start)
 flat = [api.FlatPaths(p) for p in seq]
 for f in flat: ctx.score(f)
@@ -37,3 +37,9 @@ for f in flat[-3:]:
         m = ok & (cls == c)
         if m.any():
             print(f"  class tag {c}: {m.sum()} blocks, enter {np.median(ent[m]):.2f} (max {ent[m].max():.2f}), done median {np.median(end[m]):.2f} p90 {np.percentile(end[m], 90):.2f} max {end[m].max():.2f}, duration median {np.median(end[m] - ent[m]):.2f} max {(end[m] - ent[m]).max():.2f}")
+    m2 = ok & (cls == 2)
+    if m2.any():
+        dur = end - ent
+        worst = np.argsort(-(dur * m2))[:6]
+        print("  slowest blocks outside the two big classes (logical block = blocks - 1 - dispatch index; classes", ctx.debug_class_counts(rs), "):",
+              [(int(nb - 1 - b), round(float(dur[b]), 1)) for b in worst])
