@@ -185,6 +185,7 @@ def _load():
     L.gaml_hip_debug_table_occurrences.restype = C.c_int64
     L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
+    L.gaml_hip_debug_fold_check.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
     if hasattr(L, "gaml_hip_shm_exchange_open"):
         L.gaml_hip_shm_exchange_open.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
@@ -678,6 +679,13 @@ class Context:
 
     def debug_set_knob(self, knob, value):
         self._check(_lib.gaml_hip_debug_set_knob(self._h, knob, value))
+
+    def debug_fold_check(self, rs):
+        """Host-only: record tables with / without the always-overwritten records, compared pair by pair."""
+        out = np.zeros(6, np.int64)
+        self._check(_lib.gaml_hip_debug_fold_check(self._h, rs, out))
+        return {"records_left_out": [int(out[0]), int(out[1])], "compact_pairs": [int(out[2]), int(out[3])], "records_checked": int(out[4]),
+                "violations": int(out[5])}
 
     def debug_class_counts(self, rs):
         out = np.zeros(4, np.int64)

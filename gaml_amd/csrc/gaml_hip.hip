@@ -2761,6 +2761,53 @@ int gaml_hip_debug_class_counts(gaml_hip_ctx* c, int rs, int64_t* out4) {
   return GAML_HIP_OK;
 }
 
+// Host-only check of the record tables' rule "a record that is always overwritten stays out" (host_model.cc
+// dominated_records) on the windows that are active now: builds the tables with and without the rule (no device) and
+// verifies, record by record, that every pair's records with the rule are the records without it minus records of a
+// junction window J for which the first node's own window -- active -- holds a record of the same read at the same
+// position. out6 = {records left out mate 1, mate 2, pairs of the compact class with / without the rule, records
+// checked, violations}. Returns GAML_HIP_ESTATE when a violation was found.
+int gaml_hip_debug_fold_check(gaml_hip_ctx* c, int rs, int64_t* out6) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out6) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  PairTables with, without;
+  build_pair_tables(s.mate[0], s.mate[1], with, true);
+  build_pair_tables(s.mate[0], s.mate[1], without, false);
+  int64_t checked = 0, bad = 0;
+  const int64_t n = s.mate[0].n_local();
+  PairedSet::RecList a, b;
+  for (int mt = 0; mt < 2; mt++) {
+    const ShortMate& m = s.mate[mt];
+    // per (window, read, position): is it a record of an active single-node window?
+    for (int64_t read = 0; read < n; read++) {
+      a = PairedSet::RecList(); b = PairedSet::RecList();
+      paired_base_records(with, with.slot_of_read[read], mt, a);
+      paired_base_records(without, without.slot_of_read[read], mt, b);
+      size_t ia = 0;
+      for (size_t ib = 0; ib < b.size(); ib++) {
+        checked++;
+        const RecQuad& r = b[ib];
+        if (ia < a.size() && a[ia].wid == r.wid && a[ia].pos == r.pos && a[ia].flags == r.flags) { ia++; continue; }
+        // left out: must be a junction window whose first node's own window holds (read, position)
+        const Window& j = m.wins[r.wid];
+        bool ok = false;
+        if (j.head >= 0) {
+          auto it = m.solo_of_node.find(j.head);
+          if (it != m.solo_of_node.end() && m.wins[it->second].active)
+            for (size_t q = 0; q < b.size(); q++) ok = ok || (b[q].wid == it->second && b[q].pos == r.pos);
+        }
+        bad += !ok;
+      }
+      bad += ia != a.size();  // (a record with the rule that the tables without it do not hold)
+    }
+  }
+  out6[0] = with.dropped_records[0]; out6[1] = with.dropped_records[1];
+  out6[2] = with.class_count[0]; out6[3] = without.class_count[0];
+  out6[4] = checked; out6[5] = bad;
+  return bad ? fail(c, GAML_HIP_ESTATE, "record tables: a record was left out that is not always overwritten") : GAML_HIP_OK;
+}
+
 int gaml_hip_last_timing(const gaml_hip_ctx* c, double* out3) {
   if (!c || !out3) return GAML_HIP_EINVAL;
   MULTI_FWD(c, multi_last_timing(c->multi, out3));

@@ -84,6 +84,11 @@ int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
  * backtrace on stderr when the process aborts or faults (also after the HIP runtime reports a GPU memory fault). */
 /* pairs per record-count class of the device table {<=1, <=2, <=4, more} (paired sets) */
 int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);
+/* host-only (works without a device): the record tables of the windows that are active now, built with and without the
+ * rule "a junction record that the first node's own record always overwrites stays out" (knob 16), compared pair by
+ * pair. out6 = {records left out mate 1, mate 2, compact-class pairs with / without the rule, records checked,
+ * violations}; GAML_HIP_ESTATE if a record was left out that the rule does not cover. */
+int gaml_hip_debug_fold_check(gaml_hip_ctx* ctx, int readset, int64_t* out6);
 
 #ifdef __cplusplus
 }

@@ -197,3 +197,22 @@ def test_sharded_contexts_partition_the_records(built):
         for r, p in enumerate(parts):
             if p is not None and len(p):
                 assert p[:, 2].min() >= n * r // 3 and p[:, 2].max() < n * (r + 1) // 3
+
+
+def test_record_tables_leave_out_only_records_that_are_always_overwritten(built):
+    """The record tables drop a junction window's record when the first node's own window (on the device itself) holds
+    a record of the same read at the same position: that one is looked up right behind it at the same path position
+    and overwrites it (graph.cc:563-566, 583-592). Host-only check over path sets that activate the windows in
+    different orders: with the rule, every pair's records are the records without it minus exactly such records."""
+    g, ctx, rs, _, _ = _pair_setup(G=120_000, n=12_000, seed=77, repeats=2)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 3
+    seen = []
+    for paths in ([[x] for x in walk[:k]], [walk[:k]], [walk], [walk[k:], walk[:k]], [[x ^ 1 for x in reversed(walk)]]):
+        ctx.debug_prepare(paths)
+        st = ctx.debug_fold_check(rs)
+        assert st["violations"] == 0 and st["records_checked"] > 0
+        seen.append(st)
+    assert seen[0]["records_left_out"] == [0, 0]                    # one-node paths: no junction window is in use
+    assert min(seen[2]["records_left_out"]) > 0                      # the whole walk: every junction is
+    assert seen[2]["compact_pairs"][0] > seen[2]["compact_pairs"][1]  # ... and pairs move to the one-record class
