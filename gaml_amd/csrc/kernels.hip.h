@@ -707,7 +707,16 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
           c.lc = code; c.L1 = L1; c.L2 = L2;
           q.dist = dist; q.scores = true; q.skip = false;
           q.memo_idx = ((code * 7 + q.x.edit) * 7 + q.y.edit) * a.ins_n + dist;
-          compact_finish(a, i, c, q, a.memo[q.memo_idx], lsum, zeros, cap);
+          // the two per-code values are requested WITH the memo entry, not behind the store that needs it (the store may
+          // alias them for all the compiler knows: they were a round trip of their own at the end of every such wave)
+          const double tfl = a.tfloor_c[code], lfl = a.logfloor_c[code];
+          const double2 m = a.memo[q.memo_idx];
+          if (cap) *cap = PairVal{m.x, m.y, code, 1};
+          compact_cover(a, c, q, m.x);
+          __builtin_nontemporal_store(m.x, &a.probs[i]);
+          const bool floored = m.x < tfl;  // as compact_finish
+          lsum += floored ? lfl : m.y - a.log_two_T;
+          zeros += (int)floored;
           return;
         }
       }
