@@ -268,7 +268,10 @@ int gaml_hip_compact_tables(gaml_hip_ctx* ctx);
  *     gaml_hip_eval_pacbio_finish_async(ctx, i, intervals, n_intervals, contribute, stream)   `intervals`: the
  *         n_intervals gathered intervals of all ranks (this rank's among them) in device memory; sorts them
  *         together with the contigs' node intervals, runs the sweep on the device and stores bad_bases into the
- *         partials like the paired form. No interval ever visits the host. */
+ *         partials like the paired form. No interval ever visits the host.
+ * `stream` everywhere here: a real stream handle the caller orders its own copies and collectives on; NULL selects the
+ * context's private stream -- not the legacy default stream (several contexts of one process handed NULL work on
+ * several unrelated streams). */
 int32_t gaml_hip_eval_score_async(gaml_hip_ctx* ctx, void* d_partials, void* stream);
 int gaml_hip_eval_coverage_export_async(gaml_hip_ctx* ctx, int32_t i, void* dst, int64_t cap, int64_t* bytes_out, void* stream);
 int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* ctx, int32_t i, const void* maps, int32_t n_maps, int32_t contribute,

@@ -332,7 +332,11 @@ def test_sharded_coverage_penalty_merges_the_ranks_maps():
     reduced = np.maximum.reduce([c.eval_pending_maxpos() for c in shards])
     for c in shards:
         c.eval_apply_maxpos(reduced)
-    stream = torch.cuda.current_stream().cuda_stream
+    # ONE explicit stream for the library's work and for torch's (a null stream handle would make every context fall
+    # back to its OWN stream, unordered against torch's copies: the three "ranks" share one process here)
+    ts = torch.cuda.Stream()
+    torch.cuda.set_stream(ts)
+    stream = ts.cuda_stream
     parts = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in shards]
     maps = []
     for c, p in zip(shards, parts):
@@ -346,6 +350,7 @@ def test_sharded_coverage_penalty_merges_the_ranks_maps():
     for r, (c, p) in enumerate(zip(shards, parts)):
         c.eval_coverage_finish_async(0, gathered.data_ptr(), 3, r == 0, stream)
     torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
     own_bad = [float(p[2]) for p in parts]
     assert own_bad[0] == bad_whole and own_bad[1] == 0.0 and own_bad[2] == 0.0
     acc = torch.stack(parts).sum(0).cpu().numpy()  # the all-reduce(sum)
@@ -391,7 +396,9 @@ def test_sharded_pacbio_penalty_merges_the_ranks_intervals():
     bad_whole = whole.bad_bases(wrs)
     assert bad_whole > 0
     shards = [make(r, 3)[0] for r in range(3)]
-    stream = torch.cuda.current_stream().cuda_stream
+    ts = torch.cuda.Stream()  # one explicit stream for the library's work and torch's (see the coverage test above)
+    torch.cuda.set_stream(ts)
+    stream = ts.cuda_stream
     parts = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in shards]
     own, counts = [], []
     for c, p in zip(shards, parts):
@@ -409,6 +416,7 @@ def test_sharded_pacbio_penalty_merges_the_ranks_intervals():
     for r, c in enumerate(shards):
         c.eval_pacbio_finish_async(0, merged.data_ptr(), sum(counts), r == 1, stream)  # any one rank may contribute
     torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
     assert [float(p[2]) for p in parts] == [0.0, float(bad_whole), 0.0]
     acc = torch.stack(parts).sum(0).cpu().numpy()
     got, z = shards[0].combine_partials(acc, tl)
