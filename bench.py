@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s ach
 def source_hash() -> str:
     """What the committed rocprofv3 summaries must have been taken on to describe this run: the kernel sources + this file."""
     h = hashlib.sha256()
-    for rel in ("bench.py", "gaml_amd/csrc/kernels.hip.h", "gaml_amd/csrc/gaml_hip.hip", "gaml_amd/csrc/paired_launch.hip.h", "gaml_amd/csrc/ctx.hip.h",
-                "gaml_amd/csrc/multi.hip", "gaml_amd/csrc/host_model.cc", "gaml_amd/csrc/host_model.h"):
+    rels = subprocess.check_output(["make", "-s", "-C", os.path.join(ROOT, "gaml_amd", "csrc"), "print-srcs"], text=True).split()
+    for rel in ["bench.py"] + rels:  # the Makefile's list: every file in csrc/ and include/
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -186,6 +186,8 @@ def _load():
     L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_fold_check.argtypes = [vp, C.c_int, _i64p]
+    if hasattr(L, "gaml_hip_debug_static_check"):  # absent from older A/B builds loaded through GAML_HIP_LIB
+        L.gaml_hip_debug_static_check.argtypes = [vp, C.c_int, _i64p]
     L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
     if hasattr(L, "gaml_hip_shm_exchange_open"):
         L.gaml_hip_shm_exchange_open.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
@@ -659,7 +661,8 @@ class Context:
         out = np.zeros(10, np.int64)
         self._check(_lib.gaml_hip_debug_table_stats(self._h, rs, out))
         return {"full_rebuilds": int(out[0]), "delta_updates": int(out[1]), "dirty_pairs": int(out[2]), "worker_rebuilds": int(out[3]),
-                "batches_patched": int(out[4]), "batches_full": int(out[5]), "records_left_out": [int(out[6]), int(out[7])], "delta_records_left_out": int(out[8])}
+                "batches_patched": int(out[4]), "batches_full": int(out[5]), "records_left_out": [int(out[6]), int(out[7])], "delta_records_left_out": int(out[8]),
+                "static_index_pairs": int(out[9])}
 
     def aligner_stats(self):
         w, k, us = C.c_int64(), C.c_int64(), C.c_double()
@@ -686,6 +689,19 @@ class Context:
         self._check(_lib.gaml_hip_debug_fold_check(self._h, rs, out))
         return {"records_left_out": [int(out[0]), int(out[1])], "compact_pairs": [int(out[2]), int(out[3])], "records_checked": int(out[4]),
                 "violations": int(out[5])}
+
+    def debug_static_check(self, rs):
+        """Host-only: the compact class's static memo indices recomputed from the window cache."""
+        out = np.zeros(8, np.int64)
+        self._check(_lib.gaml_hip_debug_static_check(self._h, rs, out))
+        return {"static_pairs": int(out[0]), "other_pairs": int(out[1]), "violations": int(out[2]), "no_record": int(out[3]),
+                "different_windows": int(out[4]), "orientation": int(out[5]), "distance": int(out[6]), "edits_or_code": int(out[7])}
+
+    def debug_block_partials(self, rs, set_index=0):
+        sums, zeros, lay = np.zeros(8192, np.float64), np.zeros(8192, np.int32), np.zeros(8, np.int32)
+        _lib.gaml_hip_debug_block_partials.argtypes = [C.c_void_p, C.c_int, C.c_int32, _f64p, _i32p, C.c_int32, _i32p]
+        n = _lib.gaml_hip_debug_block_partials(self._h, rs, set_index, sums, zeros, 8192, lay)
+        return sums[:max(n, 0)].copy(), zeros[:max(n, 0)].copy(), lay.tolist()
 
     def debug_class_counts(self, rs):
         out = np.zeros(4, np.int64)

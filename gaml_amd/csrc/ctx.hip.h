@@ -162,11 +162,11 @@ struct MateDev {
 
 // the device side of one build of the record tables (PairTables): everything a rebuild replaces as a whole
 struct TableDev {
-  DevBuf rec8[2], first[2], extra[2], inl[2], len_code, len_combo, len12, combo_tabs, memo;
+  DevBuf rec8[2], first[2], extra[2], inl[2], len_code, len_combo, len12, combo_tabs, memo, static_idx, static_val;
   int memo_codes = 0;     // length combinations the memo of pair terms covers (0: no memo)
   void release() {
     for (int m = 0; m < 2; m++) { rec8[m].release(); first[m].release(); extra[m].release(); inl[m].release(); }
-    len_code.release(); len_combo.release(); len12.release(); combo_tabs.release(); memo.release();
+    len_code.release(); len_combo.release(); len12.release(); combo_tabs.release(); memo.release(); static_idx.release(); static_val.release();
   }
 };
 
@@ -217,6 +217,7 @@ struct TableRebuild {
   double snapshot_us = 0, build_ms = 0;
   int64_t start_eval = 0;      // the set's evaluation count when the rebuild was decided
   bool keep_dominated = false; // knob 16 as the worker read it
+  int static_ins_n = 0;        // paired_static_ins_n() when the rebuild was decided
   size_t next_w[2] = {0, 0};   // state 4: progress of the private copy (first window not copied yet)
 };
 
@@ -389,6 +390,8 @@ struct gaml_hip_ctx {
   int event_every = 1;    // time every k-th scoring launch (attached events cost ~4 us of host time per launch)
   int64_t event_tick = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // one pair per scoring launch of a call
+  std::vector<uint64_t> ev_call;  // ... and the evaluation (eval_serial) it belongs to
+  uint64_t eval_serial = 0;
   size_t ev_used = 0;
   double t_host_us = 0, t_dev_wall_us = 0, t_kernel_us = 0;
   int64_t stat_launches = 0;

@@ -108,14 +108,18 @@ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 // sum the elapsed time of every event pair recorded since the last collection (the stream
 // they were recorded on must have been synchronised by the caller)
 int collect_events(gaml_hip_ctx* c) {
-  c->t_kernel_us = 0;
+  // t_kernel_us (gaml_hip_last_timing [2]) describes the LAST call: the scoring kernels of the newest evaluation that
+  // carried events -- not the sum over everything collected lazily (gaml_hip_kernel_stats drains hundreds of launches)
+  double sum = 0, last = 0;
   for (size_t i = 0; i < c->ev_used; i++) {
     float ms = 0;
     HIP_TRY(c, hipEventSynchronize(c->ev_pool[i].second));
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
-    c->t_kernel_us += ms * 1000.0;
+    sum += ms * 1000.0;
+    last = c->ev_call[i] == c->ev_call[c->ev_used - 1] ? last + ms * 1000.0 : 0.0;
   }
-  c->stat_device_us += c->t_kernel_us;
+  if (c->ev_used) c->t_kernel_us = last;
+  c->stat_device_us += sum;
   c->ev_used = 0;
   return 0;
 }
@@ -128,6 +132,8 @@ int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
     HIP_TRY(c, hipEventCreate(&b));
     c->ev_pool.emplace_back(a, b);
   }
+  if (c->ev_call.size() < c->ev_pool.size()) c->ev_call.resize(c->ev_pool.size(), 0);
+  c->ev_call[c->ev_used] = c->eval_serial;
   *out = &c->ev_pool[c->ev_used++];
   return 0;
 }
@@ -1028,6 +1034,7 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
   if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
   if (n_paths < 0 || (n_paths > 0 && (!flat || !offs))) return fail(c, GAML_HIP_EINVAL, "bad path arguments");
   const double t0 = now_us();
+  c->eval_serial++;
   for (int32_t i = 0; i < n_paths; i++) if (offs[i + 1] < offs[i]) return fail(c, GAML_HIP_EINVAL, "path offsets must not decrease");
   // Paired sets take the paths in the ABI's flat form (their planner diffs them against the previous call's); the
   // other kinds, or a context without a paired set, get them as vectors (reused: a set of ~900 short paths would
@@ -1135,6 +1142,9 @@ int combine(gaml_hip_ctx* c, const double* partials, double* prob_out, int32_t* 
       v = (sum / (double)(int64_t)n - bad * cfg.penalty_constant) * cfg.weight;
     } else if (h.kind == 1) {
       const gaml_paired_cfg& cfg = c->paireds[h.idx]->cfg;
+      // no sum of logs and floors is NaN; a block of the scoring launch poisons its partial when the two mates'
+      // occurrence tables disagree about a window both hold (kernels.hip.h paired_static4_body): report, do not score
+      if (std::isnan(sum)) return fail(c, GAML_HIP_ESTATE, "paired read set: the mates' occurrence tables disagree about a shared window (static memo index)");
       v = (sum / (double)(int64_t)n - bad * cfg.penalty_constant) * cfg.weight;
     } else {
       const gaml_single_cfg& cfg = c->pacbios[h.idx]->cfg;
@@ -2714,7 +2724,7 @@ int gaml_hip_debug_table_stats(gaml_hip_ctx* c, int rs, int64_t* out10) {
   out8[0] = s.full_rebuilds; out8[1] = s.delta_updates; out8[2] = (int64_t)s.dirty.size(); out8[3] = s.async_rebuilds;
   out8[4] = s.batches_patched; out8[5] = s.batches_full;
   out8[6] = s.pt.dropped_records[0]; out8[7] = s.pt.dropped_records[1];
-  out10[8] = s.delta_left_out; out10[9] = 0;
+  out10[8] = s.delta_left_out; out10[9] = s.pt.n0a;
   return GAML_HIP_OK;
 }
 
@@ -2806,6 +2816,77 @@ int gaml_hip_debug_fold_check(gaml_hip_ctx* c, int rs, int64_t* out6) {
   out6[2] = with.class_count[0]; out6[3] = without.class_count[0];
   out6[4] = checked; out6[5] = bad;
   return bad ? fail(c, GAML_HIP_ESTATE, "record tables: a record was left out that is not always overwritten") : GAML_HIP_OK;
+}
+
+// Host-only check of the static memo indices (PairTables::static_idx): tables of the windows that are active now,
+// every compact-class pair looked at again from the window cache -- the two records' windows compared by their node
+// walks, orientation rule and insert distance recomputed (graph.cc:1864-1876). out8 = {pairs with a static index, other
+// compact-class pairs, violations (an index that differs, or a pair that qualifies and has none), then why the other
+// pairs have none: a mate without record, records in different windows, orientation rule, distance outside the
+// insert-size table, edit count / length code outside the memo}.
+int gaml_hip_debug_static_check(gaml_hip_ctx* c, int rs, int64_t* out8) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out8) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  if (int e = paired_host_tabs(c, s)) return e;
+  const int ins_n = (int)s.ins_tab.size();
+  link_mate_windows(s.mate[0], s.mate[1]);
+  PairTables pt;
+  build_pair_tables(s.mate[0], s.mate[1], pt, true, ins_n);
+  for (int k = 0; k < 8; k++) out8[k] = 0;
+  const int64_t n0 = pt.class_count[0];
+  out8[0] = pt.n0a; out8[1] = n0 - pt.n0a;
+  const int codes = (int)std::min<size_t>(pt.len_combo.size(), kMemoCodes);
+  for (int64_t slot = 0; slot < n0; slot++) {
+    const uint64_t r1 = pt.rec8[0][slot], r2 = pt.rec8[1][slot];
+    const int32_t read = pt.read_of_slot[slot];
+    int why = 0;  // 0: qualifies
+    int32_t idx = -1;
+    if (r1 == kNoRec8 || r2 == kNoRec8) { idx = kStaticZero; }  // never scores: static, too
+    else {
+      const int32_t w1 = (int32_t)(r1 & 0xffffff), w2 = (int32_t)(r2 & 0xffffff);
+      if (*s.mate[0].win_walk[w1] != *s.mate[1].win_walk[w2]) why = 4;
+      else {
+        const int32_t p1 = (int32_t)((r1 >> 24) & 0xfffffff), p2 = (int32_t)((r2 >> 24) & 0xfffffff);
+        const int32_t e1 = (int32_t)((r1 >> 52) & 63), e2 = (int32_t)((r2 >> 52) & 63), o1 = (int32_t)((r1 >> 58) & 1), o2 = (int32_t)((r2 >> 58) & 1);
+        const int32_t L1 = s.mate[0].lens[read], L2 = s.mate[1].lens[read];
+        int32_t dist = -1;
+        if (o1 != o2) {  // graph.cc:1864-1876 on window positions (both alignments get the window's shift)
+          if (p1 < p2) { if (o1 == 0 && o2 == 1) dist = p2 - p1 + L2; }
+          else if (o1 == 1 && o2 == 0) dist = p1 - p2 + L1;
+        }
+        const int lc = pt.len_code[slot];
+        if (dist < 0 && !(o1 != o2 && ((p1 < p2 && o1 == 0) || (p1 >= p2 && o1 == 1)))) why = 5;
+        else if (dist < 0 || dist >= ins_n) why = 6;
+        else if (e1 >= 7 || e2 >= 7 || lc >= codes) why = 7;
+        else idx = ((lc * 7 + e1) * 7 + e2) * ins_n + dist;
+      }
+    }
+    if (slot < pt.n0a) out8[2] += (why != 0 || idx != pt.static_idx[slot]);
+    else { out8[2] += why == 0; if (why) out8[why]++; }
+  }
+  return out8[2] ? fail(c, GAML_HIP_ESTATE, "record tables: a static memo index is wrong or missing") : GAML_HIP_OK;
+}
+
+// per-block partial sums of the last blocking evaluation of paired read set rs (path set `set` of a batch launch; 0 for a
+// single call), in block order [lane-per-pair classes | wave-per-pair blocks | paired_general_kernel blocks]: which
+// block's sum differs when two routes that should agree bit for bit do not. Returns the number of blocks.
+int32_t gaml_hip_debug_block_partials(gaml_hip_ctx* c, int rs, int32_t set, double* sums, int32_t* zeros, int32_t cap, int32_t* layout8) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1) return GAML_HIP_EINVAL;
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  if (!s.last_host_partials || set < 0 || set >= kMaxSets) return 0;
+  const int n = s.last_blocks[set];
+  const double* hs = (const double*)s.h_part_sum.p + (size_t)set * s.host_part_stride;
+  const int* hz = (const int*)s.h_part_zero.p + (size_t)set * s.host_part_stride;
+  for (int b = 0; b < n && b < cap; b++) { if (sums) sums[b] = hs[b]; if (zeros) zeros[b] = hz[b]; }
+  if (layout8) {
+    PairedArgs a; GridPlan gp;
+    paired_base_args(c, s, a, gp);
+    layout8[0] = gp.blocks0a; layout8[1] = gp.blocks0; layout8[2] = a.blocks01; layout8[3] = a.blocks012; layout8[4] = a.main_blocks; layout8[5] = a.total_blocks;
+    layout8[6] = gp.gen_blocks; layout8[7] = n;
+  }
+  return n;
 }
 
 int gaml_hip_last_timing(const gaml_hip_ctx* c, double* out3) {

@@ -1150,7 +1150,17 @@ int64_t undominated_records(const ShortMate& m, int32_t wid, std::vector<uint8_t
   return kept;
 }
 
-void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold) {
+void link_mate_windows(ShortMate& a, ShortMate& b) {
+  for (size_t w = 0; w < a.wins.size(); w++) {
+    if (a.wins[w].peer >= 0) continue;
+    const int32_t p = b.find(*a.win_walk[w]);
+    a.wins[w].peer = p;
+    if (p >= 0) b.wins[p].peer = (int32_t)w;
+  }
+  for (Window& w : b.wins) if (w.peer == -2) w.peer = -1;  // (not in `a`, or the loop above would have linked it)
+}
+
+void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold, int ins_n) {
   static const bool trace_bpt = getenv("GAML_HIP_TRACE_HOST") != nullptr;
   auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_stage[8]; int n_stage = 0;
@@ -1200,10 +1210,33 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, 
     lc[i] = it->second;
     last_c = c; last_id = it->second;
   }
+  // the memo index of a class-0 pair whose two records sit in the same window, or -1 (PairTables::static_idx): same
+  // orientation rule and insert distance as the scorers apply per call (graph.cc:1864-1876), on window positions -- the
+  // two alignments get the same shift wherever the window occurs
+  const int memo_codes = (int)std::min<size_t>(out.len_combo.size(), kMemoCodes);
+  const bool memo_fits = ins_n > 0 && (size_t)memo_codes * 49 * (size_t)ins_n <= kMemoMaxEntries;
+  auto static_idx = [&](int64_t i) -> int32_t {  // (only asked for pairs that fit the compact class)
+    if (!memo_fits) return -1;
+    const uint64_t r1 = one[0][i], r2 = one[1][i];
+    if (r1 == kNoRec8 || r2 == kNoRec8) return kStaticZero;  // a mate without alignment: the pair scores nothing, in every path set
+    if (lc[i] >= memo_codes) return -1;
+    const int32_t w1 = (int32_t)(r1 & 0xffffff), w2 = (int32_t)(r2 & 0xffffff);
+    if (a.wins[w1].peer != w2) return -1;
+    const int32_t p1 = (int32_t)((r1 >> 24) & 0xfffffff), p2 = (int32_t)((r2 >> 24) & 0xfffffff);
+    const int32_t e1 = (int32_t)((r1 >> 52) & 63), e2 = (int32_t)((r2 >> 52) & 63);
+    const int32_t or1 = (int32_t)((r1 >> 58) & 1), or2 = (int32_t)((r2 >> 58) & 1);
+    if (or1 == or2 || e1 >= 7 || e2 >= 7) return -1;
+    const bool fwd = p1 < p2;
+    if (or1 != (fwd ? 0 : 1)) return -1;
+    const int32_t dist = fwd ? p2 - p1 + b.lens[i] : p1 - p2 + a.lens[i];
+    if (dist < 0 || dist >= ins_n) return -1;
+    return ((lc[i] * 7 + e1) * 7 + e2) * ins_n + dist;
+  };
+  // internal classes: 0 = class 0 with a static memo index, 1 = the rest of class 0, 2..4 = the reference classes 1..3
   auto cls = [&](int64_t i) {
     int m = std::max(k[0][i], k[1][i]);
-    if (m <= 1 && lc[i] >= 0 && one[0][i] != kNoRec8 - 1 && one[1][i] != kNoRec8 - 1) return 0;
-    return m <= 2 ? 1 : m <= 4 ? 2 : 3;
+    if (m <= 1 && lc[i] >= 0 && one[0][i] != kNoRec8 - 1 && one[1][i] != kNoRec8 - 1) return static_idx(i) != -1 ? 0 : 1;
+    return m <= 2 ? 2 : m <= 4 ? 3 : 4;
   };
   // device order: by (class, window of mate 1, window of mate 2, read id) -- for a read with several records the window
   // of its first one. Lanes of a wave then look up the same few occurrence entries (a broadcast instead of a gather: the
@@ -1211,6 +1244,15 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, 
   // ordered by read id). Two stable counting passes (least significant key first), O(pairs + windows).
   std::vector<uint8_t> cl(n);
   parallel_ranges(n, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) cl[i] = (uint8_t)cls(i); });
+  {
+    // A handful of pairs with 3-4 records per mate do not get a block range of their own: one lane resolving such a pair
+    // (16 + 16 liveness tests, up to 16 terms, all in registers) takes ~6.5 us -- as long as the rest of the launch put
+    // together at BASELINE config 3, where the class holds ONE pair. The wave-per-pair path spreads the same work over 64
+    // lanes; it takes them while they are few.
+    int64_t n3 = 0;
+    for (int64_t i = 0; i < n; i++) n3 += cl[i] == 3;
+    if (n3 > 0 && n3 <= kFoldClass2Below) for (int64_t i = 0; i < n; i++) if (cl[i] == 3) cl[i] = 4;
+  }
   const uint32_t nw1 = (uint32_t)a.wins.size() + 2, nw2 = (uint32_t)b.wins.size() + 2;
   // (`one` holds a read's first record, or a marker when it has none / the record does not fit the 8-byte form)
   auto win_of = [&](int mt, int32_t i, uint32_t none) -> uint32_t { return one[mt][i] >= kNoRec8 - 1 ? none : (uint32_t)(one[mt][i] & 0xffffff); };
@@ -1237,24 +1279,27 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, 
     run([&](int t) { auto [lo, hi] = part(t); for (int64_t i = lo; i < hi; i++) dst[cnt[t][key_of_pos(i)]++] = item_of_pos(i); });
   };
   counting_pass(nw2 + 1, [&](int64_t i) { return key2((int32_t)i); }, [&](int64_t i) { return (int32_t)i; }, tmp);
-  counting_pass(4 * nw1, [&](int64_t i) { return key1(tmp[i]); }, [&](int64_t i) { return tmp[i]; }, order);
+  counting_pass(5 * nw1, [&](int64_t i) { return key1(tmp[i]); }, [&](int64_t i) { return tmp[i]; }, order);
   t_stage[n_stage++] = now_ms();
   for (int c = 0; c < 4; c++) out.class_count[c] = 0;
   out.slot_of_read.assign(n, 0);
   out.read_of_slot.assign(n, 0);
-  for (int64_t i = 0; i < n; i++) out.class_count[cl[i]]++;
+  out.n0a = 0;
+  for (int64_t i = 0; i < n; i++) { out.class_count[cl[i] == 0 ? 0 : cl[i] - 1]++; out.n0a += cl[i] == 0; }
   parallel_ranges(n, [&](int64_t lo, int64_t hi) {
     for (int64_t s = lo; s < hi; s++) { out.read_of_slot[s] = order[s]; out.slot_of_read[order[s]] = (int32_t)s; }
   });
   const int64_t n0 = out.class_count[0];
   for (int mt = 0; mt < 2; mt++) out.rec8[mt].resize(n0);
   out.len_code.resize(n0);
+  out.static_idx.resize(out.n0a);
   parallel_ranges(n0, [&](int64_t lo, int64_t hi) {
     for (int64_t s = lo; s < hi; s++) {
       const int32_t r = order[s];
       out.rec8[0][s] = one[0][r];
       out.rec8[1][s] = one[1][r];
       out.len_code[s] = (uint8_t)lc[r];
+      if (s < out.n0a) out.static_idx[s] = static_idx(r);
     }
   });
   out.len12.resize(n - n0);

@@ -58,6 +58,8 @@ struct Window {
   int32_t solo = -1;          // single-node window: the node
   int32_t head = -1;          // window of several nodes whose first node is longer than kTail: that node. Wherever this
                               // window is looked up, the node's own window is looked up right after it (graph.cc:563-566)
+  int32_t peer = -2;          // id of the window with the SAME node walk in the other mate of a paired set (-1: it has none
+                              // yet, -2: not looked up yet): link_mate_windows, read by build_pair_tables
 };
 
 // One occurrence of a window in the path set being scored.
@@ -188,6 +190,15 @@ inline uint64_t rec8_pack(int32_t wid, int32_t pos, int32_t edit, int32_t orient
 struct PairTables {
   std::vector<int32_t> slot_of_read, read_of_slot;
   int64_t class_count[4] = {0, 0, 0, 0};  // 0: compact; 1: <= 2 records; 2: <= 4; 3: more
+  // Class 0 comes in two parts. Slots [0, n0a): both mates' records sit in the SAME window (same node walk) and the pair's
+  // term is covered by the memo of pair terms -- wherever that window occurs in a path set the two alignments get the same
+  // shift, so orientation rule, insert distance and with them the memo index (graph.cc:1864-1882) do not depend on the path
+  // set: static_idx[slot] holds it, computed here once. The path set only decides WHETHER the pair scores (the window
+  // occurs, position filter graph.cc:577). A pair with a mate that has no alignment at all (the max-hash aligner finds
+  // ~85 % of the reads at 1 % substitutions) is there too, index kStaticZero: it scores nothing whatever the path set.
+  // Slots [n0a, class_count[0]): every other class-0 pair (resolved per call).
+  int64_t n0a = 0;
+  std::vector<int32_t> static_idx;        // [n0a]
   std::vector<uint64_t> rec8[2];          // [n0]
   std::vector<uint8_t> len_code;          // [n0] index into len_combo
   std::vector<uint32_t> len_combo;        // distinct L1 | L2<<16 values (<= 256)
@@ -198,8 +209,20 @@ struct PairTables {
   std::vector<RecQuad> inl[2];
   int64_t dropped_records[2] = {0, 0};    // records of active windows left out of the tables (dominated_records)
 };
-// fold = false keeps the records that can never survive the overwrite rule (A/B and tests; same values either way)
-void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold = true);
+// fold = false keeps the records that can never survive the overwrite rule (A/B and tests; same values either way).
+// ins_n: length of the insert-size table the memo of pair terms is built over (memo index = ((code * 7 + edit 1) * 7 + edit 2)
+// * ins_n + distance, first kMemoCodes length combinations, edits < 7); 0: no static indices (n0a = 0).
+#ifndef GAML_FOLD_CLASS2_BELOW
+#define GAML_FOLD_CLASS2_BELOW 1024
+#endif
+constexpr int64_t kFoldClass2Below = GAML_FOLD_CLASS2_BELOW;  // fewer pairs than this with 3-4 records per mate: scored one wave per pair (class 3)
+constexpr int kMemoCodes = 4;
+constexpr int32_t kStaticZero = -2;  // PairTables::static_idx of a pair that never scores
+constexpr size_t kMemoMaxEntries = (size_t)1 << 24;
+void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold = true, int ins_n = 0);
+// which windows of the two mates of a paired set hold the same node walk (Window::peer); only windows not linked yet are
+// looked up. Call before build_pair_tables (on the thread that owns the window caches).
+void link_mate_windows(ShortMate& a, ShortMate& b);
 // The same rule for ONE window that joins the device tables later (delta lists): keep[k] = 0 for the records of window
 // `wid` that its first node's own window -- active -- always overwrites. Returns the number of records to keep.
 int64_t undominated_records(const ShortMate& m, int32_t wid, std::vector<uint8_t>& keep);

@@ -32,6 +32,25 @@ struct MateView {
 };
 
 struct PairedArgs {
+  // ---- what the blocks of the static part of the compact class read (paired_score_kernel's lean entry), together at
+  // the front: two wide scalar fetches, one wait, and the first records can be requested
+  int total_blocks, blocks0a, n0a, n_codes;   // grid size; static part: blocks [0, blocks0a), slots [0, n0a); length combinations (<= 256)
+  int blocks0;               // blocks [0, blocks0): compact path; [blocks0, blocks01): <= 2 records; [blocks01, blocks012): <= 4;
+  int blocks01, blocks012;   // [blocks012, main_blocks): delta pairs (lane per pair)
+  int main_blocks;           // partial slots [0, main_blocks) main, then the wave-per-pair blocks (total_blocks in all)
+  const double2* memo;                        // (documented below)
+  uint32_t* cov_bits;                         // coverage marks (only when penalty_constant > 0), else null
+  const unsigned long long* rec8[2];          // class 0 (compact): slots [0, n0): 8-byte records
+  const double2* static_val;                  // [n0a] the static pairs' memo entries {t, log t} (static_values_kernel)
+  const Occ12* occ12[2];                      // = m[mt].occ12
+  double* probs;                              // out: per-pair summed probability (ScoringState::probs)
+  double* part_sum;                           // per-block partials: main kernel blocks, then overflow kernel blocks
+  int* part_zero;
+  double log_two_T;                           // log(2T), host libm, per call
+  double tfloor0, logfloor0;                  // tfloor_c[0] / logfloor_c[0] by value (sets with one length combination)
+  uint32_t len_combo0; int pad0_;             // len_combo[0] by value
+  unsigned long long* gen_bits;               // (documented below)
+  // ---- everything else
   MateView m[2];
   const uint32_t* len12;     // L1 | L2<<16 per pair
   const double* ins_tab;     // insert-size Gaussian (graph.cc:1593-1598, 1801-1804) for d in [0, ins_n); the
@@ -41,15 +60,10 @@ struct PairedArgs {
   const double* covthr_tab;  // exp(c + k*2*L2) indexed by L2 (graph.cc:1855-1857 quirk), or null
   double two_T;              // 2 * total_len as double (graph.cc:1505)
   int n;                     // pairs in this shard
-  double* probs;             // out: per-pair summed probability (ScoringState::probs)
-  uint32_t* cov_bits;        // coverage marks (only when penalty_constant > 0), else null
   const int* path_base;      // bit offset of each path in cov_bits
   // class 0 (compact): slots [0, n0): 8-byte records, 1-byte length code, 8-byte occurrence entries
-  const unsigned long long* rec8[2];
   const unsigned char* len_code;
   const uint32_t* len_combo;
-  int n_codes;               // entries of len_combo / floor_c / logfloor_c (<= 256)
-  const Occ12* occ12[2];     // = m[mt].occ12
   // per length-combination tables of the compact path (host libm, indexed by len_code):
   const double* pe[2];       // [code*64 + e] = mismatch^e * match^(L-e)  (the product of graph.cc:1859-1863)
   const double* floor_c;     // [code] exp(c + k (L1+L2)); logfloor_c = log of it; covthr_c = exp(c + k 2 L2)
@@ -63,14 +77,13 @@ struct PairedArgs {
   //                                       host with the same division: the SAME decision as the reference, exactly)
   //   log(p)    =   log(t) - log(2T)     (within an ulp or two of log(fl(t / 2T)): ~1e-16 relative on the mean)
   // so a change of total_len costs two doubles per length code per call instead of a table rebuild. null: off
-  const double2* memo;
-  int lt_codes;              // codes covered (< lt_codes), edits < 7
+  int lt_codes;              // memo: codes covered (< lt_codes), edits < 7
   const double* tfloor_c;    // [code] per call: see above
-  double log_two_T;          // log(2T), host libm, per call
   const int4* inl[2];        // inline records of the register classes: [2t + k] (class 1), [2 n1 + 4 t2 + k] (class 2)
   int n0;                    // first[] / extra[] / len12[] hold slots >= n0, indexed slot - n0
-  int blocks0;               // blocks [0, blocks0): compact path; [blocks0, blocks01): <= 2 records; [blocks01, blocks012): <= 4;
-  int blocks01, blocks012;   // [blocks012, main_blocks): delta pairs (lane per pair)
+  // class 0 in two parts (PairTables::n0a): slots [0, n0a) carry a memo index that does not depend on the path set
+  // (static_idx, both records in one window), blocks [0, blocks0a); slots [n0a, n0) are resolved per call, blocks [blocks0a, blocks0)
+  const int* static_idx;
   int n01;                   // slots [n0, n01): class 1 (<= 2 records per mate); [n01, n_main): class 2 (<= 4)
   int n_main;                // the lane-per-pair paths score slots [0, n_main)
   // Pairs of the table classes with a record in a window that occurs several times (or whose occurrence does not
@@ -78,10 +91,8 @@ struct PairedArgs {
   // 64-bit ballot per wave and iteration (class-relative slot index; every word of a class is written by exactly
   // one wave, so nothing has to be zeroed); paired_general_kernel scores them in a second launch. Null when the
   // host saw no such window in this path set -- then neither the notes nor the second launch exist.
-  unsigned long long* gen_bits;
   unsigned long long* timeline;  // TL instantiation only: 8 wall-clock stamps (10 ns units) per wave of the grid
-  int gen_w1, gen_w2;        // first word of class 1 / class 2 (class 0 starts at word 0)
-  int main_blocks, total_blocks;  // grid sizes: partial slots [0, main_blocks) main, then overflow
+  int gen_w0b, gen_w1, gen_w2;  // first word of the second part of class 0 / class 1 / class 2 (class 0 starts at word 0)
   // Delta: pairs whose record lists changed since the device tables were built (newly activated
   // windows). Their slots carry a DIRTY mark in the tables; their complete record lists travel with
   // every evaluation and the overflow path scores them.
@@ -93,8 +104,6 @@ struct PairedArgs {
   const int4* spill_recs[2];
   const int* spill_slot;      // [n_spill] slot of the pair (scored one WAVE per pair, behind the table pairs with long lists)
   int n_spill;
-  double* part_sum;          // per-block partials: main kernel blocks, then overflow kernel blocks
-  int* part_zero;
   unsigned* ticket;          // zero before first launch; the last block resets it
   double* out;               // the read set's 4 partials {sum of logs, floored reads, bad_bases, reads}
   double n_reads;
@@ -512,24 +521,32 @@ __device__ __forceinline__ void compact_load(const PairedArgs& a, int i, bool ok
   c.lc = ok ? a.len_code[i] : 0;
 }
 
+// One part of class 0 and the blocks that score it: slots [lo, hi), `blocks` blocks of which this is number `lb`; the
+// part's notes for paired_general_kernel start at word gen_w.
+struct SlotRange { int lo, hi, lb, blocks, gen_w; };
+__device__ __forceinline__ SlotRange compact_range(const PairedArgs& a, int lb) {
+  return lb < a.blocks0a ? SlotRange{0, a.n0a, lb, a.blocks0a, 0} : SlotRange{a.n0a, a.n0, lb - a.blocks0a, a.blocks0 - a.blocks0a, a.gen_w0b};
+}
+
 template <bool GEN>
-__device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb, double& lsum, int& zeros) {
+__device__ __forceinline__ void paired_compact_body(const PairedArgs& a, const SlotRange rg, double& lsum, int& zeros) {
   // Class 0 in the general form (coverage marks to set, or no memo): two pairs per lane and iteration, software
   // pipelined -- the record loads of iteration k+1 are issued before iteration k's occurrence lookups and arithmetic.
-  const int stride = a.blocks0 * kBlock;
-  int i0 = lb * kBlock + threadIdx.x;
-  if (i0 >= a.n0) return;
+  const int stride = rg.blocks * kBlock, hi = rg.hi;
+  int i0 = rg.lo + rg.lb * kBlock + threadIdx.x;
+  if (i0 >= hi) return;
+  unsigned long long* const gen_bits = GEN ? a.gen_bits + rg.gen_w : nullptr;
   Compact1 c0, c1;
   compact_load(a, i0, true, c0);
-  compact_load(a, i0 + stride, i0 + stride < a.n0, c1);
+  compact_load(a, i0 + stride, i0 + stride < hi, c1);
   while (true) {
     const int i1 = i0 + stride;
-    const bool two = i1 < a.n0;
+    const bool two = i1 < hi;
     const int j0 = i0 + 2 * stride;
-    const bool more = j0 < a.n0;
+    const bool more = j0 < hi;
     Compact1 n0v, n1v;  // next iteration's records: issued now, consumed after this iteration's work
     compact_load(a, j0, more, n0v);
-    compact_load(a, j0 + stride, j0 + stride < a.n0, n1v);
+    compact_load(a, j0 + stride, j0 + stride < hi, n1v);
     const uint32_t l0 = a.len_combo[c0.lc], l1 = a.len_combo[c1.lc];
     c0.L1 = l0 & 0xffff; c0.L2 = l0 >> 16; c1.L1 = l1 & 0xffff; c1.L2 = l1 >> 16;
     const bool d0 = c0.r1 == kDirty8, d1 = c1.r1 == kDirty8;  // scored from the delta lists (paired_delta_body)
@@ -547,7 +564,7 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, int lb,
     const double2 m1 = q1.memo_idx >= 0 ? a.memo[q1.memo_idx] : make_double2(0.0, 0.0);
     if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
       const unsigned long long k0 = __ballot(q0.skip), k1 = __ballot(q1.skip);
-      if ((threadIdx.x & 63) == 0) { a.gen_bits[i0 >> 6] = k0; if (two) a.gen_bits[i1 >> 6] = k1; }
+      if ((threadIdx.x & 63) == 0) { gen_bits[(i0 - rg.lo) >> 6] = k0; if (two) gen_bits[(i1 - rg.lo) >> 6] = k1; }
     }
     if (!d0 && !q0.skip) compact_finish(a, i0, c0, q0, m0, lsum, zeros);
     if (two && !d1 && !q1.skip) compact_finish(a, i1, c1, q1, m1, lsum, zeros);
@@ -594,8 +611,9 @@ __device__ __forceinline__ int compact_state(const PairedArgs& a, uint2 r1, uint
 // ONE: every pair has the same length combination (n_codes == 1, the usual case): no length-code loads, no LDS tables --
 // the combination and its log-floor are two uniform values.
 template <bool GEN, bool TL = false, bool ONE = false>
-__device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb, double& lsum, int& zeros) {
-  const unsigned stride = (unsigned)a.blocks0 * kBlock, n0 = (unsigned)a.n0;
+__device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const SlotRange rg, double& lsum, int& zeros) {
+  const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;  // (n0: end of this part's slots)
+  unsigned long long* const gen_bits = GEN ? a.gen_bits + rg.gen_w : nullptr;
   unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
 #define GAML_STAMP(slot, dep) if (TL) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[slot] = (unsigned long long)wall_clock64() + ((dep) == 0x12345u ? 1 : 0); }
   // 32-bit byte offsets from uniform bases: one address register per load instead of a 64-bit add (tables < 4 GB)
@@ -607,7 +625,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
   char* const probs = (char*)a.probs;
   const uint32_t l12_one = ONE ? a.len_combo[0] : 0u;
   const double logfloor_one = ONE ? a.logfloor_c[0] : 0.0, tfloor_one = ONE ? a.tfloor_c[0] : 0.0, log2T = a.log_two_T;
-  for (unsigned base = (unsigned)lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
+  for (unsigned base = (unsigned)rg.lo + (unsigned)rg.lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
     uint2 r1[4], r2[4], o1[4], o2[4];
     unsigned lc[4];
 #pragma unroll
@@ -639,7 +657,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const unsigned long long w = __ballot((skip_bits >> k) & 1u);
-        if ((threadIdx.x & 63) == 0 && base + k * stride < n0) a.gen_bits[(base + k * stride) >> 6] = w;
+        if ((threadIdx.x & 63) == 0 && base + k * stride < n0) gen_bits[(base + k * stride - (unsigned)rg.lo) >> 6] = w;
       }
     }
     bool other = false;
@@ -679,6 +697,170 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, int lb
 #undef GAML_STAMP
 }
 
+// The first part of class 0 (slots [0, n0a), PairTables::static_idx): both records of a pair sit in the SAME window, so
+// the pair's memo index was computed when the tables were built. Stage by stage like paired_compact4_body, but ONE round
+// trip shorter: the records and the index come in together, then the occurrence entries AND the memo entries are requested
+// together -- the occurrence entries only decide whether the pair scores at all (both windows occur, once, at the same
+// place; position filter graph.cc:577). State between the stages: 1 scores (memo entry), 0 scores nothing (probability 0,
+// floored), 2 noted for paired_general_kernel, 3 nothing here (dirty slot, out of range), 4 the entries of the two
+// mates disagree about where the window sits (cannot happen; the block's partial is poisoned). An index < 0 marks a pair
+// with a mate that has no alignment: state 0 whatever the tables say.
+// Pairs, lanes and the order of additions are those of paired_compact_body over the same range.
+#ifndef GAML_LEAN_ENTRY
+#define GAML_LEAN_ENTRY 1
+#endif
+// A fresh, branch-local view of the kernel's argument block: re-read through a pointer the optimiser cannot see through
+// (kernel-argument segment, constant address space: scalar loads), so that a class's code fetches the words IT needs where
+// it runs instead of every wave fetching all ~150 at kernel entry (see paired_score_kernel).
+#if GAML_LEAN_ENTRY && defined(__HIP_DEVICE_COMPILE__)
+#define GAML_FRESH_ARGS(name, fallback)                                                                                   \
+  const __attribute__((address_space(4))) PairedArgs* name##_p =                                                          \
+      (const __attribute__((address_space(4))) PairedArgs*)__builtin_amdgcn_kernarg_segment_ptr();                        \
+  asm volatile("" : "+s"(name##_p));                                                                                      \
+  const PairedArgs name = *name##_p;
+#else
+#define GAML_FRESH_ARGS(name, fallback) const PairedArgs& name = fallback;
+#endif
+#ifndef GAML_STATIC_P
+#define GAML_STATIC_P 4
+#endif
+#ifndef GAML_STATIC_PIPE
+#define GAML_STATIC_PIPE 0
+#endif
+#ifndef GAML_STATIC_X  // timing experiments (results wrong): 1 no occurrence lookups, 2 no stores, 4 no value loads
+#define GAML_STATIC_X 0
+#endif
+// static_val[slot] = the memo entry {t, log t} of a static pair ({0, 0}: a mate without alignment -- floored like any
+// term below the threshold), copied out of the memo once per table build: the scoring launch then STREAMS the pair's
+// value with its records instead of gathering it. (A gather of 16 bytes per pair out of a 1 MB table moves a 128-byte
+// line from L2 per pair: 100 MB of line traffic per launch at BASELINE config 3 for 12 MB of values, ~3 us of the L1s'
+// fill bandwidth -- what kept the launch at 9 us whatever was done to its chain of dependent loads.)
+__global__ __launch_bounds__(kBlock) void static_values_kernel(const int* static_idx, int n0a, const double2* memo, double2* static_val) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n0a; i += gridDim.x * kBlock) {
+    const int mi = static_idx[i];
+    static_val[i] = mi >= 0 ? memo[mi] : make_double2(0.0, 0.0);
+  }
+}
+
+// Rounds of P pairs per lane, software-pipelined when a lane takes several: a round's occurrence entries are requested,
+// then the NEXT round's records and values, then the round is finished -- its arithmetic and stores run under the next
+// round's loads.
+template <bool GEN, bool TL = false, bool ONE = false>
+__device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const SlotRange rg, double& lsum, int& zeros) {
+  constexpr int P = GAML_STATIC_P;
+  const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;
+  unsigned long long* const gen_bits = GEN ? a.gen_bits + rg.gen_w : nullptr;
+  unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
+#define GAML_STAMP(slot, dep) if (TL && first_round) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[slot] = (unsigned long long)wall_clock64() + ((dep) == 0x12345u ? 1 : 0); }
+  const char* const rec0 = (const char*)a.rec8[0];
+  const char* const rec1 = (const char*)a.rec8[1];
+  const char* const sval = (const char*)a.static_val;
+  const char* const occ0 = (const char*)a.occ12[0];
+  const char* const occ1 = (const char*)a.occ12[1];
+  char* const probs = (char*)a.probs;
+  const double logfloor_one = ONE ? a.logfloor0 : 0.0, tfloor_one = ONE ? a.tfloor0 : 0.0, log2T = a.log_two_T;
+  unsigned base = (unsigned)rg.lo + (unsigned)rg.lb * kBlock + threadIdx.x;
+  if (base >= n0) return;
+  uint2 r1[P], r2[P];
+  double2 m[P];
+  unsigned lc[P];
+#pragma unroll
+  for (int k = 0; k < P; k++) {
+    const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
+    r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); m[k] = (GAML_STATIC_X & 4) ? make_double2(1e-9 * (double)ic, -20.0) : *(const double2*)(sval + ic * 16u);
+    lc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
+  }
+  bool first_round = true;
+  while (true) {
+    GAML_STAMP(2, r1[0].x ^ r2[0].x ^ (unsigned)__double2loint(m[0].x))
+    uint2 o1[P], o2[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) {  // (no record, or a dirty slot: entry 0, ignored; a mask, not a select: no branches here)
+      const unsigned w1 = (r1[k].x & 0xffffffu) & (0u - (unsigned)(r1[k].y != ~0u)), w2 = (r2[k].x & 0xffffffu) & (0u - (unsigned)(r2[k].y != ~0u));
+      const Occ12* e1 = (const Occ12*)(occ0 + w1 * 12u);
+      const Occ12* e2 = (const Occ12*)(occ1 + w2 * 12u);
+      o1[k] = make_uint2(e1->lo, e1->hi); o2[k] = make_uint2(e2->lo, e2->hi);
+      if (GAML_STATIC_X & 1) { o1[k] = make_uint2(r1[k].x >> 8, 0u); o2[k] = make_uint2(r1[k].x >> 8, 0u); }
+    }
+    // the next round's records (wave-uniform branch; a lane without a next round asks for its first slot again)
+    const unsigned nbase = base + P * stride;
+    const bool more = nbase < n0;
+    uint2 nr1[P], nr2[P];
+    double2 nm[P];
+    unsigned nlc[P];
+    if (GAML_STATIC_PIPE && __any(more)) {
+#pragma unroll
+      for (int k = 0; k < P; k++) {
+        const unsigned ic = nbase + k * stride < n0 ? nbase + k * stride : base;
+        nr1[k] = *(const uint2*)(rec0 + ic * 8u); nr2[k] = *(const uint2*)(rec1 + ic * 8u); nm[k] = *(const double2*)(sval + ic * 16u);
+        nlc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
+      }
+    }
+    GAML_STAMP(3, o1[0].x ^ o2[0].x)
+    unsigned st[P];
+    unsigned skip_bits = 0;
+#pragma unroll
+    for (int k = 0; k < P; k++) {
+      const bool none1 = r1[k].y == ~0u, none2 = r2[k].y == ~0u;          // no record (or, mate 1, the dirty mark)
+      const bool here = (base + k * stride < n0) & !(none1 & (r1[k].x == 0xfffffffeu));  // a pair, and not a dirty slot (those: paired_delta_body)
+      const bool w1 = !none1 & (o1[k].y != ~0u), w2 = !none2 & (o2[k].y != ~0u);  // a record whose window occurs in this path set
+      const bool gen = (w1 & ((int)o1[k].y < 0)) | (w2 & ((int)o2[k].y < 0));  // ... several times: general path (as compact_state: also
+                                                                               // when the other mate has no record -- which block counts the pair
+                                                                               // decides the last bit of the sum, and batches must agree with calls)
+      const bool same = (o1[k].x == o2[k].x) & (((o1[k].y ^ o2[k].y) >> 16) == 0);      // same shift, same path
+      const int p1 = (int)(__funnelshift_r(r1[k].x, r1[k].y, 24) & 0xfffffffu), p2 = (int)(__funnelshift_r(r2[k].x, r2[k].y, 24) & 0xfffffffu);
+      const bool kept = (p1 >= (int)(short)(o1[k].y & 0xffffu)) & (p2 >= (int)(short)(o2[k].y & 0xffffu));  // position filter (graph.cc:577)
+      const bool both = w1 & w2;
+      // a mate without alignment: scores nothing whatever the tables say (its lookups read entry 0)
+      st[k] = !here ? 3u : gen ? 2u : (none1 | none2) ? 0u : (both & !same) ? 4u : (both & kept) ? 1u : 0u;
+      skip_bits |= (unsigned)(st[k] == 2u) << k;
+    }
+    if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
+#pragma unroll
+      for (int k = 0; k < P; k++) {
+        const unsigned long long w = __ballot((skip_bits >> k) & 1u);
+        if ((threadIdx.x & 63) == 0 && base + k * stride < n0) gen_bits[(base + k * stride - (unsigned)rg.lo) >> 6] = w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < P; k++) {
+      double* const out = (double*)(probs + (base + k * stride) * 8u);
+      if (st[k] == 1u) {  // as compact_finish
+        if (!(GAML_STATIC_X & 2)) __builtin_nontemporal_store(m[k].x, out);
+        const bool floored = m[k].x < (ONE ? tfloor_one : a.tfloor_c[lc[k]]);
+        lsum += floored ? (ONE ? logfloor_one : a.logfloor_c[lc[k]]) : m[k].y - log2T;
+        zeros += (int)floored;
+      } else if (st[k] == 0u) {  // as finish_read_compact(acc = 0)
+        if (!(GAML_STATIC_X & 2)) __builtin_nontemporal_store(0.0, out);
+        zeros++;
+        lsum += ONE ? logfloor_one : a.logfloor_c[lc[k]];
+      } else if (st[k] == 4u) {
+        // Cannot happen: both mates register the same walks under the same rules, a walk's occurrences depend on the
+        // path set alone, and a pair is only here when its two windows are linked (link_mate_windows). No second code
+        // path for it (its registers would be every wave's): the block's partial is poisoned instead, and the host
+        // reports GAML_HIP_ESTATE rather than a likelihood (combine()).
+        lsum += __builtin_nan("");
+      }
+    }
+    GAML_STAMP(5, 0u)
+    first_round = false;
+    if (!more) break;
+    base = nbase;
+    if (GAML_STATIC_PIPE) {
+#pragma unroll
+      for (int k = 0; k < P; k++) { r1[k] = nr1[k]; r2[k] = nr2[k]; m[k] = nm[k]; lc[k] = nlc[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < P; k++) {
+        const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
+        r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); m[k] = (GAML_STATIC_X & 4) ? make_double2(1e-9 * (double)ic, -20.0) : *(const double2*)(sval + ic * 16u);
+        lc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
+      }
+    }
+  }
+#undef GAML_STAMP
+}
+
 // up to K live candidates per mate in registers -> per-read probability, floor / log, running sums
 template <int K>
 __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int i, uint32_t l12, const RegCands<K>& x, const RegCands<K>& y,
@@ -696,9 +878,12 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
         if (x.live[k]) { n1++; q.x.path = x.path[k]; q.x.pos = x.pos[k]; q.x.edit = x.ef[k] & 0xff; q.x.orient = x.ef[k] >> 8; }
         if (y.live[k]) { n2++; q.y.path = y.path[k]; q.y.pos = y.pos[k]; q.y.edit = y.ef[k] & 0xff; q.y.orient = y.ef[k] >> 8; }
       }
-      int code = -1;
+      // the pair's length code: combination 0 travels by value (the usual set has one), the others are looked up
+      int code = (a.lt_codes > 0 && l12 == a.len_combo0) ? 0 : -1;
+      if (code < 0 && a.n_codes > 1) {
 #pragma unroll
-      for (int k = 3; k >= 0; k--) if (k < a.lt_codes && a.len_combo[k] == l12) code = k;
+        for (int k = 3; k >= 1; k--) if (k < a.lt_codes && a.len_combo[k] == l12) code = k;
+      }
       if (n1 == 1 && n2 == 1 && q.x.path == q.y.path && code >= 0 && q.x.orient != q.y.orient && q.x.edit < 7 && q.y.edit < 7) {
         const bool fwd = q.x.pos < q.y.pos;  // orientation rule and insert distance (graph.cc:1864-1876)
         const bool ok = fwd ? (q.x.orient == 0) : (q.x.orient == 1);
@@ -709,7 +894,7 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
           q.memo_idx = ((code * 7 + q.x.edit) * 7 + q.y.edit) * a.ins_n + dist;
           // the two per-code values are requested WITH the memo entry, not behind the store that needs it (the store may
           // alias them for all the compiler knows: they were a round trip of their own at the end of every such wave)
-          const double tfl = a.tfloor_c[code], lfl = a.logfloor_c[code];
+          const double tfl = code == 0 ? a.tfloor0 : a.tfloor_c[code], lfl = code == 0 ? a.logfloor0 : a.logfloor_c[code];
           const double2 m = a.memo[q.memo_idx];
           if (cap) *cap = PairVal{m.x, m.y, code, 1};
           compact_cover(a, c, q, m.x);
@@ -811,35 +996,52 @@ __global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const DeltaPa
 // TL: the in-kernel timeline of tools/kernel_timeline.py (a separate instantiation: the product kernels carry none of it)
 template <bool TICKET, bool GEN, bool TL>
 __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z) {
+  // `a`: the argument block as the kernel received it; only its leading words (grid layout, partial slots) are read
+  // here -- every class takes a fresh view of its own (GAML_FRESH_ARGS)
   double lsum = 0.0;
   int zeros = 0;
   unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
   if (TL && (threadIdx.x & 63) == 0) { tl[0] = wall_clock64(); tl[7] = lb < a.blocks0 ? 0 : (lb < a.blocks01 ? 1 : 2); }
-  if (lb < a.blocks0) {
-    const bool wide = a.memo && !a.cov_bits;  // block-uniform: memo present, no coverage marks to set
-    if (!TL && wide && a.n_codes == 1) {
-      paired_compact4_body<GEN, false, true>(a, lb, lsum, zeros);  // one length combination: no tables, no barrier
+  if ((GAML_STATIC_X & 8) && lb >= a.blocks0a) {  // timing experiment: only the static part of class 0 does anything
+  } else if ((GAML_STATIC_X & 16) && lb < a.blocks0a) {  // ... or everything but it
+  } else if (lb < a.blocks0) {
+    GAML_FRESH_ARGS(c, a)
+    const bool wide = c.memo && !c.cov_bits;  // block-uniform: memo present, no coverage marks to set
+    const SlotRange rg = compact_range(c, lb);
+    const bool stat = wide && lb < c.blocks0a;  // the part of class 0 whose memo indices came with the tables
+    if (!TL && wide && c.n_codes == 1) {  // one length combination: no tables, no barrier
+      if (stat) paired_static4_body<GEN, false, true>(c, rg, lsum, zeros);
+      else paired_compact4_body<GEN, false, true>(c, rg, lsum, zeros);
     } else {
       // the per-length-combination tables of the compact class (<= 256 entries each) are looked up once or twice
       // per pair, each time behind another load: from LDS they cost an LDS access instead of an L2 round trip
       __shared__ uint32_t sh_combo[256];
       __shared__ double sh_floor[256], sh_logfloor[256], sh_tfloor[256];
-      for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_floor[k] = a.floor_c[k]; sh_logfloor[k] = a.logfloor_c[k]; sh_tfloor[k] = a.tfloor_c ? a.tfloor_c[k] : 0.0; }
+      for (int k = threadIdx.x; k < c.n_codes; k += kBlock) { sh_combo[k] = c.len_combo[k]; sh_floor[k] = c.floor_c[k]; sh_logfloor[k] = c.logfloor_c[k]; sh_tfloor[k] = c.tfloor_c ? c.tfloor_c[k] : 0.0; }
       __syncthreads();
-      PairedArgs b = a;
+      PairedArgs b = c;
       b.len_combo = sh_combo; b.floor_c = sh_floor; b.logfloor_c = sh_logfloor; b.tfloor_c = sh_tfloor;
       if (TL && (threadIdx.x & 63) == 0) tl[1] = wall_clock64();
-      if (wide) paired_compact4_body<GEN, TL>(b, lb, lsum, zeros);
-      else paired_compact_body<GEN>(b, lb, lsum, zeros);
+      if (stat) paired_static4_body<GEN, TL>(b, rg, lsum, zeros);
+      else if (wide) paired_compact4_body<GEN, TL>(b, rg, lsum, zeros);
+      else paired_compact_body<GEN>(b, rg, lsum, zeros);
     }
-  } else if (lb < a.blocks01) paired_regs_body<2, GEN>(a, lb, a.n0, a.n01, a.blocks0, a.blocks01, lsum, zeros, tl);
-  else if (lb < a.blocks012) paired_regs_body<4, GEN>(a, lb, a.n01, a.n_main, a.blocks01, a.blocks012, lsum, zeros);
-  else paired_delta_body(a, lb - a.blocks012, a.main_blocks - a.blocks012, lsum, zeros);
+  } else if (lb < a.blocks01) {
+    GAML_FRESH_ARGS(c, a)
+    paired_regs_body<2, GEN>(c, lb, c.n0, c.n01, c.blocks0, c.blocks01, lsum, zeros, tl);
+  } else if (lb < a.blocks012) {
+    GAML_FRESH_ARGS(c, a)
+    paired_regs_body<4, GEN>(c, lb, c.n01, c.n_main, c.blocks01, c.blocks012, lsum, zeros);
+  } else {
+    GAML_FRESH_ARGS(c, a)
+    paired_delta_body(c, lb - c.blocks012, c.main_blocks - c.blocks012, lsum, zeros);
+  }
   block_reduce(lsum, zeros, sh_s, sh_z);
   if (TL && (threadIdx.x & 63) == 0) tl[6] = wall_clock64();
   if (TICKET) {
-    grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out,
-                a.cov_bits ? -1.0 : 0.0, a.n_reads, sh_s, sh_z);
+    GAML_FRESH_ARGS(c, a)
+    grid_finish(lsum, zeros, lb, c.total_blocks, c.part_sum, c.part_zero, c.ticket, c.out,
+                c.cov_bits ? -1.0 : 0.0, c.n_reads, sh_s, sh_z);
   } else if (threadIdx.x == 0) {
     a.part_sum[lb] = lsum;
     a.part_zero[lb] = zeros;
@@ -1000,8 +1202,30 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_kernel(PairedArgs a) {
   // REVERSE dispatch order so that the few long-latency blocks (overflow, multi-record classes)
   // start first and hide under the compact stream instead of forming a tail.
   const int lb = a.total_blocks - 1 - (int)blockIdx.x;
+#if GAML_LEAN_ENTRY && defined(__HIP_DEVICE_COMPILE__)
+  // The argument block is ~600 bytes. Left to itself the compiler fetches ALL of it at kernel entry -- more than the
+  // scalar registers hold, so in six dependent fetch-wait-spill rounds (~90 v_writelane) before any wave can request
+  // its first record -- although the blocks that score nearly all pairs (static part of the compact class, one length
+  // combination) need two dozen of its words. Those blocks read `a` directly (its leading words: PairedArgs); every other
+  // class takes a fresh view of the block where its code starts (GAML_FRESH_ARGS).
+  if (!TL && lb < a.blocks0a && a.memo && !a.cov_bits && a.n_codes == 1) {
+    double lsum = 0.0;
+    int zeros = 0;
+    paired_static4_body<GEN, false, true>(a, SlotRange{0, a.n0a, lb, a.blocks0a, 0}, lsum, zeros);
+    block_reduce(lsum, zeros, sh_s, sh_z);
+    if (TICKET) grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out, 0.0, a.n_reads, sh_s, sh_z);
+    else if (threadIdx.x == 0) { a.part_sum[lb] = lsum; a.part_zero[lb] = zeros; }
+    return;
+  }
+  if (lb < a.main_blocks) paired_main_body<TICKET, GEN, TL>(a, lb, sh_s, sh_z);
+  else {
+    GAML_FRESH_ARGS(c, a)
+    paired_overflow_body<TICKET>(c, lb - c.main_blocks, c.total_blocks - c.main_blocks, sh_s, sh_z, cand);
+  }
+#else
   if (lb < a.main_blocks) paired_main_body<TICKET, GEN, TL>(a, lb, sh_s, sh_z);
   else paired_overflow_body<TICKET>(a, lb - a.main_blocks, a.total_blocks - a.main_blocks, sh_s, sh_z, cand);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1020,6 +1244,7 @@ struct SetDev {  // what differs between the path sets of one batch
   const int* multi_off[2];
   const int4* multi[2];
   const double* tfloor_c;          // [code] for this set's 2T
+  double tfloor0;                  // = tfloor_c[0], by value
   double two_T, log_two_T;
   unsigned long long* gen_bits;    // this set's notes for paired_general_kernel (GEN instantiation)
   double* part_sum;                // this set's per-block partials
@@ -1038,7 +1263,7 @@ __device__ __forceinline__ PairedArgs with_set(const PairedArgs& a, const SetDev
   PairedArgs b = a;
 #pragma unroll
   for (int mt = 0; mt < 2; mt++) { b.m[mt].occ12 = sd.occ12[mt]; b.occ12[mt] = sd.occ12[mt]; b.m[mt].multi_off = sd.multi_off[mt]; b.m[mt].multi = sd.multi[mt]; }
-  b.tfloor_c = tfloor_lds ? tfloor_lds : sd.tfloor_c; b.two_T = sd.two_T; b.log_two_T = sd.log_two_T; b.gen_bits = sd.gen_bits;
+  b.tfloor_c = tfloor_lds ? tfloor_lds : sd.tfloor_c; b.tfloor0 = sd.tfloor0; b.two_T = sd.two_T; b.log_two_T = sd.log_two_T; b.gen_bits = sd.gen_bits;
   b.part_sum = sd.part_sum; b.part_zero = sd.part_zero;
   return b;
 }
@@ -1046,15 +1271,15 @@ __device__ __forceinline__ PairedArgs with_set(const PairedArgs& a, const SetDev
 // paired_compact4_body with the path sets in the inner loop. acc_s / acc_z: one running sum per (set, thread) in LDS
 // (a lane may take several rounds of four pairs; registers cannot be indexed by the set number).
 template <bool GEN, bool ONE>
-__device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, const MultiSets& ms, int lb, double* acc_s, int* acc_z, const double* tf) {
-  const unsigned stride = (unsigned)a.blocks0 * kBlock, n0 = (unsigned)a.n0;
+__device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, const MultiSets& ms, const SlotRange rg, double* acc_s, int* acc_z, const double* tf) {
+  const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;  // (n0: end of this part's slots)
   const char* const rec0 = (const char*)a.rec8[0];
   const char* const rec1 = (const char*)a.rec8[1];
   const char* const memo = (const char*)a.memo;
   char* const probs = (char*)a.probs;
   const uint32_t l12_one = ONE ? a.len_combo[0] : 0u;
   const double logfloor_one = ONE ? a.logfloor_c[0] : 0.0;
-  for (unsigned base = (unsigned)lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
+  for (unsigned base = (unsigned)rg.lo + (unsigned)rg.lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
     uint2 r1[4], r2[4];
     unsigned lc[4];
 #pragma unroll
@@ -1096,7 +1321,7 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const unsigned long long w = __ballot((skip_bits >> k) & 1u);
-          if ((threadIdx.x & 63) == 0 && base + k * stride < n0) sd.gen_bits[(base + k * stride) >> 6] = w;
+          if ((threadIdx.x & 63) == 0 && base + k * stride < n0) sd.gen_bits[rg.gen_w + ((base + k * stride - (unsigned)rg.lo) >> 6)] = w;
         }
       }
       double lsum = 0.0;
@@ -1314,7 +1539,10 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArg
       return;
     }
     if (lb < a.blocks0) {
-      if (a.n_codes == 1) paired_compact4_multi_body<GEN, true>(a, ms, lb, acc_s, acc_z, tf);
+      // (both parts of class 0 resolve every pair per set here: the lanes, pairs and order of additions are the single-set
+      // kernel's, and so are the values -- a static memo index is the index the per-call arithmetic arrives at)
+      const SlotRange rg = compact_range(a, lb);
+      if (a.n_codes == 1) paired_compact4_multi_body<GEN, true>(a, ms, rg, acc_s, acc_z, tf);
       else {
         __shared__ uint32_t sh_combo[256];
         __shared__ double sh_logfloor[256];
@@ -1322,7 +1550,7 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArg
         __syncthreads();
         PairedArgs b = a;
         b.len_combo = sh_combo; b.logfloor_c = sh_logfloor;
-        paired_compact4_multi_body<GEN, false>(b, ms, lb, acc_s, acc_z, tf);
+        paired_compact4_multi_body<GEN, false>(b, ms, rg, acc_s, acc_z, tf);
       }
     } else if (lb < a.blocks01) paired_regs_multi_body<2, GEN>(a, ms, lb, a.n0, a.n01, a.blocks0, a.blocks01, acc_s, acc_z, tf);
     else if (lb < a.blocks012) paired_regs_multi_body<4, GEN>(a, ms, lb, a.n01, a.n_main, a.blocks01, a.blocks012, acc_s, acc_z, tf);
@@ -1366,8 +1594,9 @@ __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, in
   int zeros = 0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_main; i += gridDim.x * kBlock) {
     const int cls = i < a.n0 ? 0 : (i < a.n01 ? 1 : 2);
-    const int rel = cls == 0 ? i : (cls == 1 ? i - a.n0 : i - a.n01);
-    const unsigned long long word = a.gen_bits[(cls == 0 ? 0 : (cls == 1 ? a.gen_w1 : a.gen_w2)) + (rel >> 6)];
+    const bool part_b = i >= a.n0a;  // class 0, second part (its notes start at a word of their own)
+    const int rel = cls == 0 ? (part_b ? i - a.n0a : i) : (cls == 1 ? i - a.n0 : i - a.n01);
+    const unsigned long long word = a.gen_bits[(cls == 0 ? (part_b ? a.gen_w0b : 0) : (cls == 1 ? a.gen_w1 : a.gen_w2)) + (rel >> 6)];
     if (!((word >> (rel & 63)) & 1ull)) continue;
     if (cls == 0) compact_general(a, i, lsum, zeros);
     else {

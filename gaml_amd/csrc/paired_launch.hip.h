@@ -13,8 +13,9 @@
 
 namespace {
 
-int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
-  if (s.tabs_uploaded) return 0;
+// the host half of prepare_paired_tables: insert-size / floor tables (host libm); needs no device
+int paired_host_tabs(gaml_hip_ctx* c, PairedSet& s) {
+  if (!s.ins_tab.empty() || !s.floor_tab.empty()) return 0;
   const double c0 = s.cfg.min_prob_start, k0 = s.cfg.min_prob_per_base;
   // The reference tabulates GetInsertProbability for d < mean + 5 sd (graph.cc:1801-1804) and calls
   // the same function directly beyond (:1877-1882). Same formula, so one host table serves both;
@@ -43,6 +44,12 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
   }
   s.covthr_tab.resize(s.mate[1].max_len + 1);
   for (int v = 0; v <= s.mate[1].max_len; v++) s.covthr_tab[v] = std::exp(c0 + k0 * (v + v));  // graph.cc:1855-1857
+  return 0;
+}
+
+int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
+  if (s.tabs_uploaded) return 0;
+  if (int e = paired_host_tabs(c, s)) return e;
   size_t total = s.ins_tab.size() + s.floor_tab.size() + s.logfloor_tab.size() + s.covthr_tab.size();
   HIP_TRY(c, s.tabs.reserve(std::max<size_t>(1, total) * sizeof(double)));
   double* d = s.tabs.as<double>();
@@ -232,6 +239,7 @@ int paired_upload_tables(gaml_hip_ctx* c, PairedSet& s, const PairTables& pt, Ta
     UP_TRY(up(T.extra[mt], pt.rm[mt].extra.data(), pt.rm[mt].extra.size() * sizeof(RecQuad)));
     UP_TRY(up(T.inl[mt], pt.inl[mt].data(), pt.inl[mt].size() * sizeof(RecQuad)));
   }
+  UP_TRY(up(T.static_idx, pt.static_idx.data(), pt.static_idx.size() * sizeof(int32_t)));
   UP_TRY(up(T.len_code, pt.len_code.data(), pt.len_code.size()));
   UP_TRY(up(T.len_combo, pt.len_combo.data(), pt.len_combo.size() * sizeof(uint32_t)));
   UP_TRY(up(T.len12, pt.len12.data(), pt.len12.size() * sizeof(uint32_t)));
@@ -251,17 +259,24 @@ int paired_upload_tables(gaml_hip_ctx* c, PairedSet& s, const PairTables& pt, Ta
   // memo of the pair terms a single-term pair can take (first 4 length combinations, edits < 7, every tabulated distance)
   T.memo_codes = 0;
   if (c->knobs[4] == 0 && s.floor_positive && !pt.len_combo.empty() && !s.ins_tab.empty()) {
-    const int codes = (int)std::min<size_t>(pt.len_combo.size(), 4);
+    const int codes = (int)std::min<size_t>(pt.len_combo.size(), kMemoCodes);
     const size_t entries = (size_t)codes * 49 * s.ins_tab.size();
-    if (entries <= ((size_t)1 << 24)) {
+    if (entries <= kMemoMaxEntries) {  // (the same bound build_pair_tables applies to its static indices)
       UP_TRY(T.memo.reserve(entries * sizeof(double2)));
       const double* ct = T.combo_tabs.as<double>();
       hipLaunchKernelGGL(logterm_kernel, dim3((unsigned)std::min<size_t>((entries + kBlock - 1) / kBlock, 1024)), dim3(kBlock), 0, st,
                          ct, ct + nc * 64, s.tabs.as<double>(), (int)s.ins_tab.size(), codes, T.memo.as<double2>());
       UP_TRY(hipGetLastError());
       T.memo_codes = codes;
+      if (pt.n0a > 0) {  // the static pairs' entries, streamed with their records from here on
+        UP_TRY(T.static_val.reserve((size_t)pt.n0a * sizeof(double2)));
+        hipLaunchKernelGGL(static_values_kernel, dim3((unsigned)std::min<int64_t>((pt.n0a + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0, st,
+                           T.static_idx.as<int>(), (int)pt.n0a, T.memo.as<double2>(), T.static_val.as<double2>());
+        UP_TRY(hipGetLastError());
+      }
     }
   }
+  if (pt.n0a > 0 && T.memo_codes == 0) return bad("record tables carry static memo indices but the memo is off", hipErrorInvalidValue);
 #undef UP_TRY
   return 0;
 }
@@ -301,13 +316,20 @@ void paired_retire_windows(gaml_hip_ctx* c, PairedSet& s) {
   s.planner.note_rebuild(n > 0);
 }
 
+// the table length the static memo indices of class 0 are built over (PairTables::static_idx), 0: none -- no memo
+// (knob 4, or a floor of 0: the reference then takes log(0)), or knob 19 = 1 (A/B: every class-0 pair resolved per call)
+int paired_static_ins_n(const gaml_hip_ctx* c, const PairedSet& s) {
+  return (c->knobs[4] == 0 && c->knobs[19] == 0 && s.floor_positive) ? (int)s.ins_tab.size() : 0;
+}
+
 int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   paired_reset_delta(s);
   s.full_rebuilds++;
   paired_retire_windows(c, s);
   for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
   const double tb0 = now_us();
-  build_pair_tables(s.mate[0], s.mate[1], s.pt, c->knobs[16] != 1);
+  link_mate_windows(s.mate[0], s.mate[1]);
+  build_pair_tables(s.mate[0], s.mate[1], s.pt, c->knobs[16] != 1, paired_static_ins_n(c, s));
   s.built_keep_dominated = c->knobs[16] == 1;
   const double tb1 = now_us();
   HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old tables
@@ -370,7 +392,7 @@ void paired_launch_worker(gaml_hip_ctx* c, PairedSet& s) {
     rb.sh_dirty.clear();  // the lists of the tables before last (swapped out at the previous take-over): emptied here, off the caller's thread
     if (!rc) {
       rb.keep_dominated = c->knobs[16] == 1;
-      build_pair_tables(rb.snap[0], rb.snap[1], rb.pt, !rb.keep_dominated);
+      build_pair_tables(rb.snap[0], rb.snap[1], rb.pt, !rb.keep_dominated, rb.static_ins_n);
       rc = paired_upload_tables(c, s, rb.pt, rb.tab, rb.stream, &rb.err);
       if (!rc && hipStreamSynchronize(rb.stream) != hipSuccess) { rc = GAML_HIP_EHIP; rb.err = "stream synchronise failed in the rebuild worker"; }
     }
@@ -396,6 +418,8 @@ int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s) {
   const double t0 = now_us();
   if (rb.th.joinable()) rb.th.join();
   paired_retire_windows(c, s);
+  link_mate_windows(s.mate[0], s.mate[1]);  // (the snapshot's window headers carry the links)
+  rb.static_ins_n = paired_static_ins_n(c, s);
   const double t1 = now_us();
   for (int mt = 0; mt < 2; mt++) {
     paired_snapshot_begin(s.mate[mt], rb.snap[mt]);
@@ -834,6 +858,12 @@ int paired_persist_update(gaml_hip_ctx* c, PairedSet& s, double two_T, hipStream
   return 0;
 }
 
+// tfloor_c[0] for this 2T, by value in the kernel arguments (what paired_pack_thresholds writes for length combination 0)
+double paired_tfloor0(const PairedSet& s, double two_T) {
+  if (s.pt.len_combo.empty()) return 0.0;
+  return tfloor_for(s.floor_tab[(s.pt.len_combo[0] & 0xffff) + (s.pt.len_combo[0] >> 16)], two_T);
+}
+
 void paired_persist_view(const PairedSet& s, int32_t total_len, SetDev& sd) {
   const PairedSet::Persist& P = s.persist;
   const char* base = (const char*)P.dev;
@@ -845,6 +875,7 @@ void paired_persist_view(const PairedSet& s, int32_t total_len, SetDev& sd) {
   sd.tfloor_c = (const double*)(base + P.off_tfloor);
   const int tl = total_len == 0 ? 1 : total_len;
   sd.two_T = (double)(2 * tl);
+  sd.tfloor0 = paired_tfloor0(s, sd.two_T);
   sd.log_two_T = std::log(sd.two_T);
   sd.gen_bits = nullptr; sd.part_sum = nullptr; sd.part_zero = nullptr;
 }
@@ -852,7 +883,7 @@ void paired_persist_view(const PairedSet& s, int32_t total_len, SetDev& sd) {
 // ---------------------------------------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------------------------------------
-struct GridPlan { int blocks0, blocks1, blocks2, blocks_d, main_blocks, ovf_blocks, total_blocks, gen_blocks; int64_t gen_words[3]; };
+struct GridPlan { int blocks0a, blocks0, blocks1, blocks2, blocks_d, main_blocks, ovf_blocks, total_blocks, gen_blocks; int64_t gen_words[3]; };
 
 // what every path set of a launch shares: record tables, length tables, memo, classes, grid
 void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp) {
@@ -881,12 +912,18 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   a.ticket = s.red.ticket.as<unsigned>();
   const int64_t n0 = s.pt.class_count[0], n01 = n0 + s.pt.class_count[1], n_main = n01 + s.pt.class_count[2];
   a.n0 = (int)n0; a.n01 = (int)n01; a.n_main = (int)n_main;
+  const int64_t n0a = s.pt.n0a, n0b = n0 - n0a;
+  a.n0a = (int)n0a;
+  a.static_idx = s.tab.static_idx.as<int>();
+  a.static_val = s.tab.static_val.as<double2>();
   const size_t nc = std::max<size_t>(1, s.pt.len_combo.size());
   const double* ct = s.tab.combo_tabs.as<double>();
   a.pe[0] = ct; a.pe[1] = ct + nc * 64; a.floor_c = ct + 2 * nc * 64; a.logfloor_c = a.floor_c + nc; a.covthr_c = a.logfloor_c + nc;
   a.len_code = s.tab.len_code.as<unsigned char>();
   a.len_combo = s.tab.len_combo.as<uint32_t>();
   a.n_codes = (int)std::min<size_t>(256, s.pt.len_combo.size());
+  a.len_combo0 = s.pt.len_combo.empty() ? 0xffffffffu : s.pt.len_combo[0];
+  a.logfloor0 = s.pt.len_combo.empty() ? 0.0 : s.logfloor_tab[(s.pt.len_combo[0] & 0xffff) + (s.pt.len_combo[0] >> 16)];  // = logfloor_c[0], by value
   a.memo = s.tab.memo_codes > 0 ? s.tab.memo.as<double2>() : nullptr;
   a.lt_codes = s.tab.memo_codes;
   const size_t nd = s.dirty.size();
@@ -899,10 +936,15 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   // 3 blocks per CU and one round of four pairs per lane at cfg3 (tools/kbench.py sweep); larger sets get more blocks, up to 8 per CU
   // A second round for a few lanes doubles the launch (every block is resident: the launch lasts as long as its longest
   // lane): up to 5 blocks per CU the compact class gets exactly the blocks one round needs.
-  const int64_t one_round = (n0 + 4 * kBlock - 1) / (4 * kBlock);
+  // The two parts of class 0 get blocks of their own (PairedArgs::blocks0a): the first by the rule above; the second --
+  // a few per cent of the pairs, one more round trip per pair -- a lane per pair up to a third of that.
+  const int64_t one_round = (n0a + 4 * kBlock - 1) / (4 * kBlock);
   const int cap0 = c->knobs[0] > 0 ? c->knobs[0]
                                    : (int)std::min<int64_t>(kMaxBlocks, one_round > 768 && one_round <= 1280 ? one_round : std::max<int64_t>(768, n0 / 2900));
-  gp.blocks0 = (int)std::max<int64_t>(1, std::min<int64_t>((n0 + 2 * kBlock - 1) / (2 * kBlock), cap0));
+  gp.blocks0a = n0a > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>((n0a + 2 * kBlock - 1) / (2 * kBlock), cap0)) : 0;
+  const int cap0b = c->knobs[20] > 0 ? c->knobs[20] : std::max(1, n0a > 0 ? cap0 / 3 : cap0);
+  const int64_t blocks0b = n0b > 0 ? std::max<int64_t>(1, std::min<int64_t>(n0a > 0 ? (n0b + kBlock - 1) / kBlock : (n0b + 2 * kBlock - 1) / (2 * kBlock), cap0b)) : 0;
+  gp.blocks0 = (int)std::max<int64_t>(1, gp.blocks0a + blocks0b);
   // the 2-record class: a third of the compact class's blocks (one block per CU at cfg3), lanes take 1-2 pairs; more
   // blocks only crowd the compact class out (tools/blocks_sweep.py at cfg3, pairs ordered by window in every class:
   // 128 blocks 11.4 us, 192: 10.1, 224-256: 9.8-9.9, 320: 10.2)
@@ -914,8 +956,10 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   gp.main_blocks = gp.blocks0 + gp.blocks1 + gp.blocks2 + gp.blocks_d;
   gp.ovf_blocks = ovf_total > 0 ? (int)std::min<int64_t>((ovf_total + 3) / 4, kOvfMaxBlocks) : 0;
   gp.total_blocks = gp.main_blocks + gp.ovf_blocks;
-  gp.gen_words[0] = (n0 + 63) / 64; gp.gen_words[1] = (n01 - n0 + 63) / 64; gp.gen_words[2] = (n_main - n01 + 63) / 64;
+  gp.gen_words[0] = (n0a + 63) / 64 + (n0b + 63) / 64; gp.gen_words[1] = (n01 - n0 + 63) / 64; gp.gen_words[2] = (n_main - n01 + 63) / 64;
   gp.gen_blocks = n_main > 0 ? (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, kMaxBlocks) : 0;
+  a.blocks0a = gp.blocks0a;
+  a.gen_w0b = (int)((n0a + 63) / 64);
   a.blocks0 = gp.blocks0;
   a.blocks01 = gp.blocks0 + gp.blocks1;
   a.blocks012 = gp.blocks0 + gp.blocks1 + gp.blocks2;
@@ -925,7 +969,7 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
 }
 
 // what one path set changes: its occurrence tables inside `arena`, 2T and the thresholds that follow from it
-void paired_set_view(const PairedLayout& L, const char* arena, int32_t total_len, SetDev& sd) {
+void paired_set_view(const PairedSet& s, const PairedLayout& L, const char* arena, int32_t total_len, SetDev& sd) {
   const OccLayout* l[2] = {&L.l0, &L.l1};
   for (int mt = 0; mt < 2; mt++) {
     sd.occ12[mt] = (const Occ12*)(arena + l[mt]->direct);
@@ -935,13 +979,14 @@ void paired_set_view(const PairedLayout& L, const char* arena, int32_t total_len
   sd.tfloor_c = (const double*)(arena + L.tfloor_off);
   const int tl = total_len == 0 ? 1 : total_len;  // graph.cc:1500-1502
   sd.two_T = (double)(2 * tl);
+  sd.tfloor0 = paired_tfloor0(s, sd.two_T);
   sd.log_two_T = std::log(sd.two_T);
   sd.gen_bits = nullptr; sd.part_sum = nullptr; sd.part_zero = nullptr;
 }
 
 void paired_apply_set(PairedArgs& a, const SetDev& sd) {
   for (int mt = 0; mt < 2; mt++) { a.m[mt].occ12 = sd.occ12[mt]; a.m[mt].occ = nullptr; a.occ12[mt] = sd.occ12[mt]; a.m[mt].multi_off = sd.multi_off[mt]; a.m[mt].multi = sd.multi[mt]; }
-  a.tfloor_c = sd.tfloor_c; a.two_T = sd.two_T; a.log_two_T = sd.log_two_T;
+  a.tfloor_c = sd.tfloor_c; a.tfloor0 = sd.tfloor0; a.two_T = sd.two_T; a.log_two_T = sd.log_two_T;
   a.gen_bits = sd.gen_bits; a.part_sum = sd.part_sum; a.part_zero = sd.part_zero;
 }
 
@@ -1014,7 +1059,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
     paired_pack_thresholds(s, L, (double)(2 * tl), wp);
     if (int e = arena_commit(c, s.arena, slot, L.total, st)) return e;
     arena = (const char*)s.arena.dev[slot];
-    paired_set_view(L, arena, total_len, sd);
+    paired_set_view(s, L, arena, total_len, sd);
     c->prof[6] = (double)L.total;
   }
   const double tp2 = now_us();
@@ -1154,7 +1199,7 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, co
   if (chg && c->knobs[11] < 64) { ms.chg[0] = chg[0]; ms.chg[1] = chg[1]; }  // (>= 64: and every set resolves every pair)  // (which table entries differ between the sets: only a batch built from patches knows)
   for (int k = 0; k < n_sets; k++) {
     const int g = first + k;  // the set's number in the batch
-    paired_set_view(L[g], arena + (size_t)g * stride, total_lens[g], ms.set[k]);
+    paired_set_view(s, L[g], arena + (size_t)g * stride, total_lens[g], ms.set[k]);
     ms.set[k].part_sum = d_sum + (size_t)g * s.host_part_stride;
     ms.set[k].part_zero = d_zero + (size_t)g * s.host_part_stride;
     if (any_general) ms.set[k].gen_bits = (unsigned long long*)((char*)s.gen_bits.p + (size_t)g * gen_bytes);

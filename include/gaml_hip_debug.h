@@ -50,7 +50,8 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int
  * done by the worker thread (of the full rebuilds), gaml_hip_calc_prob_batch chunks whose per-set tables were built on
  * the device from patches, chunks whose tables were written whole, records of mate 1 / mate 2 that the current tables
  * leave out because another record of the same read always overwrites them (knob 16), such records of windows that
- * joined later and therefore never reached the delta lists (since creation), 0}.
+ * joined later and therefore never reached the delta lists (since creation), pairs of the compact class whose memo index
+ * came with the tables (both records in one window: PairedArgs::static_idx)}.
  * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables); knob 14 = 1 keeps every
  * rebuild on the calling thread, knob 14 = k > 1 lets a worker's tables take over k evaluations after its start
  * (default 1152); knob 15 = 1: rebuilds never retire unused windows. */
@@ -72,7 +73,9 @@ int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
  * 12 = 1: every path set planned from scratch, 13 = 1: whole per-call tables through the ring (no resident copy),
  * 14 / 15: table rebuilds (above), 16 = 1: record tables keep the records that can never survive the overwrite rule
  * (host_model.cc dominated_records; takes effect at the next table build; same values either way), 18 = d: tables are
- * rebuilt when the delta lists pass pairs / d (default 8) */
+ * rebuilt when the delta lists pass pairs / d (default 8), 19 = 1: no static memo indices (every compact-class pair is
+ * resolved per call; takes effect at the next table build; same values either way), 20 = blocks of the compact class's
+ * second part */
 /* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
  * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
  * number of waves copied. Tuning aid (tools/kernel_timeline.py). */
@@ -89,6 +92,17 @@ int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);
  * pair. out6 = {records left out mate 1, mate 2, compact-class pairs with / without the rule, records checked,
  * violations}; GAML_HIP_ESTATE if a record was left out that the rule does not cover. */
 int gaml_hip_debug_fold_check(gaml_hip_ctx* ctx, int readset, int64_t* out6);
+/* host-only: the static memo indices of the compact class (both records of a pair in windows with the same node walk:
+ * orientation rule, insert distance and memo index do not depend on the path set) recomputed from the window cache.
+ * out8 = {pairs with an index, other compact-class pairs, violations, then why those others have none: a mate without
+ * record, records in different windows, orientation rule, distance outside the insert-size table, edit count or length
+ * code outside the memo}; GAML_HIP_ESTATE on a violation. */
+int gaml_hip_debug_static_check(gaml_hip_ctx* ctx, int readset, int64_t* out8);
+/* per-block partial sums / floored counts of the last blocking evaluation of paired set `readset` (path set `set` of a
+ * batch launch, 0 for a single call), in block order; layout8 = {blocks of the compact class's static part, of the
+ * compact class, up to the <= 2-record class, up to the <= 4-record class, lane-per-pair blocks, all scoring blocks,
+ * paired_general_kernel blocks, partials}. Returns the number of partials. For bit-equality hunts between routes. */
+int32_t gaml_hip_debug_block_partials(gaml_hip_ctx* ctx, int readset, int32_t set, double* sums, int32_t* zeros, int32_t cap, int32_t* layout8);
 
 #ifdef __cplusplus
 }

@@ -33,10 +33,11 @@ def test_library_was_built_from_this_tree(built):
     """gaml_hip_version() carries the hash of the sources the .so was built from (csrc/Makefile: SRC_HASH): the GPU box
     receives the prebuilt library, this is how a stale one is noticed."""
     import hashlib
+    import subprocess
     from gaml_amd import api
-    rel = ["gaml_amd/csrc/kernels.hip.h", "gaml_amd/csrc/aligner.hip.h", "gaml_amd/csrc/pacbio_dp.hip.h", "gaml_amd/csrc/ctx.hip.h",
-           "gaml_amd/csrc/internal.h", "gaml_amd/csrc/paired_launch.hip.h", "gaml_amd/csrc/gaml_hip.hip", "gaml_amd/csrc/multi.hip", "gaml_amd/csrc/host_model.h",
-           "gaml_amd/csrc/host_model.cc", "include/gaml_hip.h", "include/gaml_hip_debug.h"]
+    # the ONE list of sources: the Makefile's (everything in csrc/ and include/, so a new header cannot be left out)
+    rel = subprocess.check_output(["make", "-s", "-C", os.path.join(ROOT, "gaml_amd", "csrc"), "print-srcs"], text=True).split()
+    assert "gaml_amd/csrc/pacbio_sweep.hip.h" in rel and "include/gaml_hip_debug.h" in rel and len(rel) >= 14
     h = hashlib.sha256()
     for r in rel:
         h.update(open(os.path.join(ROOT, r), "rb").read())

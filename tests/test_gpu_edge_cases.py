@@ -273,3 +273,53 @@ def test_records_that_are_always_overwritten_stay_out_of_the_tables():
         _agree(ctx2, rs2, orc2, ors2, paths)
     st2, st_k2 = ctx2.debug_table_stats(rs2), keep2.debug_table_stats(rs_k2)
     assert st2["delta_records_left_out"] > 0 and st_k2["delta_records_left_out"] == 0
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_static_memo_indices_change_no_value(ragged):
+    """A compact-class pair whose two records sit in the same window gets its memo index when the tables are built
+    (host_model.cc build_pair_tables: orientation rule and insert distance, graph.cc:1864-1882, do not depend on where the
+    window sits); the scoring launch then only asks the occurrence tables WHETHER the pair scores. Knob 19 = 1 resolves
+    every pair per call instead. Same per-read probabilities bit for bit -- over path sets that use, cut, drop, invert and
+    repeat the windows (general path), for one and for several read-length combinations, single calls and batches -- and
+    both agree with the oracle."""
+    G, n, seed = 150_000, 36_000, 777
+    rng = np.random.default_rng(seed)
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(500, 3500)))
+    pr = synth.make_paired_reads(genome, n, 100, 260.0, 26.0, 0.01, seed)
+    if ragged:  # several (L1, L2) combinations: the length-code tables instead of the one-combination fast path
+        m1 = [pr.mate1[i, : (100 if i % 3 else 96)].copy() for i in range(n)]
+        m2 = [pr.mate2[i, : (100 if i % 5 else 92)].copy() for i in range(n)]
+        m1[-1] = pr.mate1[-1].copy(); m2[-1] = pr.mate2[-1].copy()  # the index assumes the LAST read's length (graph.cc:1286)
+        r1, r2 = _pack_ragged(m1), _pack_ragged(m2)
+    else:
+        r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 3
+    inv = [x ^ 1 for x in reversed(walk[:k])]
+    sets = [[walk], [walk[:k], walk[k:]], [walk[:k] + walk[k + 2:]], [walk[k:2 * k], walk[:k]], [inv, walk[k:]],
+            [walk[:k] + [-35] + walk[k:]], [walk, walk[k:2 * k]], [walk[:k] + walk[:k]], [], [walk]]
+    ctx, rs, orc, ors = _both(*g.packed(), r1, r2, {}, 260.0, 26.0)
+    dyn, rs_d, _, _ = _both(*g.packed(), r1, r2, {}, 260.0, 26.0)
+    dyn.debug_set_knob(19, 1)
+    for rnd in range(2):  # second round: tables rebuilt with every window of the sets on the device
+        for paths in sets:
+            got, want = ctx.calc_prob(paths), dyn.calc_prob(paths)
+            assert np.array_equal(ctx.read_probs(rs), dyn.read_probs(rs_d)), (rnd, len(paths))
+            assert got[1].tolist() == want[1].tolist() and got[2] == want[2]
+            assert got[0] == want[0] or abs(got[0] - want[0]) <= 1e-13 * abs(want[0])
+            _agree(ctx, rs, orc, ors, paths)
+        b1, b2 = ctx.calc_prob_batch(sets[:8]), dyn.calc_prob_batch(sets[:8])
+        for s_, x, y in zip(sets[:8], b1, b2):
+            assert x[1].tolist() == y[1].tolist() and (x[0] == y[0] or abs(x[0] - y[0]) <= 1e-13 * abs(y[0]))
+            one = ctx.calc_prob(s_)
+            assert one[0] == x[0], "a batch gives what the calls give one by one, bit for bit"
+        ctx.compact_tables()
+        dyn.compact_tables()
+    ctx.calc_prob(sets[0])
+    dyn.calc_prob(sets[0])
+    st, st_d = ctx.debug_table_stats(rs), dyn.debug_table_stats(rs_d)
+    c0 = ctx.debug_class_counts(rs)
+    assert st_d["static_index_pairs"] == 0 and 0.5 * c0[0] < st["static_index_pairs"] <= c0[0]
+    assert list(c0) == list(dyn.debug_class_counts(rs_d))

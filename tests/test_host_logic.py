@@ -216,3 +216,23 @@ def test_record_tables_leave_out_only_records_that_are_always_overwritten(built)
     assert seen[0]["records_left_out"] == [0, 0]                    # one-node paths: no junction window is in use
     assert min(seen[2]["records_left_out"]) > 0                      # the whole walk: every junction is
     assert seen[2]["compact_pairs"][0] > seen[2]["compact_pairs"][1]  # ... and pairs move to the one-record class
+
+
+def test_static_memo_indices_follow_from_the_window_cache(built):
+    """A compact-class pair whose two records sit in windows with the same node walk carries its memo index in the record
+    tables (orientation rule and insert distance, graph.cc:1864-1876, on window positions: both alignments get the
+    window's shift wherever it occurs); a pair with an unaligned mate carries "never scores". Host-only: every index
+    recomputed from the window cache, every pair without one has a reason, over path sets that activate the windows in
+    different orders (incl. the inverted walk, whose windows are other walks)."""
+    g, ctx, rs, _, _ = _pair_setup(G=120_000, n=12_000, seed=78, repeats=2)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 3
+    seen = []
+    for paths in ([[x] for x in walk[:k]], [walk[:k]], [walk], [walk[k:], walk[:k]], [[x ^ 1 for x in reversed(walk)]]):
+        ctx.debug_prepare(paths)
+        st = ctx.debug_static_check(rs)
+        assert st["violations"] == 0
+        seen.append(st)
+    whole = seen[2]
+    assert whole["static_pairs"] > 10 * whole["other_pairs"] > 0
+    assert whole["other_pairs"] == whole["different_windows"] + whole["orientation"] + whole["distance"] + whole["edits_or_code"]
