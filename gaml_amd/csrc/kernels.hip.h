@@ -797,49 +797,45 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
       }
     }
     GAML_STAMP(3, o1[0].x ^ o2[0].x)
-    unsigned st[P];
+    // Everything below is straight-line: bit logic on the 32-bit halves, selects instead of branches, every loaded word
+    // used unconditionally (a value that is only used inside a branch gets its LOAD moved into that branch by the
+    // compiler -- behind a full wait, a round trip of its own; it did that to the fourth pair's records and values).
     unsigned skip_bits = 0;
 #pragma unroll
     for (int k = 0; k < P; k++) {
       const bool none1 = r1[k].y == ~0u, none2 = r2[k].y == ~0u;          // no record (or, mate 1, the dirty mark)
       const bool here = (base + k * stride < n0) & !(none1 & (r1[k].x == 0xfffffffeu));  // a pair, and not a dirty slot (those: paired_delta_body)
       const bool w1 = !none1 & (o1[k].y != ~0u), w2 = !none2 & (o2[k].y != ~0u);  // a record whose window occurs in this path set
-      const bool gen = (w1 & ((int)o1[k].y < 0)) | (w2 & ((int)o2[k].y < 0));  // ... several times: general path (as compact_state: also
-                                                                               // when the other mate has no record -- which block counts the pair
-                                                                               // decides the last bit of the sum, and batches must agree with calls)
+      // ... several times: general path (as compact_state: also when the other mate has no record -- which block counts the
+      // pair decides the last bit of the sum, and batches must agree with calls)
+      const bool gen = here & ((w1 & ((int)o1[k].y < 0)) | (w2 & ((int)o2[k].y < 0)));
       const bool same = (o1[k].x == o2[k].x) & (((o1[k].y ^ o2[k].y) >> 16) == 0);      // same shift, same path
       const int p1 = (int)(__funnelshift_r(r1[k].x, r1[k].y, 24) & 0xfffffffu), p2 = (int)(__funnelshift_r(r2[k].x, r2[k].y, 24) & 0xfffffffu);
       const bool kept = (p1 >= (int)(short)(o1[k].y & 0xffffu)) & (p2 >= (int)(short)(o2[k].y & 0xffffu));  // position filter (graph.cc:577)
-      const bool both = w1 & w2;
-      // a mate without alignment: scores nothing whatever the tables say (its lookups read entry 0)
-      st[k] = !here ? 3u : gen ? 2u : (none1 | none2) ? 0u : (both & !same) ? 4u : (both & kept) ? 1u : 0u;
-      skip_bits |= (unsigned)(st[k] == 2u) << k;
+      const bool both = here & !gen & w1 & w2;          // (a mate without alignment: w false -- scores nothing whatever the tables say)
+      const bool scores = both & same & kept;           // the pair's value counts: as compact_finish
+      // `both & !same` cannot happen: both mates register the same walks under the same rules, a walk's occurrences depend on
+      // the path set alone, and a pair is only here when its two windows are linked (link_mate_windows). No second code path
+      // for it (its registers would be every wave's): the block's partial is poisoned instead, and the host reports
+      // GAML_HIP_ESTATE rather than a likelihood (combine()).
+      const bool poison = both & !same;
+      const bool counted = here & !gen;                 // scores, or scores nothing: probability written, floor / log added
+      skip_bits |= (unsigned)gen << k;
+      const double t = scores ? m[k].x : 0.0;
+      const bool floored = counted & (!scores | (t < (ONE ? tfloor_one : a.tfloor_c[lc[k]])));  // (0 < tfloor: as finish_read_compact(acc = 0))
+      const double lf = ONE ? logfloor_one : a.logfloor_c[lc[k]];
+      double add = floored ? lf : m[k].y - log2T;
+      add = counted ? add : 0.0;
+      add = poison ? __builtin_nan("") : add;
+      lsum += add;                                       // (adding 0.0 changes no bit of a sum of negative logs)
+      zeros += (int)floored;
+      if (counted && !(GAML_STATIC_X & 2)) __builtin_nontemporal_store(t, (double*)(probs + (base + k * stride) * 8u));
     }
     if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
 #pragma unroll
       for (int k = 0; k < P; k++) {
         const unsigned long long w = __ballot((skip_bits >> k) & 1u);
         if ((threadIdx.x & 63) == 0 && base + k * stride < n0) gen_bits[(base + k * stride - (unsigned)rg.lo) >> 6] = w;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < P; k++) {
-      double* const out = (double*)(probs + (base + k * stride) * 8u);
-      if (st[k] == 1u) {  // as compact_finish
-        if (!(GAML_STATIC_X & 2)) __builtin_nontemporal_store(m[k].x, out);
-        const bool floored = m[k].x < (ONE ? tfloor_one : a.tfloor_c[lc[k]]);
-        lsum += floored ? (ONE ? logfloor_one : a.logfloor_c[lc[k]]) : m[k].y - log2T;
-        zeros += (int)floored;
-      } else if (st[k] == 0u) {  // as finish_read_compact(acc = 0)
-        if (!(GAML_STATIC_X & 2)) __builtin_nontemporal_store(0.0, out);
-        zeros++;
-        lsum += ONE ? logfloor_one : a.logfloor_c[lc[k]];
-      } else if (st[k] == 4u) {
-        // Cannot happen: both mates register the same walks under the same rules, a walk's occurrences depend on the
-        // path set alone, and a pair is only here when its two windows are linked (link_mate_windows). No second code
-        // path for it (its registers would be every wave's): the block's partial is poisoned instead, and the host
-        // reports GAML_HIP_ESTATE rather than a likelihood (combine()).
-        lsum += __builtin_nan("");
       }
     }
     GAML_STAMP(5, 0u)
@@ -1211,6 +1207,7 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_kernel(PairedArgs a) {
   if (!TL && lb < a.blocks0a && a.memo && !a.cov_bits && a.n_codes == 1) {
     double lsum = 0.0;
     int zeros = 0;
+    if (!(GAML_STATIC_X & 16))
     paired_static4_body<GEN, false, true>(a, SlotRange{0, a.n0a, lb, a.blocks0a, 0}, lsum, zeros);
     block_reduce(lsum, zeros, sh_s, sh_z);
     if (TICKET) grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out, 0.0, a.n_reads, sh_s, sh_z);
