@@ -160,8 +160,7 @@ def inproc_child(args):
     from gaml_amd import api, synth
     devs = [int(x) for x in args.inproc_devices.split(",")]
     wl = synth.WORKLOADS[args.workload]
-    genome = synth.make_genome(wl.genome_len, wl.seed)
-    g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
+    genome, g = wl.build()
     pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
     ctx = api.Context(devices=devs)
     ctx.set_graph(*g.packed())
@@ -189,7 +188,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "tiny"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "tiny", "cfg3r", "tinyr", "cfg3x8"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = BASELINE config 3's read set split over the GPUs (default); weak = a fresh read set of the same size per GPU")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs the CPU baseline scores (0 = the whole read set)")
@@ -235,8 +234,7 @@ def main():
 
     wl = synth.WORKLOADS[args.workload]
     strong = args.scaling == "strong"
-    genome = synth.make_genome(wl.genome_len, wl.seed)
-    g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
+    genome, g = wl.build()
     # strong: every rank draws the SAME read set (the N = 1 seed) and keeps its contiguous share; weak: its own set
     read_seed = wl.seed if (strong or world == 1) else wl.seed + 1000 * rank
     pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, read_seed)

@@ -697,6 +697,12 @@ class Context:
         return {"static_pairs": int(out[0]), "other_pairs": int(out[1]), "violations": int(out[2]), "no_record": int(out[3]),
                 "different_windows": int(out[4]), "orientation": int(out[5]), "distance": int(out[6]), "edits_or_code": int(out[7])}
 
+    def debug_general_stats(self):
+        n, us = C.c_int64(), C.c_double()
+        _lib.gaml_hip_debug_general_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        self._check(_lib.gaml_hip_debug_general_stats(self._h, C.byref(n), C.byref(us)))
+        return {"launches": n.value, "device_us": us.value}
+
     def debug_block_partials(self, rs, set_index=0):
         sums, zeros, lay = np.zeros(8192, np.float64), np.zeros(8192, np.int32), np.zeros(8, np.int32)
         _lib.gaml_hip_debug_block_partials.argtypes = [C.c_void_p, C.c_int, C.c_int32, _f64p, _i32p, C.c_int32, _i32p]

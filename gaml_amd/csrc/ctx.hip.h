@@ -391,6 +391,8 @@ struct gaml_hip_ctx {
   int64_t event_tick = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // one pair per scoring launch of a call
   std::vector<uint64_t> ev_call;  // ... and the evaluation (eval_serial) it belongs to
+  std::vector<uint8_t> ev_kind;   // 0: a scoring launch (gaml_hip_kernel_stats), 1: paired_general_kernel (second launch of a path set with repeated windows)
+  double stat_general_us = 0; int64_t stat_general_launches = 0;
   uint64_t eval_serial = 0;
   size_t ev_used = 0;
   double t_host_us = 0, t_dev_wall_us = 0, t_kernel_us = 0;

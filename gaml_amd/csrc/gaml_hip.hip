@@ -115,6 +115,7 @@ int collect_events(gaml_hip_ctx* c) {
     float ms = 0;
     HIP_TRY(c, hipEventSynchronize(c->ev_pool[i].second));
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+    if (c->ev_kind[i] == 1) { c->stat_general_us += ms * 1000.0; c->stat_general_launches++; continue; }
     sum += ms * 1000.0;
     last = c->ev_call[i] == c->ev_call[c->ev_used - 1] ? last + ms * 1000.0 : 0.0;
   }
@@ -124,7 +125,7 @@ int collect_events(gaml_hip_ctx* c) {
   return 0;
 }
 
-int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
+int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out, int kind = 0) {
   if (c->ev_used == c->ev_pool.size() && c->ev_pool.size() >= 2048) { if (int e = collect_events(c)) return e; }
   if (c->ev_used == c->ev_pool.size()) {
     hipEvent_t a, b;
@@ -133,6 +134,8 @@ int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
     c->ev_pool.emplace_back(a, b);
   }
   if (c->ev_call.size() < c->ev_pool.size()) c->ev_call.resize(c->ev_pool.size(), 0);
+  if (c->ev_kind.size() < c->ev_pool.size()) c->ev_kind.resize(c->ev_pool.size(), 0);
+  c->ev_kind[c->ev_used] = (uint8_t)kind;
   c->ev_call[c->ev_used] = c->eval_serial;
   *out = &c->ev_pool[c->ev_used++];
   return 0;
@@ -2889,6 +2892,17 @@ int32_t gaml_hip_debug_block_partials(gaml_hip_ctx* c, int rs, int32_t set, doub
   return n;
 }
 
+// device time of paired_general_kernel (the second launch of a path set in which some window occurs several times),
+// from events attached to its dispatches while event timing is on; reset with gaml_hip_kernel_stats(reset)
+int gaml_hip_debug_general_stats(gaml_hip_ctx* c, int64_t* launches, double* device_us) {
+  MULTI_SHARD0(c);
+  if (!c) return GAML_HIP_EINVAL;
+  if (c->device >= 0 && c->ev_used) { if (int e = collect_events(c)) return e; }
+  if (launches) *launches = c->stat_general_launches;
+  if (device_us) *device_us = c->stat_general_us;
+  return GAML_HIP_OK;
+}
+
 int gaml_hip_last_timing(const gaml_hip_ctx* c, double* out3) {
   if (!c || !out3) return GAML_HIP_EINVAL;
   MULTI_FWD(c, multi_last_timing(c->multi, out3));
@@ -2921,7 +2935,7 @@ int gaml_hip_kernel_stats(gaml_hip_ctx* c, int reset, int64_t* launches, double*
   if (launches) *launches = c->stat_launches;
   if (device_us) *device_us = c->stat_device_us;
   if (algo_bytes) *algo_bytes = c->stat_algo_bytes;
-  if (reset) { c->stat_launches = 0; c->stat_device_us = 0; c->stat_algo_bytes = 0; }
+  if (reset) { c->stat_launches = 0; c->stat_device_us = 0; c->stat_algo_bytes = 0; c->stat_general_us = 0; c->stat_general_launches = 0; }
   return GAML_HIP_OK;
 }
 

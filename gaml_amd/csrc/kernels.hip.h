@@ -93,6 +93,7 @@ struct PairedArgs {
   // host saw no such window in this path set -- then neither the notes nor the second launch exist.
   unsigned long long* timeline;  // TL instantiation only: 8 wall-clock stamps (10 ns units) per wave of the grid
   int gen_w0b, gen_w1, gen_w2;  // first word of the second part of class 0 / class 1 / class 2 (class 0 starts at word 0)
+  int gen_wd;                   // ... and of the delta pairs' notes (one bit per delta index)
   // Delta: pairs whose record lists changed since the device tables were built (newly activated
   // windows). Their slots carry a DIRTY mark in the tables; their complete record lists travel with
   // every evaluation and the overflow path scores them.
@@ -200,9 +201,13 @@ __device__ __forceinline__ double pair_term(const PairedArgs& a, const Cand& x, 
     if (x.orient != 1 || y.orient != 0) return 0.0;
     dist = x.pos - y.pos + L1;
   }
+  // beyond the insert-size table the Gaussian is exactly 0.0 in f64 (PairedArgs::ins_tab), and so is the term: two finite
+  // products times 0.0 -- no need to fetch the factors (two occurrences of a repeat are thousands of bases apart: most
+  // combinations of a pair in a 5-copy repeat end here)
+  if ((unsigned)dist >= (unsigned)a.ins_n) return 0.0;
   double p1 = a.m[0].mism_pow[x.edit] * a.m[0].match_pow[L1 - x.edit];
   double p2 = a.m[1].mism_pow[y.edit] * a.m[1].match_pow[L2 - y.edit];
-  double ip = (unsigned)dist < (unsigned)a.ins_n ? a.ins_tab[dist] : 0.0;
+  double ip = a.ins_tab[dist];
   double t = p1 * p2 * ip;
   if (a.cov_bits && t > a.covthr_tab[L2]) {  // coverage events at both ends (use_all_to_cov, graph.cc:1883-1888)
     int base = a.path_base[x.path];
@@ -215,7 +220,7 @@ __device__ __forceinline__ double pair_term(const PairedArgs& a, const Cand& x, 
 // reads with several records and/or windows that occur several times: fully general, one
 // thread, quadratic; only the last resort of the overflow kernel (more than kOvfCap candidates)
 template <class Src>
-__device__ __forceinline__ double paired_general_src(const PairedArgs& a, const Src& s1, const Src& s2, int L1, int L2) {
+__device__ __forceinline__ double paired_general_src_slow(const PairedArgs& a, const Src& s1, const Src& s2, int L1, int L2) {
   double acc = 0.0;
   for_each_cand_src(a.m[0], s1, [&](const Cand& x) {
     if (!is_live_src(a.m[0], s1, x)) return;
@@ -227,8 +232,49 @@ __device__ __forceinline__ double paired_general_src(const PairedArgs& a, const 
   });
   return acc;
 }
+// Which candidates of one mate are live, as a bit per candidate in visiting order; false when there are more than 64.
+// One pass per candidate over the candidates (n^2 derivations), ONCE per mate -- the loop above re-derives the liveness
+// of every candidate of mate 2 for every candidate of mate 1 (n1 n2^2 derivations, each a chain of dependent loads: a
+// read in a 5-copy repeat seen through 4 windows took 8,000 of them, and its lane 50 us).
+template <class Src>
+__device__ __forceinline__ bool live_mask_src(const MateView& v, const Src& src, unsigned long long& mask) {
+  mask = 0;
+  int n = 0;
+  for_each_cand_src(v, src, [&](const Cand& c) {
+    if (n < 64 && is_live_src(v, src, c)) mask |= 1ull << n;
+    n++;
+  });
+  return n <= 64;
+}
+// Same terms in the same order as the loop above. For paired_general_kernel only: inside the scoring kernel (delta pairs
+// and the wave-per-pair fallback reach the general loop too, rarely) its registers put EVERY launch on scratch memory.
+template <class Src>
+__device__ __forceinline__ double paired_general_src_masks(const PairedArgs& a, const Src& s1, const Src& s2, int L1, int L2) {
+  unsigned long long live1, live2;
+  if (!live_mask_src(a.m[0], s1, live1) || !live_mask_src(a.m[1], s2, live2)) return paired_general_src_slow(a, s1, s2, L1, L2);
+  double acc = 0.0;
+  if (!live1 || !live2) return acc;
+  int ix = 0;
+  for_each_cand_src(a.m[0], s1, [&](const Cand& x) {
+    const bool lx = (live1 >> ix) & 1ull;
+    ix++;
+    if (!lx) return;
+    int iy = 0;
+    for_each_cand_src(a.m[1], s2, [&](const Cand& y) {
+      const bool ly = (live2 >> iy) & 1ull;
+      iy++;
+      if (!ly || y.path != x.path) return;
+      acc += pair_term(a, x, y, L1, L2);
+    });
+  });
+  return acc;
+}
+template <class Src>
+__device__ __forceinline__ double paired_general_src(const PairedArgs& a, const Src& s1, const Src& s2, int L1, int L2) {
+  return paired_general_src_slow(a, s1, s2, L1, L2);
+}
 __device__ __forceinline__ double paired_general(const PairedArgs& a, const int4& r1, const int4& r2, int L1, int L2) {
-  return paired_general_src(a, TableSrc{&a.m[0], r1}, TableSrc{&a.m[1], r2}, L1, L2);
+  return paired_general_src_masks(a, TableSrc{&a.m[0], r1}, TableSrc{&a.m[1], r2}, L1, L2);
 }
 
 // wave (64 lanes) + block reduction of (double, int); result valid in thread 0
@@ -470,10 +516,37 @@ __device__ __forceinline__ void compact_cover(const PairedArgs& a, const Compact
 // does not fit the 8-byte form): fully general loop over (record, occurrence) candidates, one lane per pair
 // (paired_general_kernel). Doing this inside the streaming loop cost the loop 1.2 us of 12 at cfg3 even when no
 // such pair exists (registers / code size), hence the second launch.
+// One record per mate: every valid candidate is live (the overwrite rule only ever decides between DIFFERENT records of a
+// read that land on the same path position), so the pair's probability is the plain double sum over the two windows'
+// occurrences -- each window's list bounds found once, its entries read in order. Terms and their order are those of
+// paired_general.
+struct OccList { const int4* e; int n; int4 one; };
+__device__ __forceinline__ OccList occ_list(const MateView& v, int wid) {
+  OccList l{nullptr, 0, make_int4(0, 0, -1, 0)};
+  if (wid < 0) return l;
+  const int4 o = mate_occ(v, wid);
+  if (o.z < 0) return l;
+  if (o.w >= 0) { l.one = o; l.n = 1; return l; }
+  const int s = -o.w - 1, b = v.multi_off[s];
+  l.e = v.multi + b; l.n = v.multi_off[s + 1] - b;
+  return l;
+}
 __device__ __forceinline__ void compact_general(const PairedArgs& a, int i, double& lsum, int& zeros) {
   const int lc = a.len_code[i];
   const uint32_t l12 = a.len_combo[lc];
-  const double acc = paired_general(a, rec8_to_quad(a.rec8[0][i]), rec8_to_quad(a.rec8[1][i]), l12 & 0xffff, l12 >> 16);
+  const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+  const int4 r1 = rec8_to_quad(a.rec8[0][i]), r2 = rec8_to_quad(a.rec8[1][i]);
+  const OccList l1 = occ_list(a.m[0], r1.x), l2 = occ_list(a.m[1], r2.x);
+  double acc = 0.0;
+  for (int p = 0; p < l1.n; p++) {
+    const Cand x = make_cand(r1, l1.e ? l1.e[p] : l1.one, 0);
+    if (!x.valid) continue;
+    for (int q = 0; q < l2.n; q++) {
+      const Cand y = make_cand(r2, l2.e ? l2.e[q] : l2.one, 0);
+      if (!y.valid || y.path != x.path) continue;
+      acc += pair_term(a, x, y, L1, L2);
+    }
+  }
   finish_read_compact(a, i, acc, lc, lsum, zeros);
 }
 
@@ -943,7 +1016,12 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
 // Delta pairs (pairs that gained records since the tables were built): one LANE per pair, records from
 // the delta lists. Up to 4 records per mate go through the register path of class 2; longer lists and
 // pairs touching a window that occurs several times take the fully general per-lane loop (rare).
+template <bool GEN>
 __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, int delta_blocks, double& lsum, int& zeros) {
+  // (a delta pair touching a window that occurs several times is only NOTED here -- GEN launches: a bit per delta index,
+  // one ballot word per wave and iteration -- and scored by paired_general_kernel: the general loop inside this kernel,
+  // one lane re-deriving every candidate's liveness for every candidate, made a late annealing walk's launch 60 us)
+  unsigned long long* const notes = GEN ? a.gen_bits + a.gen_wd : nullptr;
   for (int dj = db * kBlock + threadIdx.x; dj < a.n_dirty; dj += delta_blocks * kBlock) {
     // Everything a delta pair needs sits at index dj (no chain through the pair's slot): the first record of mate 1
     // carries the two read lengths in its spare word, the first record of mate 2 the two list lengths (paired_upload_delta)
@@ -953,27 +1031,30 @@ __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, i
 #pragma unroll
     for (int k = 0; k < 2; k++) { r0[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r1[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
     const uint32_t l12 = (uint32_t)r0[0].w;
-    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-    const int c0 = r1[0].w & 0xff, c1 = (r1[0].w >> 8) & 0xff;
+    const int c0 = r1[0].w & 0xff, c1 = (r1[0].w >> 8) & 0xff;  // the two lists' lengths
+    bool general = false;
     if (__all(sp >= 0 || (c0 <= 2 && c1 <= 2))) {  // the usual delta pair: a second window per mate (a node and its twin, a junction)
-      if (sp >= 0) continue;
-      RegCands<2> x, y;
-      const int4 q0[2] = {r0[0], r0[1]}, q1[2] = {r1[0], r1[1]};
-      const bool m0 = cands_from_records<2>(a.m[0], q0, x), m1 = cands_from_records<2>(a.m[1], q1, y);
-      if (!(m0 || m1)) { score_cands_and_finish<2>(a, i, l12, x, y, lsum, zeros); continue; }
-      const double acc = paired_general_src(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
-      finish_read(a, i, acc, L1, L2, lsum, zeros);
-      continue;
-    }
-    if (sp >= 0) continue;  // a long list: one WAVE scores it (paired_overflow_body) -- a lane looping over it alone was the launch's tail
+      if (sp < 0) {
+        RegCands<2> x, y;
+        const int4 q0[2] = {r0[0], r0[1]}, q1[2] = {r1[0], r1[1]};
+        const bool m0 = cands_from_records<2>(a.m[0], q0, x), m1 = cands_from_records<2>(a.m[1], q1, y);
+        general = m0 || m1;
+        if (!general) score_cands_and_finish<2>(a, i, l12, x, y, lsum, zeros);
+      }
+    } else if (sp < 0) {  // (sp >= 0, a long list: one WAVE scores it, paired_overflow_body -- a lane looping over it alone was the launch's tail)
 #pragma unroll
-    for (int k = 2; k < 4; k++) { r0[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r1[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
-    RegCands<4> x, y;
-    const bool m0 = cands_from_records<4>(a.m[0], r0, x), m1 = cands_from_records<4>(a.m[1], r1, y);
-    if (!(m0 || m1)) { score_cands_and_finish<4>(a, i, l12, x, y, lsum, zeros); continue; }
-    // a window that occurs several times in this path set: general loop over the same records
-    const double acc = paired_general_src(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
-    finish_read(a, i, acc, L1, L2, lsum, zeros);
+      for (int k = 2; k < 4; k++) { r0[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r1[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
+      RegCands<4> x, y;
+      const bool m0 = cands_from_records<4>(a.m[0], r0, x), m1 = cands_from_records<4>(a.m[1], r1, y);
+      general = m0 || m1;
+      if (!general) score_cands_and_finish<4>(a, i, l12, x, y, lsum, zeros);
+    }
+    if (GEN) {  // lane 0 holds the wave's lowest delta index: it is active whenever any lane is
+      const unsigned long long k = __ballot(general);
+      if ((threadIdx.x & 63) == 0) notes[dj >> 6] = k;
+    } else if (general) {  // cannot happen (a launch without notes has no such window): the partial is poisoned, combine() reports it
+      lsum += __builtin_nan("");
+    }
   }
 }
 
@@ -1030,7 +1111,7 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
     paired_regs_body<4, GEN>(c, lb, c.n01, c.n_main, c.blocks01, c.blocks012, lsum, zeros);
   } else {
     GAML_FRESH_ARGS(c, a)
-    paired_delta_body(c, lb - c.blocks012, c.main_blocks - c.blocks012, lsum, zeros);
+    paired_delta_body<GEN>(c, lb - c.blocks012, c.main_blocks - c.blocks012, lsum, zeros);
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
   if (TL && (threadIdx.x & 63) == 0) tl[6] = wall_clock64();
@@ -1407,11 +1488,13 @@ __device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, cons
 }
 
 // paired_delta_body with the path sets in the inner loop
+template <bool GEN>
 __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, const MultiSets& ms, int db, int delta_blocks, double* acc_s, int* acc_z, const double* tf) {
   for (int dj = db * kBlock + threadIdx.x; dj < a.n_dirty; dj += delta_blocks * kBlock) {
     const int i = a.dirty_slots[dj];
     const int sp = a.dirty_spill[dj];
-    if (sp >= 0) continue;  // a long list: one WAVE scores it
+    const bool mine = sp < 0;  // (sp >= 0, a long list: one WAVE scores it. Such a lane stays in the loop: the note words are
+                               // written by the wave's lane 0 from a ballot over ALL its lanes)
     int4 r0[4], r1[4];
     int c0 = 0, c1 = 0;
     unsigned chg = ms.chg[0] ? 0u : 0xffu;
@@ -1423,23 +1506,27 @@ __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, con
       if (ms.chg[0]) chg |= (r0[k].x >= 0 ? ms.chg[0][r0[k].x] : 0u) | (r1[k].x >= 0 ? ms.chg[1][r1[k].x] : 0u);
     }
     const uint32_t l12 = (uint32_t)r0[0].w;  // the pair's read lengths travel with its first record (paired_upload_delta)
-    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     PairVal val{0.0, 0.0, 0, 0};
+    bool general = false;  // as resolved last: a set whose tables agree with its predecessor's on this pair's windows inherits it
 #pragma unroll 1
     for (int s = 0; s < ms.n; s++) {
       const PairedArgs b = with_set(a, ms.set[s], tf ? tf + s * kTfCodes : nullptr);
       double lsum = acc_s[s * kBlock + threadIdx.x];
       int zeros = acc_z[s * kBlock + threadIdx.x];
-      if (s == 0 || ((chg >> s) & 1u)) {
+      if (!mine) {
+      } else if (s == 0 || ((chg >> s) & 1u)) {
         RegCands<4> x, y;
         const bool m0 = cands_from_records<4>(b.m[0], r0, x), m1 = cands_from_records<4>(b.m[1], r1, y);
-        if (!(m0 || m1)) score_cands_and_finish<4>(b, i, l12, x, y, lsum, zeros, &val);
-        else {  // a window that occurs several times in this path set: general loop over the same records
-          const double acc = paired_general_src(b, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
-          finish_read(b, i, acc, L1, L2, lsum, zeros, &val);
-        }
+        general = m0 || m1;  // a window that occurs several times in this path set: noted for paired_general_kernel (as paired_delta_body)
+        val.kind = 0;
+        if (!general) score_cands_and_finish<4>(b, i, l12, x, y, lsum, zeros, &val);
+        else if (!GEN) lsum += __builtin_nan("");  // cannot happen (a launch without notes has no such window): poisoned, reported by combine()
       } else {
         finish_val(b, i, val, s == ms.n - 1, lsum, zeros);
+      }
+      if (GEN) {
+        const unsigned long long k = __ballot(general);
+        if ((threadIdx.x & 63) == 0) b.gen_bits[a.gen_wd + (dj >> 6)] = k;
       }
       acc_s[s * kBlock + threadIdx.x] = lsum;
       acc_z[s * kBlock + threadIdx.x] = zeros;
@@ -1551,7 +1638,7 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArg
       }
     } else if (lb < a.blocks01) paired_regs_multi_body<2, GEN>(a, ms, lb, a.n0, a.n01, a.blocks0, a.blocks01, acc_s, acc_z, tf);
     else if (lb < a.blocks012) paired_regs_multi_body<4, GEN>(a, ms, lb, a.n01, a.n_main, a.blocks01, a.blocks012, acc_s, acc_z, tf);
-    else paired_delta_multi_body(a, ms, lb - a.blocks012, a.main_blocks - a.blocks012, acc_s, acc_z, tf);
+    else paired_delta_multi_body<GEN>(a, ms, lb - a.blocks012, a.main_blocks - a.blocks012, acc_s, acc_z, tf);
     for (int s = 0; s < ms.n; s++) {
       double lsum = acc_s[s * kBlock + threadIdx.x];
       int zeros = acc_z[s * kBlock + threadIdx.x];
@@ -1602,6 +1689,15 @@ __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, in
       const double acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
       finish_read(a, i, acc, L1, L2, lsum, zeros);
     }
+  }
+  // ... and the delta pairs the scoring launch noted (paired_delta_body), one lane per pair, records from the delta lists
+  for (int dj = blockIdx.x * kBlock + threadIdx.x; dj < a.n_dirty; dj += gridDim.x * kBlock) {
+    if (!((a.gen_bits[a.gen_wd + (dj >> 6)] >> (dj & 63)) & 1ull)) continue;
+    const int4 h0 = a.dirty_recs[0][4 * (size_t)dj], h1 = a.dirty_recs[1][4 * (size_t)dj];
+    const uint32_t l12 = (uint32_t)h0.w;
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    const double acc = paired_general_src_masks(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, h1.w & 0xff}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, (h1.w >> 8) & 0xff}, L1, L2);
+    finish_read(a, a.dirty_slots[dj], acc, L1, L2, lsum, zeros);
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
   if (threadIdx.x == 0) { a.part_sum[part_base + blockIdx.x] = lsum; a.part_zero[part_base + blockIdx.x] = zeros; }

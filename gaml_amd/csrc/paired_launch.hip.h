@@ -883,7 +883,7 @@ void paired_persist_view(const PairedSet& s, int32_t total_len, SetDev& sd) {
 // ---------------------------------------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------------------------------------
-struct GridPlan { int blocks0a, blocks0, blocks1, blocks2, blocks_d, main_blocks, ovf_blocks, total_blocks, gen_blocks; int64_t gen_words[3]; };
+struct GridPlan { int blocks0a, blocks0, blocks1, blocks2, blocks_d, main_blocks, ovf_blocks, total_blocks, gen_blocks; int64_t gen_words[4]; };  // gen_words: notes of class 0 / 1 / 2 / the delta pairs
 
 // what every path set of a launch shares: record tables, length tables, memo, classes, grid
 void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp) {
@@ -957,6 +957,7 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   gp.ovf_blocks = ovf_total > 0 ? (int)std::min<int64_t>((ovf_total + 3) / 4, kOvfMaxBlocks) : 0;
   gp.total_blocks = gp.main_blocks + gp.ovf_blocks;
   gp.gen_words[0] = (n0a + 63) / 64 + (n0b + 63) / 64; gp.gen_words[1] = (n01 - n0 + 63) / 64; gp.gen_words[2] = (n_main - n01 + 63) / 64;
+  gp.gen_words[3] = ((int64_t)nd + 63) / 64;
   gp.gen_blocks = n_main > 0 ? (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, kMaxBlocks) : 0;
   a.blocks0a = gp.blocks0a;
   a.gen_w0b = (int)((n0a + 63) / 64);
@@ -966,6 +967,7 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   a.main_blocks = gp.main_blocks;
   a.total_blocks = gp.total_blocks;
   a.gen_w1 = (int)gp.gen_words[0]; a.gen_w2 = (int)(gp.gen_words[0] + gp.gen_words[1]);
+  a.gen_wd = (int)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2]);
 }
 
 // what one path set changes: its occurrence tables inside `arena`, 2T and the thresholds that follow from it
@@ -1082,7 +1084,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   const bool gen_pass = a.n_main > 0 && p.general;
   int gen_blocks = 0;
   if (gen_pass) {
-    const size_t bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2]) * sizeof(unsigned long long);
+    const size_t bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2] + gp.gen_words[3]) * sizeof(unsigned long long);
     if (bytes > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(bytes + bytes / 4)); }
     sd.gen_bits = s.gen_bits.as<unsigned long long>();
     gen_blocks = gp.gen_blocks;
@@ -1126,7 +1128,9 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
 #undef GAML_LAUNCH_SCORE
     HIP_TRY(c, hipGetLastError());
     if (gen_pass) {
-      hipLaunchKernelGGL(paired_general_kernel, dim3(gen_blocks), dim3(kBlock), 0, st, a, a.total_blocks);
+      std::pair<hipEvent_t, hipEvent_t>* gev = nullptr;
+      if (ev) { if (int e = take_events(c, &gev, 1)) return e; }  // (timed like the scoring launch: gaml_hip_debug_general_stats)
+      hipExtLaunchKernelGGL(paired_general_kernel, dim3(gen_blocks), dim3(kBlock), 0, st, gev ? gev->first : nullptr, gev ? gev->second : nullptr, 0, a, a.total_blocks);
       HIP_TRY(c, hipGetLastError());
     }
     if (fin_mode == 1) {
@@ -1182,7 +1186,7 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, co
   const int64_t n = s.mate[0].n_local();
   bool any_general = false;
   for (int k = first; k < first + n_sets; k++) any_general = any_general || (a.n_main > 0 && preps[k].general);
-  const size_t gen_bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2]) * sizeof(unsigned long long);
+  const size_t gen_bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2] + gp.gen_words[3]) * sizeof(unsigned long long);
   if (any_general && gen_bytes * kMaxSets > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(gen_bytes * kMaxSets + 64)); }
   const int n_partials = gp.total_blocks + (any_general ? gp.gen_blocks : 0);
   double* d_sum = nullptr;

@@ -60,6 +60,7 @@ class Graph:
     """2n node sequences; node 2i is piece i forward, node 2i+1 its twin (reverse complement)."""
     seqs: list  # list[np.ndarray uint8]
     arcs: list = field(default_factory=list)  # (src velvet id, dst velvet id), 1-based signed
+    true_walk: list | None = None  # the genome as a walk when it is not "every forward piece once" (collapsed repeats)
 
     @property
     def n_nodes(self) -> int:
@@ -100,8 +101,47 @@ def write_lastgraph(path: str, g: Graph) -> None:
 
 
 def genome_walk(g: Graph) -> list[int]:
-    """The true genome as one walk: all forward pieces in order."""
-    return list(range(0, g.n_nodes, 2))
+    """The true genome as one walk: all forward pieces in order (a graph with collapsed repeats carries its own)."""
+    return list(g.true_walk) if g.true_walk is not None else list(range(0, g.n_nodes, 2))
+
+
+def make_repeat_graph(length: int, seed: int, frac: float = 0.02, rep_rng=(1000, 3000), copies: int = 5,
+                      long_rng=(2000, 8000), short_rng=(40, 120)):
+    """A genome with COLLAPSED repeats, the case GAML's repeat moves exist for (FixBigReps / FixRepForNode2,
+    moves.cc:1156-1305): `frac` of the genome lies in repeat families of `copies` identical copies, rep_rng bases each.
+    A family is ONE node of the graph, as in a de Bruijn assembly graph; the true genome walk visits it `copies` times, so
+    its windows occur several times in the path set and its reads align once but sit at several path positions.
+    Returns (genome sequence, graph); unique pieces alternate long / short as in make_graph, every repeat occurrence is
+    followed by a short unique piece of its own."""
+    rng = np.random.default_rng(seed + 11)
+    cuts = cut_lengths(length, seed, long_rng, short_rng)
+    n_fam = max(1, int(round(frac * length / (copies * 0.5 * (rep_rng[0] + rep_rng[1])))))
+    fams = [_ACGT[rng.integers(0, 4, size=int(rng.integers(rep_rng[0], rep_rng[1] + 1)), dtype=np.uint8)] for _ in range(n_fam)]
+    uniq = make_genome(length, seed)
+    # unique pieces, then the places (before a long piece, behind a short one) where repeat occurrences go
+    pieces, pos = [], 0
+    for n in cuts:
+        pieces.append(uniq[pos:pos + n]); pos += n
+    slots = [i for i in range(2, len(pieces), 2)]  # index of a long piece with a short one before it
+    take = rng.choice(len(slots), size=min(len(slots), n_fam * copies), replace=False)
+    occ_at = {}
+    for k, t in enumerate(sorted(take.tolist())):
+        occ_at[slots[t]] = k % n_fam  # families interleaved along the genome
+    seqs, walk, genome_parts, node_of_fam = [], [], [], {}
+    def add_node(seq):
+        seqs.append(np.ascontiguousarray(seq)); seqs.append(np.ascontiguousarray(revcomp(seq)))
+        return len(seqs) - 2
+    for i, piece in enumerate(pieces):
+        if i in occ_at:
+            f = occ_at[i]
+            if f not in node_of_fam:
+                node_of_fam[f] = add_node(fams[f])
+            walk.append(node_of_fam[f]); genome_parts.append(fams[f])
+            spacer = _ACGT[rng.integers(0, 4, size=int(rng.integers(short_rng[0], short_rng[1] + 1)), dtype=np.uint8)]
+            walk.append(add_node(spacer)); genome_parts.append(spacer)
+        walk.append(add_node(piece)); genome_parts.append(piece)
+    arcs = sorted({(a // 2 + 1, b // 2 + 1) for a, b in zip(walk, walk[1:])})
+    return np.concatenate(genome_parts), Graph(seqs, arcs, true_walk=walk)
 
 
 def _mutate(reads: np.ndarray, err: float, rng) -> np.ndarray:
@@ -380,6 +420,14 @@ class Workload:
     insert_std: float = 30.0
     err: float = 0.01
     seed: int = 20260301
+    repeat_frac: float = 0.0   # > 0: collapsed repeats (make_repeat_graph): that share of the genome in 5-copy families of 1-3 kbp
+
+    def build(self):
+        """(genome sequence, graph) of the workload."""
+        if self.repeat_frac > 0:
+            return make_repeat_graph(self.genome_len, self.seed, self.repeat_frac)
+        genome = make_genome(self.genome_len, self.seed)
+        return genome, make_graph(genome, cut_lengths(self.genome_len, self.seed))
 
 
 # BASELINE.json configs (SURVEY.md 8d sizes)
@@ -387,6 +435,10 @@ WORKLOADS = {
     "cfg2": Workload("cfg2: 1 Mbp, 30x 2x150 paired, insert 300+-30", 1_000_000, 100_000),
     "cfg3": Workload("cfg3: 5 Mbp, 50x 2x150 paired, insert 300+-30", 5_000_000, 833_333),
     "tiny": Workload("tiny: 60 kbp, 2x150 paired", 60_000, 3_000),
+    # "optionally with planted repeats" -- config 3's recipe with 2 % of the genome in collapsed 5-copy repeat
+    # families of 1-3 kbp: the true walk visits those nodes five times (windows that occur several times: general path)
+    "cfg3r": Workload("cfg3r: 5 Mbp + 2 % collapsed 5-copy repeats of 1-3 kbp, 50x 2x150 paired, insert 300+-30", 5_000_000, 850_000, repeat_frac=0.02),
+    "tinyr": Workload("tinyr: 120 kbp + 5 % collapsed repeats, 2x150 paired", 120_000, 20_000, repeat_frac=0.05),
     # not a BASELINE config: the cfg3 recipe at 8x the size, to see where the scoring kernel's bandwidth levels off
     "cfg3x8": Workload("cfg3x8: 40 Mbp, 50x 2x150 paired, insert 300+-30", 40_000_000, 6_666_664),
 }

@@ -82,6 +82,10 @@ int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
 int gaml_hip_debug_timeline(gaml_hip_ctx* ctx, int rs, unsigned long long* out, int64_t cap_waves);
 
 int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
+/* launches and device time (microseconds, events attached to the dispatches while event timing is on) of
+ * paired_general_kernel: the second launch of a path set in which some window occurs several times (collapsed repeats).
+ * Reset together with gaml_hip_kernel_stats. */
+int gaml_hip_debug_general_stats(gaml_hip_ctx* ctx, int64_t* launches, double* device_us);
 /* Environment (read once): GAML_HIP_TRACE_HOST=1 -- host-side phase times of slow calls, table builds and rebuilds on
  * stderr; GAML_HIP_TRACE_ALIGNER=1 -- aligner stage times with gaml_hip_aligner_stats; GAML_HIP_BACKTRACE=1 -- a
  * backtrace on stderr when the process aborts or faults (also after the HIP runtime reports a GPU memory fault). */

@@ -8,8 +8,7 @@ from gaml_amd import synth, api
 import bench
 
 wl = synth.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg3"]
-genome = synth.make_genome(wl.genome_len, wl.seed)
-g = synth.make_graph(genome, synth.cut_lengths(wl.genome_len, wl.seed))
+genome, g = wl.build()
 pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
 ctx = api.Context(device=0)
 ctx.set_graph(*g.packed())

@@ -33,7 +33,7 @@ for d in delays:
           f"take-overs seen by call {at}; slowest calls {[(int(k), int(per[k])) for k in slow]}; {ctx.debug_table_stats(rs)}", flush=True)
     ctx.set_event_timing(True); ctx.kernel_stats(reset=True)
     for f in flat[-200:]: ctx.score(f)
-    print("   last 200 paths again, event timing:", ctx.kernel_stats(reset=True), "classes", ctx.debug_class_counts(rs), "general windows / multi:", [len(ctx.debug_table_occurrences(rs, m)[0]) for m in (0, 1)], flush=True)
+    print("   last 200 paths again, event timing:", ctx.kernel_stats(), "general kernel", ctx.debug_general_stats() if hasattr(ctx, "debug_general_stats") else None, "classes", ctx.debug_class_counts(rs), "general windows / multi:", [len(ctx.debug_table_occurrences(rs, m)[0]) for m in (0, 1)], flush=True)
     ctx.set_event_timing(False)
     prof = np.array(prof)
     for b in range(0, n_it, 1000):
