@@ -154,6 +154,91 @@ def batched_candidates(ctx, g, api, synth, n_batches=40, per_batch=8):
             "ms_per_set": 1e3 * dt / (n_batches * per_batch), "pattern": "8 single-edit candidates of one ~900-path assembly per call"}
 
 
+def repeats_block(api, synth, device, sa_iters=5000):
+    """Repeat-rich assemblies, untimed for the headline ("optionally with planted repeats"; GAML's repeat moves,
+    moves.cc:1156-1305, exist for them): (1) cfg3r = config 3's recipe with 2 % of the genome in COLLAPSED 5-copy repeat
+    families -- one node each, visited five times by the true walk, so its windows occur several times in the path set
+    (second launch: paired_general_kernel) -- scored through the same 8 rotating path sets, with the likelihood against
+    the CPU oracle on ALL pairs; (2) the late state of a long synthetic annealing walk at config 3 (duplicated nodes
+    pile up: 60 % of the moves are accepted whatever they do)."""
+    wl = synth.WORKLOADS["cfg3r"]
+    genome, g = wl.build()
+    pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
+    gb, go = g.packed()
+    r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
+    ctx = api.Context(device=device)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *r1, *r2)
+    walk = synth.genome_walk(g)
+    variants_py = path_variants(walk)
+    variants = [api.FlatPaths(v) for v in variants_py]
+    vals = [ctx.score(v) for v in variants]
+    ctx.compact_tables()
+    for _ in range(2):
+        vals = [ctx.score(v) for v in variants]
+    gc.disable()
+    t0 = time.perf_counter()
+    n = 400
+    for i in range(n):
+        ctx.score(variants[i % 8])
+    step_us = (time.perf_counter() - t0) / n * 1e6
+    gc.enable()
+    ctx.set_event_timing(1)
+    ctx.kernel_stats(reset=True)
+    for i in range(128):
+        ctx.score(variants[i % 8])
+    ks, gs = ctx.kernel_stats(reset=True), ctx.debug_general_stats()
+    ctx.set_event_timing(False)
+    out = {"workload": wl.name, "pairs": wl.n_pairs, "walk_nodes": len(walk), "distinct_nodes": len(set(walk)),
+           "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
+           "step_us": step_us, "reads_per_sec": 2.0 * wl.n_pairs / (step_us * 1e-6),
+           "scoring_kernel_us": ks["device_us"] / max(1, ks["launches"]),
+           "general_kernel_us": gs["device_us"] / max(1, gs["launches"]), "general_launches_per_step": gs["launches"] / max(1, ks["launches"]),
+           "algo_bytes_per_launch": ks["algo_bytes"] / max(1, ks["launches"])}
+    ctx.close()
+    # the CPU oracle on all pairs, two path sets (the whole walk; the walk in two pieces): cold, incl. window alignment
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    orc.add_paired(*r1, *r2, wl.err, op.paired_cfg(wl.insert_mean, wl.insert_std))
+    t0 = time.time()
+    want = [orc.calc_prob(v, fresh=True)[0] for v in variants_py[:2]]
+    out["ll_max_rel_delta_vs_cpu"] = max(abs(a - b) / abs(b) for a, b in zip(vals[:2], want))
+    out["ll_delta_pairs"] = wl.n_pairs
+    out["cpu_oracle_s"] = time.time() - t0
+    del orc
+    # (2) late in a long annealing walk at config 3
+    wl3 = synth.WORKLOADS["cfg3"]
+    genome, g = wl3.build()
+    pr = synth.make_paired_reads(genome, wl3.n_pairs, wl3.read_len, wl3.insert_mean, wl3.insert_std, wl3.err, wl3.seed)
+    ctx = api.Context(device=device)
+    ctx.set_graph(*g.packed())
+    rs = ctx.add_paired(api.paired_cfg(wl3.insert_mean, wl3.insert_std), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    start, seq = synth.sa_sequence(g, sa_iters)
+    flat = [api.FlatPaths(p) for p in seq]
+    ctx.calc_prob(start)
+    per = np.zeros(len(flat))
+    gc.disable()
+    for k, f in enumerate(flat):
+        t1 = time.perf_counter()
+        ctx.score(f)
+        per[k] = time.perf_counter() - t1
+    gc.enable()
+    ctx.set_event_timing(1)
+    ctx.kernel_stats(reset=True)
+    for f in flat[-200:]:
+        ctx.score(f)
+    ks, gs = ctx.kernel_stats(reset=True), ctx.debug_general_stats()
+    out["late_annealing_walk"] = {"iterations": sa_iters, "paths_at_end": len(seq[-1]), "call_us_median_last_1000": float(np.median(per[-1000:]) * 1e6),
+                                  "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
+                                  "delta_pairs": ctx.debug_table_stats(rs)["dirty_pairs"],
+                                  "scoring_kernel_us": ks["device_us"] / max(1, ks["launches"]),
+                                  "general_kernel_us": gs["device_us"] / max(1, gs["launches"])}
+    ctx.close()
+    return out
+
+
 def inproc_child(args):
     """`--inproc-devices 0,1,..`: ONE process, one context over those devices (gaml_hip_create_multi) -- what a gaml.cc
     linked against the adapter header runs. Same read set and steps as the headline; prints its own JSON line."""
@@ -194,6 +279,7 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs the CPU baseline scores (0 = the whole read set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sa", action="store_true", help="skip the annealing-pattern block (N = 1)")
+    ap.add_argument("--no-repeats", action="store_true", help="skip the repeat-rich block (N = 1)")
     ap.add_argument("--no-extras", action="store_true", help="timed region only (no kernel-timing pass, batch or annealing block): "
                     "what the rocprofv3 --pmc passes run, so that the last --steps dispatches are the timed steps")
     ap.add_argument("--sa-iters", type=int, default=1000)
@@ -446,6 +532,9 @@ def main():
             if not args.no_sa:
                 out["sa_pattern"] = sa_pattern(ctx, rs, g, args.sa_iters, api, synth)
                 out["batched_candidates"] = batched_candidates(ctx, g, api, synth)
+        if not use_dist and not args.no_extras and not args.no_repeats and not args.no_cpu_baseline:
+            ctx.close()  # (the headline context's tables: ~100 MB of device memory back before two more read sets are built)
+            out["repeats"] = repeats_block(api, synth, local_rank)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is taken on rank 0 at N = 1 only
             pairs = min(args.cpu_sample_pairs or wl.n_pairs, wl.n_pairs)
             cb, cpu_vals = cpu_baseline(gb, go, b1, o1, b2, o2, pairs, wl.read_len, variants_py, cfg)

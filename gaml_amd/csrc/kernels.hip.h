@@ -538,13 +538,35 @@ __device__ __forceinline__ void compact_general(const PairedArgs& a, int i, doub
   const int4 r1 = rec8_to_quad(a.rec8[0][i]), r2 = rec8_to_quad(a.rec8[1][i]);
   const OccList l1 = occ_list(a.m[0], r1.x), l2 = occ_list(a.m[1], r2.x);
   double acc = 0.0;
-  for (int p = 0; p < l1.n; p++) {
-    const Cand x = make_cand(r1, l1.e ? l1.e[p] : l1.one, 0);
-    if (!x.valid) continue;
-    for (int q = 0; q < l2.n; q++) {
-      const Cand y = make_cand(r2, l2.e ? l2.e[q] : l2.one, 0);
-      if (!y.valid || y.path != x.path) continue;
-      acc += pair_term(a, x, y, L1, L2);
+  constexpr int K = 8;
+  if (l1.n <= K && l2.n <= K) {
+    // both lists in registers: 2 K independent loads (one round trip) instead of a load-use chain per combination
+    int4 e1[K], e2[K];
+#pragma unroll
+    for (int p = 0; p < K; p++) {
+      e1[p] = l1.e ? l1.e[p < l1.n ? p : 0] : l1.one;
+      e2[p] = l2.e ? l2.e[p < l2.n ? p : 0] : l2.one;
+    }
+#pragma unroll
+    for (int p = 0; p < K; p++) {
+      const Cand x = make_cand(r1, e1[p], 0);
+      if (p >= l1.n || !x.valid) continue;
+#pragma unroll
+      for (int q = 0; q < K; q++) {
+        const Cand y = make_cand(r2, e2[q], 0);
+        if (q >= l2.n || !y.valid || y.path != x.path) continue;
+        acc += pair_term(a, x, y, L1, L2);
+      }
+    }
+  } else {
+    for (int p = 0; p < l1.n; p++) {
+      const Cand x = make_cand(r1, l1.e[p], 0);
+      if (!x.valid) continue;
+      for (int q = 0; q < l2.n; q++) {
+        const Cand y = make_cand(r2, l2.e[q], 0);
+        if (!y.valid || y.path != x.path) continue;
+        acc += pair_term(a, x, y, L1, L2);
+      }
     }
   }
   finish_read_compact(a, i, acc, lc, lsum, zeros);
@@ -1682,6 +1704,10 @@ __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, in
     const int rel = cls == 0 ? (part_b ? i - a.n0a : i) : (cls == 1 ? i - a.n0 : i - a.n01);
     const unsigned long long word = a.gen_bits[(cls == 0 ? (part_b ? a.gen_w0b : 0) : (cls == 1 ? a.gen_w1 : a.gen_w2)) + (rel >> 6)];
     if (!((word >> (rel & 63)) & 1ull)) continue;
+#ifdef GAML_GEN_X  // timing experiments (results wrong): leave a class of noted pairs out
+    if ((GAML_GEN_X & 1) && cls == 0) continue;
+    if ((GAML_GEN_X & 2) && cls != 0) continue;
+#endif
     if (cls == 0) compact_general(a, i, lsum, zeros);
     else {
       const uint32_t l12 = a.len12[i - a.n0];
@@ -1693,6 +1719,9 @@ __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, in
   // ... and the delta pairs the scoring launch noted (paired_delta_body), one lane per pair, records from the delta lists
   for (int dj = blockIdx.x * kBlock + threadIdx.x; dj < a.n_dirty; dj += gridDim.x * kBlock) {
     if (!((a.gen_bits[a.gen_wd + (dj >> 6)] >> (dj & 63)) & 1ull)) continue;
+#ifdef GAML_GEN_X
+    if (GAML_GEN_X & 4) continue;
+#endif
     const int4 h0 = a.dirty_recs[0][4 * (size_t)dj], h1 = a.dirty_recs[1][4 * (size_t)dj];
     const uint32_t l12 = (uint32_t)h0.w;
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;

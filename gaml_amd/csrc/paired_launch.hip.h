@@ -958,7 +958,7 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   gp.total_blocks = gp.main_blocks + gp.ovf_blocks;
   gp.gen_words[0] = (n0a + 63) / 64 + (n0b + 63) / 64; gp.gen_words[1] = (n01 - n0 + 63) / 64; gp.gen_words[2] = (n_main - n01 + 63) / 64;
   gp.gen_words[3] = ((int64_t)nd + 63) / 64;
-  gp.gen_blocks = n_main > 0 ? (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, kMaxBlocks) : 0;
+  gp.gen_blocks = n_main > 0 ? (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, c->knobs[21] > 0 ? c->knobs[21] : kMaxBlocks) : 0;
   a.blocks0a = gp.blocks0a;
   a.gen_w0b = (int)((n0a + 63) / 64);
   a.blocks0 = gp.blocks0;

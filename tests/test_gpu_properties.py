@@ -161,3 +161,49 @@ def test_cfg5_annealing_pattern_at_full_size_is_history_independent():
     again = ctx.calc_prob_batch([seq[999], seq[149], seq[60], seq[5]])
     for b, k in zip(again, (999, 149, 60, 5)):
         assert abs(b[0] - vals[k][0]) <= 1e-12 * abs(vals[k][0])
+
+
+def test_collapsed_repeats_at_1mbp_against_the_oracle():
+    """A repeat-rich assembly, the case GAML's repeat moves exist for (FixBigReps / FixRepForNode2, moves.cc:1156-1305):
+    1 Mbp with 3 % of the genome in COLLAPSED 5-copy repeat families (one node each, visited five times by the true
+    walk). The families' windows occur several times in the path set, so their reads take the second launch
+    (paired_general_kernel) and the wave-per-pair blocks. All 170,000 pairs against the oracle: the whole walk, the walk
+    cut inside and outside repeats, a repeat dropped, the twin walk, a batch; then the same sets again over rebuilt tables
+    (static indices, delta lists folded in)."""
+    import oracle_py as op
+    from gaml_amd import api
+    genome, g = synth.make_repeat_graph(1_000_000, 424242, frac=0.03)
+    n = 170_000
+    pr = synth.make_paired_reads(genome, n, 150, 300.0, 30.0, 0.01, 424242)
+    r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
+    walk = synth.genome_walk(g)
+    from collections import Counter
+    rep = [x for x, c in Counter(walk).items() if c > 1]
+    assert len(rep) >= 2 and len(walk) > len(set(walk)) + 6
+    at = walk.index(rep[0])
+    k = len(walk) // 2
+    sets = [[walk], [walk[:at + 1], walk[at + 1:]], [walk[:k], walk[k:]], [walk[:at] + walk[at + 1:]],
+            [[x ^ 1 for x in reversed(walk)]], [walk[:k] + [-120] + walk[k + 2:], walk[max(0, at - 3):at + 4]]]
+    ctx = api.Context(device=0)
+    ctx.set_graph(*g.packed())
+    rs = ctx.add_paired(api.paired_cfg(300.0, 30.0), *r1, *r2)
+    orc = op.Oracle()
+    orc.set_graph(*g.packed())
+    ors = orc.add_paired(*r1, *r2, 0.01, op.paired_cfg(300.0, 30.0))
+    want = []
+    for rnd in range(2):
+        for i, paths in enumerate(sets):
+            got = ctx.calc_prob(paths)
+            if rnd == 0:
+                w = orc.calc_prob(paths, fresh=True)
+                want.append((w, orc.paired_probs(ors)[0].copy()))
+            w, wprobs = want[i]
+            assert got[2] == w[2] and got[1].tolist() == w[1].tolist(), (rnd, i)
+            np.testing.assert_allclose(ctx.read_probs(rs), wprobs, rtol=4e-16, atol=0)
+            assert abs(got[0] - w[0]) <= 1e-9 * abs(w[0])
+        batch = ctx.calc_prob_batch(sets)
+        for b, (w, _) in zip(batch, want):
+            assert b[1].tolist() == w[1].tolist() and abs(b[0] - w[0]) <= 1e-9 * abs(w[0])
+        ctx.compact_tables()
+    c = ctx.debug_class_counts(rs)
+    assert c[3] > 0 or c[2] > 0  # reads at the ends of a repeat are seen through several junction windows
