@@ -154,6 +154,59 @@ def batched_candidates(ctx, g, api, synth, n_batches=40, per_batch=8):
             "ms_per_set": 1e3 * dt / (n_batches * per_batch), "pattern": "8 single-edit candidates of one ~900-path assembly per call"}
 
 
+def drift_block(api, synth, device, g, b1, o1, b2, o2, read_len, cfg, iters=1000, sample=50_000):
+    """The reference keeps its per-read probabilities across calls and updates them in place (probs[i] -= old term,
+    += new term: graph.cc:1936-1950); the GPU path rescores every read from scratch. Over BASELINE config 5's call
+    pattern, on the first `sample` pairs: the CPU oracle in the reference's INCREMENTAL mode against the GPU value along
+    the same `iters` path sets -- how far the long-running state drifts, how many accept decisions `new > cur`
+    (gaml.cc:286) come out differently, and how many reads end up scored from a rounding residue instead of the floor
+    ("Incremental FP drift"). The oracle from scratch at checkpoints separates drift from GPU-vs-CPU delta."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    nb = sample * read_len
+    sb1, so1, sb2, so2 = b1[:nb], o1[:sample + 1], b2[:nb], o2[:sample + 1]
+    gb, go = g.packed()
+    start, seq, parent = synth.sa_sequence_parents(g, iters)
+    ctx = api.Context(device=device)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_paired(api.paired_cfg(*cfg), sb1, so1, sb2, so2)
+    gpu0 = ctx.calc_prob(start)[0]
+    gpu = [ctx.calc_prob(p)[0] for p in seq]
+    gpu_probs_end = ctx.read_probs(rs)
+    ctx.close()
+    inc = op.Oracle()
+    inc.set_graph(gb, go)
+    irs = inc.add_paired(sb1, so1, sb2, so2, 0.01, op.paired_cfg(*cfg))
+    t0 = time.time()
+    ref0 = inc.calc_prob(start, fresh=False)[0]
+    ref = [inc.calc_prob(p, fresh=False)[0] for p in seq]
+    inc_s = time.time() - t0
+    inc_probs_end = inc.paired_probs(irs)[0].copy()
+    checks = sorted({iters - 1, iters // 2, iters // 10})
+    fresh_delta = 0.0
+    for k in checks:
+        want = inc.calc_prob(seq[k], fresh=True)[0]  # (a fresh state on the same window cache; resets the incremental one)
+        fresh_delta = max(fresh_delta, abs(gpu[k] - want) / abs(want))
+    rel = np.array([abs(a - b) / abs(b) for a, b in zip(gpu, ref)])
+    cur_gpu = [gpu0 if p < 0 else gpu[p] for p in parent]
+    cur_ref = [ref0 if p < 0 else ref[p] for p in parent]
+    margin = np.array([abs(b - cb) / abs(cb) for b, cb in zip(ref, cur_ref)])
+    differ = np.array([(a > ca) != (b > cb) for a, ca, b, cb in zip(gpu, cur_gpu, ref, cur_ref)])
+    flips = int(differ.sum())
+    # a move that leaves the likelihood unchanged up to rounding (a path reversed, a gap trimmed) is a coin toss in BOTH
+    # implementations: the reference's own result for it depends on the order of its += / -= updates
+    flips_real = int((differ & (margin > 1e-12)).sum())
+    residue = int(np.count_nonzero((gpu_probs_end == 0.0) & (inc_probs_end != 0.0)))
+    neg = int(np.count_nonzero(inc_probs_end < 0.0))
+    return {"pairs": sample, "iterations": iters, "what": "CPU oracle with the reference's incremental ScoringState (graph.cc:1936-1950) vs the GPU value, same path sets",
+            "ll_rel_delta_max": float(rel.max()), "ll_rel_delta_mean": float(rel.mean()), "ll_rel_delta_last": float(rel[-1]),
+            "accept_decisions_that_differ": flips, "of_which_with_a_margin_above_1e-12": flips_real,
+            "moves_within_1e-12_of_a_tie": int((margin <= 1e-12).sum()),
+            "smallest_rel_margin_above_1e-12": float(margin[margin > 1e-12].min()) if (margin > 1e-12).any() else 0.0,
+            "reads_scored_from_a_residue_at_the_end": residue, "reads_with_negative_probability_at_the_end": neg,
+            "gpu_vs_fresh_oracle_rel_delta_max_at_checkpoints": fresh_delta, "checkpoints": checks, "oracle_incremental_s": inc_s}
+
+
 def repeats_block(api, synth, device, sa_iters=5000):
     """Repeat-rich assemblies, untimed for the headline ("optionally with planted repeats"; GAML's repeat moves,
     moves.cc:1156-1305, exist for them): (1) cfg3r = config 3's recipe with 2 % of the genome in COLLAPSED 5-copy repeat
@@ -535,6 +588,7 @@ def main():
         if not use_dist and not args.no_extras and not args.no_repeats and not args.no_cpu_baseline:
             ctx.close()  # (the headline context's tables: ~100 MB of device memory back before two more read sets are built)
             out["repeats"] = repeats_block(api, synth, local_rank)
+            out["incremental_drift"] = drift_block(api, synth, local_rank, g, b1, o1, b2, o2, wl.read_len, cfg)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is taken on rank 0 at N = 1 only
             pairs = min(args.cpu_sample_pairs or wl.n_pairs, wl.n_pairs)
             cb, cpu_vals = cpu_baseline(gb, go, b1, o1, b2, o2, pairs, wl.read_len, variants_py, cfg)

@@ -480,16 +480,24 @@ def sa_move(rng, paths, g):
 def sa_sequence(g, iters: int, seed: int = 7, threshold: int = 500):
     """BASELINE config 5's call pattern: the reference's start state (every long node a one-node walk,
     gaml.cc:1002-1005) and `iters` edited path sets, 60 % of the edits accepted."""
+    start, seq, _ = sa_sequence_parents(g, iters, seed, threshold)
+    return start, seq
+
+
+def sa_sequence_parents(g, iters: int, seed: int = 7, threshold: int = 500):
+    """sa_sequence plus, per edited path set, the index of the set it was derived from (-1: the start state) -- the
+    "current" assembly whose likelihood the annealing loop compares the new one with (gaml.cc:286)."""
     walk = genome_walk(g)
     start = [[x] for x in walk if g.node_len(x) > threshold]
     rng = np.random.default_rng(seed)
-    seq, cur = [], start
-    for _ in range(iters):
+    seq, parent, cur, cur_idx = [], [], start, -1
+    for k in range(iters):
         new = sa_move(rng, cur, g)
         seq.append(new)
+        parent.append(cur_idx)
         if rng.random() < 0.6:
-            cur = new
-    return start, seq
+            cur, cur_idx = new, k
+    return start, seq, parent
 
 
 def flatten_paths(paths: list[list[int]]):

@@ -147,7 +147,14 @@ def test_cfg5_annealing_pattern_at_full_size_is_history_independent():
         seq.append(new)
         if rng.random() < 0.6:
             cur = new
-    vals = [ctx.calc_prob(p) for p in seq]
+    # at checkpoints: the per-read probabilities of the first 50,000 pairs as the long-lived context holds them (delta
+    # store, worker rebuilds, static indices: whatever state the walk has put the tables in by then)
+    n_or, checks = 50_000, (999, 700, 149, 60, 5)
+    vals, kept = [], {}
+    for it, p in enumerate(seq):
+        vals.append(ctx.calc_prob(p))
+        if it in checks:
+            kept[it] = ctx.read_probs(rs)[:n_or].copy()
     stats = ctx.debug_table_stats(rs)
     assert stats["delta_updates"] > 5  # the delta path really ran
     fresh = api.Context(device=0)
@@ -161,6 +168,27 @@ def test_cfg5_annealing_pattern_at_full_size_is_history_independent():
     again = ctx.calc_prob_batch([seq[999], seq[149], seq[60], seq[5]])
     for b, k in zip(again, (999, 149, 60, 5)):
         assert abs(b[0] - vals[k][0]) <= 1e-12 * abs(vals[k][0])
+    # ... and against the ORACLE with a fresh scoring state on those 50,000 pairs (reference graph.cc:1952-1989 evaluated
+    # from scratch): per-read probabilities, and the likelihood of those pairs recomputed from the GPU's probabilities by
+    # GetTotalProb's formula (graph.cc:1495-1516). A pair's probability does not depend on the other pairs -- except
+    # through the position filter's window maxima (graph.cc:577), which only ever drops a record that an earlier window
+    # holds at the same path position.
+    import oracle_py as op
+    orc = op.Oracle()
+    orc.set_graph(*g.packed())
+    ors = orc.add_paired(*synth.pack_reads(pr.mate1[:n_or]), *synth.pack_reads(pr.mate2[:n_or]), wl.err,
+                         op.paired_cfg(wl.insert_mean, wl.insert_std))
+    cfg = api.paired_cfg(wl.insert_mean, wl.insert_std)
+    for k in checks:
+        want, wz, wtl = orc.calc_prob(seq[k], fresh=True)
+        wprobs, _ = orc.paired_probs(ors)
+        np.testing.assert_allclose(kept[k], wprobs, rtol=4e-16, atol=0)
+        assert wtl == vals[k][2]
+        floor = np.exp(cfg.min_prob_start + cfg.min_prob_per_base * 2 * wl.read_len)
+        pr_k = kept[k] / (2.0 * max(1, wtl))
+        ll = np.where(pr_k < floor, np.log(floor), np.log(np.maximum(pr_k, 1e-300))).mean()
+        assert int((pr_k < floor).sum()) == int(wz[0][0])
+        assert abs(ll - want) <= 1e-12 * abs(want), (k, ll, want)
 
 
 def test_collapsed_repeats_at_1mbp_against_the_oracle():

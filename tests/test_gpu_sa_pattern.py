@@ -166,3 +166,39 @@ def test_rebuild_on_the_worker_thread_takes_over_mid_walk():
     st = ctxs[0].debug_table_stats(0)
     assert st["worker_rebuilds"] >= 1, st
     assert ctxs[1].debug_table_stats(0)["worker_rebuilds"] == 0 and ctxs[1].debug_table_stats(0)["full_rebuilds"] >= 2
+
+
+def test_worker_take_overs_at_the_large_table_scale_against_the_oracle():
+    """The rebuild machinery at the scale where build_pair_tables takes its multi-threaded branch (>= 2^16 pairs): 90,000
+    pairs, tables rebuilt when the delta lists pass pairs / 64 (knob 18) and taken over 24 evaluations after the worker
+    started (knob 14), so that several take-overs -- snapshot in slices, second delta store, re-basing of what was
+    activated meanwhile, windows retired while a snapshot is copied -- happen within a few hundred annealing steps.
+    Value, floored count and per-read probabilities against the ORACLE (fresh scoring state) at every step."""
+    import oracle_py as op
+    from gaml_amd import api
+    G, n, seed = 600_000, 90_000, 31
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(800, 5000)))
+    pr = synth.make_paired_reads(genome, n, 100, 240.0, 24.0, 0.01, seed)
+    r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
+    ctx = api.Context(device=0)
+    ctx.set_graph(*g.packed())
+    rs = ctx.add_paired(api.paired_cfg(240.0, 24.0), *r1, *r2)
+    ctx.debug_set_knob(14, 24)
+    ctx.debug_set_knob(18, 64)
+    orc = op.Oracle()
+    orc.set_graph(*g.packed())
+    ors = orc.add_paired(*r1, *r2, 0.01, op.paired_cfg(240.0, 24.0))
+    start, seq = synth.sa_sequence(g, 260, seed=13, threshold=400)
+    seen = 0
+    for k, ps in enumerate([start] + seq):
+        got = ctx.calc_prob(ps)
+        want, wz, wtl = orc.calc_prob(ps, fresh=True)
+        assert got[2] == wtl and got[1].tolist() == wz.tolist(), k
+        assert abs(got[0] - want) <= 1e-9 * abs(want), (k, got[0], want)
+        w = ctx.debug_table_stats(rs)["worker_rebuilds"]
+        if w != seen or k % 40 == 0:  # right after a take-over, and now and then
+            np.testing.assert_allclose(ctx.read_probs(rs), orc.paired_probs(ors)[0], rtol=4e-16, atol=0)
+            seen = w
+    st = ctx.debug_table_stats(rs)
+    assert st["worker_rebuilds"] >= 3 and st["delta_updates"] > 20, st
