@@ -415,6 +415,7 @@ struct gaml_hip_ctx {
   std::vector<std::unique_ptr<PairedPrep>> pending_prep;  // per paired set
   double pending_host_us = 0;
   double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // phase stamps of the last blocking call (us): see gaml_hip_debug_profile
+  bool used_default_stream = false;  // an *_async entry point was handed NULL (the legacy default stream) since the last gaml_hip_sync
   bool host_results = false;  // blocking call: kernels write their results into pinned host memory, no D2H copy
   // sharded evaluation with a coverage penalty: sweeps wait for the other ranks' coverage maps
   bool defer_cov = false;

@@ -1886,11 +1886,21 @@ int gaml_hip_eval_apply_maxpos(gaml_hip_ctx* c, const int32_t* reduced, int64_t 
   return GAML_HIP_OK;
 }
 
+// The stream a caller names. NULL is the legacy default stream -- what `torch.cuda.current_stream().cuda_stream` is on
+// torch's default stream -- and is used as such: the library's work is then ordered against everything else the caller
+// has on that stream, like any other handle. (Until round 3 NULL selected the context's PRIVATE stream: three contexts
+// of one process handed NULL worked on three unrelated streams, unordered against the caller's copies -- a sharded
+// coverage penalty came out as 2771 bad bases instead of 694, silently.) gaml_hip_sync covers it.
+static hipStream_t caller_stream(gaml_hip_ctx* c, void* stream) {
+  if (!stream) c->used_default_stream = true;
+  return (hipStream_t)stream;
+}
+
 int gaml_hip_eval_finish_async(gaml_hip_ctx* c, void* d_partials, void* stream) {
   if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   MULTI_REFUSE(c, "the gaml_hip_eval_* protocol is for one shard per process");
   if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
-  return eval_finish(c, d_partials, stream ? (hipStream_t)stream : c->stream);
+  return eval_finish(c, d_partials, caller_stream(c, stream));
 }
 
 int32_t gaml_hip_eval_score_async(gaml_hip_ctx* c, void* d_partials, void* stream) {
@@ -1900,7 +1910,7 @@ int32_t gaml_hip_eval_score_async(gaml_hip_ctx* c, void* d_partials, void* strea
   c->pending_cov.clear();
   c->pending_pb.clear();
   c->defer_cov = c->peers > 1;
-  const int e = eval_finish(c, d_partials, stream ? (hipStream_t)stream : c->stream);
+  const int e = eval_finish(c, d_partials, caller_stream(c, stream));
   c->defer_cov = false;
   if (e) { c->pending_cov.clear(); c->pending_pb.clear(); return e; }
   return (int32_t)c->pending_cov.size();
@@ -1920,7 +1930,7 @@ int gaml_hip_eval_pacbio_export_async(gaml_hip_ctx* c, int32_t i, void* dst, int
   HIP_TRY(c, hipSetDevice(c->device));
   PacbioSet& s = *c->pacbios[pb.pacbio_idx];
   if (pb.n_own > 0)
-    HIP_TRY(c, hipMemcpyAsync(dst, s.sweep.all.as<int4>() + pb.n_node, (size_t)pb.n_own * sizeof(int4), hipMemcpyDeviceToDevice, stream ? (hipStream_t)stream : c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dst, s.sweep.all.as<int4>() + pb.n_node, (size_t)pb.n_own * sizeof(int4), hipMemcpyDeviceToDevice, caller_stream(c, stream)));
   return GAML_HIP_OK;
 }
 
@@ -1928,7 +1938,7 @@ int gaml_hip_eval_pacbio_finish_async(gaml_hip_ctx* c, int32_t i, const void* in
   if (!c || i < 0 || i >= (int32_t)c->pending_pb.size() || n_intervals < 0 || (n_intervals > 0 && !intervals) || n_intervals > ((int64_t)1 << 28))
     return fail(c, GAML_HIP_EINVAL, "bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t st = caller_stream(c, stream);
   const gaml_hip_ctx::PendingPacbio& pb = c->pending_pb[i];
   PacbioSet& s = *c->pacbios[pb.pacbio_idx];
   PbSweepDev& d = s.sweep;
@@ -1954,14 +1964,14 @@ int gaml_hip_eval_coverage_export_async(gaml_hip_ctx* c, int32_t i, void* dst, i
   if (!dst) return GAML_HIP_OK;  // size query
   if (cap < bytes) return fail(c, GAML_HIP_EINVAL, "coverage map does not fit the destination");
   HIP_TRY(c, hipSetDevice(c->device));
-  if (bytes > 0) HIP_TRY(c, hipMemcpyAsync(dst, c->pending_cov[i].args.bits, (size_t)bytes, hipMemcpyDeviceToDevice, stream ? (hipStream_t)stream : c->stream));
+  if (bytes > 0) HIP_TRY(c, hipMemcpyAsync(dst, c->pending_cov[i].args.bits, (size_t)bytes, hipMemcpyDeviceToDevice, caller_stream(c, stream)));
   return GAML_HIP_OK;
 }
 
 int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* c, int32_t i, const void* maps, int32_t n_maps, int32_t contribute, void* stream) {
   if (!c || i < 0 || i >= (int32_t)c->pending_cov.size() || n_maps < 0 || (n_maps > 0 && !maps)) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t st = caller_stream(c, stream);
   const gaml_hip_ctx::PendingCov& pc = c->pending_cov[i];
   PairedSet& s = *c->paireds[pc.paired_idx];
   if (pc.args.total_words > 0) {
@@ -2059,7 +2069,7 @@ int gaml_hip_fetch_async(gaml_hip_ctx* c, const void* d_src, int32_t n_doubles, 
     HIP_TRY(c, c->fetch_host.reserve(bytes));
     memset(c->fetch_host.p, 0, c->fetch_host.cap);
   }
-  c->fetch_stream = stream ? (hipStream_t)stream : c->stream;
+  c->fetch_stream = caller_stream(c, stream);
   c->fetch_seq++;
   char* dev = (char*)c->fetch_host.dev;
   hipLaunchKernelGGL(fetch_kernel, dim3(1), dim3(64), 0, c->fetch_stream, (const double*)d_src, (int)n_doubles, (double*)(dev + 512),
@@ -2092,6 +2102,7 @@ int gaml_hip_sync(gaml_hip_ctx* c) {
   if (!c || c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "no device");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->used_default_stream) { HIP_TRY(c, hipStreamSynchronize(nullptr)); c->used_default_stream = false; }  // (an *_async call was handed NULL)
   return GAML_HIP_OK;
 }
 
@@ -2118,7 +2129,7 @@ int gaml_hip_calc_partials_async(gaml_hip_ctx* c, const int32_t* paths, const in
   if (!c || !d_partials) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   MULTI_REFUSE(c, "partials of several devices have no single device address; use gaml_hip_calc_partials");
   if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
-  return evaluate(c, paths, offs, n_paths, d_partials, stream ? (hipStream_t)stream : c->stream, total_len_out);
+  return evaluate(c, paths, offs, n_paths, d_partials, caller_stream(c, stream), total_len_out);
 }
 
 int gaml_hip_calc_partials(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths,

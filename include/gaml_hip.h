@@ -269,9 +269,9 @@ int gaml_hip_compact_tables(gaml_hip_ctx* ctx);
  *         n_intervals gathered intervals of all ranks (this rank's among them) in device memory; sorts them
  *         together with the contigs' node intervals, runs the sweep on the device and stores bad_bases into the
  *         partials like the paired form. No interval ever visits the host.
- * `stream` everywhere here: a real stream handle the caller orders its own copies and collectives on; NULL selects the
- * context's private stream -- not the legacy default stream (several contexts of one process handed NULL work on
- * several unrelated streams). */
+ * `stream` everywhere here: the stream the caller orders its own copies and collectives on. NULL is the legacy default
+ * stream (what torch.cuda.current_stream().cuda_stream is on torch's default stream) and is used as such -- the
+ * library's work is ordered against the caller's other work on it like on any other handle. */
 int32_t gaml_hip_eval_score_async(gaml_hip_ctx* ctx, void* d_partials, void* stream);
 int gaml_hip_eval_coverage_export_async(gaml_hip_ctx* ctx, int32_t i, void* dst, int64_t cap, int64_t* bytes_out, void* stream);
 int gaml_hip_eval_coverage_finish_async(gaml_hip_ctx* ctx, int32_t i, const void* maps, int32_t n_maps, int32_t contribute,
@@ -284,9 +284,8 @@ int gaml_hip_eval_pacbio_finish_async(gaml_hip_ctx* ctx, int32_t i, const void* 
 
 /* Device-resident form for callers that already own a HIP stream (e.g. torch): enqueue the
  * whole evaluation on `stream` and leave the 4*n_sets partials in device memory at
- * d_partials (f64). No host synchronisation. `hip_stream` must be a real stream handle the caller
- * orders its own work on; NULL selects the library's private stream (then synchronise with
- * gaml_hip_sync before touching d_partials) -- NOT the legacy default stream. */
+ * d_partials (f64). No host synchronisation. `hip_stream`: the stream the caller orders its own work
+ * on; NULL is the legacy default stream (gaml_hip_sync waits for it as well as for the library's own). */
 int gaml_hip_calc_partials_async(gaml_hip_ctx* ctx, const int32_t* paths, const int64_t* path_offs, int32_t n_paths,
                                  void* d_partials, void* hip_stream, int32_t* total_len_out);
 

@@ -302,7 +302,8 @@ def test_sharded_context_refuses_coverage_penalty():
     assert e.value.code == api.ESTATE and "coverage" in str(e.value)
 
 
-def test_sharded_coverage_penalty_merges_the_ranks_maps():
+@pytest.mark.parametrize("stream_kind", ["explicit", "default"])
+def test_sharded_coverage_penalty_merges_the_ranks_maps(stream_kind):
     """penalty_constant > 0 on a sharded paired set (the one non-separable piece): bad_bases
     depends on the union of all ranks' coverage marks. Three shards on one GPU play the ranks; the
     all-gather a multi-process run does over RCCL is a torch.cat here. Low coverage, so that every
@@ -332,11 +333,14 @@ def test_sharded_coverage_penalty_merges_the_ranks_maps():
     reduced = np.maximum.reduce([c.eval_pending_maxpos() for c in shards])
     for c in shards:
         c.eval_apply_maxpos(reduced)
-    # ONE explicit stream for the library's work and for torch's (a null stream handle would make every context fall
-    # back to its OWN stream, unordered against torch's copies: the three "ranks" share one process here)
-    ts = torch.cuda.Stream()
+    # ONE stream for the library's work and for torch's: an explicit one, or torch's default stream -- whose handle is 0,
+    # the legacy default stream, which the library uses as such. (Until round 3 a null handle made every context fall
+    # back to its OWN private stream, unordered against torch's copies -- the three "ranks" share one process here --
+    # and this test read 2771 bad bases instead of 694.)
+    ts = torch.cuda.Stream() if stream_kind == "explicit" else torch.cuda.default_stream()
     torch.cuda.set_stream(ts)
     stream = ts.cuda_stream
+    assert (stream == 0) == (stream_kind == "default")
     parts = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in shards]
     maps = []
     for c, p in zip(shards, parts):
@@ -370,7 +374,8 @@ def test_sharded_coverage_penalty_merges_the_ranks_maps():
         c.eval_finish()
 
 
-def test_sharded_pacbio_penalty_merges_the_ranks_intervals():
+@pytest.mark.parametrize("stream_kind", ["explicit", "default"])
+def test_sharded_pacbio_penalty_merges_the_ranks_intervals(stream_kind):
     """A PacBio set with penalty_constant > 0 on sharded contexts: bad_bases (graph.cc:3198-3250) sweeps the
     alignment intervals of ALL reads, so the ranks exchange their interval lists (device memory). Three shards on one GPU
     play the ranks; sparse long reads leave uncovered stretches that only the union closes."""
@@ -396,7 +401,7 @@ def test_sharded_pacbio_penalty_merges_the_ranks_intervals():
     bad_whole = whole.bad_bases(wrs)
     assert bad_whole > 0
     shards = [make(r, 3)[0] for r in range(3)]
-    ts = torch.cuda.Stream()  # one explicit stream for the library's work and torch's (see the coverage test above)
+    ts = torch.cuda.Stream() if stream_kind == "explicit" else torch.cuda.default_stream()  # (see the coverage test above)
     torch.cuda.set_stream(ts)
     stream = ts.cuda_stream
     parts = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in shards]

@@ -202,3 +202,69 @@ def test_worker_take_overs_at_the_large_table_scale_against_the_oracle():
             seen = w
     st = ctx.debug_table_stats(rs)
     assert st["worker_rebuilds"] >= 3 and st["delta_updates"] > 20, st
+
+
+@pytest.mark.parametrize("phase", ["snapshot", "worker"])
+def test_destroy_and_compact_while_a_rebuild_is_in_flight(phase):
+    """Lifecycle around the rebuild worker (paired_launch.hip.h: paired_start_async_rebuild .. paired_finish_async_rebuild):
+    a context is DESTROYED, and another one asked to compact its tables (a rebuild on the calling thread), while a worker
+    rebuild is between "decided" and "taken over" -- during the sliced private copy (state 4: 140,000 pairs hold more
+    active records than one slice copies) and while / after the worker thread builds (state 1 / 2, take-over far away).
+    Nothing may abort (a joinable std::thread destroyed, buffers released under the worker), and the compacted context
+    must go on giving the values of a context that never had a worker."""
+    from gaml_amd import api
+    G, n, seed = 900_000, 140_000, 57
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=(1000, 6000)))
+    pr = synth.make_paired_reads(genome, n, 100, 240.0, 24.0, 0.01, seed)
+    r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 2
+
+    def make(knobs):
+        c = api.Context(device=0)
+        c.set_graph(*g.packed())
+        c.add_paired(api.paired_cfg(240.0, 24.0), *r1, *r2)
+        for kk, v in knobs.items():
+            c.debug_set_knob(kk, v)
+        return c
+
+    def into_flight(c):
+        """tables built over the single-node windows, then every junction window activates at once: the delta lists pass
+        the threshold and a worker rebuild is decided in that call"""
+        c.calc_prob([[x] for x in walk])
+        c.compact_tables()
+        c.calc_prob([[x] for x in walk])
+        before = c.debug_table_stats(0)
+        v = c.calc_prob([walk])
+        if phase == "worker":  # two more calls: the sliced copy completes, the worker thread starts (and may finish)
+            c.calc_prob([walk[:k], walk[k:]])
+            c.calc_prob([walk])
+        st = c.debug_table_stats(0)
+        assert st["dirty_pairs"] > 4096 and st["worker_rebuilds"] == before["worker_rebuilds"]  # decided, not taken over
+        return v
+
+    ref = make({14: 1})  # rebuilds on the calling thread only
+    want = [ref.calc_prob(p) for p in ([[x] for x in walk], [walk], [walk[:k], walk[k:]], [walk])]
+    # (1) destroy in flight, several times (the worker is at a different point each time)
+    for _ in range(3):
+        c = make({14: 100000})
+        into_flight(c)
+        c.close()
+    # (2) compact in flight: the calling thread joins the worker, discards or uses its tables, rebuilds -- values unchanged
+    c = make({14: 100000})
+    v = into_flight(c)
+    assert v[1].tolist() == want[1][1].tolist() and abs(v[0] - want[1][0]) <= 1e-12 * abs(want[1][0])
+    c.compact_tables()
+    for p, w in zip(([walk], [walk[:k], walk[k:]], [[x] for x in walk]), (want[1], want[2], want[0])):
+        got = c.calc_prob(p)
+        assert got[1].tolist() == w[1].tolist() and got[2] == w[2] and abs(got[0] - w[0]) <= 1e-12 * abs(w[0])
+    assert c.debug_table_stats(0)["dirty_pairs"] < 4096  # (the lists were folded in; what the calls above activated is new)
+    # (3) ... and a second worker rebuild right after that one (the thread object is reused)
+    c.calc_prob([[x ^ 1 for x in reversed(walk)]])  # the twin walk: as many new windows again
+    c.calc_prob([walk])
+    c.compact_tables()
+    got = c.calc_prob([walk])
+    assert abs(got[0] - want[1][0]) <= 1e-12 * abs(want[1][0])
+    c.close()
+    ref.close()
