@@ -298,11 +298,13 @@ class Context:
         return _lib.gaml_hip_num_shards(self._h)
 
     def set_exchange(self, mode: str):
-        """'rccl' (all-reduce on the shards' streams) or 'host' (pinned-host partials summed in rank order)."""
-        self._check(_lib.gaml_hip_set_exchange(self._h, {"host": 0, "rccl": 1}[mode]))
+        """'rccl' (all-gather of the shards' partials on their streams, summed in rank order by every shard: the default
+        when every shard has its own GPU), 'rccl-allreduce' (ncclAllReduce(sum): RCCL's order of additions) or 'host'
+        (pinned-host partials summed in rank order by the calling thread)."""
+        self._check(_lib.gaml_hip_set_exchange(self._h, {"host": 0, "rccl": 1, "rccl-allreduce": 2}[mode]))
 
     def exchange(self) -> str:
-        return {0: "host", 1: "rccl"}[self._check(_lib.gaml_hip_get_exchange(self._h))]
+        return {0: "host", 1: "rccl", 2: "rccl-allreduce"}[self._check(_lib.gaml_hip_get_exchange(self._h))]
 
     def last_error(self) -> str:
         return _lib.gaml_hip_last_error(self._h).decode()

@@ -1186,6 +1186,24 @@ void ctx_note_reduced(gaml_hip_ctx* c, const double* partials) {
     else if (order[k].kind == 2) c->pacbios[order[k].idx]->last_bad_bases = (int64_t)partials[4 * k + 2];
   }
 }
+int ctx_fetch_wait_bounded(gaml_hip_ctx* c, double* out, int32_t n_doubles, double timeout_s) {
+  if (!c || !out || n_doubles <= 0 || !c->fetch_host.p) return fail(c, GAML_HIP_EINVAL, "bad arguments / no fetch in flight");
+  volatile unsigned long long* word = (volatile unsigned long long*)c->fetch_host.p;
+  const double t0 = now_us(), limit = timeout_s * 1e6;
+  unsigned spins = 0;
+  while (*word != c->fetch_seq) {
+    if ((++spins & 1023u) == 0) {
+      const double waited = now_us() - t0;
+      if (waited > limit) return 1;
+      if (waited > 5000.0) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (a collective that takes milliseconds: stop burning the core)
+    }
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  memcpy(out, (const char*)c->fetch_host.p + 512, (size_t)n_doubles * sizeof(double));
+  return 0;
+}
+void ctx_eval_abandon(gaml_hip_ctx* c) { if (c) { c->pending_open = false; c->pending_cov.clear(); c->pending_pb.clear(); } }
 bool ctx_has_penalty(const gaml_hip_ctx* c) {
   for (auto& ps : c->paireds) if (ps->cfg.penalty_constant > 0) return true;
   for (auto& ps : c->pacbios) if (ps->cfg.penalty_constant > 0) return true;

@@ -31,6 +31,12 @@ gaml_hip_ctx* ctx_new_parent();
 void ctx_note_reduced(gaml_hip_ctx* c, const double* partials);
 // does any paired / PacBio read set carry a coverage penalty (the non-separable piece)?
 bool ctx_has_penalty(const gaml_hip_ctx* c);
+// gaml_hip_fetch_wait that gives up: polls the fetch's sequence word for at most timeout_s seconds (never an unbounded
+// stream synchronise -- a collective whose peer died never completes). Returns 1 on time-out, < 0 on error, 0 when done.
+int ctx_fetch_wait_bounded(gaml_hip_ctx* c, double* out, int32_t n_doubles, double timeout_s);
+// close an evaluation that gaml_hip_eval_begin opened and that will not be finished (another shard failed)
+void ctx_eval_abandon(gaml_hip_ctx* c);
+
 
 // ---- implemented in multi.hip ------------------------------------------------------------------------------
 void multi_destroy(MultiState* m);

@@ -48,6 +48,7 @@ struct Rccl {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;  // (optional)
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -67,6 +68,7 @@ Rccl* rccl() {
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
     r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
@@ -93,8 +95,20 @@ struct DevMem {  // grow-only device buffer (the caller synchronises the stream 
 struct CommState {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
-  DevMem part, small, own, all, pack;  // partials (f64) | maxima, sizes | this rank's map / intervals | the gathered ones | the gathered intervals, contiguous
+  int mode = 0;       // hot-path exchange: 0 all-gather of the ranks' partials, summed in RANK ORDER by every rank; 1 all-reduce(sum)
+  bool dead = false;  // aborted after a time-out: every later evaluation fails at once
+  double timeout_s = 60.0;
+  DevMem part, small, own, all, pack, gath;  // partials (f64) + 2 status words | maxima, sizes | this rank's map / intervals | the gathered ones | the gathered intervals, contiguous | every rank's partials
 };
+
+// one block writes two doubles behind a rank's partials: its status for the exchange (no host-to-device copy command)
+__global__ void comm_status_kernel(double* at, double a, double b) { if (threadIdx.x == 0 && blockIdx.x == 0) { at[0] = a; at[1] = b; } }
+
+static double comm_timeout_s() {
+  const char* e = getenv("GAML_HIP_COMM_TIMEOUT_S");
+  const double v = e ? atof(e) : 0.0;
+  return v > 0.0 ? v : 60.0;
+}
 
 #define COMM_HIP(c, expr)                                                                            \
   do {                                                                                               \
@@ -109,8 +123,8 @@ struct CommState {
 
 void comm_destroy(CommState* s) {
   if (!s) return;
-  if (s->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(s->comm);
-  s->part.release(); s->small.release(); s->own.release(); s->all.release(); s->pack.release();
+  if (s->comm && !s->dead && rccl()->CommDestroy) (void)rccl()->CommDestroy(s->comm);  // (an aborted communicator is gone already)
+  s->part.release(); s->small.release(); s->own.release(); s->all.release(); s->pack.release(); s->gath.release();
   delete s;
 }
 
@@ -118,9 +132,10 @@ namespace {
 
 // phase 1 of a sharded evaluation: registration / alignment, then the largest record position of every newly
 // aligned window as a maximum over ALL ranks' reads (the reference's position filter, graph.cc:577)
-int comm_begin(gaml_hip_ctx* c, CommState* s, const int32_t* paths, const int64_t* offs, int32_t n_paths, int32_t* tl) {
+int comm_begin(gaml_hip_ctx* c, CommState* s, const int32_t* paths, const int64_t* offs, int32_t n_paths, int32_t* tl, int64_t* aligned) {
   int64_t pending = 0;
   if (int e = gaml_hip_eval_begin(c, paths, offs, n_paths, &pending, tl)) return e;
+  if (aligned) *aligned = pending;
   if (pending > 0) {
     hipStream_t st = ctx_stream(c);
     std::vector<int32_t> mx((size_t)pending);
@@ -182,46 +197,115 @@ int comm_score(gaml_hip_ctx* c, CommState* s, double* d_part) {
 
 }  // namespace
 
+namespace {
+
+// The hot path's ONE exchange. Every rank contributes its partials (n doubles, in s->part) and two status words {its
+// return code so far, the windows it aligned in this evaluation}:
+//   mode 0 (default): all-gather; every rank adds the blocks up in RANK ORDER on the host -- the same doubles in the
+//     same order everywhere and every run, whatever algorithm RCCL picks for the collective (the annealing
+//     loop compares likelihoods with strict >, ties must be stable), and every rank sees every rank's status: a rank
+//     that failed before the exchange still joins it, and ALL ranks return its error instead of waiting for it;
+//   mode 1: all-reduce(sum) of the partials (the status words: sum of codes, sum of counts), the measured alternative.
+// The wait is bounded (GAML_HIP_COMM_TIMEOUT_S, default 60): a peer that died inside an earlier collective never
+// arrives -- then this rank aborts its communicator (ncclCommAbort) and reports, instead of hanging in the stream.
+int comm_exchange(gaml_hip_ctx* c, CommState* s, size_t n, int local_rc, int64_t aligned, double* out) {
+  hipStream_t st = ctx_stream(c);
+  const size_t blk = n + 2;
+  double* mine = (double*)s->part.p;
+  hipLaunchKernelGGL(comm_status_kernel, dim3(1), dim3(64), 0, st, mine + n, (double)local_rc, (double)aligned);
+  COMM_HIP(c, hipGetLastError());
+  std::vector<double> host(blk * (size_t)(s->mode == 0 ? s->world : 1));
+  if (s->mode == 0) {
+    COMM_HIP(c, s->gath.reserve(blk * (size_t)s->world * sizeof(double), st));
+    COMM_NCCL(c, rccl()->AllGather(mine, s->gath.p, blk, ncclDouble, s->comm, st));
+    if (int e = gaml_hip_fetch_async(c, s->gath.p, (int32_t)host.size(), st)) return e;
+  } else {
+    COMM_NCCL(c, rccl()->AllReduce(mine, mine, blk, ncclDouble, ncclSum, s->comm, st));
+    if (int e = gaml_hip_fetch_async(c, mine, (int32_t)host.size(), st)) return e;
+  }
+  const int w = ctx_fetch_wait_bounded(c, host.data(), (int32_t)host.size(), s->timeout_s);
+  if (w < 0) return w;
+  if (w > 0) {
+    s->dead = true;
+    if (rccl()->CommAbort) (void)rccl()->CommAbort(s->comm);
+    return ctx_fail(c, GAML_HIP_EHIP, "sharded evaluation: the exchange did not complete within " + std::to_string((int)s->timeout_s) +
+                                      " s (a peer failed or left the protocol); communicator aborted");
+  }
+  if (s->mode == 0) {
+    for (size_t j = 0; j < n; j++) { double v = 0; for (int r = 0; r < s->world; r++) v += host[(size_t)r * blk + j]; out[j] = v; }
+    for (int r = 0; r < s->world; r++)
+      if (host[(size_t)r * blk + n] != 0.0)
+        return r == s->rank ? local_rc : ctx_fail(c, (int)host[(size_t)r * blk + n], "sharded evaluation: rank " + std::to_string(r) + " failed (its own error text says why)");
+    for (int r = 0; r < s->world; r++)
+      if (host[(size_t)r * blk + n + 1] != (double)aligned)
+        return ctx_fail(c, GAML_HIP_ESTATE, "sharded evaluation: ranks aligned different numbers of windows for the same paths (rank " + std::to_string(r) + ")");
+  } else {
+    for (size_t j = 0; j < n; j++) out[j] = host[j];
+    if (host[n] != 0.0) return local_rc ? local_rc : ctx_fail(c, GAML_HIP_EHIP, "sharded evaluation: a rank failed");
+    if (host[n + 1] != (double)aligned * s->world) return ctx_fail(c, GAML_HIP_ESTATE, "sharded evaluation: ranks aligned different numbers of windows for the same paths");
+  }
+  return local_rc;
+}
+
+}  // namespace
+
+// the part of a sharded evaluation behind gaml_hip_eval_begin (+ the maxima exchange): kernels, penalty merges, exchange.
+// begin_rc: what this rank's first phase returned -- a rank that failed there skips the kernels and joins the exchange
+// with its code, so that no peer waits for it.
+static int comm_finish_reduced(gaml_hip_ctx* c, CommState* s, int begin_rc, int64_t aligned, double* partials_out) {
+  hipStream_t st = ctx_stream(c);
+  const size_t nd = 4 * (size_t)std::max(1, gaml_hip_num_readsets(c));
+  COMM_HIP(c, s->part.reserve((nd + 2) * sizeof(double), st));
+  int rc = begin_rc;
+  if (!rc) rc = comm_score(c, s, (double*)s->part.p);
+  else COMM_HIP(c, hipMemsetAsync(s->part.p, 0, nd * sizeof(double), st));
+  if (rc) ctx_eval_abandon(c);
+  const std::string why = rc ? gaml_hip_last_error(c) : "";
+  const int e = comm_exchange(c, s, nd, rc, aligned, partials_out);
+  if (e) { if (rc && e == rc) ctx_fail(c, rc, why); return e; }  // (this rank's own failure keeps its own text)
+  ctx_note_reduced(c, partials_out);
+  return 0;
+}
+
 int comm_eval_reduced(gaml_hip_ctx* c, const int32_t* paths, const int64_t* offs, int32_t n_paths, double* partials_out,
                       int32_t* total_len_out) {
   CommState* s = ctx_comm(c);
   if (!s || !s->comm) return ctx_fail(c, GAML_HIP_ESTATE, "no communicator on this context");
+  if (s->dead) return ctx_fail(c, GAML_HIP_ESTATE, "the communicator of this context was aborted after a time-out");
   COMM_HIP(c, hipSetDevice(ctx_device(c)));
-  hipStream_t st = ctx_stream(c);
   int32_t tl = 0;
-  if (int e = comm_begin(c, s, paths, offs, n_paths, &tl)) return e;
+  int64_t aligned = 0;
+  const int rc = comm_begin(c, s, paths, offs, n_paths, &tl, &aligned);
   if (total_len_out) *total_len_out = tl;
-  const size_t nd = 4 * (size_t)std::max(1, gaml_hip_num_readsets(c));
-  COMM_HIP(c, s->part.reserve(nd * sizeof(double), st));
-  if (int e = comm_score(c, s, (double*)s->part.p)) return e;
-  // the one collective of the hot path: {sum of logs, floored reads, bad_bases (one contributor), reads} per read set
-  COMM_NCCL(c, rccl()->AllReduce(s->part.p, s->part.p, nd, ncclDouble, ncclSum, s->comm, st));
-  if (int e = gaml_hip_fetch_async(c, s->part.p, (int32_t)nd, st)) return e;
-  if (int e = gaml_hip_fetch_wait(c, partials_out, (int32_t)nd)) return e;
-  ctx_note_reduced(c, partials_out);
-  return 0;
+  return comm_finish_reduced(c, s, rc, aligned, partials_out);
 }
 
 int comm_eval_reduced_batch(gaml_hip_ctx* c, int32_t n_sets, const int32_t* paths, const int64_t* offs, const int32_t* set_offs,
                             double* partials_out, int32_t* total_lens_out) {
   CommState* s = ctx_comm(c);
   if (!s || !s->comm) return ctx_fail(c, GAML_HIP_ESTATE, "no communicator on this context");
+  if (s->dead) return ctx_fail(c, GAML_HIP_ESTATE, "the communicator of this context was aborted after a time-out");
   if (n_sets <= 0) return 0;
   COMM_HIP(c, hipSetDevice(ctx_device(c)));
   hipStream_t st = ctx_stream(c);
   const size_t nd = 4 * (size_t)std::max(1, gaml_hip_num_readsets(c));
-  COMM_HIP(c, s->part.reserve(nd * sizeof(double) * (size_t)n_sets, st));
-  for (int32_t i = 0; i < n_sets; i++) {
+  COMM_HIP(c, s->part.reserve((nd * (size_t)n_sets + 2) * sizeof(double), st));
+  int rc = 0;
+  int64_t aligned_all = 0;
+  std::string why;
+  for (int32_t i = 0; i < n_sets && !rc; i++) {
     const int32_t p0 = set_offs[i], p1 = set_offs[i + 1];
-    if (p1 < p0) return ctx_fail(c, GAML_HIP_EINVAL, "set offsets must not decrease");
+    if (p1 < p0) { rc = ctx_fail(c, GAML_HIP_EINVAL, "set offsets must not decrease"); break; }
     int32_t tl = 0;
-    if (int e = comm_begin(c, s, paths, offs + p0, p1 - p0, &tl)) return e;
+    int64_t aligned = 0;
+    rc = comm_begin(c, s, paths, offs + p0, p1 - p0, &tl, &aligned);
+    aligned_all += aligned;
     if (total_lens_out) total_lens_out[i] = tl;
-    if (int e = comm_score(c, s, (double*)s->part.p + nd * (size_t)i)) return e;
+    if (!rc) rc = comm_score(c, s, (double*)s->part.p + nd * (size_t)i);
   }
-  COMM_NCCL(c, rccl()->AllReduce(s->part.p, s->part.p, nd * (size_t)n_sets, ncclDouble, ncclSum, s->comm, st));  // ONE for the batch
-  if (int e = gaml_hip_fetch_async(c, s->part.p, (int32_t)(nd * (size_t)n_sets), st)) return e;
-  if (int e = gaml_hip_fetch_wait(c, partials_out, (int32_t)(nd * (size_t)n_sets))) return e;
+  if (rc) { why = gaml_hip_last_error(c); ctx_eval_abandon(c); }
+  const int e = comm_exchange(c, s, nd * (size_t)n_sets, rc, aligned_all, partials_out);  // ONE for the batch
+  if (e) { if (rc && e == rc) ctx_fail(c, rc, why); return e; }
   ctx_note_reduced(c, partials_out + nd * (size_t)(n_sets - 1));
   return 0;
 }
@@ -498,9 +582,21 @@ int multi_calc_partials(MultiState* m, const int32_t* paths, const int64_t* offs
   std::vector<std::vector<double>> part((size_t)n, std::vector<double>(nd, 0.0));
   std::vector<int32_t> tl((size_t)n, 0);
   if (m->exchange == 1) {
-    // every shard runs the whole sharded evaluation on its own thread: registration, maxima, kernels, ONE RCCL
-    // all-reduce(sum) on its stream, fetch; all shards end up with the same reduced values
-    int rc = m->run_all([&](int k, gaml_hip_ctx* kid) { return comm_eval_reduced(kid, paths, offs, n_paths, part[k].data(), &tl[k]); });
+    // Two hand-overs per step. First every shard registers / aligns on its own thread; back here the shards' return
+    // codes and the windows they aligned are compared BEFORE any collective is posted -- a shard that failed must not
+    // leave the others waiting in one -- and the new windows' maxima are merged on the host (the shards share this
+    // process). Then kernels and the ONE RCCL exchange per shard, on its stream; all shards end up with the same values.
+    std::vector<int64_t> pending((size_t)n, 0);
+    int rc = m->run_all([&](int k, gaml_hip_ctx* kid) { return gaml_hip_eval_begin(kid, paths, offs, n_paths, &pending[k], &tl[k]); });
+    if (!rc) rc = multi_maxima_exchange(m, pending);
+    if (rc) { for (gaml_hip_ctx* kid : m->kids) ctx_eval_abandon(kid); return rc; }
+    rc = m->run_all([&](int k, gaml_hip_ctx* kid) {
+      CommState* s = ctx_comm(kid);
+      if (!s || !s->comm) return ctx_fail(kid, GAML_HIP_ESTATE, "no communicator on this shard");
+      if (s->dead) return ctx_fail(kid, GAML_HIP_ESTATE, "the communicator of this shard was aborted after a time-out");
+      if (hipSetDevice(ctx_device(kid)) != hipSuccess) return ctx_fail(kid, GAML_HIP_EHIP, "hipSetDevice failed");
+      return comm_finish_reduced(kid, s, 0, pending[k], part[k].data());
+    });
     if (rc) return rc;
     memcpy(partials_out, part[0].data(), nd * sizeof(double));
     if (total_len_out) *total_len_out = tl[0];
@@ -644,6 +740,8 @@ int gaml_hip_create_multi(gaml_hip_ctx** out, const int32_t* devices, int32_t n_
     for (int32_t j = 0; j < i; j++) distinct = distinct && devices[i] != devices[j];
   }
   int rc = GAML_HIP_OK;
+  int caller_device = -1;  // gaml_hip_create makes its device current: the caller's choice is put back below
+  if (all_gpu && hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
   for (int32_t i = 0; i < n_devices && rc == GAML_HIP_OK; i++) {
     gaml_hip_ctx* kid = nullptr;
     rc = gaml_hip_create(&kid, devices[i]);
@@ -673,7 +771,7 @@ int gaml_hip_create_multi(gaml_hip_ctx** out, const int32_t* devices, int32_t n_
       if (nr == ncclSuccess) {
         for (int32_t i = 0; i < n_devices; i++) {
           CommState* s = new CommState();
-          s->comm = comms[(size_t)i]; s->rank = i; s->world = n_devices;
+          s->comm = comms[(size_t)i]; s->rank = i; s->world = n_devices; s->timeout_s = comm_timeout_s();
           ctx_set_comm(m->kids[(size_t)i], s);
         }
         m->have_comm = true;
@@ -693,6 +791,7 @@ int gaml_hip_create_multi(gaml_hip_ctx** out, const int32_t* devices, int32_t n_
     }
   }
   ctx_set_multi(parent, m.release());
+  if (caller_device >= 0) (void)hipSetDevice(caller_device);
   *out = parent;
   return GAML_HIP_OK;
 }
@@ -726,19 +825,31 @@ int gaml_hip_num_shards(const gaml_hip_ctx* ctx) {
 }
 
 int gaml_hip_set_exchange(gaml_hip_ctx* ctx, int32_t mode) {
-  if (!ctx || (mode != GAML_HIP_EXCHANGE_HOST && mode != GAML_HIP_EXCHANGE_RCCL)) return ctx_fail(ctx, GAML_HIP_EINVAL, "bad arguments");
+  if (!ctx || (mode != GAML_HIP_EXCHANGE_HOST && mode != GAML_HIP_EXCHANGE_RCCL && mode != GAML_HIP_EXCHANGE_RCCL_ALLREDUCE)) return ctx_fail(ctx, GAML_HIP_EINVAL, "bad arguments");
+  const bool rccl_mode = mode != GAML_HIP_EXCHANGE_HOST;
   MultiState* m = ctx_multi(ctx);
-  if (!m) return ctx_fail(ctx, GAML_HIP_ESTATE, "not a multi-device context");
-  if (mode == GAML_HIP_EXCHANGE_RCCL && !m->have_comm)
+  if (!m) {  // one shard per process: only the form of the RCCL exchange can be chosen
+    CommState* s = ctx_comm(ctx);
+    if (!s || !rccl_mode) return ctx_fail(ctx, GAML_HIP_ESTATE, "not a multi-device context (and no communicator whose exchange could be chosen)");
+    s->mode = mode == GAML_HIP_EXCHANGE_RCCL_ALLREDUCE ? 1 : 0;
+    return GAML_HIP_OK;
+  }
+  if (rccl_mode && !m->have_comm)
     return ctx_fail(ctx, GAML_HIP_ESTATE, "no RCCL communicator on this context (" + (m->err.empty() ? std::string("shards share a device") : m->err) + ")");
-  m->exchange = mode;
+  m->exchange = rccl_mode ? 1 : 0;
+  if (rccl_mode) for (gaml_hip_ctx* kid : m->kids) if (CommState* s = ctx_comm(kid)) s->mode = mode == GAML_HIP_EXCHANGE_RCCL_ALLREDUCE ? 1 : 0;
   return GAML_HIP_OK;
 }
 
 int gaml_hip_get_exchange(const gaml_hip_ctx* ctx) {
   if (!ctx) return GAML_HIP_EINVAL;
-  if (MultiState* m = ctx_multi(ctx)) return m->exchange;
-  return ctx_comm(ctx) ? GAML_HIP_EXCHANGE_RCCL : GAML_HIP_EXCHANGE_HOST;
+  if (MultiState* m = ctx_multi(ctx)) {
+    if (!m->exchange) return GAML_HIP_EXCHANGE_HOST;
+    CommState* s = ctx_comm(m->kids[0]);
+    return s && s->mode == 1 ? GAML_HIP_EXCHANGE_RCCL_ALLREDUCE : GAML_HIP_EXCHANGE_RCCL;
+  }
+  CommState* s = ctx_comm(ctx);
+  return !s ? GAML_HIP_EXCHANGE_HOST : (s->mode == 1 ? GAML_HIP_EXCHANGE_RCCL_ALLREDUCE : GAML_HIP_EXCHANGE_RCCL);
 }
 
 int gaml_hip_comm_unique_id(void* id_out) {
@@ -765,7 +876,7 @@ int gaml_hip_comm_init_rank(gaml_hip_ctx* c, const void* id_bytes, int32_t rank,
   ncclUniqueId id;
   memcpy(&id, id_bytes, sizeof(id));
   std::unique_ptr<CommState> s(new CommState());
-  s->rank = rank; s->world = world;
+  s->rank = rank; s->world = world; s->timeout_s = comm_timeout_s();
   COMM_NCCL(c, r->CommInitRank(&s->comm, world, id, rank));
   ctx_set_comm(c, s.release());
   return GAML_HIP_OK;

@@ -103,7 +103,9 @@ int gaml_hip_create_multi(gaml_hip_ctx** out, const int32_t* devices, int32_t n_
 int gaml_hip_create_from_env(gaml_hip_ctx** out);
 int gaml_hip_num_shards(const gaml_hip_ctx* ctx);  /* 1 for a plain context */
 #define GAML_HIP_EXCHANGE_HOST 0
-#define GAML_HIP_EXCHANGE_RCCL 1
+#define GAML_HIP_EXCHANGE_RCCL 1            /* ncclAllGather of the ranks' partials, summed in RANK ORDER by every rank: the same
+                                             * doubles in the same order on every rank and in every run (default) */
+#define GAML_HIP_EXCHANGE_RCCL_ALLREDUCE 2  /* ncclAllReduce(sum): the order of the additions is RCCL's choice */
 int gaml_hip_set_exchange(gaml_hip_ctx* ctx, int32_t mode);  /* multi-device contexts only; RCCL needs distinct devices */
 int gaml_hip_get_exchange(const gaml_hip_ctx* ctx);
 #define GAML_HIP_COMM_ID_BYTES 128

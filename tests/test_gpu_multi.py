@@ -132,8 +132,24 @@ def test_one_shard_over_rccl_and_comm_init_rank():
     for c in (multi, solo):
         for (p, z, tl), ps in zip(c.calc_prob_batch(api.BatchPaths(sets)), sets):
             assert _rel(p, plain.calc_prob(ps)[0]) <= 1e-13
-    multi.set_exchange("host")
-    assert _rel(multi.calc_prob(sets[1])[0], plain.calc_prob(sets[1])[0]) <= 1e-13
+    # the three carriers of the hot-path exchange: ranks' partials gathered and added up in rank order by every rank (the
+    # default), ncclAllReduce(sum), the calling thread adding the shards' pinned-host partials in rank order. The first and
+    # the last add the same doubles in the same order: bit for bit the same value (ties in the annealing loop
+    # must be stable); with one rank the all-reduce has nothing to re-order either.
+    vals = {}
+    for mode in ("rccl", "rccl-allreduce", "host", "rccl"):
+        multi.set_exchange(mode)
+        assert multi.exchange() == mode
+        vals[mode] = [multi.calc_prob(ps)[0] for ps in sets] + [b[0] for b in multi.calc_prob_batch(api.BatchPaths(sets))]
+    assert vals["rccl"] == vals["host"] == vals["rccl-allreduce"]
+    solo.set_exchange("rccl-allreduce")
+    assert [solo.calc_prob(ps)[0] for ps in sets] == vals["rccl"][:2]
+    solo.set_exchange("rccl")
+    # a failure on a rank BEFORE the exchange reaches every rank through it (here: the one rank; a bad node id)
+    for c in (multi, solo):
+        with pytest.raises(api.GamlHipError):
+            c.calc_prob([[walk[0], 10 ** 6]])
+        assert _rel(c.calc_prob(sets[0])[0], plain.calc_prob(sets[0])[0]) <= 1e-13  # ... and the context goes on working
     multi.close()
     solo.close()
 
