@@ -109,7 +109,7 @@ def sa_pattern(ctx, rs, g, iters, api, synth):
     ctx.calc_prob(start)
     first_s = time.perf_counter() - t0
     a0 = ctx.aligner_stats()
-    t_stats0 = ctx.debug_table_stats(rs)
+    t_stats0 = ctx.table_stats(rs)
     per = np.zeros(len(flat))
     gc.disable()
     t0 = time.perf_counter()
@@ -120,13 +120,13 @@ def sa_pattern(ctx, rs, g, iters, api, synth):
     total = time.perf_counter() - t0
     gc.enable()
     a1 = ctx.aligner_stats()
-    t_stats1 = ctx.debug_table_stats(rs)
+    t_stats1 = ctx.table_stats(rs)
     per *= 1e6
     # where a warm call of this pattern goes (replay of the last 200 sets: everything cached), library-side phases
     prof = []
     for f in flat[-200:]:
         ctx.score(f)
-        prof.append(ctx.debug_profile())
+        prof.append(ctx.last_phases())
     ph = np.median(np.array(prof), axis=0)
     return {"iterations": iters, "paths_at_start": len(start), "total_s": total, "first_call_cold_s": first_s,
             "us_median": float(np.median(per)), "us_p90": float(np.percentile(per, 90)), "us_p99": float(np.percentile(per, 99)),
@@ -254,10 +254,10 @@ def repeats_block(api, synth, device, sa_iters=5000):
     ctx.kernel_stats(reset=True)
     for i in range(128):
         ctx.score(variants[i % 8])
-    ks, gs = ctx.kernel_stats(reset=True), ctx.debug_general_stats()
+    ks, gs = ctx.kernel_stats(reset=True), ctx.general_stats()
     ctx.set_event_timing(False)
     out = {"workload": wl.name, "pairs": wl.n_pairs, "walk_nodes": len(walk), "distinct_nodes": len(set(walk)),
-           "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
+           "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.pair_classes(rs)],
            "step_us": step_us, "reads_per_sec": 2.0 * wl.n_pairs / (step_us * 1e-6),
            "scoring_kernel_us": ks["device_us"] / max(1, ks["launches"]),
            "general_kernel_us": gs["device_us"] / max(1, gs["launches"]), "general_launches_per_step": gs["launches"] / max(1, ks["launches"]),
@@ -296,10 +296,10 @@ def repeats_block(api, synth, device, sa_iters=5000):
     ctx.kernel_stats(reset=True)
     for f in flat[-200:]:
         ctx.score(f)
-    ks, gs = ctx.kernel_stats(reset=True), ctx.debug_general_stats()
+    ks, gs = ctx.kernel_stats(reset=True), ctx.general_stats()
     out["late_annealing_walk"] = {"iterations": sa_iters, "paths_at_end": len(seq[-1]), "call_us_median_last_1000": float(np.median(per[-1000:]) * 1e6),
-                                  "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
-                                  "delta_pairs": ctx.debug_table_stats(rs)["dirty_pairs"],
+                                  "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.pair_classes(rs)],
+                                  "delta_pairs": ctx.table_stats(rs)["dirty_pairs"],
                                   "scoring_kernel_us": ks["device_us"] / max(1, ks["launches"]),
                                   "general_kernel_us": gs["device_us"] / max(1, gs["launches"])}
     ctx.close()
@@ -614,7 +614,7 @@ def main():
             "step_us_distribution": {"p50": float(np.percentile(d, 50)), "p90": float(np.percentile(d, 90)),
                                      "p99": float(np.percentile(d, 99)), "max": float(d.max())},
             "log_likelihood": last, "prime_s": prime_s,
-            "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.debug_class_counts(rs)],
+            "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.pair_classes(rs)],
             "timing_last_step_us": ctx.last_timing(),
         }
         if use_dist:

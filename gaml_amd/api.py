@@ -14,7 +14,11 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GAML_HIP_LIB") or os.path.join(_HERE, "libgaml_hip.so")  # override: A/B builds (tools/)
+# Two flavours of the library (gaml_amd/csrc/Makefile): libgaml_hip.so, the product, and libgaml_hip_dev.so, the same
+# sources with the gaml_hip_debug_* entry points, A/B knobs and in-kernel time stamps compiled in. The product is what
+# gets loaded unless GAML_HIP_FLAVOUR=dev (tests/conftest.py and tools/ set it) or GAML_HIP_LIB names a file (A/B builds).
+FLAVOUR = os.environ.get("GAML_HIP_FLAVOUR", "release")
+LIB_PATH = os.environ.get("GAML_HIP_LIB") or os.path.join(_HERE, "libgaml_hip_dev.so" if FLAVOUR == "dev" else "libgaml_hip.so")
 
 OK, EINVAL, ENODEVICE, EHIP, ESTATE = 0, -1, -2, -3, -4
 
@@ -137,10 +141,13 @@ def _load():
     L.gaml_hip_pacbio_records.argtypes = [vp, C.c_int, _i32p, C.c_int32, vp, C.c_int64]
     L.gaml_hip_pacbio_records.restype = C.c_int64
     L.gaml_hip_pacbio_dp_stats.argtypes = [vp, C.c_int, _f64p]
-    L.gaml_hip_debug_sam_logprob.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int64, C.c_double, C.POINTER(C.c_double), vp, vp, C.c_int32]
-    L.gaml_hip_debug_sam_shape.argtypes = [C.c_char_p, C.c_int64, C.c_int32, _i32p, C.c_void_p, C.c_int32]
-    L.gaml_hip_debug_sam_band.argtypes = [C.c_char_p, C.c_int64, C.c_int32, _i32p, _i32p, _i32p, _i32p, C.c_int32]
-    L.gaml_hip_debug_sam_band.restype = C.c_int32
+    if hasattr(L, "gaml_hip_debug_sam_logprob"):  # development build only
+        L.gaml_hip_debug_sam_logprob.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int64, C.c_double, C.POINTER(C.c_double), vp, vp, C.c_int32]
+    if hasattr(L, "gaml_hip_debug_sam_shape"):  # development build only
+        L.gaml_hip_debug_sam_shape.argtypes = [C.c_char_p, C.c_int64, C.c_int32, _i32p, C.c_void_p, C.c_int32]
+    if hasattr(L, "gaml_hip_debug_sam_band"):  # development build only
+        L.gaml_hip_debug_sam_band.argtypes = [C.c_char_p, C.c_int64, C.c_int32, _i32p, _i32p, _i32p, _i32p, C.c_int32]
+        L.gaml_hip_debug_sam_band.restype = C.c_int32
     L.gaml_hip_calc_prob.argtypes = [vp, _i32p, _i64p, C.c_int32, C.POINTER(C.c_double), _i32p, C.POINTER(C.c_int32)]
     L.gaml_hip_calc_prob_batch.argtypes = [vp, C.c_int32, _i32p, _i64p, _i32p, _f64p, vp, vp]
     L.gaml_hip_calc_partials.argtypes = [vp, _i32p, _i64p, C.c_int32, _f64p, C.POINTER(C.c_int32)]
@@ -178,17 +185,25 @@ def _load():
     L.gaml_hip_window_records.restype = C.c_int64
     L.gaml_hip_align_window.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int32]
     L.gaml_hip_align_window.restype = C.c_int64
-    L.gaml_hip_debug_prepare.argtypes = [vp, _i32p, _i64p, C.c_int32]
-    L.gaml_hip_debug_occurrences.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int64]
-    L.gaml_hip_debug_occurrences.restype = C.c_int64
-    L.gaml_hip_debug_table_occurrences.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int64, _i64p]
-    L.gaml_hip_debug_table_occurrences.restype = C.c_int64
-    L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
-    L.gaml_hip_debug_class_counts.argtypes = [vp, C.c_int, _i64p]
-    L.gaml_hip_debug_fold_check.argtypes = [vp, C.c_int, _i64p]
+    if hasattr(L, "gaml_hip_debug_prepare"):  # development build only
+        L.gaml_hip_debug_prepare.argtypes = [vp, _i32p, _i64p, C.c_int32]
+    if hasattr(L, "gaml_hip_debug_occurrences"):  # development build only
+        L.gaml_hip_debug_occurrences.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int64]
+    if hasattr(L, "gaml_hip_debug_occurrences"):  # development build only
+        L.gaml_hip_debug_occurrences.restype = C.c_int64
+    if hasattr(L, "gaml_hip_debug_table_occurrences"):  # development build only
+        L.gaml_hip_debug_table_occurrences.argtypes = [vp, C.c_int, C.c_int, _i32p, C.c_int64, _i64p]
+    if hasattr(L, "gaml_hip_debug_table_occurrences"):  # development build only
+        L.gaml_hip_debug_table_occurrences.restype = C.c_int64
+    if hasattr(L, "gaml_hip_debug_window_walk"):  # development build only
+        L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
+    L.gaml_hip_pair_classes.argtypes = [vp, C.c_int, _i64p]
+    if hasattr(L, "gaml_hip_debug_fold_check"):  # development build only
+        L.gaml_hip_debug_fold_check.argtypes = [vp, C.c_int, _i64p]
     if hasattr(L, "gaml_hip_debug_static_check"):  # absent from older A/B builds loaded through GAML_HIP_LIB
         L.gaml_hip_debug_static_check.argtypes = [vp, C.c_int, _i64p]
-    L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
+    if hasattr(L, "gaml_hip_debug_set_knob"):  # development build only
+        L.gaml_hip_debug_set_knob.argtypes = [vp, C.c_int, C.c_int]
     if hasattr(L, "gaml_hip_shm_exchange_open"):
         L.gaml_hip_shm_exchange_open.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
         L.gaml_hip_shm_allreduce_sum.argtypes = [vp, C.c_void_p, C.c_int32]
@@ -198,8 +213,9 @@ def _load():
         L.gaml_hip_fetch_wait.argtypes = [vp, C.c_void_p, C.c_int32]
     if hasattr(L, "gaml_hip_debug_timeline"):  # absent from older A/B builds loaded through GAML_HIP_LIB
         L.gaml_hip_debug_timeline.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
-    L.gaml_hip_debug_profile.argtypes = [vp, _f64p]
-    L.gaml_hip_debug_table_stats.argtypes = [vp, C.c_int, _i64p]
+    L.gaml_hip_last_phases.argtypes = [vp, _f64p]
+    L.gaml_hip_table_stats.argtypes = [vp, C.c_int, _i64p]
+    L.gaml_hip_general_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.gaml_hip_aligner_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.gaml_hip_last_timing.argtypes = [vp, _f64p]
     L.gaml_hip_set_event_timing.argtypes = [vp, C.c_int]
@@ -659,9 +675,9 @@ class Context:
             _lib.gaml_hip_debug_window_walk(self._h, rs, mate, wid, buf, n)
         return [int(x) for x in buf[:n]]
 
-    def debug_table_stats(self, rs):
+    def table_stats(self, rs):
         out = np.zeros(10, np.int64)
-        self._check(_lib.gaml_hip_debug_table_stats(self._h, rs, out))
+        self._check(_lib.gaml_hip_table_stats(self._h, rs, out))
         return {"full_rebuilds": int(out[0]), "delta_updates": int(out[1]), "dirty_pairs": int(out[2]), "worker_rebuilds": int(out[3]),
                 "batches_patched": int(out[4]), "batches_full": int(out[5]), "records_left_out": [int(out[6]), int(out[7])], "delta_records_left_out": int(out[8]),
                 "static_index_pairs": int(out[9])}
@@ -671,9 +687,9 @@ class Context:
         _lib.gaml_hip_aligner_stats(self._h, C.byref(w), C.byref(k), C.byref(us))
         return {"windows": w.value, "candidates": k.value, "us": us.value}
 
-    def debug_profile(self):
+    def last_phases(self):
         out = np.zeros(8, np.float64)
-        _lib.gaml_hip_debug_profile(self._h, out)
+        _lib.gaml_hip_last_phases(self._h, out)
         return out
 
     def debug_timeline(self, rs: int, cap_waves: int = 1 << 16) -> np.ndarray:
@@ -699,10 +715,9 @@ class Context:
         return {"static_pairs": int(out[0]), "other_pairs": int(out[1]), "violations": int(out[2]), "no_record": int(out[3]),
                 "different_windows": int(out[4]), "orientation": int(out[5]), "distance": int(out[6]), "edits_or_code": int(out[7])}
 
-    def debug_general_stats(self):
+    def general_stats(self):
         n, us = C.c_int64(), C.c_double()
-        _lib.gaml_hip_debug_general_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
-        self._check(_lib.gaml_hip_debug_general_stats(self._h, C.byref(n), C.byref(us)))
+        self._check(_lib.gaml_hip_general_stats(self._h, C.byref(n), C.byref(us)))
         return {"launches": n.value, "device_us": us.value}
 
     def debug_block_partials(self, rs, set_index=0):
@@ -711,10 +726,13 @@ class Context:
         n = _lib.gaml_hip_debug_block_partials(self._h, rs, set_index, sums, zeros, 8192, lay)
         return sums[:max(n, 0)].copy(), zeros[:max(n, 0)].copy(), lay.tolist()
 
-    def debug_class_counts(self, rs):
+    def pair_classes(self, rs):
         out = np.zeros(4, np.int64)
-        self._check(_lib.gaml_hip_debug_class_counts(self._h, rs, out))
+        self._check(_lib.gaml_hip_pair_classes(self._h, rs, out))
         return out
+
+    # (the names these carried while they lived in gaml_hip_debug.h)
+    debug_table_stats, debug_profile, debug_general_stats, debug_class_counts = table_stats, last_phases, general_stats, pair_classes
 
     def last_timing(self):
         out = np.zeros(3, np.float64)

@@ -32,6 +32,14 @@
 #include "internal.h"
 
 
+// A/B switches and tuning knobs (gaml_hip_debug_set_knob) exist in development builds (-DGAML_HIP_DEV) only; the release
+// library is compiled with every one of them at its default, 0.
+#ifdef GAML_HIP_DEV
+#define KNOB(c, i) ((c)->knobs[i])
+#else
+#define KNOB(c, i) 0
+#endif
+
 namespace gaml {
 namespace detail {
 
@@ -381,7 +389,7 @@ struct gaml_hip_ctx {
   double aln_us = 0;
   double aln_stage_us[5] = {0, 0, 0, 0, 0};  // window strings + upload, spans + candidates, extension, D2H of hits, sort + finalize
   int64_t aln_batches = 0;
-  int knobs[24] = {0};  // tuning experiments: [0] grid cap, [1] dynamic LDS bytes, [2] finish mode
+  int knobs[24] = {0};  // tuning experiments and A/B switches (gaml_hip_debug.h), development builds only: read through KNOB()
   bool direct_write = false;  // large-BAR device: the host writes per-call tables straight into device memory (Arena)
   int32_t peers = 1;  // contexts (incl. this one) that hold reads of the same read sets: >1 => window maxima must be exchanged
   std::string err;

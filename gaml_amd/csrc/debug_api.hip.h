@@ -1,0 +1,211 @@
+// debug_api.hip.h -- the gaml_hip_debug_* entry points (include/gaml_hip_debug.h): development builds only (-DGAML_HIP_DEV)
+// (one translation unit with gaml_hip.hip, which includes this file at the place its contents used to stand)
+#pragma once
+
+int gaml_hip_debug_prepare(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t n_paths) {
+  if (!c || n_paths < 0 || (n_paths > 0 && (!flat || !offs))) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->multi) {  // every shard registers / aligns / places on its own reads (host-only shards included)
+    for (int k = 0; k < gaml::multi_num_shards(c->multi); k++)
+      if (int e = gaml_hip_debug_prepare(gaml::multi_shard(c->multi, k), flat, offs, n_paths)) return fail(c, e, gaml_hip_last_error(gaml::multi_shard(c->multi, k)));
+    return GAML_HIP_OK;
+  }
+  if (!c->have_graph) return fail(c, GAML_HIP_ESTATE, "no graph set");
+  std::vector<Walk> paths = unflatten(flat, offs, n_paths);
+  for (auto& h : scoring_order(c)) {
+    if (h.kind == 0) { std::vector<Occ> occs; prepare_single_host(c, *c->singles[h.idx], paths, occs); }
+    else if (h.kind == 1) {
+      PairedPrep p;
+      PairedSet& ps = *c->paireds[h.idx];
+      if (int e = prepare_paired_structure(c, ps, flat, offs, n_paths)) return e;
+      if (int e = align_pending_pair(c, ps)) return e;
+      prepare_paired_tables_host(c, ps, p);
+    }
+  }
+  if (c->peers == 1) {
+    for (ShortMate* m : filter_mates(c)) m->unsynced.clear();
+  }
+  return GAML_HIP_OK;
+}
+
+int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* c, int rs, int mate, int32_t* out5, int64_t cap) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size()) return -1;
+  SetRef h = c->handles[rs];
+  const std::vector<Occ>* v = nullptr;
+  if (h.kind == 0) v = &c->singles[h.idx]->last_occ;
+  else if (h.kind == 1 && (mate == 0 || mate == 1)) { PairedSet& ps = *c->paireds[h.idx]; ps.planner.flat_occurrences(mate, ps.scratch_occ[mate]); v = &ps.scratch_occ[mate]; }
+  if (!v) return -1;
+  for (int64_t i = 0; i < (int64_t)v->size() && i < cap; i++) {
+    const Occ& o = (*v)[i];
+    out5[5 * i] = o.wid; out5[5 * i + 1] = o.shift; out5[5 * i + 2] = o.min_pos; out5[5 * i + 3] = o.path; out5[5 * i + 4] = o.rank;
+  }
+  return (int64_t)v->size();
+}
+
+int64_t gaml_hip_debug_table_occurrences(gaml_hip_ctx* c, int rs, int mate, int32_t* out5, int64_t cap, int64_t* info3) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || (mate != 0 && mate != 1)) return -1;
+  PairedSet& ps = *c->paireds[c->handles[rs].idx];
+  if (info3) { info3[0] = ps.planner.last_was_incremental(); info3[1] = (int64_t)ps.planner.incremental_calls; info3[2] = (int64_t)ps.planner.full_calls; }
+  std::vector<Occ> v;
+  ps.image[mate].dump(v);
+  const std::vector<int32_t>& slots = ps.planner.slots();
+  std::unordered_map<int32_t, int32_t> pos;
+  for (size_t k = 0; k < slots.size(); k++) pos[slots[k]] = (int32_t)k;
+  for (Occ& o : v) { auto it = pos.find(o.path); o.path = it == pos.end() ? -1 : it->second; }
+  std::sort(v.begin(), v.end(), [](const Occ& a, const Occ& b) { return a.path != b.path ? a.path < b.path : (a.rank != b.rank ? a.rank < b.rank : a.wid < b.wid); });
+  for (int64_t i = 0; i < (int64_t)v.size() && i < cap; i++) {
+    const Occ& o = v[(size_t)i];
+    out5[5 * i] = o.wid; out5[5 * i + 1] = o.shift; out5[5 * i + 2] = o.min_pos; out5[5 * i + 3] = o.path; out5[5 * i + 4] = o.rank;
+  }
+  return (int64_t)v.size();
+}
+
+int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* c, int rs, int mate, int32_t wid, int32_t* out, int32_t cap) {
+  MULTI_SHARD0(c);
+  ShortMate* m = mate_of(c, rs, mate);
+  if (!m || wid < 0 || wid >= (int32_t)m->win_walk.size()) return -1;
+  const Walk& w = *m->win_walk[wid];
+  for (int32_t i = 0; i < (int32_t)w.size() && i < cap; i++) out[i] = w[i];
+  return (int32_t)w.size();
+}
+
+
+
+int gaml_hip_debug_timeline(gaml_hip_ctx* c, int rs, unsigned long long* out, int64_t cap_waves) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  if (!s.h_timeline.p) return 0;
+  const int64_t n = std::min<int64_t>(cap_waves, s.timeline_waves);
+  memcpy(out, s.h_timeline.p, (size_t)n * 8 * sizeof(unsigned long long));
+  return (int)n;
+}
+
+int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
+  if (!c || knob < 0 || knob >= 24) return GAML_HIP_EINVAL;
+  if (c->multi) { for (int k = 0; k < gaml::multi_num_shards(c->multi); k++) gaml::multi_shard(c->multi, k)->knobs[knob] = value; return GAML_HIP_OK; }
+  c->knobs[knob] = value;
+  return GAML_HIP_OK;
+}
+
+
+// Host-only check of the record tables' rule "a record that is always overwritten stays out" (host_model.cc
+// dominated_records) on the windows that are active now: builds the tables with and without the rule (no device) and
+// verifies, record by record, that every pair's records with the rule are the records without it minus records of a
+// junction window J for which the first node's own window -- active -- holds a record of the same read at the same
+// position. out6 = {records left out mate 1, mate 2, pairs of the compact class with / without the rule, records
+// checked, violations}. Returns GAML_HIP_ESTATE when a violation was found.
+int gaml_hip_debug_fold_check(gaml_hip_ctx* c, int rs, int64_t* out6) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out6) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  PairTables with, without;
+  build_pair_tables(s.mate[0], s.mate[1], with, true);
+  build_pair_tables(s.mate[0], s.mate[1], without, false);
+  int64_t checked = 0, bad = 0;
+  const int64_t n = s.mate[0].n_local();
+  PairedSet::RecList a, b;
+  for (int mt = 0; mt < 2; mt++) {
+    const ShortMate& m = s.mate[mt];
+    // per (window, read, position): is it a record of an active single-node window?
+    for (int64_t read = 0; read < n; read++) {
+      a = PairedSet::RecList(); b = PairedSet::RecList();
+      paired_base_records(with, with.slot_of_read[read], mt, a);
+      paired_base_records(without, without.slot_of_read[read], mt, b);
+      size_t ia = 0;
+      for (size_t ib = 0; ib < b.size(); ib++) {
+        checked++;
+        const RecQuad& r = b[ib];
+        if (ia < a.size() && a[ia].wid == r.wid && a[ia].pos == r.pos && a[ia].flags == r.flags) { ia++; continue; }
+        // left out: must be a junction window whose first node's own window holds (read, position)
+        const Window& j = m.wins[r.wid];
+        bool ok = false;
+        if (j.head >= 0) {
+          auto it = m.solo_of_node.find(j.head);
+          if (it != m.solo_of_node.end() && m.wins[it->second].active)
+            for (size_t q = 0; q < b.size(); q++) ok = ok || (b[q].wid == it->second && b[q].pos == r.pos);
+        }
+        bad += !ok;
+      }
+      bad += ia != a.size();  // (a record with the rule that the tables without it do not hold)
+    }
+  }
+  out6[0] = with.dropped_records[0]; out6[1] = with.dropped_records[1];
+  out6[2] = with.class_count[0]; out6[3] = without.class_count[0];
+  out6[4] = checked; out6[5] = bad;
+  return bad ? fail(c, GAML_HIP_ESTATE, "record tables: a record was left out that is not always overwritten") : GAML_HIP_OK;
+}
+
+// Host-only check of the static memo indices (PairTables::static_idx): tables of the windows that are active now,
+// every compact-class pair looked at again from the window cache -- the two records' windows compared by their node
+// walks, orientation rule and insert distance recomputed (graph.cc:1864-1876). out8 = {pairs with a static index, other
+// compact-class pairs, violations (an index that differs, or a pair that qualifies and has none), then why the other
+// pairs have none: a mate without record, records in different windows, orientation rule, distance outside the
+// insert-size table, edit count / length code outside the memo}.
+int gaml_hip_debug_static_check(gaml_hip_ctx* c, int rs, int64_t* out8) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out8) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  if (int e = paired_host_tabs(c, s)) return e;
+  const int ins_n = (int)s.ins_tab.size();
+  link_mate_windows(s.mate[0], s.mate[1]);
+  PairTables pt;
+  build_pair_tables(s.mate[0], s.mate[1], pt, true, ins_n);
+  for (int k = 0; k < 8; k++) out8[k] = 0;
+  const int64_t n0 = pt.class_count[0];
+  out8[0] = pt.n0a; out8[1] = n0 - pt.n0a;
+  const int codes = (int)std::min<size_t>(pt.len_combo.size(), kMemoCodes);
+  for (int64_t slot = 0; slot < n0; slot++) {
+    const uint64_t r1 = pt.rec8[0][slot], r2 = pt.rec8[1][slot];
+    const int32_t read = pt.read_of_slot[slot];
+    int why = 0;  // 0: qualifies
+    int32_t idx = -1;
+    if (r1 == kNoRec8 || r2 == kNoRec8) { idx = kStaticZero; }  // never scores: static, too
+    else {
+      const int32_t w1 = (int32_t)(r1 & 0xffffff), w2 = (int32_t)(r2 & 0xffffff);
+      if (*s.mate[0].win_walk[w1] != *s.mate[1].win_walk[w2]) why = 4;
+      else {
+        const int32_t p1 = (int32_t)((r1 >> 24) & 0xfffffff), p2 = (int32_t)((r2 >> 24) & 0xfffffff);
+        const int32_t e1 = (int32_t)((r1 >> 52) & 63), e2 = (int32_t)((r2 >> 52) & 63), o1 = (int32_t)((r1 >> 58) & 1), o2 = (int32_t)((r2 >> 58) & 1);
+        const int32_t L1 = s.mate[0].lens[read], L2 = s.mate[1].lens[read];
+        int32_t dist = -1;
+        if (o1 != o2) {  // graph.cc:1864-1876 on window positions (both alignments get the window's shift)
+          if (p1 < p2) { if (o1 == 0 && o2 == 1) dist = p2 - p1 + L2; }
+          else if (o1 == 1 && o2 == 0) dist = p1 - p2 + L1;
+        }
+        const int lc = pt.len_code[slot];
+        if (dist < 0 && !(o1 != o2 && ((p1 < p2 && o1 == 0) || (p1 >= p2 && o1 == 1)))) why = 5;
+        else if (dist < 0 || dist >= ins_n) why = 6;
+        else if (e1 >= 7 || e2 >= 7 || lc >= codes) why = 7;
+        else idx = ((lc * 7 + e1) * 7 + e2) * ins_n + dist;
+      }
+    }
+    if (slot < pt.n0a) out8[2] += (why != 0 || idx != pt.static_idx[slot]);
+    else { out8[2] += why == 0; if (why) out8[why]++; }
+  }
+  return out8[2] ? fail(c, GAML_HIP_ESTATE, "record tables: a static memo index is wrong or missing") : GAML_HIP_OK;
+}
+
+// per-block partial sums of the last blocking evaluation of paired read set rs (path set `set` of a batch launch; 0 for a
+// single call), in block order [lane-per-pair classes | wave-per-pair blocks | paired_general_kernel blocks]: which
+// block's sum differs when two routes that should agree bit for bit do not. Returns the number of blocks.
+int32_t gaml_hip_debug_block_partials(gaml_hip_ctx* c, int rs, int32_t set, double* sums, int32_t* zeros, int32_t cap, int32_t* layout8) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1) return GAML_HIP_EINVAL;
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  if (!s.last_host_partials || set < 0 || set >= kMaxSets) return 0;
+  const int n = s.last_blocks[set];
+  const double* hs = (const double*)s.h_part_sum.p + (size_t)set * s.host_part_stride;
+  const int* hz = (const int*)s.h_part_zero.p + (size_t)set * s.host_part_stride;
+  for (int b = 0; b < n && b < cap; b++) { if (sums) sums[b] = hs[b]; if (zeros) zeros[b] = hz[b]; }
+  if (layout8) {
+    PairedArgs a; GridPlan gp;
+    paired_base_args(c, s, a, gp);
+    layout8[0] = gp.blocks0a; layout8[1] = gp.blocks0; layout8[2] = a.blocks01; layout8[3] = a.blocks012; layout8[4] = a.main_blocks; layout8[5] = a.total_blocks;
+    layout8[6] = gp.gen_blocks; layout8[7] = n;
+  }
+  return n;
+}
+
+

@@ -76,7 +76,7 @@ int prepare_paired_tables(gaml_hip_ctx* c, PairedSet& s) {
 int prepare_paired_structure(gaml_hip_ctx* c, PairedSet& s, const int32_t* flat, const int64_t* offs, int32_t n_paths) {
   // a coverage penalty needs per-path bitmap layout by position (and the sweep's contig starts): whole-set planning;
   // knob 12 = 1 forces it for A/B runs and tests
-  const bool incremental = !(s.cfg.penalty_constant > 0) && c->knobs[12] == 0;
+  const bool incremental = !(s.cfg.penalty_constant > 0) && KNOB(c, 12) == 0;
   std::string err;
   if (!s.planner.begin(c->g, s.mate, flat, offs, n_paths, incremental, &err)) return fail(c, GAML_HIP_EINVAL, err);
   return 0;
@@ -258,7 +258,7 @@ int paired_upload_tables(gaml_hip_ctx* c, PairedSet& s, const PairTables& pt, Ta
   UP_TRY(up(T.combo_tabs, t.data(), t.size() * sizeof(double)));
   // memo of the pair terms a single-term pair can take (first 4 length combinations, edits < 7, every tabulated distance)
   T.memo_codes = 0;
-  if (c->knobs[4] == 0 && s.floor_positive && !pt.len_combo.empty() && !s.ins_tab.empty()) {
+  if (KNOB(c, 4) == 0 && s.floor_positive && !pt.len_combo.empty() && !s.ins_tab.empty()) {
     const int codes = (int)std::min<size_t>(pt.len_combo.size(), kMemoCodes);
     const size_t entries = (size_t)codes * 49 * s.ins_tab.size();
     if (entries <= kMemoMaxEntries) {  // (the same bound build_pair_tables applies to its static indices)
@@ -308,7 +308,7 @@ int paired_shadow_upload(gaml_hip_ctx* c, PairedSet& s, hipStream_t st);
 // a rebuild is also when windows that no scored path set has used since the previous rebuild leave the device tables
 // (knob 15 = 1: never). The current path set's windows stay, whatever their marks.
 void paired_retire_windows(gaml_hip_ctx* c, PairedSet& s) {
-  if (c->knobs[15] == 1) return;
+  if (KNOB(c, 15) == 1) return;
   s.planner.mark_used(s.mate, s.image);
   int64_t n = 0;
   for (int mt = 0; mt < 2; mt++) n += s.mate[mt].retire_unused();
@@ -319,7 +319,7 @@ void paired_retire_windows(gaml_hip_ctx* c, PairedSet& s) {
 // the table length the static memo indices of class 0 are built over (PairTables::static_idx), 0: none -- no memo
 // (knob 4, or a floor of 0: the reference then takes log(0)), or knob 19 = 1 (A/B: every class-0 pair resolved per call)
 int paired_static_ins_n(const gaml_hip_ctx* c, const PairedSet& s) {
-  return (c->knobs[4] == 0 && c->knobs[19] == 0 && s.floor_positive) ? (int)s.ins_tab.size() : 0;
+  return (KNOB(c, 4) == 0 && KNOB(c, 19) == 0 && s.floor_positive) ? (int)s.ins_tab.size() : 0;
 }
 
 int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
@@ -329,8 +329,8 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
   const double tb0 = now_us();
   link_mate_windows(s.mate[0], s.mate[1]);
-  build_pair_tables(s.mate[0], s.mate[1], s.pt, c->knobs[16] != 1, paired_static_ins_n(c, s));
-  s.built_keep_dominated = c->knobs[16] == 1;
+  build_pair_tables(s.mate[0], s.mate[1], s.pt, KNOB(c, 16) != 1, paired_static_ins_n(c, s));
+  s.built_keep_dominated = KNOB(c, 16) == 1;
   const double tb1 = now_us();
   HIP_TRY(c, hipStreamSynchronize(st));  // earlier evaluations may still read the old tables
   if (int e = paired_upload_pows(c, s)) return e;
@@ -339,7 +339,7 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   if (int e = paired_reserve_delta(c, s)) return e;
   // room for the private copy a later rebuild off this thread takes (paired_snapshot_mate): allocated and touched here,
   // inside a call that takes tens of milliseconds anyway, so that the snapshot itself is a plain copy
-  if (c->knobs[14] != 1 && s.rebuild.state.load(std::memory_order_acquire) == 0 && !s.rebuild.th.joinable()) {
+  if (KNOB(c, 14) != 1 && s.rebuild.state.load(std::memory_order_acquire) == 0 && !s.rebuild.th.joinable()) {
     if (!s.rebuild.stream) HIP_TRY(c, hipStreamCreateWithFlags(&s.rebuild.stream, hipStreamNonBlocking));  // (a new queue: ~ms)
     for (int mt = 0; mt < 2; mt++) {
       ShortMate& sn = s.rebuild.snap[mt];
@@ -391,7 +391,7 @@ void paired_launch_worker(gaml_hip_ctx* c, PairedSet& s) {
     if (rc) rb.err = "hipSetDevice failed in the rebuild worker";
     rb.sh_dirty.clear();  // the lists of the tables before last (swapped out at the previous take-over): emptied here, off the caller's thread
     if (!rc) {
-      rb.keep_dominated = c->knobs[16] == 1;
+      rb.keep_dominated = KNOB(c, 16) == 1;
       build_pair_tables(rb.snap[0], rb.snap[1], rb.pt, !rb.keep_dominated, rb.static_ins_n);
       rc = paired_upload_tables(c, s, rb.pt, rb.tab, rb.stream, &rb.err);
       if (!rc && hipStreamSynchronize(rb.stream) != hipSuccess) { rc = GAML_HIP_EHIP; rb.err = "stream synchronise failed in the rebuild worker"; }
@@ -452,7 +452,7 @@ int paired_finish_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   // what this call's planning just activated joins the windows noted since the snapshot (on the old lists as well: the
   // bookkeeping is the same as in any other call), then the lists for the new tables are completed -- usually all
   // but the last few windows are in them already (paired_shadow_advance, a slice per evaluation)
-  if (!s.mate[0].activated_log.empty() || !s.mate[1].activated_log.empty()) paired_extend_delta(s, c->knobs[16] != 1, true);
+  if (!s.mate[0].activated_log.empty() || !s.mate[1].activated_log.empty()) paired_extend_delta(s, KNOB(c, 16) != 1, true);
   paired_shadow_advance(s, INT64_MAX / 4);
   HIP_TRY(c, hipStreamSynchronize(st));  // launches in flight may still read the old tables
   std::swap(s.tab, rb.tab);
@@ -494,7 +494,7 @@ int paired_reserve_delta(gaml_hip_ctx* c, PairedSet& s) {
   HIP_TRY(c, s.dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
   HIP_TRY(c, s.dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
   for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
-  if (c->knobs[14] != 1) {  // the second store, for the lists that go with a worker's tables
+  if (KNOB(c, 14) != 1) {  // the second store, for the lists that go with a worker's tables
     HIP_TRY(c, s.rebuild.sh_dl_slot.reserve(s.delta_cap * sizeof(int32_t)));
     HIP_TRY(c, s.rebuild.sh_dl_spill.reserve(s.delta_cap * sizeof(int32_t)));
     for (int mt = 0; mt < 2; mt++) HIP_TRY(c, s.rebuild.sh_dl_rec[mt].reserve(s.delta_cap * 4 * sizeof(RecQuad)));
@@ -628,7 +628,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   // happens to be done: a rebuild changes the order of the final sum (last bits), and equal inputs must give equal
   // outputs run to run (the annealing loop compares likelihoods with strict >). The worker needs ~30 ms at
   // 833 k pairs, 768 evaluations take at least that long; if it is not done by then, this call waits for it.
-  const int64_t swap_after = c->knobs[14] > 1 ? c->knobs[14] : 1152;
+  const int64_t swap_after = KNOB(c, 14) > 1 ? KNOB(c, 14) : 1152;
   if (rstate != 0 && s.eval_count - rb.start_eval >= swap_after) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; rstate = 0; }
   else if (rstate == 4) { if (int e = paired_continue_snapshot(c, s, false)) return e; rstate = 1; }  // the next slice of the private copy
   else if (rstate != 0) {  // (ready or not: not yet)
@@ -656,15 +656,15 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     // cache has been quiet for 64 evaluations with pairs still on the delta path (steady re-scoring: an annealing run adds
     // windows every few calls), or on request. On request the calling thread does it (gaml_hip_compact_tables: "at the next
     // evaluation"); otherwise a worker does, and the evaluations go on over the old tables + delta lists meanwhile.
-    const size_t limit = c->knobs[6] == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / (c->knobs[18] > 0 ? c->knobs[18] : 8));
+    const size_t limit = KNOB(c, 6) == 1 ? 0 : (size_t)std::max<int64_t>(4096, np / (KNOB(c, 18) > 0 ? KNOB(c, 18) : 8));
     size_t new_records = 0;
     if (activated_now) for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
     const bool over = activated_now && s.dirty.size() + new_records > limit;
-    const bool quiet = !activated_now && !s.dirty.empty() && s.quiet_calls >= 64 && c->knobs[6] != 2;
-    const bool refold = (c->knobs[16] == 1) != s.built_keep_dominated;  // A/B of the table contents: a request rebuilds even without delta pairs
+    const bool quiet = !activated_now && !s.dirty.empty() && s.quiet_calls >= 64 && KNOB(c, 6) != 2;
+    const bool refold = (KNOB(c, 16) == 1) != s.built_keep_dominated;  // A/B of the table contents: a request rebuilds even without delta pairs
     const bool asked = s.compact_requested && (!s.dirty.empty() || activated_now || refold);
     s.compact_requested = false;
-    const bool use_worker = c->knobs[14] != 1 && c->knobs[6] != 1;
+    const bool use_worker = KNOB(c, 14) != 1 && KNOB(c, 6) != 1;
     // the delta store must hold what accumulates while a worker builds; when it cannot, wait for the worker
     const size_t hard = s.delta_cap ? s.delta_cap - 2048 : (size_t)std::max<int64_t>(4096, np / 2);
     const bool overflow = s.dirty.size() + new_records > hard;
@@ -679,7 +679,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     }
     ts1 = now_us();
     if (activated_now) {
-      paired_extend_delta(s, c->knobs[16] != 1, rstate == 1);
+      paired_extend_delta(s, KNOB(c, 16) != 1, rstate == 1);
     }
     tr_new = new_records; tr_touched = s.dirty_touched.size();
     ts2 = now_us();
@@ -765,7 +765,7 @@ int arena_acquire(gaml_hip_ctx* c, Arena& A, size_t bytes, hipStream_t st, int* 
   A.next = (A.next + 1) % kRing;
   if (A.armed[k]) { HIP_TRY(c, hipEventSynchronize(A.done[k])); A.armed[k] = false; }
   if (!A.done[k]) HIP_TRY(c, hipEventCreateWithFlags(&A.done[k], hipEventDisableTiming));
-  const bool direct = c->direct_write && c->knobs[8] == 0;
+  const bool direct = c->direct_write && KNOB(c, 8) == 0;
   if (bytes > A.cap[k] || A.direct[k] != direct) {
     HIP_TRY(c, hipStreamSynchronize(st));
     if (A.dev[k]) { HIP_TRY(c, hipFree(A.dev[k])); A.dev[k] = nullptr; A.cap[k] = 0; }
@@ -784,7 +784,7 @@ int arena_acquire(gaml_hip_ctx* c, Arena& A, size_t bytes, hipStream_t st, int* 
 int arena_commit(gaml_hip_ctx* c, Arena& A, int k, size_t bytes, hipStream_t st) {
   if (A.direct[k]) { _mm_sfence(); return 0; }  // drain the write-combining buffers; the doorbell write of the launch orders behind them
   if (bytes == 0) return 0;
-  if (c->knobs[8] == 1 || (bytes & 15)) { HIP_TRY(c, hipMemcpyAsync(A.dev[k], A.host[k].p, bytes, hipMemcpyHostToDevice, st)); return 0; }
+  if (KNOB(c, 8) == 1 || (bytes & 15)) { HIP_TRY(c, hipMemcpyAsync(A.dev[k], A.host[k].p, bytes, hipMemcpyHostToDevice, st)); return 0; }
   const int n16 = (int)(bytes / 16);
   hipLaunchKernelGGL(stage_copy_kernel, dim3((unsigned)std::min(64, (n16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                      (const int4*)A.host[k].dev, (int4*)A.dev[k], n16);
@@ -939,16 +939,16 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   // The two parts of class 0 get blocks of their own (PairedArgs::blocks0a): the first by the rule above; the second --
   // a few per cent of the pairs, one more round trip per pair -- a lane per pair up to a third of that.
   const int64_t one_round = (n0a + 4 * kBlock - 1) / (4 * kBlock);
-  const int cap0 = c->knobs[0] > 0 ? c->knobs[0]
+  const int cap0 = KNOB(c, 0) > 0 ? KNOB(c, 0)
                                    : (int)std::min<int64_t>(kMaxBlocks, one_round > 768 && one_round <= 1280 ? one_round : std::max<int64_t>(768, n0 / 2900));
   gp.blocks0a = n0a > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>((n0a + 2 * kBlock - 1) / (2 * kBlock), cap0)) : 0;
-  const int cap0b = c->knobs[20] > 0 ? c->knobs[20] : std::max(1, n0a > 0 ? cap0 / 3 : cap0);
+  const int cap0b = KNOB(c, 20) > 0 ? KNOB(c, 20) : std::max(1, n0a > 0 ? cap0 / 3 : cap0);
   const int64_t blocks0b = n0b > 0 ? std::max<int64_t>(1, std::min<int64_t>(n0a > 0 ? (n0b + kBlock - 1) / kBlock : (n0b + 2 * kBlock - 1) / (2 * kBlock), cap0b)) : 0;
   gp.blocks0 = (int)std::max<int64_t>(1, gp.blocks0a + blocks0b);
   // the 2-record class: a third of the compact class's blocks (one block per CU at cfg3), lanes take 1-2 pairs; more
   // blocks only crowd the compact class out (tools/blocks_sweep.py at cfg3, pairs ordered by window in every class:
   // 128 blocks 11.4 us, 192: 10.1, 224-256: 9.8-9.9, 320: 10.2)
-  const int cap1 = c->knobs[10] > 0 ? c->knobs[10] : cap0 / 3;
+  const int cap1 = KNOB(c, 10) > 0 ? KNOB(c, 10) : cap0 / 3;
   gp.blocks1 = (int)std::max<int64_t>(1, std::min<int64_t>((n01 - n0 + kBlock - 1) / kBlock, cap1));
   gp.blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>((n_main - n01 + kBlock - 1) / kBlock, kMaxBlocks / 4));
   // delta pairs: one lane per pair behind the table classes
@@ -958,7 +958,7 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   gp.total_blocks = gp.main_blocks + gp.ovf_blocks;
   gp.gen_words[0] = (n0a + 63) / 64 + (n0b + 63) / 64; gp.gen_words[1] = (n01 - n0 + 63) / 64; gp.gen_words[2] = (n_main - n01 + 63) / 64;
   gp.gen_words[3] = ((int64_t)nd + 63) / 64;
-  gp.gen_blocks = n_main > 0 ? (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, c->knobs[21] > 0 ? c->knobs[21] : kMaxBlocks) : 0;
+  gp.gen_blocks = n_main > 0 ? (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, KNOB(c, 21) > 0 ? KNOB(c, 21) : kMaxBlocks) : 0;
   a.blocks0a = gp.blocks0a;
   a.gen_w0b = (int)((n0a + 63) / 64);
   a.blocks0 = gp.blocks0;
@@ -1042,7 +1042,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   const int tl = total_len == 0 ? 1 : total_len;
   // blocking call on a large-BAR device: the resident copy of the tables is patched in place (a few entries when the
   // path set shares most paths with the previous call's); otherwise a ring slot receives the whole tables
-  const bool resident = c->host_results && c->direct_write && c->knobs[8] == 0 && c->knobs[13] == 0 && !cov;
+  const bool resident = c->host_results && c->direct_write && KNOB(c, 8) == 0 && KNOB(c, 13) == 0 && !cov;
   PairedLayout L;
   memset(&L, 0, sizeof(L));
   int slot = -1;
@@ -1099,7 +1099,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   paired_apply_set(a, sd);
   a.out = out4;
   a.timeline = nullptr;
-  const bool timeline = c->knobs[3] == 8;
+  const bool timeline = KNOB(c, 3) == 8;
   if (timeline) {  // in-kernel timeline (tools/kernel_timeline.py): stamps land in mapped host memory
     HIP_TRY(c, s.h_timeline.reserve((size_t)(4 * kMaxBlocks + kOvfMaxBlocks + 256) * (kBlock / 64) * 8 * sizeof(unsigned long long)));
     memset(s.h_timeline.p, 0, s.h_timeline.cap);
@@ -1111,7 +1111,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   if (n > 0) {
     // HIP events bracket the dominant kernel only (bench.py's roofline; rocprofv3 must agree)
     if (c->event_timing && (c->event_tick++ % c->event_every) == 0) { if (int e = take_events(c, &ev)) return e; }
-    int fin_mode = c->host_results ? 2 : (c->knobs[2] ? c->knobs[2] - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
+    int fin_mode = c->host_results ? 2 : (KNOB(c, 2) ? KNOB(c, 2) - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
     if (fin_mode == 0 && gen_pass) fin_mode = 1;
     s.last_total_blocks = n_partials;
     const dim3 grid(a.total_blocks), block(kBlock);
@@ -1120,9 +1120,12 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
     // markers around the launch would add the marker packets' processing to the interval: an EMPTY kernel
     // of this grid reads 6 us that way (tools/stream_floor.hip).
     hipEvent_t e0 = ev ? ev->first : nullptr, e1 = ev ? ev->second : nullptr;
-#define GAML_LAUNCH_SCORE(...) hipExtLaunchKernelGGL((paired_score_kernel<__VA_ARGS__>), grid, block, c->knobs[1], st, e0, e1, 0, a)
-    if (timeline) GAML_LAUNCH_SCORE(false, false, true);
-    else if (gen_pass) GAML_LAUNCH_SCORE(false, true);
+#define GAML_LAUNCH_SCORE(...) hipExtLaunchKernelGGL((paired_score_kernel<__VA_ARGS__>), grid, block, KNOB(c, 1), st, e0, e1, 0, a)
+#ifdef GAML_HIP_DEV
+    if (timeline) GAML_LAUNCH_SCORE(false, false, true);  // (the instantiation with in-kernel stamps: development builds only)
+    else
+#endif
+    if (gen_pass) GAML_LAUNCH_SCORE(false, true);
     else if (fin_mode) GAML_LAUNCH_SCORE(false, false);
     else GAML_LAUNCH_SCORE(true, false);
 #undef GAML_LAUNCH_SCORE
@@ -1171,7 +1174,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
 // consecutive regions of ONE arena slot: `arena` + k * stride, layouts L[k]. Blocking only (partials in pinned memory).
 // ---------------------------------------------------------------------------------------------------------
 bool paired_multi_capable(const gaml_hip_ctx* c, const PairedSet& s) {
-  return !(s.cfg.penalty_constant > 0) && c->knobs[3] == 0 && c->knobs[4] == 0 && s.floor_positive;
+  return !(s.cfg.penalty_constant > 0) && KNOB(c, 3) == 0 && KNOB(c, 4) == 0 && s.floor_positive;
 }
 
 // Sets [first, first + n_sets) of a batch (L / preps / total_lens / arena regions / partial regions are indexed by the
@@ -1199,8 +1202,8 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, co
   MultiSets ms;
   memset(&ms, 0, sizeof(ms));
   ms.n = n_sets;
-  if (c->knobs[11] >= 32) ms.pad_ = (c->knobs[11] - 32) & 31;  // timing experiments: leave out classes of blocks (bits: compact, <=2, <=4, delta, wave-per-pair)
-  if (chg && c->knobs[11] < 64) { ms.chg[0] = chg[0]; ms.chg[1] = chg[1]; }  // (>= 64: and every set resolves every pair)  // (which table entries differ between the sets: only a batch built from patches knows)
+  if (KNOB(c, 11) >= 32) ms.pad_ = (KNOB(c, 11) - 32) & 31;  // timing experiments: leave out classes of blocks (bits: compact, <=2, <=4, delta, wave-per-pair)
+  if (chg && KNOB(c, 11) < 64) { ms.chg[0] = chg[0]; ms.chg[1] = chg[1]; }  // (>= 64: and every set resolves every pair)  // (which table entries differ between the sets: only a batch built from patches knows)
   for (int k = 0; k < n_sets; k++) {
     const int g = first + k;  // the set's number in the batch
     paired_set_view(s, L[g], arena + (size_t)g * stride, total_lens[g], ms.set[k]);

@@ -5,4 +5,9 @@
 #define GAML_SRC_HASH "unknown"
 #endif
 
-extern "C" const char* gaml_hip_version(void) { return "gaml_hip 0.2 (gfx950) src " GAML_SRC_HASH; }
+#ifdef GAML_HIP_DEV
+#define GAML_FLAVOUR " dev"
+#else
+#define GAML_FLAVOUR ""
+#endif
+extern "C" const char* gaml_hip_version(void) { return "gaml_hip 0.3" GAML_FLAVOUR " (gfx950) src " GAML_SRC_HASH; }

@@ -326,8 +326,27 @@ int64_t gaml_hip_window_records(gaml_hip_ctx* ctx, int readset, int mate, const 
 /* force alignment of one window with the library's own aligner (AlignSubpathInternal graph.cc:839-899) */
 int64_t gaml_hip_align_window(gaml_hip_ctx* ctx, int readset, int mate, const int32_t* subpath, int32_t subpath_len);
 /* GPU window aligner (cold path): windows aligned on the device so far, seed candidates extended, wall time.
- * Knob 5 = 1 (gaml_hip_debug_set_knob, gaml_hip_debug.h) forces the host aligner. */
+ * (Development builds: knob 5 = 1, gaml_hip_debug.h, forces the host aligner.) */
 int gaml_hip_aligner_stats(gaml_hip_ctx* ctx, int64_t* windows, int64_t* candidates, double* microseconds);
+/* ---- monitoring (what bench.py prints beside its numbers; all cheap, host-side) --------------------------------- */
+/* pairs per record-count class of a paired set's device tables {<= 1 record per mate, <= 2, <= 4, more} */
+int gaml_hip_pair_classes(gaml_hip_ctx* ctx, int readset, int64_t* out4);
+/* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta lists, rebuilds
+ * done by the worker thread (of the full rebuilds), gaml_hip_calc_prob_batch chunks whose per-set tables were built on
+ * the device from patches, chunks whose tables were written whole, records of mate 1 / mate 2 that the current tables
+ * leave out because another record of the same read always overwrites them, such records of windows that joined later
+ * and therefore never reached the delta lists (since creation), pairs of the compact class whose pair term came with
+ * the tables (both records in one window, or a mate without alignment)} */
+int gaml_hip_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out10);
+/* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner; includes [2]),
+ * [1] thresholds + occurrence tables, [2] alignment of newly registered windows (inside pass 1), [3] per-call tables
+ * written, [4] record tables / delta lists brought up to date, [5] kernel launches, [6] bytes of per-call tables
+ * written, [7] wait for the device */
+int gaml_hip_last_phases(gaml_hip_ctx* ctx, double* out8);
+/* launches and device time (microseconds, events attached to the dispatches while event timing is on) of
+ * paired_general_kernel: the second launch of a path set in which some window occurs several times (collapsed repeats).
+ * Reset together with gaml_hip_kernel_stats. */
+int gaml_hip_general_stats(gaml_hip_ctx* ctx, int64_t* launches, double* device_us);
 /* timing of the last scoring call, microseconds: [0] host preparation (window registration,
  * alignment of new windows, occurrence tables), [1] H2D + kernels + D2H wall, [2] device time
  * of the scoring kernels measured with HIP events on the library's stream (0 if events off). */

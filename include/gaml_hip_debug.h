@@ -1,8 +1,11 @@
-/* gaml_hip_debug.h -- test, tuning and tracing entry points of libgaml_hip.so.
+/* gaml_hip_debug.h -- test, tuning and tracing entry points of the DEVELOPMENT build, libgaml_hip_dev.so
+ * (gaml_amd/csrc/Makefile: the same sources compiled with -DGAML_HIP_DEV).
  *
- * NOT part of the drop-in boundary (include/gaml_hip.h): nothing here replaces a reference interface. These entry
- * points expose intermediate state to the parity tests (tests/), the tuning tools (tools/) and bench.py's reporting;
- * a caller that only wants ProbCalculator::CalcProb never includes this file.
+ * NOT part of the drop-in boundary (include/gaml_hip.h), and not in the product: libgaml_hip.so exports none of these
+ * symbols, carries none of the A/B switches and tuning knobs they set (every knob is compiled in at its default), no
+ * kernel instantiation with in-kernel time stamps and no crash hook. These entry points expose intermediate state to
+ * the parity tests (tests/) and the tuning tools (tools/); a caller that only wants ProbCalculator::CalcProb never
+ * includes this file.
  */
 #ifndef GAML_HIP_DEBUG_H_
 #define GAML_HIP_DEBUG_H_
@@ -46,23 +49,7 @@ int64_t gaml_hip_debug_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int
 int64_t gaml_hip_debug_table_occurrences(gaml_hip_ctx* ctx, int readset, int mate, int32_t* out5, int64_t cap, int64_t* info3);
 /* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
-/* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta list, rebuilds
- * done by the worker thread (of the full rebuilds), gaml_hip_calc_prob_batch chunks whose per-set tables were built on
- * the device from patches, chunks whose tables were written whole, records of mate 1 / mate 2 that the current tables
- * leave out because another record of the same read always overwrites them (knob 16), such records of windows that
- * joined later and therefore never reached the delta lists (since creation), pairs of the compact class whose memo index
- * came with the tables (both records in one window: PairedArgs::static_idx)}.
- * Knob 6 = 1 disables the delta list (every newly activated window rebuilds the tables); knob 14 = 1 keeps every
- * rebuild on the calling thread, knob 14 = k > 1 lets a worker's tables take over k evaluations after its start
- * (default 1152); knob 15 = 1: rebuilds never retire unused windows. */
-int gaml_hip_debug_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out10);
-
 /* ---- tuning ------------------------------------------------------------------------------------- */
-/* host-side phase times of the last blocking paired evaluation, microseconds: [0] pass 1 (planner; includes [2]),
- * [1] thresholds + occurrence tables, [2] alignment of newly registered windows (inside pass 1), [3] per-call tables
- * written, [4] record tables / delta lists brought up to date, [5] kernel launches, [6] bytes of per-call tables
- * written, [7] wait for the device */
-int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
 /* tuning experiments and A/B switches (tools/, tests): 0 = compact-class blocks, 1 = dynamic LDS bytes, 2 = finish mode
  * (1 ticket, 2 finisher kernel), 3 = 8: in-kernel timeline, 4 = 1: no floor/log memo, 5 = 1: host window aligner,
  * 2: hits sorted on the host, 3: always the general aligner route, 4: one small-batch pipeline per mate, 6 = 1: no delta
@@ -75,22 +62,19 @@ int gaml_hip_debug_profile(gaml_hip_ctx* ctx, double* out8);
  * (host_model.cc dominated_records; takes effect at the next table build; same values either way), 18 = d: tables are
  * rebuilt when the delta lists pass pairs / d (default 8), 19 = 1: no static memo indices (every compact-class pair is
  * resolved per call; takes effect at the next table build; same values either way), 20 = blocks of the compact class's
- * second part */
+ * second part, 21 = blocks of paired_general_kernel.
+ * Record tables: knob 6 = 1 disables the delta lists (every newly activated window rebuilds the tables); knob 14 = 1 keeps
+ * every rebuild on the calling thread, knob 14 = k > 1 lets a worker's tables take over k evaluations after its start
+ * (default 1152); knob 15 = 1: rebuilds never retire unused windows. */
 /* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
  * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
  * number of waves copied. Tuning aid (tools/kernel_timeline.py). */
 int gaml_hip_debug_timeline(gaml_hip_ctx* ctx, int rs, unsigned long long* out, int64_t cap_waves);
 
 int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
-/* launches and device time (microseconds, events attached to the dispatches while event timing is on) of
- * paired_general_kernel: the second launch of a path set in which some window occurs several times (collapsed repeats).
- * Reset together with gaml_hip_kernel_stats. */
-int gaml_hip_debug_general_stats(gaml_hip_ctx* ctx, int64_t* launches, double* device_us);
 /* Environment (read once): GAML_HIP_TRACE_HOST=1 -- host-side phase times of slow calls, table builds and rebuilds on
  * stderr; GAML_HIP_TRACE_ALIGNER=1 -- aligner stage times with gaml_hip_aligner_stats; GAML_HIP_BACKTRACE=1 -- a
  * backtrace on stderr when the process aborts or faults (also after the HIP runtime reports a GPU memory fault). */
-/* pairs per record-count class of the device table {<=1, <=2, <=4, more} (paired sets) */
-int gaml_hip_debug_class_counts(gaml_hip_ctx* ctx, int readset, int64_t* out4);
 /* host-only (works without a device): the record tables of the windows that are active now, built with and without the
  * rule "a junction record that the first node's own record always overwrites stays out" (knob 16), compared pair by
  * pair. out6 = {records left out mate 1, mate 2, compact-class pairs with / without the rule, records checked,

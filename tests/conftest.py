@@ -5,6 +5,10 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# The tests look inside the library (occurrence tables, class counts, A/B knobs): they load the development build,
+# libgaml_hip_dev.so -- the same sources plus include/gaml_hip_debug.h. The product library is checked by
+# tests/test_abi.py (no debug surface) and tests/test_gpu_release_lib.py (parity through it), smoke() and bench.py.
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")
 sys.path.insert(0, os.path.join(ROOT, "oracle"))  # oracle_py: the checker (tests only)
 
 

@@ -17,16 +17,29 @@ def declared_symbols(header="gaml_hip.h"):
 
 
 def test_every_declared_symbol_is_exported(built):
-    lib = ctypes.CDLL(os.path.join(ROOT, "gaml_amd", "libgaml_hip.so"))
+    """The product library exports exactly the drop-in surface (include/gaml_hip.h) and NOTHING of the test / tuning
+    surface (include/gaml_hip_debug.h: entry points, A/B knobs, in-kernel time stamps); the development build, the same
+    sources with -DGAML_HIP_DEV, exports both."""
+    import subprocess
     names = declared_symbols()
     assert len(names) >= 30
-    missing = [n for n in names if not hasattr(lib, n)]
-    assert not missing, missing
-    # the drop-in header carries no debug surface; that lives in gaml_hip_debug.h (tests / tools only) -- also exported
-    assert not [n for n in names if "_debug_" in n]
+    assert not [n for n in names if "_debug_" in n]  # the drop-in header carries no debug surface
     dbg = declared_symbols("gaml_hip_debug.h")
     assert len(dbg) >= 10 and all("_debug_" in n for n in dbg)
-    assert not [n for n in dbg if not hasattr(lib, n)]
+    exported = {}
+    for lib in ("libgaml_hip.so", "libgaml_hip_dev.so"):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "gaml_amd", lib)], text=True)
+        exported[lib] = {ln.split()[-1] for ln in out.splitlines() if ln.split()}
+    release, dev = exported["libgaml_hip.so"], exported["libgaml_hip_dev.so"]
+    assert not [n for n in names if n not in release], [n for n in names if n not in release]
+    assert not [n for n in names + dbg if n not in dev], [n for n in names + dbg if n not in dev]
+    assert not [n for n in release if "debug" in n], [n for n in release if "debug" in n]
+    # ... and no kernel instantiation with in-kernel time stamps (paired_score_kernel<false, false, true>) in the product
+    blob = open(os.path.join(ROOT, "gaml_amd", "libgaml_hip.so"), "rb").read()
+    assert b"paired_score_kernelILb0ELb0ELb1E" not in blob
+    assert b"paired_score_kernelILb0ELb0ELb1E" in open(os.path.join(ROOT, "gaml_amd", "libgaml_hip_dev.so"), "rb").read()
+    lib = ctypes.CDLL(os.path.join(ROOT, "gaml_amd", "libgaml_hip.so"))
+    assert not [n for n in names if not hasattr(lib, n)]
 
 
 def test_library_was_built_from_this_tree(built):
@@ -42,6 +55,11 @@ def test_library_was_built_from_this_tree(built):
     for r in rel:
         h.update(open(os.path.join(ROOT, r), "rb").read())
     assert api.version().endswith("src " + h.hexdigest()[:16]), api.version()
+    assert " dev " in api.version()  # tests load the development build (tests/conftest.py)
+    rel = ctypes.CDLL(os.path.join(ROOT, "gaml_amd", "libgaml_hip.so"))
+    rel.gaml_hip_version.restype = ctypes.c_char_p
+    v = rel.gaml_hip_version().decode()
+    assert v.endswith("src " + h.hexdigest()[:16]) and " dev " not in v, v
 
 
 def test_record_layouts_match_the_reference_structs(built):

@@ -1,6 +1,7 @@
 """Which class of blocks bounds paired_score_multi_kernel: candidate batches at cfg3 with classes of blocks left out
 (knob 11 = 32 + mask; results are wrong, only the time is looked at).  python tools/batch_ablate.py"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

@@ -1,6 +1,7 @@
 """Candidate batches (8 single-edit candidates of one ~900-path assembly) at cfg3: one-pass kernel vs one launch per set,
 and the same candidates one blocking call at a time.  python tools/batch_profile.py"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

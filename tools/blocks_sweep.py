@@ -1,6 +1,7 @@
 """cfg3, warm steps: launch duration and step time over the number of compact-class blocks (knob 0) and <=2-record
 class blocks (knob 10).  python tools/blocks_sweep.py"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

@@ -8,8 +8,9 @@ HERE=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$HERE/gaml_amd/csrc
 T=/tmp/gaml_variant_$NAME; mkdir -p $T $HERE/build_ab
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -Wno-sign-compare"
-(cd $SRC && /opt/rocm/bin/hipcc $FL "$@" -Rpass-analysis=kernel-resource-usage -c gaml_hip.hip -o $T/gaml_hip.o > $T/usage.txt 2>&1) || { tail -20 $T/usage.txt; exit 1; }
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $HERE/build_ab/libgaml_hip_$NAME.so $SRC/host_model.o $T/gaml_hip.o $SRC/multi.o $SRC/version.o -ldl -lpthread
+# (variants are development builds: the probes that load them use knobs and debug entry points)
+(cd $SRC && /opt/rocm/bin/hipcc $FL -DGAML_HIP_DEV "$@" -Rpass-analysis=kernel-resource-usage -c gaml_hip.hip -o $T/gaml_hip.o > $T/usage.txt 2>&1) || { tail -20 $T/usage.txt; exit 1; }
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $HERE/build_ab/libgaml_hip_$NAME.so $SRC/obj_dev/host_model.o $T/gaml_hip.o $SRC/obj_dev/multi.o $SRC/obj_dev/version.o -ldl -lpthread
 python3 - $T/usage.txt $NAME <<'PY'
 import re, sys
 t = open(sys.argv[1]).read()

@@ -1,5 +1,6 @@
 """The cold first evaluation at cfg3 (every window aligned, first table build): where it goes.  python tools/cold_probe.py"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaml_amd import synth, api
 wl = synth.WORKLOADS["cfg3"]

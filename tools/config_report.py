@@ -5,6 +5,7 @@ minutes). Not the driver's benchmark (that is bench.py); a record of the other c
   python tools/config_report.py [out.jsonl]"""
 import json
 import os
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 import sys
 import time
 

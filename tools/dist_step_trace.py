@@ -1,5 +1,6 @@
 """Where the time of one sharded (N > 1 code path) step goes, single rank over RCCL."""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
 from gaml_amd import synth, api

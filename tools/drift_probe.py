@@ -1,5 +1,6 @@
 """bench.py's incremental_drift block on its own.  python tools/drift_probe.py [iterations] [sample pairs]"""
 import json, os, sys
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaml_amd import synth, api
 import bench

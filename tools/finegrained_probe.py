@@ -1,6 +1,7 @@
 """Does it matter to the scoring launch whether the occurrence tables sit in fine-grained device memory (written by
 the host through the BAR) or in ordinary device memory (staged copy)?  cfg3 warm steps, knob 8.  python tools/finegrained_probe.py"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaml_amd import synth, api
 wl = synth.WORKLOADS["cfg3"]

@@ -1,6 +1,7 @@
 """A/B of the record tables with and without the records that are always overwritten (knob 16, host_model.cc
 dominated_records): one cfg3 context, tables rebuilt between the legs, interleaved rounds."""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

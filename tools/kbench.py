@@ -1,5 +1,6 @@
 """Kernel tuning harness: one cfg3 context, interleaved rounds over knob settings (guide 5.4 rule 24)."""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

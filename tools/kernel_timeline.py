@@ -2,6 +2,7 @@
 stage boundaries of every wave; this prints per class the distribution of each stage, relative to the first wave's
 entry.  python tools/kernel_timeline.py [cfg3]"""
 import os, sys
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

@@ -3,6 +3,7 @@ own: a path set with a repeated window (general pass: gen_bits), the stream-orde
 fetch buffer), a batch (ring arena, multi-set partials), the resident tables, the aligner's small-batch buffers, a
 multi-device context with its worker threads and -- one rank -- an RCCL communicator.   python tools/lifecycle.py"""
 import os, sys, resource, gc
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gaml_amd import synth, api

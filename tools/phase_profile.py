@@ -2,6 +2,7 @@
 BAR, 1 = staging + hipMemcpyAsync, 2 = staging + copy kernel): medians of gaml_hip_debug_profile over 400 steps.
   python tools/phase_profile.py [cfg3|cfg2] [batch]"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import os
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 import shutil
 import sys
 

@@ -2,6 +2,7 @@
 scoring launch and the second launch (paired_general_kernel: pairs on windows that occur several times), step time, and
 -- ORACLE=1 -- the likelihood against the CPU oracle on all pairs.    python tools/repeats_probe.py [cfg3r|tinyr]"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

@@ -1,6 +1,7 @@
 """Where one slow call of the annealing pattern spends its time: aligner stage split before / after the call.
 python tools/sa_call_probe.py 20"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

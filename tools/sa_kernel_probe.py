@@ -1,6 +1,7 @@
 """Annealing pattern at cfg3: how long is the scoring launch itself, call by call, and what do the tables look like?
   python tools/sa_kernel_probe.py [iterations]"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

@@ -1,6 +1,7 @@
 """Long annealing-pattern run at cfg3 size: stability of the per-call time and of the process memory over many
 iterations (planner memos, window cache, delta store, table rebuilds).  python tools/sa_long.py [iterations]"""
 import os, sys, time, resource
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

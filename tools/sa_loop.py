@@ -4,6 +4,7 @@ use of CalcProb: one evaluation per iteration on a slightly edited path set, new
 appearing all the time. Prints per-iteration cost and where it goes; optionally the CPU oracle on a
 read sample drives the same sequence (incremental ScoringState, like the reference)."""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np

@@ -1,4 +1,5 @@
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, '/root/repo')
 import numpy as np
 from gaml_amd import synth, api

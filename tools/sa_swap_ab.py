@@ -1,6 +1,7 @@
 """Annealing pattern over several table take-overs: total time, tail and the take-over calls for different take-over
 delays (knob 14).  python tools/sa_swap_ab.py [iterations] [delays...]"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

@@ -1,6 +1,7 @@
 """Tail of the annealing pattern at cfg3: per-call times with / without the quiet-spell table fold (knob 6 = 2), where
 the slow calls come from, aligner stage breakdown.  python tools/sa_tail.py"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

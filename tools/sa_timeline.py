@@ -1,6 +1,7 @@
 """In-kernel timeline (knob 3 = 8) of the scoring kernel for annealing-pattern path sets on tables that were built for
 other path sets (delta pairs present): which class of blocks ends last.  python tools/sa_timeline.py"""
 import os, sys
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api

@@ -4,6 +4,7 @@ nodes and reversed paths; single calls, batch calls and re-evaluations interleav
 count, bad_bases and (periodically) every per-read probability compared with the oracle evaluated from
 scratch.   python tools/soak.py [seeds] [steps]"""
 import os
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 import sys
 import time
 

@@ -1,5 +1,6 @@
 """Replay one soak seed and report the first mismatch in detail.  python tools/soak_debug.py SEED [knob=value ...]"""
 import os, sys
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))

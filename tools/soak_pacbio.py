@@ -3,6 +3,7 @@ positions (including alignments that run past the end of the target or into the 
 random soft clips (XS/XE/XQ) -- GPU kernel through the C ABI against the oracle: band equal row by row,
 log probability to 1e-9 (or both minus infinity).   python tools/soak_pacbio.py [cases]"""
 import os
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 import sys
 
 import numpy as np

@@ -3,6 +3,7 @@ of knob settings, e.g. static memo indices on / off (knob 19; takes effect at a 
 after every change), blocks of the compact class's two parts (knobs 0 / 20), of the two-record class (knob 10).
   python tools/static_ab.py [workload]      SWEEP='[{}, {19: 1}, {20: 64}]'"""
 import os, sys, time
+os.environ.setdefault("GAML_HIP_FLAVOUR", "dev")  # tools look inside the library: the development build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaml_amd import synth, api
