@@ -369,6 +369,7 @@ void ShortReadSet::positions_only_path(const Graph& g, const std::vector<int>& c
 void ShortReadSet::clear_positions() {  // graph.cc:316-321
   positions.resize(reads.size());
   for (auto& v : positions) v.clear();
+  several.assign(reads.size(), 0);
 }
 
 void ShortReadSet::add_positions(const Graph& g, const std::vector<int>& ctg, int& total_len, int st) {
@@ -391,8 +392,11 @@ void ShortReadSet::add_positions(const Graph& g, const std::vector<int>& ctg, in
         auto& mine = positions[al.read];
         bool replaced = false;
         for (auto& old : mine)
-          if (old.first == al.pos + cur_pos) { old.second = std::make_pair(al.edit, al.orient); replaced = true; break; }
-        if (!replaced) mine.push_back(std::make_pair(al.pos + cur_pos, std::make_pair(al.edit, al.orient)));
+          if (old.first == al.pos + cur_pos) {
+            if (old.second != std::make_pair(al.edit, al.orient)) several[al.read] = 1;  // (bookkeeping for the cross-check below, not in the reference)
+            old.second = std::make_pair(al.edit, al.orient); replaced = true; break;
+          }
+        if (!replaced) { if (!mine.empty()) several[al.read] = 1; mine.push_back(std::make_pair(al.pos + cur_pos, std::make_pair(al.edit, al.orient))); }
       }
     }
     cur_pos += g.len(ctg[i]);
@@ -558,6 +562,87 @@ double score_paired(const Graph& g, const std::vector<std::vector<int>>& paths, 
   double tp = total_prob_paired(st.probs, total_len, zero_reads, floor_per_base, floor_start, r1, r2);
   st.old_paths = paths;
   return tp - st.bad_bases * penalty;
+}
+
+// ---------------------------------------------------------------------------
+// The reference's OTHER paired scorer: the slow, non-incremental CalcScoreForPaths (graph.cc:1991-2127), unreachable
+// from gaml (its call is commented out at prob_calculator.h:80-86, next to a printf("cmp ...") that compared it with
+// the incremental scorer). Restated as a second, differently structured opinion on the paired value: positions are
+// assembled the single-end way (AddPositions graph.cc:600-649: junction windows only, no position filter, absolute
+// coordinates with the paths 1,000,000 apart), every position of mate 1 is paired with every position of mate 2
+// whatever path they are on (graph.cc:2053-2088), coverage events are sorted and swept once over all paths
+// (:2089-2117). It agrees with score_paired where the two definitions coincide: every node at most kWindowTail long
+// (no whole-node windows), no gaps, penalty 0, and no record that the incremental scorer's position filter drops
+// without an earlier window holding it (tests/test_oracle_golden.py).
+// ---------------------------------------------------------------------------
+double score_paired_slow(const Graph& g, const std::vector<std::vector<int>>& paths, ShortReadSet& r1, ShortReadSet& r2,
+                         double ins_mean, double ins_sd, int& zero_reads, int& total_len, double penalty, double cov_move,
+                         bool all_to_cov, double floor_per_base, double floor_start, std::vector<double>* probs_out,
+                         int* bad_bases_out, std::vector<uint8_t>* several_out) {
+  int tl1 = 0, tl2 = 0, st = 0;
+  std::vector<double> probs(r1.n());
+  r1.clear_positions();
+  r2.clear_positions();
+  r1.precompute_for_paths(g, paths);
+  r2.precompute_for_paths(g, paths);
+  std::vector<std::pair<int, int>> events;  // (position, type): 3 a well-aligned pair's end, 1 a contig start
+  for (auto& path : paths) {
+    std::vector<std::vector<int>> ctgs;
+    std::vector<int> gaps;
+    split_at_gaps(path, ctgs, gaps);
+    events.push_back(std::make_pair(st + tl1, 1));
+    for (size_t i = 0; i < ctgs.size(); i++) {
+      if (i > 0) { tl1 += gaps[i - 1]; tl2 += gaps[i - 1]; events.push_back(std::make_pair(st + tl1, 1)); }
+      const int at1 = st + tl1, at2 = st + tl2;  // arguments evaluated before the callee advances total_len (:2038-2039)
+      r1.add_positions(g, ctgs[i], tl1, at1);
+      r2.add_positions(g, ctgs[i], tl2, at2);
+    }
+    st += 1000000;
+  }
+  std::vector<double> ins_tab((size_t)(int)(ins_mean + 5 * ins_sd));
+  for (size_t d = 0; d < ins_tab.size(); d++) ins_tab[d] = insert_prob((double)d, ins_mean, ins_sd);
+  for (int i = 0; i < r1.n(); i++) {
+    const double threshold = std::exp(floor_start + floor_per_base * (r1.lens[i] + r2.lens[i]));  // (:2051: both lengths here)
+    for (auto& x : r1.positions[i]) {
+      const double p1 = r1.base_prob(i, x.second.first);
+      for (auto& y : r2.positions[i]) {
+        const double p2 = r2.base_prob(i, y.second.first);
+        if (x.second.second == y.second.second) continue;
+        int dist;
+        if (x.first < y.first) {
+          if (x.second.second != 0 || y.second.second != 1) continue;
+          dist = y.first - x.first + r2.lens[i];
+        } else {
+          if (x.second.second != 1 || y.second.second != 0) continue;
+          dist = x.first - y.first + r1.lens[i];
+        }
+        const double ip = (size_t)dist < ins_tab.size() ? ins_tab[dist] : insert_prob((double)dist, ins_mean, ins_sd);
+        if (p1 * p2 * ip > threshold) {
+          events.push_back(std::make_pair(std::max(x.first, y.first), 3));
+          if (all_to_cov) events.push_back(std::make_pair(std::min(x.first, y.first), 3));
+        }
+        probs[i] += p1 * p2 * ip;
+      }
+    }
+  }
+  std::sort(events.begin(), events.end());
+  int last_pos = 0, last_type = -1, last_begin = 0, bad_bases = 0;
+  for (auto& ev : events) {
+    if (ev.second == 3 && ev.first - last_pos > cov_move && (last_type == 3 || last_type < 0) && ev.first - last_begin > ins_mean + 5 * ins_sd)
+      bad_bases += ev.first - last_pos;
+    if (ev.second == 1) last_begin = ev.first;
+    last_pos = ev.first;
+    last_type = ev.second;
+  }
+  const double tp = total_prob_paired(probs, tl1, zero_reads, floor_per_base, floor_start, r1, r2);
+  total_len = tl1;
+  if (probs_out) *probs_out = probs;
+  if (bad_bases_out) *bad_bases_out = bad_bases;
+  if (several_out) {  // reads with more than one distinct alignment on a mate: where the two paired scorers may part
+    several_out->assign(r1.n(), 0);
+    for (int i = 0; i < r1.n(); i++) (*several_out)[i] = r1.several[i] | r2.several[i];
+  }
+  return tp - bad_bases * penalty;
 }
 
 // ---------------------------------------------------------------------------

@@ -150,6 +150,7 @@ struct ShortReadSet {
   MaxHashIndex index;
   std::unordered_map<std::vector<int>, std::vector<Rec>, WalkHash> cache;  // aligment_cache_
   std::vector<std::vector<std::pair<int, std::pair<int, int>>>> positions;  // positions_ (single-end)
+  std::vector<uint8_t> several;  // (not in the reference) add_positions met a second distinct alignment of the read
   long windows_aligned = 0;
 
   int n() const { return (int)reads.size(); }
@@ -208,6 +209,11 @@ double score_paired(const Graph& g, const std::vector<std::vector<int>>& paths, 
                     ShortReadSet& r2, double ins_mean, double ins_sd, int& zero_reads, int& total_len,
                     PairedState& st, double penalty, double cov_move, bool all_to_cov,
                     double floor_per_base, double floor_start);
+// the slow, non-incremental paired CalcScoreForPaths (:1991-2127; unreachable from gaml: a cross-check)
+double score_paired_slow(const Graph& g, const std::vector<std::vector<int>>& paths, ShortReadSet& r1, ShortReadSet& r2,
+                         double ins_mean, double ins_sd, int& zero_reads, int& total_len, double penalty, double cov_move,
+                         bool all_to_cov, double floor_per_base, double floor_start, std::vector<double>* probs_out = nullptr,
+                         int* bad_bases_out = nullptr, std::vector<uint8_t>* several_out = nullptr);
 // CalcScoreForPaths single (:1650-1743)
 double score_single(const Graph& g, const std::vector<std::vector<int>>& paths, ShortReadSet& r,
                     int& zero_reads, int& total_len, double penalty, double cov_move,

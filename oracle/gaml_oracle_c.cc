@@ -222,6 +222,22 @@ int orc_paired_probs(void* p, int set, double* out, int32_t* bad_bases) {
   if (bad_bases) *bad_bases = st.bad_bases;
   return (int)st.probs.size();
 }
+// the slow non-incremental paired scorer (graph.cc:1991-2127) with per-read output; out3 = {zero_reads, total_len, bad_bases}
+double orc_paired_slow(void* p, int set, const int32_t* flat, const int64_t* offs, int n_paths, double* probs_out, int32_t* out3, uint8_t* several_out) {
+  Session* s = S(p);
+  auto k = s->sets[set];
+  if (k.first != 1) return 0.0;
+  auto& e = s->calc.paired[k.second];
+  std::vector<double> probs; int zero = 0, tl = 0, bad = 0;
+  std::vector<uint8_t> several;
+  double v = score_paired_slow(s->g, unflatten(flat, offs, n_paths), *e.second.first, *e.second.second, e.first.insert_mean, e.first.insert_std,
+                               zero, tl, e.first.penalty_constant, e.first.step, true /* use_all_to_cov: prob_calculator.h:84 */,
+                               e.first.min_prob_per_base, e.first.min_prob_start, &probs, &bad, &several);
+  if (probs_out) memcpy(probs_out, probs.data(), probs.size() * sizeof(double));
+  if (several_out) memcpy(several_out, several.data(), several.size());
+  if (out3) { out3[0] = zero; out3[1] = tl; out3[2] = bad; }
+  return v;
+}
 // single-end / pacbio scorers recomputed with per-read output (stateless in the reference)
 double orc_single_detail(void* p, int set, const int32_t* flat, const int64_t* offs, int n_paths, double* probs_out,
                          int32_t* out3 /*zero_reads,total_len,bad_bases*/) {

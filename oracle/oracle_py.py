@@ -58,6 +58,8 @@ def _load():
     L.orc_paired_probs.argtypes = [C.c_void_p, C.c_int, _f64p, _i32p]
     L.orc_single_detail.argtypes = [C.c_void_p, C.c_int, _i32p, _i64p, C.c_int, _f64p, _i32p]
     L.orc_single_detail.restype = C.c_double
+    L.orc_paired_slow.argtypes = [C.c_void_p, C.c_int, _i32p, _i64p, C.c_int, _f64p, _i32p, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]
+    L.orc_paired_slow.restype = C.c_double
     L.orc_pacbio_detail.argtypes = [C.c_void_p, C.c_int, _i32p, _i64p, C.c_int, _f64p, _i32p]
     L.orc_pacbio_detail.restype = C.c_double
     L.orc_window_count.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -250,6 +252,16 @@ class Oracle:
         bb = np.zeros(1, np.int32)
         self.L.orc_paired_probs(self.h, rs, out, bb)
         return out, int(bb[0])
+
+    def paired_slow(self, rs, paths):
+        """The reference's slow non-incremental paired scorer (graph.cc:1991-2127): value, per-read probabilities,
+        {zero_reads, total_len, bad_bases}, and per read whether a mate had more than one distinct alignment."""
+        flat, offs = _flat(paths)
+        probs = np.zeros(self.set_reads(rs), np.float64)
+        o3 = np.zeros(3, np.int32)
+        several = np.zeros(self.set_reads(rs), np.uint8)
+        v = self.L.orc_paired_slow(self.h, rs, flat, offs, len(paths), probs, o3, several)
+        return v, probs, o3, several
 
     def single_detail(self, rs, paths):
         flat, offs = _flat(paths)

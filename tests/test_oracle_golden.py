@@ -314,3 +314,59 @@ def test_pacbio_sam_pins():
         np.testing.assert_allclose(lp, [float.fromhex(x) for x in want["logp"]], rtol=1e-13, atol=0)
     v, z, tl = o.calc_prob([walk])
     assert abs(v - float.fromhex(ing["prob"])) <= 1e-13 * abs(v) and z.tolist() == ing["zeros"] and tl == ing["total_len"]
+
+
+def _slow_vs_incremental(err, long_rng, seed=5, G=30_000, n=4000):
+    import oracle_py as op
+    from gaml_amd import synth
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed, long_rng=long_rng, short_rng=(40, 120)))
+    pr = synth.make_paired_reads(genome, n, 100, 250.0, 25.0, err, seed)
+    o = op.Oracle()
+    o.set_graph(*g.packed())
+    rs = o.add_paired(*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2), 0.01, op.paired_cfg(250.0, 25.0))
+    walk = synth.genome_walk(g)
+    k = len(walk) // 2
+    out = []
+    for paths in ([walk], [walk[:k], walk[k:]], [walk[:k]], [[x ^ 1 for x in reversed(walk)]]):
+        fast = o.calc_prob(paths, fresh=True)
+        fast_probs = o.paired_probs(rs)[0].copy()
+        slow = o.paired_slow(rs, paths)
+        out.append((fast, fast_probs, slow))
+    return out
+
+
+def test_slow_paired_scorer_agrees_with_the_incremental_one_where_the_definitions_coincide(built):
+    """The reference carries a second paired scorer, the slow non-incremental CalcScoreForPaths (graph.cc:1991-2127),
+    whose comparison with CalcScoreForPathsNew is commented out at prob_calculator.h:80-95. Restated in the oracle as a
+    differently structured opinion on the paired value (single-end style position assembly, all-against-all pairing
+    over absolute coordinates). The two definitions coincide when every node is at most kMinSubpathLength long (the slow
+    scorer knows no whole-node windows), there are no gaps and no penalty, and a read has ONE distinct alignment per mate
+    (a second one a base or two away -- short tandem repeats allow it even without sequencing errors -- is kept, dropped
+    or overwritten by different rules: graph.cc:577, 583-592 vs 633-644). On those reads: bit for bit; the others are few."""
+    for fast, fast_probs, slow in _slow_vs_incremental(err=0.0, long_rng=(180, 300)):
+        one = slow[3] == 0
+        assert one.sum() >= 0.99 * len(one)
+        assert np.array_equal(fast_probs[one], slow[1][one])
+        assert fast[2] == int(slow[2][1]) and abs(fast[1][0][0] - int(slow[2][0])) <= int((~one).sum())
+        assert abs(fast[0] - slow[0]) <= 1e-3 * abs(fast[0])
+    # with sequencing errors the lossy aligner finds a few reads in a later window only, at a position the incremental
+    # scorer's filter (max_pos - 5, graph.cc:577) has already passed: dropped there, kept by AddPositions
+    for fast, fast_probs, slow in _slow_vs_incremental(err=0.01, long_rng=(180, 300)):
+        one = slow[3] == 0
+        differ = one & (fast_probs != slow[1])
+        assert one.sum() >= 0.98 * len(one) and differ.sum() <= 4
+        assert np.all(fast_probs[differ] == 0.0) and np.all(slow[1][differ] > 0.0)
+
+
+def test_slow_paired_scorer_where_the_definitions_part(built):
+    """With sequencing errors a few reads get a second, shifted alignment a base or two away; the incremental scorer's
+    position filter (graph.cc:577) and overwrite rule (:583-592) then keep another subset than AddPositions (:633-644):
+    all but a handful of reads still agree bit for bit, the likelihood to 1e-3. With nodes longer than
+    kMinSubpathLength the slow scorer misses every read in a node's interior (junction windows only, the first node cut to
+    its last 300 bases, graph.cc:846-848) -- which is presumably why the reference stopped calling it."""
+    for fast, fast_probs, slow in _slow_vs_incremental(err=0.01, long_rng=(180, 300)):
+        assert abs(fast[0] - slow[0]) <= 1e-3 * abs(fast[0])
+    for fast, fast_probs, slow in _slow_vs_incremental(err=0.0, long_rng=(900, 2500)):
+        assert int(slow[2][0]) > fast[1][0][0] + len(fast_probs) // 5  # far more floored reads
+        assert np.all(slow[1] <= fast_probs + 1e-300)        # it only ever loses alignments here
