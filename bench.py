@@ -100,6 +100,71 @@ def cpu_baseline(gb, go, b1, o1, b2, o2, pairs, read_len, variants, cfg, budget_
                       f"alignment {cold_s:.1f} s"}, vals
 
 
+def cpu_shard_child(args):
+    """`--cpu-shard-child R,N`: one of N CPU processes of the courtesy row (no GPU, no torch): the oracle on reads
+    [pairs R/N, pairs (R+1)/N) of the workload, cold pass over the 8 path sets, then warm from-scratch CalcProb calls for
+    the budget. Prints one JSON line."""
+    from gaml_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    r, n = (int(x) for x in args.cpu_shard_child.split(","))
+    wl = synth.WORKLOADS[args.workload]
+    genome, g = wl.build()
+    pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
+    lo, hi = wl.n_pairs * r // n, wl.n_pairs * (r + 1) // n
+    b1, o1 = synth.pack_reads(pr.mate1[lo:hi])
+    b2, o2 = synth.pack_reads(pr.mate2[lo:hi])
+    variants = path_variants(synth.genome_walk(g))
+    orc = op.Oracle()
+    orc.set_graph(*g.packed())
+    orc.add_paired(b1, o1, b2, o2, wl.err, op.paired_cfg(wl.insert_mean, wl.insert_std))
+    t0 = time.time()
+    for v in variants:
+        orc.calc_prob(v, fresh=True)
+    cold_s = time.time() - t0
+    n_eval, t_warm = 0, 0.0
+    while t_warm < args.cpu_shard_budget or n_eval < 3:
+        t0 = time.time()
+        orc.calc_prob(variants[n_eval % len(variants)], fresh=True)
+        t_warm += time.time() - t0
+        n_eval += 1
+    print("CPUSHARD " + json.dumps({"rank": r, "pairs": hi - lo, "evals": n_eval, "warm_s": t_warm, "cold_s": cold_s}), flush=True)
+
+
+def cpu_baseline_sharded(workload, n_pairs, budget_s=8.0):
+    """The courtesy row of BASELINE.md's plan: the same CPU restatement read-sharded over the box's cores, one process
+    per core (the reference itself is single-threaded: its native mode is the 1-core row). Cores = this process's CPU
+    affinity, at most 16 (a GPU box's share per GPU). Each process holds a contiguous shard of the reads against the full
+    graph and re-scores it from scratch for `budget_s` seconds; the shards' rates add up."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-shard-child", f"{r},{cores}", "--workload", workload,
+                               "--cpu-shard-budget", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(cores)]
+    rate, evals, cold, done = 0.0, 0, 0.0, 0
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            continue
+        line = [l for l in out.splitlines() if l.startswith("CPUSHARD ")]
+        if p.returncode == 0 and line:
+            d = json.loads(line[-1][9:])
+            rate += 2.0 * d["pairs"] * d["evals"] / d["warm_s"]
+            evals += d["evals"]
+            cold = max(cold, d["cold_s"])
+            done += 1
+    return {"value": rate, "unit": "reads/s", "cores": cores, "kind": "port", "processes_finished": done,
+            "sample": f"{n_pairs} pairs split into {cores} contiguous shards, one oracle process per core against the full graph, "
+                      f"{evals} warm from-scratch CalcProb calls in ~{budget_s:.0f} s each process (cold pass incl. window alignment: {cold:.1f} s, slowest shard); "
+                      "each shard's position filter sees its own reads' window maxima only: a throughput row, not a likelihood"}
+
+
 def sa_pattern(ctx, rs, g, iters, api, synth):
     """BASELINE config 5's call pattern on this GPU (untimed for the headline): the reference's start state, then
     `iters` edited path sets, one blocking CalcProb each; new junction windows get aligned on the fly."""
@@ -215,7 +280,7 @@ def drift_block(api, synth, device, g, b1, o1, b2, o2, read_len, cfg, iters=1000
     return {"pairs": sample, "iterations": iters, "what": "CPU oracle with the reference's incremental ScoringState (graph.cc:1936-1950) vs the GPU value, same path sets",
             "ll_rel_delta_max": float(rel.max()), "ll_rel_delta_mean": float(rel.mean()), "ll_rel_delta_last": float(rel[-1]),
             "accept_decisions_that_differ": flips, "of_which_with_a_margin_above_1e-12": flips_real,
-            "moves_within_1e-12_of_a_tie": int((margin <= 1e-12).sum()),
+            "moves_within_1e-12_of_a_tie": int((margin <= 1e-12).sum()),  # (most edits of the one-node start state touch no pair of the sample)
             "smallest_rel_margin_above_1e-12": float(margin[margin > 1e-12].min()) if (margin > 1e-12).any() else 0.0,
             "reads_scored_from_a_residue_at_the_end": residue, "reads_with_negative_probability_at_the_end": neg,
             "gpu_vs_fresh_oracle_rel_delta_max_at_checkpoints": fresh_delta, "checkpoints": checks, "oracle_incremental_s": inc_s}
@@ -254,7 +319,8 @@ def repeats_block(api, synth, device, sa_iters=5000):
     ctx.kernel_stats(reset=True)
     for i in range(128):
         ctx.score(variants[i % 8])
-    ks, gs = ctx.kernel_stats(reset=True), ctx.general_stats()
+    gs = ctx.general_stats()  # (before the reset below, which clears both)
+    ks = ctx.kernel_stats(reset=True)
     ctx.set_event_timing(False)
     out = {"workload": wl.name, "pairs": wl.n_pairs, "walk_nodes": len(walk), "distinct_nodes": len(set(walk)),
            "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.pair_classes(rs)],
@@ -296,7 +362,8 @@ def repeats_block(api, synth, device, sa_iters=5000):
     ctx.kernel_stats(reset=True)
     for f in flat[-200:]:
         ctx.score(f)
-    ks, gs = ctx.kernel_stats(reset=True), ctx.general_stats()
+    gs = ctx.general_stats()  # (before the reset below, which clears both)
+    ks = ctx.kernel_stats(reset=True)
     out["late_annealing_walk"] = {"iterations": sa_iters, "paths_at_end": len(seq[-1]), "call_us_median_last_1000": float(np.median(per[-1000:]) * 1e6),
                                   "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.pair_classes(rs)],
                                   "delta_pairs": ctx.table_stats(rs)["dirty_pairs"],
@@ -355,9 +422,14 @@ def main():
                     "with one rank -- rehearsal on a 1-GPU box")
     ap.add_argument("--no-inproc", action="store_true", help="N > 1: skip the single-process multi-device run on rank 0")
     ap.add_argument("--inproc-devices", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-shard-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-shard-budget", type=float, default=8.0, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-sharded", action="store_true", help="skip the N-process CPU courtesy row")
     args = ap.parse_args()
     if args.inproc_devices:
         return inproc_child(args)
+    if args.cpu_shard_child:
+        return cpu_shard_child(args)
 
     import torch
     import torch.distributed as dist
@@ -673,6 +745,8 @@ def main():
             out["ll_max_rel_delta_vs_cpu"] = max(abs(a - b) / abs(b) for a, b in zip(gpu_vals, cpu_vals))
             out["ll_delta_pairs"] = pairs
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            if not args.no_cpu_sharded and not args.no_extras:
+                out["cpu_baseline_all_cores"] = cpu_baseline_sharded(args.workload, wl.n_pairs)
         print(json.dumps(out), flush=True)
     if use_dist:
         if scorer is not None:
