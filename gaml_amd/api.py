@@ -197,6 +197,10 @@ def _load():
         L.gaml_hip_debug_table_occurrences.restype = C.c_int64
     if hasattr(L, "gaml_hip_debug_window_walk"):  # development build only
         L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
+    for new, old in (("gaml_hip_pair_classes", "gaml_hip_debug_class_counts"), ("gaml_hip_last_phases", "gaml_hip_debug_profile"),
+                     ("gaml_hip_table_stats", "gaml_hip_debug_table_stats"), ("gaml_hip_general_stats", "gaml_hip_debug_general_stats")):
+        if not hasattr(L, new) and hasattr(L, old):  # an older A/B build loaded through GAML_HIP_LIB (tools/)
+            setattr(L, new, getattr(L, old))
     L.gaml_hip_pair_classes.argtypes = [vp, C.c_int, _i64p]
     if hasattr(L, "gaml_hip_debug_fold_check"):  # development build only
         L.gaml_hip_debug_fold_check.argtypes = [vp, C.c_int, _i64p]
@@ -215,7 +219,8 @@ def _load():
         L.gaml_hip_debug_timeline.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
     L.gaml_hip_last_phases.argtypes = [vp, _f64p]
     L.gaml_hip_table_stats.argtypes = [vp, C.c_int, _i64p]
-    L.gaml_hip_general_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    if hasattr(L, "gaml_hip_general_stats"):
+        L.gaml_hip_general_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.gaml_hip_aligner_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.gaml_hip_last_timing.argtypes = [vp, _f64p]
     L.gaml_hip_set_event_timing.argtypes = [vp, C.c_int]

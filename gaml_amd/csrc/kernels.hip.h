@@ -892,6 +892,7 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
       }
     }
     GAML_STAMP(3, o1[0].x ^ o2[0].x)
+    GAML_STAMP(4, 0u)  // (no memo stage here: the values came in with the records)
     // Everything below is straight-line: bit logic on the 32-bit halves, selects instead of branches, every loaded word
     // used unconditionally (a value that is only used inside a branch gets its LOAD moved into that branch by the
     // compiler -- behind a full wait, a round trip of its own; it did that to the fourth pair's records and values).
