@@ -18,6 +18,9 @@
 
 namespace gaml {
 
+#ifdef GAML_ALN_STAMPS
+__device__ unsigned long long g_aln_stamp[32];  // timing builds only (aligner_small.hip.h)
+#endif
 constexpr int kAlnBlock = 256;
 constexpr int kAlnSeed = 15;
 constexpr int kAlnMaxRead = 254;  // visited bitset: 4 x 64 bits per diagonal
@@ -29,7 +32,10 @@ struct AlnCand { int32_t win, strand, order, seed_end, read; };
 struct AlnHit { int32_t win, pos, edit, read, strand, order; };       // edit < 0: no alignment
 
 __device__ __forceinline__ uint32_t aln_code(char c) {  // graph.h:326-331 (G0 A1 T2 C3; anything else 0)
-  return c == 'A' ? 1u : c == 'T' ? 2u : c == 'C' ? 3u : 0u;
+  // branch-free: (c >> 1) & 3 tells A C T G apart (0 1 2 3), 0x2D holds their codes two bits each; a compare chain became
+  // a chain of branches, fifteen of them per seed code
+  const uint32_t known = (uint32_t)(c == 'A') | (uint32_t)(c == 'C') | (uint32_t)(c == 'T');
+  return ((0x2Du >> ((((uint32_t)(unsigned char)c >> 1) & 3u) * 2u)) & 3u) * known;
 }
 __device__ __forceinline__ char aln_comp(char c) {  // graph.h:58-64
   return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
@@ -49,7 +55,8 @@ __device__ __forceinline__ char aln_wbase(const char* s, int W, int strand, int 
 //    blk[w] = first block of window w (blk[n_win] = grid size): 2 x chunks(window length) blocks per window.
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline int aln_span_first(int R) { return R - 1 > kAlnSeed ? R - 1 : kAlnSeed; }  // the reference's loop starts at i = kIndexKmer
-__host__ __device__ inline int aln_span_chunks(int W, int R) { const int f = aln_span_first(R); return W > f ? (W - f + kAlnBlock - 1) / kAlnBlock : 0; }
+constexpr int kAlnSpans = kAlnBlock - 1;  // span ends per block: lane 0 only computes the predecessor of lane 1's span
+__host__ __device__ inline int aln_span_chunks(int W, int R) { const int f = aln_span_first(R); return W > f ? (W - f + kAlnSpans - 1) / kAlnSpans : 0; }
 
 // the bucket whose key is `hash`, or -1: top[h] = first bucket with key >= h << 16 (65537 entries), so the lower
 // bound runs over the few dozen keys that share the hash's upper half -- 5 dependent loads instead of 21
@@ -61,7 +68,11 @@ __device__ __forceinline__ int aln_find_bucket(const uint64_t* bucket_hash, cons
 
 // Both mates of a paired read set in ONE small batch: windows [0, split) are mate 1's, [split, n) mate 2's (the same
 // junction strings, looked up in the other mate's index and extended against the other mate's reads).
+struct AlnHashSlot { uint32_t key; int32_t b0, cnt, used; };  // open addressing, linear probing (aln_hash_home); used = 0 ends a probe sequence
+__host__ __device__ inline uint32_t aln_hash_home(uint32_t key, int bits) { return (key * 0x9E3779B1u) >> (32 - bits); }
 struct AlnMates {
+  const AlnHashSlot* htab[2];  // max-hash key -> its bucket (first entry in bucket_reads, size): 2^hbits slots
+  int hbits[2];
   const uint64_t* bucket_hash[2];
   const int32_t* bucket_top[2];
   const int32_t* bucket_off[2];
@@ -72,68 +83,125 @@ struct AlnMates {
   int split;
 };
 
-// FUSED (small batches of both mates): an emitted span looks its bucket up right here and appends its candidates -- no
-// span list, no second launch.
-// (windows [split, n_win) belong to a second read set -- the other mate -- whose index was built for read length R2)
-template <bool FUSED>
-__global__ __launch_bounds__(kAlnBlock) void span_maxima_kernel(const char* wstr, const AlnWindow* wins, int n_win, int R, const int* blk,
-                                                               AlnSpan* spans, unsigned* n_spans, unsigned cap_spans, int split, int R2,
-                                                               AlnMates ix, AlnCand* cands, unsigned* n_cands, unsigned cap_cands) {
-  __shared__ char sh_str[kAlnBlock + kAlnMaxRead + 2];
-  __shared__ uint32_t sh_code[kAlnBlock + kAlnMaxRead + 2];
-  __shared__ uint32_t sh_max[kAlnBlock];
-  __shared__ int sh_wave[kAlnBlock / 64];
-  __shared__ unsigned sh_base;
-  int lo = 0, hi = n_win;  // the window this block belongs to: last w with blk[w] <= blockIdx.x
+// One block's share of the sliding maximum: the chunk's slice of the window string and its scrambled codes staged in
+// LDS, then per lane (span end i = base + threadIdx.x) the span maximum m, the earliest seed attaining it p, and whether
+// the reference emits here. Returns false (block-uniform) when the block has no work.
+constexpr int kAlnGrpSlots = (kAlnBlock + kAlnMaxRead + 2 + 7) / 8;
+constexpr int kAlnGroups = (kAlnMaxRead - kAlnSeed + 1 + 7) / 8 + 1;  // whole groups of eight keys a span can hold
+struct AlnSpanLds {
+  char str[kAlnBlock + kAlnMaxRead + 2];
+  unsigned long long key[8 * kAlnGrpSlots];             // code << 32 | ~position per seed end (>= kAlnBlock + kAlnMaxRead + 2)
+  unsigned long long grp[kAlnGrpSlots];                 // maxima of aligned groups of eight keys
+  uint32_t mx[kAlnBlock];
+};
+struct AlnSpanLane { bool emit; uint32_t m; int p, i, w, strand; };
+// which window a block of the span grid belongs to: the last w with blk[w] <= blockIdx.x (blk, wins: global memory, or
+// the kernel's own argument segment for a handful of windows -- AlnWinArgs)
+template <class BlkT, class WinT>
+__device__ __forceinline__ int aln_span_locate(const BlkT& blk, const WinT& wins, int n_win, AlnWindow& win, int& rel) {
+  int lo = 0, hi = n_win;
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (blk[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
-  const int w = lo;
-  if (w >= split) R = R2;
-  const AlnWindow win = wins[w];
+  win = wins[lo];
+  rel = (int)blockIdx.x - blk[lo];
+  return lo;
+}
+__device__ __forceinline__ bool aln_span_front(AlnSpanLds& L, const char* wstr, const AlnWindow win, const int w, const int rel, int R, AlnSpanLane& o, char* copy = nullptr) {
   const char* s = wstr + win.str_off;
   const int W = win.len;
   const int chunks = aln_span_chunks(W, R);
-  const int rel = (int)blockIdx.x - blk[w];
-  if (chunks == 0 || rel >= 2 * chunks) return;
+  if (chunks == 0 || rel >= 2 * chunks) return false;
   const int strand = rel / chunks, chunk = rel % chunks;
-  const int base = aln_span_first(R) + chunk * kAlnBlock;     // span ends [base, base + 256)
-  // codes of the seeds ending at j in [c_lo, c_hi]: those of span base - 1 (the first lane's predecessor) up to the last span's
-  const int c_lo = max(base - 1 - R + kAlnSeed, kAlnSeed - 1), c_hi = min(base + kAlnBlock - 1, W - 1);
+  const int base = aln_span_first(R) + chunk * kAlnSpans;     // span ends [base, base + 255): lane t holds span base - 1 + t
+  // codes of the seeds ending at j in [c_lo, c_hi]: those of span base - 1 (lane 0: the predecessor of the block's first span) up to the last span's
+  const int c_lo = max(base - 1 - R + kAlnSeed, kAlnSeed - 1), c_hi = min(base + kAlnSpans - 1, W - 1);
   const int s_lo = c_lo - (kAlnSeed - 1);                        // string bases [s_lo, c_hi]
-  for (int k = threadIdx.x; k <= c_hi - s_lo; k += kAlnBlock) sh_str[k] = aln_wbase(s, W, strand, s_lo + k);
-  __syncthreads();
-  for (int k = threadIdx.x; k <= c_hi - c_lo; k += kAlnBlock) {  // scrambled code of the 15-mer ENDING at c_lo + k
-    uint32_t code = 0;
-    for (int q = 0; q < kAlnSeed; q++) code = (code << 2) | aln_code(sh_str[k + q]);
-    sh_code[k] = code ^ 0x2204abcdu;
-  }
-  __syncthreads();
-  auto span_max = [&](int i, int& p) -> uint32_t {  // maximum over the seeds of the span ending at i; p = the earliest seed attaining it
-    const int lo_j = max(i - R + kAlnSeed, kAlnSeed - 1);
-    uint32_t m = 0;
-    p = -1;
-    for (int j = lo_j; j <= i; j++) { const uint32_t v = sh_code[j - c_lo]; if (p < 0 || v > m) { m = v; p = j; } }  // strictly greater: earliest maximum
-    return m;
-  };
-  const int i = base + (int)threadIdx.x;
-  uint32_t m = 0;
-  int p = -1;
-  if (i < W) m = span_max(i, p);
-  sh_max[threadIdx.x] = m;
-  __syncthreads();
-  bool emit = false;
-  if (i < W) {
-    if (i == R - 1) emit = true;
-    else {
-      // previous span's maximum == what the reference last emitted, except before the first emission
-      // (i-1 < R-1 can only happen when R-1 < kAlnSeed; the host path handles such short reads)
-      uint32_t mprev;
-      if (threadIdx.x > 0) mprev = sh_max[threadIdx.x - 1];
-      else { int pp; mprev = span_max(i - 1, pp); }
-      emit = m != mprev;
+  {  // (both rounds' loads requested before the first LDS store: c_hi - s_lo < 2 * kAlnBlock)
+    const int k0 = threadIdx.x, k1 = threadIdx.x + kAlnBlock, n = c_hi - s_lo;
+    const char a0 = k0 <= n ? aln_wbase(s, W, strand, s_lo + k0) : '\0', a1 = k1 <= n ? aln_wbase(s, W, strand, s_lo + k1) : '\0';
+    if (k0 <= n) L.str[k0] = a0;
+    if (k1 <= n) L.str[k1] = a1;
+    if (copy && strand == 0) {  // the forward chunks of a window cover its whole string (chunk 0 starts at base 0)
+      if (k0 <= n) copy[win.str_off + s_lo + k0] = a0;
+      if (k1 <= n) copy[win.str_off + s_lo + k1] = a1;
     }
   }
+  __syncthreads();
+#ifdef GAML_ALN_STAMPS
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 2) atomicMax(&g_aln_stamp[22], (unsigned long long)wall_clock64());
+#endif
+  // scrambled code of the 15-mer ENDING at c_lo + k, as a key (code << 32 | ~position): the maximum key over a span is its
+  // largest code at the EARLIEST position (graph.cc:1303-1321 keeps the first of equal codes). All fifteen bases of a
+  // code are requested before the first is used (a load per base with its own wait: 3.7 us of this kernel).
+  const int n_codes = c_hi - c_lo + 1;
+  for (int k = threadIdx.x; k < n_codes; k += kAlnBlock) {
+    unsigned char bs[kAlnSeed];
+#pragma unroll
+    for (int q = 0; q < kAlnSeed; q++) bs[q] = (unsigned char)L.str[k + q];
+    uint32_t code = 0;
+#pragma unroll
+    for (int q = 0; q < kAlnSeed; q++) code = (code << 2) | aln_code((char)bs[q]);
+    L.key[k] = ((unsigned long long)(code ^ 0x2204abcdu) << 32) | (uint32_t)~(uint32_t)(c_lo + k);
+  }
+  __syncthreads();
+#ifdef GAML_ALN_STAMPS
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 2) atomicMax(&g_aln_stamp[23], (unsigned long long)wall_clock64());
+#endif
+  // maxima of aligned groups of eight keys; a span's maximum is then <= 7 keys at either end + <= 17 group maxima
+  // instead of R - 14 keys (2.8 us)
+  if ((int)threadIdx.x * 8 < n_codes) {
+    unsigned long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const unsigned long long t = L.key[threadIdx.x * 8 + u]; v[u] = (int)threadIdx.x * 8 + u < n_codes ? t : 0ull; }  // (L.key holds 8 x 64 slots)
+    unsigned long long g8 = 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) g8 = v[u] > g8 ? v[u] : g8;
+    L.grp[threadIdx.x] = g8;
+  }
+  __syncthreads();
+  const int i = base - 1 + (int)threadIdx.x;
+  unsigned long long best = 0;
+  if (i < W) {
+    const int xa = max(i - R + kAlnSeed, kAlnSeed - 1) - c_lo, xb = i - c_lo;  // the span's keys: [xa, xb]
+    if (xa <= xb) {
+      const int ga = (xa + 7) >> 3, gb = (xb + 1) >> 3;  // whole groups [ga, gb)
+      unsigned long long e[14], gm[kAlnGroups];
+      // (every load unconditional, its index clamped, the value masked afterwards: a predicated load compiles to a branch
+      // around the load with a wait of its own)
+#pragma unroll
+      for (int u = 0; u < 7; u++) { const int x = xa + u; const unsigned long long v = L.key[min(x, xb)]; e[u] = (x <= xb && x < 8 * ga) ? v : 0ull; }       // before the first whole group
+#pragma unroll
+      for (int u = 0; u < 7; u++) { const int x = xb - u; const unsigned long long v = L.key[max(x, xa)]; e[7 + u] = (x >= xa && x >= 8 * gb) ? v : 0ull; }  // after the last (a key counted twice changes no maximum)
+#pragma unroll
+      for (int u = 0; u < kAlnGroups; u++) { const unsigned long long v = L.grp[min(ga + u, kAlnGrpSlots - 1)]; gm[u] = ga + u < gb ? v : 0ull; }
+#pragma unroll
+      for (int u = 0; u < 14; u++) best = e[u] > best ? e[u] : best;
+#pragma unroll
+      for (int u = 0; u < kAlnGroups; u++) best = gm[u] > best ? gm[u] : best;
+    }
+  }
+  const uint32_t m = (uint32_t)(best >> 32);
+  const int p = (int)~(uint32_t)best;  // (-1 when the span holds no seed)
+  L.mx[threadIdx.x] = m;
+  __syncthreads();
+  // emission: the first full span, and wherever the maximum differs from the previous span's (== what the reference
+  // last emitted; i - 1 < R - 1 can only happen when R - 1 < kAlnSeed: the host path handles such short reads)
+  const bool emit = threadIdx.x > 0 && i < W && (i == R - 1 || m != L.mx[threadIdx.x - 1]);
+  o = AlnSpanLane{emit, m, p, i, w, strand};
+  return true;
+}
+
+__global__ __launch_bounds__(kAlnBlock) void span_maxima_kernel(const char* wstr, const AlnWindow* wins, int n_win, int R, const int* blk,
+                                                               AlnSpan* spans, unsigned* n_spans, unsigned cap_spans) {
+  __shared__ AlnSpanLds L;
+  __shared__ int sh_wave[kAlnBlock / 64];
+  __shared__ unsigned sh_base;
+  AlnSpanLane o;
+  AlnWindow win;
+  int rel;
+  const int w = aln_span_locate(blk, wins, n_win, win, rel);
+  if (!aln_span_front(L, wstr, win, w, rel, R, o)) return;
   // ordered compaction inside the block: ballots per wave, wave totals through LDS
-  const unsigned long long bal = __ballot(emit);
+  const unsigned long long bal = __ballot(o.emit);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int before = __popcll(bal & ((1ull << lane) - 1ull));
   if (lane == 0) sh_wave[wave] = __popcll(bal);
@@ -142,22 +210,9 @@ __global__ __launch_bounds__(kAlnBlock) void span_maxima_kernel(const char* wstr
   for (int q = 0; q < kAlnBlock / 64; q++) { if (q < wave) wave_before += sh_wave[q]; total += sh_wave[q]; }
   if (threadIdx.x == 0) sh_base = total ? atomicAdd(n_spans, (unsigned)total) : 0;
   __syncthreads();
-  if (emit) {
-    if (FUSED) {
-      const int mt = w >= ix.split ? 1 : 0;
-      const int b = aln_find_bucket(ix.bucket_hash[mt], ix.bucket_top[mt], ix.n_buckets[mt], m);
-      if (b >= 0) {
-        const int b0 = ix.bucket_off[mt][b], b1 = ix.bucket_off[mt][b + 1];
-        const unsigned at = atomicAdd(n_cands, (unsigned)(b1 - b0));
-        for (int k = b0; k < b1; k++) {
-          const unsigned o = at + (unsigned)(k - b0);
-          if (o < cap_cands) cands[o] = AlnCand{w, strand, i, p, ix.bucket_reads[mt][k]};
-        }
-      }
-    } else {
-      const unsigned at = sh_base + (unsigned)(wave_before + before);
-      if (at < cap_spans) spans[at] = AlnSpan{m, p, w, strand, i};
-    }
+  if (o.emit) {
+    const unsigned at = sh_base + (unsigned)(wave_before + before);
+    if (at < cap_spans) spans[at] = AlnSpan{o.m, o.p, o.w, o.strand, o.i};
   }
 }
 
@@ -199,13 +254,15 @@ __global__ __launch_bounds__(kAlnBlock) void candidates_kernel(const AlnSpan* sp
 constexpr int kAlnQueue = 128;                 // heads: r+1 (8 bits) | diag+4 (4 bits) | cost (3 bits)
 constexpr int kAlnWinSeg = kAlnMaxRead + 18;   // window bases a search can touch (read length + 2 x 4 diagonals + slack)
 constexpr int kAlnWaves = 4;                   // candidates per block
-struct AlnWaveLds {
+template <int WS>
+struct AlnWaveLdsT {
   unsigned char rd[kAlnMaxRead + 2];           // the read as aligned (strand applied)
-  unsigned char ws[kAlnWinSeg + 2];            // window segment, 0 beyond the window's end
+  unsigned char ws[WS];                        // window segment, 0 beyond the window's end
   unsigned char seed[16];
   uint32_t vis[9 * 8];                         // 256-bit visited set per diagonal shift in [-4, 4]; bit = read index + 1
   unsigned short q[kAlnQueue];
 };
+using AlnWaveLds = AlnWaveLdsT<kAlnWinSeg + 2>;
 
 __device__ __forceinline__ void aln_lds_sync() {  // LDS traffic of ONE wave: in order in hardware, keep the compiler from reordering
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -213,11 +270,12 @@ __device__ __forceinline__ void aln_lds_sync() {  // LDS traffic of ONE wave: in
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <class Lds>
 struct AlnWaveSearch {
-  AlnWaveLds& L;
+  Lds& L;
   const int lane;
   int qn;
-  __device__ __forceinline__ AlnWaveSearch(AlnWaveLds& l, int ln) : L(l), lane(ln), qn(0) {}
+  __device__ __forceinline__ AlnWaveSearch(Lds& l, int ln) : L(l), lane(ln), qn(0) {}
   __device__ __forceinline__ void reset() {
     qn = 0;
     L.vis[lane] = 0;
@@ -258,6 +316,130 @@ struct AlnWaveSearch {
     }
     aln_lds_sync();
   }
+  // The end of a head's run in ONE round of LDS reads: the run's cells [r_lo, r_hi] of `diag` are marked, and -- when the
+  // run ended in a mismatch (`succ`) -- its up to three successors are tested and marked in the order the reference
+  // pushes them: S = (diag, rs), W = (dw, rw) (both only if `sw`), R = (dr, rr). Every word involved is requested
+  // before any is used; the separate mark_range + 3 x mark took seven dependent LDS round trips per head. Same final
+  // visited set: the successors' bits never lie inside the run's range. Returns bit 0 / 1 / 2 = S / W / R was unvisited.
+  __device__ __forceinline__ unsigned finish_run(int diag, int r_lo, int r_hi, bool succ, bool sw, int rs, int dw, int rw, int dr, int rr) {
+    const int bs = rs + 1, bw = rw + 1, br = rr + 1;
+    const int iw = (dw + 4) * 8 + (bw >> 5), ir = (dr + 4) * 8 + (br >> 5);
+    uint32_t own = 0, ww = ~0u, wr = ~0u;
+    if (lane < 8) own = L.vis[(diag + 4) * 8 + lane];
+    if (succ) { if (sw) ww = L.vis[iw]; wr = L.vis[ir]; }
+    // S lives in one of the run's own words (lane bs >> 5)
+    const uint32_t s_word = (uint32_t)__builtin_amdgcn_readlane((int)own, __builtin_amdgcn_readfirstlane(bs >> 5) & 7);
+    const bool s_new = succ && sw && !((s_word >> (bs & 31)) & 1u);
+    const bool w_new = succ && sw && !((ww >> (bw & 31)) & 1u);
+    const bool r_new = succ && !((wr >> (br & 31)) & 1u);
+    if (lane < 8) {
+      uint32_t m = 0;
+      if (r_hi >= r_lo) {
+        const int lo = r_lo + 1, hi = r_hi + 1, w0 = 32 * lane;  // bit range, inclusive
+        const int a = max(lo, w0), b = min(hi, w0 + 31);
+        if (a <= b) m = (b - a == 31 ? 0xffffffffu : ((1u << (b - a + 1)) - 1u)) << (a - w0);
+      }
+      if (s_new && lane == (bs >> 5)) m |= 1u << (bs & 31);
+      if (m) L.vis[(diag + 4) * 8 + lane] = own | m;
+    }
+    if (lane == 0) {
+      if (w_new) L.vis[iw] = ww | (1u << (bw & 31));
+      if (r_new) L.vis[ir] = wr | (1u << (br & 31));
+    }
+    return (s_new ? 1u : 0u) | (w_new ? 2u : 0u) | (r_new ? 4u : 0u);
+  }
+  // graph.cc:761-793: cost of the cheapest chain from the seed's end to the read's end, or -1. wbase(g) = window base g.
+  template <class WB>
+  __device__ __forceinline__ int forward(const WB& wbase, const int R, const int W, const int win_pos, const int read_pos) {
+    reset();
+    push(0, 0, read_pos + kAlnSeed);
+    aln_lds_sync();
+    for (int qi = 0; qi < qn; qi++) {
+      const uint32_t e = L.q[qi];
+      const int d = (int)(e >> 12), diag = (int)((e >> 8) & 15) - 4;
+      int r = (int)(e & 255) - 1;
+      int g = win_pos + (r - read_pos) + diag;
+      if (d > 3) return -1;
+      while (true) {
+        // lane k looks at cell (g + k, r + k) of the diagonal
+        const int rr = r + lane, gg = g + lane;
+        const bool at_end = rr == R;
+        // (the three LDS reads unconditional and side by side, indices clamped; `||` chains compile to a branch per load)
+        const bool in_read = rr < R;
+        const unsigned char wb = wbase(gg), rb = L.rd[min(rr, kAlnMaxRead)];
+        const bool seen = visited(diag, min(rr, kAlnMaxRead) + 1);
+        const bool may_advance = (gg + 1 < W) | (rr + 1 == R);
+        const bool mism = in_read & (wb != rb);
+        const bool stop = at_end | (in_read & ((wb != rb) | !may_advance | seen));
+        const unsigned long long stops = __ballot(stop & (rr <= R));
+        if (!stops) {  // 64 matching, unvisited cells: the run goes on
+          mark_range(diag, r + 1, r + 64);
+          g += 64; r += 64;
+          continue;
+        }
+        const int k = __ffsll((long long)stops) - 1;
+        const bool end_here = (__ballot(at_end) >> k) & 1ull;
+        const bool mism_here = (__ballot(mism) >> k) & 1ull;
+        if (end_here) return d;
+        // the cells the run moved into, and at a mismatch the successors: substitution, window base skipped, read base skipped
+        const int r0 = r + 1;
+        g += k; r += k;
+        const unsigned fresh = finish_run(diag, r0, r, mism_here, g + 1 < W, r + 1, diag + 1, r, diag - 1, r + 1);
+        if (fresh & 1u) push(d + 1, diag, r + 1);
+        if (fresh & 2u) push(d + 1, diag + 1, r);
+        if (fresh & 4u) push(d + 1, diag - 1, r + 1);
+        aln_lds_sync();
+        break;  // mismatch handled, or the run ended at the window's edge / a visited cell
+      }
+    }
+    return -1;
+  }
+  // graph.cc:794-835: cost from the seed's start back to the read's start and where the alignment begins, or -1
+  template <class WB>
+  __device__ __forceinline__ int backward(const WB& wbase, const int W, const int win_pos, const int read_pos, int& begin_pos) {
+    begin_pos = -1;
+    if (win_pos == 0) return read_pos < 6 ? read_pos : -1;
+    reset();
+    push(0, 0, read_pos - 1);
+    aln_lds_sync();
+    for (int qi = 0; qi < qn; qi++) {
+      const uint32_t e = L.q[qi];
+      const int d = (int)(e >> 12), diag = (int)((e >> 8) & 15) - 4;
+      int r = (int)(e & 255) - 1;
+      int g = win_pos + (r - read_pos) + diag;
+      if (d > 3) return -1;
+      while (true) {
+        // lane k looks at cell (g - k, r - k)
+        const int rr = r - lane, gg = g - lane;
+        const bool at_end = rr == -1;
+        const bool in_read = rr >= 0;
+        const unsigned char wb = wbase(gg), rb = L.rd[max(rr, 0)];
+        const bool seen = visited(diag, max(rr, 0) - 1);
+        const bool may_advance = (gg - 1 >= 0) | (rr - 1 == -1);
+        const bool mism = in_read & (wb != rb);
+        const bool stop = at_end | (in_read & ((wb != rb) | !may_advance | seen));
+        const unsigned long long stops = __ballot(stop & (rr >= -1));
+        if (!stops) {
+          mark_range(diag, r - 64, r - 1);
+          g -= 64; r -= 64;
+          continue;
+        }
+        const int k = __ffsll((long long)stops) - 1;
+        const bool end_here = (__ballot(at_end) >> k) & 1ull;
+        const bool mism_here = (__ballot(mism) >> k) & 1ull;
+        const int r1 = r - 1;
+        g -= k; r -= k;
+        if (end_here) { begin_pos = g + 1; return d; }
+        const unsigned fresh = finish_run(diag, r, r1, mism_here, g - 1 >= 0, r - 1, diag - 1, r, diag + 1, r - 1);
+        if (fresh & 1u) push(d + 1, diag, r - 1);
+        if (fresh & 2u) push(d + 1, diag - 1, r);
+        if (fresh & 4u) push(d + 1, diag + 1, r - 1);
+        aln_lds_sync();
+        break;
+      }
+    }
+    return -1;
+  }
 };
 
 // one candidate, one wave (every `return` leaves the candidate, not the kernel)
@@ -287,7 +469,7 @@ __device__ __forceinline__ void extend_candidate(AlnWaveLds& L, const int lane, 
     const int i = base + lane;
     bool same = i + kAlnSeed <= R;
 #pragma unroll
-    for (int k = 0; k < kAlnSeed; k++) same = same && L.rd[min(i + k, kAlnMaxRead)] == L.seed[k];
+    for (int k = 0; k < kAlnSeed; k++) same = same & (L.rd[min(i + k, kAlnMaxRead)] == L.seed[k]);
     const unsigned long long hit = __ballot(same);
     if (hit) read_pos = base + (__ffsll((long long)hit) - 1);
   }
@@ -297,103 +479,12 @@ __device__ __forceinline__ void extend_candidate(AlnWaveLds& L, const int lane, 
   const int seg = min(kAlnWinSeg, win_pos + (R - read_pos) + 6 - g0);
   for (int b = lane; b < seg; b += 64) L.ws[b] = (unsigned char)(g0 + b < W ? ws[g0 + b] : '\0');  // the reference reads the terminator at g == W
   aln_lds_sync();
-  auto wbase = [&](int g) -> unsigned char { const int i = g - g0; return (i >= 0 && i < seg) ? L.ws[i] : (unsigned char)'\0'; };
-  AlnWaveSearch S(L, lane);
-  // ---- forward (graph.cc:761-793)
-  int fwd = -1;
-  S.reset();
-  S.push(0, 0, read_pos + kAlnSeed);
-  aln_lds_sync();
-  for (int qi = 0; qi < S.qn && fwd < 0; qi++) {
-    const uint32_t e = L.q[qi];
-    const int d = (int)(e >> 12), diag = (int)((e >> 8) & 15) - 4;
-    int r = (int)(e & 255) - 1;
-    int g = win_pos + (r - read_pos) + diag;
-    if (d > 3) { if (lane == 0) hits[t] = out; return; }
-    while (true) {
-      // lane k looks at cell (g + k, r + k) of the diagonal
-      const int rr = r + lane, gg = g + lane;
-      const bool at_end = rr == R;
-      bool stop = at_end, mism = false;
-      if (rr < R) {
-        const bool match = wbase(gg) == L.rd[rr];
-        const bool may_advance = gg + 1 < W || rr + 1 == R;
-        mism = !match;
-        stop = !match || !may_advance || S.visited(diag, rr + 1);
-      }
-      const unsigned long long stops = __ballot(stop && rr <= R);
-      if (!stops) {  // 64 matching, unvisited cells: the run goes on
-        S.mark_range(diag, r + 1, r + 64);
-        g += 64; r += 64;
-        continue;
-      }
-      const int k = __ffsll((long long)stops) - 1;
-      S.mark_range(diag, r + 1, r + k);  // the cells the run moved into
-      const bool end_here = (__ballot(at_end) >> k) & 1ull;
-      const bool mism_here = (__ballot(mism) >> k) & 1ull;
-      g += k; r += k;
-      if (end_here) { fwd = d; break; }
-      if (mism_here) {
-        if (g + 1 < W) {
-          if (S.mark(diag, r + 1)) S.push(d + 1, diag, r + 1);          // substitution
-          if (S.mark(diag + 1, r)) S.push(d + 1, diag + 1, r);          // window base skipped
-        }
-        if (S.mark(diag - 1, r + 1)) S.push(d + 1, diag - 1, r + 1);    // read base skipped
-        aln_lds_sync();
-      }
-      break;  // mismatch handled, or the run ended at the window's edge / a visited cell
-    }
-  }
+  auto wbase = [&](int g) -> unsigned char { const int i = g - g0; const unsigned char v = L.ws[min(max(i, 0), kAlnWinSeg)]; return (i >= 0 && i < seg) ? v : (unsigned char)'\0'; };
+  AlnWaveSearch<AlnWaveLds> S(L, lane);
+  const int fwd = S.forward(wbase, R, W, win_pos, read_pos);
   if (fwd < 0) { if (lane == 0) hits[t] = out; return; }
-  // ---- backward (graph.cc:794-835)
-  int bwd = -1, begin_pos = -1;
-  if (win_pos == 0) {
-    if (read_pos < 6) bwd = read_pos;
-  } else {
-    S.reset();
-    S.push(0, 0, read_pos - 1);
-    aln_lds_sync();
-    for (int qi = 0; qi < S.qn && bwd < 0; qi++) {
-      const uint32_t e = L.q[qi];
-      const int d = (int)(e >> 12), diag = (int)((e >> 8) & 15) - 4;
-      int r = (int)(e & 255) - 1;
-      int g = win_pos + (r - read_pos) + diag;
-      if (d > 3) { if (lane == 0) hits[t] = out; return; }
-      while (true) {
-        // lane k looks at cell (g - k, r - k)
-        const int rr = r - lane, gg = g - lane;
-        const bool at_end = rr == -1;
-        bool stop = at_end, mism = false;
-        if (rr >= 0) {
-          const bool match = wbase(gg) == L.rd[rr];
-          const bool may_advance = gg - 1 >= 0 || rr - 1 == -1;
-          mism = !match;
-          stop = !match || !may_advance || S.visited(diag, rr - 1);
-        }
-        const unsigned long long stops = __ballot(stop && rr >= -1);
-        if (!stops) {
-          S.mark_range(diag, r - 64, r - 1);
-          g -= 64; r -= 64;
-          continue;
-        }
-        const int k = __ffsll((long long)stops) - 1;
-        S.mark_range(diag, r - k, r - 1);
-        const bool end_here = (__ballot(at_end) >> k) & 1ull;
-        const bool mism_here = (__ballot(mism) >> k) & 1ull;
-        g -= k; r -= k;
-        if (end_here) { bwd = d; begin_pos = g + 1; break; }
-        if (mism_here) {
-          if (g - 1 >= 0) {
-            if (S.mark(diag, r - 1)) S.push(d + 1, diag, r - 1);
-            if (S.mark(diag - 1, r)) S.push(d + 1, diag - 1, r);
-          }
-          if (S.mark(diag + 1, r - 1)) S.push(d + 1, diag + 1, r - 1);
-          aln_lds_sync();
-        }
-        break;
-      }
-    }
-  }
+  int begin_pos = -1;
+  const int bwd = S.backward(wbase, W, win_pos, read_pos, begin_pos);
   if (bwd < 0) { if (lane == 0) hits[t] = out; return; }
   out.pos = begin_pos + 1 + win.offset;  // graph.cc:890
   out.edit = fwd + bwd;
@@ -410,19 +501,6 @@ __global__ __launch_bounds__(64 * kAlnWaves) void extend_kernel(const AlnCand* c
   AlnWaveLds& L = lds_all[threadIdx.x >> 6];
   for (unsigned t = blockIdx.x * kAlnWaves + (threadIdx.x >> 6); t < n; t += gridDim.x * kAlnWaves) {  // whole waves move together
     extend_candidate(L, lane, t, cands, wstr, wins, reads, read_off, hits);
-    aln_lds_sync();  // the wave's LDS slice is reused by its next candidate
-  }
-}
-
-__global__ __launch_bounds__(64 * kAlnWaves) void extend_pair_kernel(const AlnCand* cands, const unsigned* n_cands, unsigned cap_cands,
-                                                                     const char* wstr, const AlnWindow* wins, AlnMates ix, AlnHit* hits) {
-  __shared__ AlnWaveLds lds_all[kAlnWaves];
-  const unsigned n = *n_cands < cap_cands ? *n_cands : cap_cands;
-  const int lane = (int)(threadIdx.x & 63);
-  AlnWaveLds& L = lds_all[threadIdx.x >> 6];
-  for (unsigned t = blockIdx.x * kAlnWaves + (threadIdx.x >> 6); t < n; t += gridDim.x * kAlnWaves) {  // whole waves move together
-    const int mt = cands[t].win >= ix.split ? 1 : 0;  // wave-uniform
-    extend_candidate(L, lane, t, cands, wstr, wins, ix.reads[mt], ix.read_off[mt], hits);
     aln_lds_sync();  // the wave's LDS slice is reused by its next candidate
   }
 }

@@ -36,6 +36,32 @@ int aln_upload_index(gaml_hip_ctx* c, const ShortMate& m, AlignDev& d) {
   }
   HIP_TRY(c, up(d.bucket_off, m.bucket_off.data(), m.bucket_off.size() * sizeof(int32_t)));
   HIP_TRY(c, up(d.bucket_reads, m.bucket_reads.data(), m.bucket_reads.size() * sizeof(int32_t)));
+  {
+    // key -> bucket as an open-addressing table (span_cands_kernel: a lookup is one or two loads): load <= 1/2, linear
+    // probing; hbits = 0 (no table: the small batches of both mates take the per-mate route) if a key does not fit 32
+    // bits or a probe sequence would exceed what the kernel walks
+    d.hbits = 0;
+    int bits = 4;
+    while (((size_t)1 << bits) < 2 * m.bucket_hash.size()) bits++;
+    bool fits = bits <= 28;
+    for (uint64_t k : m.bucket_hash) fits = fits && k <= 0xffffffffull;
+    if (fits) {
+      std::vector<AlnHashSlot> tab((size_t)1 << bits, AlnHashSlot{0, 0, 0, 0});
+      const uint32_t mask = (1u << bits) - 1u;
+      int longest = 0;
+      for (size_t b = 0; b < m.bucket_hash.size(); b++) {
+        uint32_t h = aln_hash_home((uint32_t)m.bucket_hash[b], bits);
+        int probes = 1;
+        while (tab[h].used) { h = (h + 1) & mask; probes++; }
+        tab[h] = AlnHashSlot{(uint32_t)m.bucket_hash[b], m.bucket_off[b], m.bucket_off[b + 1] - m.bucket_off[b], 1};
+        longest = std::max(longest, probes);
+      }
+      if (longest <= 60) {
+        HIP_TRY(c, up(d.htab, tab.data(), tab.size() * sizeof(AlnHashSlot)));
+        d.hbits = bits;
+      }
+    }
+  }
   d.uploaded = true;
   return 0;
 }
@@ -45,8 +71,9 @@ int aln_upload_index(gaml_hip_ctx* c, const ShortMate& m, AlignDev& d) {
 int aln_small_reserve(gaml_hip_ctx* c, AlignSmall& S) {
   if (!S.counters.p) { HIP_TRY(c, S.counters.reserve(256)); HIP_TRY(c, hipMemset(S.counters.p, 0, 256)); }  // (publish_hits_kernel leaves them at zero)
   HIP_TRY(c, S.spans.reserve((size_t)kFastSpans * sizeof(AlnSpan)));
-  HIP_TRY(c, S.cands.reserve((size_t)kFastCands * sizeof(AlnCand)));
+  HIP_TRY(c, S.cands.reserve((size_t)kFastCands * sizeof(AlnCandX)));  // (AlnCand, or AlnCandX when both mates share a pipeline)
   HIP_TRY(c, S.hits.reserve((size_t)kFastCands * sizeof(AlnHit)));
+  HIP_TRY(c, S.wcopy.reserve(((size_t)1 << 18) + 64));  // a batch's window strings in ordinary device memory (span_cands_kernel writes, extend_pair2_kernel reads)
   if (!S.out_host.p) { HIP_TRY(c, S.out_host.reserve(64 + 64 + (size_t)kFastCands * sizeof(AlnHit))); memset(S.out_host.p, 0, 128); }
   if (!S.in_dev) {
     const bool direct = c->direct_write && KNOB(c, 8) == 0;
@@ -108,8 +135,8 @@ int aln_small_enqueue(gaml_hip_ctx* c, const ShortMate& m, AlignDev& d, AlignSma
   const AlnWindow* d_wins = (const AlnWindow*)dbase;
   const int* d_blk = (const int*)(dbase + off_blk);
   const char* d_wstr = dbase + off_str;
-  hipLaunchKernelGGL(span_maxima_kernel<false>, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, d_wstr, d_wins, nw, m.index_read_len, d_blk,
-                     S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans, INT_MAX, 0, AlnMates{}, (AlnCand*)nullptr, (unsigned*)nullptr, 0u);
+  hipLaunchKernelGGL(span_maxima_kernel, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, d_wstr, d_wins, nw, m.index_read_len, d_blk,
+                     S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans);
   hipLaunchKernelGGL(candidates_kernel, dim3(64), dim3(kAlnBlock), 0, st, S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans,
                      d.bucket_hash.as<uint64_t>(), d.bucket_top.as<int32_t>(), d.bucket_off.as<int32_t>(), d.bucket_reads.as<int32_t>(), (int)m.bucket_hash.size(), S.cands.as<AlnCand>(),
                      S.counters.as<unsigned>() + 1, kFastCands);
@@ -251,12 +278,14 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   ShortMate* mm[2] = {&ps.mate[0], &ps.mate[1]};
   if (KNOB(c, 5) == 3 || KNOB(c, 5) == 4) return 1;  // knob 5 = 3: general route, 4: one small pipeline per mate (A/B, tests)
   for (int mt = 0; mt < 2; mt++) if (mm[mt]->pending.empty() || !aln_gpu_capable(c, *mm[mt])) return 1;
+  for (int mt = 0; mt < 2; mt++) if (ps.dev[mt].aln.uploaded && ps.dev[mt].aln.hbits == 0) return 1;  // no key table (aln_upload_index)
   const double t0 = now_us();
   HIP_TRY(c, hipSetDevice(c->device));
   AlignSmall& S = c->aln_small[0];
   for (int mt = 0; mt < 2; mt++) {
     if (!ps.dev[mt].aln.uploaded) { if (int e = aln_small_reserve(c, c->aln_small[mt])) return e; }
     if (int e = aln_upload_index(c, *mm[mt], ps.dev[mt].aln)) return e;
+    if (ps.dev[mt].aln.hbits == 0) return 1;
   }
   // windows: mate 1's, then mate 2's; a mate-2 window with the walk of the mate-1 window at the same place shares its string
   const int n0 = (int)mm[0]->pending.size(), n1 = (int)mm[1]->pending.size(), nw = n0 + n1;
@@ -283,14 +312,19 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   if (int e = aln_small_reserve(c, S)) return e;
   const bool direct = c->direct_write && KNOB(c, 8) == 0;
   if (in_bytes > S.in_cap || S.in_direct != direct) return 1;  // (the per-mate route sizes its own input block)
-  char* wp = (char*)S.in_dev;
-  if (!direct) { HIP_TRY(c, S.in_host.reserve(in_bytes)); wp = (char*)S.in_host.p; }
+  // a handful of windows and their strings travel with the launches themselves (AlnWinArgs, AlnStrArgs); otherwise
+  // through the input block: [windows][code-buffer offsets][window strings]
+  const bool in_args = nw <= kAlnArgWins && job.wstr.size() <= (size_t)kAlnArgStr && KNOB(c, 5) != 5;  // knob 5 = 5: always the input block (tests)
   const size_t off_blk = align16(nw * sizeof(AlnWindow)), off_str = off_blk + align16((nw + 1) * sizeof(int32_t));
-  memcpy(wp, job.wins.data(), nw * sizeof(AlnWindow));
-  memcpy(wp + off_blk, job.blk.data(), (nw + 1) * sizeof(int32_t));
-  memcpy(wp + off_str, job.wstr.data(), job.wstr.size());
-  if (direct) _mm_sfence();
-  else HIP_TRY(c, hipMemcpyAsync(S.in_dev, S.in_host.p, in_bytes, hipMemcpyHostToDevice, st));
+  if (!in_args) {
+    char* wp = (char*)S.in_dev;
+    if (!direct) { HIP_TRY(c, S.in_host.reserve(in_bytes)); wp = (char*)S.in_host.p; }
+    memcpy(wp, job.wins.data(), nw * sizeof(AlnWindow));
+    memcpy(wp + off_blk, job.blk.data(), (nw + 1) * sizeof(int32_t));
+    memcpy(wp + off_str, job.wstr.data(), job.wstr.size());
+    if (direct) _mm_sfence();
+    else HIP_TRY(c, hipMemcpyAsync(S.in_dev, S.in_host.p, in_bytes, hipMemcpyHostToDevice, st));
+  }
   const char* dbase = (const char*)S.in_dev;
   const AlnWindow* d_wins = (const AlnWindow*)dbase;
   const int* d_blk = (const int*)(dbase + off_blk);
@@ -298,20 +332,47 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   AlnMates ix;
   for (int mt = 0; mt < 2; mt++) {
     const AlignDev& d = ps.dev[mt].aln;
+    ix.htab[mt] = d.htab.as<AlnHashSlot>(); ix.hbits[mt] = d.hbits;
     ix.bucket_hash[mt] = d.bucket_hash.as<uint64_t>(); ix.bucket_top[mt] = d.bucket_top.as<int32_t>(); ix.bucket_off[mt] = d.bucket_off.as<int32_t>(); ix.bucket_reads[mt] = d.bucket_reads.as<int32_t>();
     ix.n_buckets[mt] = (int)mm[mt]->bucket_hash.size();
     ix.reads[mt] = d.reads.as<char>(); ix.read_off[mt] = d.read_off.as<int64_t>();
   }
   ix.split = n0;
-  hipLaunchKernelGGL(span_maxima_kernel<true>, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, d_wstr, d_wins, nw, mm[0]->index_read_len, d_blk,
-                     S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), kFastSpans, n0, mm[1]->index_read_len, ix, S.cands.as<AlnCand>(),
-                     S.counters.as<unsigned>() + 1, kFastCands);
-  hipLaunchKernelGGL(extend_pair_kernel, dim3(1024), dim3(64 * kAlnWaves), 0, st, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1, kFastCands, d_wstr,
-                     d_wins, ix, S.hits.as<AlnHit>());
+  // two dispatches: spans + candidates, then the extension, whose last block publishes (aligner_small.hip.h)
+#ifdef GAML_ALN_STAMPS
+  {
+    unsigned long long z[32];
+    for (int k = 0; k < 32; k++) z[k] = (k == 0 || k == 8) ? ~0ull : 0ull;
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_aln_stamp), z, sizeof(z)));
+  }
+#endif
+  AlnWinArgs wa{};
+  AlnStrArgs& sa = S.str_args;  // (only its first job.wstr.size() bytes are read)
+  if (in_args) {
+    memcpy(sa.s, job.wstr.data(), job.wstr.size());
+    wa.n = nw;
+    for (int k = 0; k < nw; k++) { wa.blk[k] = job.blk[(size_t)k]; wa.w[k] = job.wins[(size_t)k]; }
+    wa.blk[nw] = job.blk[(size_t)nw];
+  }
+#ifdef GAML_ALN_STAMPS
+  if (getenv("GAML_ALN_TWICE")) {  // the same batch once before, unstamped results thrown away: does a warm instruction cache change the stamps?
+    hipLaunchKernelGGL(span_cands_kernel, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, sa, in_args ? 1 : 0, d_wstr, d_wins, nw, mm[0]->index_read_len, d_blk, n0,
+                       mm[1]->index_read_len, ix, wa, S.cands.as<AlnCandX>(), S.counters.as<unsigned>() + 1, kFastCands, S.wcopy.as<char>());
+    const unsigned long long sq = ++S.out_seq;
+    char* oh0 = (char*)S.out_host.dev;
+    hipLaunchKernelGGL(extend_pair2_kernel, dim3(512), dim3(128 * kAlnPairs), 0, st, sa, in_args ? 1 : 0, S.cands.as<AlnCandX>(), S.counters.as<unsigned>(), kFastCands, S.wcopy.as<char>(), ix,
+                       (AlnHit*)(oh0 + 128), (unsigned*)(oh0 + 64), (volatile unsigned long long*)oh0, sq);
+    unsigned long long z[32];
+    for (int k = 0; k < 32; k++) z[k] = (k == 0 || k == 8) ? ~0ull : 0ull;
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_aln_stamp), z, sizeof(z)));
+  }
+#endif
+  hipLaunchKernelGGL(span_cands_kernel, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, sa, in_args ? 1 : 0, d_wstr, d_wins, nw, mm[0]->index_read_len, d_blk, n0,
+                     mm[1]->index_read_len, ix, wa, S.cands.as<AlnCandX>(), S.counters.as<unsigned>() + 1, kFastCands, S.wcopy.as<char>());
   job.seq = ++S.out_seq;
   char* oh = (char*)S.out_host.dev;
-  hipLaunchKernelGGL(publish_hits_kernel, dim3(1), dim3(256), 0, st, S.counters.as<unsigned>(), S.hits.as<AlnHit>(), kFastCands, (unsigned*)(oh + 64),
-                     (AlnHit*)(oh + 128), kFastCands, (volatile unsigned long long*)oh, job.seq);
+  hipLaunchKernelGGL(extend_pair2_kernel, dim3(512), dim3(128 * kAlnPairs), 0, st, sa, in_args ? 1 : 0, S.cands.as<AlnCandX>(), S.counters.as<unsigned>(), kFastCands, S.wcopy.as<char>(), ix,
+                     (AlnHit*)(oh + 128), (unsigned*)(oh + 64), (volatile unsigned long long*)oh, job.seq);
   HIP_TRY(c, hipGetLastError());
   job.enqueued = true;
   const double t1 = now_us();
@@ -320,6 +381,17 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   const int rc = aln_small_collect(c, S, job, hits, &nc);
   if (rc != 0) return rc;  // 1: the candidates did not fit: the per-mate route redoes the batch
   const double t2 = now_us();
+#ifdef GAML_ALN_STAMPS
+  {
+    unsigned long long z[32];
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpyFromSymbol(z, HIP_SYMBOL(g_aln_stamp), sizeof(z)));
+    auto us = [&](int k, int ref) { return z[k] ? (double)(long long)(z[k] - z[ref]) * 0.01 : -1.0; };
+    fprintf(stderr, "aln stamps (us after the first wave of each kernel; last wave through): windows %d cands %u | span: entry %.2f strings %.2f codes %.2f front %.2f hash %.2f scan+atomic %.2f expanded %.2f | "
+            "gap %.2f | extend: entry %.2f cand %.2f reads ptr %.2f read bytes %.2f all bytes %.2f (shader clock %.0f MHz) bytes->lds %.2f seed %.2f fwd %.2f bwd %.2f block done %.2f published %.2f | host enqueue->seen %.1f\n",
+            nw, nc, us(1, 0), us(22, 0), us(23, 0), us(2, 0), us(3, 0), us(4, 0), us(5, 0), us(8, 0), us(9, 8), us(10, 8), us(18, 8), us(19, 8), us(17, 8), z[21] ? (double)z[20] / ((double)z[21] * 0.01) : 0.0, us(11, 8), us(12, 8), us(13, 8), us(14, 8), us(15, 8), us(16, 8), t2 - t1);
+  }
+#endif
   // split by mate (the window numbers of mate 2 start at n0)
   std::vector<AlnHit> h1;
   h1.reserve(hits.size());
@@ -389,9 +461,8 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
     HIP_TRY(c, S.cands.reserve(cap_cands * sizeof(AlnCand)));
     HIP_TRY(c, hipMemset(S.counters.p, 0, 16));
     if (blk[(size_t)nw] > 0) {
-      hipLaunchKernelGGL(span_maxima_kernel<false>, dim3((unsigned)blk[(size_t)nw]), dim3(kAlnBlock), 0, 0, S.wstr.as<char>(), S.wins.as<AlnWindow>(), nw,
-                         m.index_read_len, S.blk.as<int>(), S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), (unsigned)cap_spans, INT_MAX, 0, AlnMates{},
-                         (AlnCand*)nullptr, (unsigned*)nullptr, 0u);
+      hipLaunchKernelGGL(span_maxima_kernel, dim3((unsigned)blk[(size_t)nw]), dim3(kAlnBlock), 0, 0, S.wstr.as<char>(), S.wins.as<AlnWindow>(), nw,
+                         m.index_read_len, S.blk.as<int>(), S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), (unsigned)cap_spans);
       HIP_TRY(c, hipGetLastError());
     }
     hipLaunchKernelGGL(candidates_kernel, dim3(256), dim3(kAlnBlock), 0, 0, S.spans.as<AlnSpan>(), S.counters.as<unsigned>(),

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "aligner.hip.h"
+#include "aligner_small.hip.h"
 #include "host_model.h"
 #include "kernels.hip.h"
 #include "pacbio_dp.hip.h"
@@ -127,8 +128,10 @@ struct Reducer {  // per read set: partials + ticket + 2-double result
 
 struct AlignDev {  // device copies the GPU aligner needs: reads (1 byte per base) + the max-hash index
   DevBuf reads, read_off, bucket_hash, bucket_top, bucket_off, bucket_reads;  // bucket_top: first bucket per upper half of the key (aln_find_bucket)
+  DevBuf htab;     // key -> bucket, open addressing (AlnHashSlot, 2^hbits slots; hbits = 0: none)
+  int hbits = 0;
   bool uploaded = false;
-  void release() { reads.release(); read_off.release(); bucket_hash.release(); bucket_top.release(); bucket_off.release(); bucket_reads.release(); }
+  void release() { reads.release(); read_off.release(); bucket_hash.release(); bucket_top.release(); bucket_off.release(); bucket_reads.release(); htab.release(); }
 };
 struct AlignScratch {  // per context, grown on demand
   DevBuf wstr, wins, blk, spans, cands, hits, counters;
@@ -141,12 +144,13 @@ struct AlignScratch {  // per context, grown on demand
 // block written by the host (device memory behind the BAR, or its pinned twin), counters + hits published in mapped
 // pinned memory behind a sequence word.
 struct AlignSmall {
-  DevBuf spans, cands, hits, counters;
+  DevBuf spans, cands, hits, counters, wcopy;
   void* in_dev = nullptr; size_t in_cap = 0; bool in_direct = false;
   PinBuf in_host, out_host;
+  AlnStrArgs str_args;  // a small batch's window strings as they travel in the launches' argument segments
   unsigned long long out_seq = 0;
   void release() {
-    spans.release(); cands.release(); hits.release(); counters.release();
+    spans.release(); cands.release(); hits.release(); counters.release(); wcopy.release();
     if (in_dev) (void)hipFree(in_dev);
     in_dev = nullptr; in_cap = 0; in_host.release(); out_host.release();
   }

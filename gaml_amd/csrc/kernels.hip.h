@@ -1083,13 +1083,27 @@ __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, i
 
 // delta store maintenance: one thread per patched pair writes its slot, spill index and padded records
 struct DeltaPatch { int dj, slot, spill, pad; int4 rec[2][4]; };
-__global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const DeltaPatch* patch, int n, int* slots, int* spill, int4* rec0, int4* rec1) {
+// the class tables' "this pair lives on the delta lists now" marks (one per new delta pair); kDirty8 / kDirtyWid
+__device__ __forceinline__ void mark_dirty_slot(int s, unsigned long long* rec8_0, int n0, int4* inl_0, int n01, int n_main, int4* first_0) {
+  if (s < n0) rec8_0[s] = ~0ull - 1;
+  else {
+    if (s < n01) inl_0[(size_t)2 * (s - n0)].x = -2;
+    else if (s < n_main) inl_0[(size_t)2 * (n01 - n0) + (size_t)4 * (s - n01)].x = -2;
+    first_0[s - n0].x = -2;
+  }
+}
+// `patch` is read where the host wrote it (mapped pinned memory): no copy kernel in front; delta pairs numbered
+// mark_from and up are new with this patch and get their marks here (mark_from < 0: none) -- one dispatch where there
+// were three: copy, patch, marks
+__global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const DeltaPatch* patch, int n, int* slots, int* spill, int4* rec0, int4* rec1, int mark_from,
+                                                                   unsigned long long* rec8_0, int n0, int4* inl_0, int n01, int n_main, int4* first_0) {
   for (int t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) {
     const DeltaPatch p = patch[t];
     slots[p.dj] = p.slot;
     spill[p.dj] = p.spill;
 #pragma unroll
     for (int k = 0; k < 4; k++) { rec0[4 * (size_t)p.dj + k] = p.rec[0][k]; rec1[4 * (size_t)p.dj + k] = p.rec[1][k]; }
+    if (mark_from >= 0 && p.dj >= mark_from) mark_dirty_slot(p.slot, rec8_0, n0, inl_0, n01, n_main, first_0);
   }
 }
 
@@ -1893,15 +1907,7 @@ __global__ __launch_bounds__(kBlock) void pacbio_score_kernel(PacbioArgs a) {
 // mark the slots of delta pairs in the record tables (idempotent; runs before the scoring kernel)
 __global__ __launch_bounds__(kBlock) void mark_dirty_kernel(const int* slots, int n, unsigned long long* rec8_0, int n0, int4* inl_0,
                                                             int n01, int n_main, int4* first_0) {
-  for (int t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) {
-    const int s = slots[t];
-    if (s < n0) rec8_0[s] = kDirty8;
-    else {
-      if (s < n01) inl_0[(size_t)2 * (s - n0)].x = kDirtyWid;
-      else if (s < n_main) inl_0[(size_t)2 * (n01 - n0) + (size_t)4 * (s - n01)].x = kDirtyWid;
-      first_0[s - n0].x = kDirtyWid;
-    }
-  }
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) mark_dirty_slot(slots[t], rec8_0, n0, inl_0, n01, n_main, first_0);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -516,12 +516,18 @@ int paired_reserve_delta(gaml_hip_ctx* c, PairedSet& s) {
 // a patch for the lists `touched` names: their fixed-stride device copy (slot, spill index, 4 records per mate). The
 // lists are the live ones or those being prepared for a worker's tables (`pt` = the tables the slots refer to).
 struct DeltaStore { DevBuf* slot; DevBuf* spill; DevBuf* rec0; DevBuf* rec1; };
+// mark_from >= 0: delta pairs [mark_from, dirty.size()) are new on the LIVE tables and need their marks there; when
+// the patch names every one of them (the usual case: a new pair is a touched pair) the patch kernel sets them and
+// *marked_out becomes true
 static int delta_upload_patch(gaml_hip_ctx* c, PairedSet& s, hipStream_t st, const PairTables& pt, const std::vector<PairedSet::DirtyPair>& dirty,
                               std::vector<int32_t>& touched, std::vector<int32_t>& spill_of, std::vector<int32_t>& spill_pairs, bool* spill_changed,
-                              const DeltaStore& dev) {
+                              const DeltaStore& dev, int64_t mark_from = -1, bool* marked_out = nullptr) {
   const size_t nd = dirty.size();
   std::sort(touched.begin(), touched.end());
   touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+  const bool fuse_marks = mark_from >= 0 && (int64_t)nd > mark_from &&
+                          (int64_t)(touched.end() - std::lower_bound(touched.begin(), touched.end(), (int32_t)mark_from)) == (int64_t)nd - mark_from;
+  if (marked_out) *marked_out = fuse_marks;
   spill_of.resize(nd, -1);
   const size_t np_patch = touched.size();
   void* ph = nullptr;
@@ -550,12 +556,13 @@ static int delta_upload_patch(gaml_hip_ctx* c, PairedSet& s, hipStream_t st, con
     pe.rec[0][0].w = (int)((uint32_t)s.mate[0].lens[read] | ((uint32_t)s.mate[1].lens[read] << 16));
     pe.rec[1][0].w = lng ? 0 : (int)(d.recs[0].size() | (d.recs[1].size() << 8));
   }
-  HIP_TRY(c, s.dl_patch.reserve(np_patch * sizeof(DeltaPatch) + 1));
-  if (int e = stage_upload(c, s.stage_delta, pslot, s.dl_patch.p, np_patch * sizeof(DeltaPatch), st)) return e;
-  if (int e = stage_release(c, s.stage_delta, pslot, st)) return e;
+  // the kernel reads the patch where the host wrote it (mapped pinned memory; the slot is held until the kernel is through)
+  const int n0 = (int)s.pt.class_count[0], n01 = n0 + (int)s.pt.class_count[1], n_main = n01 + (int)s.pt.class_count[2];
   hipLaunchKernelGGL(apply_delta_patch_kernel, dim3((unsigned)std::min<size_t>((np_patch + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
-                     (const DeltaPatch*)s.dl_patch.p, (int)np_patch, dev.slot->as<int>(), dev.spill->as<int>(), dev.rec0->as<int4>(), dev.rec1->as<int4>());
+                     (const DeltaPatch*)s.stage_delta.host[pslot].dev, (int)np_patch, dev.slot->as<int>(), dev.spill->as<int>(), dev.rec0->as<int4>(), dev.rec1->as<int4>(),
+                     fuse_marks ? (int)mark_from : -1, s.tab.rec8[0].as<unsigned long long>(), n0, s.tab.inl[0].as<int4>(), n01, n_main, s.tab.first[0].as<int4>());
   HIP_TRY(c, hipGetLastError());
+  if (int e = stage_release(c, s.stage_delta, pslot, st)) return e;
   touched.clear();
   return 0;
 }
@@ -565,9 +572,12 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   if (s.dirty_touched.empty() && !s.spill_changed) return 0;
   if (int e = paired_reserve_delta(c, s)) return e;
   if (s.dirty.size() > s.delta_cap) return fail(c, GAML_HIP_ESTATE, "delta store overflow (rebuild policy violated)");
-  if (!s.dirty_touched.empty())
+  if (!s.dirty_touched.empty()) {
+    bool marked = false;
     if (int e = delta_upload_patch(c, s, st, s.pt, s.dirty, s.dirty_touched, s.spill_of, s.spill_pairs, &s.spill_changed,
-                                   DeltaStore{&s.dl_slot, &s.dl_spill, &s.dl_rec[0], &s.dl_rec[1]})) return e;
+                                   DeltaStore{&s.dl_slot, &s.dl_spill, &s.dl_rec[0], &s.dl_rec[1]}, (int64_t)s.dirty_marked, &marked)) return e;
+    if (marked) s.dirty_marked = s.dirty.size();  // (paired_sync_tables marks what a patch did not cover: after a take-over)
+  }
   if (s.spill_changed) {  // the few long lists: CSR rebuilt as a whole
     const size_t ns = s.spill_pairs.size();
     size_t dn[2] = {0, 0};
