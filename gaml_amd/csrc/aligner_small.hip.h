@@ -223,25 +223,33 @@ __global__ __launch_bounds__(128 * kAlnPairs) void extend_pair2_kernel(AlnStrArg
       const int fwd = sh_res[pair][0], bwd = sh_res[pair][2], bp = sh_res[pair][3];
       AlnHit out{c.win, 0, -1, c.read, c.strand, c.order};
       if (fwd >= 0 && bwd >= 0) { out.pos = bp + 1 + c.w_offset; out.edit = fwd + bwd; }  // graph.cc:890
-      h_hits[t] = out;
+      // system-scope stores: written through to host memory (a plain store may sit in this XCD's L2 until the kernel ends)
+      unsigned long long* dst = (unsigned long long*)(h_hits + t);
+      __hip_atomic_store(dst + 0, (unsigned long long)(uint32_t)out.win | ((unsigned long long)(uint32_t)out.pos << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(dst + 1, (unsigned long long)(uint32_t)out.edit | ((unsigned long long)(uint32_t)out.read << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(dst + 2, (unsigned long long)(uint32_t)out.strand | ((unsigned long long)(uint32_t)out.order << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();  // sh_res and the waves' LDS slices are reused by the next round
   }
   // Only blocks that had candidates draw a ticket (a thousand idle blocks' atomics on one line took 30 us, and the
-  // candidate count next to it waited behind them); with no candidate at all block 0 publishes. This block's hits have
-  // left for host memory (uncached: nothing to write back, only to wait for) before its ticket is drawn.
+  // candidate count next to it waited behind them); with no candidate at all block 0 publishes. This block's hits must
+  // have REACHED host memory before its ticket is drawn: the publisher sits on another XCD as a rule, and its own
+  // release writes back its own L2 only. (Without the per-block release below two processes sharing one GPU lost a few
+  // dozen hits of a 3,000-candidate batch once in four runs: tools/dist_diag.py -- the host saw the sequence word
+  // before some blocks' hits.)
   const unsigned working = n == 0 ? 1u : min((n + kAlnPairs - 1) / kAlnPairs, gridDim.x);
   if (blockIdx.x >= working) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   ALN_STAMP(15);
   if (threadIdx.x == 0) {
-    const unsigned ticket = __hip_atomic_fetch_add(&counters[kAlnTicketWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();  // release at system scope: everything this block wrote (the barrier above) is out of the caches
+    const unsigned ticket = __hip_atomic_fetch_add(&counters[kAlnTicketWord], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket == working - 1) {  // every other working block has left its hits: publish, and leave the counters at zero for the next batch
       h_counts[0] = 0; h_counts[1] = n_cands;
       counters[0] = 0; counters[1] = 0; counters[kAlnTicketWord] = 0;
       __threadfence_system();
-      *h_seq = seq;
+      __hip_atomic_store((unsigned long long*)h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef GAML_ALN_STAMPS
       atomicMax(&g_aln_stamp_pub, (unsigned long long)wall_clock64());
 #endif
