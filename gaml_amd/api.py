@@ -204,6 +204,8 @@ def _load():
     L.gaml_hip_pair_classes.argtypes = [vp, C.c_int, _i64p]
     if hasattr(L, "gaml_hip_debug_fold_check"):  # development build only
         L.gaml_hip_debug_fold_check.argtypes = [vp, C.c_int, _i64p]
+    if hasattr(L, "gaml_hip_debug_radix_sort"):  # development build only
+        L.gaml_hip_debug_radix_sort.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
     if hasattr(L, "gaml_hip_debug_static_check"):  # absent from older A/B builds loaded through GAML_HIP_LIB
         L.gaml_hip_debug_static_check.argtypes = [vp, C.c_int, _i64p]
     if hasattr(L, "gaml_hip_debug_set_knob"):  # development build only
@@ -712,6 +714,17 @@ class Context:
         self._check(_lib.gaml_hip_debug_fold_check(self._h, rs, out))
         return {"records_left_out": [int(out[0]), int(out[1])], "compact_pairs": [int(out[2]), int(out[3])], "records_checked": int(out[4]),
                 "violations": int(out[5])}
+
+    def debug_radix_sort(self, keys, vals=None, begin_bit=0, end_bit=64, running_max=False):
+        """The library's own stable radix sort on bits [begin_bit, end_bit) (gaml_amd/csrc/radix_sort.hip.h): returns the
+        sorted keys, the payload in the keys' order (or None) and, if asked for, the inclusive running maximum of the
+        sorted payload (of the sorted keys without one)."""
+        k = np.ascontiguousarray(keys, np.uint64).copy()
+        v = None if vals is None else np.ascontiguousarray(vals, np.uint64).copy()
+        m = np.zeros(len(k), np.uint64) if running_max else None
+        self._check(_lib.gaml_hip_debug_radix_sort(self._h, k.ctypes.data, None if v is None else v.ctypes.data, len(k), begin_bit, end_bit,
+                                                   None if m is None else m.ctypes.data))
+        return k, v, m
 
     def debug_static_check(self, rs):
         """Host-only: the compact class's static memo indices recomputed from the window cache."""

@@ -156,6 +156,10 @@ int aln_small_collect(gaml_hip_ctx* c, AlignSmall& S, AlnJob& job, std::vector<A
   volatile unsigned long long* word = (volatile unsigned long long*)S.out_host.p;
   const double t0 = now_us();
   bool seen = false;
+#ifdef GAML_HIP_DEV
+  static const int wait_mode = getenv("GAML_ALN_WAIT") ? atoi(getenv("GAML_ALN_WAIT")) : 0;  // A/B: 1 = the runtime's wait first
+  if (wait_mode == 1) { HIP_TRY(c, hipStreamSynchronize((hipStream_t)job.stream)); c->aln_stage_us[2] += now_us() - t0; }
+#endif
   while (!seen && now_us() - t0 < 5000.0) { for (int k = 0; k < 256 && !seen; k++) { seen = *word == job.seq; __builtin_ia32_pause(); } }
   if (!seen) { HIP_TRY(c, hipStreamSynchronize((hipStream_t)job.stream)); if (*word != job.seq) return fail(c, GAML_HIP_ESTATE, "aligner: the publish kernel finished without its sequence word"); }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -367,20 +371,47 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
     HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_aln_stamp), z, sizeof(z)));
   }
 #endif
-  hipLaunchKernelGGL(span_cands_kernel, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, sa, in_args ? 1 : 0, d_wstr, d_wins, nw, mm[0]->index_read_len, d_blk, n0,
-                     mm[1]->index_read_len, ix, wa, S.cands.as<AlnCandX>(), S.counters.as<unsigned>() + 1, kFastCands, S.wcopy.as<char>());
+#ifdef GAML_HIP_DEV
+  // A/B (GAML_ALN_WAIT=2): events attached to the two dispatches -- the device's own begin / end stamps next to the host's wait
+  static const int ev_mode = getenv("GAML_ALN_WAIT") ? atoi(getenv("GAML_ALN_WAIT")) : 0;
+  static hipEvent_t aev[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (ev_mode == 2 && !aev[0]) for (int k = 0; k < 4; k++) HIP_TRY(c, hipEventCreate(&aev[k]));
+  const bool timed = ev_mode == 2;
+#else
+  constexpr bool timed = false;
+  hipEvent_t aev[4] = {nullptr, nullptr, nullptr, nullptr};
+#endif
+  const double ta = now_us();
+  hipExtLaunchKernelGGL(span_cands_kernel, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, timed ? aev[0] : nullptr, timed ? aev[1] : nullptr, 0, sa, in_args ? 1 : 0, d_wstr, d_wins, nw, mm[0]->index_read_len, d_blk, n0,
+                        mm[1]->index_read_len, ix, wa, S.cands.as<AlnCandX>(), S.counters.as<unsigned>() + 1, kFastCands, S.wcopy.as<char>(),
+                        timed ? (unsigned long long*)((char*)S.out_host.dev + 32) : nullptr, S.out_seq + 1);
+  const double tb = now_us();
   job.seq = ++S.out_seq;
   char* oh = (char*)S.out_host.dev;
-  hipLaunchKernelGGL(extend_pair2_kernel, dim3(512), dim3(128 * kAlnPairs), 0, st, sa, in_args ? 1 : 0, S.cands.as<AlnCandX>(), S.counters.as<unsigned>(), kFastCands, S.wcopy.as<char>(), ix,
-                     (AlnHit*)(oh + 128), (unsigned*)(oh + 64), (volatile unsigned long long*)oh, job.seq);
+  hipExtLaunchKernelGGL(extend_pair2_kernel, dim3(512), dim3(128 * kAlnPairs), 0, st, timed ? aev[2] : nullptr, timed ? aev[3] : nullptr, 0, sa, in_args ? 1 : 0, S.cands.as<AlnCandX>(), S.counters.as<unsigned>(), kFastCands, S.wcopy.as<char>(), ix,
+                        (AlnHit*)(oh + 128), (unsigned*)(oh + 64), (volatile unsigned long long*)oh, job.seq);
   HIP_TRY(c, hipGetLastError());
   job.enqueued = true;
   const double t1 = now_us();
+  double t_started = t1;
+  if (timed) {
+    volatile unsigned long long* sw = (volatile unsigned long long*)((char*)S.out_host.p + 32);
+    while (*sw != job.seq && now_us() - t1 < 2000.0) __builtin_ia32_pause();
+    t_started = now_us();
+  }
   std::vector<AlnHit> hits;
   unsigned nc = 0;
   const int rc = aln_small_collect(c, S, job, hits, &nc);
   if (rc != 0) return rc;  // 1: the candidates did not fit: the per-mate route redoes the batch
   const double t2 = now_us();
+  if (timed) {
+    HIP_TRY(c, hipEventSynchronize(aev[3]));
+    const double t2b = now_us();
+    float k1 = 0, k2 = 0, all = 0, gap = 0;
+    (void)hipEventElapsedTime(&k1, aev[0], aev[1]); (void)hipEventElapsedTime(&k2, aev[2], aev[3]); (void)hipEventElapsedTime(&all, aev[0], aev[3]); (void)hipEventElapsedTime(&gap, aev[1], aev[2]);
+    fprintf(stderr, "aln timed: launch1 %.1f launch2 %.1f | enqueued -> grid started (seen by the host) %.1f | wait (enqueued -> seen) %.1f, + event sync %.1f | device: span %.1f gap %.1f extend %.1f, first begin -> last end %.1f us (cands %u)\n",
+            tb - ta, t1 - tb, t_started - t1, t2 - t1, t2b - t2, k1 * 1e3, gap * 1e3, k2 * 1e3, all * 1e3, nc);
+  }
 #ifdef GAML_ALN_STAMPS
   {
     unsigned long long z[32];
@@ -495,30 +526,26 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
     if (nc >= 100000 && KNOB(c, 5) != 2 && longest < (1 << 24)) {
       const size_t n = nc;
       HIP_TRY(c, S.sort_keys.reserve(4 * n * sizeof(unsigned long long)));   // minor | major | two alternates
-      HIP_TRY(c, S.sort_idx.reserve(2 * n * sizeof(unsigned)));
+      HIP_TRY(c, S.sort_idx.reserve(3 * n * sizeof(unsigned)));
       HIP_TRY(c, S.hits_sorted.reserve(n * sizeof(AlnHit)));
+      HIP_TRY(c, S.sort_tmp.reserve(rs_hist_bytes(n)));
       unsigned long long* k_minor = S.sort_keys.as<unsigned long long>();
       unsigned long long* k_major = k_minor + n;
       unsigned long long* k_alt = k_major + n;
       unsigned long long* k_alt2 = k_alt + n;
       unsigned* idx = S.sort_idx.as<unsigned>();
       unsigned* idx_alt = idx + n;
+      unsigned* idx_tmp = idx_alt + n;
       unsigned* n_ok = S.counters.as<unsigned>() + 2;
       HIP_TRY(c, hipMemset(n_ok, 0, sizeof(unsigned)));
       const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
       hipLaunchKernelGGL(hit_keys_kernel, dim3(grid), dim3(256), 0, 0, S.hits.as<AlnHit>(), (unsigned)n, k_minor, k_major, idx, n_ok);
       HIP_TRY(c, hipGetLastError());
-      size_t tmp_bytes = 0;
-      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_minor, k_alt, idx, idx_alt, (int)n, 0, 56, (hipStream_t)0));
-      HIP_TRY(c, S.sort_tmp.reserve(tmp_bytes));
-      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(S.sort_tmp.p, tmp_bytes, k_minor, k_alt, idx, idx_alt, (int)n, 0, 56, (hipStream_t)0));
-      // second, stable pass by (window, position): the major keys in the order of the first pass
+      // two stable radix sorts (radix_sort.hip.h): by (read, strand, order), then by (window, position) in that order
+      HIP_TRY(c, rs_sort<unsigned>(k_minor, k_alt, k_alt2, idx, idx_alt, idx_tmp, n, 0, 56, S.sort_tmp.as<unsigned>(), (hipStream_t)0));
       hipLaunchKernelGGL(gather_u64_kernel, dim3(grid), dim3(256), 0, 0, k_major, idx_alt, (unsigned)n, k_alt);
       HIP_TRY(c, hipGetLastError());
-      size_t tmp2 = 0;
-      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, k_alt, k_alt2, idx_alt, idx, (int)n, 0, 64, (hipStream_t)0));
-      HIP_TRY(c, S.sort_tmp.reserve(tmp2));
-      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(S.sort_tmp.p, tmp2, k_alt, k_alt2, idx_alt, idx, (int)n, 0, 64, (hipStream_t)0));
+      HIP_TRY(c, rs_sort<unsigned>(k_alt, k_alt2, k_minor, idx_alt, idx, idx_tmp, n, 0, 64, S.sort_tmp.as<unsigned>(), (hipStream_t)0));
       hipLaunchKernelGGL(gather_hits_kernel, dim3(grid), dim3(256), 0, 0, S.hits.as<AlnHit>(), idx, (unsigned)n, S.hits_sorted.as<AlnHit>());
       HIP_TRY(c, hipGetLastError());
       unsigned ok_count = 0;

@@ -66,7 +66,8 @@ __device__ __forceinline__ const char* aln_arg_strings(const char* fallback, int
 }
 // (windows [split, n_win) belong to a second read set -- the other mate -- whose index was built for read length R2)
 __global__ __launch_bounds__(kAlnBlock) void span_cands_kernel(AlnStrArgs, int str_in_args, const char* wstr, const AlnWindow* wins, int n_win, int R, const int* blk, int split, int R2,
-                                                              AlnMates ix, AlnWinArgs wa, AlnCandX* cands, unsigned* n_cands, unsigned cap_cands, char* wcopy) {
+                                                              AlnMates ix, AlnWinArgs wa, AlnCandX* cands, unsigned* n_cands, unsigned cap_cands, char* wcopy,
+                                                              unsigned long long* h_started = nullptr, unsigned long long started_seq = 0) {
   __shared__ AlnSpanLds L;
   __shared__ int sh_pref[kAlnBlock], sh_b0[kAlnBlock], sh_p[kAlnBlock];
   __shared__ int sh_wave[kAlnBlock / 64];
@@ -75,6 +76,8 @@ __global__ __launch_bounds__(kAlnBlock) void span_cands_kernel(AlnStrArgs, int s
   AlnWindow win;
   int rel;
   ALN_STAMP_FIRST(0); ALN_STAMP(1);
+  // (development A/B: block 0 tells the host that the grid has started)
+  if (h_started && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(h_started, started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   wstr = aln_arg_strings(wstr, str_in_args);
   const int w = wa.n > 0 ? aln_span_locate(wa.blk, wa.w, wa.n, win, rel) : aln_span_locate(blk, wins, n_win, win, rel);
   if (!aln_span_front(L, wstr, win, w, rel, w >= split ? R2 : R, o, wcopy)) return;

@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <hipcub/hipcub.hpp>
+#include "radix_sort.hip.h"
 
 #include <algorithm>
 #include <atomic>

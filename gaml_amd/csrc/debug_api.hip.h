@@ -137,6 +137,35 @@ int gaml_hip_debug_fold_check(gaml_hip_ctx* c, int rs, int64_t* out6) {
   return bad ? fail(c, GAML_HIP_ESTATE, "record tables: a record was left out that is not always overwritten") : GAML_HIP_OK;
 }
 
+// The library's own radix sort and running maximum (radix_sort.hip.h) on caller data, for the tests: keys[n] (+ payload
+// vals[n], null: keys only) sorted stably on bits [begin_bit, end_bit) in place; run_max (null: skip) receives the
+// inclusive running maximum of the SORTED payload (or of the sorted keys when there is no payload).
+int gaml_hip_debug_radix_sort(gaml_hip_ctx* c, uint64_t* keys, uint64_t* vals, int64_t n, int begin_bit, int end_bit, uint64_t* run_max) {
+  MULTI_SHARD0(c);
+  if (!c || c->device < 0 || !keys || n < 0 || begin_bit < 0 || end_bit > 64) return fail(c, c ? GAML_HIP_EINVAL : GAML_HIP_EINVAL, "bad arguments");
+  if (n == 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  typedef rs_u64 u64;
+  DevBuf k_in, k_out, k_tmp, v_in, v_out, v_tmp, hist, rm, mx;
+  const size_t bytes = (size_t)n * sizeof(u64);
+  for (DevBuf* b : {&k_in, &k_out, &k_tmp, &mx}) HIP_TRY(c, b->reserve(bytes));
+  if (vals) for (DevBuf* b : {&v_in, &v_out, &v_tmp}) HIP_TRY(c, b->reserve(bytes));
+  HIP_TRY(c, hist.reserve(rs_hist_bytes((size_t)n)));
+  HIP_TRY(c, rm.reserve(rm_scratch_bytes((size_t)n)));
+  hipStream_t st = c->stream;
+  HIP_TRY(c, hipMemcpyAsync(k_in.p, keys, bytes, hipMemcpyHostToDevice, st));
+  if (vals) HIP_TRY(c, hipMemcpyAsync(v_in.p, vals, bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, rs_sort<u64>(k_in.as<u64>(), k_out.as<u64>(), k_tmp.as<u64>(), vals ? v_in.as<u64>() : (const u64*)nullptr, vals ? v_out.as<u64>() : (u64*)nullptr,
+                          vals ? v_tmp.as<u64>() : (u64*)nullptr, (size_t)n, begin_bit, end_bit, hist.as<unsigned>(), st));
+  if (run_max) HIP_TRY(c, rm_inclusive_max(vals ? v_out.as<u64>() : k_out.as<u64>(), mx.as<u64>(), (size_t)n, rm.as<u64>(), st));
+  HIP_TRY(c, hipMemcpyAsync(keys, k_out.p, bytes, hipMemcpyDeviceToHost, st));
+  if (vals) HIP_TRY(c, hipMemcpyAsync(vals, v_out.p, bytes, hipMemcpyDeviceToHost, st));
+  if (run_max) HIP_TRY(c, hipMemcpyAsync(run_max, mx.p, bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  for (DevBuf* b : {&k_in, &k_out, &k_tmp, &v_in, &v_out, &v_tmp, &hist, &rm, &mx}) b->release();
+  return 0;
+}
+
 // Host-only check of the static memo indices (PairTables::static_idx): tables of the windows that are active now,
 // every compact-class pair looked at again from the window cache -- the two records' windows compared by their node
 // walks, orientation rule and insert distance recomputed (graph.cc:1864-1876). out8 = {pairs with a static index, other

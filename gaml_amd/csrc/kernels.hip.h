@@ -1828,7 +1828,15 @@ __global__ __launch_bounds__(kBlock) void single_score_kernel(SingleArgs a) {
     const int4 r0 = a.m.first[i];
     const int L = a.lens[i];
     double acc = 0.0;
-    if (r0.x >= 0) {
+    // One record whose window occurs at most once in the scored paths -- nearly every read of an assembly without
+    // repeats -- is its own only candidate: nothing can overwrite it (graph.cc:631-641), no second pass over the candidates.
+    bool single_cand = false;
+    if (r0.x >= 0 && ((unsigned)r0.z >> 9) == 0) {
+      const int4 o = mate_occ(a.m, r0.x);
+      if (o.z < 0) single_cand = true;  // the window is not part of the scored paths: the read scores nothing here
+      else if (o.w >= 0) { single_cand = true; const int e = r0.z & 0xff; acc = a.m.mism_pow[e] * a.m.match_pow[L - e]; }
+    }
+    if (r0.x >= 0 && !single_cand) {
       for_each_cand(a.m, r0, [&](const Cand& x) {
         // positions are absolute here (path index * 1e6 folded into shift); all paths share one map
         bool live = true;

@@ -76,11 +76,9 @@ int pacbio_sweep_run(gaml_hip_ctx* c, PacbioSet& s, int64_t n, int32_t n_paths, 
   int path_bits = 1;
   while ((1 << path_bits) < n_paths && path_bits < 30) path_bits++;
   const int end_bit = 32 + path_bits;
-  size_t tmp1 = 0, tmp2 = 0, tmp3 = 0;
-  HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, (const u64*)nullptr, (u64*)nullptr, (const u64*)nullptr, (u64*)nullptr, (int)n1, 0, end_bit, st));
-  HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp2, (const u64*)nullptr, (u64*)nullptr, (int)(2 * n1), 0, end_bit, st));
-  HIP_TRY(c, hipcub::DeviceScan::InclusiveScan(nullptr, tmp3, (const u64*)nullptr, (u64*)nullptr, hipcub::Max(), (int)n1, st));
-  const size_t tmp_bytes = std::max(std::max(tmp1, tmp2), std::max<size_t>(tmp3, 16));
+  // scratch of the sorts and of the running maximum (radix_sort.hip.h): [keys, 2 n][payload, n][digit counts][tile maxima]
+  const size_t off_vals = 2 * n1 * sizeof(u64), off_hist = off_vals + n1 * sizeof(u64), off_rm = off_hist + align16(rs_hist_bytes(2 * n1));
+  const size_t tmp_bytes = off_rm + align16(rm_scratch_bytes(n1));
   if (n1 * sizeof(u64) > d.key_begin.cap || tmp_bytes > d.tmp.cap || !d.bad.p) {
     HIP_TRY(c, hipStreamSynchronize(st));
     for (DevBuf* b : {&d.key_begin, &d.key_end, &d.key_begin_s, &d.key_end_s, &d.end_max}) HIP_TRY(c, b->reserve(n1 * sizeof(u64)));
@@ -93,12 +91,13 @@ int pacbio_sweep_run(gaml_hip_ctx* c, PacbioSet& s, int64_t n, int32_t n_paths, 
     const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
     hipLaunchKernelGGL(pacbio_sweep_keys_kernel, dim3(grid), dim3(256), 0, st, d.all.as<int4>(), (int)n, d.key_begin.as<u64>(), d.key_end.as<u64>(), d.pos.as<u64>());
     HIP_TRY(c, hipGetLastError());
-    size_t t = d.tmp.cap;
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(d.tmp.p, t, d.key_begin.as<u64>(), d.key_begin_s.as<u64>(), d.key_end.as<u64>(), d.key_end_s.as<u64>(), (int)n, 0, end_bit, st));
-    t = d.tmp.cap;
-    HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(d.tmp.p, t, d.pos.as<u64>(), d.pos_s.as<u64>(), (int)(2 * n), 0, end_bit, st));
-    t = d.tmp.cap;
-    HIP_TRY(c, hipcub::DeviceScan::InclusiveScan(d.tmp.p, t, d.key_end_s.as<u64>(), d.end_max.as<u64>(), hipcub::Max(), (int)n, st));
+    u64* const tmp_keys = (u64*)d.tmp.p;
+    u64* const tmp_vals = (u64*)((char*)d.tmp.p + off_vals);
+    unsigned* const hist = (unsigned*)((char*)d.tmp.p + off_hist);
+    // intervals by (contig, begin), their ends travelling with them; positions by (contig, position); running maximum of the ends
+    HIP_TRY(c, rs_sort<u64>(d.key_begin.as<u64>(), d.key_begin_s.as<u64>(), tmp_keys, d.key_end.as<u64>(), d.key_end_s.as<u64>(), tmp_vals, (size_t)n, 0, end_bit, hist, st));
+    HIP_TRY(c, rs_sort<u64>(d.pos.as<u64>(), d.pos_s.as<u64>(), tmp_keys, (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, (size_t)(2 * n), 0, end_bit, hist, st));
+    HIP_TRY(c, rm_inclusive_max(d.key_end_s.as<u64>(), d.end_max.as<u64>(), (size_t)n, (u64*)((char*)d.tmp.p + off_rm), st));
     const unsigned grid2 = (unsigned)std::min<int64_t>((2 * n + 255) / 256, 1024);
     hipLaunchKernelGGL(pacbio_sweep_kernel, dim3(grid2), dim3(256), 0, st, d.pos_s.as<u64>(), (int)(2 * n), d.key_begin_s.as<u64>(), d.end_max.as<u64>(), (int)n,
                        d.in.as<int>(), s.cfg.step, d.bad.as<u64>());

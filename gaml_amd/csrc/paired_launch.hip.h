@@ -405,7 +405,7 @@ void paired_launch_worker(gaml_hip_ctx* c, PairedSet& s) {
 int paired_continue_snapshot(gaml_hip_ctx* c, PairedSet& s, bool all_at_once) {
   TableRebuild& rb = s.rebuild;
   const double t0 = now_us();
-  const int64_t budget = all_at_once ? INT64_MAX / 4 : 96 * 1024;  // ~1.5 MB of records per evaluation
+  const int64_t budget = all_at_once ? INT64_MAX / 4 : 24 * 1024;  // ~0.4 MB of records per mate and evaluation (~40 us; 96 K records were the 250-380 us calls at the tail of an annealing run)
   bool done = true;
   for (int mt = 0; mt < 2; mt++) done = paired_snapshot_slice(s.mate[mt], rb.snap[mt], &rb.next_w[mt], budget) && done;
   rb.snapshot_us += now_us() - t0;

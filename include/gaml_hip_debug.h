@@ -80,6 +80,11 @@ int gaml_hip_debug_set_knob(gaml_hip_ctx* ctx, int knob, int value);
  * pair. out6 = {records left out mate 1, mate 2, compact-class pairs with / without the rule, records checked,
  * violations}; GAML_HIP_ESTATE if a record was left out that the rule does not cover. */
 int gaml_hip_debug_fold_check(gaml_hip_ctx* ctx, int readset, int64_t* out6);
+/* The library's own stable radix sort (gaml_amd/csrc/radix_sort.hip.h: the aligner's hit ordering, graph.cc:841, 895-897, and
+   the PacBio coverage sweep, graph.cc:3198-3250) on caller data: keys[n] and, unless null, vals[n] are sorted in place on
+   bits [begin_bit, end_bit); run_max (or null) receives the inclusive running maximum of the sorted payload (of the sorted
+   keys without one). */
+int gaml_hip_debug_radix_sort(gaml_hip_ctx* ctx, uint64_t* keys, uint64_t* vals, int64_t n, int begin_bit, int end_bit, uint64_t* run_max);
 /* host-only: the static memo indices of the compact class (both records of a pair in windows with the same node walk:
  * orientation rule, insert distance and memo index do not depend on the path set) recomputed from the window cache.
  * out8 = {pairs with an index, other compact-class pairs, violations, then why those others have none: a mate without
