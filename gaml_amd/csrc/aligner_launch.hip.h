@@ -160,9 +160,18 @@ int aln_small_collect(gaml_hip_ctx* c, AlignSmall& S, AlnJob& job, std::vector<A
   static const int wait_mode = getenv("GAML_ALN_WAIT") ? atoi(getenv("GAML_ALN_WAIT")) : 0;  // A/B: 1 = the runtime's wait first
   if (wait_mode == 1) { HIP_TRY(c, hipStreamSynchronize((hipStream_t)job.stream)); c->aln_stage_us[2] += now_us() - t0; }
 #endif
+#ifdef GAML_HIP_DEV
+  if ((wait_mode == 3 || wait_mode == 4) && S.in_direct && S.in_dev) {  // A/B: a read through the BAR per poll keeps the PCIe link out of its idle states
+    volatile unsigned* bar = (volatile unsigned*)S.in_dev;
+    unsigned sink = 0;
+    while (!seen && now_us() - t0 < 5000.0) { for (int k = 0; k < 64 && !seen; k++) { sink += *bar; seen = *word == job.seq; } }
+    if (sink == 0x12345678u) fprintf(stderr, "\n");
+  }
+#endif
   while (!seen && now_us() - t0 < 5000.0) { for (int k = 0; k < 256 && !seen; k++) { seen = *word == job.seq; __builtin_ia32_pause(); } }
   if (!seen) { HIP_TRY(c, hipStreamSynchronize((hipStream_t)job.stream)); if (*word != job.seq) return fail(c, GAML_HIP_ESTATE, "aligner: the publish kernel finished without its sequence word"); }
   std::atomic_thread_fence(std::memory_order_acquire);
+  S.seen_us = now_us();
   job.enqueued = false;
   const unsigned* counts = (const unsigned*)((const char*)S.out_host.p + 64);
   if (counts[0] > kFastSpans || counts[1] > kFastCands) return 1;  // did not fit: the general route redoes the batch
@@ -375,8 +384,8 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   // A/B (GAML_ALN_WAIT=2): events attached to the two dispatches -- the device's own begin / end stamps next to the host's wait
   static const int ev_mode = getenv("GAML_ALN_WAIT") ? atoi(getenv("GAML_ALN_WAIT")) : 0;
   static hipEvent_t aev[4] = {nullptr, nullptr, nullptr, nullptr};
-  if (ev_mode == 2 && !aev[0]) for (int k = 0; k < 4; k++) HIP_TRY(c, hipEventCreate(&aev[k]));
-  const bool timed = ev_mode == 2;
+  if ((ev_mode == 2 || ev_mode == 4) && !aev[0]) for (int k = 0; k < 4; k++) HIP_TRY(c, hipEventCreate(&aev[k]));
+  const bool timed = ev_mode == 2 || ev_mode == 4;
 #else
   constexpr bool timed = false;
   hipEvent_t aev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -409,8 +418,8 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
     const double t2b = now_us();
     float k1 = 0, k2 = 0, all = 0, gap = 0;
     (void)hipEventElapsedTime(&k1, aev[0], aev[1]); (void)hipEventElapsedTime(&k2, aev[2], aev[3]); (void)hipEventElapsedTime(&all, aev[0], aev[3]); (void)hipEventElapsedTime(&gap, aev[1], aev[2]);
-    fprintf(stderr, "aln timed: launch1 %.1f launch2 %.1f | enqueued -> grid started (seen by the host) %.1f | wait (enqueued -> seen) %.1f, + event sync %.1f | device: span %.1f gap %.1f extend %.1f, first begin -> last end %.1f us (cands %u)\n",
-            tb - ta, t1 - tb, t_started - t1, t2 - t1, t2b - t2, k1 * 1e3, gap * 1e3, k2 * 1e3, all * 1e3, nc);
+    fprintf(stderr, "aln timed: launch1 %.1f launch2 %.1f | enqueued -> grid started (seen by the host) %.1f | enqueued -> sequence word seen %.1f, hits copied %.1f, + event sync %.1f | device: span %.1f gap %.1f extend %.1f, first begin -> last end %.1f us (cands %u)\n",
+            tb - ta, t1 - tb, t_started - t1, S.seen_us - t1, t2 - t1, t2b - t2, k1 * 1e3, gap * 1e3, k2 * 1e3, all * 1e3, nc);
   }
 #ifdef GAML_ALN_STAMPS
   {

@@ -149,6 +149,7 @@ struct AlignSmall {
   PinBuf in_host, out_host;
   AlnStrArgs str_args;  // a small batch's window strings as they travel in the launches' argument segments
   unsigned long long out_seq = 0;
+  double seen_us = 0;   // host clock when the last batch's sequence word was seen (timing builds)
   void release() {
     spans.release(); cands.release(); hits.release(); counters.release(); wcopy.release();
     if (in_dev) (void)hipFree(in_dev);

@@ -534,7 +534,14 @@ static int delta_upload_patch(gaml_hip_ctx* c, PairedSet& s, hipStream_t st, con
   int pslot = stage_acquire(c, s.stage_delta, np_patch * sizeof(DeltaPatch), &ph);
   if (pslot < 0) return pslot;
   DeltaPatch* patch = (DeltaPatch*)ph;
+  const int32_t* const lens0 = s.mate[0].lens.data();
+  const int32_t* const lens1 = s.mate[1].lens.data();
   for (size_t t = 0; t < np_patch; t++) {
+    // an entry touches its delta pair (~200 bytes), the pair's read id and the read's two lengths, each chosen by the one
+    // before: three cache misses in a row per entry when taken one entry after the other. Ask for them ahead.
+    if (t + 24 < np_patch) { const char* q = (const char*)&dirty[touched[t + 24]]; __builtin_prefetch(q); __builtin_prefetch(q + 64); __builtin_prefetch(q + 128); }
+    if (t + 16 < np_patch) __builtin_prefetch(&pt.read_of_slot[dirty[touched[t + 16]].slot]);
+    if (t + 8 < np_patch) { const int32_t rd = pt.read_of_slot[dirty[touched[t + 8]].slot]; __builtin_prefetch(&lens0[rd]); __builtin_prefetch(&lens1[rd]); }
     const int32_t dj = touched[t];
     const auto& d = dirty[dj];
     DeltaPatch& pe = patch[t];
