@@ -58,6 +58,11 @@ def stdout_to_stderr():
         yield
     finally:
         sys.stdout.flush()
+        try:  # the banner goes through C stdio: out of libc's buffer while fd 1 still points at stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(saved, 1)
         os.close(saved)
 
@@ -452,10 +457,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        if share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        with stdout_to_stderr():  # (a process group with a device id makes its communicator -- and prints RCCL's banner -- here)
+            if share_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = synth.WORKLOADS[args.workload]
     strong = args.scaling == "strong"

@@ -237,17 +237,20 @@ __global__ __launch_bounds__(128 * kAlnPairs) void extend_pair2_kernel(AlnStrArg
   // Only blocks that had candidates draw a ticket (a thousand idle blocks' atomics on one line took 30 us, and the
   // candidate count next to it waited behind them); with no candidate at all block 0 publishes. This block's hits must
   // have REACHED host memory before its ticket is drawn: the publisher sits on another XCD as a rule, and its own
-  // release writes back its own L2 only. (Without the per-block release below two processes sharing one GPU lost a few
-  // dozen hits of a 3,000-candidate batch once in four runs: tools/dist_diag.py -- the host saw the sequence word
-  // before some blocks' hits.)
+  // release writes back its own L2 only. The hits are therefore stored at system scope (written through, not left in
+  // this XCD's L2) and waited for (vmcnt) before the barrier in front of the ticket. (With plain stores two processes
+  // sharing one GPU lost a few dozen hits of a 3,000-candidate batch once in four runs: tools/dist_diag.py -- the host
+  // saw the sequence word before some blocks' hits.)
   const unsigned working = n == 0 ? 1u : min((n + kAlnPairs - 1) / kAlnPairs, gridDim.x);
   if (blockIdx.x >= working) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   ALN_STAMP(15);
   if (threadIdx.x == 0) {
-    __threadfence_system();  // release at system scope: everything this block wrote (the barrier above) is out of the caches
-    const unsigned ticket = __hip_atomic_fetch_add(&counters[kAlnTicketWord], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GAML_ALN_BLOCK_FENCE  // (A/B: a full system-scope release per working block on top of the written-through stores)
+    __threadfence_system();
+#endif
+    const unsigned ticket = __hip_atomic_fetch_add(&counters[kAlnTicketWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket == working - 1) {  // every other working block has left its hits: publish, and leave the counters at zero for the next batch
       h_counts[0] = 0; h_counts[1] = n_cands;
       counters[0] = 0; counters[1] = 0; counters[kAlnTicketWord] = 0;

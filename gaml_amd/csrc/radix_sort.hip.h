@@ -3,10 +3,10 @@
 //   * the aligner's hits of a large batch by (window, position, read, strand, order) -- the order in which the reference
 //     files alignments per window (graph.cc:841, 891, 895-897; graph.h:229-232) -- aligner_launch.hip.h
 //   * the PacBio coverage sweep's intervals by (contig, begin) and its positions (graph.cc:3198-3250) -- pacbio_launch.hip.h
-// Eight bits per pass, three dispatches per pass, no library:
+// Eight bits per pass, four small dispatches per pass, no library:
 //   rs_histogram_kernel   a block counts the digits of its tile (kRsTile keys) -> hist[digit][block]
-//   rs_scan_kernel        ONE block: exclusive prefix over hist in (digit, block) order = where each block's keys of each
-//                         digit start in the output
+//   rs_scan_digit_kernel  + rs_scan_totals_kernel: exclusive prefix over hist in (digit, block) order = where each block's
+//                         keys of each digit start in the output
 //   rs_scatter_kernel     the block walks its tile again in chunks of 256 keys IN INPUT ORDER; a key's rank among the
 //                         chunk's equal digits comes from wave ballots (eight, one per digit bit) and the waves' counts in
 //                         LDS; a running base per digit carries over the chunks. Equal digits keep their input order:
@@ -40,32 +40,56 @@ __global__ __launch_bounds__(kRsBlock) void rs_histogram_kernel(const rs_u64* ke
   hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = cnt[threadIdx.x];
 }
 
-// exclusive prefix over m = 256 * n_blocks counters, in place; one block, every thread a contiguous run
-__global__ __launch_bounds__(kRsScanBlock) void rs_scan_kernel(unsigned* hist, unsigned m) {
-  __shared__ unsigned wave_sum[kRsScanBlock / 64];
-  const unsigned per = (m + kRsScanBlock - 1) / kRsScanBlock;
-  const unsigned lo = min(m, threadIdx.x * per), hi = min(m, lo + per);
-  unsigned own = 0;
-  for (unsigned i = lo; i < hi; i++) own += hist[i];
-  // exclusive prefix of `own` over the block: shuffles inside a wave, the waves' totals through LDS
+// The offsets in two small steps (one block walking all 256 * n_blocks counters took 150 us a pass -- every thread a run
+// of its own, a cache line per lane and load):
+//   rs_scan_digit_kernel   block d: exclusive prefix of digit d's counts over the blocks, in place (coalesced chunks of
+//                          256 with a carry), and the digit's total -> totals[d]
+//   rs_scan_totals_kernel  one block: exclusive prefix of the 256 totals, in place
+// A block's keys of digit d then start at totals[d] + hist[d][block] (rs_scatter_kernel adds the two).
+__global__ __launch_bounds__(kRsBlock) void rs_scan_digit_kernel(unsigned* hist, unsigned n_blocks, unsigned* totals) {
+  __shared__ unsigned wave_sum[kRsBlock / 64];
+  __shared__ unsigned carry_sh;
+  unsigned* row = hist + (size_t)blockIdx.x * n_blocks;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned incl = own;
+  if (threadIdx.x == 0) carry_sh = 0;
+  __syncthreads();
+  for (unsigned c0 = 0; c0 < n_blocks; c0 += kRsBlock) {  // (block-uniform)
+    const unsigned i = c0 + threadIdx.x;
+    const unsigned v = i < n_blocks ? row[i] : 0u;
+    unsigned incl = v;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const unsigned v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    for (int d = 1; d < 64; d <<= 1) { const unsigned u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    unsigned before = carry_sh;
+    for (int w = 0; w < wave; w++) before += wave_sum[w];
+    if (i < n_blocks) row[i] = before + incl - v;
+    __syncthreads();  // everyone has read carry_sh and wave_sum
+    if (threadIdx.x == kRsBlock - 1) carry_sh = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_sh;
+}
+__global__ __launch_bounds__(kRsBlock) void rs_scan_totals_kernel(unsigned* totals) {
+  __shared__ unsigned wave_sum[kRsBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned v = totals[threadIdx.x];
+  unsigned incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const unsigned u = __shfl_up(incl, d); if (lane >= d) incl += u; }
   if (lane == 63) wave_sum[wave] = incl;
   __syncthreads();
   unsigned before = 0;
   for (int w = 0; w < wave; w++) before += wave_sum[w];
-  unsigned run = before + incl - own;
-  for (unsigned i = lo; i < hi; i++) { const unsigned c = hist[i]; hist[i] = run; run += c; }
+  totals[threadIdx.x] = before + incl - v;
 }
 
 template <class V, bool HAS_V>
-__global__ __launch_bounds__(kRsBlock) void rs_scatter_kernel(const rs_u64* keys, const V* vals, unsigned n, int shift, unsigned mask, unsigned n_blocks, const unsigned* offs,
+__global__ __launch_bounds__(kRsBlock) void rs_scatter_kernel(const rs_u64* keys, const V* vals, unsigned n, int shift, unsigned mask, unsigned n_blocks, const unsigned* offs, const unsigned* totals,
                                                              rs_u64* keys_out, V* vals_out) {
   __shared__ unsigned base[256];                   // where this block's next key of each digit goes
   __shared__ unsigned wcnt[kRsBlock / 64][256];    // the chunk's digit counts per wave
-  base[threadIdx.x] = offs[(size_t)threadIdx.x * n_blocks + blockIdx.x];
+  base[threadIdx.x] = totals[threadIdx.x] + offs[(size_t)threadIdx.x * n_blocks + blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned lo = blockIdx.x * (unsigned)kRsTile;
   for (int k = 0; k < kRsChunks; k++) {
@@ -109,7 +133,7 @@ __global__ __launch_bounds__(kRsBlock) void rs_scatter_kernel(const rs_u64* keys
 }
 
 // bytes of `hist` scratch a sort of n keys needs
-inline size_t rs_hist_bytes(size_t n) { return (size_t)256 * ((n + kRsTile - 1) / kRsTile) * sizeof(unsigned) + 16; }
+inline size_t rs_hist_bytes(size_t n) { return (size_t)256 * ((n + kRsTile - 1) / kRsTile + 1) * sizeof(unsigned) + 16; }  // counts + the 256 digit totals
 
 // keys_in / vals_in are left untouched; the result lands in keys_out / vals_out; keys_tmp / vals_tmp: n entries each
 // (vals_*: null for a key-only sort). Bits [begin_bit, end_bit) take part. Everything is enqueued on `st`.
@@ -135,9 +159,11 @@ inline hipError_t rs_sort(const rs_u64* keys_in, rs_u64* keys_out, rs_u64* keys_
     const int shift = begin_bit + 8 * p;
     const unsigned mask = (1u << (end_bit - shift < 8 ? end_bit - shift : 8)) - 1u;  // the last pass may hold fewer than eight bits
     hipLaunchKernelGGL(rs_histogram_kernel, dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, (unsigned)n, shift, mask, n_blocks, hist);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(kRsScanBlock), 0, st, hist, 256u * n_blocks);
-    if (has_v) hipLaunchKernelGGL((rs_scatter_kernel<V, true>), dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, src_v, (unsigned)n, shift, mask, n_blocks, hist, dst_k, dst_v);
-    else hipLaunchKernelGGL((rs_scatter_kernel<V, false>), dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, (const V*)nullptr, (unsigned)n, shift, mask, n_blocks, hist, dst_k, (V*)nullptr);
+    unsigned* const totals = hist + (size_t)256 * n_blocks;
+    hipLaunchKernelGGL(rs_scan_digit_kernel, dim3(256), dim3(kRsBlock), 0, st, hist, n_blocks, totals);
+    hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(kRsBlock), 0, st, totals);
+    if (has_v) hipLaunchKernelGGL((rs_scatter_kernel<V, true>), dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, src_v, (unsigned)n, shift, mask, n_blocks, hist, totals, dst_k, dst_v);
+    else hipLaunchKernelGGL((rs_scatter_kernel<V, false>), dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, (const V*)nullptr, (unsigned)n, shift, mask, n_blocks, hist, totals, dst_k, (V*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     src_k = dst_k; src_v = dst_v;
