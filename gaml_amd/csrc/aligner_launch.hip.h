@@ -161,6 +161,9 @@ int aln_small_collect(gaml_hip_ctx* c, AlignSmall& S, AlnJob& job, std::vector<A
   if (wait_mode == 1) { HIP_TRY(c, hipStreamSynchronize((hipStream_t)job.stream)); c->aln_stage_us[2] += now_us() - t0; }
 #endif
 #ifdef GAML_HIP_DEV
+  if (wait_mode == 5) {  // A/B: spin on the (cached) word without PAUSE -- a virtual CPU that executes PAUSE in a loop may be descheduled by its hypervisor
+    while (!seen && now_us() - t0 < 5000.0) { for (int k = 0; k < 4096 && !seen; k++) seen = *word == job.seq; }
+  }
   if ((wait_mode == 3 || wait_mode == 4) && S.in_direct && S.in_dev) {  // A/B: a read through the BAR per poll keeps the PCIe link out of its idle states
     volatile unsigned* bar = (volatile unsigned*)S.in_dev;
     unsigned sink = 0;
@@ -402,11 +405,17 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   HIP_TRY(c, hipGetLastError());
   job.enqueued = true;
   const double t1 = now_us();
-  double t_started = t1;
+  double t_started = t1, t_ev_ready = 0, t_word = 0;
   if (timed) {
     volatile unsigned long long* sw = (volatile unsigned long long*)((char*)S.out_host.p + 32);
     while (*sw != job.seq && now_us() - t1 < 2000.0) __builtin_ia32_pause();
     t_started = now_us();
+    // which comes first, and when: the extension kernel's completion as the runtime sees it, or the sequence word?
+    volatile unsigned long long* word = (volatile unsigned long long*)S.out_host.p;
+    while ((!t_ev_ready || !t_word) && now_us() - t1 < 2000.0) {
+      if (!t_word && *word == job.seq) t_word = now_us();
+      if (!t_ev_ready && hipEventQuery(aev[3]) == hipSuccess) t_ev_ready = now_us();
+    }
   }
   std::vector<AlnHit> hits;
   unsigned nc = 0;
@@ -418,8 +427,8 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
     const double t2b = now_us();
     float k1 = 0, k2 = 0, all = 0, gap = 0;
     (void)hipEventElapsedTime(&k1, aev[0], aev[1]); (void)hipEventElapsedTime(&k2, aev[2], aev[3]); (void)hipEventElapsedTime(&all, aev[0], aev[3]); (void)hipEventElapsedTime(&gap, aev[1], aev[2]);
-    fprintf(stderr, "aln timed: launch1 %.1f launch2 %.1f | enqueued -> grid started (seen by the host) %.1f | enqueued -> sequence word seen %.1f, hits copied %.1f, + event sync %.1f | device: span %.1f gap %.1f extend %.1f, first begin -> last end %.1f us (cands %u)\n",
-            tb - ta, t1 - tb, t_started - t1, S.seen_us - t1, t2 - t1, t2b - t2, k1 * 1e3, gap * 1e3, k2 * 1e3, all * 1e3, nc);
+    fprintf(stderr, "aln timed: word seen %.1f / event ready %.1f after enqueue | launch1 %.1f launch2 %.1f | enqueued -> grid started (seen by the host) %.1f | enqueued -> sequence word seen %.1f, hits copied %.1f, + event sync %.1f | device: span %.1f gap %.1f extend %.1f, first begin -> last end %.1f us (cands %u)\n",
+            t_word - t1, t_ev_ready - t1, tb - ta, t1 - tb, t_started - t1, S.seen_us - t1, t2 - t1, t2b - t2, k1 * 1e3, gap * 1e3, k2 * 1e3, all * 1e3, nc);
   }
 #ifdef GAML_ALN_STAMPS
   {
