@@ -387,17 +387,25 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   // A/B (GAML_ALN_WAIT=2): events attached to the two dispatches -- the device's own begin / end stamps next to the host's wait
   static const int ev_mode = getenv("GAML_ALN_WAIT") ? atoi(getenv("GAML_ALN_WAIT")) : 0;
   static hipEvent_t aev[4] = {nullptr, nullptr, nullptr, nullptr};
-  if ((ev_mode == 2 || ev_mode == 4) && !aev[0]) for (int k = 0; k < 4; k++) HIP_TRY(c, hipEventCreate(&aev[k]));
-  const bool timed = ev_mode == 2 || ev_mode == 4;
+  if ((ev_mode == 2 || ev_mode == 4 || ev_mode == 6) && !aev[0]) for (int k = 0; k < 4; k++) HIP_TRY(c, hipEventCreate(&aev[k]));
+  const bool timed = ev_mode == 2 || ev_mode == 4 || ev_mode == 6;
 #else
   constexpr bool timed = false;
+  constexpr int ev_mode = 0;
   hipEvent_t aev[4] = {nullptr, nullptr, nullptr, nullptr};
 #endif
   const double ta = now_us();
   hipExtLaunchKernelGGL(span_cands_kernel, dim3((unsigned)job.blk[(size_t)nw]), dim3(kAlnBlock), 0, st, timed ? aev[0] : nullptr, timed ? aev[1] : nullptr, 0, sa, in_args ? 1 : 0, d_wstr, d_wins, nw, mm[0]->index_read_len, d_blk, n0,
                         mm[1]->index_read_len, ix, wa, S.cands.as<AlnCandX>(), S.counters.as<unsigned>() + 1, kFastCands, S.wcopy.as<char>(),
                         timed ? (unsigned long long*)((char*)S.out_host.dev + 32) : nullptr, S.out_seq + 1);
-  const double tb = now_us();
+  double tb = now_us();
+  double h_start_seen = 0;
+  if (timed && ev_mode == 6) {  // wait for the grid-started word BEFORE the second launch: host and device clocks side by side
+    volatile unsigned long long* sw = (volatile unsigned long long*)((char*)S.out_host.p + 32);
+    while (*sw != S.out_seq + 1 && now_us() - tb < 2000.0) { }
+    h_start_seen = now_us();
+    tb = h_start_seen;
+  }
   job.seq = ++S.out_seq;
   char* oh = (char*)S.out_host.dev;
   hipExtLaunchKernelGGL(extend_pair2_kernel, dim3(512), dim3(128 * kAlnPairs), 0, st, timed ? aev[2] : nullptr, timed ? aev[3] : nullptr, 0, sa, in_args ? 1 : 0, S.cands.as<AlnCandX>(), S.counters.as<unsigned>(), kFastCands, S.wcopy.as<char>(), ix,
@@ -427,6 +435,12 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
     const double t2b = now_us();
     float k1 = 0, k2 = 0, all = 0, gap = 0;
     (void)hipEventElapsedTime(&k1, aev[0], aev[1]); (void)hipEventElapsedTime(&k2, aev[2], aev[3]); (void)hipEventElapsedTime(&all, aev[0], aev[3]); (void)hipEventElapsedTime(&gap, aev[1], aev[2]);
+    if (ev_mode == 6) {
+      const unsigned long long g1 = *(volatile unsigned long long*)((char*)S.out_host.p + 40);
+      const unsigned* hc = (const unsigned*)((const char*)S.out_host.p + 64);
+      const unsigned long long g2 = (unsigned long long)hc[2] | ((unsigned long long)hc[3] << 32);
+      fprintf(stderr, "aln clocks: grid started -> published: device %.1f us, host (start word seen -> sequence word seen) %.1f us\n", (double)(long long)(g2 - g1) * 0.01, S.seen_us - h_start_seen);
+    }
     fprintf(stderr, "aln timed: word seen %.1f / event ready %.1f after enqueue | launch1 %.1f launch2 %.1f | enqueued -> grid started (seen by the host) %.1f | enqueued -> sequence word seen %.1f, hits copied %.1f, + event sync %.1f | device: span %.1f gap %.1f extend %.1f, first begin -> last end %.1f us (cands %u)\n",
             t_word - t1, t_ev_ready - t1, tb - ta, t1 - tb, t_started - t1, S.seen_us - t1, t2 - t1, t2b - t2, k1 * 1e3, gap * 1e3, k2 * 1e3, all * 1e3, nc);
   }

@@ -77,7 +77,10 @@ __global__ __launch_bounds__(kAlnBlock) void span_cands_kernel(AlnStrArgs, int s
   int rel;
   ALN_STAMP_FIRST(0); ALN_STAMP(1);
   // (development A/B: block 0 tells the host that the grid has started)
-  if (h_started && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(h_started, started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (h_started && blockIdx.x == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(h_started + 1, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the device's clock (100 MHz) when the grid started
+    __hip_atomic_store(h_started, started_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   wstr = aln_arg_strings(wstr, str_in_args);
   const int w = wa.n > 0 ? aln_span_locate(wa.blk, wa.w, wa.n, win, rel) : aln_span_locate(blk, wins, n_win, win, rel);
   if (!aln_span_front(L, wstr, win, w, rel, w >= split ? R2 : R, o, wcopy)) return;
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(128 * kAlnPairs) void extend_pair2_kernel(AlnStrArg
     const unsigned ticket = __hip_atomic_fetch_add(&counters[kAlnTicketWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket == working - 1) {  // every other working block has left its hits: publish, and leave the counters at zero for the next batch
       h_counts[0] = 0; h_counts[1] = n_cands;
+      h_counts[2] = (unsigned)wall_clock64(); h_counts[3] = (unsigned)(wall_clock64() >> 32);  // the device's clock at publication (timing probes)
       counters[0] = 0; counters[1] = 0; counters[kAlnTicketWord] = 0;
       __threadfence_system();
       __hip_atomic_store((unsigned long long*)h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
