@@ -161,6 +161,15 @@ int aln_small_collect(gaml_hip_ctx* c, AlignSmall& S, AlnJob& job, std::vector<A
   if (wait_mode == 1) { HIP_TRY(c, hipStreamSynchronize((hipStream_t)job.stream)); c->aln_stage_us[2] += now_us() - t0; }
 #endif
 #ifdef GAML_HIP_DEV
+  static const int keepalive = getenv("GAML_ALN_KEEPALIVE") ? atoi(getenv("GAML_ALN_KEEPALIVE")) : 0;  // A/B: PCIe traffic from the host while it waits: 1 reads through the BAR, 2 writes
+  if (keepalive && S.in_direct && S.in_dev) {
+    volatile unsigned* bar = (volatile unsigned*)((char*)S.in_dev + S.in_cap - 64);  // (the input block's last line: no batch reaches it)
+    unsigned sink = 0, tick = 0;
+    while (!seen && now_us() - t0 < 5000.0) {
+      for (int k = 0; k < 64 && !seen; k++) { if (keepalive == 1) sink += *bar; else { *bar = ++tick; _mm_sfence(); } seen = *word == job.seq; }
+    }
+    if (sink == 0x12345678u) fprintf(stderr, "\n");
+  }
   if (wait_mode == 5) {  // A/B: spin on the (cached) word without PAUSE -- a virtual CPU that executes PAUSE in a loop may be descheduled by its hypervisor
     while (!seen && now_us() - t0 < 5000.0) { for (int k = 0; k < 4096 && !seen; k++) seen = *word == job.seq; }
   }
@@ -377,7 +386,7 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
     const unsigned long long sq = ++S.out_seq;
     char* oh0 = (char*)S.out_host.dev;
     hipLaunchKernelGGL(extend_pair2_kernel, dim3(512), dim3(128 * kAlnPairs), 0, st, sa, in_args ? 1 : 0, S.cands.as<AlnCandX>(), S.counters.as<unsigned>(), kFastCands, S.wcopy.as<char>(), ix,
-                       (AlnHit*)(oh0 + 128), (unsigned*)(oh0 + 64), (volatile unsigned long long*)oh0, sq);
+                       (AlnHit*)(oh0 + 128), (unsigned*)(oh0 + 64), (volatile unsigned long long*)oh0, sq, S.hits.as<AlnHit>());
     unsigned long long z[32];
     for (int k = 0; k < 32; k++) z[k] = (k == 0 || k == 8) ? ~0ull : 0ull;
     HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_aln_stamp), z, sizeof(z)));
@@ -409,7 +418,7 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   job.seq = ++S.out_seq;
   char* oh = (char*)S.out_host.dev;
   hipExtLaunchKernelGGL(extend_pair2_kernel, dim3(512), dim3(128 * kAlnPairs), 0, st, timed ? aev[2] : nullptr, timed ? aev[3] : nullptr, 0, sa, in_args ? 1 : 0, S.cands.as<AlnCandX>(), S.counters.as<unsigned>(), kFastCands, S.wcopy.as<char>(), ix,
-                        (AlnHit*)(oh + 128), (unsigned*)(oh + 64), (volatile unsigned long long*)oh, job.seq);
+                        (AlnHit*)(oh + 128), (unsigned*)(oh + 64), (volatile unsigned long long*)oh, job.seq, S.hits.as<AlnHit>());
   HIP_TRY(c, hipGetLastError());
   job.enqueued = true;
   const double t1 = now_us();
@@ -439,7 +448,9 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
       const unsigned long long g1 = *(volatile unsigned long long*)((char*)S.out_host.p + 40);
       const unsigned* hc = (const unsigned*)((const char*)S.out_host.p + 64);
       const unsigned long long g2 = (unsigned long long)hc[2] | ((unsigned long long)hc[3] << 32);
-      fprintf(stderr, "aln clocks: grid started -> published: device %.1f us, host (start word seen -> sequence word seen) %.1f us\n", (double)(long long)(g2 - g1) * 0.01, S.seen_us - h_start_seen);
+      const unsigned long long g3 = *(const volatile unsigned long long*)(hc + 4);  // (after the publisher's release: builds with -DGAML_ALN_STAMP_AFTER_FENCE)
+      fprintf(stderr, "aln clocks: grid started -> published: device %.1f us (after the release %.1f), host (start word seen -> sequence word seen) %.1f us\n", (double)(long long)(g2 - g1) * 0.01,
+              g3 ? (double)(long long)(g3 - g1) * 0.01 : -1.0, S.seen_us - h_start_seen);
     }
     fprintf(stderr, "aln timed: word seen %.1f / event ready %.1f after enqueue | launch1 %.1f launch2 %.1f | enqueued -> grid started (seen by the host) %.1f | enqueued -> sequence word seen %.1f, hits copied %.1f, + event sync %.1f | device: span %.1f gap %.1f extend %.1f, first begin -> last end %.1f us (cands %u)\n",
             t_word - t1, t_ev_ready - t1, tb - ta, t1 - tb, t_started - t1, S.seen_us - t1, t2 - t1, t2b - t2, k1 * 1e3, gap * 1e3, k2 * 1e3, all * 1e3, nc);

@@ -143,9 +143,10 @@ constexpr int kAlnTicketWord = 32;                       // counters[32]: workin
 
 // counters: [1] candidates (span_cands_kernel), [kAlnTicketWord] working blocks done. h_counts / h_hits / h_seq: mapped pinned host memory.
 __global__ __launch_bounds__(128 * kAlnPairs) void extend_pair2_kernel(AlnStrArgs, int str_in_args, const AlnCandX* cands, unsigned* counters, unsigned cap_cands, const char* wstr, AlnMates ix,
-                                                                      AlnHit* h_hits, unsigned* h_counts, volatile unsigned long long* h_seq, unsigned long long seq) {
+                                                                      AlnHit* h_hits, unsigned* h_counts, volatile unsigned long long* h_seq, unsigned long long seq, AlnHit* d_hits) {
   __shared__ AlnWave2Lds lds_all[2 * kAlnPairs];
   __shared__ int sh_res[kAlnPairs][4];
+  __shared__ int sh_last;
   ALN_STAMP_FIRST(8); ALN_STAMP(9);
 #ifdef GAML_ALN_STAMPS
   const unsigned long long ck0 = clock64(), wc0 = wall_clock64();
@@ -229,41 +230,56 @@ __global__ __launch_bounds__(128 * kAlnPairs) void extend_pair2_kernel(AlnStrArg
       const int fwd = sh_res[pair][0], bwd = sh_res[pair][2], bp = sh_res[pair][3];
       AlnHit out{c.win, 0, -1, c.read, c.strand, c.order};
       if (fwd >= 0 && bwd >= 0) { out.pos = bp + 1 + c.w_offset; out.edit = fwd + bwd; }  // graph.cc:890
-      // system-scope stores: written through to host memory (a plain store may sit in this XCD's L2 until the kernel ends)
-      unsigned long long* dst = (unsigned long long*)(h_hits + t);
-      __hip_atomic_store(dst + 0, (unsigned long long)(uint32_t)out.win | ((unsigned long long)(uint32_t)out.pos << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(dst + 1, (unsigned long long)(uint32_t)out.edit | ((unsigned long long)(uint32_t)out.read << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(dst + 2, (unsigned long long)(uint32_t)out.strand | ((unsigned long long)(uint32_t)out.order << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      d_hits[t] = out;  // device memory; the publishing block carries all of them to the host in one go (below)
     }
     __syncthreads();  // sh_res and the waves' LDS slices are reused by the next round
   }
   // Only blocks that had candidates draw a ticket (a thousand idle blocks' atomics on one line took 30 us, and the
-  // candidate count next to it waited behind them); with no candidate at all block 0 publishes. This block's hits must
-  // have REACHED host memory before its ticket is drawn: the publisher sits on another XCD as a rule, and its own
-  // release writes back its own L2 only. The hits are therefore stored at system scope (written through, not left in
-  // this XCD's L2) and waited for (vmcnt) before the barrier in front of the ticket. (With plain stores two processes
-  // sharing one GPU lost a few dozen hits of a 3,000-candidate batch once in four runs: tools/dist_diag.py -- the host
-  // saw the sequence word before some blocks' hits.)
+  // candidate count next to it waited behind them); with no candidate at all block 0 publishes.
+  // A block's hits are in DEVICE memory, released at agent scope before its ticket is drawn (the publisher sits on another
+  // XCD as a rule: it must find them in memory, not in this XCD's L2). The block that draws the last ticket copies all
+  // hits to the host's buffer -- whole words, neighbouring lanes neighbouring words: a few dozen wide PCIe writes --, and
+  // publishes. (Every block storing its own hits straight into host memory meant ~900 eight-byte writes in a burst at the
+  // end of the kernel, the sequence word queued behind them: the host saw a batch 13-35 us after the device had finished
+  // it, by the two clocks side by side -- GAML_ALN_WAIT=6. And with PLAIN stores from every block the host could see the
+  // sequence word before some blocks' hits had left their XCD's L2: two processes sharing one GPU lost a few dozen hits of a
+  // 3,000-candidate batch once in four runs, tools/dist_diag.py.)
   const unsigned working = n == 0 ? 1u : min((n + kAlnPairs - 1) / kAlnPairs, gridDim.x);
   if (blockIdx.x >= working) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   ALN_STAMP(15);
   if (threadIdx.x == 0) {
-#ifdef GAML_ALN_BLOCK_FENCE  // (A/B: a full system-scope release per working block on top of the written-through stores)
-    __threadfence_system();
-#endif
+    __threadfence();  // release (agent scope): this block's hits, whichever wave stored them (the barrier above)
     const unsigned ticket = __hip_atomic_fetch_add(&counters[kAlnTicketWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket == working - 1) {  // every other working block has left its hits: publish, and leave the counters at zero for the next batch
-      h_counts[0] = 0; h_counts[1] = n_cands;
-      h_counts[2] = (unsigned)wall_clock64(); h_counts[3] = (unsigned)(wall_clock64() >> 32);  // the device's clock at publication (timing probes)
-      counters[0] = 0; counters[1] = 0; counters[kAlnTicketWord] = 0;
-      __threadfence_system();
-      __hip_atomic_store((unsigned long long*)h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef GAML_ALN_STAMPS
-      atomicMax(&g_aln_stamp_pub, (unsigned long long)wall_clock64());
-#endif
+    sh_last = ticket == working - 1;
+    if (sh_last) __threadfence();  // acquire: every other working block's hits
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  {
+    const unsigned long long* src = (const unsigned long long*)d_hits;
+    unsigned long long* dst = (unsigned long long*)h_hits;
+    const unsigned words = n * (unsigned)(sizeof(AlnHit) / 8);
+    for (unsigned w = threadIdx.x; w < words; w += blockDim.x) {
+      const unsigned long long v = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (past this CU's L1)
+      __hip_atomic_store(dst + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {  // publish, and leave the counters at zero for the next batch
+    h_counts[0] = 0; h_counts[1] = n_cands;
+    h_counts[2] = (unsigned)wall_clock64(); h_counts[3] = (unsigned)(wall_clock64() >> 32);  // the device's clock at publication (timing probes)
+    counters[0] = 0; counters[1] = 0; counters[kAlnTicketWord] = 0;
+    __threadfence_system();
+#ifdef GAML_ALN_STAMP_AFTER_FENCE
+    { const unsigned long long wc = wall_clock64(); __hip_atomic_store((unsigned long long*)(h_counts + 4), wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+#endif
+    __hip_atomic_store((unsigned long long*)h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef GAML_ALN_STAMPS
+    atomicMax(&g_aln_stamp_pub, (unsigned long long)wall_clock64());
+#endif
   }
 }
 

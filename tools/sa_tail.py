@@ -37,3 +37,10 @@ for knob6 in (0,):
     print("   last 200 calls median", np.median(per[-200:]), ctx.debug_table_stats(rs))
     os.environ["GAML_HIP_TRACE_ALIGNER"] = "1"; print("   at the end:", end=" ", flush=True); ctx.aligner_stats(); del os.environ["GAML_HIP_TRACE_ALIGNER"]
     ctx.close()
+
+# calls that aligned nothing and still took long: what they did (delta-list moves of windows aligned earlier)
+if os.environ.get("SA_TAIL_OTHERS"):
+    slow = [k for k in np.argsort(-per) if not al[k] and per[k] > 60.0]
+    print(f"   calls without alignment above 60 us: {len(slow)}; above 90 us: {sum(per[k] > 90 for k in slow)}; above 130 us: {sum(per[k] > 130 for k in slow)}")
+    for k in slow[::max(1, len(slow) // 16)]:
+        print(f"      call {k}: {per[k]:.0f} us, phases", np.round(prof[k], 1))
