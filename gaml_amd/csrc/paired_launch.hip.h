@@ -523,8 +523,14 @@ static int delta_upload_patch(gaml_hip_ctx* c, PairedSet& s, hipStream_t st, con
                               std::vector<int32_t>& touched, std::vector<int32_t>& spill_of, std::vector<int32_t>& spill_pairs, bool* spill_changed,
                               const DeltaStore& dev, int64_t mark_from = -1, bool* marked_out = nullptr) {
   const size_t nd = dirty.size();
-  std::sort(touched.begin(), touched.end());
-  touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+  {  // ascending and distinct as a rule (new delta pairs are numbered as they are touched): one pass instead of a sort
+    bool ordered = true;
+    for (size_t k = 1; k < touched.size() && ordered; k++) ordered = touched[k - 1] < touched[k];
+    if (!ordered) {
+      std::sort(touched.begin(), touched.end());
+      touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+    }
+  }
   const bool fuse_marks = mark_from >= 0 && (int64_t)nd > mark_from &&
                           (int64_t)(touched.end() - std::lower_bound(touched.begin(), touched.end(), (int32_t)mark_from)) == (int64_t)nd - mark_from;
   if (marked_out) *marked_out = fuse_marks;
@@ -702,7 +708,8 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     ts2 = now_us();
   }
   if (int e = paired_upload_delta(c, s, st)) return e;
-  if (trace && now_us() - ts0 > 300.0)
+  static const double trace_above = getenv("GAML_HIP_TRACE_SYNC_US") ? atof(getenv("GAML_HIP_TRACE_SYNC_US")) : 300.0;
+  if (trace && now_us() - ts0 > trace_above)
     fprintf(stderr, "table sync %.0f us: policy %.0f, delta lists %.0f (%zu new records, %zu list entries touched, %zu delta pairs, %zu spill), upload %.0f; worker state %d\n",
             now_us() - ts0, ts1 - ts0, ts2 - ts1, tr_new, tr_touched, s.dirty.size(), s.spill_pairs.size(), now_us() - ts2, rstate);
   const size_t nd = s.dirty.size();
