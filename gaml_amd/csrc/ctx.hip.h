@@ -202,7 +202,7 @@ struct DeltaRecList {
   }
   void push_back(const RecQuad& q) { insert(n, q); }
 };
-struct DeltaPair { int32_t slot; DeltaRecList recs[2]; };
+struct DeltaPair { int32_t slot; uint32_t len12; DeltaRecList recs[2]; };  // len12: the pair's two read lengths (L1 | L2 << 16), noted when the pair is made
 
 struct TableRebuild {
   std::thread th;

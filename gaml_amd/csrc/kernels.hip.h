@@ -1083,6 +1083,10 @@ __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, i
 
 // delta store maintenance: one thread per patched pair writes its slot, spill index and padded records
 struct DeltaPatch { int dj, slot, spill, pad; int4 rec[2][4]; };
+// the same with room for two records per mate -- the usual delta pair: a node and its twin, a node and a junction -- 80 bytes
+// instead of 144 for the host to write and the device to fetch over PCIe (a patch of a few thousand pairs is what a call costs
+// that activates a window aligned earlier)
+struct DeltaPatch2 { int dj, slot, spill, pad; int4 rec[2][2]; };
 // the class tables' "this pair lives on the delta lists now" marks (one per new delta pair); kDirty8 / kDirtyWid
 __device__ __forceinline__ void mark_dirty_slot(int s, unsigned long long* rec8_0, int n0, int4* inl_0, int n01, int n_main, int4* first_0) {
   if (s < n0) rec8_0[s] = ~0ull - 1;
@@ -1095,14 +1099,18 @@ __device__ __forceinline__ void mark_dirty_slot(int s, unsigned long long* rec8_
 // `patch` is read where the host wrote it (mapped pinned memory): no copy kernel in front; delta pairs numbered
 // mark_from and up are new with this patch and get their marks here (mark_from < 0: none) -- one dispatch where there
 // were three: copy, patch, marks
-__global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const DeltaPatch* patch, int n, int* slots, int* spill, int4* rec0, int4* rec1, int mark_from,
+template <class Patch, int K>
+__global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const Patch* patch, int n, int* slots, int* spill, int4* rec0, int4* rec1, int mark_from,
                                                                    unsigned long long* rec8_0, int n0, int4* inl_0, int n01, int n_main, int4* first_0) {
   for (int t = blockIdx.x * kBlock + threadIdx.x; t < n; t += gridDim.x * kBlock) {
-    const DeltaPatch p = patch[t];
+    const Patch p = patch[t];
     slots[p.dj] = p.slot;
     spill[p.dj] = p.spill;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { rec0[4 * (size_t)p.dj + k] = p.rec[0][k]; rec1[4 * (size_t)p.dj + k] = p.rec[1][k]; }
+    for (int k = 0; k < 4; k++) {  // (the store always holds four records per mate: the short form's missing ones are "none")
+      rec0[4 * (size_t)p.dj + k] = k < K ? p.rec[0][k < K ? k : 0] : make_int4(-1, 0, 0, 0);
+      rec1[4 * (size_t)p.dj + k] = k < K ? p.rec[1][k < K ? k : 0] : make_int4(-1, 0, 0, 0);
+    }
     if (mark_from >= 0 && p.dj >= mark_from) mark_dirty_slot(p.slot, rec8_0, n0, inl_0, n01, n_main, first_0);
   }
 }

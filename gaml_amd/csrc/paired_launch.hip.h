@@ -145,8 +145,10 @@ static void delta_add_window(const PairedSet& s, const PairTables& pt, std::vect
   // in the tables of both mates): ~100 ns of cache misses each when taken one after the other. Ask for them ahead.
   constexpr int64_t kAhead = 24, kAhead2 = 12;
   const int64_t end = win.first + win.count;
+  const int32_t* const lens0 = s.mate[0].lens.data();  // (a new delta pair notes its read lengths here, where the read id is at hand:
+  const int32_t* const lens1 = s.mate[1].lens.data();  //  the patch would otherwise go slot -> read -> lengths, three misses in a row)
   for (int64_t k = win.first; k < end; k++) {
-    if (k + kAhead < end) __builtin_prefetch(&pt.slot_of_read[m.pool[k + kAhead].read_id]);
+    if (k + kAhead < end) { const int32_t rd = m.pool[k + kAhead].read_id; __builtin_prefetch(&pt.slot_of_read[rd]); __builtin_prefetch(&lens0[rd]); __builtin_prefetch(&lens1[rd]); }
     if (k + kAhead2 < end) {
       const int32_t sl = pt.slot_of_read[m.pool[k + kAhead2].read_id];
       __builtin_prefetch(&of_slot[sl]);
@@ -161,6 +163,7 @@ static void delta_add_window(const PairedSet& s, const PairTables& pt, std::vect
       dj = of_slot[slot] = (int32_t)dirty.size();
       dirty.emplace_back();
       dirty.back().slot = slot;
+      dirty.back().len12 = (uint32_t)lens0[r.read_id] | ((uint32_t)lens1[r.read_id] << 16);
       paired_base_records(pt, slot, 0, dirty.back().recs[0]);
       paired_base_records(pt, slot, 1, dirty.back().recs[1]);
     }
@@ -536,44 +539,49 @@ static int delta_upload_patch(gaml_hip_ctx* c, PairedSet& s, hipStream_t st, con
   if (marked_out) *marked_out = fuse_marks;
   spill_of.resize(nd, -1);
   const size_t np_patch = touched.size();
+  // the short form when no touched pair holds more than two records on a mate (nearly always)
+  bool short_form = true;
+  for (size_t t = 0; t < np_patch && short_form; t++) { const auto& d = dirty[touched[t]]; short_form = d.recs[0].size() <= 2 && d.recs[1].size() <= 2; }
   void* ph = nullptr;
-  int pslot = stage_acquire(c, s.stage_delta, np_patch * sizeof(DeltaPatch), &ph);
+  int pslot = stage_acquire(c, s.stage_delta, np_patch * (short_form ? sizeof(DeltaPatch2) : sizeof(DeltaPatch)), &ph);
   if (pslot < 0) return pslot;
-  DeltaPatch* patch = (DeltaPatch*)ph;
-  const int32_t* const lens0 = s.mate[0].lens.data();
-  const int32_t* const lens1 = s.mate[1].lens.data();
-  for (size_t t = 0; t < np_patch; t++) {
-    // an entry touches its delta pair (~200 bytes), the pair's read id and the read's two lengths, each chosen by the one
-    // before: three cache misses in a row per entry when taken one entry after the other. Ask for them ahead.
-    if (t + 24 < np_patch) { const char* q = (const char*)&dirty[touched[t + 24]]; __builtin_prefetch(q); __builtin_prefetch(q + 64); __builtin_prefetch(q + 128); }
-    if (t + 16 < np_patch) __builtin_prefetch(&pt.read_of_slot[dirty[touched[t + 16]].slot]);
-    if (t + 8 < np_patch) { const int32_t rd = pt.read_of_slot[dirty[touched[t + 8]].slot]; __builtin_prefetch(&lens0[rd]); __builtin_prefetch(&lens1[rd]); }
-    const int32_t dj = touched[t];
-    const auto& d = dirty[dj];
-    DeltaPatch& pe = patch[t];
-    pe.dj = dj; pe.slot = d.slot; pe.pad = 0;
-    const bool lng = d.recs[0].size() > 4 || d.recs[1].size() > 4;
-    if (lng) {
-      if (spill_of[dj] < 0) { spill_of[dj] = (int32_t)spill_pairs.size(); spill_pairs.push_back(dj); }
-      *spill_changed = true;
-    }
-    pe.spill = spill_of[dj];
-    for (int mt = 0; mt < 2; mt++)
-      for (int k = 0; k < 4; k++) {
-        const RecQuad none{-1, 0, 0, 0};
-        const RecQuad& r = (!lng && k < (int)d.recs[mt].size()) ? d.recs[mt][k] : none;
-        pe.rec[mt][k] = make_int4(r.wid, r.pos, r.flags, r.link);
+  auto fill = [&](auto* patch, const int K) {
+    for (size_t t = 0; t < np_patch; t++) {
+      // an entry touches its delta pair (~200 bytes; the pair carries its read lengths): ask for it ahead
+      if (t + 16 < np_patch) { const char* q = (const char*)&dirty[touched[t + 16]]; __builtin_prefetch(q); __builtin_prefetch(q + 64); __builtin_prefetch(q + 128); }
+      const int32_t dj = touched[t];
+      const auto& d = dirty[dj];
+      auto& pe = patch[t];
+      pe.dj = dj; pe.slot = d.slot; pe.pad = 0;
+      const bool lng = d.recs[0].size() > 4 || d.recs[1].size() > 4;
+      if (lng) {
+        if (spill_of[dj] < 0) { spill_of[dj] = (int32_t)spill_pairs.size(); spill_pairs.push_back(dj); }
+        *spill_changed = true;
       }
-    // the spare words of the two first records: the pair's read lengths and the lengths of its lists (paired_delta_body)
-    const int32_t read = pt.read_of_slot[d.slot];
-    pe.rec[0][0].w = (int)((uint32_t)s.mate[0].lens[read] | ((uint32_t)s.mate[1].lens[read] << 16));
-    pe.rec[1][0].w = lng ? 0 : (int)(d.recs[0].size() | (d.recs[1].size() << 8));
-  }
+      pe.spill = spill_of[dj];
+      for (int mt = 0; mt < 2; mt++)
+        for (int k = 0; k < K; k++) {
+          const RecQuad none{-1, 0, 0, 0};
+          const RecQuad& r = (!lng && k < (int)d.recs[mt].size()) ? d.recs[mt][k] : none;
+          pe.rec[mt][k] = make_int4(r.wid, r.pos, r.flags, r.link);
+        }
+      // the spare words of the two first records: the pair's read lengths and the lengths of its lists (paired_delta_body)
+      pe.rec[0][0].w = (int)d.len12;
+      pe.rec[1][0].w = lng ? 0 : (int)(d.recs[0].size() | (d.recs[1].size() << 8));
+    }
+  };
+  if (short_form) fill((DeltaPatch2*)ph, 2); else fill((DeltaPatch*)ph, 4);
   // the kernel reads the patch where the host wrote it (mapped pinned memory; the slot is held until the kernel is through)
   const int n0 = (int)s.pt.class_count[0], n01 = n0 + (int)s.pt.class_count[1], n_main = n01 + (int)s.pt.class_count[2];
-  hipLaunchKernelGGL(apply_delta_patch_kernel, dim3((unsigned)std::min<size_t>((np_patch + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
-                     (const DeltaPatch*)s.stage_delta.host[pslot].dev, (int)np_patch, dev.slot->as<int>(), dev.spill->as<int>(), dev.rec0->as<int4>(), dev.rec1->as<int4>(),
-                     fuse_marks ? (int)mark_from : -1, s.tab.rec8[0].as<unsigned long long>(), n0, s.tab.inl[0].as<int4>(), n01, n_main, s.tab.first[0].as<int4>());
+  const dim3 pgrid((unsigned)std::min<size_t>((np_patch + kBlock - 1) / kBlock, 256));
+  if (short_form)
+    hipLaunchKernelGGL((apply_delta_patch_kernel<DeltaPatch2, 2>), pgrid, dim3(kBlock), 0, st,
+                       (const DeltaPatch2*)s.stage_delta.host[pslot].dev, (int)np_patch, dev.slot->as<int>(), dev.spill->as<int>(), dev.rec0->as<int4>(), dev.rec1->as<int4>(),
+                       fuse_marks ? (int)mark_from : -1, s.tab.rec8[0].as<unsigned long long>(), n0, s.tab.inl[0].as<int4>(), n01, n_main, s.tab.first[0].as<int4>());
+  else
+    hipLaunchKernelGGL((apply_delta_patch_kernel<DeltaPatch, 4>), pgrid, dim3(kBlock), 0, st,
+                       (const DeltaPatch*)s.stage_delta.host[pslot].dev, (int)np_patch, dev.slot->as<int>(), dev.spill->as<int>(), dev.rec0->as<int4>(), dev.rec1->as<int4>(),
+                       fuse_marks ? (int)mark_from : -1, s.tab.rec8[0].as<unsigned long long>(), n0, s.tab.inl[0].as<int4>(), n01, n_main, s.tab.first[0].as<int4>());
   HIP_TRY(c, hipGetLastError());
   if (int e = stage_release(c, s.stage_delta, pslot, st)) return e;
   touched.clear();
