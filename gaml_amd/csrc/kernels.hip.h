@@ -1487,6 +1487,84 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
   }
 }
 
+// paired_static4_body with the path sets in the inner loop: the static pairs' records AND values come in once for all sets
+// (the per-set arithmetic above goes records -> occurrence entries -> memo index -> memo entry, two dependent trips per set;
+// here a set costs one: its occurrence entries). Lanes, pairs, the values added and their order are the single-set
+// kernel's: a batch gives bit for bit what the sets give one by one.
+template <bool GEN, bool ONE>
+__device__ __forceinline__ void paired_static4_multi_body(const PairedArgs& a, const MultiSets& ms, const SlotRange rg, double* acc_s, int* acc_z, const double* tf) {
+  const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;
+  const char* const rec0 = (const char*)a.rec8[0];
+  const char* const rec1 = (const char*)a.rec8[1];
+  const char* const sval = (const char*)a.static_val;
+  char* const probs = (char*)a.probs;
+  const double logfloor_one = ONE ? a.logfloor_c[0] : 0.0;
+  for (unsigned base = (unsigned)rg.lo + (unsigned)rg.lb * kBlock + threadIdx.x; base < n0; base += 4 * stride) {
+    uint2 r1[4], r2[4];
+    double2 m[4];
+    unsigned lc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // records and values: ONCE for all sets
+      const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
+      r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); m[k] = *(const double2*)(sval + ic * 16u);
+      lc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
+    }
+#pragma unroll 1
+    for (int s = 0; s < ms.n; s++) {
+      const SetDev& sd = ms.set[s];
+      const char* const occ0 = (const char*)sd.occ12[0];
+      const char* const occ1 = (const char*)sd.occ12[1];
+      const double* const tfs = tf ? tf + s * kTfCodes : sd.tfloor_c;
+      const double log2T = sd.log_two_T, tfloor_one = ONE ? tfs[0] : 0.0;
+      const bool last_set = s == ms.n - 1;
+      uint2 o1[4], o2[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned w1 = (r1[k].x & 0xffffffu) & (0u - (unsigned)(r1[k].y != ~0u)), w2 = (r2[k].x & 0xffffffu) & (0u - (unsigned)(r2[k].y != ~0u));
+        const Occ12* e1 = (const Occ12*)(occ0 + w1 * 12u);
+        const Occ12* e2 = (const Occ12*)(occ1 + w2 * 12u);
+        o1[k] = make_uint2(e1->lo, e1->hi); o2[k] = make_uint2(e2->lo, e2->hi);
+      }
+      double lsum = acc_s[s * kBlock + threadIdx.x];  // (the running sum of this lane and set: additions in the single-set kernel's order)
+      int zeros = acc_z[s * kBlock + threadIdx.x];
+      unsigned skip_bits = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {  // as paired_static4_body, statement for statement
+        const bool none1 = r1[k].y == ~0u, none2 = r2[k].y == ~0u;
+        const bool here = (base + k * stride < n0) & !(none1 & (r1[k].x == 0xfffffffeu));
+        const bool w1 = !none1 & (o1[k].y != ~0u), w2 = !none2 & (o2[k].y != ~0u);
+        const bool gen = here & ((w1 & ((int)o1[k].y < 0)) | (w2 & ((int)o2[k].y < 0)));
+        const bool same = (o1[k].x == o2[k].x) & (((o1[k].y ^ o2[k].y) >> 16) == 0);
+        const int p1 = (int)(__funnelshift_r(r1[k].x, r1[k].y, 24) & 0xfffffffu), p2 = (int)(__funnelshift_r(r2[k].x, r2[k].y, 24) & 0xfffffffu);
+        const bool kept = (p1 >= (int)(short)(o1[k].y & 0xffffu)) & (p2 >= (int)(short)(o2[k].y & 0xffffu));
+        const bool both = here & !gen & w1 & w2;
+        const bool scores = both & same & kept;
+        const bool poison = both & !same;
+        const bool counted = here & !gen;
+        skip_bits |= (unsigned)gen << k;
+        const double t = scores ? m[k].x : 0.0;
+        const bool floored = counted & (!scores | (t < (ONE ? tfloor_one : tfs[lc[k]])));
+        const double lf = ONE ? logfloor_one : a.logfloor_c[lc[k]];
+        double add = floored ? lf : m[k].y - log2T;
+        add = counted ? add : 0.0;
+        add = poison ? __builtin_nan("") : add;
+        lsum += add;
+        zeros += (int)floored;
+        if (counted && last_set) __builtin_nontemporal_store(t, (double*)(probs + (base + k * stride) * 8u));
+      }
+      if (GEN) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned long long w = __ballot((skip_bits >> k) & 1u);
+          if ((threadIdx.x & 63) == 0 && base + k * stride < n0) sd.gen_bits[rg.gen_w + ((base + k * stride - (unsigned)rg.lo) >> 6)] = w;
+        }
+      }
+      acc_s[s * kBlock + threadIdx.x] = lsum;
+      acc_z[s * kBlock + threadIdx.x] = zeros;
+    }
+  }
+}
+
 // Classes 1 and 2 with the path sets in the inner loop (paired_regs_body's pairs, lane -> pair mapping and order of
 // additions): records once, set 0 resolved and captured, later sets finished from the capture unless one of the
 // pair's windows changed.
@@ -1671,15 +1749,20 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArg
       // (both parts of class 0 resolve every pair per set here: the lanes, pairs and order of additions are the single-set
       // kernel's, and so are the values -- a static memo index is the index the per-call arithmetic arrives at)
       const SlotRange rg = compact_range(a, lb);
-      if (a.n_codes == 1) paired_compact4_multi_body<GEN, true>(a, ms, rg, acc_s, acc_z, tf);
-      else {
+      // the static part streams its values like the single-set kernel (same condition as there: memo present, no coverage marks)
+      const bool stat = lb < a.blocks0a && a.memo && !a.cov_bits && a.static_val;
+      if (a.n_codes == 1) {
+        if (stat) paired_static4_multi_body<GEN, true>(a, ms, rg, acc_s, acc_z, tf);
+        else paired_compact4_multi_body<GEN, true>(a, ms, rg, acc_s, acc_z, tf);
+      } else {
         __shared__ uint32_t sh_combo[256];
         __shared__ double sh_logfloor[256];
         for (int k = threadIdx.x; k < a.n_codes; k += kBlock) { sh_combo[k] = a.len_combo[k]; sh_logfloor[k] = a.logfloor_c[k]; }
         __syncthreads();
         PairedArgs b = a;
         b.len_combo = sh_combo; b.logfloor_c = sh_logfloor;
-        paired_compact4_multi_body<GEN, false>(b, ms, rg, acc_s, acc_z, tf);
+        if (stat) paired_static4_multi_body<GEN, false>(b, ms, rg, acc_s, acc_z, tf);
+        else paired_compact4_multi_body<GEN, false>(b, ms, rg, acc_s, acc_z, tf);
       }
     } else if (lb < a.blocks01) paired_regs_multi_body<2, GEN>(a, ms, lb, a.n0, a.n01, a.blocks0, a.blocks01, acc_s, acc_z, tf);
     else if (lb < a.blocks012) paired_regs_multi_body<4, GEN>(a, ms, lb, a.n01, a.n_main, a.blocks01, a.blocks012, acc_s, acc_z, tf);
