@@ -144,3 +144,59 @@ def test_two_processes_share_the_reads(tmp_path, penalty):
             got, z, tl2 = ranks[0][kind][k]
             assert tl2 == tl and z == wz.tolist()
             assert abs(got - want) <= 1e-12 * abs(want), (kind, k, got, want)
+
+
+def _cold_alignment_worker(rank, world, port, out_dir, repeats):
+    """Two processes on the one GPU, `repeats` fresh contexts each: the cold evaluation aligns every window through the
+    small-batch pipeline while the peer does the same (what exposed the hits' publication race of round 3)."""
+    import json
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gaml_amd import api, synth
+    from gaml_amd.dist import ShardedScorer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        genome = synth.make_genome(60_000, 73)
+        g = synth.make_graph(genome, synth.cut_lengths(60_000, 73, long_rng=(900, 4000)))
+        pr = synth.make_paired_reads(genome, 1501, 100, 250.0, 25.0, 0.01, 73)
+        walk = synth.genome_walk(g)
+        out = []
+        for _ in range(repeats):
+            ctx = api.Context(device=0, rank=rank, world=world)
+            ctx.set_graph(*g.packed())
+            ctx.add_paired(api.paired_cfg(250.0, 25.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+            scorer = ShardedScorer(ctx)
+            v = scorer.calc_prob([walk])
+            out.append([v[0], v[1].tolist(), v[2]])
+            dist.barrier()
+            ctx.close()
+        with open(os.path.join(out_dir, f"cold{rank}.json"), "w") as f:
+            json.dump(out, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_cold_alignment_repeated(tmp_path):
+    import json
+    import torch.multiprocessing as mp
+    from gaml_amd import api
+    repeats, world, port = 4, 2, _free_port()
+    mp.spawn(_cold_alignment_worker, args=(world, port, str(tmp_path), repeats), nprocs=world, join=True)
+    ranks = [json.load(open(tmp_path / f"cold{r}.json")) for r in range(world)]
+    genome = synth.make_genome(60_000, 73)
+    g = synth.make_graph(genome, synth.cut_lengths(60_000, 73, long_rng=(900, 4000)))
+    pr = synth.make_paired_reads(genome, 1501, 100, 250.0, 25.0, 0.01, 73)
+    plain = api.Context(device=0)
+    plain.set_graph(*g.packed())
+    plain.add_paired(api.paired_cfg(250.0, 25.0), *synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
+    want, wz, tl = plain.calc_prob([synth.genome_walk(g)])
+    for k in range(repeats):
+        assert ranks[0][k] == ranks[1][k]
+        got, z, tl2 = ranks[0][k]
+        assert tl2 == tl and z == wz.tolist(), (k, z, wz.tolist())  # every hit of every block arrived: the floored counts are exact
+        assert abs(got - want) <= 1e-12 * abs(want)
