@@ -255,6 +255,11 @@ struct PairedSet {
   // The delta lists live on the device at a fixed stride (4 records per mate and pair, longer lists in
   // a small spill CSR); an evaluation that changed some of them uploads a patch for just those pairs.
   std::vector<int32_t> dirty_touched;   // indices into `dirty` changed since the last upload
+  // the same call's patch written while the lists are made (paired_extend_delta with a PatchSink): entry number per delta
+  // pair (-1: none), the staging slot that holds the entries, their count, how many of them are new pairs
+  std::vector<int32_t> patch_of;
+  int patch_slot = -1, patch_n = 0, patch_new = 0;
+  bool patch_ready = false;
   std::vector<int32_t> spill_of;        // per dirty pair: index in spill_pairs or -1
   std::vector<int32_t> spill_pairs;     // dirty indices with more than 4 records on a mate
   bool spill_changed = false;

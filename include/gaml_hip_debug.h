@@ -59,7 +59,8 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int
  * unchanged pairs, 32 + mask: classes of blocks left out (TIMING ONLY, results wrong; tools/batch_ablate.py),
  * 12 = 1: every path set planned from scratch, 13 = 1: whole per-call tables through the ring (no resident copy),
  * 14 / 15: table rebuilds (above), 16 = 1: record tables keep the records that can never survive the overwrite rule
- * (host_model.cc dominated_records; takes effect at the next table build; same values either way), 18 = d: tables are
+ * (host_model.cc dominated_records; takes effect at the next table build; same values either way), 17 = 1: a call's delta
+ * patch is made in a second pass over the touched pairs (default: written while the lists are made), 18 = d: tables are
  * rebuilt when the delta lists pass pairs / d (default 8), 19 = 1: no static memo indices (every compact-class pair is
  * resolved per call; takes effect at the next table build; same values either way), 20 = blocks of the compact class's
  * second part, 21 = blocks of paired_general_kernel.
