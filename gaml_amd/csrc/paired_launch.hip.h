@@ -529,12 +529,26 @@ int paired_reserve_delta(gaml_hip_ctx* c, PairedSet& s) {
   // patches: a call rarely touches more than a few thousand pairs; the largest activations (a long node's twin) ~30 k
   const size_t patch = std::min<size_t>(s.delta_cap, 32768) * sizeof(DeltaPatch);
   HIP_TRY(c, s.dl_patch.reserve(patch));
-  for (int k = 0; k < kRing; k++) HIP_TRY(c, s.stage_delta.host[k].reserve(patch));
+  for (int k = 0; k < kRing; k++) {
+    HIP_TRY(c, s.stage_delta.host[k].reserve(patch));
+    if (!s.stage_delta.done[k]) HIP_TRY(c, hipEventCreateWithFlags(&s.stage_delta.done[k], hipEventDisableTiming));  // (not in the call that first needs the slot)
+  }
+  s.patch_of.assign(s.delta_cap + 4096, -1);  // (1.7 MB written here: the first patch of an annealing run found it unallocated, 0.4 ms)
   HIP_TRY(c, s.delta_dev.reserve((size_t)1 << 20));
   // host lists: never moved while they fill (a DirtyPair is ~200 bytes; growing a vector of 60 k of them costs milliseconds)
   s.dirty.reserve(s.delta_cap);
+  // ... and their pages are touched here (85 MB at cfg3, ~20 ms inside a call of seconds): a vector's reserved storage is
+  // address space until it is written, and a delta pair made on a fresh page paid the page fault -- 116 of the 212 cycles a
+  // record cost when a window was activated, 7 ms of an annealing run's first 1000 calls
+  {
+    volatile char* base = (volatile char*)s.dirty.data();
+    const size_t bytes = s.delta_cap * sizeof(PairedSet::DirtyPair);
+    for (size_t o = 0; o < bytes; o += 4096) base[o] = 0;
+  }
   s.spill_of.reserve(s.delta_cap);
   s.dirty_touched.reserve(65536);
+  for (size_t o = 0; o < s.delta_cap * sizeof(int32_t); o += 4096) ((volatile char*)s.spill_of.data())[o] = 0;     // (pages touched: as above)
+  for (size_t o = 0; o < 65536 * sizeof(int32_t); o += 4096) ((volatile char*)s.dirty_touched.data())[o] = 0;
   s.dirty_of_slot.assign((size_t)np_all, -1);  // (3.3 MB at cfg3: touched here, not in the call that first activates a window)
   return 0;
 }
