@@ -257,7 +257,7 @@ struct PairedSet {
   std::vector<int32_t> dirty_touched;   // indices into `dirty` changed since the last upload
   // the same call's patch written while the lists are made (paired_extend_delta with a PatchSink): entry number per delta
   // pair (-1: none), the staging slot that holds the entries, their count, how many of them are new pairs
-  std::vector<int32_t> patch_of;
+  std::vector<int32_t> patch_of, patch_long;  // patch_long: pairs touched in this call that hold more than two records on a mate (the long form: a second pass over just those)
   int patch_slot = -1, patch_n = 0, patch_new = 0;
   bool patch_ready = false;
   std::vector<int32_t> spill_of;        // per dirty pair: index in spill_pairs or -1

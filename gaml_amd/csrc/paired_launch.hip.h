@@ -139,7 +139,7 @@ void paired_base_records(const PairTables& pt, int32_t slot, int mt, PairedSet::
 // The patch of a call written while its lists are made: a delta pair's entry (short form) is rewritten whenever the pair is
 // touched -- its lists are in the cache right then; a second pass over the touched pairs re-read 200 bytes per pair, 24 ns
 // an entry. `broken`: some touched pair holds more than two records on a mate (the long form: the second pass does it).
-struct PatchSink { DeltaPatch2* buf; int32_t* of; int cap, n, n_new; int64_t mark_from; bool broken; };
+struct PatchSink { DeltaPatch2* buf; int32_t* of; int cap, n, n_new; int64_t mark_from; bool broken; std::vector<int32_t>* longer; };  // longer: pairs that need the long form
 static void delta_add_window(const PairedSet& s, const PairTables& pt, std::vector<PairedSet::DirtyPair>& dirty, std::vector<int32_t>& of_slot,
                              std::vector<int32_t>* touched, int mt, int32_t w, const uint8_t* keep, PatchSink* sink = nullptr) {
   const ShortMate& m = s.mate[mt];
@@ -182,7 +182,8 @@ static void delta_add_window(const PairedSet& s, const PairTables& pt, std::vect
       const auto& d = dirty[dj];
       const size_t c0 = d.recs[0].size(), c1 = d.recs[1].size();
       int pi = sink->of[dj];
-      if (c0 > 2 || c1 > 2 || (pi < 0 && sink->n >= sink->cap)) sink->broken = true;
+      if (c0 > 2 || c1 > 2) sink->longer->push_back(dj);  // (an entry it may have here already is overwritten by the long one: the long patch is applied second)
+      else if (pi < 0 && sink->n >= sink->cap) sink->broken = true;
       else {
         if (pi < 0) { pi = sink->n++; sink->of[dj] = pi; sink->n_new += dj >= sink->mark_from; }
         DeltaPatch2& pe = sink->buf[pi];
@@ -633,15 +634,21 @@ int paired_upload_delta(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   if (!s.dirty_touched.empty() && s.patch_ready) {
     // the patch was written with the lists (paired_sync_tables): one dispatch applies it and, when it names every new pair, sets their marks
     const size_t nd = s.dirty.size();
-    const bool fuse_marks = nd > s.dirty_marked && (size_t)s.patch_new == nd - s.dirty_marked;
+    const bool fuse_marks = s.patch_long.empty() && nd > s.dirty_marked && (size_t)s.patch_new == nd - s.dirty_marked;
     s.spill_of.resize(nd, -1);
-    const int n0 = (int)s.pt.class_count[0], n01 = n0 + (int)s.pt.class_count[1], n_main = n01 + (int)s.pt.class_count[2];
-    hipLaunchKernelGGL((apply_delta_patch_kernel<DeltaPatch2, 2>), dim3((unsigned)std::min<size_t>(((size_t)s.patch_n + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
-                       (const DeltaPatch2*)s.stage_delta.host[s.patch_slot].dev, s.patch_n, s.dl_slot.as<int>(), s.dl_spill.as<int>(), s.dl_rec[0].as<int4>(), s.dl_rec[1].as<int4>(),
-                       fuse_marks ? (int)s.dirty_marked : -1, s.tab.rec8[0].as<unsigned long long>(), n0, s.tab.inl[0].as<int4>(), n01, n_main, s.tab.first[0].as<int4>());
-    HIP_TRY(c, hipGetLastError());
+    if (s.patch_n > 0) {
+      const int n0 = (int)s.pt.class_count[0], n01 = n0 + (int)s.pt.class_count[1], n_main = n01 + (int)s.pt.class_count[2];
+      hipLaunchKernelGGL((apply_delta_patch_kernel<DeltaPatch2, 2>), dim3((unsigned)std::min<size_t>(((size_t)s.patch_n + kBlock - 1) / kBlock, 256)), dim3(kBlock), 0, st,
+                         (const DeltaPatch2*)s.stage_delta.host[s.patch_slot].dev, s.patch_n, s.dl_slot.as<int>(), s.dl_spill.as<int>(), s.dl_rec[0].as<int4>(), s.dl_rec[1].as<int4>(),
+                         fuse_marks ? (int)s.dirty_marked : -1, s.tab.rec8[0].as<unsigned long long>(), n0, s.tab.inl[0].as<int4>(), n01, n_main, s.tab.first[0].as<int4>());
+      HIP_TRY(c, hipGetLastError());
+    }
     if (int e = stage_release(c, s.stage_delta, s.patch_slot, st)) return e;
     if (fuse_marks) s.dirty_marked = nd;
+    if (!s.patch_long.empty()) {  // the few pairs with three or more records on a mate: long form, applied behind the short one (same stream)
+      if (int e = delta_upload_patch(c, s, st, s.pt, s.dirty, s.patch_long, s.spill_of, s.spill_pairs, &s.spill_changed,
+                                     DeltaStore{&s.dl_slot, &s.dl_spill, &s.dl_rec[0], &s.dl_rec[1]})) return e;
+    }
     s.dirty_touched.clear();
     s.patch_ready = false;
   } else if (!s.dirty_touched.empty()) {
@@ -771,7 +778,8 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
         const int slot = stage_acquire(c, s.stage_delta, new_records * sizeof(DeltaPatch2), &ph);
         if (slot < 0) return slot;
         if (s.patch_of.size() < s.delta_cap + 4096) s.patch_of.assign(s.delta_cap + 4096, -1);
-        sink = PatchSink{(DeltaPatch2*)ph, s.patch_of.data(), (int)new_records, 0, 0, (int64_t)s.dirty_marked, false};
+        s.patch_long.clear();
+        sink = PatchSink{(DeltaPatch2*)ph, s.patch_of.data(), (int)new_records, 0, 0, (int64_t)s.dirty_marked, false, &s.patch_long};
         s.patch_slot = slot;
         use = &sink;
       }
@@ -779,7 +787,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
       if (use) {
         for (int k = 0; k < sink.n; k++) s.patch_of[sink.buf[k].dj] = -1;  // (the map is all -1 again: entries are found by their pair numbers)
         if (s.dirty.size() > s.patch_of.size()) sink.broken = true;          // (cannot happen: the store's capacity bounds the pairs)
-        s.patch_ready = !sink.broken && sink.n > 0;
+        s.patch_ready = !sink.broken && (sink.n > 0 || !s.patch_long.empty());
         s.patch_n = sink.n; s.patch_new = sink.n_new;
       }
     }

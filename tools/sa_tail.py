@@ -18,6 +18,12 @@ for knob6 in (0,):
     rs = ctx.add_paired(api.paired_cfg(300.0, 30.0), *reads)
     ctx.debug_set_knob(6, knob6)
     ctx.debug_set_knob(9, 1)
+    if os.environ.get("SA_WARM"):  # as bench.py: the context has scored the 8 rotating path sets of the headline (tables built over THEIR windows) first
+        import bench
+        variants = [api.FlatPaths(v) for v in bench.path_variants(synth.genome_walk(g))]
+        for v in variants: ctx.score(v)
+        ctx.compact_tables(); ctx.score(variants[0])
+        for i in range(200): ctx.score(variants[i % 8])
     ctx.calc_prob(start)
     os.environ["GAML_HIP_TRACE_ALIGNER"] = "1"; print("   after the cold call:", end=" ", flush=True); ctx.aligner_stats(); del os.environ["GAML_HIP_TRACE_ALIGNER"]
     per, prof, kinds = [], [], []
