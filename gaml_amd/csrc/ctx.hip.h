@@ -231,6 +231,7 @@ struct TableRebuild {
   int64_t start_eval = 0;      // the set's evaluation count when the rebuild was decided
   bool keep_dominated = false; // knob 16 as the worker read it
   int static_ins_n = 0;        // paired_static_ins_n() when the rebuild was decided
+  bool sh_touched_pages = false;  // the second lists' reserved storage has been written once (no page faults while they fill)
   size_t next_w[2] = {0, 0};   // state 4: progress of the private copy (first window not copied yet)
 };
 

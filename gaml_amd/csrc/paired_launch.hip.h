@@ -417,6 +417,11 @@ void paired_launch_worker(gaml_hip_ctx* c, PairedSet& s) {
     int rc = hipSetDevice(device) == hipSuccess ? 0 : GAML_HIP_EHIP;
     if (rc) rb.err = "hipSetDevice failed in the rebuild worker";
     rb.sh_dirty.clear();  // the lists of the tables before last (swapped out at the previous take-over): emptied here, off the caller's thread
+    if (!rb.sh_touched_pages && rb.sh_dirty.capacity()) {  // ... and their reserved storage's pages touched once, here (paired_reserve_delta does it for the live lists)
+      volatile char* base = (volatile char*)rb.sh_dirty.data();
+      for (size_t o = 0; o < rb.sh_dirty.capacity() * sizeof(PairedSet::DirtyPair); o += 4096) base[o] = 0;
+      rb.sh_touched_pages = true;
+    }
     if (!rc) {
       rb.keep_dominated = KNOB(c, 16) == 1;
       build_pair_tables(rb.snap[0], rb.snap[1], rb.pt, !rb.keep_dominated, rb.static_ins_n);
