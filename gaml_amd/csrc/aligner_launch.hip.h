@@ -212,14 +212,22 @@ void aln_file_hits(ShortMate& m, int nw, std::vector<AlnHit>& hits, bool device_
       std::vector<int64_t> fill(wstart.begin(), wstart.end() - 1);
       for (const AlnHit& h : hits) if (h.edit >= 0) ok[(size_t)fill[h.win]++] = h;
     }
+    // (the four-part order as two integers per hit: a comparison is two compares of registers instead of four of loaded fields)
+    auto key1 = [](const AlnHit& h) { return ((uint64_t)((uint32_t)h.pos + 0x80000000u) << 32) | (uint32_t)((uint32_t)h.read + 0x80000000u); };
+    auto key2 = [](const AlnHit& h) { return ((uint64_t)((uint32_t)h.strand + 0x80000000u) << 32) | (uint32_t)((uint32_t)h.order + 0x80000000u); };
     auto sort_range = [&](int k0, int k1) {
-      for (int k = k0; k < k1; k++)
-        std::sort(ok.begin() + wstart[k], ok.begin() + wstart[k + 1], [](const AlnHit& a, const AlnHit& b) {
-          if (a.pos != b.pos) return a.pos < b.pos;
-          if (a.read != b.read) return a.read < b.read;
-          if (a.strand != b.strand) return a.strand < b.strand;
-          return a.order < b.order;
-        });
+      struct Key { uint64_t a, b; uint32_t at; };
+      std::vector<Key> keys;
+      std::vector<AlnHit> tmp;
+      for (int k = k0; k < k1; k++) {
+        const int64_t lo = wstart[k], n = wstart[k + 1] - lo;
+        if (n < 2) continue;
+        keys.resize((size_t)n);
+        for (int64_t i = 0; i < n; i++) keys[(size_t)i] = Key{key1(ok[lo + i]), key2(ok[lo + i]), (uint32_t)i};
+        std::sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+        tmp.assign(ok.begin() + lo, ok.begin() + lo + n);
+        for (int64_t i = 0; i < n; i++) ok[lo + i] = tmp[keys[(size_t)i].at];
+      }
     };
     const int n_threads = ok.size() > (size_t)200000 ? (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
     if (n_threads > 1) {
@@ -287,7 +295,7 @@ void aln_file_hits(ShortMate& m, int nw, std::vector<AlnHit>& hits, bool device_
       }
     });
   } else {
-    std::vector<gaml_aligment> recs;
+    thread_local std::vector<gaml_aligment> recs;
     for (int k = 0; k < nw; k++) {
       recs.clear();
       for (int64_t at = wstart[k]; at < wstart[k + 1]; at++)
