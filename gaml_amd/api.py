@@ -206,6 +206,8 @@ def _load():
         L.gaml_hip_debug_fold_check.argtypes = [vp, C.c_int, _i64p]
     if hasattr(L, "gaml_hip_debug_radix_sort"):  # development build only
         L.gaml_hip_debug_radix_sort.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+    if hasattr(L, "gaml_hip_debug_tables_check"):
+        L.gaml_hip_debug_tables_check.argtypes = [vp, C.c_int, _i64p]
     if hasattr(L, "gaml_hip_debug_static_check"):  # absent from older A/B builds loaded through GAML_HIP_LIB
         L.gaml_hip_debug_static_check.argtypes = [vp, C.c_int, _i64p]
     if hasattr(L, "gaml_hip_debug_set_knob"):  # development build only
@@ -732,6 +734,16 @@ class Context:
         self._check(_lib.gaml_hip_debug_static_check(self._h, rs, out))
         return {"static_pairs": int(out[0]), "other_pairs": int(out[1]), "violations": int(out[2]), "no_record": int(out[3]),
                 "different_windows": int(out[4]), "orientation": int(out[5]), "distance": int(out[6]), "edits_or_code": int(out[7])}
+
+    def debug_tables_check(self, rs):
+        """The device table build against the host restatement, entry by entry (development build)."""
+        out = np.zeros(8, np.int64)
+        rc = _lib.gaml_hip_debug_tables_check(self._h, rs, out)
+        res = {"pairs": int(out[0]), "compact": int(out[1]), "static": int(out[2]), "two": int(out[3]), "four": int(out[4]), "more": int(out[5]),
+               "compared": int(out[6]), "mismatches": int(out[7])}
+        if rc != 0 and res["compared"] == 0:
+            self._check(rc)
+        return res
 
     def general_stats(self):
         n, us = C.c_int64(), C.c_double()

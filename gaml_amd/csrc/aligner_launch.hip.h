@@ -294,6 +294,7 @@ void aln_file_hits(ShortMate& m, int nw, std::vector<AlnHit>& hits, bool device_
         win.pending = false;
       }
     });
+    for (int k = 0; k < nw; k++) m.filed.push_back(m.pending[k]);
   } else {
     thread_local std::vector<gaml_aligment> recs;
     for (int k = 0; k < nw; k++) {

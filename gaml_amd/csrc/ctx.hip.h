@@ -28,6 +28,8 @@
 #include "aligner_small.hip.h"
 #include "host_model.h"
 #include "kernels.hip.h"
+#include "table_build.hip.h"
+#include "delta_dev.hip.h"
 #include "pacbio_dp.hip.h"
 #include "pacbio_sweep.hip.h"
 #include "internal.h"
@@ -167,110 +169,95 @@ struct AlnJob {
 };
 
 struct MateDev {
-  DevBuf first, extra, pows;  // pows = mismatch_pow | match_pow
+  DevBuf first, extra, pows;  // pows = mismatch_pow | match_pow (first / extra: the read-major tables of a single-end set)
   AlignDev aln;
   uint64_t uploaded_generation = ~0ull;
   size_t pow_n = 0;
+  // paired sets: the alignment-window cache's records ON THE DEVICE, window-major (a window's records contiguous, ordered by
+  // (position, read)): int4 {window id, position, edit | orient << 8, read}. Window::dfirst points into it. Filled by the
+  // aligner's filing kernels, or mirrored from the host pool for windows the host filed (host aligner, caller-supplied records)
+  DevBuf pool;
+  int64_t pool_n = 0;         // records in use
+  size_t filed_done = 0;      // ShortMate::filed[0 .. filed_done) are on the device
+  DevBuf lens;                // read lengths
 };
 
-// the device side of one build of the record tables (PairTables): everything a rebuild replaces as a whole
+// the device side of one build of the record tables: everything a rebuild replaces as a whole (table_build.hip.h)
 struct TableDev {
-  DevBuf rec8[2], first[2], extra[2], inl[2], len_code, len_combo, len12, combo_tabs, memo, static_idx, static_val;
-  int memo_codes = 0;     // length combinations the memo of pair terms covers (0: no memo)
+  DevBuf rec8[2], first[2], extra[2], inl[2], len_code, len12, static_idx, static_val;
+  DevBuf slot_of_read, read_of_slot, dirty_of_slot;  // read -> slot, slot -> read, slot -> index on the delta lists (-1: none)
+  DevBuf cnt;              // the build's device counters (kTb*)
+  bool built = false;
+  // what the host knows of it once the build is through
+  int64_t class_count[4] = {0, 0, 0, 0}, n0a = 0, extras[2] = {0, 0}, dropped[2] = {0, 0};
+  bool keep_dominated = false;   // knob 16 when it was built
+  std::vector<int32_t> read_of_slot_host;  // fetched on demand (gaml_hip_read_probs)
+  bool ros_valid = false;
   void release() {
     for (int m = 0; m < 2; m++) { rec8[m].release(); first[m].release(); extra[m].release(); inl[m].release(); }
-    len_code.release(); len_combo.release(); len12.release(); combo_tabs.release(); memo.release(); static_idx.release(); static_val.release();
+    len_code.release(); len12.release(); static_idx.release(); static_val.release(); slot_of_read.release(); read_of_slot.release(); dirty_of_slot.release(); cnt.release();
   }
 };
 
-// A rebuild of the record tables off the caller's thread: the calling thread takes a private copy of what the build
-// reads (active windows' records, ~4 ms at 833 k pairs), a worker builds the tables (~30 ms) and uploads them into a
-// second set of device buffers; evaluations go on meanwhile over the old tables + delta lists, and a later call swaps.
-// a delta pair's record list: up to 4 records inline -- the usual case, no allocation per pair -- or all of them in `more`
-struct DeltaRecList {
-  uint32_t n = 0;
-  RecQuad in[4];
-  std::vector<RecQuad> more;
-  size_t size() const { return n; }
-  const RecQuad* data() const { return n <= 4 ? in : more.data(); }
-  const RecQuad& operator[](size_t k) const { return data()[k]; }
-  void insert(size_t at, const RecQuad& q) {
-    if (n < 4) { for (size_t k = n; k > at; k--) in[k] = in[k - 1]; in[at] = q; n++; return; }
-    if (n == 4) more.assign(in, in + 4);
-    more.insert(more.begin() + at, q);
-    n++;
+// scratch of a table build (one build at a time per set)
+struct BuildScratch {
+  DevBuf k_in, k_out, k_tmp, v_in, v_tmp, hist, v_sorted[2], rstart[2], rend[2], one[2], cl, sidx, more[2], start[2], tiles, wins[2], peer0;
+  PinBuf h_wins[2], h_peer, h_cnt;
+  void release() {
+    k_in.release(); k_out.release(); k_tmp.release(); v_in.release(); v_tmp.release(); hist.release(); cl.release(); sidx.release(); tiles.release(); peer0.release();
+    for (int m = 0; m < 2; m++) { v_sorted[m].release(); rstart[m].release(); rend[m].release(); one[m].release(); more[m].release(); start[m].release(); wins[m].release(); h_wins[m].release(); }
+    h_peer.release(); h_cnt.release();
   }
-  void push_back(const RecQuad& q) { insert(n, q); }
 };
-struct DeltaPair { int32_t slot; uint32_t len12; DeltaRecList recs[2]; };  // len12: the pair's two read lengths (L1 | L2 << 16), noted when the pair is made
 
+// A rebuild of the record tables beside the evaluations: the build is a chain of kernels on a stream of its own over the
+// device pool (a few hundred microseconds at 833 k pairs); evaluations go on over the old tables + delta lists, and the new
+// tables take over a FIXED number of evaluations later (equal inputs must give equal outputs run to run, and a rebuild
+// changes the order of the final sum). What was activated in between is applied to the new tables' (empty) delta lists by
+// the same kernel that maintains the live ones.
 struct TableRebuild {
-  std::thread th;
-  std::atomic<int> state{0};   // 0 idle, 4 taking the private copy (a slice per evaluation), 1 worker running, 2 ready, 3 failed
-  ShortMate snap[2];
-  PairTables pt;
-  TableDev tab;
-  std::string err;
-  // windows activated since the snapshot, call by call (mate 0's, then mate 1's): what the new tables do not hold
-  struct After { int32_t mate, wid; int64_t keep_at; };  // keep_at: -1, or where the window's keep mask starts in after_keep
-  std::vector<After> after;
-  std::vector<uint8_t> after_keep;  // per record of such a window: 0 = always overwritten, left out (as the live lists left it out)
-  // Their pairs' lists relative to the NEW tables ("shadow" lists), filled on the calling thread a slice per evaluation
-  // once the worker is done, so that the call at which the tables take over has only the last few windows left.
-  std::vector<DeltaPair> sh_dirty;
-  std::vector<int32_t> sh_of_slot;
-  // ... and their device copy: a second delta store, patched slice by slice like the live one (swapped in at the take-over)
-  std::vector<int32_t> sh_touched, sh_spill_of, sh_spill_pairs;
-  DevBuf sh_dl_slot, sh_dl_spill, sh_dl_rec[2];
-  size_t sh_next = 0;          // first entry of `after` not yet in the shadow lists
-  bool sh_open = false;
-  int64_t sh_records = 0;      // records of after[sh_next..) still to go (budget of a slice)
-  uint64_t gen_snap[2] = {0, 0};
-  hipStream_t stream = nullptr;
-  double snapshot_us = 0, build_ms = 0;
+  bool active = false;
   int64_t start_eval = 0;      // the set's evaluation count when the rebuild was decided
-  bool keep_dominated = false; // knob 16 as the worker read it
-  int static_ins_n = 0;        // paired_static_ins_n() when the rebuild was decided
-  bool sh_touched_pages = false;  // the second lists' reserved storage has been written once (no page faults while they fill)
-  size_t next_w[2] = {0, 0};   // state 4: progress of the private copy (first window not copied yet)
+  TableDev tab;                // the spare set of buffers: being built, or idle
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr, mark = nullptr;
+  std::vector<std::pair<int32_t, int32_t>> after;  // (mate, window) activated since the build started: not in the new tables
+};
+
+// what the host keeps of the live tables (the tables themselves exist on the device only)
+struct PairInfo {
+  int64_t class_count[4] = {0, 0, 0, 0};  // 0: compact; 1: <= 2 records; 2: <= 4; 3: more
+  int64_t n0a = 0;                        // static part of the compact class
+  std::vector<uint32_t> len_combo;        // distinct L1 | L2 << 16 values (<= 256), in order of first appearance: fixed per read set
+  int64_t dropped_records[2] = {0, 0};
 };
 
 struct PairedSet {
   gaml_paired_cfg cfg;
   ShortMate mate[2];
-  PairTables pt;                      // device order + compact / 16-byte record tables (cold path)
-  MateDev dev[2];                     // (pows, aligner index, generation; the record tables themselves are in `tab`)
-  TableDev tab;
+  PairInfo pt;
+  MateDev dev[2];                     // (pows, aligner index, record pool, generation)
+  TableDev tab;                       // the live record tables
   TableRebuild rebuild;
+  BuildScratch scratch;
   int64_t async_rebuilds = 0, retired_windows = 0, eval_count = 0;
-  // delta since the last full table build: pairs whose record lists gained records of newly
-  // activated windows. Their complete lists (device-table order: window id, position) travel with
-  // every evaluation; a full rebuild folds them back in when they become too many.
-  // (a pair's list: up to 4 records inline -- the usual case, no allocation per pair -- or all of them in `more`)
-  using RecList = DeltaRecList;
-  using DirtyPair = DeltaPair;
-  std::vector<DirtyPair> dirty;
-  std::vector<int32_t> dirty_of_slot;                // slot -> index in `dirty`, -1: not on the delta list
+  // per set, fixed: length-combination code per pair, the per-combination tables, the memo of pair terms
+  DevBuf lcode, len_combo_dev, combo_tabs, memo;
+  int memo_codes = 0;
+  bool statics_uploaded = false;
+  // Delta store (device): pairs whose record lists gained records of windows activated after the tables were built. Their
+  // complete lists sit at a fixed stride (4 records per mate; longer ones in the spill area); maintained by
+  // delta_apply_kernel, read by the scoring launch. The host knows upper bounds (and the exact counts once a blocking call
+  // has returned: h_dstate, written by the kernels).
+  DevBuf dl_slot, dl_spill, dl_rec[2], sp_rng[2], sp_rec[2], sp_slot, dstate;
+  PinBuf h_dstate;
+  size_t delta_cap = 0, cap_spill = 0, cap_sprec = 0;
+  int64_t nd_est = 0, ns_est = 0;     // delta pairs (upper bound) / long lists (last exact count) as the host knows them
+  bool spill_may_grow = false;        // activations since the counts were last read back
+  int dl_seq = 0;                     // sequence number of the last maintenance launch (h_dstate[kDsSeq] == dl_seq: the counts are current)
   int64_t full_rebuilds = 0, delta_updates = 0;
-  size_t dirty_marked = 0;   // delta pairs whose slots already carry the mark on the device
-  // The delta lists live on the device at a fixed stride (4 records per mate and pair, longer lists in
-  // a small spill CSR); an evaluation that changed some of them uploads a patch for just those pairs.
-  std::vector<int32_t> dirty_touched;   // indices into `dirty` changed since the last upload
-  // the same call's patch written while the lists are made (paired_extend_delta with a PatchSink): entry number per delta
-  // pair (-1: none), the staging slot that holds the entries, their count, how many of them are new pairs
-  std::vector<int32_t> patch_of, patch_long;  // patch_long: pairs touched in this call that hold more than two records on a mate (the long form: a second pass over just those)
-  int patch_slot = -1, patch_n = 0, patch_new = 0;
-  bool patch_ready = false;
-  std::vector<int32_t> spill_of;        // per dirty pair: index in spill_pairs or -1
-  std::vector<int32_t> spill_pairs;     // dirty indices with more than 4 records on a mate
-  bool spill_changed = false;
-  size_t delta_cap = 0;                 // pairs the device store holds
-  DevBuf dl_slot, dl_spill, dl_rec[2], dl_patch, delta_dev /* spill CSR */;
-  Staging stage_delta;
-  size_t delta_off[5] = {0, 0, 0, 0, 0};   // spill CSR: offsets mate 0, records mate 0, offsets mate 1, records mate 1, slots
   int quiet_calls = 0;       // evaluations since the last window activation
-  int64_t delta_left_out = 0;         // records of later windows that never reached the delta lists (always overwritten)
-  bool built_keep_dominated = false;  // knob 16 at the last table build on the calling thread
+  int64_t delta_left_out = 0;         // (statistics: not tracked on the device path)
   bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
   PinBuf h_timeline; int timeline_waves = 0;  // ablation 8 (tools/kernel_timeline.py)
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls): [set][block]
@@ -298,6 +285,7 @@ struct PairedSet {
   OccImage image[2];                 // persistent host images of the occurrence tables, patched per call
   std::vector<Occ> scratch_occ[2];   // debug dumps only
   Reducer red;
+  Staging stage_pool;                // host-filed windows on their way into the device pool
   std::vector<double> ins_tab, floor_tab, logfloor_tab, covthr_tab;
   bool floor_positive = true;  // every floor exp(c + k s) > 0 (else "probability 0 is floored" does not hold: no memo / shortcut paths)
   bool tabs_uploaded = false;

@@ -96,6 +96,21 @@ int gaml_hip_debug_set_knob(gaml_hip_ctx* c, int knob, int value) {
 // junction window J for which the first node's own window -- active -- holds a record of the same read at the same
 // position. out6 = {records left out mate 1, mate 2, pairs of the compact class with / without the rule, records
 // checked, violations}. Returns GAML_HIP_ESTATE when a violation was found.
+// a pair's records as the host restatement of the tables holds them (build_pair_tables)
+static void paired_base_records(const PairTables& pt, int32_t slot, int mt, std::vector<RecQuad>& out) {
+  const int64_t n0s = pt.class_count[0];
+  if (slot < n0s) {
+    const uint64_t r = pt.rec8[mt][slot];
+    if (r != kNoRec8) out.push_back(RecQuad{(int32_t)(r & 0xffffff), (int32_t)((r >> 24) & 0xfffffff), (int32_t)((r >> 52) & 63) | ((int32_t)((r >> 58) & 1) << 8), 0});
+  } else {
+    const RecQuad& f = pt.rm[mt].first[slot - n0s];
+    if (f.wid >= 0) {
+      const int cnt1 = 1 + (int)((uint32_t)f.flags >> 9);
+      for (int q = 0; q < cnt1; q++) { RecQuad r = q == 0 ? f : pt.rm[mt].extra[f.link + q - 1]; r.flags &= 0x1ff; r.link = 0; out.push_back(r); }
+    }
+  }
+}
+
 int gaml_hip_debug_fold_check(gaml_hip_ctx* c, int rs, int64_t* out6) {
   MULTI_SHARD0(c);
   if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out6) return fail(c, GAML_HIP_EINVAL, "bad arguments");
@@ -105,12 +120,12 @@ int gaml_hip_debug_fold_check(gaml_hip_ctx* c, int rs, int64_t* out6) {
   build_pair_tables(s.mate[0], s.mate[1], without, false);
   int64_t checked = 0, bad = 0;
   const int64_t n = s.mate[0].n_local();
-  PairedSet::RecList a, b;
+  std::vector<RecQuad> a, b;
   for (int mt = 0; mt < 2; mt++) {
     const ShortMate& m = s.mate[mt];
     // per (window, read, position): is it a record of an active single-node window?
     for (int64_t read = 0; read < n; read++) {
-      a = PairedSet::RecList(); b = PairedSet::RecList();
+      a.clear(); b.clear();
       paired_base_records(with, with.slot_of_read[read], mt, a);
       paired_base_records(without, without.slot_of_read[read], mt, b);
       size_t ia = 0;
@@ -238,3 +253,76 @@ int32_t gaml_hip_debug_block_partials(gaml_hip_ctx* c, int rs, int32_t set, doub
 }
 
 
+
+// The device table build (table_build.hip.h) against the host restatement (host_model.cc build_pair_tables) on the windows
+// that are active now: a fresh build into a scratch set of buffers, every array fetched and compared entry by entry. The
+// host side works on a copy of the device pool (the records of windows the aligner's kernels filed exist nowhere else).
+// out8 = {pairs, compact class, static part, <= 2 records, <= 4, more, entries compared, mismatches}.
+int gaml_hip_debug_tables_check(gaml_hip_ctx* c, int rs, int64_t* out8) {
+  MULTI_SHARD0(c);
+  if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out8) return fail(c, GAML_HIP_EINVAL, "bad arguments");
+  if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "host-only context");
+  PairedSet& s = *c->paireds[c->handles[rs].idx];
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (s.rebuild.active) { HIP_TRY(c, hipEventSynchronize(s.rebuild.done)); s.rebuild.active = false; s.rebuild.after.clear(); }
+  if (int e = prepare_paired_tables(c, s)) return e;
+  if (int e = pool_mirror(c, s, c->stream)) return e;
+  if (int e = paired_upload_statics(c, s, c->stream)) return e;
+  TableDev T;
+  if (int e = paired_build_enqueue(c, s, T, c->stream)) return e;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (int e = paired_build_collect(c, s, T)) { T.release(); return e; }
+  // host side
+  ShortMate hm[2];
+  for (int mt = 0; mt < 2; mt++) {
+    const ShortMate& m = s.mate[mt];
+    hm[mt].n_global = m.n_global; hm[mt].lo = m.lo; hm[mt].hi = m.hi; hm[mt].lens = m.lens;
+    hm[mt].wins = m.wins;
+    std::vector<int4> dp((size_t)s.dev[mt].pool_n);
+    if (!dp.empty()) HIP_TRY(c, hipMemcpy(dp.data(), s.dev[mt].pool.p, dp.size() * sizeof(int4), hipMemcpyDeviceToHost));
+    hm[mt].pool.resize(dp.size());
+    for (size_t k = 0; k < dp.size(); k++) hm[mt].pool[k] = gaml_aligment{dp[k].y, dp[k].z & 0xff, dp[k].w, (dp[k].z >> 8) & 1};
+    for (Window& w : hm[mt].wins) w.first = w.dfirst < 0 ? 0 : w.dfirst;
+    for (Window& w : hm[mt].wins) if (w.dfirst < 0) { w.count = 0; }
+  }
+  PairTables pt;
+  build_pair_tables(hm[0], hm[1], pt, KNOB(c, 16) != 1, paired_static_ins_n(c, s));
+  const int64_t n = s.mate[0].n_local();
+  int64_t compared = 0, bad = 0;
+  auto fetch = [&](const DevBuf& d, size_t bytes, std::vector<char>& out) -> int {
+    out.resize(bytes);
+    if (bytes) HIP_TRY(c, hipMemcpy(out.data(), d.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+  };
+  auto cmp = [&](const DevBuf& d, const void* host, size_t bytes, size_t elem, const char* what) -> int {
+    std::vector<char> v;
+    if (int e = fetch(d, bytes, v)) return e;
+    int64_t b0 = bad;
+    for (size_t k = 0; k < bytes / elem; k++) { compared++; if (memcmp(v.data() + k * elem, (const char*)host + k * elem, elem) != 0) bad++; }
+    if (bad != b0 && getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "tables_check: %s differs in %lld of %zu entries\n", what, (long long)(bad - b0), bytes / elem);
+    return 0;
+  };
+  for (int k = 0; k < 4; k++) { compared++; bad += T.class_count[k] != pt.class_count[k]; }
+  compared++; bad += T.n0a != pt.n0a;
+  if (bad == 0) {
+    const int64_t n0 = pt.class_count[0], n16 = n - n0;
+    if (int e = cmp(T.slot_of_read, pt.slot_of_read.data(), (size_t)n * 4, 4, "slot_of_read")) return e;
+    if (int e = cmp(T.read_of_slot, pt.read_of_slot.data(), (size_t)n * 4, 4, "read_of_slot")) return e;
+    for (int mt = 0; mt < 2; mt++) {
+      if (int e = cmp(T.rec8[mt], pt.rec8[mt].data(), (size_t)n0 * 8, 8, "rec8")) return e;
+      if (int e = cmp(T.first[mt], pt.rm[mt].first.data(), (size_t)n16 * 16, 16, "first")) return e;
+      if (int e = cmp(T.extra[mt], pt.rm[mt].extra.data(), pt.rm[mt].extra.size() * 16, 16, "extra")) return e;
+      if (int e = cmp(T.inl[mt], pt.inl[mt].data(), pt.inl[mt].size() * 16, 16, "inl")) return e;
+      compared++; bad += T.extras[mt] != (int64_t)pt.rm[mt].extra.size();
+      compared++; bad += T.dropped[mt] != pt.dropped_records[mt];
+    }
+    if (int e = cmp(T.len_code, pt.len_code.data(), (size_t)n0, 1, "len_code")) return e;
+    if (int e = cmp(T.static_idx, pt.static_idx.data(), (size_t)pt.n0a * 4, 4, "static_idx")) return e;
+    if (int e = cmp(T.len12, pt.len12.data(), (size_t)n16 * 4, 4, "len12")) return e;
+    compared++; bad += pt.len_combo != s.pt.len_combo;
+  }
+  out8[0] = n; out8[1] = T.class_count[0]; out8[2] = T.n0a; out8[3] = T.class_count[1]; out8[4] = T.class_count[2]; out8[5] = T.class_count[3];
+  out8[6] = compared; out8[7] = bad;
+  T.release();
+  return bad ? fail(c, GAML_HIP_ESTATE, "record tables: the device build differs from the host restatement") : GAML_HIP_OK;
+}

@@ -462,11 +462,14 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     auto drop_stage = [](Staging& s) { for (int k = 0; k < kRing; k++) { s.host[k].release(); if (s.done[k]) (void)hipEventDestroy(s.done[k]); } };
     for (auto& s : c->singles) { s->dev.first.release(); s->dev.extra.release(); s->dev.pows.release(); s->lens.release(); s->probs.release(); s->tabs.release(); s->occ_arena.release(); s->red.release(); drop_stage(s->stage); }
     for (auto& s : c->paireds) {
-      if (s->rebuild.th.joinable()) s->rebuild.th.join();
       if (s->rebuild.stream) (void)hipStreamDestroy(s->rebuild.stream);
-      s->tab.release(); s->rebuild.tab.release();
-      for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); }
-      s->delta_dev.release(); s->dl_slot.release(); s->dl_spill.release(); s->dl_rec[0].release(); s->dl_rec[1].release(); s->dl_patch.release(); s->rebuild.sh_dl_slot.release(); s->rebuild.sh_dl_spill.release(); s->rebuild.sh_dl_rec[0].release(); s->rebuild.sh_dl_rec[1].release(); drop_stage(s->stage_delta); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release();
+      if (s->rebuild.done) (void)hipEventDestroy(s->rebuild.done);
+      if (s->rebuild.mark) (void)hipEventDestroy(s->rebuild.mark);
+      s->tab.release(); s->rebuild.tab.release(); s->scratch.release();
+      for (int m = 0; m < 2; m++) { s->dev[m].first.release(); s->dev[m].extra.release(); s->dev[m].pows.release(); s->dev[m].aln.release(); s->dev[m].pool.release(); s->dev[m].lens.release();
+                                    s->dl_rec[m].release(); s->sp_rng[m].release(); s->sp_rec[m].release(); }
+      s->dl_slot.release(); s->dl_spill.release(); s->sp_slot.release(); s->dstate.release(); s->h_dstate.release(); s->lcode.release(); s->len_combo_dev.release(); s->combo_tabs.release(); s->memo.release();
+      drop_stage(s->stage_pool); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release();
       s->probs.release(); s->tabs.release(); s->arena.release(); s->persist.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
       s->red.release(); s->gen_bits.release();
     }
@@ -952,6 +955,7 @@ int gaml_hip_sync(gaml_hip_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->used_default_stream) { HIP_TRY(c, hipStreamSynchronize(nullptr)); c->used_default_stream = false; }  // (an *_async call was handed NULL)
+  for (auto& ps : c->paireds) paired_refresh_counts(*ps);
   return GAML_HIP_OK;
 }
 
@@ -1066,6 +1070,12 @@ static int fetch_partials(gaml_hip_ctx* c, double* partials_out) {
     }
   }
   memcpy(partials_out, c->packed_host.p, c->handles.size() * 4 * sizeof(double));
+  // the device is through with this evaluation: the delta lists' exact counts are in pinned memory (written by the kernels
+  // that maintain them, in stream order before the scoring launch)
+  for (auto& ps : c->paireds) {
+    paired_refresh_counts(*ps);
+    if (paired_delta_overflowed(*ps)) return fail(c, GAML_HIP_ESTATE, "delta store overflow (spill area); call gaml_hip_compact_tables and evaluate again");
+  }
   c->t_kernel_us = 0;
   if (!spun) { if (int e2 = collect_events(c)) return e2; }  // after a spin the events are collected lazily (gaml_hip_kernel_stats)
   // bookkeeping for gaml_hip_bad_bases
@@ -1209,7 +1219,13 @@ int gaml_hip_read_probs(gaml_hip_ctx* c, int rs, double* out, int64_t n) {
   HIP_TRY(c, hipDeviceSynchronize());
   if (have) HIP_TRY(c, hipMemcpy(out, src, have * sizeof(double), hipMemcpyDeviceToHost));
   if (h.kind == 1 && have) {  // device order -> read order
-    const auto& ros = c->paireds[h.idx]->pt.read_of_slot;
+    TableDev& T = c->paireds[h.idx]->tab;
+    if (!T.ros_valid) {
+      T.read_of_slot_host.resize((size_t)have);
+      HIP_TRY(c, hipMemcpy(T.read_of_slot_host.data(), T.read_of_slot.p, (size_t)have * sizeof(int32_t), hipMemcpyDeviceToHost));
+      T.ros_valid = true;
+    }
+    const auto& ros = T.read_of_slot_host;
     std::vector<double> tmp(out, out + have);
     for (int64_t j = 0; j < have; j++) out[ros[j]] = tmp[j];
   }
@@ -1240,6 +1256,16 @@ int64_t gaml_hip_window_records(gaml_hip_ctx* c, int rs, int mate, const int32_t
   if (id < 0) return -1;
   if (m->wins[id].pending) m->flush_pending_cpu(c->g);
   const Window& w = m->wins[id];
+  if (w.first < 0 && w.count > 0 && cap > 0) {  // filed by the aligner's kernels: the records exist in the device pool only
+    SetRef h = c->handles[rs];
+    if (h.kind != 1 || w.dfirst < 0 || c->device < 0) return -2;
+    const int64_t k = std::min<int64_t>(w.count, cap);
+    std::vector<int4> tmp((size_t)k);
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(tmp.data(), c->paireds[h.idx]->dev[mate].pool.as<int4>() + w.dfirst, (size_t)k * sizeof(int4), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    for (int64_t i = 0; i < k; i++) out[i] = gaml_aligment{tmp[i].y, tmp[i].z & 0xff, tmp[i].w + (int32_t)m->lo, (tmp[i].z >> 8) & 1};
+    return w.count;
+  }
   for (int64_t i = 0; i < w.count && i < cap; i++) {
     out[i] = m->pool[w.first + i];
     out[i].read_id += (int32_t)m->lo;
@@ -1273,7 +1299,8 @@ int gaml_hip_table_stats(gaml_hip_ctx* c, int rs, int64_t* out10) {
   MULTI_SHARD0(c);
   if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out10) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
-  out8[0] = s.full_rebuilds; out8[1] = s.delta_updates; out8[2] = (int64_t)s.dirty.size(); out8[3] = s.async_rebuilds;
+  paired_refresh_counts(s);
+  out8[0] = s.full_rebuilds; out8[1] = s.delta_updates; out8[2] = s.nd_est; out8[3] = s.async_rebuilds;
   out8[4] = s.batches_patched; out8[5] = s.batches_full;
   out8[6] = s.pt.dropped_records[0]; out8[7] = s.pt.dropped_records[1];
   out10[8] = s.delta_left_out; out10[9] = s.pt.n0a;

@@ -393,6 +393,7 @@ void ShortMate::finalize_window(int32_t wid, std::vector<gaml_aligment>& recs) {
   win.global_max_pos = win.max_pos;
   win.pending = false;
   pool.insert(pool.end(), recs.begin(), recs.end());
+  filed.push_back(wid);
 }
 
 void ShortMate::cpu_align_records(const GraphStore& g, const Walk& w, std::vector<gaml_aligment>& recs) const {

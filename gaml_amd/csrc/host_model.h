@@ -48,7 +48,8 @@ using Walk = std::vector<int32_t>;
 // One cached window: records live in ShortMate::pool[first, first+count), sorted by
 // (position, read_id) like the reference's per-window vector.
 struct Window {
-  int64_t first = 0;
+  int64_t first = 0;          // where its records start in ShortMate::pool; -1: they exist on the device only (dfirst)
+  int64_t dfirst = -1;        // ... in the device pool of a paired set (MateDev::pool); -1: not there (yet)
   int32_t count = 0;
   int32_t max_pos = INT_MIN;  // largest record position among THIS shard's reads (INT_MIN when empty)
   int32_t global_max_pos = INT_MIN;  // ... among all shards' reads (== max_pos until exchanged)
@@ -91,7 +92,9 @@ struct ShortMate {
   std::vector<Window> wins;
   std::vector<const Walk*> win_walk;     // window id -> its node ids (keys of win_id are stable)
   std::unordered_map<int32_t, int32_t> solo_of_node;  // node -> id of its single-node window (tag_window)
-  std::vector<gaml_aligment> pool;       // read_id = LOCAL id inside the shard
+  std::vector<gaml_aligment> pool;       // read_id = LOCAL id inside the shard (host-filed windows; a paired set on a device keeps the
+                                         // records of windows its kernels filed in the device pool only)
+  std::vector<int32_t> filed;            // windows whose records were appended to `pool`, in pool order (mirrored to the device)
   std::vector<int32_t> unsynced;         // windows added since the last max-position exchange (sharded runs)
   std::vector<int32_t> added_log;        // windows added since the planner last looked (memo invalidation)
   std::vector<int32_t> activated_log;    // windows activated since the device tables last took them in

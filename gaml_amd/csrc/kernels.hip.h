@@ -16,6 +16,9 @@ namespace gaml {
 
 constexpr int kBlock = 256;      // 4 waves of 64
 constexpr int kMaxBlocks = 2048; // 256 CUs x 8 blocks, grid-stride beyond (guide G11)
+// device counters of a paired set's delta store (delta_dev.hip.h): delta pairs, long lists, used spill records per mate,
+// overflow flag, sequence number of the last maintenance launch
+enum { kDsDirty = 0, kDsSpill = 1, kDsTop0 = 2, kDsTop1 = 3, kDsOverflow = 4, kDsSeq = 5, kDsInts = 8 };
 
 // Occ12 (host_model.h): {lo, hi, rank}, 4-byte aligned: one dwordx3 load (register classes) or a dwordx2 of the first two words (class 0)
 __device__ __forceinline__ unsigned long long occ8_of(const Occ12* t, unsigned w) { const Occ12* e = t + w; return (unsigned long long)e->lo | ((unsigned long long)e->hi << 32); }
@@ -97,14 +100,14 @@ struct PairedArgs {
   // Delta: pairs whose record lists changed since the device tables were built (newly activated
   // windows). Their slots carry a DIRTY mark in the tables; their complete record lists travel with
   // every evaluation and the overflow path scores them.
-  int n_dirty;
+  const int* dstate;          // the delta store's device counters (kDs*): [kDsDirty] delta pairs, [kDsSpill] long lists -- the lists are
+                              // maintained by kernels (delta_dev.hip.h), the host only knows upper bounds when it sizes the grid
   const int* dirty_slots;     // [n_dirty] slot of the pair in the tables
   const int4* dirty_recs[2];  // [4 * n_dirty] per mate: the pair's complete record list {wid, pos, edit | orient<<8, 0}, padded with wid = -1
   const int* dirty_spill;     // [n_dirty] -1, or the pair's index in the spill lists (more than 4 records on a mate)
-  const int* spill_off[2];    // CSR of the spill lists
+  const int2* spill_rng[2];   // long lists: {begin, count} in spill_recs per spill index (a list that changes is written anew behind the others)
   const int4* spill_recs[2];
   const int* spill_slot;      // [n_spill] slot of the pair (scored one WAVE per pair, behind the table pairs with long lists)
-  int n_spill;
   unsigned* ticket;          // zero before first launch; the last block resets it
   double* out;               // the read set's 4 partials {sum of logs, floored reads, bad_bases, reads}
   double n_reads;
@@ -1045,7 +1048,7 @@ __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, i
   // one ballot word per wave and iteration -- and scored by paired_general_kernel: the general loop inside this kernel,
   // one lane re-deriving every candidate's liveness for every candidate, made a late annealing walk's launch 60 us)
   unsigned long long* const notes = GEN ? a.gen_bits + a.gen_wd : nullptr;
-  for (int dj = db * kBlock + threadIdx.x; dj < a.n_dirty; dj += delta_blocks * kBlock) {
+  for (int dj = db * kBlock + threadIdx.x; dj < a.dstate[kDsDirty]; dj += delta_blocks * kBlock) {
     // Everything a delta pair needs sits at index dj (no chain through the pair's slot): the first record of mate 1
     // carries the two read lengths in its spare word, the first record of mate 2 the two list lengths (paired_upload_delta)
     const int i = a.dirty_slots[dj];
@@ -1275,7 +1278,7 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
   const int wave_global = ovf_block * (kBlock / 64) + wave;
   const int n_waves = ovf_blocks * (kBlock / 64);
   const int n_table = a.n - a.n_main;  // table pairs with more than 4 records on a mate
-  const int n_items = n_table + a.n_spill;  // ... then the delta pairs with long lists
+  const int n_items = n_table + a.dstate[kDsSpill];  // ... then the delta pairs with long lists
   double lsum = 0.0;
   int zeros = 0;
   int4* c1 = cand[wave][0];
@@ -1294,9 +1297,8 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
       const int i = a.spill_slot[sp];
       const uint32_t l12 = i < a.n0 ? a.len_combo[a.len_code[i]] : a.len12[i - a.n0];
       const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-      const int b0 = a.spill_off[0][sp], b1 = a.spill_off[1][sp];
-      const double acc = wave_score_pair(a, ListSrc{a.spill_recs[0] + b0, a.spill_off[0][sp + 1] - b0},
-                                         ListSrc{a.spill_recs[1] + b1, a.spill_off[1][sp + 1] - b1}, L1, L2, c1, c2, lane);
+      const int2 g0 = a.spill_rng[0][sp], g1 = a.spill_rng[1][sp];
+      const double acc = wave_score_pair(a, ListSrc{a.spill_recs[0] + g0.x, g0.y}, ListSrc{a.spill_recs[1] + g1.x, g1.y}, L1, L2, c1, c2, lane);
       if (lane == 0) finish_read(a, i, acc, L1, L2, lsum, zeros);
     }
   }
@@ -1613,7 +1615,7 @@ __device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, cons
 // paired_delta_body with the path sets in the inner loop
 template <bool GEN>
 __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, const MultiSets& ms, int db, int delta_blocks, double* acc_s, int* acc_z, const double* tf) {
-  for (int dj = db * kBlock + threadIdx.x; dj < a.n_dirty; dj += delta_blocks * kBlock) {
+  for (int dj = db * kBlock + threadIdx.x; dj < a.dstate[kDsDirty]; dj += delta_blocks * kBlock) {
     const int i = a.dirty_slots[dj];
     const int sp = a.dirty_spill[dj];
     const bool mine = sp < 0;  // (sp >= 0, a long list: one WAVE scores it. Such a lane stays in the loop: the note words are
@@ -1674,7 +1676,7 @@ __device__ __forceinline__ void paired_overflow_multi_body(const PairedArgs& a, 
   const int wave_global = ovf_block * (kBlock / 64) + wave;
   const int n_waves = ovf_blocks * (kBlock / 64);
   const int n_table = a.n - a.n_main;
-  const int n_items = n_table + a.n_spill;
+  const int n_items = n_table + a.dstate[kDsSpill];
   int4* c1 = cand[wave][0];
   int4* c2 = cand[wave][1];
   for (int item = wave_global; item < n_items; item += n_waves) {  // fixed item -> wave assignment
@@ -1693,9 +1695,9 @@ __device__ __forceinline__ void paired_overflow_multi_body(const PairedArgs& a, 
       i = a.spill_slot[sp];
       const uint32_t l12 = i < a.n0 ? a.len_combo[a.len_code[i]] : a.len12[i - a.n0];
       L1 = l12 & 0xffff; L2 = l12 >> 16;
-      const int b0 = a.spill_off[0][sp], b1 = a.spill_off[1][sp];
-      l1 = ListSrc{a.spill_recs[0] + b0, a.spill_off[0][sp + 1] - b0};
-      l2 = ListSrc{a.spill_recs[1] + b1, a.spill_off[1][sp + 1] - b1};
+      const int2 g0 = a.spill_rng[0][sp], g1 = a.spill_rng[1][sp];
+      l1 = ListSrc{a.spill_recs[0] + g0.x, g0.y};
+      l2 = ListSrc{a.spill_recs[1] + g1.x, g1.y};
     }
     unsigned chg = 0xffu;
     if (ms.chg[0]) chg = table ? (wave_changed(t1, ms.chg[0], lane) | wave_changed(t2, ms.chg[1], lane)) : (wave_changed(l1, ms.chg[0], lane) | wave_changed(l2, ms.chg[1], lane));
@@ -1823,7 +1825,7 @@ __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, in
     }
   }
   // ... and the delta pairs the scoring launch noted (paired_delta_body), one lane per pair, records from the delta lists
-  for (int dj = blockIdx.x * kBlock + threadIdx.x; dj < a.n_dirty; dj += gridDim.x * kBlock) {
+  for (int dj = blockIdx.x * kBlock + threadIdx.x; dj < a.dstate[kDsDirty]; dj += gridDim.x * kBlock) {
     if (!((a.gen_bits[a.gen_wd + (dj >> 6)] >> (dj & 63)) & 1ull)) continue;
 #ifdef GAML_GEN_X
     if (GAML_GEN_X & 4) continue;

@@ -92,6 +92,11 @@ int gaml_hip_debug_radix_sort(gaml_hip_ctx* ctx, uint64_t* keys, uint64_t* vals,
  * record, records in different windows, orientation rule, distance outside the insert-size table, edit count or length
  * code outside the memo}; GAML_HIP_ESTATE on a violation. */
 int gaml_hip_debug_static_check(gaml_hip_ctx* ctx, int readset, int64_t* out8);
+/* The device table build (gaml_amd/csrc/table_build.hip.h: the read-major join the reference does per call through hash maps,
+ * graph.cc:535-598) against the host restatement build_pair_tables on the windows that are active now: a fresh build into
+ * scratch buffers, every array compared entry by entry. out8 = {pairs, compact class, its static part, <= 2 records, <= 4,
+ * more, entries compared, mismatches}; GAML_HIP_ESTATE when they differ. */
+int gaml_hip_debug_tables_check(gaml_hip_ctx* ctx, int readset, int64_t* out8);
 /* per-block partial sums / floored counts of the last blocking evaluation of paired set `readset` (path set `set` of a
  * batch launch, 0 for a single call), in block order; layout8 = {blocks of the compact class's static part, of the
  * compact class, up to the <= 2-record class, up to the <= 4-record class, lane-per-pair blocks, all scoring blocks,
