@@ -151,6 +151,19 @@ int aln_small_enqueue(gaml_hip_ctx* c, const ShortMate& m, AlignDev& d, AlignSma
   return 0;
 }
 
+// the one wait of a small batch whose hits are filed on the device: the sequence word behind the windows' headers
+int aln_small_wait(gaml_hip_ctx* c, AlignSmall& S, AlnJob& job) {
+  volatile unsigned long long* word = (volatile unsigned long long*)S.out_host.p;
+  const double t0 = now_us();
+  bool seen = false;
+  while (!seen && now_us() - t0 < 5000.0) { for (int k = 0; k < 256 && !seen; k++) { seen = *word == job.seq; __builtin_ia32_pause(); } }
+  if (!seen) { HIP_TRY(c, hipStreamSynchronize((hipStream_t)job.stream)); if (*word != job.seq) return fail(c, GAML_HIP_ESTATE, "aligner: the filing kernel finished without its sequence word"); }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  S.seen_us = now_us();
+  job.enqueued = false;
+  return 0;
+}
+
 // the one wait of a small batch: poll the sequence word (bounded), then the runtime's wait. 1: capacities exceeded
 int aln_small_collect(gaml_hip_ctx* c, AlignSmall& S, AlnJob& job, std::vector<AlnHit>& hits, unsigned* n_cands_out) {
   volatile unsigned long long* word = (volatile unsigned long long*)S.out_host.p;
@@ -431,8 +444,24 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   }
   job.seq = ++S.out_seq;
   char* oh = (char*)S.out_host.dev;
+  // The hits are filed on the device (aligner_file.hip.h): ordered, de-duplicated and appended to the mates' record pools by
+  // one more small dispatch; the host gets the windows' headers back. Not when the batch has more windows than the filing
+  // kernel's argument block names (knob 5 = 6: never -- the host files, A/B and tests).
+  const bool file_dev = nw <= kFileMaxWins && KNOB(c, 5) != 6 && !timed;
+  if (file_dev) {
+    for (int mt = 0; mt < 2; mt++) if (int e = pool_reserve(c, ps, mt, ps.dev[mt].pool_n + kFileMaxHits)) return e;
+    if (int e = pool_mirror(c, ps, st)) return e;  // (windows the host filed earlier come first in the pools)
+  }
   hipExtLaunchKernelGGL(extend_pair2_kernel, dim3(512), dim3(128 * kAlnPairs), 0, st, timed ? aev[2] : nullptr, timed ? aev[3] : nullptr, 0, sa, in_args ? 1 : 0, S.cands.as<AlnCandX>(), S.counters.as<unsigned>(), kFastCands, S.wcopy.as<char>(), ix,
-                        (AlnHit*)(oh + 128), (unsigned*)(oh + 64), (volatile unsigned long long*)oh, job.seq, S.hits.as<AlnHit>());
+                        (AlnHit*)(oh + 128), (unsigned*)(oh + 64), (volatile unsigned long long*)oh, job.seq, S.hits.as<AlnHit>(), file_dev ? 1 : 0);
+  if (file_dev) {
+    AlnFileArgs fa;
+    fa.n_win = nw; fa.split = n0;
+    for (int mt = 0; mt < 2; mt++) { fa.pool_base[mt] = (int)ps.dev[mt].pool_n; fa.pool_cap[mt] = (int)std::min<size_t>(ps.dev[mt].pool.cap / sizeof(int4), 0x7fffffff); fa.pool[mt] = ps.dev[mt].pool.as<int4>(); }
+    for (int k = 0; k < nw; k++) fa.wid[k] = k < n0 ? mm[0]->pending[(size_t)k] : mm[1]->pending[(size_t)(k - n0)];
+    hipLaunchKernelGGL(aln_file_small_kernel, dim3(1), dim3(kFileThreads), 0, st, fa, S.hits.as<AlnHit>(), S.counters.as<unsigned>(), kFastCands, (AlnFileOut*)(oh + 128),
+                       (volatile unsigned long long*)oh, job.seq);
+  }
   HIP_TRY(c, hipGetLastError());
   job.enqueued = true;
   const double t1 = now_us();
@@ -450,6 +479,36 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
   }
   std::vector<AlnHit> hits;
   unsigned nc = 0;
+  if (file_dev) {
+    if (int e = aln_small_wait(c, S, job)) return e;
+    const AlnFileOut* fo = (const AlnFileOut*)((const char*)S.out_host.p + 128);
+    if (fo->status != 0) return 1;  // not filed (too many hits for one block, more candidates than the buffers hold): the per-mate route redoes the batch
+    nc = fo->n_cands;
+    int64_t at[2] = {ps.dev[0].pool_n, ps.dev[1].pool_n};
+    for (int k = 0; k < nw; k++) {
+      const int mt = k < n0 ? 0 : 1;
+      Window& w = mm[mt]->wins[(size_t)(mt == 0 ? mm[0]->pending[(size_t)k] : mm[1]->pending[(size_t)(k - n0)])];
+      w.first = -1;  // its records exist in the device pool only
+      w.dfirst = at[mt];
+      w.count = fo->hdr[k][0];
+      w.max_pos = w.count ? fo->hdr[k][1] : INT_MIN;
+      w.global_max_pos = w.max_pos;
+      w.pending = false;
+      at[mt] += w.count;
+    }
+    for (int mt = 0; mt < 2; mt++) {
+      if (at[mt] - ps.dev[mt].pool_n != (int64_t)fo->added[mt]) return fail(c, GAML_HIP_ESTATE, "aligner: the filed records do not add up to the windows' counts");
+      ps.dev[mt].pool_n = at[mt];
+      mm[mt]->pending.clear();
+    }
+    const double t3 = now_us();
+    c->aln_windows += nw;
+    c->aln_candidates += nc;
+    c->aln_us += t3 - t0;
+    c->aln_stage_us[0] += t1 - t0; c->aln_stage_us[1] += t3 - t1;
+    c->aln_batches++;
+    return 0;
+  }
   const int rc = aln_small_collect(c, S, job, hits, &nc);
   if (rc != 0) return rc;  // 1: the candidates did not fit: the per-mate route redoes the batch
   const double t2 = now_us();

@@ -143,7 +143,7 @@ constexpr int kAlnTicketWord = 32;                       // counters[32]: workin
 
 // counters: [1] candidates (span_cands_kernel), [kAlnTicketWord] working blocks done. h_counts / h_hits / h_seq: mapped pinned host memory.
 __global__ __launch_bounds__(128 * kAlnPairs) void extend_pair2_kernel(AlnStrArgs, int str_in_args, const AlnCandX* cands, unsigned* counters, unsigned cap_cands, const char* wstr, AlnMates ix,
-                                                                      AlnHit* h_hits, unsigned* h_counts, volatile unsigned long long* h_seq, unsigned long long seq, AlnHit* d_hits) {
+                                                                      AlnHit* h_hits, unsigned* h_counts, volatile unsigned long long* h_seq, unsigned long long seq, AlnHit* d_hits, int file_on_device = 0) {
   __shared__ AlnWave2Lds lds_all[2 * kAlnPairs];
   __shared__ int sh_res[kAlnPairs][4];
   __shared__ int sh_last;
@@ -244,6 +244,7 @@ __global__ __launch_bounds__(128 * kAlnPairs) void extend_pair2_kernel(AlnStrArg
   // it, by the two clocks side by side -- GAML_ALN_WAIT=6. And with PLAIN stores from every block the host could see the
   // sequence word before some blocks' hits had left their XCD's L2: two processes sharing one GPU lost a few dozen hits of a
   // 3,000-candidate batch once in four runs, tools/dist_diag.py.)
+  if (file_on_device) return;  // aln_file_small_kernel, next on the stream, files the hits and publishes (aligner_file.hip.h)
   const unsigned working = n == 0 ? 1u : min((n + kAlnPairs - 1) / kAlnPairs, gridDim.x);
   if (blockIdx.x >= working) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -26,6 +26,7 @@
 
 #include "aligner.hip.h"
 #include "aligner_small.hip.h"
+#include "aligner_file.hip.h"
 #include "host_model.h"
 #include "kernels.hip.h"
 #include "table_build.hip.h"
@@ -257,7 +258,7 @@ struct PairedSet {
   int dl_seq = 0;                     // sequence number of the last maintenance launch (h_dstate[kDsSeq] == dl_seq: the counts are current)
   int64_t full_rebuilds = 0, delta_updates = 0;
   int quiet_calls = 0;       // evaluations since the last window activation
-  int64_t delta_left_out = 0;         // (statistics: not tracked on the device path)
+  int64_t delta_left_out = 0, delta_left_out_base = 0;  // records of later windows that never reached the delta lists (always overwritten); the device counts them per list generation
   bool compact_requested = false;  // gaml_hip_compact_tables: fold the delta lists into the tables at the next evaluation
   PinBuf h_timeline; int timeline_waves = 0;  // ablation 8 (tools/kernel_timeline.py)
   PinBuf h_part_sum, h_part_zero;     // per-block partials written straight to pinned host memory (blocking calls): [set][block]

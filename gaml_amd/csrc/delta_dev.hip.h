@@ -67,6 +67,9 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
   __shared__ unsigned long long keys[kDlMaxRecs];
   __shared__ int sc[4][kDlThreads / 64];
   __shared__ int tot[4];
+  __shared__ int n_left_out;
+  if (threadIdx.x == 0) n_left_out = 0;
+  __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int N = 64;
   while (N < a.n_total) N <<= 1;
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
       const int4 r = a.pool[mate][a.w[k].first + (p - a.w[k].start)];
       const bool drop = a.w[k].dom_count > 0 && tb_holds(a.pool[mate], a.w[k].dom_first, a.w[k].dom_count, r.y, r.w);
       if (!drop) key = ((unsigned long long)(unsigned)a.slot_of_read[r.w] << 33) | ((unsigned long long)mate << 32) | (unsigned)p;
+      else atomicAdd(&n_left_out, 1);
     }
     keys[p] = key;
   }
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
     int st[kDsInts];
     st[kDsDirty] = overflow ? nd0 : nd0 + tot[0]; st[kDsSpill] = overflow ? ns0 : ns0 + tot[1];
     st[kDsTop0] = overflow ? top0 : top0 + tot[2]; st[kDsTop1] = overflow ? top1 : top1 + tot[3];
-    st[kDsOverflow] = a.state[kDsOverflow] | (overflow ? 1 : 0); st[kDsSeq] = a.seq; st[6] = 0; st[7] = 0;
+    st[kDsOverflow] = a.state[kDsOverflow] | (overflow ? 1 : 0); st[kDsSeq] = a.seq; st[6] = a.state[6] + n_left_out; st[7] = 0;
     for (int k = 0; k < kDsInts; k++) a.state[k] = st[k];
     if (a.host_state) {
       for (int k = 0; k < kDsInts; k++) if (k != kDsSeq) __hip_atomic_store(&a.host_state[k], st[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -146,6 +146,7 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
   bool spun = false;
   if (int e = wait_host_partials(c, &spun)) return e;
   if (!spun) { if (int e2 = collect_events(c)) return e2; }
+  for (auto& ps : c->paireds) paired_refresh_counts(*ps);
   // the device is done with the resident copies: they follow the images (now the last set's)
   for (size_t i = 0; i < nps; i++) {
     PairedSet& ps = *c->paireds[i];
@@ -232,6 +233,7 @@ static int batch_chunk_fast(gaml_hip_ctx* c, int n, const int32_t* paths, const 
   bool spun = false;
   if (int e = wait_host_partials(c, &spun)) return e;
   if (!spun) { if (int e2 = collect_events(c)) return e2; }
+  for (auto& ps : c->paireds) paired_refresh_counts(*ps);
   for (size_t i = 0; i < nps; i++) c->paireds[i]->batches_full++;
   for (int k = 0; k < n; k++)
     for (size_t i = 0; i < nps; i++) {

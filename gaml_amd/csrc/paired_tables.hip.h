@@ -185,6 +185,22 @@ void dominating_window(const ShortMate& m, const Window& w, bool fold, int* dom_
   *dom_first = (int)sw.dfirst; *dom_count = sw.count;
 }
 
+// one set of table buffers for n pairs and A[mate] active records (grow-only)
+int paired_reserve_tabledev(gaml_hip_ctx* c, TableDev& T, int64_t n, const int64_t* A) {
+  HIP_TRY(c, T.cnt.reserve(kTbInts * sizeof(int)));
+  for (int mt = 0; mt < 2; mt++) {
+    HIP_TRY(c, T.rec8[mt].reserve((size_t)n * sizeof(unsigned long long)));
+    HIP_TRY(c, T.first[mt].reserve((size_t)n * sizeof(int4)));
+    HIP_TRY(c, T.extra[mt].reserve(std::max<size_t>(1, (size_t)A[mt]) * sizeof(int4)));
+    HIP_TRY(c, T.inl[mt].reserve(std::max<size_t>(1, (size_t)std::min<int64_t>(4 * n, 3 * (A[0] + A[1]) + 4)) * sizeof(int4)));
+  }
+  HIP_TRY(c, T.len_code.reserve(std::max<size_t>(1, (size_t)n))); HIP_TRY(c, T.len12.reserve((size_t)n * sizeof(unsigned)));
+  HIP_TRY(c, T.static_idx.reserve((size_t)n * sizeof(int))); HIP_TRY(c, T.static_val.reserve((size_t)n * sizeof(double2)));
+  HIP_TRY(c, T.slot_of_read.reserve((size_t)n * sizeof(int))); HIP_TRY(c, T.read_of_slot.reserve((size_t)n * sizeof(unsigned)));
+  HIP_TRY(c, T.dirty_of_slot.reserve((size_t)n * sizeof(int)));
+  return 0;
+}
+
 // ---- table build ---------------------------------------------------------------------------------------------------
 // Enqueues one build of the record tables into T on `st`: the ACTIVE windows of both mates as they are now. The host's part
 // is the list of those windows (a few thousand headers) and the link between the two mates' windows.
@@ -244,15 +260,11 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
     HIP_TRY(c, B.rstart[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.rend[mt].reserve((size_t)n * sizeof(int)));
     HIP_TRY(c, B.one[mt].reserve((size_t)n * sizeof(unsigned long long)));
     HIP_TRY(c, B.more[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.start[mt].reserve((size_t)n * sizeof(int)));
-    HIP_TRY(c, T.rec8[mt].reserve((size_t)n * sizeof(unsigned long long)));
-    HIP_TRY(c, T.first[mt].reserve((size_t)n * sizeof(int4)));
-    HIP_TRY(c, T.extra[mt].reserve(std::max<size_t>(1, (size_t)A[mt]) * sizeof(int4)));
-    HIP_TRY(c, T.inl[mt].reserve(std::max<size_t>(1, (size_t)std::min<int64_t>(4 * n, 3 * (A[0] + A[1]) + 4)) * sizeof(int4)));
   }
-  HIP_TRY(c, T.len_code.reserve((size_t)n)); HIP_TRY(c, T.len12.reserve((size_t)n * sizeof(unsigned)));
-  HIP_TRY(c, T.static_idx.reserve((size_t)n * sizeof(int))); HIP_TRY(c, T.static_val.reserve((size_t)n * sizeof(double2)));
-  HIP_TRY(c, T.slot_of_read.reserve((size_t)n * sizeof(int))); HIP_TRY(c, T.read_of_slot.reserve((size_t)n * sizeof(unsigned)));
-  HIP_TRY(c, T.dirty_of_slot.reserve((size_t)n * sizeof(int)));
+  {  // (room for half as many records again: a later build into these buffers then allocates nothing)
+    const int64_t As[2] = {A[0] + A[0] / 2 + 65536, A[1] + A[1] / 2 + 65536};
+    if (int e = paired_reserve_tabledev(c, T, n, As)) return e;
+  }
   int* cnt = T.cnt.as<int>();
   auto grid = [](int64_t items) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, 4096))); };
   for (int mt = 0; mt < 2; mt++) {
@@ -375,6 +387,7 @@ void paired_refresh_counts(PairedSet& s) {
   std::atomic_thread_fence(std::memory_order_acquire);
   s.nd_est = h[kDsDirty];
   s.ns_est = h[kDsSpill];
+  s.delta_left_out = s.delta_left_out_base + h[6];
   s.spill_may_grow = false;
 }
 bool paired_delta_overflowed(const PairedSet& s) {
@@ -440,6 +453,7 @@ int paired_delta_reset(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   hipLaunchKernelGGL(delta_reset_kernel, dim3(1), dim3(64), 0, st, s.dstate.as<int>(), (int*)s.h_dstate.dev, seq);
   HIP_TRY(c, hipGetLastError());
   s.nd_est = 0; s.ns_est = 0; s.spill_may_grow = false;
+  s.delta_left_out_base = s.delta_left_out;  // (the device counter starts again at zero)
   return 0;
 }
 
@@ -463,6 +477,22 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   paired_adopt_tables(s);
   if (int e = paired_delta_reset(c, s, st)) return e;
   for (int mt = 0; mt < 2; mt++) s.dev[mt].uploaded_generation = s.mate[mt].active_generation;
+  // Everything a later call would otherwise allocate (device allocations cost 0.1-3 ms each; an annealing run must not meet
+  // them in the call that happens to activate a window or to start a rebuild): the spare set of table buffers with room
+  // for half as many records again, the build's stream and events, the delta store (paired_delta_reset above)
+  if (!rb.tab.rec8[0].p && KNOB(c, 14) != 1) {
+    const int64_t A2[2] = {s.mate[0].active_records + s.mate[0].active_records / 2 + 65536, s.mate[1].active_records + s.mate[1].active_records / 2 + 65536};
+    const int64_t n = s.mate[0].n_local();
+    if (int e = paired_reserve_tabledev(c, rb.tab, n, A2)) return e;
+    BuildScratch& B = s.scratch;
+    const size_t maxA = (size_t)std::max<int64_t>(std::max(A2[0], A2[1]), n);
+    HIP_TRY(c, B.k_in.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_out.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_tmp.reserve(maxA * sizeof(rs_u64)));
+    HIP_TRY(c, B.v_in.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.v_tmp.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.hist.reserve(rs_hist_bytes(maxA)));
+    for (int mt = 0; mt < 2; mt++) HIP_TRY(c, B.v_sorted[mt].reserve((size_t)A2[mt] * sizeof(unsigned)));
+    if (!rb.stream) HIP_TRY(c, hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
+    if (!rb.done) HIP_TRY(c, hipEventCreateWithFlags(&rb.done, hipEventDisableTiming));
+    if (!rb.mark) HIP_TRY(c, hipEventCreateWithFlags(&rb.mark, hipEventDisableTiming));
+  }
   if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "rebuild on the calling stream: %.2f ms\n", (now_us() - tb0) * 1e-3);
   return 0;
 }
