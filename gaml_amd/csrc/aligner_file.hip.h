@@ -30,6 +30,7 @@ __global__ __launch_bounds__(kFileThreads) void aln_file_small_kernel(AlnFileArg
   __shared__ int sc[kFileThreads / 64];
   __shared__ int n_mate0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = (int)blockDim.x;  // (as many threads as the batch is likely to need: the network's barriers cost by the wave)
   const unsigned n_cands = counters[1];
   const bool fits = n_cands <= cap_cands && n_cands <= (unsigned)kFileMaxHits;
   const int n = fits ? (int)n_cands : 0;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(kFileThreads) void aln_file_small_kernel(AlnFileArg
   if (tid == 0) n_mate0 = 0;
   int N = 64;
   while (N < n) N <<= 1;
-  for (int i = tid; i < N; i += kFileThreads) {
+  for (int i = tid; i < N; i += nthr) {
     unsigned long long hi = ~0ull, lo = ~0ull;
     if (i < n) {
       const AlnHit h = d_hits[i];
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(kFileThreads) void aln_file_small_kernel(AlnFileArg
   __syncthreads();
   for (int k = 2; k <= N; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (N >> 1); t += kFileThreads) {
+      for (int t = tid; t < (N >> 1); t += nthr) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
         const unsigned long long xh = khi[i], xl = klo[i], yh = khi[l], yl = klo[l];
         const bool gt = xh != yh ? xh > yh : xl > yl;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kFileThreads) void aln_file_small_kernel(AlnFileArg
     }
   }
   // survivors: the first of every (window, position, read); thread t owns the sorted positions [t * per, (t + 1) * per)
-  const int per = N > kFileThreads ? N / kFileThreads : 1;
+  const int per = (N + nthr - 1) / nthr;
   const int p_lo = tid * per, p_hi = min(N, p_lo + per);
   auto survives = [&](int p) { return khi[p] != ~0ull && (p == 0 || khi[p - 1] != khi[p] || (klo[p - 1] >> 32) != (klo[p] >> 32)); };
   int mine = 0, mine0 = 0;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(kFileThreads) void aln_file_small_kernel(AlnFileArg
   if (mine0) atomicAdd(&n_mate0, mine0);
   __syncthreads();
   int before = incl - mine, total = 0;
-  for (int w = 0; w < kFileThreads / 64; w++) { if (w < wave) before += sc[w]; total += sc[w]; }
+  for (int w = 0; w < (nthr >> 6); w++) { if (w < wave) before += sc[w]; total += sc[w]; }
   const int add0 = n_mate0, add1 = total - n_mate0;
   const bool room = a.pool_base[0] + add0 <= a.pool_cap[0] && a.pool_base[1] + add1 <= a.pool_cap[1];
   const bool filed = fits && room && a.n_win <= kFileMaxWins;

@@ -459,7 +459,7 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
     fa.n_win = nw; fa.split = n0;
     for (int mt = 0; mt < 2; mt++) { fa.pool_base[mt] = (int)ps.dev[mt].pool_n; fa.pool_cap[mt] = (int)std::min<size_t>(ps.dev[mt].pool.cap / sizeof(int4), 0x7fffffff); fa.pool[mt] = ps.dev[mt].pool.as<int4>(); }
     for (int k = 0; k < nw; k++) fa.wid[k] = k < n0 ? mm[0]->pending[(size_t)k] : mm[1]->pending[(size_t)(k - n0)];
-    hipLaunchKernelGGL(aln_file_small_kernel, dim3(1), dim3(kFileThreads), 0, st, fa, S.hits.as<AlnHit>(), S.counters.as<unsigned>(), kFastCands, (AlnFileOut*)(oh + 128),
+    hipLaunchKernelGGL(aln_file_small_kernel, dim3(1), dim3(256), 0, st, fa, S.hits.as<AlnHit>(), S.counters.as<unsigned>(), kFastCands, (AlnFileOut*)(oh + 128),
                        (volatile unsigned long long*)oh, job.seq);
   }
   HIP_TRY(c, hipGetLastError());

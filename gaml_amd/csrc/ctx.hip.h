@@ -216,8 +216,13 @@ struct BuildScratch {
 // tables take over a FIXED number of evaluations later (equal inputs must give equal outputs run to run, and a rebuild
 // changes the order of the final sum). What was activated in between is applied to the new tables' (empty) delta lists by
 // the same kernel that maintains the live ones.
+// what the slices of one build share (paired_build_enqueue)
+struct BuildPlan { int64_t A[2] = {0, 0}; int n_act[2] = {0, 0}; unsigned tiles = 0, none1 = 0, none2 = 0; int ins_n = 0; bool empty = true; };
+
 struct TableRebuild {
   bool active = false;
+  bool retired = false;        // a rebuild beside the evaluations was decided and the unused windows have left: the next evaluation starts the build
+  int next_slice = 0;          // slices of the build's launch chain enqueued so far
   int64_t start_eval = 0;      // the set's evaluation count when the rebuild was decided
   TableDev tab;                // the spare set of buffers: being built, or idle
   hipStream_t stream = nullptr;
@@ -241,6 +246,7 @@ struct PairedSet {
   TableDev tab;                       // the live record tables
   TableRebuild rebuild;
   BuildScratch scratch;
+  BuildPlan build_plan;
   int64_t async_rebuilds = 0, retired_windows = 0, eval_count = 0;
   // per set, fixed: length-combination code per pair, the per-combination tables, the memo of pair terms
   DevBuf lcode, len_combo_dev, combo_tabs, memo;
@@ -251,6 +257,7 @@ struct PairedSet {
   // delta_apply_kernel, read by the scoring launch. The host knows upper bounds (and the exact counts once a blocking call
   // has returned: h_dstate, written by the kernels).
   DevBuf dl_slot, dl_spill, dl_rec[2], sp_rng[2], sp_rec[2], sp_slot, dstate;
+  DevBuf dl_bins, dl_bin_count, dl_blk_tot, dl_wlist;   // multi-block maintenance launches (delta_dev.hip.h)
   PinBuf h_dstate;
   size_t delta_cap = 0, cap_spill = 0, cap_sprec = 0;
   int64_t nd_est = 0, ns_est = 0;     // delta pairs (upper bound) / long lists (last exact count) as the host knows them

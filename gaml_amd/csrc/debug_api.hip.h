@@ -264,7 +264,7 @@ int gaml_hip_debug_tables_check(gaml_hip_ctx* c, int rs, int64_t* out8) {
   if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "host-only context");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
   HIP_TRY(c, hipSetDevice(c->device));
-  if (s.rebuild.active) { HIP_TRY(c, hipEventSynchronize(s.rebuild.done)); s.rebuild.active = false; s.rebuild.after.clear(); }
+  if (s.rebuild.active) { if (int e = paired_build_continue(c, s, true)) return e; HIP_TRY(c, hipEventSynchronize(s.rebuild.done)); s.rebuild.active = false; s.rebuild.after.clear(); }
   if (int e = prepare_paired_tables(c, s)) return e;
   if (int e = pool_mirror(c, s, c->stream)) return e;
   if (int e = paired_upload_statics(c, s, c->stream)) return e;

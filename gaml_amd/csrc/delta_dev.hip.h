@@ -23,7 +23,8 @@
 
 namespace gaml {
 
-constexpr int kDlThreads = 1024, kDlMaxRecs = 8192, kDlMaxWins = 32;
+constexpr int kDlThreads = 1024, kDlMaxRecs = 8192, kDlMaxWins = 64;
+constexpr int kDlBins = 32, kDlBinCap = kDlThreads * 8, kDlMbMaxRecs = 49152;  // multi-block launches: bins of keys by a hash of the pair's slot
 // (the store's device counters, kDs*: kernels.hip.h)
 
 struct DlWin { int mate, wid, first, count, dom_first, dom_count, start; };
@@ -51,8 +52,26 @@ struct DlArgs {
   int* state;       // kDs*
   int* host_state;  // the same words in pinned host memory, written at the end of every launch
   int cap_pairs, cap_spill, cap_sprec, seq;
+  // multi-block launches (delta_mb_*): the bins, how many keys each holds, per block what it hands out + the counters' values before the launch
+  unsigned long long* bins;
+  int* bin_count;
+  int* blk_tot;     // [kDlBins][4], then [4] base values, then [1] records left out, [1] a bin overflowed
+  const DlWin* wlist;  // multi-block launches of more windows than w[] holds: the list in device memory (else null)
   DlWin w[kDlMaxWins];
 };
+
+// the window that holds position p of the launch's record sequence: from the argument block's copy in LDS, or -- launches
+// of many windows -- by bisection of the list in device memory
+__device__ __forceinline__ DlWin dl_window_of(const DlArgs& a, const DlWin* sw, int p) {
+  if (a.wlist) {
+    int lo = 0, hi = a.n_wins - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.wlist[mid].start <= p) lo = mid; else hi = mid - 1; }
+    return a.wlist[lo];
+  }
+  int k = 0;
+  while (k + 1 < a.n_wins && sw[k + 1].start <= p) k++;
+  return sw[k];
+}
 
 // where a pair's present list of one mate comes from
 struct DlOld { int kind, n; const int4* p; int4 first; };  // kind 0: p[k] (delta store / spill area); 1: tables (first + extra)
@@ -63,35 +82,100 @@ __device__ __forceinline__ int4 dl_old_get(const DlOld& o, int k) {
 }
 __device__ __forceinline__ bool dl_before_eq(const int4& x, const int4& y) { return x.x != y.x ? x.x < y.x : x.y <= y.y; }  // x goes first (an old record before an equal new one: upper_bound)
 
+// PER: sorted positions per thread (kDlThreads * PER >= the launch's records, rounded up to a power of two). A thread's
+// PER items go through every stage side by side (their loads in flight together): one lane working off eight chains of
+// dependent loads one after the other was the kernel's duration.
+// MODE 0: one block does everything. MODE 1 / 2: a block per bin of a multi-block launch (keys by delta_mb_keys_kernel) --
+// 1 only counts what the block will hand out (new pairs, spill entries, spill records), 2 writes, its numbers starting
+// behind those of the blocks before it.
+template <int PER, int MODE = 0>
 __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
-  __shared__ unsigned long long keys[kDlMaxRecs];
+  __shared__ unsigned long long keys[kDlThreads * PER];
+  constexpr bool kCache = PER <= 4 && MODE == 0;  // the launch's records stay in LDS between the key stage and the merge
+  __shared__ int4 rec_lds[kCache ? kDlThreads * PER : 1];
   __shared__ int sc[4][kDlThreads / 64];
   __shared__ int tot[4];
   __shared__ int n_left_out;
+  __shared__ DlWin sw[kDlMaxWins];  // (indexed by a lane's own window number: from LDS, not from a scratch copy of the argument block)
   if (threadIdx.x == 0) n_left_out = 0;
+  if (threadIdx.x < kDlMaxWins) sw[threadIdx.x] = a.w[(int)threadIdx.x < a.n_wins && !a.wlist ? threadIdx.x : 0];
   __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = (int)blockDim.x, nwav = nthr >> 6;  // (PER == 1: as many threads as the records' power of two, 64 .. 1,024)
+  const int n_here = MODE == 0 ? a.n_total : min(a.bin_count[blockIdx.x], kDlBinCap);
+  const bool mb_bad = MODE != 0 && (a.blk_tot[4 * kDlBins + 5] != 0);  // a bin overflowed: the launch changes nothing
   int N = 64;
-  while (N < a.n_total) N <<= 1;
-  // ---- 1. keys
-  for (int p = tid; p < N; p += kDlThreads) {
-    unsigned long long key = ~0ull;
-    if (p < a.n_total) {
+  while (N < n_here) N <<= 1;
+  if (MODE != 0) {
+    for (int p = tid; p < N; p += nthr) keys[p] = p < n_here ? a.bins[(size_t)blockIdx.x * kDlBinCap + p] : ~0ull;
+  } else
+  // ---- 1. keys: record j of this thread is position tid + j * kDlThreads of the launch's record sequence
+  {
+    int4 r[PER];
+    int kw[PER], lo[PER], hi[PER];
+    bool live[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int p = tid + j * nthr;
+      live[j] = p < a.n_total;
       int k = 0;
-      while (k + 1 < a.n_wins && a.w[k + 1].start <= p) k++;
-      const int mate = a.w[k].mate;
-      const int4 r = a.pool[mate][a.w[k].first + (p - a.w[k].start)];
-      const bool drop = a.w[k].dom_count > 0 && tb_holds(a.pool[mate], a.w[k].dom_first, a.w[k].dom_count, r.y, r.w);
-      if (!drop) key = ((unsigned long long)(unsigned)a.slot_of_read[r.w] << 33) | ((unsigned long long)mate << 32) | (unsigned)p;
-      else atomicAdd(&n_left_out, 1);
+      if (live[j]) while (k + 1 < a.n_wins && sw[k + 1].start <= p) k++;
+      kw[j] = k;
+      r[j] = live[j] ? a.pool[sw[k].mate][sw[k].first + (p - sw[k].start)] : make_int4(0, 0, 0, 0);
+      lo[j] = 0; hi[j] = live[j] ? sw[k].dom_count : 0;
     }
-    keys[p] = key;
+    // is the record among the dominating window's (ordered by (position, read))? Lower bound, sixteen-way: a round asks for
+    // fifteen pivots at once (a binary search through a long node's 2,800 records was eleven dependent trips: most of this
+    // kernel's duration for an annealing move's junction windows), the PER searches in step
+    bool more = true;
+    while (more) {
+      more = false;
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        if (lo[j] >= hi[j]) continue;
+        const int4* base = a.pool[sw[kw[j]].mate] + sw[kw[j]].dom_first;
+        const int span = hi[j] - lo[j];
+        int4 pv[15];
+#pragma unroll
+        for (int q = 0; q < 15; q++) pv[q] = base[lo[j] + (int)(((long long)span * (q + 1)) >> 4)];  // (pivot q: < hi, distinct positions may repeat when span < 16)
+        int nlo = lo[j], nhi = hi[j];
+#pragma unroll
+        for (int q = 0; q < 15; q++) {
+          const int at = lo[j] + (int)(((long long)span * (q + 1)) >> 4);
+          if (tb_rec_before(pv[q], r[j].y, r[j].w)) nlo = max(nlo, at + 1); else nhi = min(nhi, at);
+        }
+        lo[j] = nlo; hi[j] = nhi;
+        more = more || lo[j] < hi[j];
+      }
+    }
+    int4 at[PER];
+    int slot[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const bool in = live[j] && lo[j] < sw[kw[j]].dom_count;
+      at[j] = in ? a.pool[sw[kw[j]].mate][sw[kw[j]].dom_first + lo[j]] : make_int4(0, -1, 0, -1);
+      slot[j] = live[j] ? a.slot_of_read[r[j].w] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int p = tid + j * nthr;
+      if (p >= N) continue;
+      if (kCache) rec_lds[p] = r[j];
+      unsigned long long key = ~0ull;
+      if (live[j]) {
+        const bool drop = sw[kw[j]].dom_count > 0 && lo[j] < sw[kw[j]].dom_count && at[j].y == r[j].y && at[j].w == r[j].w;
+        if (!drop) key = ((unsigned long long)(unsigned)slot[j] << 33) | ((unsigned long long)sw[kw[j]].mate << 32) | (unsigned)p;
+        else atomicAdd(&n_left_out, 1);
+      }
+      keys[p] = key;
+    }
   }
   __syncthreads();
-  // ---- 2. bitonic sort, ascending
+  // ---- 2. bitonic sort, ascending (a launch of few records runs with as many threads as records: a barrier over sixteen
+  // waves per step of the network, 36-55 steps, was most of a small launch's duration)
   for (int k = 2; k <= N; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (N >> 1); t += kDlThreads) {
+      for (int t = tid; t < (N >> 1); t += nthr) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
         const unsigned long long x = keys[i], y = keys[l];
         const bool up = (i & k) == 0;
@@ -101,41 +185,59 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
     }
   }
   // ---- 3. per touched pair. Thread t owns the sorted positions [t * per, (t + 1) * per): numbers are handed out in that order.
-  const int per = N > kDlThreads ? N / kDlThreads : 1;
-  const int p_lo = tid * per, p_hi = min(N, p_lo + per);
-  const int nd0 = a.state[kDsDirty], ns0 = a.state[kDsSpill], top0 = a.state[kDsTop0], top1 = a.state[kDsTop1];
-  // what a head finds: counts of the present lists, and what the new ones will be
-  auto head_info = [&](int p, int& slot, int& dj, int& sp_old, int& c0, int& c1, int& add0, int& add1, int& q_end) {
-    slot = (int)(keys[p] >> 33);
-    add0 = add1 = 0;
-    int q = p;
-    while (q < N && keys[q] != ~0ull && (int)(keys[q] >> 33) == slot) { if ((keys[q] >> 32) & 1ull) add1++; else add0++; q++; }
-    q_end = q;
-    dj = a.dirty_of_slot[slot];
-    sp_old = -1;
-    if (dj >= 0) {
-      sp_old = a.dl_spill[dj];
-      if (sp_old >= 0) { c0 = a.sp_rng[0][sp_old].y; c1 = a.sp_rng[1][sp_old].y; }
-      else { const int cc = a.dl_rec[1][4 * (size_t)dj].w; c0 = cc & 0xff; c1 = (cc >> 8) & 0xff; }
-    } else if (slot < a.n0) {
-      c0 = a.rec8[0][slot] != ~0ull ? 1 : 0;
-      c1 = a.rec8[1][slot] != ~0ull ? 1 : 0;
-    } else {
-      const int4 f0 = a.first[0][slot - a.n0], f1 = a.first[1][slot - a.n0];
-      c0 = f0.x < 0 ? 0 : 1 + (int)((unsigned)f0.z >> 9);
-      c1 = f1.x < 0 ? 0 : 1 + (int)((unsigned)f1.z >> 9);
+  const int per = N > nthr ? N / nthr : 1;
+  const int p_lo = tid * per;
+  const int* base4 = MODE == 0 ? a.state : a.blk_tot + 4 * kDlBins;  // (multi-block: the counters as the count launch found them)
+  const int nd0 = base4[kDsDirty], ns0 = base4[kDsSpill], top0 = base4[kDsTop0], top1 = base4[kDsTop1];
+  // what a head finds: where its pair's present lists are and how long, how many records join them
+  bool head[PER];
+  int slot[PER], dj[PER], sp_old[PER], c0[PER], c1[PER], add0[PER], add1[PER], q_end[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int p = p_lo + j;
+    head[j] = j < per && p < N && keys[p] != ~0ull && (p == 0 || (keys[p - 1] >> 33) != (keys[p] >> 33));
+    slot[j] = 0; add0[j] = add1[j] = 0; q_end[j] = p; dj[j] = -1; sp_old[j] = -1; c0[j] = c1[j] = 0;
+    if (head[j]) {
+      slot[j] = (int)(keys[p] >> 33);
+      int q = p;
+      while (q < N && keys[q] != ~0ull && (int)(keys[q] >> 33) == slot[j]) { if ((keys[q] >> 32) & 1ull) add1[j]++; else add0[j]++; q++; }
+      q_end[j] = q;
     }
-  };
+  }
+#pragma unroll
+  for (int j = 0; j < PER; j++) if (head[j]) dj[j] = a.dirty_of_slot[slot[j]];
+  {
+    int v0[PER], v1[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      v0[j] = v1[j] = 0;
+      if (!head[j]) continue;
+      if (dj[j] >= 0) { v0[j] = a.dl_spill[dj[j]]; v1[j] = a.dl_rec[1][4 * (size_t)dj[j]].w; }
+      else if (slot[j] < a.n0) { v0[j] = a.rec8[0][slot[j]] != ~0ull ? 1 : 0; v1[j] = a.rec8[1][slot[j]] != ~0ull ? 1 : 0; }
+      else {
+        const int4 f0 = a.first[0][slot[j] - a.n0], f1 = a.first[1][slot[j] - a.n0];
+        v0[j] = f0.x < 0 ? 0 : 1 + (int)((unsigned)f0.z >> 9);
+        v1[j] = f1.x < 0 ? 0 : 1 + (int)((unsigned)f1.z >> 9);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      if (!head[j]) continue;
+      if (dj[j] >= 0) {
+        sp_old[j] = v0[j];
+        if (sp_old[j] >= 0) { c0[j] = a.sp_rng[0][sp_old[j]].y; c1[j] = a.sp_rng[1][sp_old[j]].y; }
+        else { c0[j] = v1[j] & 0xff; c1[j] = (v1[j] >> 8) & 0xff; }
+      } else { c0[j] = v0[j]; c1[j] = v1[j]; }
+    }
+  }
   int my[4] = {0, 0, 0, 0};  // new pairs, new spill entries, spill records of mate 0 / 1
-  for (int p = p_lo; p < p_hi; p++) {
-    if (keys[p] == ~0ull) break;
-    if (p > 0 && (keys[p - 1] >> 33) == (keys[p] >> 33)) continue;
-    int slot, dj, sp_old, c0, c1, add0, add1, q_end;
-    head_info(p, slot, dj, sp_old, c0, c1, add0, add1, q_end);
-    const bool lng = c0 + add0 > 4 || c1 + add1 > 4;
-    my[0] += dj < 0;
-    my[1] += lng && sp_old < 0;
-    if (lng) { my[2] += c0 + add0; my[3] += c1 + add1; }
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    if (!head[j]) continue;
+    const bool lng = c0[j] + add0[j] > 4 || c1[j] + add1[j] > 4;
+    my[0] += dj[j] < 0;
+    my[1] += lng && sp_old[j] < 0;
+    if (lng) { my[2] += c0[j] + add0[j]; my[3] += c1[j] + add1[j]; }
   }
   int excl[4];
   for (int v = 0; v < 4; v++) {
@@ -145,54 +247,72 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
     excl[v] = incl - my[v];
   }
   __syncthreads();
-  if (tid < 4) { int s = 0; for (int w = 0; w < kDlThreads / 64; w++) { const int t = sc[tid][w]; sc[tid][w] = s; s += t; } tot[tid] = s; }
+  if (tid < 4) { int s = 0; for (int w = 0; w < nwav; w++) { const int t = sc[tid][w]; sc[tid][w] = s; s += t; } tot[tid] = s; }
   __syncthreads();
   for (int v = 0; v < 4; v++) excl[v] += sc[v][wave];
-  const bool overflow = nd0 + tot[0] > a.cap_pairs || ns0 + tot[1] > a.cap_spill || top0 + tot[2] > a.cap_sprec || top1 + tot[3] > a.cap_sprec;
+  if (MODE == 1) {  // what this block will hand out; block 0 also notes the counters' present values for the apply launch
+    if (tid < 4) { a.blk_tot[4 * blockIdx.x + tid] = tot[tid]; if (blockIdx.x == 0) a.blk_tot[4 * kDlBins + tid] = a.state[tid]; }
+    return;
+  }
+  int all4[4] = {tot[0], tot[1], tot[2], tot[3]};
+  if (MODE == 2) {
+    __shared__ int before_sh[4], all_sh[4];
+    if (tid < 4) { int bf = 0, al = 0; for (int b = 0; b < kDlBins; b++) { const int t = a.blk_tot[4 * b + tid]; al += t; if (b < (int)blockIdx.x) bf += t; } before_sh[tid] = bf; all_sh[tid] = al; }
+    __syncthreads();
+    for (int v = 0; v < 4; v++) { excl[v] += before_sh[v]; all4[v] = all_sh[v]; }
+  }
+  const bool overflow = mb_bad || nd0 + all4[0] > a.cap_pairs || ns0 + all4[1] > a.cap_spill || top0 + all4[2] > a.cap_sprec || top1 + all4[3] > a.cap_sprec;
   if (!overflow) {
     int at[4] = {nd0 + excl[0], ns0 + excl[1], top0 + excl[2], top1 + excl[3]};
-    for (int p = p_lo; p < p_hi; p++) {
-      if (keys[p] == ~0ull) break;
-      if (p > 0 && (keys[p - 1] >> 33) == (keys[p] >> 33)) continue;
-      int slot, dj, sp_old, c0, c1, add0, add1, q_end;
-      head_info(p, slot, dj, sp_old, c0, c1, add0, add1, q_end);
-      const int cnt_old[2] = {c0, c1}, cnt_add[2] = {add0, add1};
-      const bool lng = c0 + add0 > 4 || c1 + add1 > 4;
-      const bool fresh = dj < 0;
-      if (fresh) dj = at[0]++;
-      int sp = sp_old;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      if (!head[j]) continue;
+      const int p = p_lo + j;
+      const int cnt_old[2] = {c0[j], c1[j]}, cnt_add[2] = {add0[j], add1[j]};
+      const bool lng = c0[j] + add0[j] > 4 || c1[j] + add1[j] > 4;
+      const bool fresh = dj[j] < 0;
+      const int sl = slot[j];
+      int d = dj[j];
+      if (fresh) d = at[0]++;
+      int sp = sp_old[j];
       if (lng && sp < 0) sp = at[1]++;
-      const unsigned l12 = slot < a.n0 ? a.len_combo[a.len_code[slot]] : a.len12[slot - a.n0];
+      const unsigned l12 = sl < a.n0 ? a.len_combo[a.len_code[sl]] : a.len12[sl - a.n0];
+      // the present lists, requested together: up to four records per mate at the fixed stride / one compact record
+      int4 reg[2][4];
+      if (!fresh && sp_old[j] < 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { reg[0][k] = a.dl_rec[0][4 * (size_t)d + k]; reg[1][k] = a.dl_rec[1][4 * (size_t)d + k]; }
+      } else if (fresh && sl < a.n0) {
+        const unsigned long long r0 = a.rec8[0][sl], r1 = a.rec8[1][sl];
+        reg[0][0] = make_int4((int)(r0 & 0xffffff), (int)((r0 >> 24) & 0xfffffff), (int)((r0 >> 52) & 63) | ((int)((r0 >> 58) & 1) << 8), 0);
+        reg[1][0] = make_int4((int)(r1 & 0xffffff), (int)((r1 >> 24) & 0xfffffff), (int)((r1 >> 52) & 63) | ((int)((r1 >> 58) & 1) << 8), 0);
+      }
       int q = p;  // the pair's new records: mate 0's, then mate 1's, each in (window id, position) order
       for (int mt = 0; mt < 2; mt++) {
         DlOld o;
         o.n = cnt_old[mt];
-        int4 reg[4];
-        if (!fresh && sp_old < 0) {  // at the fixed stride: into registers first (the output may land on the same words)
-          for (int k = 0; k < 4; k++) reg[k] = a.dl_rec[mt][4 * (size_t)dj + k];
-          o.kind = 2;
-        } else if (!fresh) { o.kind = 0; o.p = a.sp_rec[mt] + a.sp_rng[mt][sp_old].x; }
-        else if (slot < a.n0) {
-          const unsigned long long r = a.rec8[mt][slot];
-          reg[0] = make_int4((int)(r & 0xffffff), (int)((r >> 24) & 0xfffffff), (int)((r >> 52) & 63) | ((int)((r >> 58) & 1) << 8), 0);
-          o.kind = 2;
-        } else { o.kind = 1; o.first = a.first[mt][slot - a.n0]; o.p = a.extra[mt]; }
+        o.kind = 2;
+        if (!fresh && sp_old[j] >= 0) { o.kind = 0; o.p = a.sp_rec[mt] + a.sp_rng[mt][sp_old[j]].x; }
+        else if (fresh && sl >= a.n0) { o.kind = 1; o.first = a.first[mt][sl - a.n0]; o.p = a.extra[mt]; }
         auto old_get = [&](int k) -> int4 {
-          if (o.kind == 2) { int4 r = k == 0 ? reg[0] : k == 1 ? reg[1] : k == 2 ? reg[2] : reg[3]; r.z &= 0x1ff; r.w = 0; return r; }
+          if (o.kind == 2) { int4 r = k == 0 ? reg[mt][0] : k == 1 ? reg[mt][1] : k == 2 ? reg[mt][2] : reg[mt][3]; r.z &= 0x1ff; r.w = 0; return r; }
           return dl_old_get(o, k);
         };
         const int n_new = cnt_old[mt] + cnt_add[mt];
-        int4* out = lng ? a.sp_rec[mt] + at[2 + mt] : a.dl_rec[mt] + 4 * (size_t)dj;
+        int4* out = lng ? a.sp_rec[mt] + at[2 + mt] : a.dl_rec[mt] + 4 * (size_t)d;
         int io = 0, w = 0;
         int4 nr = make_int4(0, 0, 0, 0);
         bool have_new = false;
         auto next_new = [&]() {
           have_new = false;
-          if (q < q_end && (int)((keys[q] >> 32) & 1ull) == mt) {
+          if (q < q_end[j] && (int)((keys[q] >> 32) & 1ull) == mt) {
             const int pp = (int)(unsigned)keys[q];
-            int k = 0;
-            while (k + 1 < a.n_wins && a.w[k + 1].start <= pp) k++;
-            const int4 r = a.pool[mt][a.w[k].first + (pp - a.w[k].start)];
+            int4 r;
+            if (kCache) r = rec_lds[pp];
+            else {
+              const DlWin wn = dl_window_of(a, sw, pp);
+              r = a.pool[mt][wn.first + (pp - wn.start)];
+            }
             nr = make_int4(r.x, r.y, r.z & 0x1ff, 0);
             have_new = true;
             q++;
@@ -214,33 +334,35 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
         if (lng) {
           a.sp_rng[mt][sp] = make_int2(at[2 + mt], n_new);
           at[2 + mt] += n_new;
-          for (int k = 0; k < 4; k++) a.dl_rec[mt][4 * (size_t)dj + k] = make_int4(-1, 0, 0, k == 0 ? (mt == 0 ? (int)l12 : 0) : 0);
+          for (int k = 0; k < 4; k++) a.dl_rec[mt][4 * (size_t)d + k] = make_int4(-1, 0, 0, k == 0 ? (mt == 0 ? (int)l12 : 0) : 0);
         } else {
           for (int k = n_new; k < 4; k++) if (k > 0) out[k] = make_int4(-1, 0, 0, 0);
-          head0.w = mt == 0 ? (int)l12 : ((c0 + add0) | ((c1 + add1) << 8));
+          head0.w = mt == 0 ? (int)l12 : ((c0[j] + add0[j]) | ((c1[j] + add1[j]) << 8));
           out[0] = head0;
         }
       }
-      a.dl_slot[dj] = slot;
-      a.dl_spill[dj] = lng ? sp : -1;
-      if (lng) a.sp_slot[sp] = slot;
+      a.dl_slot[d] = sl;
+      a.dl_spill[d] = lng ? sp : -1;
+      if (lng) a.sp_slot[sp] = sl;
       if (fresh) {
-        a.dirty_of_slot[slot] = dj;
+        a.dirty_of_slot[sl] = d;
         // the tables' "this pair lives on the delta lists now" marks (kDirty8 / kDirtyWid)
-        if (slot < a.n0) a.rec8[0][slot] = ~0ull - 1;
+        if (sl < a.n0) a.rec8[0][sl] = ~0ull - 1;
         else {
-          if (slot < a.n01) a.inl0[(size_t)2 * (slot - a.n0)].x = -2;
-          else if (slot < a.n_main) a.inl0[(size_t)2 * (a.n01 - a.n0) + (size_t)4 * (slot - a.n01)].x = -2;
-          a.first[0][slot - a.n0].x = -2;
+          if (sl < a.n01) a.inl0[(size_t)2 * (sl - a.n0)].x = -2;
+          else if (sl < a.n_main) a.inl0[(size_t)2 * (a.n01 - a.n0) + (size_t)4 * (sl - a.n01)].x = -2;
+          a.first[0][sl - a.n0].x = -2;
         }
       }
     }
   }
   __syncthreads();
-  if (tid == 0) {
+  if (MODE == 2 && tid == 0) a.bin_count[blockIdx.x] = 0;  // (for the next multi-block launch)
+  if (tid == 0 && (MODE == 0 || blockIdx.x == 0)) {  // (multi-block: nobody reads the counters in the apply launch)
     int st[kDsInts];
-    st[kDsDirty] = overflow ? nd0 : nd0 + tot[0]; st[kDsSpill] = overflow ? ns0 : ns0 + tot[1];
-    st[kDsTop0] = overflow ? top0 : top0 + tot[2]; st[kDsTop1] = overflow ? top1 : top1 + tot[3];
+    if (MODE == 2) n_left_out = a.blk_tot[4 * kDlBins + 4];
+    st[kDsDirty] = overflow ? nd0 : nd0 + all4[0]; st[kDsSpill] = overflow ? ns0 : ns0 + all4[1];
+    st[kDsTop0] = overflow ? top0 : top0 + all4[2]; st[kDsTop1] = overflow ? top1 : top1 + all4[3];
     st[kDsOverflow] = a.state[kDsOverflow] | (overflow ? 1 : 0); st[kDsSeq] = a.seq; st[6] = a.state[6] + n_left_out; st[7] = 0;
     for (int k = 0; k < kDsInts; k++) a.state[k] = st[k];
     if (a.host_state) {
@@ -249,6 +371,47 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
     }
   }
 }
+
+// multi-block launches, first dispatch: a lane per record -- left out or keyed as in the one-block kernel -- and the key
+// appended to the bin its pair's slot hashes to (the order inside a bin is whatever the atomics make it: the bin is sorted
+// by the block that takes it). Resets what the launch's other dispatches accumulate.
+__global__ __launch_bounds__(256) void delta_mb_keys_kernel(DlArgs a) {
+  __shared__ DlWin sw[kDlMaxWins];
+  if (threadIdx.x < kDlMaxWins) sw[threadIdx.x] = a.w[(int)threadIdx.x < a.n_wins && !a.wlist ? threadIdx.x : 0];
+  __syncthreads();
+  int left_out = 0;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < a.n_total; p += gridDim.x * 256) {
+    const DlWin wn = dl_window_of(a, sw, p);
+    const int mate = wn.mate;
+    const int4 r = a.pool[mate][wn.first + (p - wn.start)];
+    int lo = 0, hi = wn.dom_count;
+    const int4* base = a.pool[mate] + wn.dom_first;
+    while (lo < hi) {  // sixteen-way lower bound over the dominating window's records
+      const int span = hi - lo;
+      int4 pv[15];
+#pragma unroll
+      for (int q = 0; q < 15; q++) pv[q] = base[lo + (int)(((long long)span * (q + 1)) >> 4)];
+      int nlo = lo, nhi = hi;
+#pragma unroll
+      for (int q = 0; q < 15; q++) {
+        const int at = lo + (int)(((long long)span * (q + 1)) >> 4);
+        if (tb_rec_before(pv[q], r.y, r.w)) nlo = max(nlo, at + 1); else nhi = min(nhi, at);
+      }
+      lo = nlo; hi = nhi;
+    }
+    bool drop = false;
+    if (wn.dom_count > 0 && lo < wn.dom_count) { const int4 at = base[lo]; drop = at.y == r.y && at.w == r.w; }
+    if (drop) { left_out++; continue; }
+    const unsigned slot = (unsigned)a.slot_of_read[r.w];
+    const unsigned bin = (slot * 2654435761u) >> 27;  // (kDlBins = 32)
+    const int at = atomicAdd(&a.bin_count[bin], 1);
+    if (at < kDlBinCap) a.bins[(size_t)bin * kDlBinCap + at] = ((unsigned long long)slot << 33) | ((unsigned long long)mate << 32) | (unsigned)p;
+    else a.blk_tot[4 * kDlBins + 5] = 1;
+  }
+  for (int off = 32; off > 0; off >>= 1) left_out += __shfl_down(left_out, off, 64);
+  if ((threadIdx.x & 63) == 0 && left_out) atomicAdd(&a.blk_tot[4 * kDlBins + 4], left_out);
+}
+__global__ void delta_mb_begin_kernel(int* blk_tot) { if (threadIdx.x < 2) blk_tot[4 * kDlBins + 4 + threadIdx.x] = 0; }
 
 // the delta store back to empty (a table build took the lists in): counters only -- the marks sit in the OLD tables
 __global__ void delta_reset_kernel(int* state, int* host_state, int seq) {

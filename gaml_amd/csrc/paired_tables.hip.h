@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int64_t kTakeOverAfter = 128;   // evaluations between the start of a rebuild beside the evaluations and its take-over
+constexpr int64_t kTakeOverAfter = 64;    // evaluations between the start of a rebuild beside the evaluations and its take-over
 constexpr int64_t kDeltaMaxPerCall = 65536;  // more new records than this in one call: rebuild instead of lists
 
 int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) b++; return b; }
@@ -204,74 +204,86 @@ int paired_reserve_tabledev(gaml_hip_ctx* c, TableDev& T, int64_t n, const int64
 // ---- table build ---------------------------------------------------------------------------------------------------
 // Enqueues one build of the record tables into T on `st`: the ACTIVE windows of both mates as they are now. The host's part
 // is the list of those windows (a few thousand headers) and the link between the two mates' windows.
-int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t st) {
+// The chain is cut into kBuildSlices slices (slice 0 also holds the host's part): a build beside the evaluations enqueues one
+// slice per evaluation -- the ~60 launches of a build are ~250 us of host time, too much for one annealing call.
+constexpr int kBuildSlices = 6;
+int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t st, int slice_from = 0, int slice_to = kBuildSlices - 1) {
   BuildScratch& B = s.scratch;
+  BuildPlan& P = s.build_plan;
   const int64_t n = s.mate[0].n_local();
-  const bool fold = KNOB(c, 16) != 1;
-  T.keep_dominated = !fold;
-  T.built = false; T.ros_valid = false;
-  HIP_TRY(c, T.cnt.reserve(kTbInts * sizeof(int)));
-  HIP_TRY(c, B.h_cnt.reserve(kTbInts * sizeof(int)));
-  HIP_TRY(c, hipMemsetAsync(T.cnt.p, 0, kTbInts * sizeof(int), st));
-  if (n == 0) { memset(B.h_cnt.p, 0, kTbInts * sizeof(int)); return 0; }
-  link_mate_windows(s.mate[0], s.mate[1]);
-  int64_t A[2] = {0, 0};
-  int n_act[2] = {0, 0};
-  for (int mt = 0; mt < 2; mt++) {
-    const ShortMate& m = s.mate[mt];
-    size_t na = 0;
-    for (const Window& w : m.wins) na += (w.active && w.count > 0);
-    HIP_TRY(c, B.h_wins[mt].reserve(std::max<size_t>(1, na) * sizeof(TbWin)));
-    TbWin* hw = (TbWin*)B.h_wins[mt].p;
-    int k = 0;
-    int64_t at = 0;
-    for (size_t wid = 0; wid < m.wins.size(); wid++) {
-      const Window& w = m.wins[wid];
-      if (!w.active || w.count == 0) continue;
-      if (w.dfirst < 0) return fail(c, GAML_HIP_ESTATE, "table build: an active window's records are not in the device pool");
-      TbWin t;
-      t.first = (int)w.dfirst; t.count = w.count; t.wid = (int)wid; t.astart = (int)at;
-      dominating_window(m, w, fold, &t.dom_first, &t.dom_count);
-      hw[k++] = t;
-      at += w.count;
+  auto in = [&](int slice) { return slice >= slice_from && slice <= slice_to; };
+  if (in(0)) {
+    const bool fold = KNOB(c, 16) != 1;
+    T.keep_dominated = !fold;
+    T.built = false; T.ros_valid = false;
+    HIP_TRY(c, T.cnt.reserve(kTbInts * sizeof(int)));
+    HIP_TRY(c, B.h_cnt.reserve(kTbInts * sizeof(int)));
+    HIP_TRY(c, hipMemsetAsync(T.cnt.p, 0, kTbInts * sizeof(int), st));
+    P.empty = n == 0;
+    if (n == 0) { memset(B.h_cnt.p, 0, kTbInts * sizeof(int)); return 0; }
+    link_mate_windows(s.mate[0], s.mate[1]);
+    for (int mt = 0; mt < 2; mt++) {
+      const ShortMate& m = s.mate[mt];
+      size_t na = 0;
+      for (const Window& w : m.wins) na += (w.active && w.count > 0);
+      HIP_TRY(c, B.h_wins[mt].reserve((2 * na + 8192) * sizeof(TbWin)));  // (room to grow: a later build must not meet a pinned allocation)
+      TbWin* hw = (TbWin*)B.h_wins[mt].p;
+      int k = 0;
+      int64_t at = 0;
+      for (size_t wid = 0; wid < m.wins.size(); wid++) {
+        const Window& w = m.wins[wid];
+        if (!w.active || w.count == 0) continue;
+        if (w.dfirst < 0) return fail(c, GAML_HIP_ESTATE, "table build: an active window's records are not in the device pool");
+        TbWin t;
+        t.first = (int)w.dfirst; t.count = w.count; t.wid = (int)wid; t.astart = (int)at;
+        dominating_window(m, w, fold, &t.dom_first, &t.dom_count);
+        hw[k++] = t;
+        at += w.count;
+      }
+      if (at >= ((int64_t)1 << 31)) return fail(c, GAML_HIP_EINVAL, "table build: more than 2^31 active records per mate");
+      P.A[mt] = at; P.n_act[mt] = k;
+      HIP_TRY(c, B.wins[mt].reserve((2 * na + 8192) * sizeof(TbWin)));
+      if (k) HIP_TRY(c, hipMemcpyAsync(B.wins[mt].p, hw, (size_t)k * sizeof(TbWin), hipMemcpyHostToDevice, st));
     }
-    if (at >= ((int64_t)1 << 31)) return fail(c, GAML_HIP_EINVAL, "table build: more than 2^31 active records per mate");
-    A[mt] = at; n_act[mt] = k;
-    HIP_TRY(c, B.wins[mt].reserve(std::max<size_t>(1, na) * sizeof(TbWin)));
-    if (k) HIP_TRY(c, hipMemcpyAsync(B.wins[mt].p, hw, (size_t)k * sizeof(TbWin), hipMemcpyHostToDevice, st));
+    {
+      const size_t nw0 = s.mate[0].wins.size();
+      HIP_TRY(c, B.h_peer.reserve((2 * nw0 + 16384) * sizeof(int32_t)));
+      int32_t* hp = (int32_t*)B.h_peer.p;
+      for (size_t w = 0; w < nw0; w++) hp[w] = s.mate[0].wins[w].peer;
+      HIP_TRY(c, B.peer0.reserve((2 * nw0 + 16384) * sizeof(int32_t)));
+      if (nw0) HIP_TRY(c, hipMemcpyAsync(B.peer0.p, hp, nw0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    const int64_t* A = P.A;
+    const size_t maxA = (size_t)std::max<int64_t>(std::max(A[0], A[1]), n);
+    HIP_TRY(c, B.k_in.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_out.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_tmp.reserve(maxA * sizeof(rs_u64)));
+    HIP_TRY(c, B.v_in.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.v_tmp.reserve(maxA * sizeof(unsigned)));
+    HIP_TRY(c, B.hist.reserve(rs_hist_bytes(maxA)));
+    HIP_TRY(c, B.cl.reserve((size_t)n)); HIP_TRY(c, B.sidx.reserve((size_t)n * sizeof(int)));
+    P.tiles = (unsigned)((n + kTbScanTile - 1) / kTbScanTile);
+    HIP_TRY(c, B.tiles.reserve((size_t)P.tiles * sizeof(int)));
+    for (int mt = 0; mt < 2; mt++) {
+      HIP_TRY(c, B.v_sorted[mt].reserve(std::max<size_t>(1, (size_t)A[mt]) * sizeof(unsigned)));
+      HIP_TRY(c, B.rstart[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.rend[mt].reserve((size_t)n * sizeof(int)));
+      HIP_TRY(c, B.one[mt].reserve((size_t)n * sizeof(unsigned long long)));
+      HIP_TRY(c, B.more[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.start[mt].reserve((size_t)n * sizeof(int)));
+    }
+    {  // (room for half as many records again: a later build into these buffers then allocates nothing)
+      const int64_t As[2] = {A[0] + A[0] / 2 + 65536, A[1] + A[1] / 2 + 65536};
+      if (int e = paired_reserve_tabledev(c, T, n, As)) return e;
+    }
+    P.ins_n = paired_static_ins_n(c, s);
+    P.none1 = (unsigned)s.mate[0].wins.size() + 1; P.none2 = (unsigned)s.mate[1].wins.size() + 1;
   }
-  {
-    const size_t nw0 = s.mate[0].wins.size();
-    HIP_TRY(c, B.h_peer.reserve(std::max<size_t>(1, nw0) * sizeof(int32_t)));
-    int32_t* hp = (int32_t*)B.h_peer.p;
-    for (size_t w = 0; w < nw0; w++) hp[w] = s.mate[0].wins[w].peer;
-    HIP_TRY(c, B.peer0.reserve(std::max<size_t>(1, nw0) * sizeof(int32_t)));
-    if (nw0) HIP_TRY(c, hipMemcpyAsync(B.peer0.p, hp, nw0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  }
-  const size_t maxA = (size_t)std::max<int64_t>(std::max(A[0], A[1]), n);
-  HIP_TRY(c, B.k_in.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_out.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_tmp.reserve(maxA * sizeof(rs_u64)));
-  HIP_TRY(c, B.v_in.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.v_tmp.reserve(maxA * sizeof(unsigned)));
-  HIP_TRY(c, B.hist.reserve(rs_hist_bytes(maxA)));
-  HIP_TRY(c, B.cl.reserve((size_t)n)); HIP_TRY(c, B.sidx.reserve((size_t)n * sizeof(int)));
-  const unsigned tiles = (unsigned)((n + kTbScanTile - 1) / kTbScanTile);
-  HIP_TRY(c, B.tiles.reserve((size_t)tiles * sizeof(int)));
-  for (int mt = 0; mt < 2; mt++) {
-    HIP_TRY(c, B.v_sorted[mt].reserve(std::max<size_t>(1, (size_t)A[mt]) * sizeof(unsigned)));
-    HIP_TRY(c, B.rstart[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.rend[mt].reserve((size_t)n * sizeof(int)));
-    HIP_TRY(c, B.one[mt].reserve((size_t)n * sizeof(unsigned long long)));
-    HIP_TRY(c, B.more[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.start[mt].reserve((size_t)n * sizeof(int)));
-  }
-  {  // (room for half as many records again: a later build into these buffers then allocates nothing)
-    const int64_t As[2] = {A[0] + A[0] / 2 + 65536, A[1] + A[1] / 2 + 65536};
-    if (int e = paired_reserve_tabledev(c, T, n, As)) return e;
-  }
+  if (P.empty) return 0;
+  const int64_t* A = P.A;
   int* cnt = T.cnt.as<int>();
   auto grid = [](int64_t items) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, 4096))); };
   for (int mt = 0; mt < 2; mt++) {
+    if (!in(1 + mt)) continue;  // slices 1 and 2: a mate's records ordered by read
     HIP_TRY(c, hipMemsetAsync(B.rstart[mt].p, 0, (size_t)n * sizeof(int), st));
     HIP_TRY(c, hipMemsetAsync(B.rend[mt].p, 0, (size_t)n * sizeof(int), st));
     if (A[mt] == 0) continue;
-    hipLaunchKernelGGL(tb_keys_kernel, grid(A[mt]), dim3(256), 0, st, s.dev[mt].pool.as<int4>(), B.wins[mt].as<TbWin>(), n_act[mt], (int)A[mt], (int)n,
+    hipLaunchKernelGGL(tb_keys_kernel, grid(A[mt]), dim3(256), 0, st, s.dev[mt].pool.as<int4>(), B.wins[mt].as<TbWin>(), P.n_act[mt], (int)A[mt], (int)n,
                        B.k_in.as<rs_u64>(), B.v_in.as<unsigned>(), cnt + kTbDropped0 + mt);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), B.v_sorted[mt].as<unsigned>(), B.v_tmp.as<unsigned>(),
@@ -279,9 +291,10 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
     hipLaunchKernelGGL(tb_segments_kernel, grid(A[mt]), dim3(256), 0, st, B.k_out.as<rs_u64>(), (int)A[mt], (int)n, B.rstart[mt].as<int>(), B.rend[mt].as<int>());
     HIP_TRY(c, hipGetLastError());
   }
-  const int ins_n = paired_static_ins_n(c, s);
+  const int ins_n = P.ins_n;
   const int memo_codes = (int)std::min<size_t>(s.pt.len_combo.size(), kMemoCodes);
-  {
+  const int bits1 = bits_for(P.none1), bits2 = bits_for(P.none2);
+  if (in(3)) {  // classes and the pairs' sort keys
     TbClassArgs ca;
     for (int mt = 0; mt < 2; mt++) {
       ca.pool[mt] = s.dev[mt].pool.as<int4>(); ca.vals[mt] = B.v_sorted[mt].as<unsigned>(); ca.rstart[mt] = B.rstart[mt].as<int>(); ca.rend[mt] = B.rend[mt].as<int>();
@@ -293,14 +306,14 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
     ca.cl = B.cl.as<unsigned char>(); ca.sidx = B.sidx.as<int>(); ca.cnt = cnt;
     hipLaunchKernelGGL(tb_class_kernel, grid(n), dim3(256), 0, st, ca);
     HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(tb_pairkey_kernel, grid(n), dim3(256), 0, st, B.one[0].as<unsigned long long>(), B.one[1].as<unsigned long long>(), B.cl.as<unsigned char>(), (int)n,
+                       (int)kFoldClass2Below, P.none1, P.none2, bits1, bits2, B.k_in.as<rs_u64>(), B.v_in.as<unsigned>(), cnt);
+    HIP_TRY(c, hipGetLastError());
   }
-  const unsigned none1 = (unsigned)s.mate[0].wins.size() + 1, none2 = (unsigned)s.mate[1].wins.size() + 1;
-  const int bits1 = bits_for(none1), bits2 = bits_for(none2);
-  hipLaunchKernelGGL(tb_pairkey_kernel, grid(n), dim3(256), 0, st, B.one[0].as<unsigned long long>(), B.one[1].as<unsigned long long>(), B.cl.as<unsigned char>(), (int)n,
-                     (int)kFoldClass2Below, none1, none2, bits1, bits2, B.k_in.as<rs_u64>(), B.v_in.as<unsigned>(), cnt);
-  HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), T.read_of_slot.as<unsigned>(), B.v_tmp.as<unsigned>(), (size_t)n, 0,
-                               3 + bits1 + bits2, B.hist.as<unsigned>(), st));
+  if (in(4))  // the device order of the pairs
+    HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), T.read_of_slot.as<unsigned>(), B.v_tmp.as<unsigned>(), (size_t)n, 0,
+                                 3 + bits1 + bits2, B.hist.as<unsigned>(), st));
+  if (!in(5)) return 0;
   {
     TbCompactArgs ka;
     ka.order = T.read_of_slot.as<unsigned>();
@@ -314,6 +327,7 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
     hipLaunchKernelGGL(tb_compact_kernel, grid(n), dim3(256), 0, st, ka);
     HIP_TRY(c, hipGetLastError());
   }
+  const unsigned tiles = P.tiles;
   for (int mt = 0; mt < 2; mt++) {
     hipLaunchKernelGGL(tb_scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, B.more[mt].as<int>(), cnt, (int)n, B.tiles.as<int>());
     hipLaunchKernelGGL(tb_scan_top_kernel, dim3(1), dim3(1024), 0, st, B.tiles.as<int>(), (int)tiles, cnt + kTbExtras0 + mt);
@@ -372,6 +386,12 @@ int paired_reserve_delta(gaml_hip_ctx* c, PairedSet& s) {
   HIP_TRY(c, s.sp_slot.reserve(s.cap_spill * sizeof(int32_t)));
   HIP_TRY(c, s.dstate.reserve(kDsInts * sizeof(int)));
   HIP_TRY(c, hipMemset(s.dstate.p, 0, kDsInts * sizeof(int)));
+  HIP_TRY(c, s.dl_bins.reserve((size_t)kDlBins * kDlBinCap * sizeof(unsigned long long)));
+  HIP_TRY(c, s.dl_bin_count.reserve(kDlBins * sizeof(int)));
+  HIP_TRY(c, hipMemset(s.dl_bin_count.p, 0, kDlBins * sizeof(int)));
+  HIP_TRY(c, s.dl_blk_tot.reserve((4 * kDlBins + 8) * sizeof(int)));
+  HIP_TRY(c, s.dl_wlist.reserve(16384 * sizeof(DlWin)));
+  HIP_TRY(c, hipMemset(s.dl_blk_tot.p, 0, (4 * kDlBins + 8) * sizeof(int)));
   HIP_TRY(c, s.h_dstate.reserve(64));
   memset(s.h_dstate.p, 0, 64);
   return 0;
@@ -416,16 +436,50 @@ int paired_delta_apply(gaml_hip_ctx* c, PairedSet& s, TableDev& T, std::vector<s
   a.dl_slot = s.dl_slot.as<int>(); a.dl_spill = s.dl_spill.as<int>(); a.sp_slot = s.sp_slot.as<int>();
   a.state = s.dstate.as<int>(); a.host_state = (int*)s.h_dstate.dev;
   a.cap_pairs = (int)s.delta_cap; a.cap_spill = (int)s.cap_spill; a.cap_sprec = (int)s.cap_sprec;
+  a.bins = s.dl_bins.as<unsigned long long>(); a.bin_count = s.dl_bin_count.as<int>(); a.blk_tot = s.dl_blk_tot.as<int>();
+  int64_t all_records = 0;
+  for (const auto& mw : wins) all_records += s.mate[mw.first].wins[mw.second].count;
+  const bool multi_block = (all_records > 3000 || wins.size() > (size_t)kDlMaxWins) && KNOB(c, 22) != 1;  // knob 22 = 1: one-block launches only (A/B, tests)
+  const int max_recs = multi_block ? kDlMbMaxRecs : kDlMaxRecs;
+  std::vector<DlWin> big;  // a multi-block launch's window list when the argument block cannot hold it
   auto flush = [&]() -> int {
     if (a.n_wins == 0) return 0;
     a.seq = ++s.dl_seq;
-    hipLaunchKernelGGL(delta_apply_kernel, dim3(1), dim3(kDlThreads), 0, st, a);
+    if (multi_block) {
+      a.wlist = nullptr;
+      if (a.n_wins > kDlMaxWins) {  // the list goes through a staging slot into device memory
+        void* hp = nullptr;
+        const size_t bytes = big.size() * sizeof(DlWin);
+        const int slot = stage_acquire(c, s.stage_pool, align16(bytes), &hp);
+        if (slot < 0) return slot;
+        memcpy(hp, big.data(), bytes);
+        if (align16(bytes) > s.dl_wlist.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.dl_wlist.reserve(2 * align16(bytes))); }
+        if (int e = stage_upload(c, s.stage_pool, slot, s.dl_wlist.p, align16(bytes), st)) return e;
+        if (int e = stage_release(c, s.stage_pool, slot, st)) return e;
+        a.wlist = s.dl_wlist.as<DlWin>();
+      }
+      hipLaunchKernelGGL(delta_mb_begin_kernel, dim3(1), dim3(64), 0, st, a.blk_tot);
+      hipLaunchKernelGGL(delta_mb_keys_kernel, dim3((unsigned)std::min(256, (a.n_total + 255) / 256)), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((delta_apply_kernel<8, 1>), dim3(kDlBins), dim3(kDlThreads), 0, st, a);
+      hipLaunchKernelGGL((delta_apply_kernel<8, 2>), dim3(kDlBins), dim3(kDlThreads), 0, st, a);
+      HIP_TRY(c, hipGetLastError());
+      s.nd_est += a.n_total;
+      s.spill_may_grow = true;
+      a.n_wins = 0; a.n_total = 0;
+      big.clear();
+      return 0;
+    }
+    if (a.n_total <= kDlThreads) { int thr = 64; while (thr < a.n_total) thr <<= 1; hipLaunchKernelGGL(delta_apply_kernel<1>, dim3(1), dim3(thr), 0, st, a); }
+    else if (a.n_total <= 2 * kDlThreads) hipLaunchKernelGGL(delta_apply_kernel<2>, dim3(1), dim3(kDlThreads), 0, st, a);
+    else if (a.n_total <= 4 * kDlThreads) hipLaunchKernelGGL(delta_apply_kernel<4>, dim3(1), dim3(kDlThreads), 0, st, a);
+    else hipLaunchKernelGGL(delta_apply_kernel<8>, dim3(1), dim3(kDlThreads), 0, st, a);
     HIP_TRY(c, hipGetLastError());
     s.nd_est += a.n_total;
     s.spill_may_grow = true;
     a.n_wins = 0; a.n_total = 0;
     return 0;
   };
+  const int max_wins = multi_block ? 16384 : kDlMaxWins;
   for (const auto& mw : wins) {
     const ShortMate& m = s.mate[mw.first];
     const Window& w = m.wins[mw.second];
@@ -435,9 +489,12 @@ int paired_delta_apply(gaml_hip_ctx* c, PairedSet& s, TableDev& T, std::vector<s
     dominating_window(m, w, fold, &dom_first, &dom_count);
     int done = 0;
     while (done < w.count) {  // (a window larger than a launch holds is cut: the lists compose)
-      if (a.n_wins == kDlMaxWins || a.n_total == kDlMaxRecs) { if (int e = flush()) return e; }
-      const int take = std::min(w.count - done, kDlMaxRecs - a.n_total);
-      a.w[a.n_wins++] = DlWin{mw.first, mw.second, (int)w.dfirst + done, take, dom_first, dom_count, a.n_total};
+      if (a.n_wins == max_wins || a.n_total == max_recs) { if (int e = flush()) return e; }
+      const int take = std::min(w.count - done, max_recs - a.n_total);
+      const DlWin dw{mw.first, mw.second, (int)w.dfirst + done, take, dom_first, dom_count, a.n_total};
+      if (a.n_wins < kDlMaxWins) a.w[a.n_wins] = dw;
+      if (multi_block) big.push_back(dw);
+      a.n_wins++;
       a.n_total += take;
       done += take;
     }
@@ -458,14 +515,25 @@ int paired_delta_reset(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
 }
 
 // ---- rebuilds ----------------------------------------------------------------------------------------------------------
+int paired_build_continue(gaml_hip_ctx* c, PairedSet& s, bool rest);
+// the build's stream: lowest priority -- its workgroups yield to the evaluations' (whose stream has the highest)
+hipError_t paired_build_stream(hipStream_t* out) {
+  int lo = 0, hi = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);  // (numerically: lo is the LEAST urgent)
+  if (e != hipSuccess) return e;
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, lo);
+}
+
 // on the calling stream: the spare buffers are built from the windows that are active now and take over at once
 int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   TableRebuild& rb = s.rebuild;
   if (rb.active) {  // a build beside the evaluations is under way: let it finish (its buffers are the spare ones), then discard it
+    if (int e = paired_build_continue(c, s, true)) return e;
     HIP_TRY(c, hipEventSynchronize(rb.done));
     rb.active = false; rb.after.clear();
   }
   s.full_rebuilds++;
+  rb.retired = false;
   paired_retire_windows(c, s);
   for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
   const double tb0 = now_us();
@@ -489,7 +557,7 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
     HIP_TRY(c, B.k_in.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_out.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_tmp.reserve(maxA * sizeof(rs_u64)));
     HIP_TRY(c, B.v_in.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.v_tmp.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.hist.reserve(rs_hist_bytes(maxA)));
     for (int mt = 0; mt < 2; mt++) HIP_TRY(c, B.v_sorted[mt].reserve((size_t)A2[mt] * sizeof(unsigned)));
-    if (!rb.stream) HIP_TRY(c, hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
+    if (!rb.stream) HIP_TRY(c, paired_build_stream(&rb.stream));
     if (!rb.done) HIP_TRY(c, hipEventCreateWithFlags(&rb.done, hipEventDisableTiming));
     if (!rb.mark) HIP_TRY(c, hipEventCreateWithFlags(&rb.mark, hipEventDisableTiming));
   }
@@ -500,25 +568,47 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
 // beside the evaluations: the build runs on a stream of its own; the evaluations go on over the old tables + delta lists
 int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   TableRebuild& rb = s.rebuild;
-  paired_retire_windows(c, s);
-  if (!rb.stream) HIP_TRY(c, hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
+  const double t0 = now_us();
+  if (!rb.retired) {  // first of two evaluations: unused windows leave (O(windows) on the host); the window lists come with the next
+    paired_retire_windows(c, s);
+    rb.retired = true;
+    return 0;
+  }
+  rb.retired = false;
+  const double t1 = now_us();
+  if (!rb.stream) HIP_TRY(c, paired_build_stream(&rb.stream));
   if (!rb.done) HIP_TRY(c, hipEventCreateWithFlags(&rb.done, hipEventDisableTiming));
   if (!rb.mark) HIP_TRY(c, hipEventCreateWithFlags(&rb.mark, hipEventDisableTiming));
   // the build reads the pool as the calling stream has filled it, and overwrites buffers earlier launches may still read
   HIP_TRY(c, hipEventRecord(rb.mark, st));
   HIP_TRY(c, hipStreamWaitEvent(rb.stream, rb.mark, 0));
-  if (int e = paired_build_enqueue(c, s, rb.tab, rb.stream)) return e;
-  HIP_TRY(c, hipEventRecord(rb.done, rb.stream));
+  if (int e = paired_build_enqueue(c, s, rb.tab, rb.stream, 0, 0)) return e;  // (the other slices: one per evaluation, paired_sync_tables)
+  rb.next_slice = 1;
   rb.after.clear();
   rb.start_eval = s.eval_count;
   rb.active = true;
+  if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "rebuild beside the evaluations started: retire %.0f us, window lists + launches %.0f us\n", t1 - t0, now_us() - t1);
+  return 0;
+}
+
+// the next slice of a build beside the evaluations (all that are left when `rest`)
+int paired_build_continue(gaml_hip_ctx* c, PairedSet& s, bool rest) {
+  TableRebuild& rb = s.rebuild;
+  if (!rb.active || rb.next_slice >= kBuildSlices) return 0;
+  const int to = rest ? kBuildSlices - 1 : rb.next_slice;
+  if (int e = paired_build_enqueue(c, s, rb.tab, rb.stream, rb.next_slice, to)) return e;
+  rb.next_slice = to + 1;
+  if (rb.next_slice >= kBuildSlices) HIP_TRY(c, hipEventRecord(rb.done, rb.stream));
   return 0;
 }
 
 // the new tables take over; what was activated since the build started goes onto their (empty) delta lists
 int paired_finish_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   TableRebuild& rb = s.rebuild;
+  const double t0 = now_us();
+  if (int e = paired_build_continue(c, s, true)) return e;
   HIP_TRY(c, hipEventSynchronize(rb.done));  // (long done as a rule: the take-over is a fixed number of evaluations after the start)
+  const double t1 = now_us();
   rb.active = false;
   if (int e = paired_build_collect(c, s, rb.tab)) return e;
   std::swap(s.tab, rb.tab);
@@ -526,7 +616,10 @@ int paired_finish_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   if (int e = paired_delta_reset(c, s, st)) return e;
   // this call's own activations join the windows noted since the build started
   for (int mt = 0; mt < 2; mt++) { for (int32_t w : s.mate[mt].activated_log) rb.after.emplace_back(mt, w); s.mate[mt].activated_log.clear(); }
+  int64_t replayed = 0;
+  for (const auto& mw : rb.after) replayed += s.mate[mw.first].wins[mw.second].count;
   if (int e = paired_delta_apply(c, s, s.tab, rb.after, st)) return e;
+  if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "take-over: waited %.0f us for the build, %zu windows / %lld records onto the new lists, %.0f us in all\n", t1 - t0, rb.after.size(), (long long)replayed, now_us() - t0);
   rb.after.clear();
   for (int mt = 0; mt < 2; mt++) s.dev[mt].uploaded_generation = s.mate[mt].active_generation;
   s.full_rebuilds++;
@@ -545,6 +638,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   // run to run (the annealing loop compares likelihoods with strict >).
   const int64_t swap_after = KNOB(c, 14) > 1 ? KNOB(c, 14) : kTakeOverAfter;
   if (rb.active && s.eval_count - rb.start_eval >= swap_after) { if (int e = paired_finish_async_rebuild(c, s, st)) return e; }
+  else if (rb.active) { if (int e = paired_build_continue(c, s, false)) return e; }
   bool activated_now = !s.mate[0].activated_log.empty() || !s.mate[1].activated_log.empty();
   s.quiet_calls = activated_now ? 0 : s.quiet_calls + 1;
   if (!s.tab.built) return paired_rebuild_tables(c, s, st);
@@ -565,10 +659,10 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   if (asked || ((over || quiet) && !beside) || too_many) {
     if (int e = paired_rebuild_tables(c, s, st)) return e;
     activated_now = false;
-  } else if ((over || quiet) && !rb.active) {
+  } else if ((over || quiet || rb.retired) && !rb.active) {
     if (int e = paired_start_async_rebuild(c, s, st)) return e;  // (this call's activations are in its window list)
     s.quiet_calls = 0;
-    if (activated_now) {
+    if (activated_now && rb.active) {
       std::vector<std::pair<int32_t, int32_t>> wins;
       for (int mt = 0; mt < 2; mt++) { for (int32_t w : s.mate[mt].activated_log) wins.emplace_back(mt, w); s.mate[mt].activated_log.clear(); }
       if (int e = paired_delta_apply(c, s, s.tab, wins, st)) return e;

@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256) void tb_pairkey_kernel(const unsigned long lon
     const unsigned w2 = one1[i] >= kTbNoFit ? none2 : (unsigned)(one1[i] & 0xffffff);
     keys[i] = ((rs_u64)c << (bits1 + bits2)) | ((rs_u64)w1 << bits2) | (rs_u64)w2;
     reads[i] = (unsigned)i;
-    atomicAdd(&sh[c], 1);
+    for (int q = 0; q < 5; q++) {  // (a count per wave and class: one LDS atomic per wave, not per lane)
+      const unsigned long long b = __ballot(c == q);
+      if ((threadIdx.x & 63) == 0 && b) atomicAdd(&sh[q], (int)__popcll(b));
+    }
   }
   __syncthreads();
   if (threadIdx.x < 5 && sh[threadIdx.x]) atomicAdd(&cnt[threadIdx.x == 0 ? kTbN0a : kTbClass0 + threadIdx.x - 1], sh[threadIdx.x]);
