@@ -58,9 +58,13 @@ __global__ __launch_bounds__(kFileThreads) void aln_file_small_kernel(AlnFileArg
         const bool gt = xh != yh ? xh > yh : xl > yl;
         if (gt == ((i & k) == 0)) { khi[i] = yh; klo[i] = yl; khi[l] = xh; klo[l] = xl; }
       }
-      __syncthreads();
+      // (strides below 64: a wave's exchanges stay inside the 128 keys it owns -- no block barrier, see dl_bitonic_sort)
+      const int jn = j > 1 ? j >> 1 : k;
+      if (j >= 64 || jn >= 64) __syncthreads();
+      else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
+  __syncthreads();
   // survivors: the first of every (window, position, read); thread t owns the sorted positions [t * per, (t + 1) * per)
   const int per = (N + nthr - 1) / nthr;
   const int p_lo = tid * per, p_hi = min(N, p_lo + per);

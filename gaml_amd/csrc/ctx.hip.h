@@ -217,7 +217,7 @@ struct BuildScratch {
 // changes the order of the final sum). What was activated in between is applied to the new tables' (empty) delta lists by
 // the same kernel that maintains the live ones.
 // what the slices of one build share (paired_build_enqueue)
-struct BuildPlan { int64_t A[2] = {0, 0}; int n_act[2] = {0, 0}; unsigned tiles = 0, none1 = 0, none2 = 0; int ins_n = 0; bool empty = true; };
+struct BuildPlan { int64_t A[2] = {0, 0}; int n_act[2] = {0, 0}; unsigned tiles = 0, none1 = 0, none2 = 0; int ins_n = 0, units = 1; bool empty = true; };
 
 struct TableRebuild {
   bool active = false;
@@ -251,13 +251,13 @@ struct PairedSet {
   // per set, fixed: length-combination code per pair, the per-combination tables, the memo of pair terms
   DevBuf lcode, len_combo_dev, combo_tabs, memo;
   int memo_codes = 0;
-  bool statics_uploaded = false;
+  bool statics_uploaded = false, kernels_warm = false;
   // Delta store (device): pairs whose record lists gained records of windows activated after the tables were built. Their
   // complete lists sit at a fixed stride (4 records per mate; longer ones in the spill area); maintained by
   // delta_apply_kernel, read by the scoring launch. The host knows upper bounds (and the exact counts once a blocking call
   // has returned: h_dstate, written by the kernels).
   DevBuf dl_slot, dl_spill, dl_rec[2], sp_rng[2], sp_rec[2], sp_slot, dstate;
-  DevBuf dl_bins, dl_bin_count, dl_blk_tot, dl_wlist;   // multi-block maintenance launches (delta_dev.hip.h)
+  DevBuf dl_bins, dl_bin_count, dl_blk_tot, dl_wlist, dl_stamps;   // multi-block maintenance launches (delta_dev.hip.h)
   PinBuf h_dstate;
   size_t delta_cap = 0, cap_spill = 0, cap_sprec = 0;
   int64_t nd_est = 0, ns_est = 0;     // delta pairs (upper bound) / long lists (last exact count) as the host knows them

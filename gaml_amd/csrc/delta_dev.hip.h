@@ -52,10 +52,12 @@ struct DlArgs {
   int* state;       // kDs*
   int* host_state;  // the same words in pinned host memory, written at the end of every launch
   int cap_pairs, cap_spill, cap_sprec, seq;
+  int slot_bits;    // bits a slot number takes (the sort's passes)
   // multi-block launches (delta_mb_*): the bins, how many keys each holds, per block what it hands out + the counters' values before the launch
   unsigned long long* bins;
   int* bin_count;
   int* blk_tot;     // [kDlBins][4], then [4] base values, then [1] records left out, [1] a bin overflowed
+  unsigned long long* stamps;  // timing probes (development): wall-clock stamps (10 ns) of thread 0 at the stage boundaries, or null
   const DlWin* wlist;  // multi-block launches of more windows than w[] holds: the list in device memory (else null)
   DlWin w[kDlMaxWins];
 };
@@ -82,6 +84,96 @@ __device__ __forceinline__ int4 dl_old_get(const DlOld& o, int k) {
 }
 __device__ __forceinline__ bool dl_before_eq(const int4& x, const int4& y) { return x.x != y.x ? x.x < y.x : x.y <= y.y; }  // x goes first (an old record before an equal new one: upper_bound)
 
+// Bitonic sort of N (a power of two >= 64) distinct keys in LDS, ascending. A thread takes compare-exchange t, t + nthr, ...;
+// with strides below 64 both elements of every exchange of a wave's 64 threads lie in the 128 keys that wave owns, so only
+// the steps with larger strides need the block's barrier -- 15 of the 66 steps at 2,048 keys (a barrier over sixteen waves
+// per step was 16 of a 40 us launch).
+__device__ __forceinline__ void dl_bitonic_sort(unsigned long long* keys, int N, int tid, int nthr) {
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (N >> 1); t += nthr) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const unsigned long long x = keys[i], y = keys[l];
+        const bool up = (i & k) == 0;
+        if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+      }
+      // the next step's partners: within the wave's own keys when its stride is below 64 and so was this one's
+      const int jn = j > 1 ? j >> 1 : k;  // (the next stage starts at stride k)
+      if (j >= 64 || jn >= 64) __syncthreads();
+      else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  __syncthreads();
+}
+
+// Grouping without a sort (one-block launches of up to 4,096 records): the keys of one pair brought together, pairs in the
+// order of their first record in the launch's sequence, a pair's records in sequence order -- the same lists as a sort by
+// (slot, mate, sequence) gives, the pairs numbered by first touch instead of by slot (either is a function of the input
+// alone). A hash table in LDS keyed by slot takes every record (compare-and-swap on the key, then count / smallest
+// sequence number / a chain through the slot's records by atomics: their order is arbitrary, what is read off them is
+// not); the record whose number is the slot's smallest is its head; a scan over the heads in sequence order places the
+// groups; a record's place in its group is the number of chain members before it in the sequence. Four dependent LDS
+// steps and a scan per 1,024 records, where the bitonic network took 55-78 (12 us at 1,024 keys, 31 us at 4,096).
+struct DlGroupLds { int* tkey; int* thead; int* tcnt; int* tmin; int* next; int* scan /* [nthr / 64 + 1] */; };
+template <int PER>
+__device__ __forceinline__ void dl_group(const unsigned long long* keys, unsigned long long* out, int N, int tid, int nthr, const DlGroupLds& L) {
+  const int H = N;  // (a power of two >= 64; at most N distinct slots)
+  const int lane = tid & 63, wave = tid >> 6, nwav = nthr >> 6;
+  for (int h = tid; h < H; h += nthr) { L.tkey[h] = -1; L.thead[h] = -1; L.tcnt[h] = 0; L.tmin[h] = 0x7fffffff; }
+  for (int p = tid; p < N; p += nthr) out[p] = ~0ull;
+  __syncthreads();
+  int hp[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int p = tid + j * nthr;
+    hp[j] = -1;
+    if (p >= N || keys[p] == ~0ull) continue;
+    const int slot = (int)(keys[p] >> 33);
+    int h = (int)(((unsigned)slot * 2654435761u) >> 7) & (H - 1);
+    for (;;) {
+      const int k = atomicCAS(&L.tkey[h], -1, slot);
+      if (k == -1 || k == slot) break;
+      h = (h + 1) & (H - 1);
+    }
+    hp[j] = h;
+    atomicAdd(&L.tcnt[h], 1);
+    atomicMin(&L.tmin[h], p);
+    L.next[p] = atomicExch(&L.thead[h], p);
+  }
+  __syncthreads();
+  // the groups' places: heads in sequence order (round by round: p = tid + j * nthr), each followed by its slot's records
+  bool is_head[PER];
+  int size[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) { is_head[j] = hp[j] >= 0 && L.tmin[hp[j]] == tid + j * nthr; size[j] = is_head[j] ? L.tcnt[hp[j]] : 0; }
+  __syncthreads();  // (every head flag is settled before tmin is reused for the groups' places)
+  int carry = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    int incl = size[j];
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
+    if (lane == 63) L.scan[wave] = incl;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; w++) before += L.scan[w];
+    int total = 0;
+    for (int w = 0; w < nwav; w++) total += L.scan[w];
+    if (is_head[j]) L.tmin[hp[j]] = before + incl - size[j];
+    carry += total;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    if (hp[j] < 0) continue;
+    const int p = tid + j * nthr;
+    int rank = 0;
+    for (int q = L.thead[hp[j]]; q >= 0; q = L.next[q]) rank += q < p;
+    out[L.tmin[hp[j]] + rank] = keys[p];
+  }
+  __syncthreads();
+}
+
 // PER: sorted positions per thread (kDlThreads * PER >= the launch's records, rounded up to a power of two). A thread's
 // PER items go through every stage side by side (their loads in flight together): one lane working off eight chains of
 // dependent loads one after the other was the kernel's duration.
@@ -90,9 +182,13 @@ __device__ __forceinline__ bool dl_before_eq(const int4& x, const int4& y) { ret
 // behind those of the blocks before it.
 template <int PER, int MODE = 0>
 __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
-  __shared__ unsigned long long keys[kDlThreads * PER];
-  constexpr bool kCache = PER <= 4 && MODE == 0;  // the launch's records stay in LDS between the key stage and the merge
-  __shared__ int4 rec_lds[kCache ? kDlThreads * PER : 1];
+  constexpr bool kGroup = PER <= 4 && MODE == 0;  // keys grouped through a hash table (dl_group); else sorted (bitonic network)
+  __shared__ unsigned long long keys_a[kDlThreads * PER], keys_b[kGroup ? kDlThreads * PER : 1];
+  __shared__ __attribute__((aligned(16))) int g_tab[kGroup ? 5 * kDlThreads * PER : 4];
+  __shared__ int g_scan[kDlThreads / 64 + 1];
+  unsigned long long* keys = keys_a;
+  constexpr bool kCache = kGroup;  // the launch's records sit in LDS for the merge (where the grouping's tables were: 20 bytes per key, a record takes 16)
+  int4* const rec_lds = (int4*)g_tab;
   __shared__ int sc[4][kDlThreads / 64];
   __shared__ int tot[4];
   __shared__ int n_left_out;
@@ -102,16 +198,18 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
   __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthr = (int)blockDim.x, nwav = nthr >> 6;  // (PER == 1: as many threads as the records' power of two, 64 .. 1,024)
+#define DL_STAMP(k) do { if (a.stamps && tid == 0 && blockIdx.x == 0) a.stamps[k] = wall_clock64(); } while (0)
+  DL_STAMP(0);
   const int n_here = MODE == 0 ? a.n_total : min(a.bin_count[blockIdx.x], kDlBinCap);
   const bool mb_bad = MODE != 0 && (a.blk_tot[4 * kDlBins + 5] != 0);  // a bin overflowed: the launch changes nothing
   int N = 64;
   while (N < n_here) N <<= 1;
+  int4 r[PER];
   if (MODE != 0) {
     for (int p = tid; p < N; p += nthr) keys[p] = p < n_here ? a.bins[(size_t)blockIdx.x * kDlBinCap + p] : ~0ull;
   } else
   // ---- 1. keys: record j of this thread is position tid + j * kDlThreads of the launch's record sequence
   {
-    int4 r[PER];
     int kw[PER], lo[PER], hi[PER];
     bool live[PER];
 #pragma unroll
@@ -160,7 +258,6 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
     for (int j = 0; j < PER; j++) {
       const int p = tid + j * nthr;
       if (p >= N) continue;
-      if (kCache) rec_lds[p] = r[j];
       unsigned long long key = ~0ull;
       if (live[j]) {
         const bool drop = sw[kw[j]].dom_count > 0 && lo[j] < sw[kw[j]].dom_count && at[j].y == r[j].y && at[j].w == r[j].w;
@@ -173,17 +270,17 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
   __syncthreads();
   // ---- 2. bitonic sort, ascending (a launch of few records runs with as many threads as records: a barrier over sixteen
   // waves per step of the network, 36-55 steps, was most of a small launch's duration)
-  for (int k = 2; k <= N; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (N >> 1); t += nthr) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-        const unsigned long long x = keys[i], y = keys[l];
-        const bool up = (i & k) == 0;
-        if ((x > y) == up) { keys[i] = y; keys[l] = x; }
-      }
-      __syncthreads();
-    }
-  }
+  DL_STAMP(1);
+  if (kGroup) {
+    __syncthreads();
+    const DlGroupLds G{g_tab, g_tab + N, g_tab + 2 * N, g_tab + 3 * N, g_tab + 4 * N, g_scan};
+    dl_group<PER>(keys_a, keys_b, N, tid, nthr, G);
+    keys = keys_b;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { const int p = tid + j * nthr; if (p < N) rec_lds[p] = r[j]; }  // (the tables are done with: dl_group ended on a barrier)
+    __syncthreads();
+  } else dl_bitonic_sort(keys, N, tid, nthr);
+  DL_STAMP(2);
   // ---- 3. per touched pair. Thread t owns the sorted positions [t * per, (t + 1) * per): numbers are handed out in that order.
   const int per = N > nthr ? N / nthr : 1;
   const int p_lo = tid * per;
@@ -206,14 +303,18 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < PER; j++) if (head[j]) dj[j] = a.dirty_of_slot[slot[j]];
+  unsigned long long r8[2][PER];  // a compact-class pair's two records (what its lists start from when it is new to them)
+  unsigned l12v[PER];            // the pair's read lengths
   {
     int v0[PER], v1[PER];
+    int code[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) {
-      v0[j] = v1[j] = 0;
+      v0[j] = v1[j] = 0; code[j] = -1; l12v[j] = 0; r8[0][j] = r8[1][j] = ~0ull;
       if (!head[j]) continue;
+      if (slot[j] < a.n0) code[j] = a.len_code[slot[j]]; else l12v[j] = a.len12[slot[j] - a.n0];
       if (dj[j] >= 0) { v0[j] = a.dl_spill[dj[j]]; v1[j] = a.dl_rec[1][4 * (size_t)dj[j]].w; }
-      else if (slot[j] < a.n0) { v0[j] = a.rec8[0][slot[j]] != ~0ull ? 1 : 0; v1[j] = a.rec8[1][slot[j]] != ~0ull ? 1 : 0; }
+      else if (slot[j] < a.n0) { r8[0][j] = a.rec8[0][slot[j]]; r8[1][j] = a.rec8[1][slot[j]]; v0[j] = r8[0][j] != ~0ull ? 1 : 0; v1[j] = r8[1][j] != ~0ull ? 1 : 0; }
       else {
         const int4 f0 = a.first[0][slot[j] - a.n0], f1 = a.first[1][slot[j] - a.n0];
         v0[j] = f0.x < 0 ? 0 : 1 + (int)((unsigned)f0.z >> 9);
@@ -228,8 +329,10 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
         if (sp_old[j] >= 0) { c0[j] = a.sp_rng[0][sp_old[j]].y; c1[j] = a.sp_rng[1][sp_old[j]].y; }
         else { c0[j] = v1[j] & 0xff; c1[j] = (v1[j] >> 8) & 0xff; }
       } else { c0[j] = v0[j]; c1[j] = v1[j]; }
+      if (code[j] >= 0) l12v[j] = a.len_combo[code[j]];
     }
   }
+  DL_STAMP(3);
   int my[4] = {0, 0, 0, 0};  // new pairs, new spill entries, spill records of mate 0 / 1
 #pragma unroll
   for (int j = 0; j < PER; j++) {
@@ -261,6 +364,7 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
     __syncthreads();
     for (int v = 0; v < 4; v++) { excl[v] += before_sh[v]; all4[v] = all_sh[v]; }
   }
+  DL_STAMP(4);
   const bool overflow = mb_bad || nd0 + all4[0] > a.cap_pairs || ns0 + all4[1] > a.cap_spill || top0 + all4[2] > a.cap_sprec || top1 + all4[3] > a.cap_sprec;
   if (!overflow) {
     int at[4] = {nd0 + excl[0], ns0 + excl[1], top0 + excl[2], top1 + excl[3]};
@@ -276,14 +380,14 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
       if (fresh) d = at[0]++;
       int sp = sp_old[j];
       if (lng && sp < 0) sp = at[1]++;
-      const unsigned l12 = sl < a.n0 ? a.len_combo[a.len_code[sl]] : a.len12[sl - a.n0];
+      const unsigned l12 = l12v[j];
       // the present lists, requested together: up to four records per mate at the fixed stride / one compact record
       int4 reg[2][4];
       if (!fresh && sp_old[j] < 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) { reg[0][k] = a.dl_rec[0][4 * (size_t)d + k]; reg[1][k] = a.dl_rec[1][4 * (size_t)d + k]; }
       } else if (fresh && sl < a.n0) {
-        const unsigned long long r0 = a.rec8[0][sl], r1 = a.rec8[1][sl];
+        const unsigned long long r0 = r8[0][j], r1 = r8[1][j];
         reg[0][0] = make_int4((int)(r0 & 0xffffff), (int)((r0 >> 24) & 0xfffffff), (int)((r0 >> 52) & 63) | ((int)((r0 >> 58) & 1) << 8), 0);
         reg[1][0] = make_int4((int)(r1 & 0xffffff), (int)((r1 >> 24) & 0xfffffff), (int)((r1 >> 52) & 63) | ((int)((r1 >> 58) & 1) << 8), 0);
       }
@@ -357,6 +461,7 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
     }
   }
   __syncthreads();
+  DL_STAMP(5);
   if (MODE == 2 && tid == 0) a.bin_count[blockIdx.x] = 0;  // (for the next multi-block launch)
   if (tid == 0 && (MODE == 0 || blockIdx.x == 0)) {  // (multi-block: nobody reads the counters in the apply launch)
     int st[kDsInts];
@@ -370,6 +475,8 @@ __global__ __launch_bounds__(kDlThreads) void delta_apply_kernel(DlArgs a) {
       __hip_atomic_store(&a.host_state[kDsSeq], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  DL_STAMP(6);
+#undef DL_STAMP
 }
 
 // multi-block launches, first dispatch: a lane per record -- left out or keyed as in the one-block kernel -- and the key

@@ -185,6 +185,14 @@ void dominating_window(const ShortMate& m, const Window& w, bool fold, int* dom_
   *dom_first = (int)sw.dfirst; *dom_count = sw.count;
 }
 
+// room for the records of a mate's active windows in the tables and the build's scratch: every record aligned so far may be
+// active one day, plus a quarter (an annealing run adds a few hundred records per move): a build beside the evaluations must
+// not meet an allocation (device allocations of this size take milliseconds)
+int64_t paired_records_cap(const PairedSet& s, int mt) {
+  const int64_t have = s.dev[mt].pool_n;
+  return std::max<int64_t>(have + have / 4, s.mate[0].n_local()) + 65536;
+}
+
 // one set of table buffers for n pairs and A[mate] active records (grow-only)
 int paired_reserve_tabledev(gaml_hip_ctx* c, TableDev& T, int64_t n, const int64_t* A) {
   HIP_TRY(c, T.cnt.reserve(kTbInts * sizeof(int)));
@@ -206,13 +214,14 @@ int paired_reserve_tabledev(gaml_hip_ctx* c, TableDev& T, int64_t n, const int64
 // is the list of those windows (a few thousand headers) and the link between the two mates' windows.
 // The chain is cut into kBuildSlices slices (slice 0 also holds the host's part): a build beside the evaluations enqueues one
 // slice per evaluation -- the ~60 launches of a build are ~250 us of host time, too much for one annealing call.
-constexpr int kBuildSlices = 6;
-int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t st, int slice_from = 0, int slice_to = kBuildSlices - 1) {
+constexpr int kBuildAll = 1 << 20;
+int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t st, int slice_from = 0, int slice_to = kBuildAll) {
   BuildScratch& B = s.scratch;
   BuildPlan& P = s.build_plan;
   const int64_t n = s.mate[0].n_local();
-  auto in = [&](int slice) { return slice >= slice_from && slice <= slice_to; };
-  if (in(0)) {
+  int unit = 0;  // the chain's slices are numbered as they come: a slice = the host's part, or up to half a dozen launches
+  auto in = [&]() { const int u = unit++; return u >= slice_from && u <= slice_to; };
+  if (in()) {
     const bool fold = KNOB(c, 16) != 1;
     T.keep_dominated = !fold;
     T.built = false; T.ros_valid = false;
@@ -220,13 +229,14 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
     HIP_TRY(c, B.h_cnt.reserve(kTbInts * sizeof(int)));
     HIP_TRY(c, hipMemsetAsync(T.cnt.p, 0, kTbInts * sizeof(int), st));
     P.empty = n == 0;
+    P.units = 1;
     if (n == 0) { memset(B.h_cnt.p, 0, kTbInts * sizeof(int)); return 0; }
     link_mate_windows(s.mate[0], s.mate[1]);
     for (int mt = 0; mt < 2; mt++) {
       const ShortMate& m = s.mate[mt];
       size_t na = 0;
       for (const Window& w : m.wins) na += (w.active && w.count > 0);
-      HIP_TRY(c, B.h_wins[mt].reserve((2 * na + 8192) * sizeof(TbWin)));  // (room to grow: a later build must not meet a pinned allocation)
+      HIP_TRY(c, B.h_wins[mt].reserve((2 * m.wins.size() + 16384) * sizeof(TbWin)));  // (room to grow: a later build must not meet a pinned allocation)
       TbWin* hw = (TbWin*)B.h_wins[mt].p;
       int k = 0;
       int64_t at = 0;
@@ -242,7 +252,7 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
       }
       if (at >= ((int64_t)1 << 31)) return fail(c, GAML_HIP_EINVAL, "table build: more than 2^31 active records per mate");
       P.A[mt] = at; P.n_act[mt] = k;
-      HIP_TRY(c, B.wins[mt].reserve((2 * na + 8192) * sizeof(TbWin)));
+      HIP_TRY(c, B.wins[mt].reserve((2 * m.wins.size() + 16384) * sizeof(TbWin)));
       if (k) HIP_TRY(c, hipMemcpyAsync(B.wins[mt].p, hw, (size_t)k * sizeof(TbWin), hipMemcpyHostToDevice, st));
     }
     {
@@ -267,9 +277,14 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
       HIP_TRY(c, B.one[mt].reserve((size_t)n * sizeof(unsigned long long)));
       HIP_TRY(c, B.more[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.start[mt].reserve((size_t)n * sizeof(int)));
     }
-    {  // (room for half as many records again: a later build into these buffers then allocates nothing)
-      const int64_t As[2] = {A[0] + A[0] / 2 + 65536, A[1] + A[1] / 2 + 65536};
+    {  // (room for as many records again, at least a record per pair: a later build into these buffers then allocates nothing)
+      const int64_t As[2] = {std::max(A[0], paired_records_cap(s, 0)), std::max(A[1], paired_records_cap(s, 1))};
       if (int e = paired_reserve_tabledev(c, T, n, As)) return e;
+      for (int mt = 0; mt < 2; mt++) HIP_TRY(c, B.v_sorted[mt].reserve((size_t)As[mt] * sizeof(unsigned)));
+      const size_t maxAs = (size_t)std::max<int64_t>(std::max(As[0], As[1]), n);
+      HIP_TRY(c, B.k_in.reserve(maxAs * sizeof(rs_u64))); HIP_TRY(c, B.k_out.reserve(maxAs * sizeof(rs_u64))); HIP_TRY(c, B.k_tmp.reserve(maxAs * sizeof(rs_u64)));
+      HIP_TRY(c, B.v_in.reserve(maxAs * sizeof(unsigned))); HIP_TRY(c, B.v_tmp.reserve(maxAs * sizeof(unsigned)));
+      HIP_TRY(c, B.hist.reserve(rs_hist_bytes(maxAs)));
     }
     P.ins_n = paired_static_ins_n(c, s);
     P.none1 = (unsigned)s.mate[0].wins.size() + 1; P.none2 = (unsigned)s.mate[1].wins.size() + 1;
@@ -278,23 +293,30 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
   const int64_t* A = P.A;
   int* cnt = T.cnt.as<int>();
   auto grid = [](int64_t items) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, 4096))); };
-  for (int mt = 0; mt < 2; mt++) {
-    if (!in(1 + mt)) continue;  // slices 1 and 2: a mate's records ordered by read
-    HIP_TRY(c, hipMemsetAsync(B.rstart[mt].p, 0, (size_t)n * sizeof(int), st));
-    HIP_TRY(c, hipMemsetAsync(B.rend[mt].p, 0, (size_t)n * sizeof(int), st));
-    if (A[mt] == 0) continue;
-    hipLaunchKernelGGL(tb_keys_kernel, grid(A[mt]), dim3(256), 0, st, s.dev[mt].pool.as<int4>(), B.wins[mt].as<TbWin>(), P.n_act[mt], (int)A[mt], (int)n,
-                       B.k_in.as<rs_u64>(), B.v_in.as<unsigned>(), cnt + kTbDropped0 + mt);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), B.v_sorted[mt].as<unsigned>(), B.v_tmp.as<unsigned>(),
-                                 (size_t)A[mt], 0, bits_for((uint64_t)n), B.hist.as<unsigned>(), st));
-    hipLaunchKernelGGL(tb_segments_kernel, grid(A[mt]), dim3(256), 0, st, B.k_out.as<rs_u64>(), (int)A[mt], (int)n, B.rstart[mt].as<int>(), B.rend[mt].as<int>());
-    HIP_TRY(c, hipGetLastError());
+  const int read_bits = bits_for((uint64_t)n), read_passes = rs_passes(0, read_bits);
+  for (int mt = 0; mt < 2; mt++) {  // a mate's records ordered by read: keys, then a slice per pass of the sort, then the reads' runs
+    if (in()) {
+      HIP_TRY(c, hipMemsetAsync(B.rstart[mt].p, 0, (size_t)n * sizeof(int), st));
+      HIP_TRY(c, hipMemsetAsync(B.rend[mt].p, 0, (size_t)n * sizeof(int), st));
+      if (A[mt] > 0) {
+        hipLaunchKernelGGL(tb_keys_kernel, grid(A[mt]), dim3(256), 0, st, s.dev[mt].pool.as<int4>(), B.wins[mt].as<TbWin>(), P.n_act[mt], (int)A[mt], (int)n,
+                           B.k_in.as<rs_u64>(), B.v_in.as<unsigned>(), cnt + kTbDropped0 + mt);
+        HIP_TRY(c, hipGetLastError());
+      }
+    }
+    for (int ps = 0; ps < read_passes; ps++)
+      if (in() && A[mt] > 0)
+        HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), B.v_sorted[mt].as<unsigned>(), B.v_tmp.as<unsigned>(),
+                                     (size_t)A[mt], 0, read_bits, B.hist.as<unsigned>(), st, ps, ps));
+    if (in() && A[mt] > 0) {
+      hipLaunchKernelGGL(tb_segments_kernel, grid(A[mt]), dim3(256), 0, st, B.k_out.as<rs_u64>(), (int)A[mt], (int)n, B.rstart[mt].as<int>(), B.rend[mt].as<int>());
+      HIP_TRY(c, hipGetLastError());
+    }
   }
   const int ins_n = P.ins_n;
   const int memo_codes = (int)std::min<size_t>(s.pt.len_combo.size(), kMemoCodes);
   const int bits1 = bits_for(P.none1), bits2 = bits_for(P.none2);
-  if (in(3)) {  // classes and the pairs' sort keys
+  if (in()) {  // classes and the pairs' sort keys
     TbClassArgs ca;
     for (int mt = 0; mt < 2; mt++) {
       ca.pool[mt] = s.dev[mt].pool.as<int4>(); ca.vals[mt] = B.v_sorted[mt].as<unsigned>(); ca.rstart[mt] = B.rstart[mt].as<int>(); ca.rend[mt] = B.rend[mt].as<int>();
@@ -310,11 +332,11 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
                        (int)kFoldClass2Below, P.none1, P.none2, bits1, bits2, B.k_in.as<rs_u64>(), B.v_in.as<unsigned>(), cnt);
     HIP_TRY(c, hipGetLastError());
   }
-  if (in(4))  // the device order of the pairs
-    HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), T.read_of_slot.as<unsigned>(), B.v_tmp.as<unsigned>(), (size_t)n, 0,
-                                 3 + bits1 + bits2, B.hist.as<unsigned>(), st));
-  if (!in(5)) return 0;
-  {
+  for (int ps = 0; ps < rs_passes(0, 3 + bits1 + bits2); ps++)  // the device order of the pairs, a slice per pass
+    if (in())
+      HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), T.read_of_slot.as<unsigned>(), B.v_tmp.as<unsigned>(), (size_t)n, 0,
+                                   3 + bits1 + bits2, B.hist.as<unsigned>(), st, ps, ps));
+  if (in()) {
     TbCompactArgs ka;
     ka.order = T.read_of_slot.as<unsigned>();
     for (int mt = 0; mt < 2; mt++) {
@@ -329,6 +351,7 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
   }
   const unsigned tiles = P.tiles;
   for (int mt = 0; mt < 2; mt++) {
+    if (!in()) continue;
     hipLaunchKernelGGL(tb_scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, B.more[mt].as<int>(), cnt, (int)n, B.tiles.as<int>());
     hipLaunchKernelGGL(tb_scan_top_kernel, dim3(1), dim3(1024), 0, st, B.tiles.as<int>(), (int)tiles, cnt + kTbExtras0 + mt);
     hipLaunchKernelGGL(tb_scan_apply_kernel, dim3(tiles), dim3(256), 0, st, B.more[mt].as<int>(), cnt, (int)n, B.tiles.as<int>(), B.start[mt].as<int>());
@@ -339,11 +362,14 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
     hipLaunchKernelGGL(tb_fill16_kernel, grid(n), dim3(256), 0, st, fa);
     HIP_TRY(c, hipGetLastError());
   }
-  if (ins_n > 0) {
-    hipLaunchKernelGGL(tb_static_values_kernel, grid(n), dim3(256), 0, st, T.static_idx.as<int>(), cnt, s.memo.as<double2>(), T.static_val.as<double2>());
-    HIP_TRY(c, hipGetLastError());
+  if (in()) {
+    if (ins_n > 0) {
+      hipLaunchKernelGGL(tb_static_values_kernel, grid(n), dim3(256), 0, st, T.static_idx.as<int>(), cnt, s.memo.as<double2>(), T.static_val.as<double2>());
+      HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipMemcpyAsync(B.h_cnt.p, T.cnt.p, kTbInts * sizeof(int), hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(c, hipMemcpyAsync(B.h_cnt.p, T.cnt.p, kTbInts * sizeof(int), hipMemcpyDeviceToHost, st));
+  P.units = unit;
   return 0;
 }
 
@@ -436,12 +462,17 @@ int paired_delta_apply(gaml_hip_ctx* c, PairedSet& s, TableDev& T, std::vector<s
   a.dl_slot = s.dl_slot.as<int>(); a.dl_spill = s.dl_spill.as<int>(); a.sp_slot = s.sp_slot.as<int>();
   a.state = s.dstate.as<int>(); a.host_state = (int*)s.h_dstate.dev;
   a.cap_pairs = (int)s.delta_cap; a.cap_spill = (int)s.cap_spill; a.cap_sprec = (int)s.cap_sprec;
+  a.slot_bits = bits_for((uint64_t)s.mate[0].n_local());
   a.bins = s.dl_bins.as<unsigned long long>(); a.bin_count = s.dl_bin_count.as<int>(); a.blk_tot = s.dl_blk_tot.as<int>();
   int64_t all_records = 0;
   for (const auto& mw : wins) all_records += s.mate[mw.first].wins[mw.second].count;
   const bool multi_block = (all_records > 3000 || wins.size() > (size_t)kDlMaxWins) && KNOB(c, 22) != 1;  // knob 22 = 1: one-block launches only (A/B, tests)
   const int max_recs = multi_block ? kDlMbMaxRecs : kDlMaxRecs;
   std::vector<DlWin> big;  // a multi-block launch's window list when the argument block cannot hold it
+#ifdef GAML_HIP_DEV
+  static const bool stamp = getenv("GAML_DL_STAMPS") != nullptr;
+  if (stamp) { HIP_TRY(c, s.dl_stamps.reserve(64)); a.stamps = s.dl_stamps.as<unsigned long long>(); }
+#endif
   auto flush = [&]() -> int {
     if (a.n_wins == 0) return 0;
     a.seq = ++s.dl_seq;
@@ -463,6 +494,9 @@ int paired_delta_apply(gaml_hip_ctx* c, PairedSet& s, TableDev& T, std::vector<s
       hipLaunchKernelGGL((delta_apply_kernel<8, 1>), dim3(kDlBins), dim3(kDlThreads), 0, st, a);
       hipLaunchKernelGGL((delta_apply_kernel<8, 2>), dim3(kDlBins), dim3(kDlThreads), 0, st, a);
       HIP_TRY(c, hipGetLastError());
+#ifdef GAML_HIP_DEV
+      if (stamp) { const double t0 = now_us(); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "delta launch (multi-block) of %d records / %d windows: %.1f us until the stream is through\n", a.n_total, a.n_wins, now_us() - t0); }
+#endif
       s.nd_est += a.n_total;
       s.spill_may_grow = true;
       a.n_wins = 0; a.n_total = 0;
@@ -474,6 +508,15 @@ int paired_delta_apply(gaml_hip_ctx* c, PairedSet& s, TableDev& T, std::vector<s
     else if (a.n_total <= 4 * kDlThreads) hipLaunchKernelGGL(delta_apply_kernel<4>, dim3(1), dim3(kDlThreads), 0, st, a);
     else hipLaunchKernelGGL(delta_apply_kernel<8>, dim3(1), dim3(kDlThreads), 0, st, a);
     HIP_TRY(c, hipGetLastError());
+#ifdef GAML_HIP_DEV
+    if (stamp) {
+      unsigned long long z[8];
+      HIP_TRY(c, hipStreamSynchronize(st));
+      HIP_TRY(c, hipMemcpy(z, s.dl_stamps.p, sizeof(z), hipMemcpyDeviceToHost));
+      fprintf(stderr, "delta launch of %d records / %d windows: keys %.1f, sort %.1f, heads %.1f, scan %.1f, merge %.1f, counters %.1f us\n", a.n_total, a.n_wins, (z[1] - z[0]) * 0.01, (z[2] - z[1]) * 0.01,
+              (z[3] - z[2]) * 0.01, (z[4] - z[3]) * 0.01, (z[5] - z[4]) * 0.01, (z[6] - z[5]) * 0.01);
+    }
+#endif
     s.nd_est += a.n_total;
     s.spill_may_grow = true;
     a.n_wins = 0; a.n_total = 0;
@@ -501,6 +544,37 @@ int paired_delta_apply(gaml_hip_ctx* c, PairedSet& s, TableDev& T, std::vector<s
   }
   if (int e = flush()) return e;
   s.delta_updates++;
+  return 0;
+}
+
+// every maintenance kernel once, on no records (the counters keep their values): the first launch of a kernel costs the
+// runtime 50-150 us -- paid here, inside the first table build, not in the annealing call that first needs the variant
+int paired_warm_delta_kernels(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t st) {
+  DlArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int mt = 0; mt < 2; mt++) {
+    a.pool[mt] = s.dev[mt].pool.as<int4>();
+    a.rec8[mt] = T.rec8[mt].as<unsigned long long>(); a.first[mt] = T.first[mt].as<int4>(); a.extra[mt] = T.extra[mt].as<int4>();
+    a.dl_rec[mt] = s.dl_rec[mt].as<int4>(); a.sp_rng[mt] = s.sp_rng[mt].as<int2>(); a.sp_rec[mt] = s.sp_rec[mt].as<int4>();
+  }
+  a.inl0 = T.inl[0].as<int4>();
+  a.len_code = T.len_code.as<unsigned char>(); a.len_combo = s.len_combo_dev.as<unsigned>(); a.len12 = T.len12.as<unsigned>();
+  a.slot_of_read = T.slot_of_read.as<int>(); a.dirty_of_slot = T.dirty_of_slot.as<int>();
+  a.n0 = (int)T.class_count[0]; a.n01 = a.n0 + (int)T.class_count[1]; a.n_main = a.n01 + (int)T.class_count[2];
+  a.dl_slot = s.dl_slot.as<int>(); a.dl_spill = s.dl_spill.as<int>(); a.sp_slot = s.sp_slot.as<int>();
+  a.state = s.dstate.as<int>(); a.host_state = (int*)s.h_dstate.dev;
+  a.cap_pairs = (int)s.delta_cap; a.cap_spill = (int)s.cap_spill; a.cap_sprec = (int)s.cap_sprec;
+  a.bins = s.dl_bins.as<unsigned long long>(); a.bin_count = s.dl_bin_count.as<int>(); a.blk_tot = s.dl_blk_tot.as<int>();
+  a.seq = s.dl_seq;
+  hipLaunchKernelGGL(delta_apply_kernel<1>, dim3(1), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(delta_apply_kernel<2>, dim3(1), dim3(kDlThreads), 0, st, a);
+  hipLaunchKernelGGL(delta_apply_kernel<4>, dim3(1), dim3(kDlThreads), 0, st, a);
+  hipLaunchKernelGGL(delta_apply_kernel<8>, dim3(1), dim3(kDlThreads), 0, st, a);
+  hipLaunchKernelGGL(delta_mb_begin_kernel, dim3(1), dim3(64), 0, st, a.blk_tot);
+  hipLaunchKernelGGL(delta_mb_keys_kernel, dim3(1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((delta_apply_kernel<8, 1>), dim3(kDlBins), dim3(kDlThreads), 0, st, a);
+  hipLaunchKernelGGL((delta_apply_kernel<8, 2>), dim3(kDlBins), dim3(kDlThreads), 0, st, a);
+  HIP_TRY(c, hipGetLastError());
   return 0;
 }
 
@@ -548,9 +622,10 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   // Everything a later call would otherwise allocate (device allocations cost 0.1-3 ms each; an annealing run must not meet
   // them in the call that happens to activate a window or to start a rebuild): the spare set of table buffers with room
   // for half as many records again, the build's stream and events, the delta store (paired_delta_reset above)
+  if (!s.kernels_warm && s.mate[0].n_local() > 0) { if (int e = paired_warm_delta_kernels(c, s, s.tab, st)) return e; s.kernels_warm = true; }
   if (!rb.tab.rec8[0].p && KNOB(c, 14) != 1) {
-    const int64_t A2[2] = {s.mate[0].active_records + s.mate[0].active_records / 2 + 65536, s.mate[1].active_records + s.mate[1].active_records / 2 + 65536};
     const int64_t n = s.mate[0].n_local();
+    const int64_t A2[2] = {paired_records_cap(s, 0), paired_records_cap(s, 1)};
     if (int e = paired_reserve_tabledev(c, rb.tab, n, A2)) return e;
     BuildScratch& B = s.scratch;
     const size_t maxA = (size_t)std::max<int64_t>(std::max(A2[0], A2[1]), n);
@@ -584,6 +659,7 @@ int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   HIP_TRY(c, hipStreamWaitEvent(rb.stream, rb.mark, 0));
   if (int e = paired_build_enqueue(c, s, rb.tab, rb.stream, 0, 0)) return e;  // (the other slices: one per evaluation, paired_sync_tables)
   rb.next_slice = 1;
+  if (s.build_plan.units <= 1) HIP_TRY(c, hipEventRecord(rb.done, rb.stream));  // (an empty read set: nothing follows)
   rb.after.clear();
   rb.start_eval = s.eval_count;
   rb.active = true;
@@ -594,11 +670,11 @@ int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
 // the next slice of a build beside the evaluations (all that are left when `rest`)
 int paired_build_continue(gaml_hip_ctx* c, PairedSet& s, bool rest) {
   TableRebuild& rb = s.rebuild;
-  if (!rb.active || rb.next_slice >= kBuildSlices) return 0;
-  const int to = rest ? kBuildSlices - 1 : rb.next_slice;
+  if (!rb.active || rb.next_slice >= s.build_plan.units) return 0;
+  const int to = rest ? kBuildAll : rb.next_slice;
   if (int e = paired_build_enqueue(c, s, rb.tab, rb.stream, rb.next_slice, to)) return e;
-  rb.next_slice = to + 1;
-  if (rb.next_slice >= kBuildSlices) HIP_TRY(c, hipEventRecord(rb.done, rb.stream));
+  rb.next_slice = rest ? s.build_plan.units : to + 1;
+  if (rb.next_slice >= s.build_plan.units) HIP_TRY(c, hipEventRecord(rb.done, rb.stream));
   return 0;
 }
 

@@ -137,9 +137,11 @@ inline size_t rs_hist_bytes(size_t n) { return (size_t)256 * ((n + kRsTile - 1) 
 
 // keys_in / vals_in are left untouched; the result lands in keys_out / vals_out; keys_tmp / vals_tmp: n entries each
 // (vals_*: null for a key-only sort). Bits [begin_bit, end_bit) take part. Everything is enqueued on `st`.
+inline int rs_passes(int begin_bit, int end_bit) { return (end_bit - begin_bit + 7) / 8; }
+// pass_from / pass_to: enqueue only these passes of the sort (a caller that spreads the launches over several of its own steps)
 template <class V>
 inline hipError_t rs_sort(const rs_u64* keys_in, rs_u64* keys_out, rs_u64* keys_tmp, const V* vals_in, V* vals_out, V* vals_tmp, size_t n, int begin_bit, int end_bit,
-                          unsigned* hist, hipStream_t st) {
+                          unsigned* hist, hipStream_t st, int pass_from = 0, int pass_to = 1 << 30) {
   if (n == 0) return hipSuccess;
   if (n >= ((size_t)1 << 31)) return hipErrorInvalidValue;
   const bool has_v = vals_in != nullptr;
@@ -156,6 +158,7 @@ inline hipError_t rs_sort(const rs_u64* keys_in, rs_u64* keys_out, rs_u64* keys_
     const bool to_out = ((passes - 1 - p) & 1) == 0;  // the last pass writes the caller's output
     rs_u64* dst_k = to_out ? keys_out : keys_tmp;
     V* dst_v = to_out ? vals_out : vals_tmp;
+    if (p < pass_from || p > pass_to) { src_k = dst_k; src_v = dst_v; continue; }
     const int shift = begin_bit + 8 * p;
     const unsigned mask = (1u << (end_bit - shift < 8 ? end_bit - shift : 8)) - 1u;  // the last pass may hold fewer than eight bits
     hipLaunchKernelGGL(rs_histogram_kernel, dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, (unsigned)n, shift, mask, n_blocks, hist);
