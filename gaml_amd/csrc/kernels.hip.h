@@ -1798,14 +1798,100 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArg
   }
 }
 
-// Second launch, only for path sets in which some window occurs several times: one lane per table-class slot,
-// the lanes whose bit the main kernel set run the fully general loop. Partials go behind the main kernel's
-// (slots [part_base, part_base + gridDim.x)); fixed slot -> lane assignment, so the sums are reproducible.
+// One pair with up to four records per mate (table classes 1 and 2 through their inline copies, delta pairs at the fixed
+// stride) on windows that occur several times, in a lane: every load of a stage asked for before any is used -- the eight
+// records, their occurrence entries, the bounds of their occurrence lists, the lists' entries -- four dependent trips, where
+// the general loop (paired_general_src_masks) derives each candidate anew for every liveness test and every term: hundreds of
+// dependent chains for a read in a 5-copy repeat seen through two windows. The candidates sit in (private) arrays; more than
+// kGenCands on a mate: false, the caller takes the loop. Same candidates, same liveness rule, same terms in the same order.
+constexpr int kGenCands = 16;
+__device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const int4 (&r1)[4], const int4 (&r2)[4], int L1, int L2, double& acc_out) {
+  int4 cand[2][kGenCands];  // {path, position on the path, edit | orient << 8 | valid << 9, rank}; index = visiting order
+  int ck[2][kGenCands];     // the record the candidate came from (ties between equal ranks go by record)
+  int n[2] = {0, 0};
+  Occ12 e[2][4];
+  int lb[2][4], le[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int4& r = m == 0 ? r1[k] : r2[k]; e[m][k] = a.m[m].occ12[r.x >= 0 ? r.x : 0]; }
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int4& r = m == 0 ? r1[k] : r2[k];
+      const bool occurs = r.x >= 0 && !(e[m][k].lo == ~0u && e[m][k].hi == ~0u);
+      const bool list = occurs && e[m][k].rank < 0;
+      lb[m][k] = le[m][k] = 0;
+      if (list) { const int s = -e[m][k].rank - 1; lb[m][k] = a.m[m].multi_off[s]; le[m][k] = a.m[m].multi_off[s + 1]; }
+      else if (occurs) le[m][k] = -1;  // one occurrence, described by the entry itself
+    }
+  bool fits = true;
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int4& r = m == 0 ? r1[k] : r2[k];
+      if (le[m][k] == -1) {
+        if (n[m] < kGenCands) {
+          const int4 o = occ_from_compact((unsigned long long)e[m][k].lo | ((unsigned long long)e[m][k].hi << 32), e[m][k].rank);
+          cand[m][n[m]] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | (r.y >= o.y ? 0x200 : 0), o.w);
+          ck[m][n[m]] = k;
+        }
+        n[m]++;
+      } else {
+        for (int q = lb[m][k]; q < le[m][k]; q++) {
+          if (n[m] < kGenCands) {
+            const int4 o = a.m[m].multi[q];
+            cand[m][n[m]] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | (r.y >= o.y ? 0x200 : 0), o.w);
+            ck[m][n[m]] = k;
+          }
+          n[m]++;
+        }
+      }
+    }
+    fits = fits && n[m] <= kGenCands;
+  }
+  if (!fits) return false;
+  // liveness (graph.cc:583-592): valid, and no later valid candidate of the mate at the same (path, position)
+  unsigned live[2] = {0, 0};
+  for (int m = 0; m < 2; m++)
+    for (int x = 0; x < n[m]; x++) {
+      const int4 me = cand[m][x];
+      bool lv = (me.z & 0x200) != 0;
+      for (int y = 0; y < n[m] && lv; y++) {
+        const int4 ot = cand[m][y];
+        if (y != x && (ot.z & 0x200) && ot.x == me.x && ot.y == me.y && (ot.w > me.w || (ot.w == me.w && ck[m][y] > ck[m][x]))) lv = false;
+      }
+      if (lv) live[m] |= 1u << x;
+    }
+  double acc = 0.0;
+  for (int x = 0; x < n[0]; x++) {
+    if (!((live[0] >> x) & 1u)) continue;
+    const int4 cx = cand[0][x];
+    Cand X; X.path = cx.x; X.pos = cx.y; X.edit = cx.z & 0xff; X.orient = (cx.z >> 8) & 1;
+    for (int y = 0; y < n[1]; y++) {
+      if (!((live[1] >> y) & 1u)) continue;
+      const int4 cy = cand[1][y];
+      if (cy.x != cx.x) continue;
+      Cand Y; Y.path = cy.x; Y.pos = cy.y; Y.edit = cy.z & 0xff; Y.orient = (cy.z >> 8) & 1;
+      acc += pair_term(a, X, Y, L1, L2);
+    }
+  }
+  acc_out = acc;
+  return true;
+}
+
+// Second launch, only for path sets in which some window occurs several times: one lane per table-class slot and per
+// delta pair, the lanes whose bit the main kernel set score their pair -- the compact class from both occurrence lists in
+// registers (compact_general), pairs with several records through general_pair_staged. Partials go behind the main
+// kernel's (slots [part_base, part_base + gridDim.x)); fixed slot -> lane assignment, so the sums are reproducible.
 __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, int part_base) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
   double lsum = 0.0;
   int zeros = 0;
+  const int4 none = make_int4(-1, 0, 0, 0);
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_main; i += gridDim.x * kBlock) {
     const int cls = i < a.n0 ? 0 : (i < a.n01 ? 1 : 2);
     const bool part_b = i >= a.n0a;  // class 0, second part (its notes start at a word of their own)
@@ -1820,7 +1906,12 @@ __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, in
     else {
       const uint32_t l12 = a.len12[i - a.n0];
       const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-      const double acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
+      const size_t at = cls == 1 ? (size_t)2 * (i - a.n0) : (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01);
+      int4 r1[4], r2[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const bool has = cls == 2 || k < 2; r1[k] = has ? a.inl[0][at + (has ? k : 0)] : none; r2[k] = has ? a.inl[1][at + (has ? k : 0)] : none; }
+      double acc;
+      if (!general_pair_staged(a, r1, r2, L1, L2, acc)) acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
       finish_read(a, i, acc, L1, L2, lsum, zeros);
     }
   }
@@ -1830,10 +1921,15 @@ __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, in
 #ifdef GAML_GEN_X
     if (GAML_GEN_X & 4) continue;
 #endif
-    const int4 h0 = a.dirty_recs[0][4 * (size_t)dj], h1 = a.dirty_recs[1][4 * (size_t)dj];
-    const uint32_t l12 = (uint32_t)h0.w;
+    int4 r1[4], r2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { r1[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r2[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
+    const uint32_t l12 = (uint32_t)r1[0].w;
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-    const double acc = paired_general_src_masks(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, h1.w & 0xff}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, (h1.w >> 8) & 0xff}, L1, L2);
+    const int c0 = r2[0].w & 0xff, c1 = (r2[0].w >> 8) & 0xff;
+    double acc;
+    if (!general_pair_staged(a, r1, r2, L1, L2, acc))
+      acc = paired_general_src_masks(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
     finish_read(a, a.dirty_slots[dj], acc, L1, L2, lsum, zeros);
   }
   block_reduce(lsum, zeros, sh_s, sh_z);

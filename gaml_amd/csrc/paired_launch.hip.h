@@ -457,6 +457,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   if (int e = paired_sync_tables(c, s, st)) return e;  // cold path: nothing to do on a warm cache
   const double tp1 = now_us();
   c->prof[4] = tp1 - t_after_host;
+  if (tp1 - t_after_host > 1000.0 && getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "table sync took %.0f us (evaluation %lld of the set, rebuild active %d slice %d)\n", tp1 - t_after_host, (long long)s.eval_count, (int)s.rebuild.active, s.rebuild.next_slice);
 
   const bool cov = s.cfg.penalty_constant > 0;
   const int tl = total_len == 0 ? 1 : total_len;

@@ -264,21 +264,21 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
       if (nw0) HIP_TRY(c, hipMemcpyAsync(B.peer0.p, hp, nw0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
     const int64_t* A = P.A;
-    const size_t maxA = (size_t)std::max<int64_t>(std::max(A[0], A[1]), n);
-    HIP_TRY(c, B.k_in.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_out.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_tmp.reserve(maxA * sizeof(rs_u64)));
-    HIP_TRY(c, B.v_in.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.v_tmp.reserve(maxA * sizeof(unsigned)));
-    HIP_TRY(c, B.hist.reserve(rs_hist_bytes(maxA)));
     HIP_TRY(c, B.cl.reserve((size_t)n)); HIP_TRY(c, B.sidx.reserve((size_t)n * sizeof(int)));
     P.tiles = (unsigned)((n + kTbScanTile - 1) / kTbScanTile);
     HIP_TRY(c, B.tiles.reserve((size_t)P.tiles * sizeof(int)));
     for (int mt = 0; mt < 2; mt++) {
-      HIP_TRY(c, B.v_sorted[mt].reserve(std::max<size_t>(1, (size_t)A[mt]) * sizeof(unsigned)));
       HIP_TRY(c, B.rstart[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.rend[mt].reserve((size_t)n * sizeof(int)));
       HIP_TRY(c, B.one[mt].reserve((size_t)n * sizeof(unsigned long long)));
       HIP_TRY(c, B.more[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.start[mt].reserve((size_t)n * sizeof(int)));
     }
-    {  // (room for as many records again, at least a record per pair: a later build into these buffers then allocates nothing)
-      const int64_t As[2] = {std::max(A[0], paired_records_cap(s, 0)), std::max(A[1], paired_records_cap(s, 1))};
+    {  // what exists is kept when it is large enough; what has to grow grows to the pool's size and a quarter (paired_records_cap)
+      const size_t inl_need = (size_t)std::min<int64_t>(4 * n, 3 * (A[0] + A[1]) + 4) * sizeof(int4);
+      bool fits = T.rec8[0].p != nullptr && T.inl[0].cap >= inl_need && T.inl[1].cap >= inl_need;
+      for (int mt = 0; mt < 2; mt++) fits = fits && T.extra[mt].cap >= (size_t)A[mt] * sizeof(int4) && B.v_sorted[mt].cap >= (size_t)A[mt] * sizeof(unsigned);
+      const size_t maxA0 = (size_t)std::max<int64_t>(std::max(A[0], A[1]), n);
+      fits = fits && B.k_in.cap >= maxA0 * sizeof(rs_u64) && B.hist.cap >= rs_hist_bytes(maxA0);
+      const int64_t As[2] = {fits ? A[0] : std::max(A[0], paired_records_cap(s, 0)), fits ? A[1] : std::max(A[1], paired_records_cap(s, 1))};
       if (int e = paired_reserve_tabledev(c, T, n, As)) return e;
       for (int mt = 0; mt < 2; mt++) HIP_TRY(c, B.v_sorted[mt].reserve((size_t)As[mt] * sizeof(unsigned)));
       const size_t maxAs = (size_t)std::max<int64_t>(std::max(As[0], As[1]), n);
