@@ -464,6 +464,173 @@ def repeats_block(api, synth, device, sa_iters=5000):
     return out
 
 
+def jumping_block(api, synth, device, oracle_sets=2):
+    """The reference's own example configuration has a jumping library (example.cfg:20-29: insert 3700 +- 350,
+    penalty_constant 0.00013, penalty_step 3000, min_prob_start -80). Untimed for the headline: pair classes, the static
+    share of the compact class, kernel and step time through the 8 rotating path sets, and the likelihood + bad_bases
+    against the CPU oracle on ALL pairs."""
+    wl = synth.WORKLOADS["cfg3j"]
+    genome, g = wl.build()
+    pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl.insert_std, wl.err, wl.seed)
+    gb, go = g.packed()
+    r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
+    kw = dict(penalty_constant=0.00013, penalty_step=3000.0, min_prob_start=-80.0)  # (min_prob_per_base stays -0.7: gaml.cc:855 reads another key)
+    ctx = api.Context(device=device)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std, **kw), *r1, *r2)
+    walk = synth.genome_walk(g)
+    variants_py = path_variants(walk)
+    variants = [api.FlatPaths(v) for v in variants_py]
+    t0 = time.perf_counter()
+    vals = [ctx.calc_prob(v) for v in variants_py]
+    cold_s = time.perf_counter() - t0
+    bad = []
+    for v in variants_py[:oracle_sets]:
+        ctx.calc_prob(v)
+        bad.append(ctx.bad_bases(rs))
+    ctx.compact_tables()
+    for _ in range(2):
+        for v in variants:
+            ctx.score(v)
+    gc.disable()
+    t0 = time.perf_counter()
+    n = 400
+    for i in range(n):
+        ctx.score(variants[i % 8])
+    step_us = (time.perf_counter() - t0) / n * 1e6
+    gc.enable()
+    ctx.set_event_timing(1)
+    ctx.kernel_stats(reset=True)
+    prof = []
+    for i in range(128):
+        ctx.score(variants[i % 8])
+        prof.append(ctx.last_phases())
+    ks = ctx.kernel_stats(reset=True)
+    ctx.set_event_timing(False)
+    ph = np.median(np.array(prof), axis=0)
+    classes = [int(x) for x in ctx.pair_classes(rs)]
+    st = ctx.table_stats(rs)
+    out = {"workload": wl.name, "pairs": wl.n_pairs, "config": dict(kw, insert_mean=wl.insert_mean, insert_std=wl.insert_std, min_prob_per_base=-0.7),
+           "pair_classes_le1_le2_le4_more": classes, "static_pairs": st["static_index_pairs"],
+           "static_fraction_of_compact_class": st["static_index_pairs"] / max(1, classes[0]),
+           "cold_8_sets_s": cold_s, "step_us": step_us, "reads_per_sec": 2.0 * wl.n_pairs / (step_us * 1e-6),
+           "scoring_kernel_us": ks["device_us"] / max(1, ks["launches"]), "algo_bytes_per_launch": ks["algo_bytes"] / max(1, ks["launches"]),
+           "step_phases_us": {"planning": float(ph[0]), "tables": float(ph[1]), "write": float(ph[3]), "launch": float(ph[5]), "wait": float(ph[7])},
+           "note": "penalty_constant > 0: every call plans the whole path set, marks coverage (atomics into a bitmap) and runs coverage_sweep_kernel behind the scoring launch"}
+    ctx.close()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    ors = orc.add_paired(*r1, *r2, wl.err, op.paired_cfg(wl.insert_mean, wl.insert_std, **kw))
+    t0 = time.time()
+    worst, bad_ok = 0.0, True
+    for k, v in enumerate(variants_py[:oracle_sets]):
+        want, wz, wtl = orc.calc_prob(v, fresh=True)
+        worst = max(worst, abs(vals[k][0] - want) / abs(want))
+        bad_ok = bad_ok and vals[k][1].tolist() == wz.tolist() and bad[k] == orc.paired_probs(ors)[1]
+    out["ll_max_rel_delta_vs_cpu"] = worst
+    out["floored_counts_and_bad_bases_equal_cpu"] = bool(bad_ok)
+    out["ll_delta_pairs"] = wl.n_pairs
+    out["cpu_oracle_s"] = time.time() - t0
+    return out
+
+
+def aligner_block(api, synth, device, g, gb, go, b1, o1, b2, o2, cfg, read_len, sa_iters=300):
+    """SURVEY 8(d)'s separate figure for GPU window alignment: L read bytes + a 16-byte record per seed candidate. A fresh
+    context: the cold batch (every window of the start assembly, both mates) and the small batches of an annealing walk
+    (a move's new junction windows, both mates in one pipeline). Times are the host's clock around the aligner (window
+    strings, launches, the device pipeline, the wait); the kernels' own durations are in profiles/ (rocprofv3 rows
+    span_maxima_kernel / candidates_kernel / extend_kernel: cold; span_cands_kernel / extend_pair2_kernel / aln_file_small_kernel: small)."""
+    ctx = api.Context(device=device)
+    ctx.set_graph(gb, go)
+    ctx.add_paired(api.paired_cfg(*cfg), b1, o1, b2, o2)
+    start, seq = synth.sa_sequence(g, sa_iters)
+    t0 = time.perf_counter()
+    ctx.calc_prob(start)
+    cold_call_s = time.perf_counter() - t0
+    a0 = ctx.aligner_stats()
+    s0 = ctx.aligner_stages()
+    for p in seq:
+        ctx.score(api.FlatPaths(p))
+    a1 = ctx.aligner_stats()
+    s1 = ctx.aligner_stages()
+    ctx.close()
+    per_cand = read_len + 16
+    def row(w, k, us, batches):
+        return {"windows": w, "candidates": k, "batches": batches, "aligner_us": us, "us_per_batch": us / max(1, batches),
+                "candidates_per_sec": k / max(1e-9, us * 1e-6), "algo_bytes": k * per_cand,
+                "GB_per_s": k * per_cand / max(1e-9, us * 1e-6) / 1e9, "frac_of_hbm_peak": k * per_cand / max(1e-9, us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    cold = row(a0["windows"], a0["candidates"], a0["us"], s0["batches"])
+    cold["stages_us"] = {k: s0[k] for k in ("strings_upload", "spans_candidates", "extension", "hits_d2h", "sort_file")}
+    cold["first_call_cold_s"] = cold_call_s
+    small = row(a1["windows"] - a0["windows"], a1["candidates"] - a0["candidates"], a1["us"] - a0["us"], s1["batches"] - s0["batches"])
+    small["stages_us"] = {k: s1[k] - s0[k] for k in ("strings_upload", "spans_candidates", "extension", "hits_d2h", "sort_file")}
+    return {"bytes_per_candidate": per_cand, "formula": "L read bytes + 16-byte record per seed candidate (SURVEY 8d); window bases staged in LDS, amortised",
+            "cold_batch": cold, "small_batches": small,
+            "note": "latency-bound, not bandwidth-bound: a small batch lasts as long as its slowest candidate's chain of LDS steps (extension) plus three dispatches; "
+                    "the records stay in HBM (filed on the device), the host receives the windows' headers"}
+
+
+def sa_long_block(api, synth, device, g, gb, go, b1, o1, b2, o2, cfg, read_len, iters=10000, sample=50_000, t0_temp=0.008):
+    """A long annealing run with the reference's accept rule (example.cfg:3 max_iterations 10000): a move is accepted iff the
+    GPU value improves; a worse one only after BreakPath, with probability exp((new - cur) / T), T = t0 / log(it + 1)
+    (gaml.cc:274, 286, 304-311). Per 1,000 calls: median / p90 / max of the call, pairs on the delta lists, take-overs.
+    At the end the final assembly's likelihood on the first 50,000 pairs against the CPU oracle (fresh state)."""
+    ctx = api.Context(device=device)
+    ctx.set_graph(gb, go)
+    rs = ctx.add_paired(api.paired_cfg(*cfg), b1, o1, b2, o2)
+    walk = synth.genome_walk(g)
+    cur = [[x] for x in walk if g.node_len(x) > 500]
+    cur_val = ctx.calc_prob(cur)[0]
+    rng = np.random.default_rng(11)
+    per = np.zeros(iters)
+    accepted = 0
+    windows = []
+    st_prev = ctx.table_stats(rs)
+    gc.disable()
+    for it in range(iters):
+        new, kind = synth.sa_move_kind(rng, cur, g)
+        fp = api.FlatPaths(new)
+        t1 = time.perf_counter()
+        v = ctx.score(fp)
+        per[it] = time.perf_counter() - t1
+        temp = t0_temp / np.log(it + 2.0)
+        if v > cur_val or (kind == 0 and rng.random() < np.exp((v - cur_val) / temp)):
+            cur, cur_val = new, v
+            accepted += 1
+        if (it + 1) % 1000 == 0:
+            w = per[it - 999:it + 1] * 1e6
+            st = ctx.table_stats(rs)
+            windows.append({"calls": [it - 999, it + 1], "us_median": float(np.median(w)), "us_p90": float(np.percentile(w, 90)), "us_max": float(w.max()),
+                            "delta_pairs": st["dirty_pairs"], "take_overs": st["worker_rebuilds"] - st_prev["worker_rebuilds"],
+                            "table_rebuilds": st["full_rebuilds"] - st_prev["full_rebuilds"], "paths": len(cur)})
+            st_prev = st
+    gc.enable()
+    final_val = ctx.calc_prob(cur)[0]
+    out = {"iterations": iters, "accept_rule": "new > cur; Metropolis exp((new - cur) / T), T = 0.008 / log(it + 1), after BreakPath only (gaml.cc:274, 286, 304-311)",
+           "accepted": accepted, "paths_at_end": len(cur), "total_s": float(per.sum()), "windows": windows,
+           "last_over_first_median": windows[-1]["us_median"] / windows[0]["us_median"], "log_likelihood_start_end": [float(ctx.calc_prob([[x] for x in walk if g.node_len(x) > 500])[0]), float(final_val)]}
+    ctx.close()
+    # the final assembly on the first `sample` pairs: GPU (a context of its own) against the CPU oracle
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    nb = sample * read_len
+    c2 = api.Context(device=device)
+    c2.set_graph(gb, go)
+    c2.add_paired(api.paired_cfg(*cfg), b1[:nb], o1[:sample + 1], b2[:nb], o2[:sample + 1])
+    got = c2.calc_prob(cur)
+    c2.close()
+    orc = op.Oracle()
+    orc.set_graph(gb, go)
+    orc.add_paired(b1[:nb], o1[:sample + 1], b2[:nb], o2[:sample + 1], 0.01, op.paired_cfg(*cfg))
+    want, wz, wtl = orc.calc_prob(cur, fresh=True)
+    out["end_state_ll_rel_delta_vs_cpu"] = abs(got[0] - want) / abs(want)
+    out["end_state_floored_equal"] = bool(got[1].tolist() == wz.tolist() and got[2] == wtl)
+    out["end_state_pairs_checked"] = sample
+    return out
+
+
 def inproc_child(args):
     """`--inproc-devices 0,1,..`: ONE process, one context over those devices (gaml_hip_create_multi) -- what a gaml.cc
     linked against the adapter header runs. Same read set and steps as the headline; prints its own JSON line."""
@@ -505,6 +672,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sa", action="store_true", help="skip the annealing-pattern block (N = 1)")
     ap.add_argument("--no-repeats", action="store_true", help="skip the repeat-rich block (N = 1)")
+    ap.add_argument("--no-long", action="store_true", help="skip the jumping-library, aligner and long-annealing blocks (N = 1)")
+    ap.add_argument("--sa-long-iters", type=int, default=10000)
     ap.add_argument("--no-extras", action="store_true", help="timed region only (no kernel-timing pass, batch or annealing block): "
                     "what the rocprofv3 --pmc passes run, so that the last --steps dispatches are the timed steps")
     ap.add_argument("--sa-iters", type=int, default=1000)
@@ -842,9 +1011,14 @@ def main():
                 warm = sa_pattern(ctx, rs, g, args.sa_iters, api, synth)
                 out["sa_pattern"]["warm_context"] = {k: warm[k] for k in ("total_s", "us_median", "us_p90", "us_p99", "us_max", "aligning_call_us_median", "other_calls_us_p99")}
                 out["batched_candidates"] = batched_candidates(ctx, g, api, synth)
+        if not use_dist and not args.no_extras and not args.no_long and args.workload == "cfg3":
+            out["aligner"] = aligner_block(api, synth, local_rank, g, gb, go, b1, o1, b2, o2, cfg, wl.read_len)
+            out["sa_long"] = sa_long_block(api, synth, local_rank, g, gb, go, b1, o1, b2, o2, cfg, wl.read_len, iters=args.sa_long_iters)
         if not use_dist and not args.no_extras and not args.no_repeats and not args.no_cpu_baseline:
             ctx.close()  # (the headline context's tables: ~100 MB of device memory back before two more read sets are built)
             out["repeats"] = repeats_block(api, synth, local_rank)
+            if not args.no_long:
+                out["jumping"] = jumping_block(api, synth, local_rank)
             out["incremental_drift"] = drift_block(api, synth, local_rank, g, b1, o1, b2, o2, wl.read_len, cfg)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is taken on rank 0 at N = 1 only
             pairs = min(args.cpu_sample_pairs or wl.n_pairs, wl.n_pairs)

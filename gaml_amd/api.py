@@ -226,6 +226,7 @@ def _load():
     if hasattr(L, "gaml_hip_general_stats"):
         L.gaml_hip_general_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.gaml_hip_aligner_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.gaml_hip_aligner_stages.argtypes = [vp, _f64p]
     L.gaml_hip_last_timing.argtypes = [vp, _f64p]
     L.gaml_hip_set_event_timing.argtypes = [vp, C.c_int]
     L.gaml_hip_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -695,6 +696,12 @@ class Context:
         w, k, us = C.c_int64(), C.c_int64(), C.c_double()
         _lib.gaml_hip_aligner_stats(self._h, C.byref(w), C.byref(k), C.byref(us))
         return {"windows": w.value, "candidates": k.value, "us": us.value}
+
+    def aligner_stages(self):
+        """Host-clock time of the GPU aligner by stage (us, cumulative) and the number of batches."""
+        out = np.zeros(6, np.float64)
+        self._check(_lib.gaml_hip_aligner_stages(self._h, out))
+        return {"strings_upload": out[0], "spans_candidates": out[1], "extension": out[2], "hits_d2h": out[3], "sort_file": out[4], "batches": int(out[5])}
 
     def last_phases(self):
         out = np.zeros(8, np.float64)

@@ -112,3 +112,36 @@ __global__ __launch_bounds__(kFileThreads) void aln_file_small_kernel(AlnFileArg
 }
 
 }  // namespace gaml
+
+namespace gaml {
+
+// ---- large batches (the cold first evaluation: every window of the start assembly, millions of hits) -------------------------
+// The hits are already ordered on the device by (window, position, read, strand, order) with the failed extensions last
+// (two stable radix sorts, aligner_launch.hip.h). Filing them there too: a flag per hit "first of its (window, position,
+// read)" (graph.cc:841, 891, 895-897), an exclusive prefix sum of the flags (table_build.hip.h's scan), then the survivors
+// written into the mate's pool and counted per window -- instead of 67 MB of hits to the host, 20 ms of host filing and
+// the records back up into the pool.
+__global__ __launch_bounds__(256) void aln_file_flags_kernel(const AlnHit* hits, const unsigned* n_ok, unsigned n, int* flags) {
+  const unsigned ok = *n_ok;
+  for (unsigned t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+    int f = 0;
+    if (t < ok) {
+      const AlnHit h = hits[t];
+      f = 1;
+      if (t > 0) { const AlnHit p = hits[t - 1]; f = !(p.win == h.win && p.pos == h.pos && p.read == h.read); }
+    }
+    flags[t] = f;
+  }
+}
+__global__ __launch_bounds__(256) void aln_file_write_kernel(const AlnHit* hits, const int* flags, const int* place, unsigned n, int4* pool, int base, const int* wid_of,
+                                                            int* win_cnt, int* win_max) {
+  for (unsigned t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+    if (!flags[t]) continue;
+    const AlnHit h = hits[t];
+    pool[base + place[t]] = make_int4(wid_of[h.win], h.pos, (h.edit & 0xff) | ((h.strand & 1) << 8), h.read);
+    atomicAdd(&win_cnt[h.win], 1);
+    atomicMax(&win_max[h.win], h.pos);
+  }
+}
+
+}  // namespace gaml

@@ -562,7 +562,7 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
 
 // `small`: this mate's small-batch buffers (null: general route only); `job`: strings already built and possibly the
 // small-batch pipeline already in flight (eval_begin starts both mates' pipelines before it waits for either)
-int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* small = nullptr, AlnJob* job_in = nullptr) {
+int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* small = nullptr, AlnJob* job_in = nullptr, PairedSet* ps = nullptr, int mt = 0) {
   if (m.pending.empty()) return 0;
   if (!aln_gpu_capable(c, m)) {
     m.flush_pending_cpu(c->g);
@@ -667,6 +667,55 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
       unsigned ok_count = 0;
       HIP_TRY(c, hipMemcpy(&ok_count, n_ok, sizeof(unsigned), hipMemcpyDeviceToHost));
       if (KNOB(c, 9)) t3 = now_us();
+      if (ps && KNOB(c, 5) != 6 && ok_count > 0 && n < ((size_t)1 << 30)) {
+        // filed on the device: survivors flagged, placed by a prefix sum, written into this mate's pool; the windows' headers come back
+        MateDev& md = ps->dev[mt];
+        if (int e = pool_mirror(c, *ps, (hipStream_t)0)) return e;  // (windows the host filed earlier come first in the pool)
+        if (int e = pool_reserve(c, *ps, mt, md.pool_n + (int64_t)ok_count)) return e;
+        const unsigned tiles = (unsigned)((n + kTbScanTile - 1) / kTbScanTile);
+        // scratch: flags | places | tile sums | window ids | per-window counts | maxima | a zero word + the total
+        HIP_TRY(c, S.file_tmp.reserve((2 * n + tiles + 3 * (size_t)nw + 16) * sizeof(int)));
+        int* flags = S.file_tmp.as<int>();
+        int* place = flags + n;
+        int* tile_sum = place + n;
+        int* wid_of = tile_sum + tiles;
+        int* win_cnt = wid_of + nw;
+        int* win_max = win_cnt + nw;
+        int* zero = win_max + nw;  // [0] zero (the scan's "slots before"), [1] the number of survivors
+        std::vector<int> init((size_t)3 * nw + 16, 0);
+        for (int k = 0; k < nw; k++) { init[(size_t)k] = m.pending[(size_t)k]; init[(size_t)2 * nw + k] = INT_MIN; }
+        HIP_TRY(c, hipMemcpy(wid_of, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(aln_file_flags_kernel, dim3(grid), dim3(256), 0, 0, S.hits_sorted.as<AlnHit>(), n_ok, (unsigned)n, flags);
+        // (tb_scan_*: exclusive prefix of n ints, "n - cnt[kTbClass0]" entries: `zero` stands in for the counters)
+        hipLaunchKernelGGL(tb_scan_tiles_kernel, dim3(tiles), dim3(256), 0, 0, flags, zero - kTbClass0, (int)n, tile_sum);
+        hipLaunchKernelGGL(tb_scan_top_kernel, dim3(1), dim3(1024), 0, 0, tile_sum, (int)tiles, zero + 1);
+        hipLaunchKernelGGL(tb_scan_apply_kernel, dim3(tiles), dim3(256), 0, 0, flags, zero - kTbClass0, (int)n, tile_sum, place);
+        hipLaunchKernelGGL(aln_file_write_kernel, dim3(grid), dim3(256), 0, 0, S.hits_sorted.as<AlnHit>(), flags, place, (unsigned)n, md.pool.as<int4>(), (int)md.pool_n, wid_of, win_cnt, win_max);
+        HIP_TRY(c, hipGetLastError());
+        std::vector<int> back((size_t)2 * nw + 2);
+        HIP_TRY(c, hipMemcpy(back.data(), win_cnt, back.size() * sizeof(int), hipMemcpyDeviceToHost));
+        int64_t at = md.pool_n;
+        for (int k = 0; k < nw; k++) {
+          Window& w = m.wins[(size_t)m.pending[(size_t)k]];
+          w.first = -1;  // its records exist in the device pool only
+          w.dfirst = at;
+          w.count = back[(size_t)k];
+          w.max_pos = w.count ? back[(size_t)nw + k] : INT_MIN;
+          w.global_max_pos = w.max_pos;
+          w.pending = false;
+          at += w.count;
+        }
+        if (at - md.pool_n != (int64_t)back[(size_t)2 * nw + 1]) return fail(c, GAML_HIP_ESTATE, "aligner: the filed records do not add up to the windows' counts");
+        md.pool_n = at;
+        m.pending.clear();
+        c->aln_windows += nw;
+        c->aln_candidates += nc;
+        const double t5 = now_us();
+        c->aln_us += t5 - t0;
+        c->aln_stage_us[0] += t1 - t0; c->aln_stage_us[1] += t2 - t1; c->aln_stage_us[2] += t5 - t2;
+        c->aln_batches++;
+        return 0;
+      }
       hits.resize(ok_count);
       if (ok_count) HIP_TRY(c, hipMemcpy(hits.data(), S.hits_sorted.p, (size_t)ok_count * sizeof(AlnHit), hipMemcpyDeviceToHost));
       device_sorted = true;
@@ -708,7 +757,7 @@ int align_pending_pair(gaml_hip_ctx* c, PairedSet& ps) {
     }
   }
   for (int mt = 0; mt < 2; mt++)
-    if (int e = gpu_align_pending(c, ps.mate[mt], ps.dev[mt].aln, c->device >= 0 ? &c->aln_small[mt] : nullptr, &job[mt])) return e;
+    if (int e = gpu_align_pending(c, ps.mate[mt], ps.dev[mt].aln, c->device >= 0 ? &c->aln_small[mt] : nullptr, &job[mt], c->device >= 0 ? &ps : nullptr, mt)) return e;
   return 0;
 }
 

@@ -138,9 +138,9 @@ struct AlignDev {  // device copies the GPU aligner needs: reads (1 byte per bas
 };
 struct AlignScratch {  // per context, grown on demand
   DevBuf wstr, wins, blk, spans, cands, hits, counters;
-  DevBuf sort_keys, sort_idx, sort_tmp, hits_sorted;  // large batches: hits ordered on the device
+  DevBuf sort_keys, sort_idx, sort_tmp, hits_sorted, file_tmp;  // large batches: hits ordered (and filed) on the device
   void release() { wstr.release(); wins.release(); blk.release(); spans.release(); cands.release(); hits.release(); counters.release();
-                   sort_keys.release(); sort_idx.release(); sort_tmp.release(); hits_sorted.release(); }
+                   sort_keys.release(); sort_idx.release(); sort_tmp.release(); hits_sorted.release(); file_tmp.release(); }
 };
 
 // small batches (aln_small_*): one set of buffers per mate, so that the two mates' pipelines run side by side. Input

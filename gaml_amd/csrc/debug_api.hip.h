@@ -115,6 +115,7 @@ int gaml_hip_debug_fold_check(gaml_hip_ctx* c, int rs, int64_t* out6) {
   MULTI_SHARD0(c);
   if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out6) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
+  for (int mt = 0; mt < 2; mt++) for (const Window& w : s.mate[mt].wins) if (w.first < 0 && w.count > 0) return fail(c, GAML_HIP_ESTATE, "host-only check: some windows' records exist in the device pool only (use gaml_hip_debug_tables_check)");
   PairTables with, without;
   build_pair_tables(s.mate[0], s.mate[1], with, true);
   build_pair_tables(s.mate[0], s.mate[1], without, false);
@@ -191,6 +192,7 @@ int gaml_hip_debug_static_check(gaml_hip_ctx* c, int rs, int64_t* out8) {
   MULTI_SHARD0(c);
   if (!c || rs < 0 || rs >= (int)c->handles.size() || c->handles[rs].kind != 1 || !out8) return fail(c, GAML_HIP_EINVAL, "bad arguments");
   PairedSet& s = *c->paireds[c->handles[rs].idx];
+  for (int mt = 0; mt < 2; mt++) for (const Window& w : s.mate[mt].wins) if (w.first < 0 && w.count > 0) return fail(c, GAML_HIP_ESTATE, "host-only check: some windows' records exist in the device pool only (use gaml_hip_debug_tables_check)");
   if (int e = paired_host_tabs(c, s)) return e;
   const int ins_n = (int)s.ins_tab.size();
   link_mate_windows(s.mate[0], s.mate[1]);

@@ -1372,6 +1372,14 @@ int gaml_hip_aligner_stats(gaml_hip_ctx* c, int64_t* windows, int64_t* candidate
   return GAML_HIP_OK;
 }
 
+int gaml_hip_aligner_stages(gaml_hip_ctx* c, double* out6) {
+  if (!c || !out6) return GAML_HIP_EINVAL;
+  MULTI_SHARD0(c);
+  for (int k = 0; k < 5; k++) out6[k] = c->aln_stage_us[k];
+  out6[5] = (double)c->aln_batches;
+  return GAML_HIP_OK;
+}
+
 int gaml_hip_last_timing(const gaml_hip_ctx* c, double* out3) {
   if (!c || !out3) return GAML_HIP_EINVAL;
   MULTI_FWD(c, multi_last_timing(c->multi, out3));

@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int64_t kTakeOverAfter = 64;    // evaluations between the start of a rebuild beside the evaluations and its take-over
-constexpr int64_t kDeltaMaxPerCall = 65536;  // more new records than this in one call: rebuild instead of lists
+constexpr int64_t kDeltaMaxPerCall = 131072;  // more new records than this in one call: rebuild instead of lists
 
 int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) b++; return b; }
 
@@ -622,6 +622,10 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   // Everything a later call would otherwise allocate (device allocations cost 0.1-3 ms each; an annealing run must not meet
   // them in the call that happens to activate a window or to start a rebuild): the spare set of table buffers with room
   // for half as many records again, the build's stream and events, the delta store (paired_delta_reset above)
+  for (int k = 0; k < kRing; k++) {  // (pinned allocations take milliseconds: not in the annealing call that first stages a window list)
+    HIP_TRY(c, s.stage_pool.host[k].reserve((size_t)1 << 20));
+    if (!s.stage_pool.done[k]) HIP_TRY(c, hipEventCreateWithFlags(&s.stage_pool.done[k], hipEventDisableTiming));
+  }
   if (!s.kernels_warm && s.mate[0].n_local() > 0) { if (int e = paired_warm_delta_kernels(c, s, s.tab, st)) return e; s.kernels_warm = true; }
   if (!rb.tab.rec8[0].p && KNOB(c, 14) != 1) {
     const int64_t n = s.mate[0].n_local();

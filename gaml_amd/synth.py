@@ -439,6 +439,11 @@ WORKLOADS = {
     # families of 1-3 kbp: the true walk visits those nodes five times (windows that occur several times: general path)
     "cfg3r": Workload("cfg3r: 5 Mbp + 2 % collapsed 5-copy repeats of 1-3 kbp, 50x 2x150 paired, insert 300+-30", 5_000_000, 850_000, repeat_frac=0.02),
     "tinyr": Workload("tinyr: 120 kbp + 5 % collapsed repeats, 2x150 paired", 120_000, 20_000, repeat_frac=0.05),
+    # the reference's own example configuration (example.cfg:20-29) has a JUMPING library next to the short-insert one: insert
+    # 3700 +- 350, penalty_constant 0.00013, penalty_step 3000, min_prob_start -80 (its min_prob_per_base=0 is silently
+    # ignored for paired sets -- the reader looks for "min_prob_pre_base", gaml.cc:855 -- so -0.7 applies). cfg3's genome and
+    # graph, 2x150 reads at 20x: both mates of a pair rarely share a 2-8 kbp node window, the coverage sweep runs every call
+    "cfg3j": Workload("cfg3j: 5 Mbp, 20x 2x150 paired, JUMPING library insert 3700+-350 (example.cfg:20-29)", 5_000_000, 333_333, insert_mean=3700.0, insert_std=350.0),
     # not a BASELINE config: the cfg3 recipe at 8x the size, to see where the scoring kernel's bandwidth levels off
     "cfg3x8": Workload("cfg3x8: 40 Mbp, 50x 2x150 paired, insert 300+-30", 40_000_000, 6_666_664),
 }
@@ -447,6 +452,12 @@ WORKLOADS = {
 def sa_move(rng, paths, g):
     """One random edit of the kind GAML's move generators make (moves.cc: BreakPath, ExtendPaths, LocalChange, ...):
     the CalcProb call pattern of the annealing loop (gaml.cc:148-339), not the optimiser itself."""
+    return sa_move_kind(rng, paths, g)[0]
+
+
+def sa_move_kind(rng, paths, g):
+    """sa_move plus the kind of edit it drew (0 BreakPath, 1 join, 2 reverse, 3 LocalChange, 4 duplicate, 5 trim): the
+    annealing loop accepts a worse assembly only after BreakPath (gaml.cc:286, 304-311)."""
     paths = [list(p) for p in paths]
     kind = rng.integers(0, 6)
     i = int(rng.integers(0, len(paths)))
@@ -474,7 +485,7 @@ def sa_move(rng, paths, g):
             paths[i] = p[:a] + [p[a]] + p[a:]
     elif kind == 5 and len(p) > 2:  # trim an end
         paths[i] = p[1:] if rng.random() < 0.5 else p[:-1]
-    return [q for q in paths if q]
+    return [q for q in paths if q], int(kind)
 
 
 def sa_sequence(g, iters: int, seed: int = 7, threshold: int = 500):

@@ -328,6 +328,9 @@ int64_t gaml_hip_align_window(gaml_hip_ctx* ctx, int readset, int mate, const in
 /* GPU window aligner (cold path): windows aligned on the device so far, seed candidates extended, wall time.
  * (Development builds: knob 5 = 1, gaml_hip_debug.h, forces the host aligner.) */
 int gaml_hip_aligner_stats(gaml_hip_ctx* ctx, int64_t* windows, int64_t* candidates, double* microseconds);
+/* the same time by stage, host clock, cumulative: out6 = {window strings + upload, spans + candidates (small batches: the
+ * whole device pipeline up to the published headers), extension, hits to the host, ordering + filing on the host, batches} */
+int gaml_hip_aligner_stages(gaml_hip_ctx* ctx, double* out6);
 /* ---- monitoring (what bench.py prints beside its numbers; all cheap, host-side) --------------------------------- */
 /* pairs per record-count class of a paired set's device tables {<= 1 record per mate, <= 2, <= 4, more} */
 int gaml_hip_pair_classes(gaml_hip_ctx* ctx, int readset, int64_t* out4);

@@ -235,3 +235,48 @@ def test_collapsed_repeats_at_1mbp_against_the_oracle():
         ctx.compact_tables()
     c = ctx.debug_class_counts(rs)
     assert c[3] > 0 or c[2] > 0  # reads at the ends of a repeat are seen through several junction windows
+
+
+def test_jumping_library_of_the_reference_example_at_1mbp_against_the_oracle():
+    """The reference's own example configuration (example.cfg:20-29) has a jumping library: insert 3700 +- 350,
+    penalty_constant 0.00013, penalty_step 3000, min_prob_start -80 (its min_prob_per_base=0 never reaches a paired set:
+    gaml.cc:855 reads `min_prob_pre_base`, so -0.7 applies). Both mates of a pair rarely share a 2-8 kbp node window (the
+    static part of the compact class shrinks to the pairs with an unaligned mate) and the coverage sweep runs in every call.
+    Likelihood, floored counts, bad_bases and per-read probabilities against the oracle on all pairs, several path sets."""
+    from gaml_amd import api
+    import oracle_py as op
+    G, seed = 1_000_000, 41
+    genome = synth.make_genome(G, seed)
+    g = synth.make_graph(genome, synth.cut_lengths(G, seed))
+    for n in (60_000, 1_500):  # 18x; and 0.45x, where stretches longer than insert_mean - penalty_step = 700 stay uncovered
+        _jumping_case(genome, g, n, seed)
+
+
+def _jumping_case(genome, g, n, seed):
+    from gaml_amd import api
+    import oracle_py as op
+    pr = synth.make_paired_reads(genome, n, 150, 3700.0, 350.0, 0.01, seed)
+    r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
+    kw = dict(penalty_constant=0.00013, penalty_step=3000.0, min_prob_start=-80.0)
+    ctx = api.Context(device=0)
+    ctx.set_graph(*g.packed())
+    rs = ctx.add_paired(api.paired_cfg(3700.0, 350.0, **kw), *r1, *r2)
+    orc = op.Oracle()
+    orc.set_graph(*g.packed())
+    ors = orc.add_paired(*r1, *r2, 0.01, op.paired_cfg(3700.0, 350.0, **kw))
+    walk = synth.genome_walk(g)
+    k = len(walk) // 3
+    bad_seen = set()
+    for paths in ([walk], [walk[:k], walk[k:]], [walk[:k] + [-500] + walk[k + 3:]], [[x] for x in walk if g.node_len(x) > 500], [walk]):
+        got = ctx.calc_prob(paths)
+        want, wz, wtl = orc.calc_prob(paths, fresh=True)
+        wp, wbad = orc.paired_probs(ors)
+        assert got[2] == wtl and got[1].tolist() == wz.tolist()
+        assert ctx.bad_bases(rs) == wbad
+        bad_seen.add(wbad)
+        np.testing.assert_allclose(ctx.read_probs(rs), wp, rtol=4e-16, atol=0)
+        assert abs(got[0] - want) <= 1e-9 * abs(want), (got[0], want)
+    assert n > 10_000 or (len(bad_seen) > 1 and max(bad_seen) > 0), bad_seen  # (sparse reads: the penalty is live, and cutting the walk changes it)
+    cls = ctx.pair_classes(rs)
+    assert sum(cls) == n
+    ctx.close()
