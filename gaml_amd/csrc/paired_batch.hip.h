@@ -30,6 +30,7 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
     PairedLayout L; std::vector<PairedLayout> Ls; std::vector<PairedPrep> prep;
     std::vector<int> patch_off; size_t n_patches = 0;
     size_t tail_fixed = 0, chg_bytes[2] = {0, 0};
+    size_t bw[2] = {0, 0};  // table entries per mate the batch's regions carry: the windows there are + room for those the batch itself adds (the resident copy's capacity is far larger)
     int launches = 0;
     std::vector<int32_t> touched[2];  // union of the changed entries: the resident copy follows after the batch
   };
@@ -55,7 +56,8 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
     r.prep.resize((size_t)n);
     r.patch_off.assign(2 * (size_t)n + 1, 0);
     // behind the regions: the patches, their offsets, and per launch and mate one byte per table entry (MultiSets::chg)
-    r.chg_bytes[0] = align16(P.cap_w[0]); r.chg_bytes[1] = align16(P.cap_w[1]);
+    for (int mt = 0; mt < 2; mt++) r.bw[mt] = std::min<size_t>(P.cap_w[mt], ps.image[mt].occ12.size() + 8192);
+    r.chg_bytes[0] = align16(r.bw[0]); r.chg_bytes[1] = align16(r.bw[1]);
     r.tail_fixed = align16(kPatchCap * sizeof(BatchPatch)) + align16((2 * (size_t)kMaxSets + 1) * sizeof(int));
     const size_t bytes = r.stride * (size_t)n + r.tail_fixed + 2 * (r.chg_bytes[0] + r.chg_bytes[1]);
     if (int e = arena_acquire(c, ps.arena, bytes, st, &r.slot, &r.wp)) return e;
@@ -83,7 +85,7 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
       ta.regions = (char*)ps.arena.dev[r.slot];
       ta.stride = r.stride;
       for (int mt = 0; mt < 2; mt++) {
-        ta.off_occ[mt] = P.off_occ[mt]; ta.bytes_occ[mt] = P.cap_w[mt] * sizeof(Occ12);
+        ta.off_occ[mt] = P.off_occ[mt]; ta.bytes_occ[mt] = r.bw[mt] * sizeof(Occ12);
         ta.off_lo[mt] = P.off_lo[mt]; ta.bytes_lo[mt] = ps.image[mt].multi_off.size() * sizeof(int32_t);
         ta.off_m[mt] = P.off_m[mt]; ta.bytes_m[mt] = ps.image[mt].multi.size() * sizeof(OccQuad);
       }
@@ -115,7 +117,7 @@ static int batch_chunk_patched(gaml_hip_ctx* c, int n, const int32_t* paths, con
       prepare_paired_tables_host(c, ps, r.prep[(size_t)k]);
       OccImage* im = ps.image;
       bool ok = !im[0].changed_all && !im[1].changed_all && !im[0].lists_changed && !im[1].lists_changed;
-      for (int mt = 0; mt < 2 && ok; mt++) ok = im[mt].occ12.size() <= P.cap_w[mt] && r.n_patches + im[mt].changed.size() <= kPatchCap;
+      for (int mt = 0; mt < 2 && ok; mt++) ok = im[mt].occ12.size() <= r.bw[mt] && r.n_patches + im[mt].changed.size() <= kPatchCap;
       if (!ok) {
         if (getenv("GAML_HIP_TRACE_HOST"))
           fprintf(stderr, "batch set %d: not a patch (all %d %d, lists %d %d, windows %zu/%zu %zu/%zu, patches %zu + %zu + %zu)\n", k, (int)im[0].changed_all, (int)im[1].changed_all,

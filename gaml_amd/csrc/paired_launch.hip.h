@@ -235,9 +235,11 @@ int paired_persist_update(gaml_hip_ctx* c, PairedSet& s, double two_T, hipStream
     size_t at = align16(256 * sizeof(double));  // thresholds per length code
     P.off_tfloor = 0;
     for (int mt = 0; mt < 2; mt++) {
-      P.cap_w[mt] = need_w[mt] + need_w[mt] / 4 + 2048;
-      P.cap_lo[mt] = 2 * need_lo[mt] + 256;
-      P.cap_m[mt] = 2 * need_m[mt] + 1024;
+      // (room for many times the windows there are: growing means a new fine-grained allocation -- milliseconds, and an annealing run
+      //  adds two windows per move; 12 bytes a window)
+      P.cap_w[mt] = std::max<size_t>(4 * need_w[mt], (size_t)1 << 18);
+      P.cap_lo[mt] = 4 * need_lo[mt] + 16384;
+      P.cap_m[mt] = 4 * need_m[mt] + 65536;
       P.off_occ[mt] = at; at = align16(at + P.cap_w[mt] * sizeof(Occ12));
       P.off_lo[mt] = at; at = align16(at + P.cap_lo[mt] * sizeof(int32_t));
       P.off_m[mt] = at; at = align16(at + P.cap_m[mt] * sizeof(OccQuad));

@@ -186,11 +186,11 @@ void dominating_window(const ShortMate& m, const Window& w, bool fold, int* dom_
 }
 
 // room for the records of a mate's active windows in the tables and the build's scratch: every record aligned so far may be
-// active one day, plus a quarter (an annealing run adds a few hundred records per move): a build beside the evaluations must
-// not meet an allocation (device allocations of this size take milliseconds)
+// active one day, and as many again (an annealing run adds a few hundred records per move; growing costs milliseconds of
+// device allocations inside whichever call starts the build that no longer fits: geometric, so it happens a handful of times)
 int64_t paired_records_cap(const PairedSet& s, int mt) {
   const int64_t have = s.dev[mt].pool_n;
-  return std::max<int64_t>(have + have / 4, s.mate[0].n_local()) + 65536;
+  return std::max<int64_t>(2 * have, s.mate[0].n_local()) + 65536;
 }
 
 // one set of table buffers for n pairs and A[mate] active records (grow-only)
