@@ -745,6 +745,7 @@ def main():
         want = os.environ.get("GAML_BENCH_EXCHANGE", "shm" if share_gpu else "rccl")
         if want == "rccl":
             # the library's own communicator: rank 0 makes the id, torch.distributed carries the 128 bytes
+            watchdog = None
             try:
                 # a stuck ncclCommInitRank (a peer that never arrives, a fabric problem) must end the run, not hang the
                 # driver: the whole setup is on a clock, and a process that misses it exits non-zero
@@ -776,6 +777,9 @@ def main():
             except Exception as e:  # keep the run alive on the well-trodden path, and say so
                 fallback = repr(e)
                 want = "rccl-torch"
+            finally:
+                if watchdog is not None:
+                    watchdog.cancel()  # (also when setup RAISED: the fallback run must not be killed 180 s later with the setup's message)
         if want in ("rccl-torch", "shm", "gloo"):
             from gaml_amd.dist import ShardedScorer
             shm = want == "shm"

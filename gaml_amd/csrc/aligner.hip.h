@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * kAlnWaves) void extend_kernel(const AlnCand* c
 __global__ __launch_bounds__(256) void publish_hits_kernel(unsigned* counters, const AlnHit* hits, unsigned cap_cands, unsigned* h_counts,
                                                            AlnHit* h_hits, unsigned cap_host, volatile unsigned long long* h_seq, unsigned long long seq) {
   const unsigned n_spans = counters[0], n_cands = counters[1];
-  const unsigned n = n_cands < cap_cands ? (n_cands < cap_host ? n_cands : 0u) : 0u;  // overflow: counts only, the host takes the slow route
+  const unsigned n = n_cands <= cap_cands ? (n_cands <= cap_host ? n_cands : 0u) : 0u;  // overflow: counts only, the host takes the slow route
   for (unsigned t = threadIdx.x; t < n; t += 256) h_hits[t] = hits[t];
   __threadfence_system();
   __syncthreads();

@@ -262,13 +262,7 @@ void aln_file_hits(ShortMate& m, int nw, std::vector<AlnHit>& hits, bool device_
   }
   // One growth step for the whole batch. Growing copies the pool (45 MB at cfg3: ~5 ms per mate), so the cold batch
   // leaves room for twice its size -- untouched pages cost nothing -- and later growth is geometric.
-  if (m.pool.capacity() < m.pool.size() + ok.size()) {
-    m.pool.reserve(std::max(2 * (m.pool.size() + ok.size()), m.pool.capacity() + m.pool.capacity() / 2));
-    // (the spare room's pages are touched now, in the call that grows the pool -- the cold evaluation --: an annealing
-    // move's batch appends a few KB per mate, and on address space never written that is a page fault or two per batch)
-    volatile char* base = (volatile char*)m.pool.data();
-    for (size_t o = m.pool.size() * sizeof(gaml_aligment) / 4096 * 4096 + 4096; o < m.pool.capacity() * sizeof(gaml_aligment); o += 4096) base[o] = 0;
-  }
+  if (m.pool.capacity() < m.pool.size() + ok.size()) m.pool.reserve(std::max(2 * (m.pool.size() + ok.size()), m.pool.capacity() + m.pool.capacity() / 2));  // one growth step for the whole batch
   if (ok.size() >= (size_t)200000) {
     // large batch (the cold first evaluation files ~2.8 M records): count the surviving records per window, then fill the
     // pool segment and the window headers on a few threads (windows are independent; same result as the loop below)
@@ -422,7 +416,7 @@ int aln_pair_small(gaml_hip_ctx* c, PairedSet& ps) {
 #ifdef GAML_HIP_DEV
   // A/B (GAML_ALN_WAIT=2): events attached to the two dispatches -- the device's own begin / end stamps next to the host's wait
   static const int ev_mode = getenv("GAML_ALN_WAIT") ? atoi(getenv("GAML_ALN_WAIT")) : 0;
-  static hipEvent_t aev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t* const aev = S.probe_ev;  // (per context: events belong to the device and thread that made them)
   if ((ev_mode == 2 || ev_mode == 4 || ev_mode == 6) && !aev[0]) for (int k = 0; k < 4; k++) HIP_TRY(c, hipEventCreate(&aev[k]));
   const bool timed = ev_mode == 2 || ev_mode == 4 || ev_mode == 6;
 #else

@@ -120,9 +120,9 @@ struct Reducer {  // per read set: partials + ticket + 2-double result
     hipError_t e;
     if ((e = part_sum.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(double))) != hipSuccess) return e;
     if ((e = part_zero.reserve((4 * kMaxBlocks + kOvfMaxBlocks) * sizeof(int))) != hipSuccess) return e;
-    if ((e = ticket.reserve(sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = ticket.reserve(kTicketWords * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = out.reserve(4 * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipMemset(ticket.p, 0, sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMemset(ticket.p, 0, kTicketWords * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMemset(out.p, 0, 4 * sizeof(double))) != hipSuccess) return e;
     return hipDeviceSynchronize();  // the scoring stream is non-blocking: make the zeroes land first
   }
@@ -153,8 +153,10 @@ struct AlignSmall {
   AlnStrArgs str_args;  // a small batch's window strings as they travel in the launches' argument segments
   unsigned long long out_seq = 0;
   double seen_us = 0;   // host clock when the last batch's sequence word was seen (timing builds)
+  hipEvent_t probe_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // timing probes of the development build (GAML_ALN_WAIT)
   void release() {
     spans.release(); cands.release(); hits.release(); counters.release(); wcopy.release();
+    for (int k = 0; k < 4; k++) if (probe_ev[k]) { (void)hipEventDestroy(probe_ev[k]); probe_ev[k] = nullptr; }
     if (in_dev) (void)hipFree(in_dev);
     in_dev = nullptr; in_cap = 0; in_host.release(); out_host.release();
   }
@@ -431,6 +433,9 @@ struct gaml_hip_ctx {
   double pending_host_us = 0;
   double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // phase stamps of the last blocking call (us): see gaml_hip_debug_profile
   bool used_default_stream = false;  // an *_async entry point was handed NULL (the legacy default stream) since the last gaml_hip_sync
+  // sharded evaluations: two status words a scoring launch writes with its partials (ticket finish), so that the exchange needs no
+  // dispatch of its own for them (multi.hip: ctx_set_status / ctx_status_done)
+  double* status_dst = nullptr; double status_a = 0, status_b = 0; bool status_done = false;
   bool host_results = false;  // blocking call: kernels write their results into pinned host memory, no D2H copy
   // sharded evaluation with a coverage penalty: sweeps wait for the other ranks' coverage maps
   bool defer_cov = false;

@@ -415,6 +415,8 @@ int ctx_fetch_wait_bounded(gaml_hip_ctx* c, double* out, int32_t n_doubles, doub
   memcpy(out, (const char*)c->fetch_host.p + 512, (size_t)n_doubles * sizeof(double));
   return 0;
 }
+void ctx_set_status(gaml_hip_ctx* c, double* dst, double a, double b) { c->status_dst = dst; c->status_a = a; c->status_b = b; c->status_done = false; }
+bool ctx_status_done(const gaml_hip_ctx* c) { return c->status_done; }
 void ctx_eval_abandon(gaml_hip_ctx* c) { if (c) { c->pending_open = false; c->pending_cov.clear(); c->pending_pb.clear(); } }
 bool ctx_has_penalty(const gaml_hip_ctx* c) {
   for (auto& ps : c->paireds) if (ps->cfg.penalty_constant > 0) return true;

@@ -34,6 +34,10 @@ bool ctx_has_penalty(const gaml_hip_ctx* c);
 // gaml_hip_fetch_wait that gives up: polls the fetch's sequence word for at most timeout_s seconds (never an unbounded
 // stream synchronise -- a collective whose peer died never completes). Returns 1 on time-out, < 0 on error, 0 when done.
 int ctx_fetch_wait_bounded(gaml_hip_ctx* c, double* out, int32_t n_doubles, double timeout_s);
+// a sharded evaluation's status words {a, b} at `dst` (device): the next stream-ordered scoring launch that finishes its own
+// partials writes them too; ctx_status_done tells whether one did (else the caller dispatches them itself)
+void ctx_set_status(gaml_hip_ctx* c, double* dst, double a, double b);
+bool ctx_status_done(const gaml_hip_ctx* c);
 // close an evaluation that gaml_hip_eval_begin opened and that will not be finished (another shard failed)
 void ctx_eval_abandon(gaml_hip_ctx* c);
 

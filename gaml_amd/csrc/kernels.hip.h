@@ -111,6 +111,8 @@ struct PairedArgs {
   unsigned* ticket;          // zero before first launch; the last block resets it
   double* out;               // the read set's 4 partials {sum of logs, floored reads, bad_bases, reads}
   double n_reads;
+  double* status_out;        // sharded evaluations (stream-ordered, ticket finish): two status words written with the partials, or null
+  double status_a, status_b;
 };
 
 struct Cand { int path, pos, edit, orient, rank, k; bool valid; };
@@ -298,21 +300,30 @@ __device__ __forceinline__ void block_reduce(double& s, int& z, double* sh_s, in
 
 // grid-level finish: every block publishes its partial; the last block to arrive sums
 // n_partials partials in index order (deterministic), writes out[0..1] and resets the ticket.
+constexpr int kTicketWords = 17;  // [0] groups done, [1 + g] blocks of group g (= slot mod 16) done
 __device__ __forceinline__ void grid_finish(double s, int z, int my_slot, int n_partials, double* part_sum, int* part_zero,
-                                            unsigned* ticket, double* out, double bad_bases, double n_reads, double* sh_s, int* sh_z) {
+                                            unsigned* ticket, double* out, double bad_bases, double n_reads, double* sh_s, int* sh_z,
+                                            double* status_out = nullptr, double status_a = 0.0, double status_b = 0.0) {
   // n_partials = number of blocks (of ALL kernels sharing this ticket) = number of partial slots
   // Hand-off without a release fence: a full __threadfence() here writes back AND invalidates the
   // XCD's L2 once per block, which evicts the shared tables for every block still streaming. The
   // partials are stored write-through at agent scope (sc1), drained with vmcnt(0), then the
   // ticket is taken with a relaxed agent-scope add; the last block reads them back with
   // agent-scope loads (guide section 6, Guideline 16, "sc1 slab stores").
+  // Tickets in two levels: a thousand blocks' atomics on ONE word took ~20 us (they are served one after the other); a block
+  // draws from its group's word (slot mod 16), the block that completes a group draws from the top word -- ~60 atomics per
+  // word. The block that completes the last group sums the partials in index order (deterministic) and resets the words.
   __shared__ bool is_last;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&part_sum[my_slot], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&part_zero[my_slot], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t == (unsigned)n_partials - 1);
+    const int g = my_slot & 15;
+    const unsigned in_group = (unsigned)((n_partials - g + 15) >> 4), groups = (unsigned)min(16, n_partials);
+    bool last = false;
+    if (__hip_atomic_fetch_add(&ticket[1 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1)
+      last = __hip_atomic_fetch_add(&ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+    is_last = last;
   }
   __syncthreads();
   if (!is_last) return;
@@ -323,13 +334,14 @@ __device__ __forceinline__ void grid_finish(double s, int z, int my_slot, int n_
   }
   __syncthreads();
   block_reduce(ts, tz, sh_s, sh_z);
+  if (threadIdx.x < kTicketWords) __hip_atomic_store(&ticket[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) {
     // the read set's 4 partials {sum of logs, floored reads, bad_bases, reads}: ready for one D2H / all-reduce
     out[0] = ts;
     out[1] = (double)tz;
     if (bad_bases >= 0) out[2] = bad_bases;  // < 0: a later kernel (coverage sweep) fills it
     out[3] = n_reads;
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (status_out) { status_out[0] = status_a; status_out[1] = status_b; }  // (a sharded evaluation's status words ride along: no dispatch of their own)
   }
 }
 
@@ -1166,7 +1178,7 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
   if (TICKET) {
     GAML_FRESH_ARGS(c, a)
     grid_finish(lsum, zeros, lb, c.total_blocks, c.part_sum, c.part_zero, c.ticket, c.out,
-                c.cov_bits ? -1.0 : 0.0, c.n_reads, sh_s, sh_z);
+                c.cov_bits ? -1.0 : 0.0, c.n_reads, sh_s, sh_z, c.status_out, c.status_a, c.status_b);
   } else if (threadIdx.x == 0) {
     a.part_sum[lb] = lsum;
     a.part_zero[lb] = zeros;
@@ -1175,13 +1187,17 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
 
 // experiment: separate one-block finisher (sums n_partials partials in index order)
 __global__ __launch_bounds__(kBlock) void finish_partials_kernel(const double* part_sum, const int* part_zero, int n_partials,
-                                                                 double* out, double bad_bases, double n_reads) {
+                                                                 double* out, double bad_bases, double n_reads,
+                                                                 double* status_out = nullptr, double status_a = 0.0, double status_b = 0.0) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
   double ts = 0; int tz = 0;
   for (int b = threadIdx.x; b < n_partials; b += kBlock) { ts += part_sum[b]; tz += part_zero[b]; }
   block_reduce(ts, tz, sh_s, sh_z);
-  if (threadIdx.x == 0) { out[0] = ts; out[1] = (double)tz; if (bad_bases >= 0) out[2] = bad_bases; out[3] = n_reads; }
+  if (threadIdx.x == 0) {
+    out[0] = ts; out[1] = (double)tz; if (bad_bases >= 0) out[2] = bad_bases; out[3] = n_reads;
+    if (status_out) { status_out[0] = status_a; status_out[1] = status_b; }  // (a sharded evaluation's status words ride along: no dispatch of their own)
+  }
 }
 
 // Overflow body: one WAVE per pair, for slots [n_main, n) (more than 4 records on a mate).
@@ -1305,7 +1321,7 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
   block_reduce(lsum, zeros, sh_s, sh_z);
   if (TICKET) {
     grid_finish(lsum, zeros, a.main_blocks + ovf_block, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out,
-                a.cov_bits ? -1.0 : 0.0, a.n_reads, sh_s, sh_z);
+                a.cov_bits ? -1.0 : 0.0, a.n_reads, sh_s, sh_z, a.status_out, a.status_a, a.status_b);
   } else if (threadIdx.x == 0) {
     a.part_sum[a.main_blocks + ovf_block] = lsum;
     a.part_zero[a.main_blocks + ovf_block] = zeros;
@@ -1338,7 +1354,7 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_kernel(PairedArgs a) {
     if (!(GAML_STATIC_X & 16))
     paired_static4_body<GEN, false, true>(a, SlotRange{0, a.n0a, lb, a.blocks0a, 0}, lsum, zeros);
     block_reduce(lsum, zeros, sh_s, sh_z);
-    if (TICKET) grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out, 0.0, a.n_reads, sh_s, sh_z);
+    if (TICKET) grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out, 0.0, a.n_reads, sh_s, sh_z, a.status_out, a.status_a, a.status_b);
     else if (threadIdx.x == 0) { a.part_sum[lb] = lsum; a.part_zero[lb] = zeros; }
     return;
   }

@@ -130,6 +130,23 @@ void comm_destroy(CommState* s) {
 
 namespace {
 
+// Every wait behind a collective is bounded (GAML_HIP_COMM_TIMEOUT_S): `n_doubles` doubles at d_src come to the host through
+// the context's fetch slot (pinned memory behind a sequence word); when they have not arrived in time -- a peer failed
+// before the collective, or entered another one: RCCL leaves mismatched collectives undefined -- this rank aborts its
+// communicator and reports instead of hanging in its stream.
+int comm_fetch_bounded(gaml_hip_ctx* c, CommState* s, const void* d_src, double* host, int32_t n_doubles, const char* what) {
+  if (int e = gaml_hip_fetch_async(c, d_src, n_doubles, ctx_stream(c))) return e;
+  const int w = ctx_fetch_wait_bounded(c, host, n_doubles, s->timeout_s);
+  if (w < 0) return w;
+  if (w > 0) {
+    s->dead = true;
+    if (rccl()->CommAbort) (void)rccl()->CommAbort(s->comm);
+    return ctx_fail(c, GAML_HIP_EHIP, std::string("sharded evaluation: ") + what + " did not complete within " + std::to_string((int)s->timeout_s) +
+                                      " s (a peer failed or left the protocol); communicator aborted");
+  }
+  return 0;
+}
+
 // phase 1 of a sharded evaluation: registration / alignment, then the largest record position of every newly
 // aligned window as a maximum over ALL ranks' reads (the reference's position filter, graph.cc:577)
 int comm_begin(gaml_hip_ctx* c, CommState* s, const int32_t* paths, const int64_t* offs, int32_t n_paths, int32_t* tl, int64_t* aligned) {
@@ -140,11 +157,13 @@ int comm_begin(gaml_hip_ctx* c, CommState* s, const int32_t* paths, const int64_
     hipStream_t st = ctx_stream(c);
     std::vector<int32_t> mx((size_t)pending);
     if (gaml_hip_eval_pending_maxpos(c, mx.data(), pending) != pending) return ctx_fail(c, GAML_HIP_ESTATE, "pending maxima changed under the exchange");
-    COMM_HIP(c, s->small.reserve((size_t)pending * sizeof(int32_t), st));
+    const size_t nd = ((size_t)pending * sizeof(int32_t) + 7) / 8;  // (fetched as whole doubles)
+    COMM_HIP(c, s->small.reserve(nd * sizeof(double), st));
     COMM_HIP(c, hipMemcpyAsync(s->small.p, mx.data(), (size_t)pending * sizeof(int32_t), hipMemcpyHostToDevice, st));
     COMM_NCCL(c, rccl()->AllReduce(s->small.p, s->small.p, (size_t)pending, ncclInt32, ncclMax, s->comm, st));
-    COMM_HIP(c, hipMemcpyAsync(mx.data(), s->small.p, (size_t)pending * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    COMM_HIP(c, hipStreamSynchronize(st));
+    std::vector<double> back(nd);
+    if (int e = comm_fetch_bounded(c, s, s->small.p, back.data(), (int32_t)nd, "the exchange of the new windows' largest positions")) return e;
+    memcpy(mx.data(), back.data(), (size_t)pending * sizeof(int32_t));
     if (int e = gaml_hip_eval_apply_maxpos(c, mx.data(), pending)) return e;
   }
   return 0;
@@ -175,8 +194,11 @@ int comm_score(gaml_hip_ctx* c, CommState* s, double* d_part) {
     long long* d_sz = (long long*)s->small.p;
     COMM_HIP(c, hipMemcpyAsync(d_sz, &mine, sizeof(long long), hipMemcpyHostToDevice, st));
     COMM_NCCL(c, rccl()->AllGather(d_sz, d_sz + 1, 1, ncclInt64, s->comm, st));
-    COMM_HIP(c, hipMemcpyAsync(sizes.data(), d_sz + 1, sizeof(long long) * (size_t)s->world, hipMemcpyDeviceToHost, st));
-    COMM_HIP(c, hipStreamSynchronize(st));
+    {
+      std::vector<double> back((size_t)s->world);
+      if (int e = comm_fetch_bounded(c, s, d_sz + 1, back.data(), s->world, "the exchange of the interval counts")) return e;
+      memcpy(sizes.data(), back.data(), sizeof(long long) * (size_t)s->world);
+    }
     long long total = 0;
     for (long long v : sizes) total += v;
     const long long width = std::max<long long>(1, *std::max_element(sizes.begin(), sizes.end()));  // intervals per rank in the gather (16 bytes each)
@@ -212,8 +234,11 @@ int comm_exchange(gaml_hip_ctx* c, CommState* s, size_t n, int local_rc, int64_t
   hipStream_t st = ctx_stream(c);
   const size_t blk = n + 2;
   double* mine = (double*)s->part.p;
-  hipLaunchKernelGGL(comm_status_kernel, dim3(1), dim3(64), 0, st, mine + n, (double)local_rc, (double)aligned);
-  COMM_HIP(c, hipGetLastError());
+  if (!(local_rc == 0 && ctx_status_done(c))) {  // (a scoring launch that finished its own partials wrote the status words with them)
+    hipLaunchKernelGGL(comm_status_kernel, dim3(1), dim3(64), 0, st, mine + n, (double)local_rc, (double)aligned);
+    COMM_HIP(c, hipGetLastError());
+  }
+  ctx_set_status(c, nullptr, 0.0, 0.0);
   std::vector<double> host(blk * (size_t)(s->mode == 0 ? s->world : 1));
   if (s->mode == 0) {
     COMM_HIP(c, s->gath.reserve(blk * (size_t)s->world * sizeof(double), st));
@@ -257,6 +282,7 @@ static int comm_finish_reduced(gaml_hip_ctx* c, CommState* s, int begin_rc, int6
   const size_t nd = 4 * (size_t)std::max(1, gaml_hip_num_readsets(c));
   COMM_HIP(c, s->part.reserve((nd + 2) * sizeof(double), st));
   int rc = begin_rc;
+  ctx_set_status(c, (double*)s->part.p + nd, 0.0, (double)aligned);
   if (!rc) rc = comm_score(c, s, (double*)s->part.p);
   else COMM_HIP(c, hipMemsetAsync(s->part.p, 0, nd * sizeof(double), st));
   if (rc) ctx_eval_abandon(c);

@@ -534,8 +534,15 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   if (n > 0) {
     // HIP events bracket the dominant kernel only (bench.py's roofline; rocprofv3 must agree)
     if (c->event_timing && (c->event_tick++ % c->event_every) == 0) { if (int e = take_events(c, &ev)) return e; }
-    int fin_mode = c->host_results ? 2 : (KNOB(c, 2) ? KNOB(c, 2) - 1 : 1);  // 0: ticket in the kernel (2048 same-address atomics: ~20 us), 1: finisher kernel, 2: host adds the partials
+    // 0 (knob 2 = 1): the block that draws the last ticket adds the partials up (two-level tickets, grid_finish: the ~1,000 blocks
+    // end together and their atomics on 17 words still take 10 us -- a finisher dispatch costs less); 1: finisher kernel
+    // (stream-ordered calls; always when a second launch shares the partials); 2: the host adds them (blocking calls)
+    int fin_mode = c->host_results ? 2 : (KNOB(c, 2) ? KNOB(c, 2) - 1 : 1);
     if (fin_mode == 0 && gen_pass) fin_mode = 1;
+    // a sharded evaluation's status words are written by whatever finishes the partials on the device
+    double* status_out = nullptr;
+    if (fin_mode != 2 && c->status_dst && !c->status_done) { status_out = c->status_dst; c->status_done = true; }
+    if (fin_mode == 0) { a.status_out = status_out; a.status_a = c->status_a; a.status_b = c->status_b; }
     s.last_total_blocks = n_partials;
     const dim3 grid(a.total_blocks), block(kBlock);
     // Timed launches attach the two events to the dispatch itself (hipExtLaunchKernelGGL: the events carry
@@ -560,7 +567,7 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
       HIP_TRY(c, hipGetLastError());
     }
     if (fin_mode == 1) {
-      hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, n_partials, out4, cov ? -1.0 : 0.0, (double)n);
+      hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, n_partials, out4, cov ? -1.0 : 0.0, (double)n, status_out, c->status_a, c->status_b);
       HIP_TRY(c, hipGetLastError());
     }
   } else {
