@@ -1091,6 +1091,7 @@ void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_re
   out.built_generation = m.active_generation;
 }
 
+#ifdef GAML_HIP_DEV  // the host restatement of the device table build (table_build.hip.h): what the development build checks the device tables against
 // Records that can never survive the overwrite rule (graph.cc:583-592), whatever the path set. A window J of several
 // nodes whose first node i is longer than kTail is looked up together with the node's own window {i}, J first, both at
 // the node's path position and under the same position filter (GetPositionsOnlyPath graph.cc:563-577;
@@ -1151,6 +1152,8 @@ int64_t undominated_records(const ShortMate& m, int32_t wid, std::vector<uint8_t
   return kept;
 }
 
+#endif  // GAML_HIP_DEV
+
 void link_mate_windows(ShortMate& a, ShortMate& b) {
   for (size_t w = 0; w < a.wins.size(); w++) {
     if (a.wins[w].peer >= 0) continue;
@@ -1161,6 +1164,7 @@ void link_mate_windows(ShortMate& a, ShortMate& b) {
   for (Window& w : b.wins) if (w.peer == -2) w.peer = -1;  // (not in `a`, or the loop above would have linked it)
 }
 
+#ifdef GAML_HIP_DEV
 void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold, int ins_n) {
   static const bool trace_bpt = getenv("GAML_HIP_TRACE_HOST") != nullptr;
   auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1356,6 +1360,8 @@ void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, 
     fprintf(stderr, "build_pair_tables: per-read counts %.1f ms, length codes + classes %.1f, two counting sorts %.1f, compact tables %.1f, 16-byte tables %.1f\n",
             t_stage[1] - t_stage[0], t_stage[2] - t_stage[1], t_stage[3] - t_stage[2], t_stage[4] - t_stage[3], t_stage[5] - t_stage[4]);
 }
+
+#endif  // GAML_HIP_DEV
 
 static inline uint64_t occ8_pack(const OccQuad& q, bool general) {
   int32_t mp = q.min_pos < -32768 ? -32768 : q.min_pos;

@@ -185,11 +185,21 @@ void build_read_major(const ShortMate& m, const std::vector<int32_t>* slot_of_re
 //   occ8  = shift (int32) | min_pos clamped to int16 | path (15 bits) | "use the general path" (1)
 // Class-0 pairs are additionally ordered by (window of mate 1, window of mate 2): the lanes of a wave
 // then mostly share their window, so the occurrence lookups are wave-broadcasts.
+// (The tables themselves are built and kept on the device: table_build.hip.h. PairTables / build_pair_tables below are the
+// host restatement the DEVELOPMENT build checks them against -- gaml_hip_debug_tables_check -- and are not in the product.)
 constexpr uint64_t kNoRec8 = ~0ull;
 inline bool rec8_fits(int32_t wid, int32_t pos, int32_t edit) { return wid >= 0 && wid < (1 << 24) - 1 && pos >= 0 && pos < (1 << 28) && edit >= 0 && edit < 64; }
 inline uint64_t rec8_pack(int32_t wid, int32_t pos, int32_t edit, int32_t orient) {
   return (uint64_t)(uint32_t)wid | ((uint64_t)(uint32_t)pos << 24) | ((uint64_t)(uint32_t)edit << 52) | ((uint64_t)(orient & 1) << 58);
 }
+#ifndef GAML_FOLD_CLASS2_BELOW
+#define GAML_FOLD_CLASS2_BELOW 1024
+#endif
+constexpr int64_t kFoldClass2Below = GAML_FOLD_CLASS2_BELOW;  // fewer pairs than this with 3-4 records per mate: scored one wave per pair (class 3)
+constexpr int kMemoCodes = 4;
+constexpr int32_t kStaticZero = -2;  // PairTables::static_idx of a pair that never scores
+constexpr size_t kMemoMaxEntries = (size_t)1 << 24;
+#ifdef GAML_HIP_DEV
 struct PairTables {
   std::vector<int32_t> slot_of_read, read_of_slot;
   int64_t class_count[4] = {0, 0, 0, 0};  // 0: compact; 1: <= 2 records; 2: <= 4; 3: more
@@ -215,20 +225,16 @@ struct PairTables {
 // fold = false keeps the records that can never survive the overwrite rule (A/B and tests; same values either way).
 // ins_n: length of the insert-size table the memo of pair terms is built over (memo index = ((code * 7 + edit 1) * 7 + edit 2)
 // * ins_n + distance, first kMemoCodes length combinations, edits < 7); 0: no static indices (n0a = 0).
-#ifndef GAML_FOLD_CLASS2_BELOW
-#define GAML_FOLD_CLASS2_BELOW 1024
-#endif
-constexpr int64_t kFoldClass2Below = GAML_FOLD_CLASS2_BELOW;  // fewer pairs than this with 3-4 records per mate: scored one wave per pair (class 3)
-constexpr int kMemoCodes = 4;
-constexpr int32_t kStaticZero = -2;  // PairTables::static_idx of a pair that never scores
-constexpr size_t kMemoMaxEntries = (size_t)1 << 24;
 void build_pair_tables(const ShortMate& a, const ShortMate& b, PairTables& out, bool fold = true, int ins_n = 0);
+#endif  // GAML_HIP_DEV
 // which windows of the two mates of a paired set hold the same node walk (Window::peer); only windows not linked yet are
 // looked up. Call before build_pair_tables (on the thread that owns the window caches).
 void link_mate_windows(ShortMate& a, ShortMate& b);
 // The same rule for ONE window that joins the device tables later (delta lists): keep[k] = 0 for the records of window
 // `wid` that its first node's own window -- active -- always overwrites. Returns the number of records to keep.
+#ifdef GAML_HIP_DEV
 int64_t undominated_records(const ShortMate& m, int32_t wid, std::vector<uint8_t>& keep);
+#endif
 
 
 // direct-mapped occurrence table for the device: one 16-B entry per window.

@@ -837,8 +837,13 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const 
 #ifndef GAML_STATIC_PIPE
 #define GAML_STATIC_PIPE 0
 #endif
-#ifndef GAML_STATIC_X  // timing experiments (results wrong): 1 no occurrence lookups, 2 no stores, 4 no value loads
-#define GAML_STATIC_X 0
+// Timing experiments of the development build (results WRONG where a part is switched off; tools/build_variant.sh -DGAML_STATIC_X=..):
+// 1 no occurrence lookups, 2 no stores, 4 no value loads, 8 only the static part of class 0, 16 everything but it. The
+// release library is compiled without any of these arms, whatever is passed on its command line.
+#if defined(GAML_HIP_DEV) && defined(GAML_STATIC_X)
+#define GAML_TIMING_X(bit) ((GAML_STATIC_X) & (bit))
+#else
+#define GAML_TIMING_X(bit) 0
 #endif
 // static_val[slot] = the memo entry {t, log t} of a static pair ({0, 0}: a mate without alignment -- floored like any
 // term below the threshold), copied out of the memo once per table build: the scoring launch then STREAMS the pair's
@@ -877,7 +882,7 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
 #pragma unroll
   for (int k = 0; k < P; k++) {
     const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
-    r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); m[k] = (GAML_STATIC_X & 4) ? make_double2(1e-9 * (double)ic, -20.0) : *(const double2*)(sval + ic * 16u);
+    r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); m[k] = GAML_TIMING_X(4) ? make_double2(1e-9 * (double)ic, -20.0) : *(const double2*)(sval + ic * 16u);
     lc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
   }
   bool first_round = true;
@@ -890,7 +895,7 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
       const Occ12* e1 = (const Occ12*)(occ0 + w1 * 12u);
       const Occ12* e2 = (const Occ12*)(occ1 + w2 * 12u);
       o1[k] = make_uint2(e1->lo, e1->hi); o2[k] = make_uint2(e2->lo, e2->hi);
-      if (GAML_STATIC_X & 1) { o1[k] = make_uint2(r1[k].x >> 8, 0u); o2[k] = make_uint2(r1[k].x >> 8, 0u); }
+      if (GAML_TIMING_X(1)) { o1[k] = make_uint2(r1[k].x >> 8, 0u); o2[k] = make_uint2(r1[k].x >> 8, 0u); }
     }
     // the next round's records (wave-uniform branch; a lane without a next round asks for its first slot again)
     const unsigned nbase = base + P * stride;
@@ -940,7 +945,7 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
       add = poison ? __builtin_nan("") : add;
       lsum += add;                                       // (adding 0.0 changes no bit of a sum of negative logs)
       zeros += (int)floored;
-      if (counted && !(GAML_STATIC_X & 2)) __builtin_nontemporal_store(t, (double*)(probs + (base + k * stride) * 8u));
+      if (counted && !GAML_TIMING_X(2)) __builtin_nontemporal_store(t, (double*)(probs + (base + k * stride) * 8u));
     }
     if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
 #pragma unroll
@@ -960,7 +965,7 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
 #pragma unroll
       for (int k = 0; k < P; k++) {
         const unsigned ic = base + k * stride < n0 ? base + k * stride : base;
-        r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); m[k] = (GAML_STATIC_X & 4) ? make_double2(1e-9 * (double)ic, -20.0) : *(const double2*)(sval + ic * 16u);
+        r1[k] = *(const uint2*)(rec0 + ic * 8u); r2[k] = *(const uint2*)(rec1 + ic * 8u); m[k] = GAML_TIMING_X(4) ? make_double2(1e-9 * (double)ic, -20.0) : *(const double2*)(sval + ic * 16u);
         lc[k] = ONE ? 0u : (unsigned)a.len_code[ic];
       }
     }
@@ -1139,8 +1144,8 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
   int zeros = 0;
   unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
   if (TL && (threadIdx.x & 63) == 0) { tl[0] = wall_clock64(); tl[7] = lb < a.blocks0 ? 0 : (lb < a.blocks01 ? 1 : 2); }
-  if ((GAML_STATIC_X & 8) && lb >= a.blocks0a) {  // timing experiment: only the static part of class 0 does anything
-  } else if ((GAML_STATIC_X & 16) && lb < a.blocks0a) {  // ... or everything but it
+  if (GAML_TIMING_X(8) && lb >= a.blocks0a) {  // timing experiment: only the static part of class 0 does anything
+  } else if (GAML_TIMING_X(16) && lb < a.blocks0a) {  // ... or everything but it
   } else if (lb < a.blocks0) {
     GAML_FRESH_ARGS(c, a)
     const bool wide = c.memo && !c.cov_bits;  // block-uniform: memo present, no coverage marks to set
@@ -1351,7 +1356,7 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_kernel(PairedArgs a) {
   if (!TL && lb < a.blocks0a && a.memo && !a.cov_bits && a.n_codes == 1) {
     double lsum = 0.0;
     int zeros = 0;
-    if (!(GAML_STATIC_X & 16))
+    if (!GAML_TIMING_X(16))
     paired_static4_body<GEN, false, true>(a, SlotRange{0, a.n0a, lb, a.blocks0a, 0}, lsum, zeros);
     block_reduce(lsum, zeros, sh_s, sh_z);
     if (TICKET) grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out, 0.0, a.n_reads, sh_s, sh_z, a.status_out, a.status_a, a.status_b);
@@ -1914,7 +1919,7 @@ __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, in
     const int rel = cls == 0 ? (part_b ? i - a.n0a : i) : (cls == 1 ? i - a.n0 : i - a.n01);
     const unsigned long long word = a.gen_bits[(cls == 0 ? (part_b ? a.gen_w0b : 0) : (cls == 1 ? a.gen_w1 : a.gen_w2)) + (rel >> 6)];
     if (!((word >> (rel & 63)) & 1ull)) continue;
-#ifdef GAML_GEN_X  // timing experiments (results wrong): leave a class of noted pairs out
+#if defined(GAML_HIP_DEV) && defined(GAML_GEN_X)  // timing experiments of the development build (results wrong): leave a class of noted pairs out
     if ((GAML_GEN_X & 1) && cls == 0) continue;
     if ((GAML_GEN_X & 2) && cls != 0) continue;
 #endif
@@ -1934,7 +1939,7 @@ __global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, in
   // ... and the delta pairs the scoring launch noted (paired_delta_body), one lane per pair, records from the delta lists
   for (int dj = blockIdx.x * kBlock + threadIdx.x; dj < a.dstate[kDsDirty]; dj += gridDim.x * kBlock) {
     if (!((a.gen_bits[a.gen_wd + (dj >> 6)] >> (dj & 63)) & 1ull)) continue;
-#ifdef GAML_GEN_X
+#if defined(GAML_HIP_DEV) && defined(GAML_GEN_X)
     if (GAML_GEN_X & 4) continue;
 #endif
     int4 r1[4], r2[4];

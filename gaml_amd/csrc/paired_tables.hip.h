@@ -234,8 +234,6 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
     link_mate_windows(s.mate[0], s.mate[1]);
     for (int mt = 0; mt < 2; mt++) {
       const ShortMate& m = s.mate[mt];
-      size_t na = 0;
-      for (const Window& w : m.wins) na += (w.active && w.count > 0);
       HIP_TRY(c, B.h_wins[mt].reserve((2 * m.wins.size() + 16384) * sizeof(TbWin)));  // (room to grow: a later build must not meet a pinned allocation)
       TbWin* hw = (TbWin*)B.h_wins[mt].p;
       int k = 0;
