@@ -377,7 +377,7 @@ def drift_block(api, synth, device, g, b1, o1, b2, o2, read_len, cfg, iters=1000
             "gpu_vs_fresh_oracle_rel_delta_max_at_checkpoints": fresh_delta, "checkpoints": checks, "oracle_incremental_s": inc_s}
 
 
-def repeats_block(api, synth, device, sa_iters=5000):
+def repeats_block(api, synth, device, sa_iters=5000, oracle=True):
     """Repeat-rich assemblies, untimed for the headline ("optionally with planted repeats"; GAML's repeat moves,
     moves.cc:1156-1305, exist for them): (1) cfg3r = config 3's recipe with 2 % of the genome in COLLAPSED 5-copy repeat
     families -- one node each, visited five times by the true walk, so its windows occur several times in the path set
@@ -420,18 +420,19 @@ def repeats_block(api, synth, device, sa_iters=5000):
            "general_kernel_us": gs["device_us"] / max(1, gs["launches"]), "general_launches_per_step": gs["launches"] / max(1, ks["launches"]),
            "algo_bytes_per_launch": ks["algo_bytes"] / max(1, ks["launches"])}
     ctx.close()
-    # the CPU oracle on all pairs, two path sets (the whole walk; the walk in two pieces): cold, incl. window alignment
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_py as op
-    orc = op.Oracle()
-    orc.set_graph(gb, go)
-    orc.add_paired(*r1, *r2, wl.err, op.paired_cfg(wl.insert_mean, wl.insert_std))
-    t0 = time.time()
-    want = [orc.calc_prob(v, fresh=True)[0] for v in variants_py[:2]]
-    out["ll_max_rel_delta_vs_cpu"] = max(abs(a - b) / abs(b) for a, b in zip(vals[:2], want))
-    out["ll_delta_pairs"] = wl.n_pairs
-    out["cpu_oracle_s"] = time.time() - t0
-    del orc
+    if oracle:
+        # the CPU oracle on all pairs, two path sets (the whole walk; the walk in two pieces): cold, incl. window alignment
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as op
+        orc = op.Oracle()
+        orc.set_graph(gb, go)
+        orc.add_paired(*r1, *r2, wl.err, op.paired_cfg(wl.insert_mean, wl.insert_std))
+        t0 = time.time()
+        want = [orc.calc_prob(v, fresh=True)[0] for v in variants_py[:2]]
+        out["ll_max_rel_delta_vs_cpu"] = max(abs(a - b) / abs(b) for a, b in zip(vals[:2], want))
+        out["ll_delta_pairs"] = wl.n_pairs
+        out["cpu_oracle_s"] = time.time() - t0
+        del orc
     # (2) late in a long annealing walk at config 3
     wl3 = synth.WORKLOADS["cfg3"]
     genome, g = wl3.build()
@@ -464,7 +465,7 @@ def repeats_block(api, synth, device, sa_iters=5000):
     return out
 
 
-def jumping_block(api, synth, device, oracle_sets=2):
+def jumping_block(api, synth, device, oracle_sets=2, oracle=True):
     """The reference's own example configuration has a jumping library (example.cfg:20-29: insert 3700 +- 350,
     penalty_constant 0.00013, penalty_step 3000, min_prob_start -80). Untimed for the headline: pair classes, the static
     share of the compact class, kernel and step time through the 8 rotating path sets, and the likelihood + bad_bases
@@ -518,6 +519,8 @@ def jumping_block(api, synth, device, oracle_sets=2):
            "step_phases_us": {"planning": float(ph[0]), "tables": float(ph[1]), "write": float(ph[3]), "launch": float(ph[5]), "wait": float(ph[7])},
            "note": "penalty_constant > 0: every call plans the whole path set, marks coverage (atomics into a bitmap) and runs coverage_sweep_kernel behind the scoring launch"}
     ctx.close()
+    if not oracle:
+        return out
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as op
     orc = op.Oracle()
@@ -572,7 +575,7 @@ def aligner_block(api, synth, device, g, gb, go, b1, o1, b2, o2, cfg, read_len, 
                     "the records stay in HBM (filed on the device), the host receives the windows' headers"}
 
 
-def sa_long_block(api, synth, device, g, gb, go, b1, o1, b2, o2, cfg, read_len, iters=10000, sample=50_000, t0_temp=0.008):
+def sa_long_block(api, synth, device, g, gb, go, b1, o1, b2, o2, cfg, read_len, iters=10000, sample=50_000, t0_temp=0.008, oracle=True):
     """A long annealing run with the reference's accept rule (example.cfg:3 max_iterations 10000): a move is accepted iff the
     GPU value improves; a worse one only after BreakPath, with probability exp((new - cur) / T), T = t0 / log(it + 1)
     (gaml.cc:274, 286, 304-311). Per 1,000 calls: median / p90 / max of the call, pairs on the delta lists, take-overs.
@@ -612,6 +615,8 @@ def sa_long_block(api, synth, device, g, gb, go, b1, o1, b2, o2, cfg, read_len, 
            "accepted": accepted, "paths_at_end": len(cur), "total_s": float(per.sum()), "windows": windows,
            "last_over_first_median": windows[-1]["us_median"] / windows[0]["us_median"], "log_likelihood_start_end": [float(ctx.calc_prob([[x] for x in walk if g.node_len(x) > 500])[0]), float(final_val)]}
     ctx.close()
+    if not oracle:
+        return out
     # the final assembly on the first `sample` pairs: GPU (a context of its own) against the CPU oracle
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as op
@@ -927,11 +932,14 @@ def main():
         traffic, traffic_src, traffic_stale = None, None, None
         try:
             import glob
-            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]
+            # (the newest summary taken for THIS workload: <tag>_pmc_traffic.json is cfg3's, <tag>_cfg3x8_pmc_traffic.json the HBM-bound size's)
+            cands = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+                     if json.load(open(f)).get("workload", "cfg3") == args.workload]
+            f = cands[-1]
             tj = json.load(open(f))
             traffic_src = os.path.relpath(f, ROOT)
             traffic_stale = tj.get("source_hash") != source_hash()
-            if args.workload == "cfg3" and world == 1 and not traffic_stale:
+            if world == 1 and not traffic_stale:
                 traffic = tj["kernels"]["paired_score_kernel"]["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -1017,13 +1025,15 @@ def main():
                 out["batched_candidates"] = batched_candidates(ctx, g, api, synth)
         if not use_dist and not args.no_extras and not args.no_long and args.workload == "cfg3":
             out["aligner"] = aligner_block(api, synth, local_rank, g, gb, go, b1, o1, b2, o2, cfg, wl.read_len)
-            out["sa_long"] = sa_long_block(api, synth, local_rank, g, gb, go, b1, o1, b2, o2, cfg, wl.read_len, iters=args.sa_long_iters)
-        if not use_dist and not args.no_extras and not args.no_repeats and not args.no_cpu_baseline:
+            out["sa_long"] = sa_long_block(api, synth, local_rank, g, gb, go, b1, o1, b2, o2, cfg, wl.read_len, iters=args.sa_long_iters, oracle=not args.no_cpu_baseline)
+        if not use_dist and not args.no_extras and not args.no_repeats and args.workload == "cfg3":
+            # (with --no-cpu-baseline -- the profiling runs -- the GPU sides of these blocks still run, without their oracle legs)
             ctx.close()  # (the headline context's tables: ~100 MB of device memory back before two more read sets are built)
-            out["repeats"] = repeats_block(api, synth, local_rank)
+            out["repeats"] = repeats_block(api, synth, local_rank, oracle=not args.no_cpu_baseline)
             if not args.no_long:
-                out["jumping"] = jumping_block(api, synth, local_rank)
-            out["incremental_drift"] = drift_block(api, synth, local_rank, g, b1, o1, b2, o2, wl.read_len, cfg)
+                out["jumping"] = jumping_block(api, synth, local_rank, oracle=not args.no_cpu_baseline)
+            if not args.no_cpu_baseline:
+                out["incremental_drift"] = drift_block(api, synth, local_rank, g, b1, o1, b2, o2, wl.read_len, cfg)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is taken on rank 0 at N = 1 only
             pairs = min(args.cpu_sample_pairs or wl.n_pairs, wl.n_pairs)
             cb, cpu_vals = cpu_baseline(gb, go, b1, o1, b2, o2, pairs, wl.read_len, variants_py, cfg)

@@ -688,7 +688,8 @@ class Context:
     def table_stats(self, rs):
         out = np.zeros(10, np.int64)
         self._check(_lib.gaml_hip_table_stats(self._h, rs, out))
-        return {"full_rebuilds": int(out[0]), "delta_updates": int(out[1]), "dirty_pairs": int(out[2]), "worker_rebuilds": int(out[3]),
+        # ("worker_rebuilds": the name of rounds 1-3, when a host thread built the tables; now = rebuilds beside the evaluations, on a stream of their own)
+        return {"full_rebuilds": int(out[0]), "delta_updates": int(out[1]), "dirty_pairs": int(out[2]), "worker_rebuilds": int(out[3]), "side_stream_rebuilds": int(out[3]),
                 "batches_patched": int(out[4]), "batches_full": int(out[5]), "records_left_out": [int(out[6]), int(out[7])], "delta_records_left_out": int(out[8]),
                 "static_index_pairs": int(out[9])}
 

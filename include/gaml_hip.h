@@ -334,8 +334,9 @@ int gaml_hip_aligner_stages(gaml_hip_ctx* ctx, double* out6);
 /* ---- monitoring (what bench.py prints beside its numbers; all cheap, host-side) --------------------------------- */
 /* pairs per record-count class of a paired set's device tables {<= 1 record per mate, <= 2, <= 4, more} */
 int gaml_hip_pair_classes(gaml_hip_ctx* ctx, int readset, int64_t* out4);
-/* device record tables of a paired set: {full rebuilds, delta updates, pairs currently on the delta lists, rebuilds
- * done by the worker thread (of the full rebuilds), gaml_hip_calc_prob_batch chunks whose per-set tables were built on
+/* device record tables of a paired set (built and maintained by kernels: the records never leave the device): {table
+ * builds, delta updates, pairs currently on the delta lists, builds that ran BESIDE the evaluations on a stream of their
+ * own and took over a fixed number of evaluations later (of the table builds), gaml_hip_calc_prob_batch chunks whose per-set tables were built on
  * the device from patches, chunks whose tables were written whole, records of mate 1 / mate 2 that the current tables
  * leave out because another record of the same read always overwrites them, such records of windows that joined later
  * and therefore never reached the delta lists (since creation), pairs of the compact class whose pair term came with

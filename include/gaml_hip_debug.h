@@ -50,23 +50,22 @@ int64_t gaml_hip_debug_table_occurrences(gaml_hip_ctx* ctx, int readset, int mat
 /* node ids of a cached window (by id); returns its length, -1 if the id is unknown */
 int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int32_t window_id, int32_t* out, int32_t cap);
 /* ---- tuning ------------------------------------------------------------------------------------- */
-/* tuning experiments and A/B switches (tools/, tests): 0 = compact-class blocks, 1 = dynamic LDS bytes, 2 = finish mode
- * (1 ticket, 2 finisher kernel), 3 = 8: in-kernel timeline, 4 = 1: no floor/log memo, 5 = 1: host window aligner,
- * 2: hits sorted on the host, 3: always the general aligner route, 4: one small-batch pipeline per mate, 6 = 1: no delta
- * list, 2: no quiet-spell rebuild, 7 = 1: always wait with hipStreamSynchronize (no spinning on the pinned partials),
- * 8 = 1: no direct writes through the BAR (staging slots + copies), 9 = 1: aligner stage times with device syncs,
- * 10 = blocks of the <=2-record class, 11 = batches: 1 one launch per path set, 2 whole tables per set, 3 no capture of
- * unchanged pairs, 32 + mask: classes of blocks left out (TIMING ONLY, results wrong; tools/batch_ablate.py),
- * 12 = 1: every path set planned from scratch, 13 = 1: whole per-call tables through the ring (no resident copy),
- * 14 / 15: table rebuilds (above), 16 = 1: record tables keep the records that can never survive the overwrite rule
- * (host_model.cc dominated_records; takes effect at the next table build; same values either way), 17 = 1: a call's delta
- * patch is made in a second pass over the touched pairs (default: written while the lists are made), 18 = d: tables are
- * rebuilt when the delta lists pass pairs / d (default 8), 19 = 1: no static memo indices (every compact-class pair is
- * resolved per call; takes effect at the next table build; same values either way), 20 = blocks of the compact class's
- * second part, 21 = blocks of paired_general_kernel.
- * Record tables: knob 6 = 1 disables the delta lists (every newly activated window rebuilds the tables); knob 14 = 1 keeps
- * every rebuild on the calling thread, knob 14 = k > 1 lets a worker's tables take over k evaluations after its start
- * (default 1152); knob 15 = 1: rebuilds never retire unused windows. */
+/* tuning experiments and A/B switches (tools/, tests): 0 = compact-class blocks, 1 = dynamic LDS bytes, 2 = finish mode of
+ * stream-ordered calls (1 two-level tickets in the kernel, 2 finisher kernel = the default), 3 = 8: in-kernel timeline,
+ * 4 = 1: no floor/log memo, 5 = window aligner: 1 host, 2 hits sorted on the host, 3 always the general route, 4 one
+ * small-batch pipeline per mate, 5 window strings through the input block, 6 hits filed on the host (default: on the
+ * device), 6 = 1: no delta lists (every newly activated window rebuilds the tables), 2: no quiet-spell rebuild, 7 = 1:
+ * always wait with hipStreamSynchronize (no spinning on the pinned partials), 8 = 1: no direct writes through the BAR
+ * (staging slots + copies), 9 = 1: aligner stage times with device syncs, 10 = blocks of the <=2-record class, 11 =
+ * batches: 1 one launch per path set, 2 whole tables per set, 3 no capture of unchanged pairs, 32 + mask: classes of
+ * blocks left out (TIMING ONLY, results wrong), 12 = 1: every path set planned from scratch, 13 = 1: whole per-call tables
+ * through the ring (no resident copy), 14 = 1: every table build on the calling stream, k > 1: a build beside the
+ * evaluations takes over k evaluations after its start (default 64), 15 = 1: rebuilds never retire unused windows,
+ * 16 = 1: record tables keep the records that can never survive the overwrite rule (takes effect at the next table build;
+ * same values either way), 18 = d: tables are rebuilt when the delta lists pass pairs / d (default 8), 19 = 1: no static
+ * memo indices (takes effect at the next table build; same values either way), 20 = blocks of the compact class's second
+ * part, 21 = blocks of paired_general_kernel, 22 = 1: delta maintenance by one-block launches only (default: multi-block
+ * above 3,000 records). Environment (development build): GAML_DL_STAMPS=1 prints the delta kernel's stage times. */
 /* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
  * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
  * number of waves copied. Tuning aid (tools/kernel_timeline.py). */

@@ -13,6 +13,9 @@ sys.path.insert(0, os.getcwd())
 from bench import source_hash  # the sources the profile was taken on: bench.py prints roofline.traffic only when it matches
 
 tag = sys.argv[1]
+wl = sys.argv[2] if len(sys.argv) > 2 else ""   # "cfg3x8": the passes of tools/profile_round.sh with --workload cfg3x8 (directories x8_*)
+pre = "x8_" if wl == "cfg3x8" else ""
+name = f"{tag}_{wl}" if wl else tag
 root = f"gpurun_out/prof_{tag}"
 
 
@@ -21,12 +24,12 @@ def find(sub, pat):
     return f[0] if f else None
 
 
-stats = find("trace", "*kernel_stats.csv")
+stats = find(pre + "trace", "*kernel_stats.csv")
 if stats:
-    shutil.copy(stats, os.path.join(root, f"{tag}_kernel_stats.csv"))
+    shutil.copy(stats, os.path.join(root, f"{name}_kernel_stats.csv"))
 res = {}
 for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = find(sub, "*counter_collection.csv")
+    f = find(pre + sub, "*counter_collection.csv")
     if not f:
         continue
     rows = [r for r in csv.DictReader(open(f)) if "paired_score_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]
@@ -42,11 +45,12 @@ if "FETCH_SIZE_KB_mean" in res and "WRITE_SIZE_KB_mean" in res:
     res["hbm_bytes_per_launch"] = (2 * res["FETCH_SIZE_KB_mean"] + res["WRITE_SIZE_KB_mean"]) * 1024
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --no-cpu-baseline "
-               "--no-extras --steps 24 --warmup 24 (cfg3; last 24 dispatches = timed steps)",
+               "--no-extras --steps 24 --warmup 24 (" + (wl or "cfg3") + "; last 24 dispatches = timed steps)",
+    "workload": wl or "cfg3",
     "source_hash": source_hash(),
     "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM); counter unit KiB",
     "round": tag,
     "kernels": {"paired_score_kernel": res},
 }
-json.dump(out, open(os.path.join(root, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, f"{name}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out))

@@ -14,6 +14,8 @@ mkdir -p "$ev"
 bash tools/profile_round.sh "$tag" || exit 1
 cp "gpurun_out/prof_$tag/${tag}_pmc_traffic.json" "gpurun_out/prof_$tag/${tag}_kernel_stats.csv" profiles/ || exit 1
 cp "gpurun_out/prof_$tag/${tag}_pmc_traffic.json" "gpurun_out/prof_$tag/${tag}_kernel_stats.csv" "$ev/"
+# the HBM-bound size: kernel stats, PMC traffic and the bench line of --workload cfg3x8 on the same sources
+cp gpurun_out/prof_$tag/${tag}_cfg3x8_* "$ev/" 2> /dev/null
 echo "== bench" && python3 bench.py > "$ev/${tag}_bench.json" 2> "$ev/bench.err" || exit 1
 echo "== one rank through the communicator" && python3 bench.py --force-dist --no-cpu-baseline > "$ev/${tag}_bench_force_rccl_1rank.json" 2> "$ev/force.err" || exit 1
 echo "== two ranks on the one GPU" && GAML_BENCH_SHARE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
