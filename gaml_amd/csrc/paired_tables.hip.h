@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int64_t kTakeOverAfter = 64;    // evaluations between the start of a rebuild beside the evaluations and its take-over
+constexpr int64_t kTakeOverAfter = 96;    // evaluations between the start of a rebuild beside the evaluations and its take-over
 constexpr int64_t kDeltaMaxPerCall = 131072;  // more new records than this in one call: rebuild instead of lists
 
 int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) b++; return b; }
@@ -212,15 +212,17 @@ int paired_reserve_tabledev(gaml_hip_ctx* c, TableDev& T, int64_t n, const int64
 // ---- table build ---------------------------------------------------------------------------------------------------
 // Enqueues one build of the record tables into T on `st`: the ACTIVE windows of both mates as they are now. The host's part
 // is the list of those windows (a few thousand headers) and the link between the two mates' windows.
-// The chain is cut into kBuildSlices slices (slice 0 also holds the host's part): a build beside the evaluations enqueues one
-// slice per evaluation -- the ~60 launches of a build are ~250 us of host time, too much for one annealing call.
+// The chain's launches are numbered as they come (unit 0: the host's part): a build beside the evaluations enqueues a few
+// units per evaluation -- the ~65 launches of a build are 250-700 us of host time (a launch into the build's own stream
+// costs ~10 us), too much for one annealing call.
 constexpr int kBuildAll = 1 << 20;
 int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t st, int slice_from = 0, int slice_to = kBuildAll) {
   BuildScratch& B = s.scratch;
   BuildPlan& P = s.build_plan;
   const int64_t n = s.mate[0].n_local();
-  int unit = 0;  // the chain's slices are numbered as they come: a slice = the host's part, or up to half a dozen launches
-  auto in = [&]() { const int u = unit++; return u >= slice_from && u <= slice_to; };
+  RsGate gate;
+  gate.from = slice_from; gate.to = slice_to;
+  auto in = [&]() { return gate(); };
   if (in()) {
     const bool fold = KNOB(c, 16) != 1;
     T.keep_dominated = !fold;
@@ -292,6 +294,7 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
   int* cnt = T.cnt.as<int>();
   auto grid = [](int64_t items) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, 4096))); };
   const int read_bits = bits_for((uint64_t)n), read_passes = rs_passes(0, read_bits);
+  (void)read_passes;
   for (int mt = 0; mt < 2; mt++) {  // a mate's records ordered by read: keys, then a slice per pass of the sort, then the reads' runs
     if (in()) {
       HIP_TRY(c, hipMemsetAsync(B.rstart[mt].p, 0, (size_t)n * sizeof(int), st));
@@ -302,10 +305,10 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
         HIP_TRY(c, hipGetLastError());
       }
     }
-    for (int ps = 0; ps < read_passes; ps++)
-      if (in() && A[mt] > 0)
-        HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), B.v_sorted[mt].as<unsigned>(), B.v_tmp.as<unsigned>(),
-                                     (size_t)A[mt], 0, read_bits, B.hist.as<unsigned>(), st, ps, ps));
+    if (A[mt] > 0)
+      HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), B.v_sorted[mt].as<unsigned>(), B.v_tmp.as<unsigned>(),
+                                   (size_t)A[mt], 0, read_bits, B.hist.as<unsigned>(), st, &gate));
+    else for (int q = 0; q < 4 * read_passes; q++) (void)in();  // (the numbering does not depend on what a mate holds)
     if (in() && A[mt] > 0) {
       hipLaunchKernelGGL(tb_segments_kernel, grid(A[mt]), dim3(256), 0, st, B.k_out.as<rs_u64>(), (int)A[mt], (int)n, B.rstart[mt].as<int>(), B.rend[mt].as<int>());
       HIP_TRY(c, hipGetLastError());
@@ -326,14 +329,15 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
     ca.cl = B.cl.as<unsigned char>(); ca.sidx = B.sidx.as<int>(); ca.cnt = cnt;
     hipLaunchKernelGGL(tb_class_kernel, grid(n), dim3(256), 0, st, ca);
     HIP_TRY(c, hipGetLastError());
+  }
+  if (in()) {
     hipLaunchKernelGGL(tb_pairkey_kernel, grid(n), dim3(256), 0, st, B.one[0].as<unsigned long long>(), B.one[1].as<unsigned long long>(), B.cl.as<unsigned char>(), (int)n,
                        (int)kFoldClass2Below, P.none1, P.none2, bits1, bits2, B.k_in.as<rs_u64>(), B.v_in.as<unsigned>(), cnt);
     HIP_TRY(c, hipGetLastError());
   }
-  for (int ps = 0; ps < rs_passes(0, 3 + bits1 + bits2); ps++)  // the device order of the pairs, a slice per pass
-    if (in())
-      HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), T.read_of_slot.as<unsigned>(), B.v_tmp.as<unsigned>(), (size_t)n, 0,
-                                   3 + bits1 + bits2, B.hist.as<unsigned>(), st, ps, ps));
+  // the device order of the pairs
+  HIP_TRY(c, rs_sort<unsigned>(B.k_in.as<rs_u64>(), B.k_out.as<rs_u64>(), B.k_tmp.as<rs_u64>(), B.v_in.as<unsigned>(), T.read_of_slot.as<unsigned>(), B.v_tmp.as<unsigned>(), (size_t)n, 0,
+                               3 + bits1 + bits2, B.hist.as<unsigned>(), st, &gate));
   if (in()) {
     TbCompactArgs ka;
     ka.order = T.read_of_slot.as<unsigned>();
@@ -349,9 +353,11 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
   }
   const unsigned tiles = P.tiles;
   for (int mt = 0; mt < 2; mt++) {
+    if (in()) {
+      hipLaunchKernelGGL(tb_scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, B.more[mt].as<int>(), cnt, (int)n, B.tiles.as<int>());
+      hipLaunchKernelGGL(tb_scan_top_kernel, dim3(1), dim3(1024), 0, st, B.tiles.as<int>(), (int)tiles, cnt + kTbExtras0 + mt);
+    }
     if (!in()) continue;
-    hipLaunchKernelGGL(tb_scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, B.more[mt].as<int>(), cnt, (int)n, B.tiles.as<int>());
-    hipLaunchKernelGGL(tb_scan_top_kernel, dim3(1), dim3(1024), 0, st, B.tiles.as<int>(), (int)tiles, cnt + kTbExtras0 + mt);
     hipLaunchKernelGGL(tb_scan_apply_kernel, dim3(tiles), dim3(256), 0, st, B.more[mt].as<int>(), cnt, (int)n, B.tiles.as<int>(), B.start[mt].as<int>());
     TbFillArgs fa;
     fa.pool = s.dev[mt].pool.as<int4>(); fa.vals = B.v_sorted[mt].as<unsigned>(); fa.rstart = B.rstart[mt].as<int>(); fa.rend = B.rend[mt].as<int>();
@@ -367,7 +373,7 @@ int paired_build_enqueue(gaml_hip_ctx* c, PairedSet& s, TableDev& T, hipStream_t
     }
     HIP_TRY(c, hipMemcpyAsync(B.h_cnt.p, T.cnt.p, kTbInts * sizeof(int), hipMemcpyDeviceToHost, st));
   }
-  P.units = unit;
+  P.units = gate.next;
   return 0;
 }
 
@@ -673,7 +679,7 @@ int paired_start_async_rebuild(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
 int paired_build_continue(gaml_hip_ctx* c, PairedSet& s, bool rest) {
   TableRebuild& rb = s.rebuild;
   if (!rb.active || rb.next_slice >= s.build_plan.units) return 0;
-  const int to = rest ? kBuildAll : rb.next_slice;
+  const int to = rest ? kBuildAll : rb.next_slice + 1;  // two launches per evaluation
   if (int e = paired_build_enqueue(c, s, rb.tab, rb.stream, rb.next_slice, to)) return e;
   rb.next_slice = rest ? s.build_plan.units : to + 1;
   if (rb.next_slice >= s.build_plan.units) HIP_TRY(c, hipEventRecord(rb.done, rb.stream));

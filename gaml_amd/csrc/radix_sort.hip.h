@@ -138,10 +138,15 @@ inline size_t rs_hist_bytes(size_t n) { return (size_t)256 * ((n + kRsTile - 1) 
 // keys_in / vals_in are left untouched; the result lands in keys_out / vals_out; keys_tmp / vals_tmp: n entries each
 // (vals_*: null for a key-only sort). Bits [begin_bit, end_bit) take part. Everything is enqueued on `st`.
 inline int rs_passes(int begin_bit, int end_bit) { return (end_bit - begin_bit + 7) / 8; }
-// pass_from / pass_to: enqueue only these passes of the sort (a caller that spreads the launches over several of its own steps)
+// A caller that spreads a chain of launches over several of its own steps numbers the launches as they come and lets through
+// those of the step at hand: gate() is asked once per launch, in a fixed order.
+struct RsGate {
+  int next = 0, from = 0, to = 1 << 30;
+  bool operator()() { const int u = next++; return u >= from && u <= to; }
+};
 template <class V>
 inline hipError_t rs_sort(const rs_u64* keys_in, rs_u64* keys_out, rs_u64* keys_tmp, const V* vals_in, V* vals_out, V* vals_tmp, size_t n, int begin_bit, int end_bit,
-                          unsigned* hist, hipStream_t st, int pass_from = 0, int pass_to = 1 << 30) {
+                          unsigned* hist, hipStream_t st, RsGate* gate = nullptr) {
   if (n == 0) return hipSuccess;
   if (n >= ((size_t)1 << 31)) return hipErrorInvalidValue;
   const bool has_v = vals_in != nullptr;
@@ -158,15 +163,17 @@ inline hipError_t rs_sort(const rs_u64* keys_in, rs_u64* keys_out, rs_u64* keys_
     const bool to_out = ((passes - 1 - p) & 1) == 0;  // the last pass writes the caller's output
     rs_u64* dst_k = to_out ? keys_out : keys_tmp;
     V* dst_v = to_out ? vals_out : vals_tmp;
-    if (p < pass_from || p > pass_to) { src_k = dst_k; src_v = dst_v; continue; }
     const int shift = begin_bit + 8 * p;
     const unsigned mask = (1u << (end_bit - shift < 8 ? end_bit - shift : 8)) - 1u;  // the last pass may hold fewer than eight bits
-    hipLaunchKernelGGL(rs_histogram_kernel, dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, (unsigned)n, shift, mask, n_blocks, hist);
+    auto go = [&]() { return gate ? (*gate)() : true; };
+    if (go()) hipLaunchKernelGGL(rs_histogram_kernel, dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, (unsigned)n, shift, mask, n_blocks, hist);
     unsigned* const totals = hist + (size_t)256 * n_blocks;
-    hipLaunchKernelGGL(rs_scan_digit_kernel, dim3(256), dim3(kRsBlock), 0, st, hist, n_blocks, totals);
-    hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(kRsBlock), 0, st, totals);
-    if (has_v) hipLaunchKernelGGL((rs_scatter_kernel<V, true>), dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, src_v, (unsigned)n, shift, mask, n_blocks, hist, totals, dst_k, dst_v);
-    else hipLaunchKernelGGL((rs_scatter_kernel<V, false>), dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, (const V*)nullptr, (unsigned)n, shift, mask, n_blocks, hist, totals, dst_k, (V*)nullptr);
+    if (go()) hipLaunchKernelGGL(rs_scan_digit_kernel, dim3(256), dim3(kRsBlock), 0, st, hist, n_blocks, totals);
+    if (go()) hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(kRsBlock), 0, st, totals);
+    if (go()) {
+      if (has_v) hipLaunchKernelGGL((rs_scatter_kernel<V, true>), dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, src_v, (unsigned)n, shift, mask, n_blocks, hist, totals, dst_k, dst_v);
+      else hipLaunchKernelGGL((rs_scatter_kernel<V, false>), dim3(n_blocks), dim3(kRsBlock), 0, st, src_k, (const V*)nullptr, (unsigned)n, shift, mask, n_blocks, hist, totals, dst_k, (V*)nullptr);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     src_k = dst_k; src_v = dst_v;
