@@ -729,7 +729,7 @@ int paired_sync_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   // Windows activated since the tables were built put their pairs on the delta lists. The tables are rebuilt when the
   // lists pass pairs / 8, when the cache has been quiet for 64 evaluations with pairs still on the lists, or on request
   // (gaml_hip_compact_tables: at the next evaluation, on the calling stream).
-  const int64_t limit = KNOB(c, 6) == 1 ? 0 : std::max<int64_t>(4096, np / (KNOB(c, 18) > 0 ? KNOB(c, 18) : 8));
+  const int64_t limit = KNOB(c, 6) == 1 ? 0 : (KNOB(c, 18) > 0 ? std::max<int64_t>(256, np / KNOB(c, 18)) : std::max<int64_t>(4096, np / 8));  // (knob 18: tests and soaks want rebuilds at small sizes)
   int64_t new_records = 0;
   if (activated_now) for (int mt = 0; mt < 2; mt++) for (int32_t w : s.mate[mt].activated_log) new_records += s.mate[mt].wins[w].count;
   const bool over = activated_now && s.nd_est + new_records > limit;

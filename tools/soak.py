@@ -32,6 +32,11 @@ for seed in range(200, 200 + n_seeds):
     pr = synth.make_paired_reads(genome, n, L, mean, mean / 10, 0.01, seed)
     args = (*synth.pack_reads(pr.mate1), *synth.pack_reads(pr.mate2))
     ctx = api.Context(device=0)
+    # the table machinery at sizes where it would otherwise never run: rebuilds when the delta lists pass pairs / d, taking over
+    # k evaluations after their start (1: on the calling stream), delta maintenance by one-block / multi-block launches
+    knobs = {18: int(rng.choice([0, 16, 64])), 14: int(rng.choice([0, 1, 8, 24])), 22: int(rng.choice([0, 1]))}
+    for k, v in knobs.items():
+        ctx.debug_set_knob(k, v)
     ctx.set_graph(*g.packed())
     rs = ctx.add_paired(api.paired_cfg(mean, mean / 10, penalty_constant=penalty), *args)
     orc = op.Oracle()
@@ -61,6 +66,6 @@ for seed in range(200, 200 + n_seeds):
         if rng.random() < 0.6:
             cur = new
     st = ctx.debug_table_stats(rs)
-    print(f"seed {seed}: G={G} pairs={n} L={L} penalty={penalty} ok; worst rel delta so far {worst:.2e}; tables {st}", flush=True)
+    print(f"seed {seed}: G={G} pairs={n} L={L} penalty={penalty} knobs={knobs} ok; worst rel delta so far {worst:.2e}; tables {st}", flush=True)
 assert worst <= 1e-9, worst
 print(f"soak passed: {n_seeds} seeds x {steps} steps in {time.time() - t_all:.0f} s, worst relative difference {worst:.2e}")
