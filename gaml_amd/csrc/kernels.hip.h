@@ -631,6 +631,11 @@ __device__ __forceinline__ void compact_load(const PairedArgs& a, int i, bool ok
   c.lc = ok ? a.len_code[i] : 0;
 }
 
+#if defined(GAML_HIP_DEV) && defined(GAML_GEN_X)  // timing experiments of the development build (results WRONG), tools/build_variant.sh -DGAML_GEN_X=..: of the pairs on windows that occur several times: 1 static part of class 0, 8 its second part, 2 classes 1 / 2, 4 delta pairs, 16 no wave-per-pair blocks
+#define GAML_GEN_OFF(bit) ((GAML_GEN_X) & (bit))
+#else
+#define GAML_GEN_OFF(bit) 0
+#endif
 // One part of class 0 and the blocks that score it: slots [lo, hi), `blocks` blocks of which this is number `lb`; the
 // part's notes for paired_general_kernel start at word gen_w.
 struct SlotRange { int lo, hi, lb, blocks, gen_w; };
@@ -638,14 +643,14 @@ __device__ __forceinline__ SlotRange compact_range(const PairedArgs& a, int lb) 
   return lb < a.blocks0a ? SlotRange{0, a.n0a, lb, a.blocks0a, 0} : SlotRange{a.n0a, a.n0, lb - a.blocks0a, a.blocks0 - a.blocks0a, a.gen_w0b};
 }
 
-template <bool GEN>
+template <int GEN>
 __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, const SlotRange rg, double& lsum, int& zeros) {
   // Class 0 in the general form (coverage marks to set, or no memo): two pairs per lane and iteration, software
   // pipelined -- the record loads of iteration k+1 are issued before iteration k's occurrence lookups and arithmetic.
   const int stride = rg.blocks * kBlock, hi = rg.hi;
   int i0 = rg.lo + rg.lb * kBlock + threadIdx.x;
   if (i0 >= hi) return;
-  unsigned long long* const gen_bits = GEN ? a.gen_bits + rg.gen_w : nullptr;
+  unsigned long long* const gen_bits = GEN == 1 ? a.gen_bits + rg.gen_w : nullptr;
   Compact1 c0, c1;
   compact_load(a, i0, true, c0);
   compact_load(a, i0 + stride, i0 + stride < hi, c1);
@@ -672,12 +677,14 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, const S
     // both memo entries are requested before anything is stored
     const double2 m0 = q0.memo_idx >= 0 ? a.memo[q0.memo_idx] : make_double2(0.0, 0.0);
     const double2 m1 = q1.memo_idx >= 0 ? a.memo[q1.memo_idx] : make_double2(0.0, 0.0);
-    if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
+    if (GEN == 1) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
       const unsigned long long k0 = __ballot(q0.skip), k1 = __ballot(q1.skip);
       if ((threadIdx.x & 63) == 0) { gen_bits[(i0 - rg.lo) >> 6] = k0; if (two) gen_bits[(i1 - rg.lo) >> 6] = k1; }
     }
     if (!d0 && !q0.skip) compact_finish(a, i0, c0, q0, m0, lsum, zeros);
+    else if (GEN == 2 && q0.skip) compact_general(a, i0, lsum, zeros);
     if (two && !d1 && !q1.skip) compact_finish(a, i1, c1, q1, m1, lsum, zeros);
+    else if (GEN == 2 && two && q1.skip) compact_general(a, i1, lsum, zeros);
     if (!more) break;
     c0 = n0v; c1 = n1v;
     i0 = j0;
@@ -720,10 +727,10 @@ __device__ __forceinline__ int compact_state(const PairedArgs& a, uint2 r1, uint
 
 // ONE: every pair has the same length combination (n_codes == 1, the usual case): no length-code loads, no LDS tables --
 // the combination and its log-floor are two uniform values.
-template <bool GEN, bool TL = false, bool ONE = false>
+template <int GEN, bool TL = false, bool ONE = false>
 __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const SlotRange rg, double& lsum, int& zeros) {
   const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;  // (n0: end of this part's slots)
-  unsigned long long* const gen_bits = GEN ? a.gen_bits + rg.gen_w : nullptr;
+  unsigned long long* const gen_bits = GEN == 1 ? a.gen_bits + rg.gen_w : nullptr;
   unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
 #define GAML_STAMP(slot, dep) if (TL) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[slot] = (unsigned long long)wall_clock64() + ((dep) == 0x12345u ? 1 : 0); }
   // 32-bit byte offsets from uniform bases: one address register per load instead of a 64-bit add (tables < 4 GB)
@@ -763,7 +770,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const 
 #pragma unroll
     for (int k = 0; k < 4; k++) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
     GAML_STAMP(4, (unsigned)(__double2loint(m[0].x) ^ __double2loint(m[1].x) ^ __double2loint(m[2].x) ^ __double2loint(m[3].x)))
-    if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
+    if (GEN == 1) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const unsigned long long w = __ballot((skip_bits >> k) & 1u);
@@ -802,6 +809,11 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const 
         compact_prep(a, d, q);
         compact_finish(a, i, d, q, make_double2(0.0, 0.0), lsum, zeros);
       }
+    }
+    if (GEN == 2 && !GAML_GEN_OFF(8) && __any(skip_bits != 0)) {  // pairs on a window that occurs several times: here, after the round's other pairs
+#pragma unroll 1
+      for (int k = 0; k < 4; k++)
+        if ((skip_bits >> k) & 1u) compact_general(a, (int)(base + k * stride), lsum, zeros);
     }
   }
 #undef GAML_STAMP
@@ -860,11 +872,11 @@ __global__ __launch_bounds__(kBlock) void static_values_kernel(const int* static
 // Rounds of P pairs per lane, software-pipelined when a lane takes several: a round's occurrence entries are requested,
 // then the NEXT round's records and values, then the round is finished -- its arithmetic and stores run under the next
 // round's loads.
-template <bool GEN, bool TL = false, bool ONE = false>
+template <int GEN, bool TL = false, bool ONE = false>
 __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const SlotRange rg, double& lsum, int& zeros) {
   constexpr int P = GAML_STATIC_P;
   const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;
-  unsigned long long* const gen_bits = GEN ? a.gen_bits + rg.gen_w : nullptr;
+  unsigned long long* const gen_bits = GEN == 1 ? a.gen_bits + rg.gen_w : nullptr;
   unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
 #define GAML_STAMP(slot, dep) if (TL && first_round) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[slot] = (unsigned long long)wall_clock64() + ((dep) == 0x12345u ? 1 : 0); }
   const char* const rec0 = (const char*)a.rec8[0];
@@ -947,12 +959,16 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
       zeros += (int)floored;
       if (counted && !GAML_TIMING_X(2)) __builtin_nontemporal_store(t, (double*)(probs + (base + k * stride) * 8u));
     }
-    if (GEN) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
+    if (GEN == 1) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
 #pragma unroll
       for (int k = 0; k < P; k++) {
         const unsigned long long w = __ballot((skip_bits >> k) & 1u);
         if ((threadIdx.x & 63) == 0 && base + k * stride < n0) gen_bits[(base + k * stride - (unsigned)rg.lo) >> 6] = w;
       }
+    } else if (GEN == 2 && !GAML_GEN_OFF(1) && __any(skip_bits != 0)) {  // ... or score them here, after the round's other pairs
+#pragma unroll 1
+      for (int k = 0; k < P; k++)
+        if ((skip_bits >> k) & 1u) compact_general(a, (int)(base + k * stride), lsum, zeros);
     }
     GAML_STAMP(5, 0u)
     first_round = false;
@@ -971,6 +987,117 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
     }
   }
 #undef GAML_STAMP
+}
+
+// One pair with up to four records per mate (table classes 1 and 2 through their inline copies, delta pairs at the fixed
+// stride) on windows that occur several times, in a lane: every load of a stage asked for before any is used -- the eight
+// records, their occurrence entries, the bounds of their occurrence lists, the lists' entries -- four dependent trips, where
+// the general loop (paired_general_src_masks) derives each candidate anew for every liveness test and every term: hundreds of
+// dependent chains for a read in a 5-copy repeat seen through two windows. The candidates sit in (private) arrays; more than
+// kGenCands on a mate: false, the caller takes the loop. Same candidates, same liveness rule, same terms in the same order.
+constexpr int kGenCands = 16;
+__device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const int4 (&r1)[4], const int4 (&r2)[4], int L1, int L2, double& acc_out) {
+  int4 cand[2][kGenCands];  // {path, position on the path, edit | orient << 8 | valid << 9, rank}; index = visiting order
+  int ck[2][kGenCands];     // the record the candidate came from (ties between equal ranks go by record)
+  int n[2] = {0, 0};
+  Occ12 e[2][4];
+  int lb[2][4], le[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int4& r = m == 0 ? r1[k] : r2[k]; e[m][k] = a.m[m].occ12[r.x >= 0 ? r.x : 0]; }
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int4& r = m == 0 ? r1[k] : r2[k];
+      const bool occurs = r.x >= 0 && !(e[m][k].lo == ~0u && e[m][k].hi == ~0u);
+      const bool list = occurs && e[m][k].rank < 0;
+      lb[m][k] = le[m][k] = 0;
+      if (list) { const int s = -e[m][k].rank - 1; lb[m][k] = a.m[m].multi_off[s]; le[m][k] = a.m[m].multi_off[s + 1]; }
+      else if (occurs) le[m][k] = -1;  // one occurrence, described by the entry itself
+    }
+  bool fits = true;
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int4& r = m == 0 ? r1[k] : r2[k];
+      if (le[m][k] == -1) {
+        if (n[m] < kGenCands) {
+          const int4 o = occ_from_compact((unsigned long long)e[m][k].lo | ((unsigned long long)e[m][k].hi << 32), e[m][k].rank);
+          cand[m][n[m]] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | (r.y >= o.y ? 0x200 : 0), o.w);
+          ck[m][n[m]] = k;
+        }
+        n[m]++;
+      } else {
+        for (int q = lb[m][k]; q < le[m][k]; q++) {
+          if (n[m] < kGenCands) {
+            const int4 o = a.m[m].multi[q];
+            cand[m][n[m]] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | (r.y >= o.y ? 0x200 : 0), o.w);
+            ck[m][n[m]] = k;
+          }
+          n[m]++;
+        }
+      }
+    }
+    fits = fits && n[m] <= kGenCands;
+  }
+  if (!fits) return false;
+  // liveness (graph.cc:583-592): valid, and no later valid candidate of the mate at the same (path, position)
+  unsigned live[2] = {0, 0};
+  for (int m = 0; m < 2; m++)
+    for (int x = 0; x < n[m]; x++) {
+      const int4 me = cand[m][x];
+      bool lv = (me.z & 0x200) != 0;
+      for (int y = 0; y < n[m] && lv; y++) {
+        const int4 ot = cand[m][y];
+        if (y != x && (ot.z & 0x200) && ot.x == me.x && ot.y == me.y && (ot.w > me.w || (ot.w == me.w && ck[m][y] > ck[m][x]))) lv = false;
+      }
+      if (lv) live[m] |= 1u << x;
+    }
+  double acc = 0.0;
+  for (int x = 0; x < n[0]; x++) {
+    if (!((live[0] >> x) & 1u)) continue;
+    const int4 cx = cand[0][x];
+    Cand X; X.path = cx.x; X.pos = cx.y; X.edit = cx.z & 0xff; X.orient = (cx.z >> 8) & 1;
+    for (int y = 0; y < n[1]; y++) {
+      if (!((live[1] >> y) & 1u)) continue;
+      const int4 cy = cand[1][y];
+      if (cy.x != cx.x) continue;
+      Cand Y; Y.path = cy.x; Y.pos = cy.y; Y.edit = cy.z & 0xff; Y.orient = (cy.z >> 8) & 1;
+      acc += pair_term(a, X, Y, L1, L2);
+    }
+  }
+  acc_out = acc;
+  return true;
+}
+
+// A table pair of class 1 / 2 (K records per mate, the inline copies) and a delta pair on a window that occurs several times,
+// finished in the lane that met it (GEN == 2 launches; paired_general_kernel does the same for the pairs a GEN == 1 launch noted)
+template <int K>
+__device__ __forceinline__ void general_table_pair(const PairedArgs& a, int i, uint32_t l12, const int4 (&r1)[K], const int4 (&r2)[K], double& lsum, int& zeros,
+                                                   PairVal* cap = nullptr) {
+  const int4 none = make_int4(-1, 0, 0, 0);
+  int4 q1[4], q2[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { q1[k] = k < K ? r1[k < K ? k : 0] : none; q2[k] = k < K ? r2[k < K ? k : 0] : none; }
+  const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+  double acc;
+  if (!general_pair_staged(a, q1, q2, L1, L2, acc)) acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
+  finish_read(a, i, acc, L1, L2, lsum, zeros, cap);
+}
+__device__ __forceinline__ void general_delta_pair(const PairedArgs& a, int dj, int i, double& lsum, int& zeros, PairVal* cap = nullptr) {
+  int4 r1[4], r2[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { r1[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r2[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
+  const uint32_t l12 = (uint32_t)r1[0].w;
+  const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+  const int c0 = r2[0].w & 0xff, c1 = (r2[0].w >> 8) & 0xff;
+  double acc;
+  if (!general_pair_staged(a, r1, r2, L1, L2, acc))
+    acc = paired_general_src_masks(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
+  finish_read(a, i, acc, L1, L2, lsum, zeros, cap);
 }
 
 // up to K live candidates per mate in registers -> per-read probability, floor / log, running sums
@@ -1026,10 +1153,10 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
 // Slots [slot_lo, slot_hi), blocks [block_lo, block_hi).
 // (tl: the in-kernel timeline's slot of this wave, stamps [2] records in, [3] candidates (occurrence entries) in, [5]
 // first pair finished -- tools/kernel_timeline.py)
-template <int K, bool GEN>
+template <int K, int GEN>
 __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
                                                  double& lsum, int& zeros, unsigned long long* tl = nullptr) {
-  unsigned long long* bits = GEN ? a.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2) : nullptr;
+  unsigned long long* bits = GEN == 1 ? a.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2) : nullptr;
   bool first_pair = true;
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
     const int t = i - a.n0;
@@ -1049,22 +1176,22 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
     if (!dirty && !general) score_cands_and_finish<K>(a, i, l12, x, y, lsum, zeros);
     if (tl && first_pair) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[5] = (unsigned long long)wall_clock64() + (lsum == 0.12345 ? 1 : 0); }
     first_pair = false;
-    if (GEN) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
+    if (GEN == 1) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
       const unsigned long long k = __ballot(general);
       if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
-    }
+    } else if (GEN == 2 && !GAML_GEN_OFF(2) && general) general_table_pair<K>(a, i, l12, r1, r2, lsum, zeros);
   }
 }
 
 // Delta pairs (pairs that gained records since the tables were built): one LANE per pair, records from
 // the delta lists. Up to 4 records per mate go through the register path of class 2; longer lists and
 // pairs touching a window that occurs several times take the fully general per-lane loop (rare).
-template <bool GEN>
+template <int GEN>
 __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, int delta_blocks, double& lsum, int& zeros) {
   // (a delta pair touching a window that occurs several times is only NOTED here -- GEN launches: a bit per delta index,
   // one ballot word per wave and iteration -- and scored by paired_general_kernel: the general loop inside this kernel,
   // one lane re-deriving every candidate's liveness for every candidate, made a late annealing walk's launch 60 us)
-  unsigned long long* const notes = GEN ? a.gen_bits + a.gen_wd : nullptr;
+  unsigned long long* const notes = GEN == 1 ? a.gen_bits + a.gen_wd : nullptr;
   for (int dj = db * kBlock + threadIdx.x; dj < a.dstate[kDsDirty]; dj += delta_blocks * kBlock) {
     // Everything a delta pair needs sits at index dj (no chain through the pair's slot): the first record of mate 1
     // carries the two read lengths in its spare word, the first record of mate 2 the two list lengths (paired_upload_delta)
@@ -1092,9 +1219,11 @@ __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, i
       general = m0 || m1;
       if (!general) score_cands_and_finish<4>(a, i, l12, x, y, lsum, zeros);
     }
-    if (GEN) {  // lane 0 holds the wave's lowest delta index: it is active whenever any lane is
+    if (GEN == 1) {  // lane 0 holds the wave's lowest delta index: it is active whenever any lane is
       const unsigned long long k = __ballot(general);
       if ((threadIdx.x & 63) == 0) notes[dj >> 6] = k;
+    } else if (GEN == 2) {
+      if (general && !GAML_GEN_OFF(4)) general_delta_pair(a, dj, i, lsum, zeros);
     } else if (general) {  // cannot happen (a launch without notes has no such window): the partial is poisoned, combine() reports it
       lsum += __builtin_nan("");
     }
@@ -1136,7 +1265,7 @@ __global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const Patch* 
 }
 
 // TL: the in-kernel timeline of tools/kernel_timeline.py (a separate instantiation: the product kernels carry none of it)
-template <bool TICKET, bool GEN, bool TL>
+template <bool TICKET, int GEN, bool TL>
 __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z) {
   // `a`: the argument block as the kernel received it; only its leading words (grid layout, partial slots) are read
   // here -- every class takes a fresh view of its own (GAML_FRESH_ARGS)
@@ -1338,8 +1467,11 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
 // but read-only tables, so no ordering between them is needed.
 // GEN: the path set has windows that occur several times -- note their pairs for paired_general_kernel. Without
 // such windows the notes are compiled out (they cost 0.3 us of 12 at cfg3 even when nothing is noted).
-template <bool TICKET, bool GEN = false, bool TL = false>
-__global__ __launch_bounds__(kBlock, 5) void paired_score_kernel(PairedArgs a) {
+#ifndef GAML_GEN_WAVES
+#define GAML_GEN_WAVES 4
+#endif
+template <bool TICKET, int GEN = 0, bool TL = false>
+__global__ __launch_bounds__(kBlock, GEN == 2 ? GAML_GEN_WAVES : 5) void paired_score_kernel(PairedArgs a) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
   __shared__ int4 cand[kBlock / 64][2][kOvfCap];
@@ -1364,6 +1496,7 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_kernel(PairedArgs a) {
     return;
   }
   if (lb < a.main_blocks) paired_main_body<TICKET, GEN, TL>(a, lb, sh_s, sh_z);
+  else if (GAML_GEN_OFF(16)) { if (threadIdx.x == 0) { a.part_sum[lb] = 0.0; a.part_zero[lb] = 0; } }
   else {
     GAML_FRESH_ARGS(c, a)
     paired_overflow_body<TICKET>(c, lb - c.main_blocks, c.total_blocks - c.main_blocks, sh_s, sh_z, cand);
@@ -1416,7 +1549,7 @@ __device__ __forceinline__ PairedArgs with_set(const PairedArgs& a, const SetDev
 
 // paired_compact4_body with the path sets in the inner loop. acc_s / acc_z: one running sum per (set, thread) in LDS
 // (a lane may take several rounds of four pairs; registers cannot be indexed by the set number).
-template <bool GEN, bool ONE>
+template <int GEN, bool ONE>
 __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, const MultiSets& ms, const SlotRange rg, double* acc_s, int* acc_z, const double* tf) {
   const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;  // (n0: end of this part's slots)
   const char* const rec0 = (const char*)a.rec8[0];
@@ -1463,7 +1596,7 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
       double2 m[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
-      if (GEN) {
+      if (GEN == 1) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const unsigned long long w = __ballot((skip_bits >> k) & 1u);
@@ -1504,6 +1637,12 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
           compact_finish(b, i, d, q, make_double2(0.0, 0.0), lsum, zeros);
         }
       }
+      if (GEN == 2 && __any(skip_bits != 0)) {  // as paired_compact4_body
+        const PairedArgs b = with_set(a, sd, tf ? tfs : nullptr);
+#pragma unroll 1
+        for (int k = 0; k < 4; k++)
+          if ((skip_bits >> k) & 1u) compact_general(b, (int)(base + k * stride), lsum, zeros);
+      }
       acc_s[s * kBlock + threadIdx.x] += lsum;
       acc_z[s * kBlock + threadIdx.x] += zeros;
     }
@@ -1514,7 +1653,7 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
 // (the per-set arithmetic above goes records -> occurrence entries -> memo index -> memo entry, two dependent trips per set;
 // here a set costs one: its occurrence entries). Lanes, pairs, the values added and their order are the single-set
 // kernel's: a batch gives bit for bit what the sets give one by one.
-template <bool GEN, bool ONE>
+template <int GEN, bool ONE>
 __device__ __forceinline__ void paired_static4_multi_body(const PairedArgs& a, const MultiSets& ms, const SlotRange rg, double* acc_s, int* acc_z, const double* tf) {
   const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;
   const char* const rec0 = (const char*)a.rec8[0];
@@ -1575,12 +1714,17 @@ __device__ __forceinline__ void paired_static4_multi_body(const PairedArgs& a, c
         zeros += (int)floored;
         if (counted && last_set) __builtin_nontemporal_store(t, (double*)(probs + (base + k * stride) * 8u));
       }
-      if (GEN) {
+      if (GEN == 1) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const unsigned long long w = __ballot((skip_bits >> k) & 1u);
           if ((threadIdx.x & 63) == 0 && base + k * stride < n0) sd.gen_bits[rg.gen_w + ((base + k * stride - (unsigned)rg.lo) >> 6)] = w;
         }
+      } else if (GEN == 2 && __any(skip_bits != 0)) {  // as paired_static4_body
+        const PairedArgs b = with_set(a, sd, tf ? tfs : nullptr);
+#pragma unroll 1
+        for (int k = 0; k < 4; k++)
+          if ((skip_bits >> k) & 1u) compact_general(b, (int)(base + k * stride), lsum, zeros);
       }
       acc_s[s * kBlock + threadIdx.x] = lsum;
       acc_z[s * kBlock + threadIdx.x] = zeros;
@@ -1591,7 +1735,7 @@ __device__ __forceinline__ void paired_static4_multi_body(const PairedArgs& a, c
 // Classes 1 and 2 with the path sets in the inner loop (paired_regs_body's pairs, lane -> pair mapping and order of
 // additions): records once, set 0 resolved and captured, later sets finished from the capture unless one of the
 // pair's windows changed.
-template <int K, bool GEN>
+template <int K, int GEN>
 __device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, const MultiSets& ms, int lb, int slot_lo, int slot_hi, int block_lo,
                                                        int block_hi, double* acc_s, int* acc_z, const double* tf) {
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
@@ -1622,11 +1766,11 @@ __device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, cons
       } else {
         finish_val(b, i, val, s == ms.n - 1, lsum, zeros);
       }
-      if (GEN) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
+      if (GEN == 1) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
         unsigned long long* bits = b.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2);
         const unsigned long long k = __ballot(general);
         if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
-      }
+      } else if (GEN == 2 && general) general_table_pair<K>(b, i, l12, r1, r2, lsum, zeros);  // (in every set: val holds nothing of such a pair)
       acc_s[s * kBlock + threadIdx.x] = lsum;
       acc_z[s * kBlock + threadIdx.x] = zeros;
     }
@@ -1634,7 +1778,7 @@ __device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, cons
 }
 
 // paired_delta_body with the path sets in the inner loop
-template <bool GEN>
+template <int GEN>
 __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, const MultiSets& ms, int db, int delta_blocks, double* acc_s, int* acc_z, const double* tf) {
   for (int dj = db * kBlock + threadIdx.x; dj < a.dstate[kDsDirty]; dj += delta_blocks * kBlock) {
     const int i = a.dirty_slots[dj];
@@ -1670,10 +1814,10 @@ __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, con
       } else {
         finish_val(b, i, val, s == ms.n - 1, lsum, zeros);
       }
-      if (GEN) {
+      if (GEN == 1) {
         const unsigned long long k = __ballot(general);
         if ((threadIdx.x & 63) == 0) b.gen_bits[a.gen_wd + (dj >> 6)] = k;
-      }
+      } else if (GEN == 2 && mine && general) general_delta_pair(b, dj, i, lsum, zeros);
       acc_s[s * kBlock + threadIdx.x] = lsum;
       acc_z[s * kBlock + threadIdx.x] = zeros;
     }
@@ -1739,7 +1883,7 @@ __device__ __forceinline__ void paired_overflow_multi_body(const PairedArgs& a, 
   }
 }
 
-template <bool GEN>
+template <int GEN>
 __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArgs a, MultiSets ms) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
@@ -1817,90 +1961,6 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArg
     if (threadIdx.x == 0) { ms.set[s].part_sum[lb] = lsum; ms.set[s].part_zero[lb] = zeros; }
     __syncthreads();
   }
-}
-
-// One pair with up to four records per mate (table classes 1 and 2 through their inline copies, delta pairs at the fixed
-// stride) on windows that occur several times, in a lane: every load of a stage asked for before any is used -- the eight
-// records, their occurrence entries, the bounds of their occurrence lists, the lists' entries -- four dependent trips, where
-// the general loop (paired_general_src_masks) derives each candidate anew for every liveness test and every term: hundreds of
-// dependent chains for a read in a 5-copy repeat seen through two windows. The candidates sit in (private) arrays; more than
-// kGenCands on a mate: false, the caller takes the loop. Same candidates, same liveness rule, same terms in the same order.
-constexpr int kGenCands = 16;
-__device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const int4 (&r1)[4], const int4 (&r2)[4], int L1, int L2, double& acc_out) {
-  int4 cand[2][kGenCands];  // {path, position on the path, edit | orient << 8 | valid << 9, rank}; index = visiting order
-  int ck[2][kGenCands];     // the record the candidate came from (ties between equal ranks go by record)
-  int n[2] = {0, 0};
-  Occ12 e[2][4];
-  int lb[2][4], le[2][4];
-#pragma unroll
-  for (int m = 0; m < 2; m++)
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int4& r = m == 0 ? r1[k] : r2[k]; e[m][k] = a.m[m].occ12[r.x >= 0 ? r.x : 0]; }
-#pragma unroll
-  for (int m = 0; m < 2; m++)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int4& r = m == 0 ? r1[k] : r2[k];
-      const bool occurs = r.x >= 0 && !(e[m][k].lo == ~0u && e[m][k].hi == ~0u);
-      const bool list = occurs && e[m][k].rank < 0;
-      lb[m][k] = le[m][k] = 0;
-      if (list) { const int s = -e[m][k].rank - 1; lb[m][k] = a.m[m].multi_off[s]; le[m][k] = a.m[m].multi_off[s + 1]; }
-      else if (occurs) le[m][k] = -1;  // one occurrence, described by the entry itself
-    }
-  bool fits = true;
-#pragma unroll
-  for (int m = 0; m < 2; m++) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int4& r = m == 0 ? r1[k] : r2[k];
-      if (le[m][k] == -1) {
-        if (n[m] < kGenCands) {
-          const int4 o = occ_from_compact((unsigned long long)e[m][k].lo | ((unsigned long long)e[m][k].hi << 32), e[m][k].rank);
-          cand[m][n[m]] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | (r.y >= o.y ? 0x200 : 0), o.w);
-          ck[m][n[m]] = k;
-        }
-        n[m]++;
-      } else {
-        for (int q = lb[m][k]; q < le[m][k]; q++) {
-          if (n[m] < kGenCands) {
-            const int4 o = a.m[m].multi[q];
-            cand[m][n[m]] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | (r.y >= o.y ? 0x200 : 0), o.w);
-            ck[m][n[m]] = k;
-          }
-          n[m]++;
-        }
-      }
-    }
-    fits = fits && n[m] <= kGenCands;
-  }
-  if (!fits) return false;
-  // liveness (graph.cc:583-592): valid, and no later valid candidate of the mate at the same (path, position)
-  unsigned live[2] = {0, 0};
-  for (int m = 0; m < 2; m++)
-    for (int x = 0; x < n[m]; x++) {
-      const int4 me = cand[m][x];
-      bool lv = (me.z & 0x200) != 0;
-      for (int y = 0; y < n[m] && lv; y++) {
-        const int4 ot = cand[m][y];
-        if (y != x && (ot.z & 0x200) && ot.x == me.x && ot.y == me.y && (ot.w > me.w || (ot.w == me.w && ck[m][y] > ck[m][x]))) lv = false;
-      }
-      if (lv) live[m] |= 1u << x;
-    }
-  double acc = 0.0;
-  for (int x = 0; x < n[0]; x++) {
-    if (!((live[0] >> x) & 1u)) continue;
-    const int4 cx = cand[0][x];
-    Cand X; X.path = cx.x; X.pos = cx.y; X.edit = cx.z & 0xff; X.orient = (cx.z >> 8) & 1;
-    for (int y = 0; y < n[1]; y++) {
-      if (!((live[1] >> y) & 1u)) continue;
-      const int4 cy = cand[1][y];
-      if (cy.x != cx.x) continue;
-      Cand Y; Y.path = cy.x; Y.pos = cy.y; Y.edit = cy.z & 0xff; Y.orient = (cy.z >> 8) & 1;
-      acc += pair_term(a, X, Y, L1, L2);
-    }
-  }
-  acc_out = acc;
-  return true;
 }
 
 // Second launch, only for path sets in which some window occurs several times: one lane per table-class slot and per

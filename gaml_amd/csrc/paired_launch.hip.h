@@ -504,7 +504,10 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   }
   // some window occurs several times in this path set (or needs the long occurrence form): second launch over
   // the pairs the main kernel notes
-  const bool gen_pass = a.n_main > 0 && p.general;
+  // ... scored inside the scoring launch by the lanes that meet them (GEN == 2 instantiation); knob 23 = 1 (development
+  // build): noted there and scored by a second launch, paired_general_kernel (the form of rounds 2-3)
+  const bool gen_set = a.n_main > 0 && p.general;
+  const bool gen_pass = gen_set && KNOB(c, 23) == 1;
   int gen_blocks = 0;
   if (gen_pass) {
     const size_t bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2] + gp.gen_words[3]) * sizeof(unsigned long long);
@@ -552,12 +555,16 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
     hipEvent_t e0 = ev ? ev->first : nullptr, e1 = ev ? ev->second : nullptr;
 #define GAML_LAUNCH_SCORE(...) hipExtLaunchKernelGGL((paired_score_kernel<__VA_ARGS__>), grid, block, KNOB(c, 1), st, e0, e1, 0, a)
 #ifdef GAML_HIP_DEV
-    if (timeline) GAML_LAUNCH_SCORE(false, false, true);  // (the instantiation with in-kernel stamps: development builds only)
+    if (timeline) GAML_LAUNCH_SCORE(false, 0, true);  // (the instantiation with in-kernel stamps: development builds only)
     else
 #endif
-    if (gen_pass) GAML_LAUNCH_SCORE(false, true);
-    else if (fin_mode) GAML_LAUNCH_SCORE(false, false);
-    else GAML_LAUNCH_SCORE(true, false);
+#ifdef GAML_HIP_DEV
+    if (gen_pass) GAML_LAUNCH_SCORE(false, 1);
+    else
+#endif
+    if (gen_set) { if (fin_mode) GAML_LAUNCH_SCORE(false, 2); else GAML_LAUNCH_SCORE(true, 2); }
+    else if (fin_mode) GAML_LAUNCH_SCORE(false, 0);
+    else GAML_LAUNCH_SCORE(true, 0);
 #undef GAML_LAUNCH_SCORE
     HIP_TRY(c, hipGetLastError());
     if (gen_pass) {
@@ -617,8 +624,9 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, co
   paired_base_args(c, s, a, gp);
   if (!a.memo) return fail(c, GAML_HIP_ESTATE, "multi-set launch without a memo (caller must check paired_multi_capable)");
   const int64_t n = s.mate[0].n_local();
-  bool any_general = false;
-  for (int k = first; k < first + n_sets; k++) any_general = any_general || (a.n_main > 0 && preps[k].general);
+  bool any_set = false;
+  for (int k = first; k < first + n_sets; k++) any_set = any_set || (a.n_main > 0 && preps[k].general);
+  const bool any_general = any_set && KNOB(c, 23) == 1;  // (second launches per set: development build, as launch_paired)
   const size_t gen_bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2] + gp.gen_words[3]) * sizeof(unsigned long long);
   if (any_general && gen_bytes * kMaxSets > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(gen_bytes * kMaxSets + 64)); }
   const int n_partials = gp.total_blocks + (any_general ? gp.gen_blocks : 0);
@@ -646,8 +654,12 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, co
   if (c->event_timing && (c->event_tick++ % c->event_every) == 0) { if (int e = take_events(c, &ev)) return e; }
   hipEvent_t e0 = ev ? ev->first : nullptr, e1 = ev ? ev->second : nullptr;
   const dim3 grid(a.total_blocks), block(kBlock);
-  if (any_general) hipExtLaunchKernelGGL((paired_score_multi_kernel<true>), grid, block, 0, st, e0, e1, 0, a, ms);
-  else hipExtLaunchKernelGGL((paired_score_multi_kernel<false>), grid, block, 0, st, e0, e1, 0, a, ms);
+#ifdef GAML_HIP_DEV
+  if (any_general) hipExtLaunchKernelGGL((paired_score_multi_kernel<1>), grid, block, 0, st, e0, e1, 0, a, ms);
+  else
+#endif
+  if (any_set) hipExtLaunchKernelGGL((paired_score_multi_kernel<2>), grid, block, 0, st, e0, e1, 0, a, ms);
+  else hipExtLaunchKernelGGL((paired_score_multi_kernel<0>), grid, block, 0, st, e0, e1, 0, a, ms);
   HIP_TRY(c, hipGetLastError());
   if (any_general) {
     for (int k = 0; k < n_sets; k++) {  // the notes of every set were written; only sets with such windows have any bit set

@@ -14,6 +14,8 @@ pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl
 gb, go = g.packed()
 r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
 ctx = api.Context(device=0)
+for kv in filter(None, os.environ.get("KNOBS", "").split(",")):  # e.g. KNOBS=23=1: the second launch instead of the inline form
+    ctx.debug_set_knob(*map(int, kv.split("=")))
 ctx.set_graph(gb, go)
 rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *r1, *r2)
 walk = synth.genome_walk(g)
