@@ -476,6 +476,18 @@ int gaml_hip_create(gaml_hip_ctx** out, int device) {
 }
 
 void gaml_hip_destroy(gaml_hip_ctx* c) {
+#ifdef GAML_GEN_STAMPS
+  if (c && c->device >= 0) {
+    unsigned long long z[32];
+    if (hipMemcpyFromSymbol(z, HIP_SYMBOL(gaml::g_gen_stamp), sizeof(z)) == hipSuccess && z[15]) {
+      fprintf(stderr, "general_pair_staged: longest stage us: entries %.1f, bounds %.1f, lists %.1f, liveness %.1f, terms %.1f; waves above 10 us in a stage: %llu %llu %llu %llu %llu\n",
+              z[16] * 0.01, z[17] * 0.01, z[18] * 0.01, z[19] * 0.01, z[20] * 0.01, z[24], z[25], z[26], z[27], z[28]);
+    }
+    if (z[15])
+      fprintf(stderr, "general_pair_staged: %llu waves; mean us per wave: entries %.2f, bounds %.2f, lists %.2f, liveness %.2f, terms %.2f; candidates per lane-0 pair %.1f / %.1f, live %.1f, lanes %.1f; pairs that did not fit %llu; longest %.2f us, most candidates %llu / %llu, most live %llu / %llu\n",
+              z[15], z[0] * 0.01 / z[15], z[1] * 0.01 / z[15], z[2] * 0.01 / z[15], z[3] * 0.01 / z[15], z[4] * 0.01 / z[15], (double)z[8] / z[15], (double)z[9] / z[15], (double)z[10] / z[15], (double)z[11] / z[15], z[12], z[13] * 0.01, z[14] / 1000, z[14] % 1000, z[7] / 1000, z[7] % 1000);
+  }
+#endif
   if (c && c->shm_base) { munmap(c->shm_base, c->shm_bytes); c->shm_base = nullptr; }
   if (!c) return;
   if (c->multi) { gaml::multi_destroy(c->multi); c->multi = nullptr; }

@@ -587,6 +587,25 @@ __device__ __forceinline__ void compact_general(const PairedArgs& a, int i, doub
   finish_read_compact(a, i, acc, lc, lsum, zeros);
 }
 
+// The pairs on windows that occur several times are few or clustered, their code is long (compact_general: 64 unrolled
+// combinations; general_pair_staged) and was inlined wherever a class meets such a pair: the GEN == 2 kernels came to 550 KB
+// and 480 KB of code, a wave that took the rare path fetched instructions from memory line by line (40-80 us for a chain of
+// 9 us, in-kernel stamps). They are FUNCTIONS now (one copy each, called by every class of both kernels -- which also makes
+// a batch's arithmetic the single call's by construction): the callee reads the kernel's argument block itself, through its
+// address (the intrinsic that returns it is null outside a kernel: the caller passes it; set >= 0: path set `set` of a
+// multi-set launch), and returns what the caller adds to its running sums.
+struct GenOut { double add; int zeros; };
+__device__ GenOut compact_general_call(unsigned long long kernargs, int i, int set);
+// table pair of class 1 / 2 at slot i (dj < 0) or delta pair dj at slot i; lds: room for 2 * kGenCands candidates, or null
+__device__ GenOut general_pair_call(unsigned long long kernargs, int i, int dj, int set, int4* lds);
+__device__ __forceinline__ unsigned long long kernel_args_address() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  return 0;
+#endif
+}
+
 // one scored class-0 pair: per-read probability out, floor / log into the running sums
 __device__ __forceinline__ void compact_finish(const PairedArgs& a, int i, const Compact1& c, const CompactPrep& q, double2 m,
                                                double& lsum, int& zeros, PairVal* cap = nullptr) {
@@ -682,9 +701,9 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, const S
       if ((threadIdx.x & 63) == 0) { gen_bits[(i0 - rg.lo) >> 6] = k0; if (two) gen_bits[(i1 - rg.lo) >> 6] = k1; }
     }
     if (!d0 && !q0.skip) compact_finish(a, i0, c0, q0, m0, lsum, zeros);
-    else if (GEN == 2 && q0.skip) compact_general(a, i0, lsum, zeros);
+    else if (GEN == 2 && q0.skip) { const GenOut o = compact_general_call(kernel_args_address(), i0, -1); lsum += o.add; zeros += o.zeros; }
     if (two && !d1 && !q1.skip) compact_finish(a, i1, c1, q1, m1, lsum, zeros);
-    else if (GEN == 2 && two && q1.skip) compact_general(a, i1, lsum, zeros);
+    else if (GEN == 2 && two && q1.skip) { const GenOut o = compact_general_call(kernel_args_address(), i1, -1); lsum += o.add; zeros += o.zeros; }
     if (!more) break;
     c0 = n0v; c1 = n1v;
     i0 = j0;
@@ -813,7 +832,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const 
     if (GEN == 2 && !GAML_GEN_OFF(8) && __any(skip_bits != 0)) {  // pairs on a window that occurs several times: here, after the round's other pairs
 #pragma unroll 1
       for (int k = 0; k < 4; k++)
-        if ((skip_bits >> k) & 1u) compact_general(a, (int)(base + k * stride), lsum, zeros);
+        if ((skip_bits >> k) & 1u) { const GenOut o = compact_general_call(kernel_args_address(), (int)(base + k * stride), -1); lsum += o.add; zeros += o.zeros; }
     }
   }
 #undef GAML_STAMP
@@ -968,7 +987,7 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
     } else if (GEN == 2 && !GAML_GEN_OFF(1) && __any(skip_bits != 0)) {  // ... or score them here, after the round's other pairs
 #pragma unroll 1
       for (int k = 0; k < P; k++)
-        if ((skip_bits >> k) & 1u) compact_general(a, (int)(base + k * stride), lsum, zeros);
+        if ((skip_bits >> k) & 1u) { const GenOut o = compact_general_call(kernel_args_address(), (int)(base + k * stride), -1); lsum += o.add; zeros += o.zeros; }
     }
     GAML_STAMP(5, 0u)
     first_round = false;
@@ -995,17 +1014,37 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
 // the general loop (paired_general_src_masks) derives each candidate anew for every liveness test and every term: hundreds of
 // dependent chains for a read in a 5-copy repeat seen through two windows. The candidates sit in (private) arrays; more than
 // kGenCands on a mate: false, the caller takes the loop. Same candidates, same liveness rule, same terms in the same order.
-constexpr int kGenCands = 16;
-__device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const int4 (&r1)[4], const int4 (&r2)[4], int L1, int L2, double& acc_out) {
-  int4 cand[2][kGenCands];  // {path, position on the path, edit | orient << 8 | valid << 9, rank}; index = visiting order
-  int ck[2][kGenCands];     // the record the candidate came from (ties between equal ranks go by record)
+#ifndef GAML_GEN_CANDS
+#define GAML_GEN_CANDS 32
+#endif
+constexpr int kGenCands = GAML_GEN_CANDS;  // (<= 32: the liveness masks are one word)
+// timing builds only (tools/build_variant.sh NAME -DGAML_GEN_STAMPS): per stage of general_pair_staged, the time the waves that
+// score such a pair spend in it (summed over waves, 10 ns units) and [15] the number of waves; printed by gaml_hip_destroy
+#ifdef GAML_GEN_STAMPS
+__device__ unsigned long long g_gen_stamp[32];
+#define GEN_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
+  if (__ffsll((long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63)) atomicAdd(&g_gen_stamp[k], now_ - gen_t_); atomicMax(&g_gen_stamp[16 + k], now_ - gen_t_); if (now_ - gen_t_ > 1000) atomicAdd(&g_gen_stamp[24 + k], 1ull); gen_t_ = now_; } while (0)
+#define GEN_STAMP_BEGIN unsigned long long gen_t_ = wall_clock64(); const unsigned long long gen_t0_ = gen_t_; if (__ffsll((long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63)) atomicAdd(&g_gen_stamp[15], 1ull);
+#else
+#define GEN_STAMP(k) do { } while (0)
+#define GEN_STAMP_BEGIN
+#endif
+// `cand`: room for 2 * kGenCands candidates -- {path, position on the path, edit | orient << 8 | valid << 9 | record << 10, rank}, index
+// = visiting order, mate 2's behind mate 1's -- in LDS where the wave has a free slot (gen_wave_slot), else in a private array:
+// the liveness tests and the terms are chains of loads from it, 30 ns a link from LDS, 270 ns from scratch (a pair with 2 + 5
+// candidates spent 8 us of a 15 us chain there, in-kernel stamps).
+constexpr int kGenListBatch = 8;  // entries of an occurrence list requested together
+__device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const int4 (&r1)[4], const int4 (&r2)[4], int L1, int L2, double& acc_out, int4* cand) {
   int n[2] = {0, 0};
+  unsigned live[2] = {0, 0};
   Occ12 e[2][4];
   int lb[2][4], le[2][4];
+  GEN_STAMP_BEGIN
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
     for (int k = 0; k < 4; k++) { const int4& r = m == 0 ? r1[k] : r2[k]; e[m][k] = a.m[m].occ12[r.x >= 0 ? r.x : 0]; }
+  GEN_STAMP(0);
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -1017,87 +1056,89 @@ __device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const i
       if (list) { const int s = -e[m][k].rank - 1; lb[m][k] = a.m[m].multi_off[s]; le[m][k] = a.m[m].multi_off[s + 1]; }
       else if (occurs) le[m][k] = -1;  // one occurrence, described by the entry itself
     }
+  GEN_STAMP(1);
   bool fits = true;
 #pragma unroll
   for (int m = 0; m < 2; m++) {
+    int4* const cm = cand + m * kGenCands;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int4& r = m == 0 ? r1[k] : r2[k];
-      if (le[m][k] == -1) {
-        if (n[m] < kGenCands) {
-          const int4 o = occ_from_compact((unsigned long long)e[m][k].lo | ((unsigned long long)e[m][k].hi << 32), e[m][k].rank);
-          cand[m][n[m]] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | (r.y >= o.y ? 0x200 : 0), o.w);
-          ck[m][n[m]] = k;
+      const bool single = le[m][k] == -1;
+      const int cnt = single ? 1 : le[m][k] - lb[m][k];
+      if (!__any(cnt > 0)) continue;  // (wave-uniform: nobody's record k of this mate occurs)
+      if (n[m] + cnt > kGenCands) fits = false;
+      const int4 one = occ_from_compact((unsigned long long)e[m][k].lo | ((unsigned long long)e[m][k].hi << 32), e[m][k].rank);
+      const int n_before = n[m];  // candidates of the earlier records
+      for (int c0 = 0; __any(fits && c0 < cnt); c0 += kGenListBatch) {  // (wave-uniform trip count; a 5-copy repeat: one round)
+        const int left = fits ? cnt - c0 : 0;
+        // the record's occurrences: the list's entries all at once (one trip, not one per entry)
+        int4 t[kGenListBatch];
+#pragma unroll
+        for (int q = 0; q < kGenListBatch; q++) t[q] = (!single && left > 0) ? a.m[m].multi[lb[m][k] + c0 + min(q, left - 1)] : one;
+        // liveness (graph.cc:583-592): valid, and no LATER valid candidate of the mate at the same (path, position) -- later: larger
+        // (rank, record). Candidates of one record sit at different places (its window's occurrences are different places), so only
+        // the earlier records' candidates are looked at: whichever of the two is earlier dies.
+        unsigned nl = 0;
+        int pos[kGenListBatch];
+#pragma unroll
+        for (int q = 0; q < kGenListBatch; q++) { pos[q] = r.y + t[q].x; nl |= (unsigned)(q < left && r.y >= t[q].y) << q; }
+        const unsigned valid = nl;
+        for (int y = 0; y < n_before && left > 0; y++) {
+          const int4 ot = cm[y];
+          if (!(ot.z & 0x200)) continue;
+#pragma unroll
+          for (int q = 0; q < kGenListBatch; q++)
+            if (((valid >> q) & 1u) && ot.x == t[q].z && ot.y == pos[q]) { if (t[q].w >= ot.w) live[m] &= ~(1u << y); else nl &= ~(1u << q); }
         }
-        n[m]++;
-      } else {
-        for (int q = lb[m][k]; q < le[m][k]; q++) {
-          if (n[m] < kGenCands) {
-            const int4 o = a.m[m].multi[q];
-            cand[m][n[m]] = make_int4(o.z, r.y + o.x, (r.z & 0x1ff) | (r.y >= o.y ? 0x200 : 0), o.w);
-            ck[m][n[m]] = k;
-          }
-          n[m]++;
-        }
+#pragma unroll
+        for (int q = 0; q < kGenListBatch; q++)
+          if (q < left) cm[n[m] + q] = make_int4(t[q].z, pos[q], (r.z & 0x1ff) | (((valid >> q) & 1u) ? 0x200 : 0) | (k << 10), t[q].w);
+        if (left > 0) { live[m] |= nl << n[m]; n[m] += min(left, kGenListBatch); }
       }
     }
-    fits = fits && n[m] <= kGenCands;
   }
+  GEN_STAMP(2);
+#ifdef GAML_GEN_STAMPS
+  if (!fits) atomicAdd(&g_gen_stamp[12], 1ull);
+#endif
   if (!fits) return false;
-  // liveness (graph.cc:583-592): valid, and no later valid candidate of the mate at the same (path, position)
-  unsigned live[2] = {0, 0};
-  for (int m = 0; m < 2; m++)
-    for (int x = 0; x < n[m]; x++) {
-      const int4 me = cand[m][x];
-      bool lv = (me.z & 0x200) != 0;
-      for (int y = 0; y < n[m] && lv; y++) {
-        const int4 ot = cand[m][y];
-        if (y != x && (ot.z & 0x200) && ot.x == me.x && ot.y == me.y && (ot.w > me.w || (ot.w == me.w && ck[m][y] > ck[m][x]))) lv = false;
-      }
-      if (lv) live[m] |= 1u << x;
-    }
+  GEN_STAMP(3);
   double acc = 0.0;
   for (int x = 0; x < n[0]; x++) {
     if (!((live[0] >> x) & 1u)) continue;
-    const int4 cx = cand[0][x];
+    const int4 cx = cand[x];
     Cand X; X.path = cx.x; X.pos = cx.y; X.edit = cx.z & 0xff; X.orient = (cx.z >> 8) & 1;
     for (int y = 0; y < n[1]; y++) {
       if (!((live[1] >> y) & 1u)) continue;
-      const int4 cy = cand[1][y];
+      const int4 cy = cand[kGenCands + y];
       if (cy.x != cx.x) continue;
       Cand Y; Y.path = cy.x; Y.pos = cy.y; Y.edit = cy.z & 0xff; Y.orient = (cy.z >> 8) & 1;
       acc += pair_term(a, X, Y, L1, L2);
     }
   }
+  GEN_STAMP(4);
+#ifdef GAML_GEN_STAMPS
+  if (__ffsll((long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63)) { atomicAdd(&g_gen_stamp[8], (unsigned long long)n[0]); atomicAdd(&g_gen_stamp[9], (unsigned long long)n[1]); atomicAdd(&g_gen_stamp[10], (unsigned long long)__popc(live[0])); atomicAdd(&g_gen_stamp[11], (unsigned long long)__popcll(__ballot(1))); }
+  atomicMax(&g_gen_stamp[13], wall_clock64() - gen_t0_); atomicMax(&g_gen_stamp[14], (unsigned long long)(n[0] * 1000 + n[1])); atomicMax(&g_gen_stamp[7], (unsigned long long)(__popc(live[0]) * 1000 + __popc(live[1])));
+#endif
   acc_out = acc;
   return true;
 }
-
-// A table pair of class 1 / 2 (K records per mate, the inline copies) and a delta pair on a window that occurs several times,
-// finished in the lane that met it (GEN == 2 launches; paired_general_kernel does the same for the pairs a GEN == 1 launch noted)
-template <int K>
-__device__ __forceinline__ void general_table_pair(const PairedArgs& a, int i, uint32_t l12, const int4 (&r1)[K], const int4 (&r2)[K], double& lsum, int& zeros,
-                                                   PairVal* cap = nullptr) {
-  const int4 none = make_int4(-1, 0, 0, 0);
-  int4 q1[4], q2[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) { q1[k] = k < K ? r1[k < K ? k : 0] : none; q2[k] = k < K ? r2[k < K ? k : 0] : none; }
-  const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-  double acc;
-  if (!general_pair_staged(a, q1, q2, L1, L2, acc)) acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
-  finish_read(a, i, acc, L1, L2, lsum, zeros, cap);
+// candidates in a private array (scratch): paired_general_kernel
+__device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const int4 (&r1)[4], const int4 (&r2)[4], int L1, int L2, double& acc_out) {
+  int4 cand[2 * kGenCands];
+  return general_pair_staged(a, r1, r2, L1, L2, acc_out, cand);
 }
-__device__ __forceinline__ void general_delta_pair(const PairedArgs& a, int dj, int i, double& lsum, int& zeros, PairVal* cap = nullptr) {
-  int4 r1[4], r2[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) { r1[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r2[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
-  const uint32_t l12 = (uint32_t)r1[0].w;
-  const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-  const int c0 = r2[0].w & 0xff, c1 = (r2[0].w >> 8) & 0xff;
-  double acc;
-  if (!general_pair_staged(a, r1, r2, L1, L2, acc))
-    acc = paired_general_src_masks(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
-  finish_read(a, i, acc, L1, L2, lsum, zeros, cap);
+// The candidate stores of a lane-per-pair block of paired_score_kernel: the LDS its wave would stage a wave-per-pair item's
+// candidates in (4 KB a wave, idle in these blocks) holds kGenWaveSlots of them; the wave's lanes that meet such a pair in
+// one round take them in lane order, the others use a private array (general_pair_call).
+constexpr int kOvfCap = 128;     // candidates per mate the wave-per-pair blocks hold in LDS per wave (paired_overflow_body)
+constexpr int kGenWaveSlots = 2 * kOvfCap / (2 * kGenCands);
+__device__ __forceinline__ int4* gen_wave_slot(int4* wave_lds, bool mine) {
+  const unsigned long long m = __ballot(mine);
+  const int rank = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+  return (wave_lds && mine && rank < kGenWaveSlots) ? wave_lds + rank * 2 * kGenCands : nullptr;
 }
 
 // up to K live candidates per mate in registers -> per-read probability, floor / log, running sums
@@ -1155,7 +1196,7 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
 // first pair finished -- tools/kernel_timeline.py)
 template <int K, int GEN>
 __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
-                                                 double& lsum, int& zeros, unsigned long long* tl = nullptr) {
+                                                 double& lsum, int& zeros, unsigned long long* tl = nullptr, int4* wave_lds = nullptr) {
   unsigned long long* bits = GEN == 1 ? a.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2) : nullptr;
   bool first_pair = true;
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
@@ -1179,7 +1220,10 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
     if (GEN == 1) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
       const unsigned long long k = __ballot(general);
       if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
-    } else if (GEN == 2 && !GAML_GEN_OFF(2) && general) general_table_pair<K>(a, i, l12, r1, r2, lsum, zeros);
+    } else if (GEN == 2 && !GAML_GEN_OFF(2) && __any(general)) {
+      int4* const slot = gen_wave_slot(wave_lds, general);
+      if (general) { const GenOut o = general_pair_call(kernel_args_address(), i, -1, -1, slot); lsum += o.add; zeros += o.zeros; }
+    }
   }
 }
 
@@ -1187,7 +1231,7 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
 // the delta lists. Up to 4 records per mate go through the register path of class 2; longer lists and
 // pairs touching a window that occurs several times take the fully general per-lane loop (rare).
 template <int GEN>
-__device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, int delta_blocks, double& lsum, int& zeros) {
+__device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, int delta_blocks, double& lsum, int& zeros, int4* wave_lds = nullptr) {
   // (a delta pair touching a window that occurs several times is only NOTED here -- GEN launches: a bit per delta index,
   // one ballot word per wave and iteration -- and scored by paired_general_kernel: the general loop inside this kernel,
   // one lane re-deriving every candidate's liveness for every candidate, made a late annealing walk's launch 60 us)
@@ -1223,7 +1267,10 @@ __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, i
       const unsigned long long k = __ballot(general);
       if ((threadIdx.x & 63) == 0) notes[dj >> 6] = k;
     } else if (GEN == 2) {
-      if (general && !GAML_GEN_OFF(4)) general_delta_pair(a, dj, i, lsum, zeros);
+      if (!GAML_GEN_OFF(4) && __any(general)) {
+        int4* const slot = gen_wave_slot(wave_lds, general);
+        if (general) { const GenOut o = general_pair_call(kernel_args_address(), i, dj, -1, slot); lsum += o.add; zeros += o.zeros; }
+      }
     } else if (general) {  // cannot happen (a launch without notes has no such window): the partial is poisoned, combine() reports it
       lsum += __builtin_nan("");
     }
@@ -1266,7 +1313,7 @@ __global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const Patch* 
 
 // TL: the in-kernel timeline of tools/kernel_timeline.py (a separate instantiation: the product kernels carry none of it)
 template <bool TICKET, int GEN, bool TL>
-__device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z) {
+__device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z, int4* gen_lds) {
   // `a`: the argument block as the kernel received it; only its leading words (grid layout, partial slots) are read
   // here -- every class takes a fresh view of its own (GAML_FRESH_ARGS)
   double lsum = 0.0;
@@ -1297,15 +1344,19 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
       else if (wide) paired_compact4_body<GEN, TL>(b, rg, lsum, zeros);
       else paired_compact_body<GEN>(b, rg, lsum, zeros);
     }
-  } else if (lb < a.blocks01) {
-    GAML_FRESH_ARGS(c, a)
-    paired_regs_body<2, GEN>(c, lb, c.n0, c.n01, c.blocks0, c.blocks01, lsum, zeros, tl);
-  } else if (lb < a.blocks012) {
-    GAML_FRESH_ARGS(c, a)
-    paired_regs_body<4, GEN>(c, lb, c.n01, c.n_main, c.blocks01, c.blocks012, lsum, zeros);
   } else {
-    GAML_FRESH_ARGS(c, a)
-    paired_delta_body<GEN>(c, lb - c.blocks012, c.main_blocks - c.blocks012, lsum, zeros);
+    // (GEN == 2: the classes with several records per pair stage a repeated window's candidates in their wave's LDS, gen_wave_slot)
+    int4* const wave_lds = GEN == 2 ? gen_lds + (threadIdx.x >> 6) * 2 * kOvfCap : nullptr;
+    if (lb < a.blocks01) {
+      GAML_FRESH_ARGS(c, a)
+      paired_regs_body<2, GEN>(c, lb, c.n0, c.n01, c.blocks0, c.blocks01, lsum, zeros, tl, wave_lds);
+    } else if (lb < a.blocks012) {
+      GAML_FRESH_ARGS(c, a)
+      paired_regs_body<4, GEN>(c, lb, c.n01, c.n_main, c.blocks01, c.blocks012, lsum, zeros, nullptr, wave_lds);
+    } else {
+      GAML_FRESH_ARGS(c, a)
+      paired_delta_body<GEN>(c, lb - c.blocks012, c.main_blocks - c.blocks012, lsum, zeros, wave_lds);
+    }
   }
   block_reduce(lsum, zeros, sh_s, sh_z);
   if (TL && (threadIdx.x & 63) == 0) tl[6] = wall_clock64();
@@ -1340,7 +1391,6 @@ __global__ __launch_bounds__(kBlock) void finish_partials_kernel(const double* p
 // deterministic lane-strided + butterfly summation. It reads nothing the main kernel writes, so
 // both run concurrently (two streams); they share one ticket, and whichever block finishes last
 // folds all per-block partials in index order.
-constexpr int kOvfCap = 128;     // candidates per mate held in LDS per wave
 constexpr int kOvfMaxBlocks = 1024;
 
 template <class Src>
@@ -1495,14 +1545,14 @@ __global__ __launch_bounds__(kBlock, GEN == 2 ? GAML_GEN_WAVES : 5) void paired_
     else if (threadIdx.x == 0) { a.part_sum[lb] = lsum; a.part_zero[lb] = zeros; }
     return;
   }
-  if (lb < a.main_blocks) paired_main_body<TICKET, GEN, TL>(a, lb, sh_s, sh_z);
+  if (lb < a.main_blocks) paired_main_body<TICKET, GEN, TL>(a, lb, sh_s, sh_z, &cand[0][0][0]);
   else if (GAML_GEN_OFF(16)) { if (threadIdx.x == 0) { a.part_sum[lb] = 0.0; a.part_zero[lb] = 0; } }
   else {
     GAML_FRESH_ARGS(c, a)
     paired_overflow_body<TICKET>(c, lb - c.main_blocks, c.total_blocks - c.main_blocks, sh_s, sh_z, cand);
   }
 #else
-  if (lb < a.main_blocks) paired_main_body<TICKET, GEN, TL>(a, lb, sh_s, sh_z);
+  if (lb < a.main_blocks) paired_main_body<TICKET, GEN, TL>(a, lb, sh_s, sh_z, &cand[0][0][0]);
   else paired_overflow_body<TICKET>(a, lb - a.main_blocks, a.total_blocks - a.main_blocks, sh_s, sh_z, cand);
 #endif
 }
@@ -1545,6 +1595,54 @@ __device__ __forceinline__ PairedArgs with_set(const PairedArgs& a, const SetDev
   b.tfloor_c = tfloor_lds ? tfloor_lds : sd.tfloor_c; b.tfloor0 = sd.tfloor0; b.two_T = sd.two_T; b.log_two_T = sd.log_two_T; b.gen_bits = sd.gen_bits;
   b.part_sum = sd.part_sum; b.part_zero = sd.part_zero;
   return b;
+}
+
+// the kernel's argument block, read where it is needed (a callee's view of it); a multi-set launch's: {PairedArgs, MultiSets}
+struct MultiKernArgs { PairedArgs a; MultiSets ms; };
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GAML_CALLEE_ARGS(name, set)                                                                                                  \
+  const unsigned long long name##_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(kernargs >> 32)) << 32) |  \
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)kernargs); /* (uniform: scalar loads) */         \
+  const __attribute__((address_space(4))) MultiKernArgs* name##_p = (const __attribute__((address_space(4))) MultiKernArgs*)name##_u; \
+  const PairedArgs name##_0 = name##_p->a;                                                                                           \
+  const PairedArgs name = (set) >= 0 ? with_set(name##_0, name##_p->ms.set[set]) : name##_0;
+#else
+#define GAML_CALLEE_ARGS(name, set) const PairedArgs& name = *(const PairedArgs*)nullptr;
+#endif
+__device__ __noinline__ GenOut compact_general_call(unsigned long long kernargs, int i, int set) {
+  GAML_CALLEE_ARGS(a, set)
+  GenOut o{0.0, 0};
+  compact_general(a, i, o.add, o.zeros);
+  return o;
+}
+__device__ __noinline__ GenOut general_pair_call(unsigned long long kernargs, int i, int dj, int set, int4* lds) {
+  GAML_CALLEE_ARGS(a, set)
+  GenOut o{0.0, 0};
+  int4 priv[2 * kGenCands];
+  int4* const cand = lds ? lds : priv;
+  const int4 none = make_int4(-1, 0, 0, 0);
+  int4 r1[4], r2[4];
+  double acc;
+  if (dj < 0) {  // as paired_general_kernel reads a table pair of class 1 / 2: its inline copies
+    const bool four = i >= a.n01;
+    const size_t at = four ? (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01) : (size_t)2 * (i - a.n0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const bool has = four || k < 2; r1[k] = has ? a.inl[0][at + (has ? k : 0)] : none; r2[k] = has ? a.inl[1][at + (has ? k : 0)] : none; }
+    const uint32_t l12 = a.len12[i - a.n0];
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    if (!general_pair_staged(a, r1, r2, L1, L2, acc, cand)) acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
+    finish_read(a, i, acc, L1, L2, o.add, o.zeros);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { r1[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r2[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
+    const uint32_t l12 = (uint32_t)r1[0].w;
+    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+    const int c0 = r2[0].w & 0xff, c1 = (r2[0].w >> 8) & 0xff;
+    if (!general_pair_staged(a, r1, r2, L1, L2, acc, cand))
+      acc = paired_general_src_masks(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
+    finish_read(a, i, acc, L1, L2, o.add, o.zeros);
+  }
+  return o;
 }
 
 // paired_compact4_body with the path sets in the inner loop. acc_s / acc_z: one running sum per (set, thread) in LDS
@@ -1638,10 +1736,9 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
         }
       }
       if (GEN == 2 && __any(skip_bits != 0)) {  // as paired_compact4_body
-        const PairedArgs b = with_set(a, sd, tf ? tfs : nullptr);
 #pragma unroll 1
         for (int k = 0; k < 4; k++)
-          if ((skip_bits >> k) & 1u) compact_general(b, (int)(base + k * stride), lsum, zeros);
+          if ((skip_bits >> k) & 1u) { const GenOut o = compact_general_call(kernel_args_address(), (int)(base + k * stride), s); lsum += o.add; zeros += o.zeros; }
       }
       acc_s[s * kBlock + threadIdx.x] += lsum;
       acc_z[s * kBlock + threadIdx.x] += zeros;
@@ -1721,10 +1818,9 @@ __device__ __forceinline__ void paired_static4_multi_body(const PairedArgs& a, c
           if ((threadIdx.x & 63) == 0 && base + k * stride < n0) sd.gen_bits[rg.gen_w + ((base + k * stride - (unsigned)rg.lo) >> 6)] = w;
         }
       } else if (GEN == 2 && __any(skip_bits != 0)) {  // as paired_static4_body
-        const PairedArgs b = with_set(a, sd, tf ? tfs : nullptr);
 #pragma unroll 1
         for (int k = 0; k < 4; k++)
-          if ((skip_bits >> k) & 1u) compact_general(b, (int)(base + k * stride), lsum, zeros);
+          if ((skip_bits >> k) & 1u) { const GenOut o = compact_general_call(kernel_args_address(), (int)(base + k * stride), s); lsum += o.add; zeros += o.zeros; }
       }
       acc_s[s * kBlock + threadIdx.x] = lsum;
       acc_z[s * kBlock + threadIdx.x] = zeros;
@@ -1770,7 +1866,7 @@ __device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, cons
         unsigned long long* bits = b.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2);
         const unsigned long long k = __ballot(general);
         if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
-      } else if (GEN == 2 && general) general_table_pair<K>(b, i, l12, r1, r2, lsum, zeros);  // (in every set: val holds nothing of such a pair)
+      } else if (GEN == 2 && general) { const GenOut o = general_pair_call(kernel_args_address(), i, -1, s, nullptr); lsum += o.add; zeros += o.zeros; }  // (in every set: val holds nothing of such a pair)
       acc_s[s * kBlock + threadIdx.x] = lsum;
       acc_z[s * kBlock + threadIdx.x] = zeros;
     }
@@ -1817,7 +1913,7 @@ __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, con
       if (GEN == 1) {
         const unsigned long long k = __ballot(general);
         if ((threadIdx.x & 63) == 0) b.gen_bits[a.gen_wd + (dj >> 6)] = k;
-      } else if (GEN == 2 && mine && general) general_delta_pair(b, dj, i, lsum, zeros);
+      } else if (GEN == 2 && mine && general) { const GenOut o = general_pair_call(kernel_args_address(), i, dj, s, nullptr); lsum += o.add; zeros += o.zeros; }
       acc_s[s * kBlock + threadIdx.x] = lsum;
       acc_z[s * kBlock + threadIdx.x] = zeros;
     }
