@@ -381,7 +381,7 @@ def repeats_block(api, synth, device, sa_iters=5000, oracle=True):
     """Repeat-rich assemblies, untimed for the headline ("optionally with planted repeats"; GAML's repeat moves,
     moves.cc:1156-1305, exist for them): (1) cfg3r = config 3's recipe with 2 % of the genome in COLLAPSED 5-copy repeat
     families -- one node each, visited five times by the true walk, so its windows occur several times in the path set
-    (second launch: paired_general_kernel) -- scored through the same 8 rotating path sets, with the likelihood against
+    (the kernels' GEN instantiation scores their pairs where a lane meets them, by function calls) -- scored through the same 8 rotating path sets, with the likelihood against
     the CPU oracle on ALL pairs; (2) the late state of a long synthetic annealing walk at config 3 (duplicated nodes
     pile up: 60 % of the moves are accepted whatever they do)."""
     wl = synth.WORKLOADS["cfg3r"]
@@ -410,14 +410,13 @@ def repeats_block(api, synth, device, sa_iters=5000, oracle=True):
     ctx.kernel_stats(reset=True)
     for i in range(128):
         ctx.score(variants[i % 8])
-    gs = ctx.general_stats()  # (before the reset below, which clears both)
     ks = ctx.kernel_stats(reset=True)
     ctx.set_event_timing(False)
     out = {"workload": wl.name, "pairs": wl.n_pairs, "walk_nodes": len(walk), "distinct_nodes": len(set(walk)),
            "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.pair_classes(rs)],
            "step_us": step_us, "reads_per_sec": 2.0 * wl.n_pairs / (step_us * 1e-6),
            "scoring_kernel_us": ks["device_us"] / max(1, ks["launches"]),
-           "general_kernel_us": gs["device_us"] / max(1, gs["launches"]), "general_launches_per_step": gs["launches"] / max(1, ks["launches"]),
+           "launches_per_step": 1,  # (rounds 2-3: a second launch for the pairs on repeated windows, 20-25 us)
            "algo_bytes_per_launch": ks["algo_bytes"] / max(1, ks["launches"])}
     ctx.close()
     if oracle:
@@ -454,13 +453,11 @@ def repeats_block(api, synth, device, sa_iters=5000, oracle=True):
     ctx.kernel_stats(reset=True)
     for f in flat[-200:]:
         ctx.score(f)
-    gs = ctx.general_stats()  # (before the reset below, which clears both)
     ks = ctx.kernel_stats(reset=True)
     out["late_annealing_walk"] = {"iterations": sa_iters, "paths_at_end": len(seq[-1]), "call_us_median_last_1000": float(np.median(per[-1000:]) * 1e6),
                                   "pair_classes_le1_le2_le4_more": [int(x) for x in ctx.pair_classes(rs)],
                                   "delta_pairs": ctx.table_stats(rs)["dirty_pairs"],
-                                  "scoring_kernel_us": ks["device_us"] / max(1, ks["launches"]),
-                                  "general_kernel_us": gs["device_us"] / max(1, gs["launches"])}
+                                  "scoring_kernel_us": ks["device_us"] / max(1, ks["launches"])}
     ctx.close()
     return out
 

@@ -198,7 +198,7 @@ def _load():
     if hasattr(L, "gaml_hip_debug_window_walk"):  # development build only
         L.gaml_hip_debug_window_walk.argtypes = [vp, C.c_int, C.c_int, C.c_int32, _i32p, C.c_int32]
     for new, old in (("gaml_hip_pair_classes", "gaml_hip_debug_class_counts"), ("gaml_hip_last_phases", "gaml_hip_debug_profile"),
-                     ("gaml_hip_table_stats", "gaml_hip_debug_table_stats"), ("gaml_hip_general_stats", "gaml_hip_debug_general_stats")):
+                     ("gaml_hip_table_stats", "gaml_hip_debug_table_stats")):
         if not hasattr(L, new) and hasattr(L, old):  # an older A/B build loaded through GAML_HIP_LIB (tools/)
             setattr(L, new, getattr(L, old))
     L.gaml_hip_pair_classes.argtypes = [vp, C.c_int, _i64p]
@@ -223,8 +223,6 @@ def _load():
         L.gaml_hip_debug_timeline.argtypes = [vp, C.c_int, C.c_void_p, C.c_int64]
     L.gaml_hip_last_phases.argtypes = [vp, _f64p]
     L.gaml_hip_table_stats.argtypes = [vp, C.c_int, _i64p]
-    if hasattr(L, "gaml_hip_general_stats"):
-        L.gaml_hip_general_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.gaml_hip_aligner_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.gaml_hip_aligner_stages.argtypes = [vp, _f64p]
     L.gaml_hip_last_timing.argtypes = [vp, _f64p]
@@ -753,11 +751,6 @@ class Context:
             self._check(rc)
         return res
 
-    def general_stats(self):
-        n, us = C.c_int64(), C.c_double()
-        self._check(_lib.gaml_hip_general_stats(self._h, C.byref(n), C.byref(us)))
-        return {"launches": n.value, "device_us": us.value}
-
     def debug_block_partials(self, rs, set_index=0):
         sums, zeros, lay = np.zeros(8192, np.float64), np.zeros(8192, np.int32), np.zeros(8, np.int32)
         _lib.gaml_hip_debug_block_partials.argtypes = [C.c_void_p, C.c_int, C.c_int32, _f64p, _i32p, C.c_int32, _i32p]
@@ -770,7 +763,7 @@ class Context:
         return out
 
     # (the names these carried while they lived in gaml_hip_debug.h)
-    debug_table_stats, debug_profile, debug_general_stats, debug_class_counts = table_stats, last_phases, general_stats, pair_classes
+    debug_table_stats, debug_profile, debug_class_counts = table_stats, last_phases, pair_classes
 
     def last_timing(self):
         out = np.zeros(3, np.float64)

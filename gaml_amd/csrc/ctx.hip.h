@@ -289,7 +289,6 @@ struct PairedSet {
   } persist;
   int64_t batches_patched = 0, batches_full = 0;  // gaml_hip_calc_prob_batch chunks whose per-set tables were built on the device from patches / written whole
   size_t batch_slack = 0;             // extra bytes per path set region of a batch (grows when a set's tables did not fit)
-  DevBuf gen_bits;  // one bit per table-class slot: needs paired_general_kernel (written by the main kernel)
   hipEvent_t ev_tables = nullptr, ev_ovf = nullptr;
   PairedPlanner planner;
   OccImage image[2];                 // persistent host images of the occurrence tables, patched per call
@@ -368,7 +367,7 @@ struct PairedPrep {
   int64_t assembled_records = 0;  // records the reference would touch in GetPositionsOnlyPath
   std::vector<int32_t> path_base, start_off, starts;
   int32_t total_bits = 0, n_paths = 0;
-  bool general = false;           // some window occurs several times in this path set: paired_general_kernel runs too
+  bool general = false;           // some window occurs several times in this path set: the GEN instantiation of the scoring kernels
 };
 
 struct SetRef { int kind, idx; };
@@ -408,8 +407,6 @@ struct gaml_hip_ctx {
   int64_t event_tick = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // one pair per scoring launch of a call
   std::vector<uint64_t> ev_call;  // ... and the evaluation (eval_serial) it belongs to
-  std::vector<uint8_t> ev_kind;   // 0: a scoring launch (gaml_hip_kernel_stats), 1: paired_general_kernel (second launch of a path set with repeated windows)
-  double stat_general_us = 0; int64_t stat_general_launches = 0;
   uint64_t eval_serial = 0;
   size_t ev_used = 0;
   double t_host_us = 0, t_dev_wall_us = 0, t_kernel_us = 0;

@@ -234,7 +234,7 @@ int gaml_hip_debug_static_check(gaml_hip_ctx* c, int rs, int64_t* out8) {
 }
 
 // per-block partial sums of the last blocking evaluation of paired read set rs (path set `set` of a batch launch; 0 for a
-// single call), in block order [lane-per-pair classes | wave-per-pair blocks | paired_general_kernel blocks]: which
+// single call), in block order [lane-per-pair classes | wave-per-pair blocks]: which
 // block's sum differs when two routes that should agree bit for bit do not. Returns the number of blocks.
 int32_t gaml_hip_debug_block_partials(gaml_hip_ctx* c, int rs, int32_t set, double* sums, int32_t* zeros, int32_t cap, int32_t* layout8) {
   MULTI_SHARD0(c);
@@ -249,7 +249,7 @@ int32_t gaml_hip_debug_block_partials(gaml_hip_ctx* c, int rs, int32_t set, doub
     PairedArgs a; GridPlan gp;
     paired_base_args(c, s, a, gp);
     layout8[0] = gp.blocks0a; layout8[1] = gp.blocks0; layout8[2] = a.blocks01; layout8[3] = a.blocks012; layout8[4] = a.main_blocks; layout8[5] = a.total_blocks;
-    layout8[6] = gp.gen_blocks; layout8[7] = n;
+    layout8[6] = 0; layout8[7] = n;
   }
   return n;
 }

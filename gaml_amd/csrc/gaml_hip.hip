@@ -129,7 +129,6 @@ int collect_events(gaml_hip_ctx* c) {
     float ms = 0;
     HIP_TRY(c, hipEventSynchronize(c->ev_pool[i].second));
     HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
-    if (c->ev_kind[i] == 1) { c->stat_general_us += ms * 1000.0; c->stat_general_launches++; continue; }
     sum += ms * 1000.0;
     last = c->ev_call[i] == c->ev_call[c->ev_used - 1] ? last + ms * 1000.0 : 0.0;
   }
@@ -139,7 +138,7 @@ int collect_events(gaml_hip_ctx* c) {
   return 0;
 }
 
-int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out, int kind = 0) {
+int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out) {
   if (c->ev_used == c->ev_pool.size() && c->ev_pool.size() >= 2048) { if (int e = collect_events(c)) return e; }
   if (c->ev_used == c->ev_pool.size()) {
     hipEvent_t a, b;
@@ -148,8 +147,6 @@ int take_events(gaml_hip_ctx* c, std::pair<hipEvent_t, hipEvent_t>** out, int ki
     c->ev_pool.emplace_back(a, b);
   }
   if (c->ev_call.size() < c->ev_pool.size()) c->ev_call.resize(c->ev_pool.size(), 0);
-  if (c->ev_kind.size() < c->ev_pool.size()) c->ev_kind.resize(c->ev_pool.size(), 0);
-  c->ev_kind[c->ev_used] = (uint8_t)kind;
   c->ev_call[c->ev_used] = c->eval_serial;
   *out = &c->ev_pool[c->ev_used++];
   return 0;
@@ -509,7 +506,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
       s->dl_slot.release(); s->dl_spill.release(); s->sp_slot.release(); s->dstate.release(); s->dl_bins.release(); s->dl_bin_count.release(); s->dl_blk_tot.release(); s->dl_wlist.release(); s->h_dstate.release(); s->lcode.release(); s->len_combo_dev.release(); s->combo_tabs.release(); s->memo.release();
       drop_stage(s->stage_pool); s->h_part_sum.release(); s->h_part_zero.release(); s->h_timeline.release();
       s->probs.release(); s->tabs.release(); s->arena.release(); s->persist.release(); s->cov_bits.release(); s->bad.release(); if (s->ev_tables) (void)hipEventDestroy(s->ev_tables); if (s->ev_ovf) (void)hipEventDestroy(s->ev_ovf);
-      s->red.release(); s->gen_bits.release();
+      s->red.release();
     }
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage);
       s->d_bases.release(); s->dp.release(); s->sweep.release(); }
@@ -1359,16 +1356,6 @@ int gaml_hip_pair_classes(gaml_hip_ctx* c, int rs, int64_t* out4) {
   return GAML_HIP_OK;
 }
 
-// device time of paired_general_kernel (the second launch of a path set in which some window occurs several times),
-// from events attached to its dispatches while event timing is on; reset with gaml_hip_kernel_stats(reset)
-int gaml_hip_general_stats(gaml_hip_ctx* c, int64_t* launches, double* device_us) {
-  MULTI_SHARD0(c);
-  if (!c) return GAML_HIP_EINVAL;
-  if (c->device >= 0 && c->ev_used) { if (int e = collect_events(c)) return e; }
-  if (launches) *launches = c->stat_general_launches;
-  if (device_us) *device_us = c->stat_general_us;
-  return GAML_HIP_OK;
-}
 
 #ifdef GAML_HIP_DEV
 #include "debug_api.hip.h"
@@ -1426,7 +1413,7 @@ int gaml_hip_kernel_stats(gaml_hip_ctx* c, int reset, int64_t* launches, double*
   if (launches) *launches = c->stat_launches;
   if (device_us) *device_us = c->stat_device_us;
   if (algo_bytes) *algo_bytes = c->stat_algo_bytes;
-  if (reset) { c->stat_launches = 0; c->stat_device_us = 0; c->stat_algo_bytes = 0; c->stat_general_us = 0; c->stat_general_launches = 0; }
+  if (reset) { c->stat_launches = 0; c->stat_device_us = 0; c->stat_algo_bytes = 0; }
   return GAML_HIP_OK;
 }
 

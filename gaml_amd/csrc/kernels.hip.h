@@ -52,7 +52,6 @@ struct PairedArgs {
   double log_two_T;                           // log(2T), host libm, per call
   double tfloor0, logfloor0;                  // tfloor_c[0] / logfloor_c[0] by value (sets with one length combination)
   uint32_t len_combo0; int pad0_;             // len_combo[0] by value
-  unsigned long long* gen_bits;               // (documented below)
   // ---- everything else
   MateView m[2];
   const uint32_t* len12;     // L1 | L2<<16 per pair
@@ -89,14 +88,10 @@ struct PairedArgs {
   const int* static_idx;
   int n01;                   // slots [n0, n01): class 1 (<= 2 records per mate); [n01, n_main): class 2 (<= 4)
   int n_main;                // the lane-per-pair paths score slots [0, n_main)
-  // Pairs of the table classes with a record in a window that occurs several times (or whose occurrence does not
-  // fit the compact forms) need the fully general loop. The main kernel only NOTES them: one bit per slot, a
-  // 64-bit ballot per wave and iteration (class-relative slot index; every word of a class is written by exactly
-  // one wave, so nothing has to be zeroed); paired_general_kernel scores them in a second launch. Null when the
-  // host saw no such window in this path set -- then neither the notes nor the second launch exist.
+  // (Pairs of the table classes with a record in a window that occurs several times -- or whose occurrence does not fit the
+  // compact forms -- need the general loop: the GEN instantiation of the kernel scores them where it meets them, through
+  // compact_general_call / general_pair_call.)
   unsigned long long* timeline;  // TL instantiation only: 8 wall-clock stamps (10 ns units) per wave of the grid
-  int gen_w0b, gen_w1, gen_w2;  // first word of the second part of class 0 / class 1 / class 2 (class 0 starts at word 0)
-  int gen_wd;                   // ... and of the delta pairs' notes (one bit per delta index)
   // Delta: pairs whose record lists changed since the device tables were built (newly activated
   // windows). Their slots carry a DIRTY mark in the tables; their complete record lists travel with
   // every evaluation and the overflow path scores them.
@@ -251,8 +246,7 @@ __device__ __forceinline__ bool live_mask_src(const MateView& v, const Src& src,
   });
   return n <= 64;
 }
-// Same terms in the same order as the loop above. For paired_general_kernel only: inside the scoring kernel (delta pairs
-// and the wave-per-pair fallback reach the general loop too, rarely) its registers put EVERY launch on scratch memory.
+// Same terms in the same order as the loop above (general_pair_call's fallback for a pair with more candidates than it stages).
 template <class Src>
 __device__ __forceinline__ double paired_general_src_masks(const PairedArgs& a, const Src& s1, const Src& s2, int L1, int L2) {
   unsigned long long live1, live2;
@@ -438,7 +432,7 @@ __device__ __forceinline__ double score_regs(const PairedArgs& a, const RegCands
 // Main kernel: one lane per read pair, pairs pre-sorted by record-count class so that a wave is
 // homogeneous; covers the pairs with at most 4 records per mate (slots [0, n_main)). A pair that
 // touches a window occurring several times in the path set (any record, either mate, whose window entry
-// carries the general flag / rank < 0) is only NOTED here (gen_bits) and scored by paired_general_kernel.
+// carries the general flag / rank < 0) takes the general path (GEN instantiation: compact_general_call, general_pair_call).
 constexpr unsigned long long kNone8 = ~0ull;
 constexpr unsigned long long kDirty8 = ~0ull - 1;  // class-0 slot whose records moved to the delta lists
 constexpr int kDirtyWid = -2;                      // same mark in the 16-byte tables
@@ -528,9 +522,9 @@ __device__ __forceinline__ void compact_cover(const PairedArgs& a, const Compact
 }
 
 // A class-0 pair with a record in a window that occurs several times in this path set (or whose occurrence
-// does not fit the 8-byte form): fully general loop over (record, occurrence) candidates, one lane per pair
-// (paired_general_kernel). Doing this inside the streaming loop cost the loop 1.2 us of 12 at cfg3 even when no
-// such pair exists (registers / code size), hence the second launch.
+// does not fit the 8-byte form): fully general loop over (record, occurrence) candidates, one lane per pair. Inlined into
+// the streaming loop this cost the loop 1.2 us of 12 at cfg3 even when no such pair exists (registers / code size): it
+// exists in the GEN instantiation only, and there as a function (compact_general_call).
 // One record per mate: every valid candidate is live (the overwrite rule only ever decides between DIFFERENT records of a
 // read that land on the same path position), so the pair's probability is the plain double sum over the two windows'
 // occurrences -- each window's list bounds found once, its entries read in order. Terms and their order are those of
@@ -588,7 +582,7 @@ __device__ __forceinline__ void compact_general(const PairedArgs& a, int i, doub
 }
 
 // The pairs on windows that occur several times are few or clustered, their code is long (compact_general: 64 unrolled
-// combinations; general_pair_staged) and was inlined wherever a class meets such a pair: the GEN == 2 kernels came to 550 KB
+// combinations; general_pair_staged) and was inlined wherever a class meets such a pair: the GEN kernels came to 550 KB
 // and 480 KB of code, a wave that took the rare path fetched instructions from memory line by line (40-80 us for a chain of
 // 9 us, in-kernel stamps). They are FUNCTIONS now (one copy each, called by every class of both kernels -- which also makes
 // a batch's arithmetic the single call's by construction): the callee reads the kernel's argument block itself, through its
@@ -655,21 +649,19 @@ __device__ __forceinline__ void compact_load(const PairedArgs& a, int i, bool ok
 #else
 #define GAML_GEN_OFF(bit) 0
 #endif
-// One part of class 0 and the blocks that score it: slots [lo, hi), `blocks` blocks of which this is number `lb`; the
-// part's notes for paired_general_kernel start at word gen_w.
-struct SlotRange { int lo, hi, lb, blocks, gen_w; };
+// One part of class 0 and the blocks that score it: slots [lo, hi), `blocks` blocks of which this is number `lb`
+struct SlotRange { int lo, hi, lb, blocks; };
 __device__ __forceinline__ SlotRange compact_range(const PairedArgs& a, int lb) {
-  return lb < a.blocks0a ? SlotRange{0, a.n0a, lb, a.blocks0a, 0} : SlotRange{a.n0a, a.n0, lb - a.blocks0a, a.blocks0 - a.blocks0a, a.gen_w0b};
+  return lb < a.blocks0a ? SlotRange{0, a.n0a, lb, a.blocks0a} : SlotRange{a.n0a, a.n0, lb - a.blocks0a, a.blocks0 - a.blocks0a};
 }
 
-template <int GEN>
+template <bool GEN>
 __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, const SlotRange rg, double& lsum, int& zeros) {
   // Class 0 in the general form (coverage marks to set, or no memo): two pairs per lane and iteration, software
   // pipelined -- the record loads of iteration k+1 are issued before iteration k's occurrence lookups and arithmetic.
   const int stride = rg.blocks * kBlock, hi = rg.hi;
   int i0 = rg.lo + rg.lb * kBlock + threadIdx.x;
   if (i0 >= hi) return;
-  unsigned long long* const gen_bits = GEN == 1 ? a.gen_bits + rg.gen_w : nullptr;
   Compact1 c0, c1;
   compact_load(a, i0, true, c0);
   compact_load(a, i0 + stride, i0 + stride < hi, c1);
@@ -696,14 +688,10 @@ __device__ __forceinline__ void paired_compact_body(const PairedArgs& a, const S
     // both memo entries are requested before anything is stored
     const double2 m0 = q0.memo_idx >= 0 ? a.memo[q0.memo_idx] : make_double2(0.0, 0.0);
     const double2 m1 = q1.memo_idx >= 0 ? a.memo[q1.memo_idx] : make_double2(0.0, 0.0);
-    if (GEN == 1) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
-      const unsigned long long k0 = __ballot(q0.skip), k1 = __ballot(q1.skip);
-      if ((threadIdx.x & 63) == 0) { gen_bits[(i0 - rg.lo) >> 6] = k0; if (two) gen_bits[(i1 - rg.lo) >> 6] = k1; }
-    }
     if (!d0 && !q0.skip) compact_finish(a, i0, c0, q0, m0, lsum, zeros);
-    else if (GEN == 2 && q0.skip) { const GenOut o = compact_general_call(kernel_args_address(), i0, -1); lsum += o.add; zeros += o.zeros; }
+    else if (GEN && q0.skip) { const GenOut o = compact_general_call(kernel_args_address(), i0, -1); lsum += o.add; zeros += o.zeros; }
     if (two && !d1 && !q1.skip) compact_finish(a, i1, c1, q1, m1, lsum, zeros);
-    else if (GEN == 2 && two && q1.skip) { const GenOut o = compact_general_call(kernel_args_address(), i1, -1); lsum += o.add; zeros += o.zeros; }
+    else if (GEN && two && q1.skip) { const GenOut o = compact_general_call(kernel_args_address(), i1, -1); lsum += o.add; zeros += o.zeros; }
     if (!more) break;
     c0 = n0v; c1 = n1v;
     i0 = j0;
@@ -746,10 +734,9 @@ __device__ __forceinline__ int compact_state(const PairedArgs& a, uint2 r1, uint
 
 // ONE: every pair has the same length combination (n_codes == 1, the usual case): no length-code loads, no LDS tables --
 // the combination and its log-floor are two uniform values.
-template <int GEN, bool TL = false, bool ONE = false>
+template <bool GEN, bool TL = false, bool ONE = false>
 __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const SlotRange rg, double& lsum, int& zeros) {
   const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;  // (n0: end of this part's slots)
-  unsigned long long* const gen_bits = GEN == 1 ? a.gen_bits + rg.gen_w : nullptr;
   unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
 #define GAML_STAMP(slot, dep) if (TL) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[slot] = (unsigned long long)wall_clock64() + ((dep) == 0x12345u ? 1 : 0); }
   // 32-bit byte offsets from uniform bases: one address register per load instead of a 64-bit add (tables < 4 GB)
@@ -789,13 +776,6 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const 
 #pragma unroll
     for (int k = 0; k < 4; k++) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
     GAML_STAMP(4, (unsigned)(__double2loint(m[0].x) ^ __double2loint(m[1].x) ^ __double2loint(m[2].x) ^ __double2loint(m[3].x)))
-    if (GEN == 1) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned long long w = __ballot((skip_bits >> k) & 1u);
-        if ((threadIdx.x & 63) == 0 && base + k * stride < n0) gen_bits[(base + k * stride - (unsigned)rg.lo) >> 6] = w;
-      }
-    }
     bool other = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -829,7 +809,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const 
         compact_finish(a, i, d, q, make_double2(0.0, 0.0), lsum, zeros);
       }
     }
-    if (GEN == 2 && !GAML_GEN_OFF(8) && __any(skip_bits != 0)) {  // pairs on a window that occurs several times: here, after the round's other pairs
+    if (GEN && !GAML_GEN_OFF(8) && __any(skip_bits != 0)) {  // pairs on a window that occurs several times: here, after the round's other pairs
 #pragma unroll 1
       for (int k = 0; k < 4; k++)
         if ((skip_bits >> k) & 1u) { const GenOut o = compact_general_call(kernel_args_address(), (int)(base + k * stride), -1); lsum += o.add; zeros += o.zeros; }
@@ -843,7 +823,7 @@ __device__ __forceinline__ void paired_compact4_body(const PairedArgs& a, const 
 // trip shorter: the records and the index come in together, then the occurrence entries AND the memo entries are requested
 // together -- the occurrence entries only decide whether the pair scores at all (both windows occur, once, at the same
 // place; position filter graph.cc:577). State between the stages: 1 scores (memo entry), 0 scores nothing (probability 0,
-// floored), 2 noted for paired_general_kernel, 3 nothing here (dirty slot, out of range), 4 the entries of the two
+// floored), 2 takes the general path (GEN), 3 nothing here (dirty slot, out of range), 4 the entries of the two
 // mates disagree about where the window sits (cannot happen; the block's partial is poisoned). An index < 0 marks a pair
 // with a mate that has no alignment: state 0 whatever the tables say.
 // Pairs, lanes and the order of additions are those of paired_compact_body over the same range.
@@ -891,11 +871,10 @@ __global__ __launch_bounds__(kBlock) void static_values_kernel(const int* static
 // Rounds of P pairs per lane, software-pipelined when a lane takes several: a round's occurrence entries are requested,
 // then the NEXT round's records and values, then the round is finished -- its arithmetic and stores run under the next
 // round's loads.
-template <int GEN, bool TL = false, bool ONE = false>
+template <bool GEN, bool TL = false, bool ONE = false>
 __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const SlotRange rg, double& lsum, int& zeros) {
   constexpr int P = GAML_STATIC_P;
   const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;
-  unsigned long long* const gen_bits = GEN == 1 ? a.gen_bits + rg.gen_w : nullptr;
   unsigned long long* tl = TL ? a.timeline + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
 #define GAML_STAMP(slot, dep) if (TL && first_round) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[slot] = (unsigned long long)wall_clock64() + ((dep) == 0x12345u ? 1 : 0); }
   const char* const rec0 = (const char*)a.rec8[0];
@@ -978,13 +957,7 @@ __device__ __forceinline__ void paired_static4_body(const PairedArgs& a, const S
       zeros += (int)floored;
       if (counted && !GAML_TIMING_X(2)) __builtin_nontemporal_store(t, (double*)(probs + (base + k * stride) * 8u));
     }
-    if (GEN == 1) {  // note the pairs for paired_general_kernel (wave-uniform; lane 0 holds the wave's lowest slot)
-#pragma unroll
-      for (int k = 0; k < P; k++) {
-        const unsigned long long w = __ballot((skip_bits >> k) & 1u);
-        if ((threadIdx.x & 63) == 0 && base + k * stride < n0) gen_bits[(base + k * stride - (unsigned)rg.lo) >> 6] = w;
-      }
-    } else if (GEN == 2 && !GAML_GEN_OFF(1) && __any(skip_bits != 0)) {  // ... or score them here, after the round's other pairs
+    if (GEN && !GAML_GEN_OFF(1) && __any(skip_bits != 0)) {  // pairs on a window that occurs several times: here, after the round's other pairs
 #pragma unroll 1
       for (int k = 0; k < P; k++)
         if ((skip_bits >> k) & 1u) { const GenOut o = compact_general_call(kernel_args_address(), (int)(base + k * stride), -1); lsum += o.add; zeros += o.zeros; }
@@ -1125,11 +1098,6 @@ __device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const i
   acc_out = acc;
   return true;
 }
-// candidates in a private array (scratch): paired_general_kernel
-__device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const int4 (&r1)[4], const int4 (&r2)[4], int L1, int L2, double& acc_out) {
-  int4 cand[2 * kGenCands];
-  return general_pair_staged(a, r1, r2, L1, L2, acc_out, cand);
-}
 // The candidate stores of a lane-per-pair block of paired_score_kernel: the LDS its wave would stage a wave-per-pair item's
 // candidates in (4 KB a wave, idle in these blocks) holds kGenWaveSlots of them; the wave's lanes that meet such a pair in
 // one round take them in lane order, the others use a private array (general_pair_call).
@@ -1194,10 +1162,9 @@ __device__ __forceinline__ void score_cands_and_finish(const PairedArgs& a, int 
 // Slots [slot_lo, slot_hi), blocks [block_lo, block_hi).
 // (tl: the in-kernel timeline's slot of this wave, stamps [2] records in, [3] candidates (occurrence entries) in, [5]
 // first pair finished -- tools/kernel_timeline.py)
-template <int K, int GEN>
+template <int K, bool GEN>
 __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
                                                  double& lsum, int& zeros, unsigned long long* tl = nullptr, int4* wave_lds = nullptr) {
-  unsigned long long* bits = GEN == 1 ? a.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2) : nullptr;
   bool first_pair = true;
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
     const int t = i - a.n0;
@@ -1213,14 +1180,11 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
     const bool m1 = cands_from_records<K>(a.m[0], r1, x), m2 = cands_from_records<K>(a.m[1], r2, y);
     if (tl && first_pair) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[3] = (unsigned long long)wall_clock64() + (x.pos[0] == 0x12345 ? 1 : 0); }
     const bool dirty = r1[0].x == kDirtyWid;  // scored from the delta lists (paired_delta_body)
-    const bool general = !dirty && (m1 || m2);  // a window that occurs several times: paired_general_kernel
+    const bool general = !dirty && (m1 || m2);  // a window that occurs several times: general_pair_call
     if (!dirty && !general) score_cands_and_finish<K>(a, i, l12, x, y, lsum, zeros);
     if (tl && first_pair) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) tl[5] = (unsigned long long)wall_clock64() + (lsum == 0.12345 ? 1 : 0); }
     first_pair = false;
-    if (GEN == 1) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
-      const unsigned long long k = __ballot(general);
-      if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
-    } else if (GEN == 2 && !GAML_GEN_OFF(2) && __any(general)) {
+    if (GEN && !GAML_GEN_OFF(2) && __any(general)) {
       int4* const slot = gen_wave_slot(wave_lds, general);
       if (general) { const GenOut o = general_pair_call(kernel_args_address(), i, -1, -1, slot); lsum += o.add; zeros += o.zeros; }
     }
@@ -1230,12 +1194,10 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
 // Delta pairs (pairs that gained records since the tables were built): one LANE per pair, records from
 // the delta lists. Up to 4 records per mate go through the register path of class 2; longer lists and
 // pairs touching a window that occurs several times take the fully general per-lane loop (rare).
-template <int GEN>
+template <bool GEN>
 __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, int delta_blocks, double& lsum, int& zeros, int4* wave_lds = nullptr) {
-  // (a delta pair touching a window that occurs several times is only NOTED here -- GEN launches: a bit per delta index,
-  // one ballot word per wave and iteration -- and scored by paired_general_kernel: the general loop inside this kernel,
-  // one lane re-deriving every candidate's liveness for every candidate, made a late annealing walk's launch 60 us)
-  unsigned long long* const notes = GEN == 1 ? a.gen_bits + a.gen_wd : nullptr;
+  // (a delta pair touching a window that occurs several times goes through general_pair_call -- GEN launches: the general
+  // loop inlined here, one lane re-deriving every candidate's liveness for every candidate, made a late annealing walk's launch 60 us)
   for (int dj = db * kBlock + threadIdx.x; dj < a.dstate[kDsDirty]; dj += delta_blocks * kBlock) {
     // Everything a delta pair needs sits at index dj (no chain through the pair's slot): the first record of mate 1
     // carries the two read lengths in its spare word, the first record of mate 2 the two list lengths (paired_upload_delta)
@@ -1263,10 +1225,7 @@ __device__ __forceinline__ void paired_delta_body(const PairedArgs& a, int db, i
       general = m0 || m1;
       if (!general) score_cands_and_finish<4>(a, i, l12, x, y, lsum, zeros);
     }
-    if (GEN == 1) {  // lane 0 holds the wave's lowest delta index: it is active whenever any lane is
-      const unsigned long long k = __ballot(general);
-      if ((threadIdx.x & 63) == 0) notes[dj >> 6] = k;
-    } else if (GEN == 2) {
+    if (GEN) {
       if (!GAML_GEN_OFF(4) && __any(general)) {
         int4* const slot = gen_wave_slot(wave_lds, general);
         if (general) { const GenOut o = general_pair_call(kernel_args_address(), i, dj, -1, slot); lsum += o.add; zeros += o.zeros; }
@@ -1312,7 +1271,7 @@ __global__ __launch_bounds__(kBlock) void apply_delta_patch_kernel(const Patch* 
 }
 
 // TL: the in-kernel timeline of tools/kernel_timeline.py (a separate instantiation: the product kernels carry none of it)
-template <bool TICKET, int GEN, bool TL>
+template <bool TICKET, bool GEN, bool TL>
 __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, double* sh_s, int* sh_z, int4* gen_lds) {
   // `a`: the argument block as the kernel received it; only its leading words (grid layout, partial slots) are read
   // here -- every class takes a fresh view of its own (GAML_FRESH_ARGS)
@@ -1345,8 +1304,8 @@ __device__ __forceinline__ void paired_main_body(const PairedArgs& a, int lb, do
       else paired_compact_body<GEN>(b, rg, lsum, zeros);
     }
   } else {
-    // (GEN == 2: the classes with several records per pair stage a repeated window's candidates in their wave's LDS, gen_wave_slot)
-    int4* const wave_lds = GEN == 2 ? gen_lds + (threadIdx.x >> 6) * 2 * kOvfCap : nullptr;
+    // (GEN: the classes with several records per pair stage a repeated window's candidates in their wave's LDS, gen_wave_slot)
+    int4* const wave_lds = GEN ? gen_lds + (threadIdx.x >> 6) * 2 * kOvfCap : nullptr;
     if (lb < a.blocks01) {
       GAML_FRESH_ARGS(c, a)
       paired_regs_body<2, GEN>(c, lb, c.n0, c.n01, c.blocks0, c.blocks01, lsum, zeros, tl, wave_lds);
@@ -1515,13 +1474,14 @@ __device__ __forceinline__ void paired_overflow_body(const PairedArgs& a, int ov
 // ONE launch for a paired read set: blocks [0, main_blocks) run the lane-per-pair path, blocks
 // [main_blocks, total_blocks) the wave-per-pair path (block-uniform branch). They share nothing
 // but read-only tables, so no ordering between them is needed.
-// GEN: the path set has windows that occur several times -- note their pairs for paired_general_kernel. Without
-// such windows the notes are compiled out (they cost 0.3 us of 12 at cfg3 even when nothing is noted).
+// GEN: the path set has windows that occur several times -- their pairs are scored where a lane meets them, by function
+// calls (compact_general_call, general_pair_call); four waves per SIMD instead of five (the callees' registers). Without such
+// windows none of this is compiled in (rounds 2-3 noted the pairs and scored them in a second launch: 20-25 us of its own).
 #ifndef GAML_GEN_WAVES
 #define GAML_GEN_WAVES 4
 #endif
-template <bool TICKET, int GEN = 0, bool TL = false>
-__global__ __launch_bounds__(kBlock, GEN == 2 ? GAML_GEN_WAVES : 5) void paired_score_kernel(PairedArgs a) {
+template <bool TICKET, bool GEN = false, bool TL = false>
+__global__ __launch_bounds__(kBlock, GEN ? GAML_GEN_WAVES : 5) void paired_score_kernel(PairedArgs a) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
   __shared__ int4 cand[kBlock / 64][2][kOvfCap];
@@ -1539,7 +1499,7 @@ __global__ __launch_bounds__(kBlock, GEN == 2 ? GAML_GEN_WAVES : 5) void paired_
     double lsum = 0.0;
     int zeros = 0;
     if (!GAML_TIMING_X(16))
-    paired_static4_body<GEN, false, true>(a, SlotRange{0, a.n0a, lb, a.blocks0a, 0}, lsum, zeros);
+    paired_static4_body<GEN, false, true>(a, SlotRange{0, a.n0a, lb, a.blocks0a}, lsum, zeros);
     block_reduce(lsum, zeros, sh_s, sh_z);
     if (TICKET) grid_finish(lsum, zeros, lb, a.total_blocks, a.part_sum, a.part_zero, a.ticket, a.out, 0.0, a.n_reads, sh_s, sh_z, a.status_out, a.status_a, a.status_b);
     else if (threadIdx.x == 0) { a.part_sum[lb] = lsum; a.part_zero[lb] = zeros; }
@@ -1575,7 +1535,6 @@ struct SetDev {  // what differs between the path sets of one batch
   const double* tfloor_c;          // [code] for this set's 2T
   double tfloor0;                  // = tfloor_c[0], by value
   double two_T, log_two_T;
-  unsigned long long* gen_bits;    // this set's notes for paired_general_kernel (GEN instantiation)
   double* part_sum;                // this set's per-block partials
   int* part_zero;
 };
@@ -1592,7 +1551,7 @@ __device__ __forceinline__ PairedArgs with_set(const PairedArgs& a, const SetDev
   PairedArgs b = a;
 #pragma unroll
   for (int mt = 0; mt < 2; mt++) { b.m[mt].occ12 = sd.occ12[mt]; b.occ12[mt] = sd.occ12[mt]; b.m[mt].multi_off = sd.multi_off[mt]; b.m[mt].multi = sd.multi[mt]; }
-  b.tfloor_c = tfloor_lds ? tfloor_lds : sd.tfloor_c; b.tfloor0 = sd.tfloor0; b.two_T = sd.two_T; b.log_two_T = sd.log_two_T; b.gen_bits = sd.gen_bits;
+  b.tfloor_c = tfloor_lds ? tfloor_lds : sd.tfloor_c; b.tfloor0 = sd.tfloor0; b.two_T = sd.two_T; b.log_two_T = sd.log_two_T;
   b.part_sum = sd.part_sum; b.part_zero = sd.part_zero;
   return b;
 }
@@ -1623,7 +1582,7 @@ __device__ __noinline__ GenOut general_pair_call(unsigned long long kernargs, in
   const int4 none = make_int4(-1, 0, 0, 0);
   int4 r1[4], r2[4];
   double acc;
-  if (dj < 0) {  // as paired_general_kernel reads a table pair of class 1 / 2: its inline copies
+  if (dj < 0) {  // a table pair of class 1 / 2: its inline copies
     const bool four = i >= a.n01;
     const size_t at = four ? (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01) : (size_t)2 * (i - a.n0);
 #pragma unroll
@@ -1647,7 +1606,7 @@ __device__ __noinline__ GenOut general_pair_call(unsigned long long kernargs, in
 
 // paired_compact4_body with the path sets in the inner loop. acc_s / acc_z: one running sum per (set, thread) in LDS
 // (a lane may take several rounds of four pairs; registers cannot be indexed by the set number).
-template <int GEN, bool ONE>
+template <bool GEN, bool ONE>
 __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, const MultiSets& ms, const SlotRange rg, double* acc_s, int* acc_z, const double* tf) {
   const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;  // (n0: end of this part's slots)
   const char* const rec0 = (const char*)a.rec8[0];
@@ -1694,13 +1653,6 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
       double2 m[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) m[k] = *(const double2*)(memo + (unsigned)max(state[k], 0) * 16u);
-      if (GEN == 1) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const unsigned long long w = __ballot((skip_bits >> k) & 1u);
-          if ((threadIdx.x & 63) == 0 && base + k * stride < n0) sd.gen_bits[rg.gen_w + ((base + k * stride - (unsigned)rg.lo) >> 6)] = w;
-        }
-      }
       double lsum = 0.0;
       int zeros = 0;
       bool other = false;
@@ -1735,7 +1687,7 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
           compact_finish(b, i, d, q, make_double2(0.0, 0.0), lsum, zeros);
         }
       }
-      if (GEN == 2 && __any(skip_bits != 0)) {  // as paired_compact4_body
+      if (GEN && __any(skip_bits != 0)) {  // as paired_compact4_body
 #pragma unroll 1
         for (int k = 0; k < 4; k++)
           if ((skip_bits >> k) & 1u) { const GenOut o = compact_general_call(kernel_args_address(), (int)(base + k * stride), s); lsum += o.add; zeros += o.zeros; }
@@ -1750,7 +1702,7 @@ __device__ __forceinline__ void paired_compact4_multi_body(const PairedArgs& a, 
 // (the per-set arithmetic above goes records -> occurrence entries -> memo index -> memo entry, two dependent trips per set;
 // here a set costs one: its occurrence entries). Lanes, pairs, the values added and their order are the single-set
 // kernel's: a batch gives bit for bit what the sets give one by one.
-template <int GEN, bool ONE>
+template <bool GEN, bool ONE>
 __device__ __forceinline__ void paired_static4_multi_body(const PairedArgs& a, const MultiSets& ms, const SlotRange rg, double* acc_s, int* acc_z, const double* tf) {
   const unsigned stride = (unsigned)rg.blocks * kBlock, n0 = (unsigned)rg.hi;
   const char* const rec0 = (const char*)a.rec8[0];
@@ -1811,13 +1763,7 @@ __device__ __forceinline__ void paired_static4_multi_body(const PairedArgs& a, c
         zeros += (int)floored;
         if (counted && last_set) __builtin_nontemporal_store(t, (double*)(probs + (base + k * stride) * 8u));
       }
-      if (GEN == 1) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const unsigned long long w = __ballot((skip_bits >> k) & 1u);
-          if ((threadIdx.x & 63) == 0 && base + k * stride < n0) sd.gen_bits[rg.gen_w + ((base + k * stride - (unsigned)rg.lo) >> 6)] = w;
-        }
-      } else if (GEN == 2 && __any(skip_bits != 0)) {  // as paired_static4_body
+      if (GEN && __any(skip_bits != 0)) {  // as paired_static4_body
 #pragma unroll 1
         for (int k = 0; k < 4; k++)
           if ((skip_bits >> k) & 1u) { const GenOut o = compact_general_call(kernel_args_address(), (int)(base + k * stride), s); lsum += o.add; zeros += o.zeros; }
@@ -1831,7 +1777,7 @@ __device__ __forceinline__ void paired_static4_multi_body(const PairedArgs& a, c
 // Classes 1 and 2 with the path sets in the inner loop (paired_regs_body's pairs, lane -> pair mapping and order of
 // additions): records once, set 0 resolved and captured, later sets finished from the capture unless one of the
 // pair's windows changed.
-template <int K, int GEN>
+template <int K, bool GEN>
 __device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, const MultiSets& ms, int lb, int slot_lo, int slot_hi, int block_lo,
                                                        int block_hi, double* acc_s, int* acc_z, const double* tf) {
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
@@ -1856,17 +1802,13 @@ __device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, cons
       if (s == 0 || ((chg >> s) & 1u)) {
         RegCands<K> x, y;
         const bool m1 = cands_from_records<K>(b.m[0], r1, x), m2 = cands_from_records<K>(b.m[1], r2, y);
-        general = !dirty && (m1 || m2);  // a window that occurs several times: paired_general_kernel
+        general = !dirty && (m1 || m2);  // a window that occurs several times: general_pair_call
         val.kind = 0;
         if (!dirty && !general) score_cands_and_finish<K>(b, i, l12, x, y, lsum, zeros, &val);
       } else {
         finish_val(b, i, val, s == ms.n - 1, lsum, zeros);
       }
-      if (GEN == 1) {  // lane 0 holds the wave's lowest slot: it is active whenever any lane is
-        unsigned long long* bits = b.gen_bits + (K == 2 ? a.gen_w1 : a.gen_w2);
-        const unsigned long long k = __ballot(general);
-        if ((threadIdx.x & 63) == 0) bits[(i - slot_lo) >> 6] = k;
-      } else if (GEN == 2 && general) { const GenOut o = general_pair_call(kernel_args_address(), i, -1, s, nullptr); lsum += o.add; zeros += o.zeros; }  // (in every set: val holds nothing of such a pair)
+      if (GEN && general) { const GenOut o = general_pair_call(kernel_args_address(), i, -1, s, nullptr); lsum += o.add; zeros += o.zeros; }  // (in every set: val holds nothing of such a pair)
       acc_s[s * kBlock + threadIdx.x] = lsum;
       acc_z[s * kBlock + threadIdx.x] = zeros;
     }
@@ -1874,7 +1816,7 @@ __device__ __forceinline__ void paired_regs_multi_body(const PairedArgs& a, cons
 }
 
 // paired_delta_body with the path sets in the inner loop
-template <int GEN>
+template <bool GEN>
 __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, const MultiSets& ms, int db, int delta_blocks, double* acc_s, int* acc_z, const double* tf) {
   for (int dj = db * kBlock + threadIdx.x; dj < a.dstate[kDsDirty]; dj += delta_blocks * kBlock) {
     const int i = a.dirty_slots[dj];
@@ -1903,17 +1845,14 @@ __device__ __forceinline__ void paired_delta_multi_body(const PairedArgs& a, con
       } else if (s == 0 || ((chg >> s) & 1u)) {
         RegCands<4> x, y;
         const bool m0 = cands_from_records<4>(b.m[0], r0, x), m1 = cands_from_records<4>(b.m[1], r1, y);
-        general = m0 || m1;  // a window that occurs several times in this path set: noted for paired_general_kernel (as paired_delta_body)
+        general = m0 || m1;  // a window that occurs several times in this path set: general_pair_call (as paired_delta_body)
         val.kind = 0;
         if (!general) score_cands_and_finish<4>(b, i, l12, x, y, lsum, zeros, &val);
         else if (!GEN) lsum += __builtin_nan("");  // cannot happen (a launch without notes has no such window): poisoned, reported by combine()
       } else {
         finish_val(b, i, val, s == ms.n - 1, lsum, zeros);
       }
-      if (GEN == 1) {
-        const unsigned long long k = __ballot(general);
-        if ((threadIdx.x & 63) == 0) b.gen_bits[a.gen_wd + (dj >> 6)] = k;
-      } else if (GEN == 2 && mine && general) { const GenOut o = general_pair_call(kernel_args_address(), i, dj, s, nullptr); lsum += o.add; zeros += o.zeros; }
+      if (GEN && mine && general) { const GenOut o = general_pair_call(kernel_args_address(), i, dj, s, nullptr); lsum += o.add; zeros += o.zeros; }
       acc_s[s * kBlock + threadIdx.x] = lsum;
       acc_z[s * kBlock + threadIdx.x] = zeros;
     }
@@ -1979,7 +1918,7 @@ __device__ __forceinline__ void paired_overflow_multi_body(const PairedArgs& a, 
   }
 }
 
-template <int GEN>
+template <bool GEN>
 __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArgs a, MultiSets ms) {
   __shared__ double sh_s[kBlock / 64];
   __shared__ int sh_z[kBlock / 64];
@@ -2057,60 +1996,6 @@ __global__ __launch_bounds__(kBlock, 5) void paired_score_multi_kernel(PairedArg
     if (threadIdx.x == 0) { ms.set[s].part_sum[lb] = lsum; ms.set[s].part_zero[lb] = zeros; }
     __syncthreads();
   }
-}
-
-// Second launch, only for path sets in which some window occurs several times: one lane per table-class slot and per
-// delta pair, the lanes whose bit the main kernel set score their pair -- the compact class from both occurrence lists in
-// registers (compact_general), pairs with several records through general_pair_staged. Partials go behind the main
-// kernel's (slots [part_base, part_base + gridDim.x)); fixed slot -> lane assignment, so the sums are reproducible.
-__global__ __launch_bounds__(kBlock) void paired_general_kernel(PairedArgs a, int part_base) {
-  __shared__ double sh_s[kBlock / 64];
-  __shared__ int sh_z[kBlock / 64];
-  double lsum = 0.0;
-  int zeros = 0;
-  const int4 none = make_int4(-1, 0, 0, 0);
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n_main; i += gridDim.x * kBlock) {
-    const int cls = i < a.n0 ? 0 : (i < a.n01 ? 1 : 2);
-    const bool part_b = i >= a.n0a;  // class 0, second part (its notes start at a word of their own)
-    const int rel = cls == 0 ? (part_b ? i - a.n0a : i) : (cls == 1 ? i - a.n0 : i - a.n01);
-    const unsigned long long word = a.gen_bits[(cls == 0 ? (part_b ? a.gen_w0b : 0) : (cls == 1 ? a.gen_w1 : a.gen_w2)) + (rel >> 6)];
-    if (!((word >> (rel & 63)) & 1ull)) continue;
-#if defined(GAML_HIP_DEV) && defined(GAML_GEN_X)  // timing experiments of the development build (results wrong): leave a class of noted pairs out
-    if ((GAML_GEN_X & 1) && cls == 0) continue;
-    if ((GAML_GEN_X & 2) && cls != 0) continue;
-#endif
-    if (cls == 0) compact_general(a, i, lsum, zeros);
-    else {
-      const uint32_t l12 = a.len12[i - a.n0];
-      const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-      const size_t at = cls == 1 ? (size_t)2 * (i - a.n0) : (size_t)2 * (a.n01 - a.n0) + (size_t)4 * (i - a.n01);
-      int4 r1[4], r2[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) { const bool has = cls == 2 || k < 2; r1[k] = has ? a.inl[0][at + (has ? k : 0)] : none; r2[k] = has ? a.inl[1][at + (has ? k : 0)] : none; }
-      double acc;
-      if (!general_pair_staged(a, r1, r2, L1, L2, acc)) acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
-      finish_read(a, i, acc, L1, L2, lsum, zeros);
-    }
-  }
-  // ... and the delta pairs the scoring launch noted (paired_delta_body), one lane per pair, records from the delta lists
-  for (int dj = blockIdx.x * kBlock + threadIdx.x; dj < a.dstate[kDsDirty]; dj += gridDim.x * kBlock) {
-    if (!((a.gen_bits[a.gen_wd + (dj >> 6)] >> (dj & 63)) & 1ull)) continue;
-#if defined(GAML_HIP_DEV) && defined(GAML_GEN_X)
-    if (GAML_GEN_X & 4) continue;
-#endif
-    int4 r1[4], r2[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { r1[k] = a.dirty_recs[0][4 * (size_t)dj + k]; r2[k] = a.dirty_recs[1][4 * (size_t)dj + k]; }
-    const uint32_t l12 = (uint32_t)r1[0].w;
-    const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-    const int c0 = r2[0].w & 0xff, c1 = (r2[0].w >> 8) & 0xff;
-    double acc;
-    if (!general_pair_staged(a, r1, r2, L1, L2, acc))
-      acc = paired_general_src_masks(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
-    finish_read(a, a.dirty_slots[dj], acc, L1, L2, lsum, zeros);
-  }
-  block_reduce(lsum, zeros, sh_s, sh_z);
-  if (threadIdx.x == 0) { a.part_sum[part_base + blockIdx.x] = lsum; a.part_zero[part_base + blockIdx.x] = zeros; }
 }
 
 // ---------------------------------------------------------------------------------------

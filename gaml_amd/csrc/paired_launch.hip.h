@@ -296,13 +296,13 @@ void paired_persist_view(const PairedSet& s, int32_t total_len, SetDev& sd) {
   sd.two_T = (double)(2 * tl);
   sd.tfloor0 = paired_tfloor0(s, sd.two_T);
   sd.log_two_T = std::log(sd.two_T);
-  sd.gen_bits = nullptr; sd.part_sum = nullptr; sd.part_zero = nullptr;
+  sd.part_sum = nullptr; sd.part_zero = nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------------------------------------
-struct GridPlan { int blocks0a, blocks0, blocks1, blocks2, blocks_d, main_blocks, ovf_blocks, total_blocks, gen_blocks; int64_t gen_words[4]; };  // gen_words: notes of class 0 / 1 / 2 / the delta pairs
+struct GridPlan { int blocks0a, blocks0, blocks1, blocks2, blocks_d, main_blocks, ovf_blocks, total_blocks; };
 
 // what every path set of a launch shares: record tables, length tables, memo, classes, grid
 void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp) {
@@ -378,18 +378,12 @@ void paired_base_args(gaml_hip_ctx* c, PairedSet& s, PairedArgs& a, GridPlan& gp
   gp.main_blocks = gp.blocks0 + gp.blocks1 + gp.blocks2 + gp.blocks_d;
   gp.ovf_blocks = ovf_total > 0 ? (int)std::min<int64_t>((ovf_total + 3) / 4, kOvfMaxBlocks) : 0;
   gp.total_blocks = gp.main_blocks + gp.ovf_blocks;
-  gp.gen_words[0] = (n0a + 63) / 64 + (n0b + 63) / 64; gp.gen_words[1] = (n01 - n0 + 63) / 64; gp.gen_words[2] = (n_main - n01 + 63) / 64;
-  gp.gen_words[3] = ((int64_t)nd + 63) / 64;
-  gp.gen_blocks = n_main > 0 ? (int)std::min<int64_t>((n_main + kBlock - 1) / kBlock, KNOB(c, 21) > 0 ? KNOB(c, 21) : kMaxBlocks) : 0;
   a.blocks0a = gp.blocks0a;
-  a.gen_w0b = (int)((n0a + 63) / 64);
   a.blocks0 = gp.blocks0;
   a.blocks01 = gp.blocks0 + gp.blocks1;
   a.blocks012 = gp.blocks0 + gp.blocks1 + gp.blocks2;
   a.main_blocks = gp.main_blocks;
   a.total_blocks = gp.total_blocks;
-  a.gen_w1 = (int)gp.gen_words[0]; a.gen_w2 = (int)(gp.gen_words[0] + gp.gen_words[1]);
-  a.gen_wd = (int)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2]);
 }
 
 // what one path set changes: its occurrence tables inside `arena`, 2T and the thresholds that follow from it
@@ -405,13 +399,13 @@ void paired_set_view(const PairedSet& s, const PairedLayout& L, const char* aren
   sd.two_T = (double)(2 * tl);
   sd.tfloor0 = paired_tfloor0(s, sd.two_T);
   sd.log_two_T = std::log(sd.two_T);
-  sd.gen_bits = nullptr; sd.part_sum = nullptr; sd.part_zero = nullptr;
+  sd.part_sum = nullptr; sd.part_zero = nullptr;
 }
 
 void paired_apply_set(PairedArgs& a, const SetDev& sd) {
   for (int mt = 0; mt < 2; mt++) { a.m[mt].occ12 = sd.occ12[mt]; a.m[mt].occ = nullptr; a.occ12[mt] = sd.occ12[mt]; a.m[mt].multi_off = sd.multi_off[mt]; a.m[mt].multi = sd.multi[mt]; }
   a.tfloor_c = sd.tfloor_c; a.tfloor0 = sd.tfloor0; a.two_T = sd.two_T; a.log_two_T = sd.log_two_T;
-  a.gen_bits = sd.gen_bits; a.part_sum = sd.part_sum; a.part_zero = sd.part_zero;
+  a.part_sum = sd.part_sum; a.part_zero = sd.part_zero;
 }
 
 CovArgs paired_cov_args(const PairedSet& s, const PairedPrep& p, const PairedLayout& L, const char* arena) {
@@ -502,20 +496,10 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
     a.cov_bits = s.cov_bits.as<uint32_t>();
     a.path_base = (const int*)(arena + L.pb_off);
   }
-  // some window occurs several times in this path set (or needs the long occurrence form): second launch over
-  // the pairs the main kernel notes
-  // ... scored inside the scoring launch by the lanes that meet them (GEN == 2 instantiation); knob 23 = 1 (development
-  // build): noted there and scored by a second launch, paired_general_kernel (the form of rounds 2-3)
+  // some window occurs several times in this path set (or needs the long occurrence form): the GEN instantiation, whose
+  // lanes score such a pair where they meet it
   const bool gen_set = a.n_main > 0 && p.general;
-  const bool gen_pass = gen_set && KNOB(c, 23) == 1;
-  int gen_blocks = 0;
-  if (gen_pass) {
-    const size_t bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2] + gp.gen_words[3]) * sizeof(unsigned long long);
-    if (bytes > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(bytes + bytes / 4)); }
-    sd.gen_bits = s.gen_bits.as<unsigned long long>();
-    gen_blocks = gp.gen_blocks;
-  }
-  const int n_partials = gp.total_blocks + gen_blocks;
+  const int n_partials = gp.total_blocks;
   sd.part_sum = s.red.part_sum.as<double>();
   sd.part_zero = s.red.part_zero.as<int>();
   if (c->host_results && n > 0) { if (int e = paired_host_partials(c, s, 0, 1, n_partials, &sd.part_sum, &sd.part_zero)) return e; }
@@ -541,7 +525,6 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
     // end together and their atomics on 17 words still take 10 us -- a finisher dispatch costs less); 1: finisher kernel
     // (stream-ordered calls; always when a second launch shares the partials); 2: the host adds them (blocking calls)
     int fin_mode = c->host_results ? 2 : (KNOB(c, 2) ? KNOB(c, 2) - 1 : 1);
-    if (fin_mode == 0 && gen_pass) fin_mode = 1;
     // a sharded evaluation's status words are written by whatever finishes the partials on the device
     double* status_out = nullptr;
     if (fin_mode != 2 && c->status_dst && !c->status_done) { status_out = c->status_dst; c->status_done = true; }
@@ -555,24 +538,14 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
     hipEvent_t e0 = ev ? ev->first : nullptr, e1 = ev ? ev->second : nullptr;
 #define GAML_LAUNCH_SCORE(...) hipExtLaunchKernelGGL((paired_score_kernel<__VA_ARGS__>), grid, block, KNOB(c, 1), st, e0, e1, 0, a)
 #ifdef GAML_HIP_DEV
-    if (timeline) GAML_LAUNCH_SCORE(false, 0, true);  // (the instantiation with in-kernel stamps: development builds only)
+    if (timeline) GAML_LAUNCH_SCORE(false, false, true);  // (the instantiation with in-kernel stamps: development builds only)
     else
 #endif
-#ifdef GAML_HIP_DEV
-    if (gen_pass) GAML_LAUNCH_SCORE(false, 1);
-    else
-#endif
-    if (gen_set) { if (fin_mode) GAML_LAUNCH_SCORE(false, 2); else GAML_LAUNCH_SCORE(true, 2); }
-    else if (fin_mode) GAML_LAUNCH_SCORE(false, 0);
-    else GAML_LAUNCH_SCORE(true, 0);
+    if (gen_set) { if (fin_mode) GAML_LAUNCH_SCORE(false, true); else GAML_LAUNCH_SCORE(true, true); }
+    else if (fin_mode) GAML_LAUNCH_SCORE(false, false);
+    else GAML_LAUNCH_SCORE(true, false);
 #undef GAML_LAUNCH_SCORE
     HIP_TRY(c, hipGetLastError());
-    if (gen_pass) {
-      std::pair<hipEvent_t, hipEvent_t>* gev = nullptr;
-      if (ev) { if (int e = take_events(c, &gev, 1)) return e; }  // (timed like the scoring launch: gaml_hip_debug_general_stats)
-      hipExtLaunchKernelGGL(paired_general_kernel, dim3(gen_blocks), dim3(kBlock), 0, st, gev ? gev->first : nullptr, gev ? gev->second : nullptr, 0, a, a.total_blocks);
-      HIP_TRY(c, hipGetLastError());
-    }
     if (fin_mode == 1) {
       hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(kBlock), 0, st, a.part_sum, a.part_zero, n_partials, out4, cov ? -1.0 : 0.0, (double)n, status_out, c->status_a, c->status_b);
       HIP_TRY(c, hipGetLastError());
@@ -626,10 +599,7 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, co
   const int64_t n = s.mate[0].n_local();
   bool any_set = false;
   for (int k = first; k < first + n_sets; k++) any_set = any_set || (a.n_main > 0 && preps[k].general);
-  const bool any_general = any_set && KNOB(c, 23) == 1;  // (second launches per set: development build, as launch_paired)
-  const size_t gen_bytes = (size_t)(gp.gen_words[0] + gp.gen_words[1] + gp.gen_words[2] + gp.gen_words[3]) * sizeof(unsigned long long);
-  if (any_general && gen_bytes * kMaxSets > s.gen_bits.cap) { HIP_TRY(c, hipStreamSynchronize(st)); HIP_TRY(c, s.gen_bits.reserve(gen_bytes * kMaxSets + 64)); }
-  const int n_partials = gp.total_blocks + (any_general ? gp.gen_blocks : 0);
+  const int n_partials = gp.total_blocks;
   double* d_sum = nullptr;
   int* d_zero = nullptr;
   s.last_total_blocks = n > 0 ? n_partials : 0;
@@ -647,28 +617,17 @@ int launch_paired_multi(gaml_hip_ctx* c, PairedSet& s, int first, int n_sets, co
     paired_set_view(s, L[g], arena + (size_t)g * stride, total_lens[g], ms.set[k]);
     ms.set[k].part_sum = d_sum + (size_t)g * s.host_part_stride;
     ms.set[k].part_zero = d_zero + (size_t)g * s.host_part_stride;
-    if (any_general) ms.set[k].gen_bits = (unsigned long long*)((char*)s.gen_bits.p + (size_t)g * gen_bytes);
   }
   paired_apply_set(a, ms.set[0]);  // (fields every set overrides; harmless defaults)
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (c->event_timing && (c->event_tick++ % c->event_every) == 0) { if (int e = take_events(c, &ev)) return e; }
   hipEvent_t e0 = ev ? ev->first : nullptr, e1 = ev ? ev->second : nullptr;
   const dim3 grid(a.total_blocks), block(kBlock);
-#ifdef GAML_HIP_DEV
-  if (any_general) hipExtLaunchKernelGGL((paired_score_multi_kernel<1>), grid, block, 0, st, e0, e1, 0, a, ms);
-  else
-#endif
-  if (any_set) hipExtLaunchKernelGGL((paired_score_multi_kernel<2>), grid, block, 0, st, e0, e1, 0, a, ms);
-  else hipExtLaunchKernelGGL((paired_score_multi_kernel<0>), grid, block, 0, st, e0, e1, 0, a, ms);
+  // (any set with a window that occurs several times: the GEN instantiation for all of them -- a set without such a window
+  // never takes its extra branches, its sums are those of the other instantiation)
+  if (any_set) hipExtLaunchKernelGGL((paired_score_multi_kernel<true>), grid, block, 0, st, e0, e1, 0, a, ms);
+  else hipExtLaunchKernelGGL((paired_score_multi_kernel<false>), grid, block, 0, st, e0, e1, 0, a, ms);
   HIP_TRY(c, hipGetLastError());
-  if (any_general) {
-    for (int k = 0; k < n_sets; k++) {  // the notes of every set were written; only sets with such windows have any bit set
-      PairedArgs b = a;
-      paired_apply_set(b, ms.set[k]);
-      hipLaunchKernelGGL(paired_general_kernel, dim3(gp.gen_blocks), dim3(kBlock), 0, st, b, a.total_blocks);
-      HIP_TRY(c, hipGetLastError());
-    }
-  }
   if (!c->event_timing || ev) {
     double rec = 0;
     for (int k = first; k < first + n_sets; k++) rec += (double)preps[k].assembled_records;

@@ -347,10 +347,6 @@ int gaml_hip_table_stats(gaml_hip_ctx* ctx, int readset, int64_t* out10);
  * written, [4] record tables / delta lists brought up to date, [5] kernel launches, [6] bytes of per-call tables
  * written, [7] wait for the device */
 int gaml_hip_last_phases(gaml_hip_ctx* ctx, double* out8);
-/* launches and device time (microseconds, events attached to the dispatches while event timing is on) of
- * paired_general_kernel: the second launch of a path set in which some window occurs several times (collapsed repeats).
- * Reset together with gaml_hip_kernel_stats. */
-int gaml_hip_general_stats(gaml_hip_ctx* ctx, int64_t* launches, double* device_us);
 /* timing of the last scoring call, microseconds: [0] host preparation (window registration,
  * alignment of new windows, occurrence tables), [1] H2D + kernels + D2H wall, [2] device time
  * of the scoring kernels measured with HIP events on the library's stream (0 if events off). */

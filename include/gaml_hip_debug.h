@@ -60,11 +60,11 @@ int32_t gaml_hip_debug_window_walk(gaml_hip_ctx* ctx, int readset, int mate, int
  * batches: 1 one launch per path set, 2 whole tables per set, 3 no capture of unchanged pairs, 32 + mask: classes of
  * blocks left out (TIMING ONLY, results wrong), 12 = 1: every path set planned from scratch, 13 = 1: whole per-call tables
  * through the ring (no resident copy), 14 = 1: every table build on the calling stream, k > 1: a build beside the
- * evaluations takes over k evaluations after its start (default 64), 15 = 1: rebuilds never retire unused windows,
+ * evaluations takes over k evaluations after its start (default 96), 15 = 1: rebuilds never retire unused windows,
  * 16 = 1: record tables keep the records that can never survive the overwrite rule (takes effect at the next table build;
  * same values either way), 18 = d: tables are rebuilt when the delta lists pass pairs / d (default 8), 19 = 1: no static
  * memo indices (takes effect at the next table build; same values either way), 20 = blocks of the compact class's second
- * part, 21 = blocks of paired_general_kernel, 22 = 1: delta maintenance by one-block launches only (default: multi-block
+ * part, 22 = 1: delta maintenance by one-block launches only (default: multi-block
  * above 3,000 records). Environment (development build): GAML_DL_STAMPS=1 prints the delta kernel's stage times. */
 /* Ablation 8 (knob 3 = 8) of the last evaluation of paired read set rs: 8 wall-clock stamps (10 ns units) per wave,
  * [kernel entry, tables in LDS, records in, occurrences in, memo in, stores issued, block reduced, class]. Returns the
@@ -99,7 +99,7 @@ int gaml_hip_debug_tables_check(gaml_hip_ctx* ctx, int readset, int64_t* out8);
 /* per-block partial sums / floored counts of the last blocking evaluation of paired set `readset` (path set `set` of a
  * batch launch, 0 for a single call), in block order; layout8 = {blocks of the compact class's static part, of the
  * compact class, up to the <= 2-record class, up to the <= 4-record class, lane-per-pair blocks, all scoring blocks,
- * paired_general_kernel blocks, partials}. Returns the number of partials. For bit-equality hunts between routes. */
+ * 0, partials}. Returns the number of partials. For bit-equality hunts between routes. */
 int32_t gaml_hip_debug_block_partials(gaml_hip_ctx* ctx, int readset, int32_t set, double* sums, int32_t* zeros, int32_t cap, int32_t* layout8);
 
 #ifdef __cplusplus

@@ -96,7 +96,7 @@ def _paired_only(mixed_lengths=False, n=9000, seed=83):
             sets.append([walk[:cut] + walk[cut + 1:]])
         elif kind == 2:
             sets.append([walk[:cut], [x ^ 1 for x in reversed(walk[cut:])]])
-        elif kind == 3:  # a duplicated stretch: its windows occur several times (paired_general_kernel)
+        elif kind == 3:  # a duplicated stretch: its windows occur several times (the kernels' GEN instantiation)
             sets.append([walk[:cut] + walk[max(0, cut - 3):cut] + walk[cut:]])
         else:
             sets.append([walk[:cut] + [-int(rng.integers(10, 300))] + walk[cut + 2:], walk[2:9]])

@@ -103,7 +103,7 @@ def test_no_reads_align():
 def test_every_window_occurs_several_times(penalty):
     # the whole genome walk three times (twice forward, once as the twin walk) plus stretches of it: every
     # window occurs several times, so every pair of the table classes takes the general pass
-    # (paired_general_kernel); then the same paths once each, and back -- the noted pairs must not stick
+    # (GEN instantiation); then the same paths once each, and back -- nothing of the general route must stick
     g, ctx, rs, orc, ors = _setup(90_000, 6_000, 21, repeats=2, penalty=penalty)
     walk = synth.genome_walk(g)
     inv = [x ^ 1 for x in reversed(walk)]  # the twin walk

@@ -195,7 +195,7 @@ def test_collapsed_repeats_at_1mbp_against_the_oracle():
     """A repeat-rich assembly, the case GAML's repeat moves exist for (FixBigReps / FixRepForNode2, moves.cc:1156-1305):
     1 Mbp with 3 % of the genome in COLLAPSED 5-copy repeat families (one node each, visited five times by the true
     walk). The families' windows occur several times in the path set, so their reads take the second launch
-    (paired_general_kernel) and the wave-per-pair blocks. All 170,000 pairs against the oracle: the whole walk, the walk
+    (the scoring kernel's GEN instantiation) and the wave-per-pair blocks. All 170,000 pairs against the oracle: the whole walk, the walk
     cut inside and outside repeats, a repeat dropped, the twin walk, a batch; then the same sets again over rebuilt tables
     (static indices, delta lists folded in)."""
     import oracle_py as op

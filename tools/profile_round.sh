@@ -2,7 +2,7 @@
 # Profiles of one round, run ON THE GPU BOX from the repository root:
 #   bash tools/profile_round.sh r04a
 # 1. rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline`: the headline steps AND the annealing pattern (small-batch
-#    aligner, filing, delta maintenance), the repeat-rich block (paired_general_kernel), the jumping library (coverage sweep),
+#    aligner, filing, delta maintenance), the repeat-rich block (the GEN instantiation of paired_score_kernel), the jumping library (coverage sweep),
 #    the aligner block and the long annealing run (table builds beside the evaluations) -- every kernel of the path gets a row
 # 2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with traces) of the headline steps alone
 # 3. the same three for --workload cfg3x8 (the one size at which the scoring launch is HBM-bound: 295 MB > the Infinity Cache)

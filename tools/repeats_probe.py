@@ -1,5 +1,5 @@
 """A repeat-rich assembly (collapsed 5-copy repeat families: synth.make_repeat_graph) on the GPU: pair classes, the
-scoring launch and the second launch (paired_general_kernel: pairs on windows that occur several times), step time, and
+scoring launch (its GEN instantiation: pairs on windows that occur several times), step time, and
 -- ORACLE=1 -- the likelihood against the CPU oracle on all pairs.    python tools/repeats_probe.py [cfg3r|tinyr]
 python tools/repeats_probe.py late [iterations]: the late state of a long synthetic annealing walk at cfg3 (duplicated nodes pile up)."""
 import os, sys, time
@@ -31,10 +31,10 @@ def late_walk(iters):
     for f in flat[-200:]:
         ctx.score(f); k1 = ctx.kernel_stats(reset=False)
         kus.append(k1["device_us"] - tot["device_us"]); tot = k1
-    ks, gs = ctx.kernel_stats(), ctx.debug_general_stats()
+    ks = ctx.kernel_stats()
     print("   scoring launch us over the last 200 calls: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f" % (min(kus), np.percentile(kus, 10), np.median(kus), np.percentile(kus, 90), max(kus)))
-    print(f"late walk, {iters} iterations: last 1000 calls median {np.median(per[-1000:]) * 1e6:.1f} us; scoring launch {ks['device_us'] / max(1, ks['launches']):.2f} us, "
-          f"general launch {gs['device_us'] / max(1, gs['launches']):.2f} us; classes {list(map(int, ctx.debug_class_counts(rs)))}; {ctx.debug_table_stats(rs)}", flush=True)
+    print(f"late walk, {iters} iterations: last 1000 calls median {np.median(per[-1000:]) * 1e6:.1f} us; scoring launch {ks['device_us'] / max(1, ks['launches']):.2f} us; "
+          f"classes {list(map(int, ctx.debug_class_counts(rs)))}; {ctx.debug_table_stats(rs)}", flush=True)
     ctx.close()
 
 if len(sys.argv) > 1 and sys.argv[1] == "late":
@@ -46,7 +46,7 @@ pr = synth.make_paired_reads(genome, wl.n_pairs, wl.read_len, wl.insert_mean, wl
 gb, go = g.packed()
 r1, r2 = synth.pack_reads(pr.mate1), synth.pack_reads(pr.mate2)
 ctx = api.Context(device=0)
-for kv in filter(None, os.environ.get("KNOBS", "").split(",")):  # e.g. KNOBS=23=1: the second launch instead of the inline form
+for kv in filter(None, os.environ.get("KNOBS", "").split(",")):  # e.g. KNOBS=10=128
     ctx.debug_set_knob(*map(int, kv.split("=")))
 ctx.set_graph(gb, go)
 rs = ctx.add_paired(api.paired_cfg(wl.insert_mean, wl.insert_std), *r1, *r2)
@@ -69,8 +69,8 @@ n = 400
 for i in range(n):
     ctx.score(variants[i % 8])
 dt = (time.perf_counter() - t) / n * 1e6
-ks, gs = ctx.kernel_stats(), ctx.debug_general_stats()
-print(f"scoring launch {ks['device_us'] / max(1, ks['launches']):.2f} us, general launch {gs['device_us'] / max(1, gs['launches']):.2f} us ({gs['launches']} of {ks['launches']}), "
+ks = ctx.kernel_stats()
+print(f"scoring launch {ks['device_us'] / max(1, ks['launches']):.2f} us, "
       f"step {dt:.2f} us, algorithmic {ks['algo_bytes'] / max(1, ks['launches']) / 1e6:.2f} MB", flush=True)
 ctx.set_event_timing(False)
 prof = []
