@@ -30,7 +30,7 @@ def _setup(G, n, seed, repeats=0, penalty=0.0, err=0.01, min_prob_per_base=-0.7,
     return g, ctx, rs, orc, ors
 
 
-def _check(ctx, rs, orc, ors, paths, rel_tol=1e-9):
+def _check(ctx, rs, orc, ors, paths, rel_tol=1e-9, prob_rtol=4e-16):
     got, zeros, tl = ctx.calc_prob(paths)
     want, wzeros, wtl = orc.calc_prob(paths, fresh=True)
     assert tl == wtl
@@ -39,7 +39,7 @@ def _check(ctx, rs, orc, ors, paths, rel_tol=1e-9):
     wprobs, wbad = orc.paired_probs(ors)
     # per-read probabilities: same products, same tables; reads with one term are bit-identical,
     # reads with several terms may differ in summation order (<= a few ulp)
-    np.testing.assert_allclose(probs, wprobs, rtol=4e-16, atol=0)
+    np.testing.assert_allclose(probs, wprobs, rtol=prob_rtol, atol=0)
     assert ctx.bad_bases(rs) == wbad or orc is None
     assert abs(got - want) <= rel_tol * abs(want), (got, want)
     return got, want
@@ -97,6 +97,24 @@ def test_no_reads_align():
     want, wzeros, wtl = orc.calc_prob(paths, fresh=True)
     assert zeros.tolist() == wzeros.tolist()
     assert abs(got - want) <= 1e-12 * abs(want)
+
+
+@pytest.mark.parametrize("copies", [10, 40])
+def test_windows_occurring_many_times(copies):
+    # the same walk `copies` times over: every window's occurrence list is longer than the eight entries the general route
+    # requests together (10: two rounds), and a pair with two records per mate has more candidates than that route stages
+    # (40: 80 > kGenCands -- the plain loop takes over; class 0 pairs go through compact_general's loop form, lists > 8)
+    g, ctx, rs, orc, ors = _setup(40_000, 3_000, 33, repeats=1)
+    walk = synth.genome_walk(g)
+    k = len(walk) // 2
+    many = [list(walk) for _ in range(copies)] + [walk[:k], walk[k:]]
+    tol = dict(prob_rtol=copies * 1e-16)  # (a read's probability is a sum of `copies` + 1 terms here: the order of additions shows)
+    a, _ = _check(ctx, rs, orc, ors, many, **tol)
+    _check(ctx, rs, orc, ors, [walk])
+    b, _ = _check(ctx, rs, orc, ors, many, **tol)
+    assert a == b
+    res = ctx.calc_prob_batch([many, [walk], many])
+    assert res[0][0] == a and res[2][0] == a
 
 
 @pytest.mark.parametrize("penalty", [0.0, 0.5])
