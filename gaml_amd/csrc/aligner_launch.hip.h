@@ -567,6 +567,8 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
   if (!d.uploaded && small) { if (int e = aln_small_reserve(c, *small)) return e; }
   if (int e = aln_upload_index(c, m, d)) return e;
   AlignScratch& S = c->aln_scratch;
+  const hipStream_t st = c->stream;  // (the library's own stream, like every other launch of an evaluation: a second queue coming
+                                     // to life in the middle of the cold call stalled the first table build by 20 ms)
   AlnJob local;
   AlnJob& job = job_in ? *job_in : local;
   if (!job.prepared) aln_prepare(c, m, job);
@@ -590,9 +592,15 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
   HIP_TRY(c, S.wins.reserve(nw * sizeof(AlnWindow)));
   HIP_TRY(c, S.blk.reserve((nw + 1) * sizeof(int32_t)));
   HIP_TRY(c, S.counters.reserve(256));
-  if (!wstr.empty()) HIP_TRY(c, hipMemcpy(S.wstr.p, wstr.data(), wstr.size(), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(S.wins.p, wins.data(), nw * sizeof(AlnWindow), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(S.blk.p, blk.data(), (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  // pinned staging: [window strings | window headers | block index | filing: window ids, counters in | counters out]
+  const size_t o_wins = align16(wstr.size()), o_blk = o_wins + align16((size_t)nw * sizeof(AlnWindow)), o_init = o_blk + align16((size_t)(nw + 1) * sizeof(int32_t));
+  const size_t o_back = o_init + align16(((size_t)3 * nw + 16) * sizeof(int)), stage_total = o_back + align16(((size_t)2 * nw + 2) * sizeof(int));
+  HIP_TRY(c, S.stage.reserve(stage_total));
+  char* const hp = (char*)S.stage.p;
+  memcpy(hp, wstr.data(), wstr.size()); memcpy(hp + o_wins, wins.data(), (size_t)nw * sizeof(AlnWindow)); memcpy(hp + o_blk, blk.data(), (size_t)(nw + 1) * sizeof(int32_t));
+  if (!wstr.empty()) HIP_TRY(c, hipMemcpyAsync(S.wstr.p, hp, wstr.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(S.wins.p, hp + o_wins, nw * sizeof(AlnWindow), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(S.blk.p, hp + o_blk, (nw + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
   t1 = now_us();
   size_t cap_spans = std::max<size_t>(1 << 16, wstr.size());        // a span per window base and strand at most ~2x
   size_t cap_cands = std::max<size_t>(1 << 18, 8 * wstr.size());
@@ -600,34 +608,34 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
   for (int attempt = 0; attempt < 6; attempt++) {
     HIP_TRY(c, S.spans.reserve(cap_spans * sizeof(AlnSpan)));
     HIP_TRY(c, S.cands.reserve(cap_cands * sizeof(AlnCand)));
-    HIP_TRY(c, hipMemset(S.counters.p, 0, 16));
+    HIP_TRY(c, hipMemsetAsync(S.counters.p, 0, 16, st));
     if (blk[(size_t)nw] > 0) {
-      hipLaunchKernelGGL(span_maxima_kernel, dim3((unsigned)blk[(size_t)nw]), dim3(kAlnBlock), 0, 0, S.wstr.as<char>(), S.wins.as<AlnWindow>(), nw,
+      hipLaunchKernelGGL(span_maxima_kernel, dim3((unsigned)blk[(size_t)nw]), dim3(kAlnBlock), 0, st, S.wstr.as<char>(), S.wins.as<AlnWindow>(), nw,
                          m.index_read_len, S.blk.as<int>(), S.spans.as<AlnSpan>(), S.counters.as<unsigned>(), (unsigned)cap_spans);
       HIP_TRY(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(candidates_kernel, dim3(256), dim3(kAlnBlock), 0, 0, S.spans.as<AlnSpan>(), S.counters.as<unsigned>(),
+    hipLaunchKernelGGL(candidates_kernel, dim3(256), dim3(kAlnBlock), 0, st, S.spans.as<AlnSpan>(), S.counters.as<unsigned>(),
                        (unsigned)cap_spans, d.bucket_hash.as<uint64_t>(), d.bucket_top.as<int32_t>(), d.bucket_off.as<int32_t>(), d.bucket_reads.as<int32_t>(),
                        (int)m.bucket_hash.size(), S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1, (unsigned)cap_cands);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpy(counts, S.counters.p, sizeof(counts), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(counts, S.counters.p, sizeof(counts), hipMemcpyDeviceToHost, st)); HIP_TRY(c, hipStreamSynchronize(st));
     if (counts[0] <= cap_spans && counts[1] <= cap_cands) break;
     cap_spans = std::max<size_t>(cap_spans, (size_t)counts[0] + 16);
     cap_cands = std::max<size_t>(cap_cands, (size_t)counts[1] + 16);
     if (attempt == 5) { m.flush_pending_cpu(c->g); return 0; }
   }
+  gpu_probe(st, c->warm_buf.p, "  spans + candidates done");
   t2 = now_us();
   t3 = t2;
   nc = counts[1];
-  hits.assign(nc, AlnHit{0, 0, -1, 0, 0, 0});
   if (nc) {
     HIP_TRY(c, S.hits.reserve((size_t)nc * sizeof(AlnHit)));
-    hipLaunchKernelGGL(extend_kernel, dim3((nc + kAlnWaves - 1) / kAlnWaves), dim3(64 * kAlnWaves), 0, 0, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1,
+    hipLaunchKernelGGL(extend_kernel, dim3((nc + kAlnWaves - 1) / kAlnWaves), dim3(64 * kAlnWaves), 0, st, S.cands.as<AlnCand>(), S.counters.as<unsigned>() + 1,
                        (unsigned)cap_cands, S.wstr.as<char>(), S.wins.as<AlnWindow>(), d.reads.as<char>(), d.read_off.as<int64_t>(),
                        S.hits.as<AlnHit>());
     HIP_TRY(c, hipGetLastError());
     if (KNOB(c, 9)) {
-      HIP_TRY(c, hipDeviceSynchronize()); t3 = now_us();
+      HIP_TRY(c, hipStreamSynchronize(st)); t3 = now_us();
     }
     // Large batches: order the hits on the device (window, position, read, strand, order; failed extensions
     // last) and fetch only the successful ones; the host then only walks them. Keys: read < 2^31, order < 2^24.
@@ -647,24 +655,25 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
       unsigned* idx_alt = idx + n;
       unsigned* idx_tmp = idx_alt + n;
       unsigned* n_ok = S.counters.as<unsigned>() + 2;
-      HIP_TRY(c, hipMemset(n_ok, 0, sizeof(unsigned)));
+      HIP_TRY(c, hipMemsetAsync(n_ok, 0, sizeof(unsigned), st));
       const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
-      hipLaunchKernelGGL(hit_keys_kernel, dim3(grid), dim3(256), 0, 0, S.hits.as<AlnHit>(), (unsigned)n, k_minor, k_major, idx, n_ok);
+      hipLaunchKernelGGL(hit_keys_kernel, dim3(grid), dim3(256), 0, st, S.hits.as<AlnHit>(), (unsigned)n, k_minor, k_major, idx, n_ok);
       HIP_TRY(c, hipGetLastError());
       // two stable radix sorts (radix_sort.hip.h): by (read, strand, order), then by (window, position) in that order
-      HIP_TRY(c, rs_sort<unsigned>(k_minor, k_alt, k_alt2, idx, idx_alt, idx_tmp, n, 0, 56, S.sort_tmp.as<unsigned>(), (hipStream_t)0));
-      hipLaunchKernelGGL(gather_u64_kernel, dim3(grid), dim3(256), 0, 0, k_major, idx_alt, (unsigned)n, k_alt);
+      HIP_TRY(c, rs_sort<unsigned>(k_minor, k_alt, k_alt2, idx, idx_alt, idx_tmp, n, 0, 56, S.sort_tmp.as<unsigned>(), st));
+      hipLaunchKernelGGL(gather_u64_kernel, dim3(grid), dim3(256), 0, st, k_major, idx_alt, (unsigned)n, k_alt);
       HIP_TRY(c, hipGetLastError());
-      HIP_TRY(c, rs_sort<unsigned>(k_alt, k_alt2, k_minor, idx_alt, idx, idx_tmp, n, 0, 64, S.sort_tmp.as<unsigned>(), (hipStream_t)0));
-      hipLaunchKernelGGL(gather_hits_kernel, dim3(grid), dim3(256), 0, 0, S.hits.as<AlnHit>(), idx, (unsigned)n, S.hits_sorted.as<AlnHit>());
+      HIP_TRY(c, rs_sort<unsigned>(k_alt, k_alt2, k_minor, idx_alt, idx, idx_tmp, n, 0, 64, S.sort_tmp.as<unsigned>(), st));
+      hipLaunchKernelGGL(gather_hits_kernel, dim3(grid), dim3(256), 0, st, S.hits.as<AlnHit>(), idx, (unsigned)n, S.hits_sorted.as<AlnHit>());
       HIP_TRY(c, hipGetLastError());
       unsigned ok_count = 0;
-      HIP_TRY(c, hipMemcpy(&ok_count, n_ok, sizeof(unsigned), hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpyAsync(&ok_count, n_ok, sizeof(unsigned), hipMemcpyDeviceToHost, st)); HIP_TRY(c, hipStreamSynchronize(st));
+      gpu_probe(st, c->warm_buf.p, "  extension + sorts done");
       if (KNOB(c, 9)) t3 = now_us();
       if (ps && KNOB(c, 5) != 6 && ok_count > 0 && n < ((size_t)1 << 30)) {
         // filed on the device: survivors flagged, placed by a prefix sum, written into this mate's pool; the windows' headers come back
         MateDev& md = ps->dev[mt];
-        if (int e = pool_mirror(c, *ps, (hipStream_t)0)) return e;  // (windows the host filed earlier come first in the pool)
+        if (int e = pool_mirror(c, *ps, st)) return e;  // (windows the host filed earlier come first in the pool)
         if (int e = pool_reserve(c, *ps, mt, md.pool_n + (int64_t)ok_count)) return e;
         const unsigned tiles = (unsigned)((n + kTbScanTile - 1) / kTbScanTile);
         // scratch: flags | places | tile sums | window ids | per-window counts | maxima | a zero word + the total
@@ -676,18 +685,20 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
         int* win_cnt = wid_of + nw;
         int* win_max = win_cnt + nw;
         int* zero = win_max + nw;  // [0] zero (the scan's "slots before"), [1] the number of survivors
-        std::vector<int> init((size_t)3 * nw + 16, 0);
+        int* const init = (int*)(hp + o_init);
+        memset(init, 0, ((size_t)3 * nw + 16) * sizeof(int));
         for (int k = 0; k < nw; k++) { init[(size_t)k] = m.pending[(size_t)k]; init[(size_t)2 * nw + k] = INT_MIN; }
-        HIP_TRY(c, hipMemcpy(wid_of, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(aln_file_flags_kernel, dim3(grid), dim3(256), 0, 0, S.hits_sorted.as<AlnHit>(), n_ok, (unsigned)n, flags);
+        HIP_TRY(c, hipMemcpyAsync(wid_of, init, ((size_t)3 * nw + 16) * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(aln_file_flags_kernel, dim3(grid), dim3(256), 0, st, S.hits_sorted.as<AlnHit>(), n_ok, (unsigned)n, flags);
         // (tb_scan_*: exclusive prefix of n ints, "n - cnt[kTbClass0]" entries: `zero` stands in for the counters)
-        hipLaunchKernelGGL(tb_scan_tiles_kernel, dim3(tiles), dim3(256), 0, 0, flags, zero - kTbClass0, (int)n, tile_sum);
-        hipLaunchKernelGGL(tb_scan_top_kernel, dim3(1), dim3(1024), 0, 0, tile_sum, (int)tiles, zero + 1);
-        hipLaunchKernelGGL(tb_scan_apply_kernel, dim3(tiles), dim3(256), 0, 0, flags, zero - kTbClass0, (int)n, tile_sum, place);
-        hipLaunchKernelGGL(aln_file_write_kernel, dim3(grid), dim3(256), 0, 0, S.hits_sorted.as<AlnHit>(), flags, place, (unsigned)n, md.pool.as<int4>(), (int)md.pool_n, wid_of, win_cnt, win_max);
+        hipLaunchKernelGGL(tb_scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, flags, zero - kTbClass0, (int)n, tile_sum);
+        hipLaunchKernelGGL(tb_scan_top_kernel, dim3(1), dim3(1024), 0, st, tile_sum, (int)tiles, zero + 1);
+        hipLaunchKernelGGL(tb_scan_apply_kernel, dim3(tiles), dim3(256), 0, st, flags, zero - kTbClass0, (int)n, tile_sum, place);
+        hipLaunchKernelGGL(aln_file_write_kernel, dim3(grid), dim3(256), 0, st, S.hits_sorted.as<AlnHit>(), flags, place, (unsigned)n, md.pool.as<int4>(), (int)md.pool_n, wid_of, win_cnt, win_max);
         HIP_TRY(c, hipGetLastError());
-        std::vector<int> back((size_t)2 * nw + 2);
-        HIP_TRY(c, hipMemcpy(back.data(), win_cnt, back.size() * sizeof(int), hipMemcpyDeviceToHost));
+        const int* const back = (const int*)(hp + o_back);
+        HIP_TRY(c, hipMemcpyAsync(hp + o_back, win_cnt, ((size_t)2 * nw + 2) * sizeof(int), hipMemcpyDeviceToHost, st)); HIP_TRY(c, hipStreamSynchronize(st));
+        gpu_probe(st, c->warm_buf.p, "  filed");
         int64_t at = md.pool_n;
         for (int k = 0; k < nw; k++) {
           Window& w = m.wins[(size_t)m.pending[(size_t)k]];
@@ -708,13 +719,16 @@ int gpu_align_pending(gaml_hip_ctx* c, ShortMate& m, AlignDev& d, AlignSmall* sm
         c->aln_us += t5 - t0;
         c->aln_stage_us[0] += t1 - t0; c->aln_stage_us[1] += t2 - t1; c->aln_stage_us[2] += t5 - t2;
         c->aln_batches++;
+        gpu_probe(st, c->warm_buf.p, "  mate done");
         return 0;
       }
-      hits.resize(ok_count);
-      if (ok_count) HIP_TRY(c, hipMemcpy(hits.data(), S.hits_sorted.p, (size_t)ok_count * sizeof(AlnHit), hipMemcpyDeviceToHost));
+      // (the host's copy of the hits only on the routes that file on the host: 67 MB of pages to touch at cfg3's cold call)
+      hits.assign(ok_count, AlnHit{0, 0, -1, 0, 0, 0});
+      if (ok_count) HIP_TRY(c, hipMemcpyAsync(hits.data(), S.hits_sorted.p, (size_t)ok_count * sizeof(AlnHit), hipMemcpyDeviceToHost, st)); HIP_TRY(c, hipStreamSynchronize(st));
       device_sorted = true;
     } else {
-      HIP_TRY(c, hipMemcpy(hits.data(), S.hits.p, (size_t)nc * sizeof(AlnHit), hipMemcpyDeviceToHost));
+      hits.assign(nc, AlnHit{0, 0, -1, 0, 0, 0});
+      HIP_TRY(c, hipMemcpyAsync(hits.data(), S.hits.p, (size_t)nc * sizeof(AlnHit), hipMemcpyDeviceToHost, st)); HIP_TRY(c, hipStreamSynchronize(st));
     }
   }
   }  // general route
@@ -737,7 +751,10 @@ int align_pending_pair(gaml_hip_ctx* c, PairedSet& ps) {
     const int rc = aln_pair_small(c, ps);
     if (rc <= 0) return rc;
   }
-  AlnJob job[2];
+  // (the jobs' buffers -- 5 MB of window strings at cfg3's cold batch -- live in the context: giving them back to the system at
+  // the end of this call stalled the device's queues for 12-25 ms, see AlignScratch::stage)
+  AlnJob* const job = c->aln_job;
+  for (int q = 0; q < 2; q++) { job[q].prepared = false; job[q].enqueued = false; job[q].wstr.clear(); job[q].wins.clear(); job[q].blk.clear(); }
   if (c->device >= 0 && KNOB(c, 5) != 3) {
     for (int mt = 0; mt < 2; mt++) {
       ShortMate& m = ps.mate[mt];

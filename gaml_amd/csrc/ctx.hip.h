@@ -51,6 +51,22 @@ inline double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// development aid (development build, GAML_HIP_PROBE=1): a 4-byte fill + stream synchronise at a few places of an evaluation; reports
+// how long the device took to answer -- how the 12-25 ms stall after the cold alignment batch was found (AlignScratch::stage)
+inline void gpu_probe(hipStream_t st, void* p4, const char* label) {
+#ifdef GAML_HIP_DEV
+  static const bool on = getenv("GAML_HIP_PROBE") != nullptr;
+  if (!on || !p4) return;
+  const double t0 = now_us();
+  (void)hipMemsetAsync(p4, 0, 4, st);
+  (void)hipStreamSynchronize(st);
+  const double dt = now_us() - t0;
+  fprintf(stderr, "probe %-28s %8.2f ms%s\n", label, dt * 1e-3, dt > 1000.0 ? "   <-- stall" : "");
+#else
+  (void)st; (void)p4; (void)label;
+#endif
+}
+
 // grow-only device / pinned buffers
 struct DevBuf {
   void* p = nullptr;
@@ -139,8 +155,12 @@ struct AlignDev {  // device copies the GPU aligner needs: reads (1 byte per bas
 struct AlignScratch {  // per context, grown on demand
   DevBuf wstr, wins, blk, spans, cands, hits, counters;
   DevBuf sort_keys, sort_idx, sort_tmp, hits_sorted, file_tmp;  // large batches: hits ordered (and filed) on the device
+  // What a large batch sends and receives travels through pinned memory of the library's own. (Copies straight from / to the
+  // job's vectors made the runtime register those pages with the device -- and FREEING such a buffer afterwards makes the
+  // driver evict the process's queues: the first dispatch after the cold batch started 12-25 ms late, the device idle.)
+  PinBuf stage;
   void release() { wstr.release(); wins.release(); blk.release(); spans.release(); cands.release(); hits.release(); counters.release();
-                   sort_keys.release(); sort_idx.release(); sort_tmp.release(); hits_sorted.release(); file_tmp.release(); }
+                   sort_keys.release(); sort_idx.release(); sort_tmp.release(); hits_sorted.release(); file_tmp.release(); stage.release(); }
 };
 
 // small batches (aln_small_*): one set of buffers per mate, so that the two mates' pipelines run side by side. Input
@@ -253,7 +273,7 @@ struct PairedSet {
   // per set, fixed: length-combination code per pair, the per-combination tables, the memo of pair terms
   DevBuf lcode, len_combo_dev, combo_tabs, memo;
   int memo_codes = 0;
-  bool statics_uploaded = false, kernels_warm = false;
+  bool statics_uploaded = false, kernels_warm = false, prereserved = false;
   // Delta store (device): pairs whose record lists gained records of windows activated after the tables were built. Their
   // complete lists sit at a fixed stride (4 records per mate; longer ones in the spill area); maintained by
   // delta_apply_kernel, read by the scoring launch. The host knows upper bounds (and the exact counts once a blocking call
@@ -382,6 +402,8 @@ struct gaml_hip_ctx {
   gaml::MultiState* multi = nullptr;  // several device shards behind this context (gaml_hip_create_multi): every call is forwarded
   gaml::CommState* comm = nullptr;    // RCCL communicator of a sharded context (gaml_hip_comm_init_rank / the shards of a multi context)
   int device = -1;
+  DevBuf warm_buf; bool general_warm = false;  // warm_general_kernels (gaml_hip.hip)
+  AlnJob aln_job[2];  // the two mates' pending alignment batches (align_pending_pair): buffers kept from call to call
   hipStream_t stream = nullptr;
   hipStream_t aux_stream = nullptr;  // the overflow kernel runs beside the main kernel
   GraphStore g;

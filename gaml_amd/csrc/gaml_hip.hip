@@ -270,7 +270,9 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
     // windows registered by pass 1 get their records now, all at once (GPU aligner when there is a device): small
     // batches of the two mates go out together on the stream before either is waited for
     const double ta = now_us();
+    gpu_probe(c->stream, c->warm_buf.p, "before alignment");
     if (int e = align_pending_pair(c, *c->paireds[i])) return e;
+    gpu_probe(c->stream, c->warm_buf.p, "after alignment");
     c->prof[2] = (i ? c->prof[2] : 0.0) + now_us() - ta;  // alignment of newly registered windows (inside pass 1)
   }
   int64_t n = 0;
@@ -280,6 +282,7 @@ int eval_begin(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_
   }
   for (auto& s : c->singles) s->mate.unsynced.clear();  // single-end scoring has no position filter
   if (pending) *pending = n;
+  gpu_probe(c->stream, c->warm_buf.p, "end of eval_begin");
   c->pending_open = true;
   c->pending_host_us = now_us() - t0;
   c->prof[0] = c->pending_host_us;  // pass 1
@@ -335,9 +338,14 @@ int evaluate(gaml_hip_ctx* c, const int32_t* flat, const int64_t* offs, int32_t 
              hipStream_t st, int32_t* total_len_out) {
   if (c->device < 0) return fail(c, GAML_HIP_ENODEVICE, "scoring needs a HIP device: this context is host-only");
   int64_t pending = 0;
+  static const bool trace = getenv("GAML_HIP_TRACE_HOST") != nullptr;
+  const double t0 = trace ? now_us() : 0.0;
   if (int e = eval_begin(c, flat, offs, n_paths, &pending)) return e;
   if (total_len_out) *total_len_out = c->pending_total_len;
-  return eval_finish(c, d_partials, st);
+  const double t1 = trace ? now_us() : 0.0;
+  const int e = eval_finish(c, d_partials, st);
+  if (trace && now_us() - t0 > 5000.0) fprintf(stderr, "evaluation: begin (paths, windows, alignment) %.2f ms, finish (tables, launches) %.2f ms\n", (t1 - t0) * 1e-3, (now_us() - t1) * 1e-3);
+  return e;
 }
 
 int combine(gaml_hip_ctx* c, const double* partials, double* prob_out, int32_t* zeros_out, int32_t total_len) {
@@ -511,7 +519,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
     for (auto& s : c->pacbios) { s->d_lens.release(); s->rec_off.release(); s->rec_walk.release(); s->rec_logp.release(); s->walk_count.release(); s->logprobs.release(); s->red.release(); drop_stage(s->stage);
       s->d_bases.release(); s->dp.release(); s->sweep.release(); }
     c->packed.release(); c->packed_host.release(); c->batch_dev.release(); c->batch_host.release(); c->aln_scratch.release();
-    c->aln_small[0].release(); c->aln_small[1].release(); c->fetch_host.release();
+    c->aln_small[0].release(); c->aln_small[1].release(); c->fetch_host.release(); c->warm_buf.release();
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -581,6 +589,30 @@ int gaml_hip_add_single(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, 
   return (int)c->handles.size() - 1;
 }
 
+// The GEN instantiations of the paired scoring kernels (path sets with windows that occur several times) call functions and keep
+// candidates in private memory: the first launch of such a kernel makes the runtime load its code and allocate the queue's
+// scratch memory -- 7 ms, once. Paid here, when a paired read set is added, by a launch of one block that finds nothing to do,
+// not inside the annealing call whose move first duplicates a node.
+static int warm_general_kernels(gaml_hip_ctx* c) {
+  if (c->general_warm || c->device < 0) return 0;
+  HIP_TRY(c, c->warm_buf.reserve(256));
+  HIP_TRY(c, hipMemsetAsync(c->warm_buf.p, 0, 256, c->stream));
+  PairedArgs a;
+  memset((void*)&a, 0, sizeof(a));
+  a.total_blocks = 1;  // main_blocks = 0: the block takes the wave-per-pair branch, whose item count (n - n_main + dstate[kDsSpill]) is 0
+  a.dstate = c->warm_buf.as<int>();
+  a.part_sum = c->warm_buf.as<double>() + 8; a.part_zero = c->warm_buf.as<int>() + 32;
+  hipLaunchKernelGGL((paired_score_kernel<false, true>), dim3(1), dim3(kBlock), 0, c->stream, a);
+  MultiSets ms;
+  memset((void*)&ms, 0, sizeof(ms));
+  ms.pad_ = 16;  // (the wave-per-pair blocks are "left out": with no path set in `ms` the block returns at once)
+  hipLaunchKernelGGL((paired_score_multi_kernel<true>), dim3(1), dim3(kBlock), 0, c->stream, a, ms);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->general_warm = true;
+  return 0;
+}
+
 int gaml_hip_add_paired(gaml_hip_ctx* c, const gaml_paired_cfg* cfg, int32_t n, const char* b1, const int64_t* o1,
                         const char* b2, const int64_t* o2) {
   if (!c || !cfg || n < 0 || !o1 || !o2) return fail(c, GAML_HIP_EINVAL, "bad arguments");
@@ -596,6 +628,21 @@ int gaml_hip_add_paired(gaml_hip_ctx* c, const gaml_paired_cfg* cfg, int32_t n, 
   if (s->mate[0].max_len > 65535 || s->mate[1].max_len > 65535) return fail(c, GAML_HIP_EINVAL, "paired reads longer than 65535 bases");
   c->paireds.push_back(std::move(s));
   c->handles.push_back(SetRef{1, (int)c->paireds.size() - 1});
+  if (int e = warm_general_kernels(c)) return e;
+  // the reads and their max-hash index go to the device with the read set (the reference reads its reads when it starts, too),
+  // not inside the first evaluation: 250 MB of bases at cfg3
+  if (c->device >= 0) {
+    PairedSet& ps = *c->paireds.back();
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int mt = 0; mt < 2; mt++) {
+      if (!aln_gpu_capable(c, ps.mate[mt])) continue;
+      if (int e = aln_small_reserve(c, c->aln_small[mt])) return e;
+      if (int e = aln_upload_index(c, ps.mate[mt], ps.dev[mt].aln)) return e;
+    }
+    if (int e = prepare_paired_tables(c, ps)) return e;  // the set's fixed tables (insert sizes, floors), its per-read probabilities' buffer
+    if (ps.mate[0].n_local() > 0) { if (int e = paired_upload_statics(c, ps, c->stream)) return e; }  // length codes, per-combination tables, the memo of pair terms
+    if (int e = paired_prereserve(c, ps, c->stream)) return e;  // the record tables' buffers, the builds' scratch, the delta store
+  }
   return (int)c->handles.size() - 1;
 }
 

@@ -445,11 +445,13 @@ int paired_host_partials(gaml_hip_ctx* c, PairedSet& s, int first_set, int n_set
 // ONE path set
 // ---------------------------------------------------------------------------------------------------------
 int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_len, hipStream_t st, double* out4) {
+  const double tpp = now_us();
   if (int e = prepare_paired_tables(c, s)) return e;
   const double tp0 = now_us();
   prepare_paired_tables_host(c, s, p);  // pass 2 (pass 1 ran in eval_begin)
   const double t_after_host = now_us();
   c->prof[1] = t_after_host - tp0;  // thresholds + occurrence tables
+  gpu_probe(st, c->warm_buf.p, "before table sync");
   if (int e = paired_sync_tables(c, s, st)) return e;  // cold path: nothing to do on a warm cache
   const double tp1 = now_us();
   c->prof[4] = tp1 - t_after_host;
@@ -570,6 +572,9 @@ int launch_paired(gaml_hip_ctx* c, PairedSet& s, PairedPrep& p, int32_t total_le
   }
   if (slot >= 0) { if (int e = arena_release(c, s.arena, slot, st)) return e; }
   c->prof[5] = now_us() - tp2;  // kernel launches
+  if (now_us() - tpp > 5000.0 && getenv("GAML_HIP_TRACE_HOST"))
+    fprintf(stderr, "launch_paired: fixed tables %.2f ms, pass 2 %.2f, table sync %.2f, per-call tables %.2f, launches %.2f\n", (tp0 - tpp) * 1e-3, (t_after_host - tp0) * 1e-3,
+            (tp1 - t_after_host) * 1e-3, (tp2 - tp1) * 1e-3, (now_us() - tp2) * 1e-3);
   // SURVEY.md 8d accounting: 16 B per record, 8 B read lengths, 8 B probability written, per pair
   if (!c->event_timing || ev) {  // with timing on, the statistics describe the timed launches
     c->stat_algo_bytes += 16.0 * (double)p.assembled_records + 16.0 * (double)n;

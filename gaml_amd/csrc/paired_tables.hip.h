@@ -602,6 +602,66 @@ hipError_t paired_build_stream(hipStream_t* out) {
   return hipStreamCreateWithPriority(out, hipStreamNonBlocking, lo);
 }
 
+// Every buffer the record tables, their builds and their delta lists need, for a pool of up to two records per read and mate
+// -- allocated AND used once (a 4-byte fill): a device allocation becomes usable by a queue when it is first touched, and the
+// ~45 buffers of a first build cost the first evaluation 15-20 ms of an idle device at cfg3 (rocprofv3 --hip-trace: the
+// build's first dispatch started 20 ms after it was enqueued). Called when a paired read set is added (the reference, too,
+// sets its read sets up before it scores anything) and again after every build on the calling stream (no-ops then, unless
+// the pool has outgrown the assumption).
+int paired_prereserve(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
+  const int64_t n = s.mate[0].n_local();
+  if (n == 0 || c->device < 0) return 0;
+  TableRebuild& rb = s.rebuild;
+  BuildScratch& B = s.scratch;
+  const bool first = !s.prereserved;
+  const int64_t A2[2] = {std::max<int64_t>(paired_records_cap(s, 0), 2 * n + 65536), std::max<int64_t>(paired_records_cap(s, 1), 2 * n + 65536)};
+  if (first) { for (int mt = 0; mt < 2; mt++) { if (int e = pool_reserve(c, s, mt, n + n / 8)) return e; } }
+  if (first || !s.tab.rec8[0].p) { if (int e = paired_reserve_tabledev(c, s.tab, n, A2)) return e; }
+  if ((first || !rb.tab.rec8[0].p) && KNOB(c, 14) != 1) { if (int e = paired_reserve_tabledev(c, rb.tab, n, A2)) return e; }
+  if (first || !B.k_in.p) {
+    const size_t maxA = (size_t)std::max<int64_t>(std::max(A2[0], A2[1]), n);
+    HIP_TRY(c, B.k_in.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_out.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_tmp.reserve(maxA * sizeof(rs_u64)));
+    HIP_TRY(c, B.v_in.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.v_tmp.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.hist.reserve(rs_hist_bytes(maxA)));
+    for (int mt = 0; mt < 2; mt++) HIP_TRY(c, B.v_sorted[mt].reserve((size_t)A2[mt] * sizeof(unsigned)));
+  }
+  if (first) {
+    HIP_TRY(c, B.cl.reserve((size_t)n)); HIP_TRY(c, B.sidx.reserve((size_t)n * sizeof(int)));
+    HIP_TRY(c, B.tiles.reserve((size_t)((n + kTbScanTile - 1) / kTbScanTile) * sizeof(int)));
+    for (int mt = 0; mt < 2; mt++) {
+      HIP_TRY(c, B.rstart[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.rend[mt].reserve((size_t)n * sizeof(int)));
+      HIP_TRY(c, B.one[mt].reserve((size_t)n * sizeof(unsigned long long)));
+      HIP_TRY(c, B.more[mt].reserve((size_t)n * sizeof(int))); HIP_TRY(c, B.start[mt].reserve((size_t)n * sizeof(int)));
+      HIP_TRY(c, B.wins[mt].reserve((size_t)131072 * sizeof(TbWin))); HIP_TRY(c, B.h_wins[mt].reserve((size_t)131072 * sizeof(TbWin)));
+    }
+    HIP_TRY(c, B.peer0.reserve((size_t)131072 * sizeof(int32_t))); HIP_TRY(c, B.h_peer.reserve((size_t)131072 * sizeof(int32_t)));
+    HIP_TRY(c, B.h_cnt.reserve(kTbInts * sizeof(int)));
+    if (int e = paired_reserve_delta(c, s)) return e;
+  }
+  for (int k = 0; k < kRing; k++) {  // (pinned allocations take milliseconds: not in the annealing call that first stages a window list)
+    HIP_TRY(c, s.stage_pool.host[k].reserve((size_t)1 << 20));
+    if (!s.stage_pool.done[k]) HIP_TRY(c, hipEventCreateWithFlags(&s.stage_pool.done[k], hipEventDisableTiming));
+  }
+  if (KNOB(c, 14) != 1) {
+    if (!rb.stream) HIP_TRY(c, paired_build_stream(&rb.stream));
+    if (!rb.done) HIP_TRY(c, hipEventCreateWithFlags(&rb.done, hipEventDisableTiming));
+    if (!rb.mark) HIP_TRY(c, hipEventCreateWithFlags(&rb.mark, hipEventDisableTiming));
+  }
+  if (first) {
+    DevBuf* all[] = {&s.dev[0].pool, &s.dev[1].pool, &B.k_in, &B.k_out, &B.k_tmp, &B.v_in, &B.v_tmp, &B.hist, &B.v_sorted[0], &B.v_sorted[1], &B.rstart[0], &B.rstart[1],
+                     &B.rend[0], &B.rend[1], &B.one[0], &B.one[1], &B.cl, &B.sidx, &B.more[0], &B.more[1], &B.start[0], &B.start[1], &B.tiles, &B.wins[0], &B.wins[1], &B.peer0,
+                     &s.dl_slot, &s.dl_spill, &s.dl_rec[0], &s.dl_rec[1], &s.sp_rng[0], &s.sp_rng[1], &s.sp_rec[0], &s.sp_rec[1], &s.sp_slot, &s.dl_bins, &s.dl_wlist};
+    for (DevBuf* b : all) if (b->p) HIP_TRY(c, hipMemsetAsync(b->p, 0, 4, st));
+    for (TableDev* T : {&s.tab, &rb.tab}) {
+      DevBuf* tb[] = {&T->cnt, &T->rec8[0], &T->rec8[1], &T->first[0], &T->first[1], &T->extra[0], &T->extra[1], &T->inl[0], &T->inl[1], &T->len_code, &T->len12,
+                      &T->static_idx, &T->static_val, &T->slot_of_read, &T->read_of_slot, &T->dirty_of_slot};
+      for (DevBuf* b : tb) if (b->p) HIP_TRY(c, hipMemsetAsync(b->p, 0, 4, st));
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    s.prereserved = true;
+  }
+  return 0;
+}
+
 // on the calling stream: the spare buffers are built from the windows that are active now and take over at once
 int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   TableRebuild& rb = s.rebuild;
@@ -612,39 +672,32 @@ int paired_rebuild_tables(gaml_hip_ctx* c, PairedSet& s, hipStream_t st) {
   }
   s.full_rebuilds++;
   rb.retired = false;
+  gpu_probe(st, c->warm_buf.p, "before retire_windows");
   paired_retire_windows(c, s);
+  gpu_probe(st, c->warm_buf.p, "after retire_windows");
   for (int mt = 0; mt < 2; mt++) s.mate[mt].activated_log.clear();
   const double tb0 = now_us();
   if (int e = paired_upload_statics(c, s, st)) return e;
+  gpu_probe(st, c->warm_buf.p, "before build enqueue");
+  const double tb1 = now_us();
   if (int e = paired_build_enqueue(c, s, rb.tab, st)) return e;
+  const double tb2 = now_us();
   HIP_TRY(c, hipStreamSynchronize(st));
+  const double tb3 = now_us();
   if (int e = paired_build_collect(c, s, rb.tab)) return e;
   std::swap(s.tab, rb.tab);
   paired_adopt_tables(s);
   if (int e = paired_delta_reset(c, s, st)) return e;
+  const double tb4 = now_us();
   for (int mt = 0; mt < 2; mt++) s.dev[mt].uploaded_generation = s.mate[mt].active_generation;
   // Everything a later call would otherwise allocate (device allocations cost 0.1-3 ms each; an annealing run must not meet
-  // them in the call that happens to activate a window or to start a rebuild): the spare set of table buffers with room
-  // for half as many records again, the build's stream and events, the delta store (paired_delta_reset above)
-  for (int k = 0; k < kRing; k++) {  // (pinned allocations take milliseconds: not in the annealing call that first stages a window list)
-    HIP_TRY(c, s.stage_pool.host[k].reserve((size_t)1 << 20));
-    if (!s.stage_pool.done[k]) HIP_TRY(c, hipEventCreateWithFlags(&s.stage_pool.done[k], hipEventDisableTiming));
-  }
+  // them in the call that happens to activate a window or to start a rebuild): paired_prereserve -- normally done when the
+  // read set was added; here for what a larger pool than it assumed makes necessary
+  if (int e = paired_prereserve(c, s, st)) return e;
   if (!s.kernels_warm && s.mate[0].n_local() > 0) { if (int e = paired_warm_delta_kernels(c, s, s.tab, st)) return e; s.kernels_warm = true; }
-  if (!rb.tab.rec8[0].p && KNOB(c, 14) != 1) {
-    const int64_t n = s.mate[0].n_local();
-    const int64_t A2[2] = {paired_records_cap(s, 0), paired_records_cap(s, 1)};
-    if (int e = paired_reserve_tabledev(c, rb.tab, n, A2)) return e;
-    BuildScratch& B = s.scratch;
-    const size_t maxA = (size_t)std::max<int64_t>(std::max(A2[0], A2[1]), n);
-    HIP_TRY(c, B.k_in.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_out.reserve(maxA * sizeof(rs_u64))); HIP_TRY(c, B.k_tmp.reserve(maxA * sizeof(rs_u64)));
-    HIP_TRY(c, B.v_in.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.v_tmp.reserve(maxA * sizeof(unsigned))); HIP_TRY(c, B.hist.reserve(rs_hist_bytes(maxA)));
-    for (int mt = 0; mt < 2; mt++) HIP_TRY(c, B.v_sorted[mt].reserve((size_t)A2[mt] * sizeof(unsigned)));
-    if (!rb.stream) HIP_TRY(c, paired_build_stream(&rb.stream));
-    if (!rb.done) HIP_TRY(c, hipEventCreateWithFlags(&rb.done, hipEventDisableTiming));
-    if (!rb.mark) HIP_TRY(c, hipEventCreateWithFlags(&rb.mark, hipEventDisableTiming));
-  }
-  if (getenv("GAML_HIP_TRACE_HOST")) fprintf(stderr, "rebuild on the calling stream: %.2f ms\n", (now_us() - tb0) * 1e-3);
+  if (getenv("GAML_HIP_TRACE_HOST"))
+    fprintf(stderr, "rebuild on the calling stream: %.2f ms (statics %.2f, reserve + enqueue %.2f, device %.2f, collect + reset %.2f, spare buffers / warm-up %.2f)\n", (now_us() - tb0) * 1e-3,
+            (tb1 - tb0) * 1e-3, (tb2 - tb1) * 1e-3, (tb3 - tb2) * 1e-3, (tb4 - tb3) * 1e-3, (now_us() - tb4) * 1e-3);
   return 0;
 }
 
