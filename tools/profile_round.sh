@@ -4,6 +4,8 @@
 # 1. rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline`: the headline steps AND the annealing pattern (small-batch
 #    aligner, filing, delta maintenance), the repeat-rich block (the GEN instantiation of paired_score_kernel), the jumping library (coverage sweep),
 #    the aligner block and the long annealing run (table builds beside the evaluations) -- every kernel of the path gets a row
+# 1b. the same trace of the headline steps alone (`--no-extras`: 2,100 launches of the one workload `roofline` is quoted on): the
+#    average duration of paired_score_kernel there is the figure bench.py's live `roofline.kernel_us` has to agree with
 # 2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with traces) of the headline steps alone
 # 3. the same three for --workload cfg3x8 (the one size at which the scoring launch is HBM-bound: 295 MB > the Infinity Cache)
 # Summaries are made by tools/pmc_summary.py (copied into profiles/ by tools/round_evidence.sh).
@@ -14,6 +16,9 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 echo "== kernel trace" > "$out/log.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o trace -- python3 bench.py --no-cpu-baseline >> "$out/log.txt" 2>&1
+echo "== kernel trace of the headline steps alone" >> "$out/log.txt"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/headline" -o headline -- python3 bench.py --no-cpu-baseline --no-extras >> "$out/log.txt" 2>&1
+cp "$out/headline/headline_kernel_stats.csv" "$out/${tag}_headline_kernel_stats.csv"
 echo "== pmc FETCH_SIZE" >> "$out/log.txt"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o fetch -- python3 bench.py --no-cpu-baseline --no-extras --steps 24 --warmup 24 >> "$out/log.txt" 2>&1
 echo "== pmc WRITE_SIZE" >> "$out/log.txt"

@@ -13,7 +13,7 @@ ev=gpurun_out/evidence_$tag
 mkdir -p "$ev"
 bash tools/profile_round.sh "$tag" || exit 1
 cp "gpurun_out/prof_$tag/${tag}_pmc_traffic.json" "gpurun_out/prof_$tag/${tag}_kernel_stats.csv" profiles/ || exit 1
-cp "gpurun_out/prof_$tag/${tag}_pmc_traffic.json" "gpurun_out/prof_$tag/${tag}_kernel_stats.csv" "$ev/"
+cp "gpurun_out/prof_$tag/${tag}_pmc_traffic.json" "gpurun_out/prof_$tag/${tag}_kernel_stats.csv" "gpurun_out/prof_$tag/${tag}_headline_kernel_stats.csv" "$ev/"
 # the HBM-bound size: kernel stats, PMC traffic and the bench line of --workload cfg3x8 on the same sources
 cp gpurun_out/prof_$tag/${tag}_cfg3x8_* "$ev/" 2> /dev/null
 echo "== bench" && python3 bench.py > "$ev/${tag}_bench.json" 2> "$ev/bench.err" || exit 1
