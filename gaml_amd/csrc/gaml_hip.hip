@@ -488,6 +488,7 @@ void gaml_hip_destroy(gaml_hip_ctx* c) {
       fprintf(stderr, "general_pair_staged: longest stage us: entries %.1f, bounds %.1f, lists %.1f, liveness %.1f, terms %.1f; waves above 10 us in a stage: %llu %llu %llu %llu %llu\n",
               z[16] * 0.01, z[17] * 0.01, z[18] * 0.01, z[19] * 0.01, z[20] * 0.01, z[24], z[25], z[26], z[27], z[28]);
     }
+    if (z[6]) fprintf(stderr, "general_pair_call as the caller sees it: %llu calls, mean %.2f us; from the class body's entry to the call %.2f us\n", z[6], z[5] * 0.01 / z[6], z[21] * 0.01 / z[6]);
     if (z[15])
       fprintf(stderr, "general_pair_staged: %llu waves; mean us per wave: entries %.2f, bounds %.2f, lists %.2f, liveness %.2f, terms %.2f; candidates per lane-0 pair %.1f / %.1f, live %.1f, lanes %.1f; pairs that did not fit %llu; longest %.2f us, most candidates %llu / %llu, most live %llu / %llu\n",
               z[15], z[0] * 0.01 / z[15], z[1] * 0.01 / z[15], z[2] * 0.01 / z[15], z[3] * 0.01 / z[15], z[4] * 0.01 / z[15], (double)z[8] / z[15], (double)z[9] / z[15], (double)z[10] / z[15], (double)z[11] / z[15], z[12], z[13] * 0.01, z[14] / 1000, z[14] % 1000, z[7] / 1000, z[7] % 1000);

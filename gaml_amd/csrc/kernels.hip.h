@@ -1007,21 +1007,22 @@ __device__ unsigned long long g_gen_stamp[32];
 // the liveness tests and the terms are chains of loads from it, 30 ns a link from LDS, 270 ns from scratch (a pair with 2 + 5
 // candidates spent 8 us of a 15 us chain there, in-kernel stamps).
 constexpr int kGenListBatch = 8;  // entries of an occurrence list requested together
-__device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const int4 (&r1)[4], const int4 (&r2)[4], int L1, int L2, double& acc_out, int4* cand) {
+template <int K>  // records per mate the caller holds (2: the class of pairs with at most two -- half the loads, half the code)
+__device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const int4 (&r1)[K], const int4 (&r2)[K], int L1, int L2, double& acc_out, int4* cand) {
   int n[2] = {0, 0};
   unsigned live[2] = {0, 0};
-  Occ12 e[2][4];
-  int lb[2][4], le[2][4];
+  Occ12 e[2][K];
+  int lb[2][K], le[2][K];
   GEN_STAMP_BEGIN
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const int4& r = m == 0 ? r1[k] : r2[k]; e[m][k] = a.m[m].occ12[r.x >= 0 ? r.x : 0]; }
+    for (int k = 0; k < K; k++) { const int4& r = m == 0 ? r1[k] : r2[k]; e[m][k] = a.m[m].occ12[r.x >= 0 ? r.x : 0]; }
   GEN_STAMP(0);
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < K; k++) {
       const int4& r = m == 0 ? r1[k] : r2[k];
       const bool occurs = r.x >= 0 && !(e[m][k].lo == ~0u && e[m][k].hi == ~0u);
       const bool list = occurs && e[m][k].rank < 0;
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ bool general_pair_staged(const PairedArgs& a, const i
   for (int m = 0; m < 2; m++) {
     int4* const cm = cand + m * kGenCands;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < K; k++) {
       const int4& r = m == 0 ? r1[k] : r2[k];
       const bool single = le[m][k] == -1;
       const int cnt = single ? 1 : le[m][k] - lb[m][k];
@@ -1166,6 +1167,9 @@ template <int K, bool GEN>
 __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, int slot_lo, int slot_hi, int block_lo, int block_hi,
                                                  double& lsum, int& zeros, unsigned long long* tl = nullptr, int4* wave_lds = nullptr) {
   bool first_pair = true;
+#ifdef GAML_GEN_STAMPS
+  const unsigned long long tb_ = wall_clock64();
+#endif
   for (int i = slot_lo + (lb - block_lo) * kBlock + threadIdx.x; i < slot_hi; i += (block_hi - block_lo) * kBlock) {
     const int t = i - a.n0;
     const uint32_t l12 = a.len12[t];
@@ -1186,7 +1190,22 @@ __device__ __forceinline__ void paired_regs_body(const PairedArgs& a, int lb, in
     first_pair = false;
     if (GEN && !GAML_GEN_OFF(2) && __any(general)) {
       int4* const slot = gen_wave_slot(wave_lds, general);
-      if (general) { const GenOut o = general_pair_call(kernel_args_address(), i, -1, -1, slot); lsum += o.add; zeros += o.zeros; }
+#ifdef GAML_GEN_STAMPS
+      const unsigned long long tc0_ = wall_clock64();
+#endif
+      if (general) {
+        // (the class of pairs with two records a mate: staged here, from the records and in the registers this lane already has -- a
+        // late annealing walk brings 25 such lanes a wave, the call cost each 19 us; without a slot, or with more candidates than
+        // a slot holds: the function)
+        double acc;
+        const int L1 = l12 & 0xffff, L2 = l12 >> 16;
+        int4 priv[K == 2 ? 2 * kGenCands : 1];
+        if (K == 2 && general_pair_staged<K>(a, r1, r2, L1, L2, acc, slot ? slot : priv)) finish_read(a, i, acc, L1, L2, lsum, zeros);
+        else { const GenOut o = general_pair_call(kernel_args_address(), i, -1, -1, slot); lsum += o.add; zeros += o.zeros; }
+      }
+#ifdef GAML_GEN_STAMPS  // (the call as the caller sees it, per LANE that makes it; and how long after the class body's entry it begins)
+      if (general) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tc1_ = wall_clock64(); atomicAdd(&g_gen_stamp[5], tc1_ - tc0_); atomicAdd(&g_gen_stamp[6], 1ull); atomicAdd(&g_gen_stamp[21], tc0_ - tb_); }
+#endif
     }
   }
 }
@@ -1589,7 +1608,7 @@ __device__ __noinline__ GenOut general_pair_call(unsigned long long kernargs, in
     for (int k = 0; k < 4; k++) { const bool has = four || k < 2; r1[k] = has ? a.inl[0][at + (has ? k : 0)] : none; r2[k] = has ? a.inl[1][at + (has ? k : 0)] : none; }
     const uint32_t l12 = a.len12[i - a.n0];
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
-    if (!general_pair_staged(a, r1, r2, L1, L2, acc, cand)) acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
+    if (!general_pair_staged<4>(a, r1, r2, L1, L2, acc, cand)) acc = paired_general(a, a.m[0].first[i - a.n0], a.m[1].first[i - a.n0], L1, L2);
     finish_read(a, i, acc, L1, L2, o.add, o.zeros);
   } else {
 #pragma unroll
@@ -1597,7 +1616,7 @@ __device__ __noinline__ GenOut general_pair_call(unsigned long long kernargs, in
     const uint32_t l12 = (uint32_t)r1[0].w;
     const int L1 = l12 & 0xffff, L2 = l12 >> 16;
     const int c0 = r2[0].w & 0xff, c1 = (r2[0].w >> 8) & 0xff;
-    if (!general_pair_staged(a, r1, r2, L1, L2, acc, cand))
+    if (!general_pair_staged<4>(a, r1, r2, L1, L2, acc, cand))
       acc = paired_general_src_masks(a, ListSrc{a.dirty_recs[0] + 4 * (size_t)dj, c0}, ListSrc{a.dirty_recs[1] + 4 * (size_t)dj, c1}, L1, L2);
     finish_read(a, i, acc, L1, L2, o.add, o.zeros);
   }
