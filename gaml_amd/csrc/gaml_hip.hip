@@ -596,6 +596,7 @@ int gaml_hip_add_single(gaml_hip_ctx* c, const gaml_single_cfg* cfg, int32_t n, 
 // not inside the annealing call whose move first duplicates a node.
 static int warm_general_kernels(gaml_hip_ctx* c) {
   if (c->general_warm || c->device < 0) return 0;
+  HIP_TRY(c, hipSetDevice(c->device));  // (a shard of a multi-device context: the calling thread may have another device current)
   HIP_TRY(c, c->warm_buf.reserve(256));
   HIP_TRY(c, hipMemsetAsync(c->warm_buf.p, 0, 256, c->stream));
   PairedArgs a;
